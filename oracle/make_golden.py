@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""Golden-vector generator -- runs ONLY in the build container.
+
+Imports the reference NumPy path from /root/reference (never copied, never
+shipped) and records its outputs on seeded inputs as small .npz fixtures under
+tests/golden/.  The fixtures are data (inputs + expected outputs); tests on the
+GPU box read only these files.
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/oracle/make_golden.py
+
+Fixture families follow SURVEY.md section 8(c): G1 ties, G2 distances,
+G3 neighbourhoods, G4 single _update, G5 teacher-forced epochs, G6 end-to-end
+iris, G7 shard identity, G8 cosine + mexican hat.
+"""
+import contextlib
+import io
+import itertools
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+
+with contextlib.redirect_stdout(io.StringIO()):     # silence the CuPy/Dask import warnings
+    sys.path.insert(0, "/root/reference")
+    from xpysom_dask import XPySom as RefSom                                   # noqa: E402
+    from xpysom_dask import distances as rdist, neighborhoods as rneigh        # noqa: E402
+
+from oracle.som_oracle import gaussian_blobs                                   # noqa: E402
+
+F32 = np.float32
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name:28s} {os.path.getsize(path) / 1024:8.1f} KB")
+
+
+def ref_winner_ids(som, x):
+    Y = som._weights.shape[1]
+    w = som.winner(x)
+    return np.array([i * Y + j for i, j in w], dtype=np.int32)
+
+
+# ---------------------------------------------------------------- G1 ties
+def g1():
+    rng = np.random.default_rng(7)
+    X, Y, D, n = 4, 5, 8, 64
+    x = rng.integers(-3, 4, size=(n, D)).astype(np.float64)
+    w = rng.integers(-3, 4, size=(X, Y, D)).astype(np.float64)
+    w[2, 0] = w[1, 2]          # duplicated rows: lowest raveled index must win
+    w[3, 4] = w[1, 2]
+    w[0, 3] = 0.0              # a zero row
+    x[:8] = w.reshape(-1, D)[[7, 7, 10, 19, 3, 0, 7, 12]]   # samples sitting exactly on units
+    x[8] = 0.0
+    som = RefSom(X, Y, D, random_seed=1, xp=np)
+    som._weights = w.copy()
+    ids = ref_winner_ids(som, x)
+    som._weights = np.zeros_like(w)
+    ids_zero = ref_winner_ids(som, x)
+    som._weights = np.ones_like(w)
+    ids_same = ref_winner_ids(som, x)
+    save("g1_ties", x=x, w=w, ids=ids, ids_zero=ids_zero, ids_same=ids_same)
+
+
+# ---------------------------------------------------------------- G2 distances
+def distance_cases():
+    """Own regeneration of the reference's test-input families
+    (xpysom_dask/test_distances.py:37-88): every pair of binary vectors of
+    length 1..3 in six pairing patterns, then eight seeded uniform matrices."""
+    cases = []
+    for L in (1, 2, 3):
+        vecs = [[(v >> b) & 1 for b in range(L)] for v in range(2 ** L)]
+        pairs = list(itertools.product(vecs, vecs))
+        for a, b in pairs:
+            cases.append(([a], [b]))
+        xs = [a for a, _ in pairs]
+        ws = [b for _, b in pairs]
+        cases.append(([xs[0]], ws))
+        cases.append((xs, [ws[0]]))
+        cases.append((xs, ws))
+        cases.append((xs, ws[::2]))
+        cases.append((xs[::2], ws))
+    np.random.seed(0)
+    for n in (2, 7):
+        for m in (3, 11):
+            for L in (5, 13):
+                x = np.random.rand(n, L).tolist()
+                w = np.random.rand(m, L).tolist()
+                cases.append((x, w))
+    return cases
+
+
+def g2():
+    out = {}
+    cases = distance_cases()
+    with np.errstate(all="ignore"):
+        for c, (x, w) in enumerate(cases):
+            xa, wa = np.array(x, dtype=np.float64), np.array(w, dtype=np.float64)
+            out[f"c{c:03d}_x"] = xa
+            out[f"c{c:03d}_w"] = wa
+            out[f"c{c:03d}_part"] = rdist.euclidean_squared_distance_part(xa, wa, xp=np)
+            out[f"c{c:03d}_sq"] = rdist.euclidean_squared_distance(xa, wa, xp=np)
+            out[f"c{c:03d}_l2"] = rdist.euclidean_distance(xa, wa, xp=np)
+            out[f"c{c:03d}_cos"] = rdist.cosine_distance(xa, wa, xp=np)
+    out["n_cases"] = np.array(len(cases))
+    save("g2_distances", **out)
+
+
+# ---------------------------------------------------------------- G3 neighbourhoods
+def g3():
+    out = {}
+    for (X, Y) in ((5, 5), (3, 4)):
+        ci, cj = np.divmod(np.arange(X * Y), Y)
+        c = (ci.astype(np.int64), cj.astype(np.int64))
+        ni, nj = np.arange(X), np.arange(Y)
+        for sig in (0.3, 1.0, 2.5):
+            for wide in (False, True):
+                s = np.float64(sig) if wide else float(sig)
+                for compact in (False, True):
+                    key = f"{X}x{Y}_s{sig}_{'f64' if wide else 'f32'}_{'cs' if compact else 'nc'}"
+                    out["gauss_" + key] = rneigh.gaussian_rect(ni, nj, 1.0, compact, c, s, xp=np)
+                    out["gauss05_" + key] = rneigh.gaussian_rect(ni, nj, 0.5, compact, c, s, xp=np)
+                key = f"{X}x{Y}_s{sig}_{'f64' if wide else 'f32'}_nc"
+                out["mex_" + key] = rneigh.mexican_hat_rect(ni, nj, 1.0, False, c, s, xp=np)
+    save("g3_neighbourhoods", **out)
+
+
+# ---------------------------------------------------------------- G4/G5/G7 update + epoch
+SHAPES = ((6, 6, 4, 150), (8, 8, 3, 500), (24, 24, 16, 4096), (20, 30, 12, 3000))
+
+
+def g4_g5_g7():
+    T = 10
+    for (X, Y, D, n) in SHAPES:
+        data = gaussian_blobs(n, D, seed=100 + X)
+        out = {"shape": np.array([X, Y, D, n]), "data_seed": np.array(100 + X), "T": np.array(T)}
+        for decay in ("linear", "exponential"):
+            som = RefSom(X, Y, D, random_seed=1234, decay_function=decay, n_parallel=n, xp=np)
+            w0 = som._weights.astype(F32)
+            # mid-training state: 5 epochs of the reference itself
+            mid = RefSom(X, Y, D, random_seed=1234, decay_function=decay, n_parallel=n, xp=np)
+            mid.train(data, T, iter_beg=0, iter_end=T // 2)
+            wmid = mid._weights.astype(F32)
+            out[f"{decay}_wmid"] = wmid
+            for tag, w, t in (("init", w0, 0), ("mid", wmid, T // 2), ("last", wmid, T - 1)):
+                eta = som._decay_function(som._learning_rate, som._learning_rateN, t, T)
+                sig = som._decay_function(som._sigma, som._sigmaN, t, T)
+                # G4: one _update call exactly as train() makes it (w_sq cached)
+                som._sq_weights_gpu = np.power(w.reshape(-1, D), 2).sum(axis=1, keepdims=True)
+                num, den = som._update(data, w, eta, sig)
+                som._sq_weights_gpu = None
+                wins = som._winner(data, w)
+                out[f"{decay}_{tag}_bmu"] = (wins[0] * Y + wins[1]).astype(np.int32)
+                if tag == "mid" or X * Y * D < 2000:      # keep the big fixtures small
+                    out[f"{decay}_{tag}_num"] = num.astype(F32)
+                out[f"{decay}_{tag}_den"] = den.astype(F32)
+                out[f"{decay}_{tag}_eta"] = np.float64(eta)
+                out[f"{decay}_{tag}_sig"] = np.float64(sig)
+                # G5: the same epoch through train(iter_beg=t, iter_end=t+1)
+                e = RefSom(X, Y, D, random_seed=1234, decay_function=decay, n_parallel=n, xp=np)
+                e._weights = w.copy()
+                with np.errstate(all="ignore"):
+                    e.train(data, T, iter_beg=t, iter_end=t + 1)
+                out[f"{decay}_{tag}_wout"] = e._weights.astype(F32)
+                if X * Y * D >= 2000:
+                    continue
+                # same epoch chunked (n_parallel = 77) -> f32 accumulation across batches
+                e = RefSom(X, Y, D, random_seed=1234, decay_function=decay, n_parallel=77, xp=np)
+                e._weights = w.copy()
+                with np.errstate(all="ignore"):
+                    e.train(data, T, iter_beg=t, iter_end=t + 1)
+                out[f"{decay}_{tag}_wout77"] = e._weights.astype(F32)
+            if (X, Y, D) == (24, 24, 16):
+                # G7: shard identity -- per-shard partials of the 'mid' epoch
+                t = T // 2
+                eta = som._decay_function(som._learning_rate, som._learning_rateN, t, T)
+                sig = som._decay_function(som._sigma, som._sigmaN, t, T)
+                for G in (2,):
+                    nums, dens = [], []
+                    for part in np.array_split(np.arange(n), G):
+                        a, b = som._update(data[part], wmid, eta, sig)
+                        nums.append(a.astype(F32))
+                        dens.append(b.astype(F32))
+                    out[f"{decay}_shard{G}_num"] = np.sum(nums, axis=0, dtype=F32)
+                    out[f"{decay}_shard{G}_den"] = np.sum(dens, axis=0, dtype=F32)
+        save(f"g4_update_{X}x{Y}x{D}", **out)
+
+
+# ---------------------------------------------------------------- G6 end-to-end iris
+def g6():
+    raw = np.loadtxt("/root/reference/examples/iris.csv", delimiter=",", usecols=(0, 1, 2, 3))
+    z = (raw - raw.mean(axis=0)) / raw.std(axis=0)
+    out = {"iris_z": z, "iris_raw": raw}
+    for decay in ("linear", "exponential"):
+        for init in ("default", "random", "pca"):
+            som = RefSom(6, 6, 4, random_seed=10, decay_function=decay, xp=np)
+            if init == "random":
+                som.random_weights_init(z)
+            elif init == "pca":
+                som.pca_weights_init(z)
+            out[f"{decay}_{init}_w0"] = np.array(som._weights, dtype=np.float64)
+            out[f"{decay}_{init}_qe0"] = np.float64(som.quantization_error(z))
+            with np.errstate(all="ignore"):
+                som.train(z, 100)
+            out[f"{decay}_{init}_w"] = som._weights.astype(F32)
+            out[f"{decay}_{init}_bmu"] = ref_winner_ids(som, z)
+            out[f"{decay}_{init}_qe"] = np.float64(som.quantization_error(z))
+    # README configuration on raw iris: chaotic codebook, QE only
+    som = RefSom(6, 6, 4, sigma=0.3, learning_rate=0.5, random_seed=10, xp=np)
+    out["readme_qe0"] = np.float64(som.quantization_error(raw))
+    with np.errstate(all="ignore"):
+        som.train(raw, 100)
+    out["readme_qe"] = np.float64(som.quantization_error(raw))
+    save("g6_iris", **out)
+
+
+# ---------------------------------------------------------------- G8 cosine + mexican hat
+def g8():
+    X, Y, D, n, T = 8, 8, 6, 300, 10
+    data = np.abs(gaussian_blobs(n, D, seed=55))
+    data /= np.linalg.norm(data, axis=1, keepdims=True)
+    out = {"data": data}
+    for decay in ("linear", "exponential"):
+        som = RefSom(X, Y, D, random_seed=3, decay_function=decay, n_parallel=n,
+                     neighborhood_function="mexican_hat", activation_distance="cosine", xp=np)
+        som._weights = np.abs(som._weights)
+        w0 = som._weights.astype(F32)
+        out[f"{decay}_w0"] = w0
+        eta = som._decay_function(som._learning_rate, som._learning_rateN, 0, T)
+        sig = som._decay_function(som._sigma, som._sigmaN, 0, T)
+        wins = som._winner(data, w0)
+        num, den = som._update(data, w0, eta, sig)
+        out[f"{decay}_bmu"] = (wins[0] * Y + wins[1]).astype(np.int32)
+        out[f"{decay}_num"] = num.astype(F32)
+        out[f"{decay}_den"] = den.astype(F32)
+        out[f"{decay}_eta"] = np.float64(eta)
+        out[f"{decay}_sig"] = np.float64(sig)
+        with np.errstate(all="ignore"):
+            som.train(data, T, iter_beg=0, iter_end=1)
+        out[f"{decay}_wout"] = som._weights.astype(F32)
+    # a gaussian + cosine epoch as well (the separable path with the cosine BMU)
+    som = RefSom(X, Y, D, random_seed=3, decay_function="linear", n_parallel=n,
+                 activation_distance="cosine", xp=np)
+    w0 = np.abs(som._weights).astype(F32)
+    som._weights = w0.copy()
+    wins = som._winner(data, w0)
+    out["cosgauss_bmu"] = (wins[0] * Y + wins[1]).astype(np.int32)
+    with np.errstate(all="ignore"):
+        som.train(data, T, iter_beg=0, iter_end=1)
+    out["cosgauss_wout"] = som._weights.astype(F32)
+    save("g8_cosine_mexican", **out)
+
+
+# ---------------------------------------------------------------- G9 winner / QE on a trained mid-size map
+def g9():
+    X, Y, D, n = 16, 12, 10, 2000
+    data = gaussian_blobs(n, D, seed=77)
+    som = RefSom(X, Y, D, random_seed=5, decay_function="linear", xp=np)
+    som.train(data, 8)
+    probe = gaussian_blobs(700, D, seed=78)
+    save("g9_inference", data_seed=np.array(77), probe_seed=np.array(78),
+         w=som._weights.astype(F32),
+         winner=ref_winner_ids(som, probe),
+         winner64=ref_winner_ids(som, probe.astype(np.float64)),
+         qe=np.float64(som.quantization_error(probe)),
+         qe_train=np.float64(som.quantization_error(data)))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    with contextlib.redirect_stdout(io.StringIO()) as _:
+        pass
+    g1(); g2(); g3(); g4_g5_g7(); g6(); g8(); g9()

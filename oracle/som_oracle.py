@@ -1,0 +1,281 @@
+"""CPU oracle for the batch-SOM hot path -- TEST INFRASTRUCTURE ONLY.
+
+This module is a from-scratch NumPy restatement of the algorithm the
+reference (jcfaracco/xpysom-dask @ 2024-10-08) runs on its NumPy path.  It is
+the *checker* for the HIP engine: only ``tests/``, ``__graft_entry__.smoke()``
+and the ``cpu_baseline`` leg of ``bench.py`` may import it.  Nothing under
+``xpysom_dask_amd/`` imports it, and the product never falls back to it.
+
+Parity status: PINNED.  ``oracle/make_golden.py`` imported the reference in
+the build container and wrote ``tests/golden/*.npz``; ``tests/test_oracle_golden.py``
+checks every function below against those vectors (bit-exact where the
+arithmetic is the same NumPy expression, 1e-6 where only BLAS summation order
+may differ).
+
+Conventions
+-----------
+* The codebook is handled flat: ``W`` is ``(K, D)`` with ``k = i*Y + j``
+  (reference: ``xpysom.py:240`` unravel table, ``distances.py:185`` reshape).
+* dtype flow follows SURVEY.md section 3.4: data/codebook/accumulators are
+  float32; the neighbourhood is float64 when ``sigma`` is a ``numpy.float64``
+  (what ``exponential_decay`` returns) and float32 when it is a Python float
+  (``linear``/``asymptotic``) -- the NumPy >= 2 promotion rule.  Here the
+  choice is the explicit argument ``wide``.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+F32 = np.float32
+F64 = np.float64
+
+
+# --------------------------------------------------------------------------
+# schedules -- reference xpysom_dask/decays.py:4-65
+# --------------------------------------------------------------------------
+def asymptotic_decay(v0, vN, t, T):
+    """decays.py:4-20 -- ``v0 / (1 + 2t/T)`` (vN unused). Python float in, Python float out."""
+    return v0 / (1 + 2 * t / T)
+
+
+def exponential_decay(v0, vN, t, T):
+    """decays.py:23-43 -- geometric interpolation v0 -> vN; returns numpy.float64
+    because numpy's exp/log are used (this is what makes the neighbourhood float64)."""
+    rate = (-np.log(0.1) if vN == 0 else -np.log(vN / v0)) / T
+    return v0 * np.exp(-t * rate)
+
+
+def linear_decay(v0, vN, t, T):
+    """decays.py:46-65 -- straight line reaching vN at t = T-1 (T == 1 -> v0)."""
+    if T == 1:
+        return v0
+    return v0 + (vN - v0) * t / (T - 1)
+
+
+DECAYS = {
+    "exponential": exponential_decay,
+    "asymptotic": asymptotic_decay,
+    "linear": linear_decay,
+}
+
+
+def decay_is_wide(name):
+    """True when the schedule hands back numpy.float64."""
+    return name == "exponential"
+
+
+# --------------------------------------------------------------------------
+# initial codebook -- reference xpysom.py:167,189-190
+# --------------------------------------------------------------------------
+def default_codebook(X, Y, D, seed):
+    """float64 (X,Y,D): uniform(-1,1) rows scaled to unit L2 norm."""
+    rs = np.random.RandomState(seed)
+    w = rs.rand(X, Y, D) * 2 - 1
+    w /= np.linalg.norm(w, axis=-1, keepdims=True)
+    return w
+
+
+# --------------------------------------------------------------------------
+# distances -- reference xpysom_dask/distances.py:11-59
+# --------------------------------------------------------------------------
+def row_sq(a):
+    return np.power(a, 2).sum(axis=1, keepdims=True)
+
+
+def dist_euclid_part(x, w, w_sq=None):
+    """distances.py:11-23: -2 x.w^T + |w|^2 (the |x|^2 term is dropped)."""
+    if w_sq is None:
+        w_sq = row_sq(w)
+    return -2 * np.dot(x, w.T) + w_sq.T
+
+
+def dist_euclid_sq(x, w, w_sq=None):
+    """distances.py:25-31."""
+    return dist_euclid_part(x, w, w_sq) + row_sq(x)
+
+
+def dist_euclid(x, w, w_sq=None):
+    """distances.py:33-43: sqrt with NaN (negative by cancellation) mapped to 0."""
+    with np.errstate(invalid="ignore"):
+        return np.nan_to_num(np.sqrt(dist_euclid_sq(x, w, w_sq)))
+
+
+def dist_cosine(x, w, w_sq=None):
+    """distances.py:45-59: 1 - nan_to_num(x.w / sqrt(|x|^2 |w|^2))."""
+    if w_sq is None:
+        w_sq = row_sq(w)
+    x_sq = row_sq(x)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        sim = np.nan_to_num(np.dot(x, w.T) / np.sqrt(x_sq * w_sq.T))
+    return 1 - sim
+
+
+DISTANCES = {
+    "euclidean": dist_euclid_part,       # distances.py:163
+    "euclidean_no_opt": dist_euclid_sq,  # distances.py:164
+    "cosine": dist_cosine,               # distances.py:167
+}
+
+
+def bmu_ids(x, w, distance="euclidean", w_sq=None):
+    """Raveled best-matching-unit ids, first minimum wins (xpysom.py:410-417)."""
+    return np.argmin(DISTANCES[distance](x, w, w_sq), axis=1)
+
+
+# --------------------------------------------------------------------------
+# neighbourhoods (rectangular) -- reference xpysom_dask/neighborhoods.py:14-74
+# --------------------------------------------------------------------------
+def _support(n, c, sigma):
+    return np.logical_and(n > c - sigma, n < c + sigma)
+
+
+def neigh_gaussian(X, Y, std_coeff, compact, ci, cj, sigma, wide):
+    """neighborhoods.py:14-33: separable gaussian around (ci, cj); (n, X, Y).
+
+    ``wide`` selects float64 (sigma is numpy.float64) or float32 evaluation of
+    ``exp(-delta^2/d)``; ``d = 2*std_coeff^2*sigma^2`` is always formed in
+    double (Python arithmetic) first."""
+    sigma = F64(sigma) if wide else float(sigma)
+    d = 2 * std_coeff ** 2 * sigma ** 2
+    ni = np.arange(X)[None, :]
+    nj = np.arange(Y)[None, :]
+    ci = np.asarray(ci)[:, None]
+    cj = np.asarray(cj)[:, None]
+    ax = np.exp(-np.power(ni - ci, 2, dtype=F32) / d)
+    ay = np.exp(-np.power(nj - cj, 2, dtype=F32) / d)
+    if compact:
+        ax *= _support(ni, ci, sigma)
+        ay *= _support(nj, cj, sigma)
+    return ax[:, :, None] * ay[:, None, :]
+
+
+def neigh_mexican_hat(X, Y, std_coeff, compact, ci, cj, sigma, wide):
+    """neighborhoods.py:57-74 (compact_support=False only; the reference's
+    compact branch masks px twice and py never, :69-71, and is not restated)."""
+    if compact:
+        raise NotImplementedError("mexican_hat with compact_support is not restated")
+    sigma = F64(sigma) if wide else float(sigma)
+    d = 2 * std_coeff ** 2 * sigma ** 2
+    ni = np.arange(X)[None, :]
+    nj = np.arange(Y)[None, :]
+    ci = np.asarray(ci)[:, None]
+    cj = np.asarray(cj)[:, None]
+    px = np.power(ni - ci, 2, dtype=F32)
+    py = np.power(nj - cj, 2, dtype=F32)
+    p = px[:, :, None] + py[:, None, :]
+    return np.exp(-p / d) * (1 - 2 / d * p)
+
+
+NEIGHBOURHOODS = {
+    "gaussian": neigh_gaussian,
+    "mexican_hat": neigh_mexican_hat,
+}
+
+
+# --------------------------------------------------------------------------
+# one mini-batch: BMUs -> g -> (numerator, denominator); xpysom.py:420-443
+# --------------------------------------------------------------------------
+def update(x, W3, eta, sigma, *, wide, distance="euclidean", neighbourhood="gaussian",
+           std_coeff=0.5, compact=False, w_sq=None, forced_bmu=None):
+    """Returns (bmu, num, den): bmu (n,) int64 raveled, num (X,Y,D), den (X,Y,1).
+
+    num/den carry the dtype the reference's arithmetic produces (float64 when
+    ``wide``).  ``forced_bmu`` teacher-forces the BMU ids (tests use it to
+    isolate the accumulate path from near-tie BMU noise)."""
+    X, Y, D = W3.shape
+    w = W3.reshape(-1, D)
+    if forced_bmu is None:
+        bmu = bmu_ids(x, w, distance, w_sq)
+    else:
+        bmu = np.asarray(forced_bmu, dtype=np.int64)
+    ci, cj = bmu // Y, bmu % Y
+    eta = F64(eta) if wide else float(eta)
+    g = NEIGHBOURHOODS[neighbourhood](X, Y, std_coeff, compact, ci, cj, sigma, wide) * eta
+    den = g.sum(axis=0)[:, :, None]
+    num = np.dot(g.reshape(len(x), -1).T, x).reshape(W3.shape)
+    return bmu, num, den
+
+
+def merge(W3, num, den):
+    """xpysom.py:446-455: where(den != 0, num/den, W)."""
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.where(den != 0, num / den, W3)
+
+
+def epoch(data, W3, eta, sigma, *, wide, n_parallel, forced_bmu=None, **kw):
+    """One full epoch from codebook W3 (float32): xpysom.py:515-577.
+    Returns (bmu (N,), num f32 (X,Y,D), den f32 (X,Y,1), W_new f32)."""
+    X, Y, D = W3.shape
+    num = np.zeros(W3.shape, dtype=F32)
+    den = np.zeros((X, Y, 1), dtype=F32)
+    w_sq = None
+    if kw.get("distance", "euclidean") in ("euclidean", "cosine"):   # can_cache, distances.py:179-182
+        w_sq = row_sq(W3.reshape(-1, D))
+    out_bmu = []
+    for s in range(0, len(data), n_parallel):
+        fb = None if forced_bmu is None else forced_bmu[s:s + n_parallel]
+        b, a_num, a_den = update(data[s:s + n_parallel], W3, eta, sigma, wide=wide,
+                                 w_sq=w_sq, forced_bmu=fb, **kw)
+        num += a_num      # float64 -> float32 downcast on += when wide (xpysom.py:568-569)
+        den += a_den
+        out_bmu.append(b)
+    return np.concatenate(out_bmu), num, den, merge(W3, num, den)
+
+
+def train(data, W3, num_epochs, *, sigma0, sigmaN=1, lr0=0.5, lrN=0.01, decay="exponential",
+          n_parallel=4000, iter_beg=0, iter_end=None, **kw):
+    """xpysom.py:458-594 local branch. ``W3`` any float dtype; returns float32 codebook."""
+    if iter_end is None:
+        iter_end = num_epochs
+    W3 = np.asarray(W3, dtype=F32)
+    data = np.asarray(data, dtype=F32)
+    f = DECAYS[decay]
+    wide = decay_is_wide(decay)
+    for t in range(iter_beg, iter_end):
+        eta = f(lr0, lrN, t, num_epochs)
+        sig = f(sigma0, sigmaN, t, num_epochs)
+        _, _, _, W3 = epoch(data, W3, eta, sig, wide=wide, n_parallel=n_parallel, **kw)
+    return W3
+
+
+# --------------------------------------------------------------------------
+# inference -- xpysom.py:370-408 (winner), :632-707 (quantization error)
+# --------------------------------------------------------------------------
+def winner_ids(x, W3, distance="euclidean", n_parallel=4000):
+    """Raveled BMU ids exactly as ``winner`` finds them: configured distance,
+    w_sq recomputed per chunk, no dtype coercion of x."""
+    x = np.asarray(x)
+    w = np.asarray(W3).reshape(-1, W3.shape[2])
+    out = [bmu_ids(x[s:s + n_parallel], w, distance) for s in range(0, len(x), n_parallel)]
+    return np.concatenate(out) if out else np.zeros(0, dtype=np.int64)
+
+
+def quantization_ids(x32, W3, n_parallel=4000):
+    """BMU ids as ``_quantization`` finds them: always the full Euclidean
+    distance (sqrt + nan_to_num) regardless of the configured one (xpysom.py:640,670)."""
+    w = W3.reshape(-1, W3.shape[2])
+    out = [np.argmin(dist_euclid(x32[s:s + n_parallel], w), axis=1)
+           for s in range(0, len(x32), n_parallel)]
+    return np.concatenate(out)
+
+
+def quantization_error(data, W3, n_parallel=4000):
+    """xpysom.py:673-707 local branch: mean_n |x_n - W[bmu_n]| -> Python float."""
+    x = np.array(data, dtype=F32)
+    W3 = np.asarray(W3)
+    ids = quantization_ids(x, W3, n_parallel)
+    x = x - W3.reshape(-1, W3.shape[2])[ids]
+    return np.linalg.norm(x, axis=1).mean().item()
+
+
+# --------------------------------------------------------------------------
+# synthetic workload shared by bench.py and the tests
+# --------------------------------------------------------------------------
+def gaussian_blobs(N, D, seed=1234, centres=64, spread=3.0):
+    rng = np.random.default_rng(seed)
+    c = rng.normal(0.0, spread, size=(centres, D))
+    lab = rng.integers(0, centres, size=N)
+    x = c[lab] + rng.normal(0.0, 1.0, size=(N, D))
+    return x.astype(F32)

@@ -1,0 +1,209 @@
+"""The NumPy oracle against the golden vectors captured from the reference
+(oracle/make_golden.py).  CPU only.  This is what 'pins' the oracle."""
+import numpy as np
+import pytest
+
+from oracle import som_oracle as O
+from tests.conftest import load_golden
+
+F32 = np.float32
+
+
+def test_g1_ties_first_minimum_wins():
+    g = load_golden("g1_ties")
+    x, w = g["x"], g["w"]
+    assert np.array_equal(O.winner_ids(x, w), g["ids"])
+    assert np.array_equal(O.winner_ids(x, np.zeros_like(w)), g["ids_zero"])
+    assert np.array_equal(O.winner_ids(x, np.ones_like(w)), g["ids_same"])
+    assert (g["ids_zero"] == 0).all() and (g["ids_same"] == 0).all()
+    # duplicated rows 7, 10, 19 -> 7
+    assert g["ids"][0] == 7 and g["ids"][2] == 7 and g["ids"][3] == 7
+
+
+def test_g2_distances():
+    g = load_golden("g2_distances")
+    n = int(g["n_cases"])
+    assert n > 100
+    for c in range(n):
+        x, w = g[f"c{c:03d}_x"], g[f"c{c:03d}_w"]
+        with np.errstate(all="ignore"):
+            np.testing.assert_array_equal(O.dist_euclid_part(x, w), g[f"c{c:03d}_part"])
+            np.testing.assert_array_equal(O.dist_euclid_sq(x, w), g[f"c{c:03d}_sq"])
+            np.testing.assert_array_equal(O.dist_euclid(x, w), g[f"c{c:03d}_l2"])
+            np.testing.assert_array_equal(O.dist_cosine(x, w), g[f"c{c:03d}_cos"])
+
+
+def test_g2_known_answers_of_the_reference_tests():
+    """The closed forms the reference's own test file checks against
+    (xpysom_dask/test_distances.py:92-113), to 7 decimals as it does."""
+    g = load_golden("g2_distances")
+    for c in range(int(g["n_cases"])):
+        x, w = g[f"c{c:03d}_x"], g[f"c{c:03d}_w"]
+        for i, vx in enumerate(x):
+            for j, vy in enumerate(w):
+                assert abs(g[f"c{c:03d}_part"][i, j] - (-2 * vx @ vy + vy @ vy)) < 1e-7
+                assert abs(g[f"c{c:03d}_l2"][i, j] - np.linalg.norm(vx - vy)) < 1e-7
+
+
+@pytest.mark.parametrize("XY", [(5, 5), (3, 4)])
+def test_g3_neighbourhoods(XY):
+    g = load_golden("g3_neighbourhoods")
+    X, Y = XY
+    ci, cj = np.divmod(np.arange(X * Y), Y)
+    for sig in (0.3, 1.0, 2.5):
+        for wide in (False, True):
+            tag = "f64" if wide else "f32"
+            for compact in (False, True):
+                key = f"{X}x{Y}_s{sig}_{tag}_{'cs' if compact else 'nc'}"
+                for name, sc in (("gauss_", 1.0), ("gauss05_", 0.5)):
+                    ref = g[name + key]
+                    got = O.neigh_gaussian(X, Y, sc, compact, ci, cj, sig, wide)
+                    assert got.dtype == ref.dtype == (np.float64 if wide else np.float32)
+                    np.testing.assert_array_equal(got, ref)
+            ref = g[f"mex_{X}x{Y}_s{sig}_{tag}_nc"]
+            got = O.neigh_mexican_hat(X, Y, 1.0, False, ci, cj, sig, wide)
+            assert got.dtype == ref.dtype
+            np.testing.assert_array_equal(got, ref)
+
+
+SHAPES = ["6x6x4", "8x8x3", "24x24x16", "20x30x12"]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("decay", ["linear", "exponential"])
+def test_g4_g5_update_and_epoch(shape, decay):
+    g = load_golden("g4_update_" + shape)
+    X, Y, D, n = (int(v) for v in g["shape"])
+    T = int(g["T"])
+    data = O.gaussian_blobs(n, D, seed=int(g["data_seed"]))
+    w0 = O.default_codebook(X, Y, D, 1234).astype(F32)
+    wmid = g[f"{decay}_wmid"]
+    wide = O.decay_is_wide(decay)
+    f = O.DECAYS[decay]
+    for tag, w, t in (("init", w0, 0), ("mid", wmid, T // 2), ("last", wmid, T - 1)):
+        eta = f(0.5, 0.01, t, T)
+        sig = f(min(X, Y) / 2, 1, t, T)
+        assert float(eta) == float(g[f"{decay}_{tag}_eta"])
+        assert float(sig) == float(g[f"{decay}_{tag}_sig"])
+        bmu, num, den, wout = O.epoch(data, w, eta, sig, wide=wide, n_parallel=n)
+        assert np.array_equal(bmu, g[f"{decay}_{tag}_bmu"])
+        np.testing.assert_allclose(den[:, :, 0], g[f"{decay}_{tag}_den"][:, :, 0], rtol=2e-6, atol=0)
+        if f"{decay}_{tag}_num" in g:
+            np.testing.assert_allclose(num, g[f"{decay}_{tag}_num"], rtol=1e-5, atol=1e-6)
+        ok = den[:, :, 0] > 1e-30
+        np.testing.assert_allclose(wout[ok], g[f"{decay}_{tag}_wout"][ok], rtol=1e-5, atol=2e-6)
+        if f"{decay}_{tag}_wout77" in g:
+            _, _, _, w77 = O.epoch(data, w, eta, sig, wide=wide, n_parallel=77)
+            np.testing.assert_allclose(w77[ok], g[f"{decay}_{tag}_wout77"][ok], rtol=1e-5, atol=2e-6)
+
+
+def test_g5_wmid_from_full_training():
+    """Five reference epochs from the default codebook (well-conditioned small cases only)."""
+    for shape in ("6x6x4", "8x8x3"):
+        g = load_golden("g4_update_" + shape)
+        X, Y, D, n = (int(v) for v in g["shape"])
+        data = O.gaussian_blobs(n, D, seed=int(g["data_seed"]))
+        for decay in ("linear", "exponential"):
+            w = O.train(data, O.default_codebook(X, Y, D, 1234), 10, sigma0=min(X, Y) / 2,
+                        decay=decay, n_parallel=n, iter_end=5)
+            np.testing.assert_allclose(w, g[f"{decay}_wmid"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("decay", ["linear", "exponential"])
+def test_g7_shard_identity(decay):
+    g = load_golden("g4_update_24x24x16")
+    X, Y, D, n = (int(v) for v in g["shape"])
+    data = O.gaussian_blobs(n, D, seed=int(g["data_seed"]))
+    w = g[f"{decay}_wmid"]
+    eta, sig = g[f"{decay}_mid_eta"], g[f"{decay}_mid_sig"]
+    eta = np.float64(eta) if decay == "exponential" else float(eta)
+    sig = np.float64(sig) if decay == "exponential" else float(sig)
+    wide = O.decay_is_wide(decay)
+    num = np.zeros((X, Y, D), F32)
+    den = np.zeros((X, Y, 1), F32)
+    for part in np.array_split(np.arange(n), 2):
+        _, a, b = O.update(data[part], w, eta, sig, wide=wide)
+        num += a.astype(F32)
+        den += b.astype(F32)
+    np.testing.assert_allclose(num, g[f"{decay}_shard2_num"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(den, g[f"{decay}_shard2_den"], rtol=1e-5, atol=1e-30)
+    # and the shard sum equals the unsharded update (the property RCCL all-reduce relies on)
+    np.testing.assert_allclose(num, g[f"{decay}_mid_num"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("decay", ["linear", "exponential"])
+@pytest.mark.parametrize("init", ["default", "random", "pca"])
+def test_g6_iris_end_to_end(decay, init):
+    g = load_golden("g6_iris")
+    z = g["iris_z"]
+    w0 = g[f"{decay}_{init}_w0"]
+    assert abs(O.quantization_error(z, w0) - float(g[f"{decay}_{init}_qe0"])) < 1e-6
+    w = O.train(z, w0, 100, sigma0=3.0, decay=decay, n_parallel=4000)
+    np.testing.assert_allclose(w, g[f"{decay}_{init}_w"], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(O.winner_ids(z, w), g[f"{decay}_{init}_bmu"])
+    assert abs(O.quantization_error(z, w) - float(g[f"{decay}_{init}_qe"])) < 1e-5
+
+
+def test_g6_readme_config_qe():
+    g = load_golden("g6_iris")
+    raw = g["iris_raw"]
+    w0 = O.default_codebook(6, 6, 4, 10)
+    assert abs(O.quantization_error(raw, w0) - float(g["readme_qe0"])) < 1e-5
+    assert abs(float(g["readme_qe"]) - 0.296985) < 1e-5        # SURVEY 8(c) anchor
+
+
+@pytest.mark.parametrize("decay", ["linear", "exponential"])
+def test_g8_cosine_mexican_hat(decay):
+    g = load_golden("g8_cosine_mexican")
+    data, w0 = g["data"], g[f"{decay}_w0"]
+    wide = O.decay_is_wide(decay)
+    f = O.DECAYS[decay]
+    eta, sig = f(0.5, 0.01, 0, 10), f(4.0, 1, 0, 10)
+    assert float(eta) == float(g[f"{decay}_eta"]) and float(sig) == float(g[f"{decay}_sig"])
+    bmu, num, den, wout = O.epoch(data, w0, eta, sig, wide=wide, n_parallel=len(data),
+                                  distance="cosine", neighbourhood="mexican_hat")
+    assert np.array_equal(bmu, g[f"{decay}_bmu"])
+    np.testing.assert_allclose(num, g[f"{decay}_num"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(den, g[f"{decay}_den"], rtol=1e-4, atol=1e-5)
+
+
+def test_g8_cosine_gaussian():
+    g = load_golden("g8_cosine_mexican")
+    data = g["data"]
+    w0 = np.abs(O.default_codebook(8, 8, 6, 3)).astype(F32)
+    eta, sig = O.linear_decay(0.5, 0.01, 0, 10), O.linear_decay(4.0, 1, 0, 10)
+    bmu, _, den, wout = O.epoch(data, w0, eta, sig, wide=False, n_parallel=len(data), distance="cosine")
+    assert np.array_equal(bmu, g["cosgauss_bmu"])
+    np.testing.assert_allclose(wout, g["cosgauss_wout"], rtol=1e-5, atol=1e-6)
+
+
+def test_g9_inference():
+    g = load_golden("g9_inference")
+    probe = O.gaussian_blobs(700, 10, seed=int(g["probe_seed"]))
+    w = g["w"]
+    assert np.array_equal(O.winner_ids(probe, w), g["winner"])
+    assert np.array_equal(O.winner_ids(probe.astype(np.float64), w), g["winner64"])
+    assert abs(O.quantization_error(probe, w) - float(g["qe"])) < 1e-6
+
+
+def test_reference_unit_test_constants():
+    """Known answers from the reference's unittest file that need no MiniSom
+    (xpysom_dask/tests.py:31-33,66-67,77-79)."""
+    w = np.zeros((5, 5, 1))
+    w[2, 3] = 5.0
+    w[1, 1] = 2.0
+    assert O.quantization_error([[5], [2]], w) == 0.0
+    assert O.quantization_error([[4], [1]], w) == 1.0
+    assert O.dist_euclid_part(np.array([[5.0]]), w.reshape(-1, 1)).argmin() == 13
+    for i in range(5):
+        for j in range(5):
+            assert abs(np.linalg.norm(O.default_codebook(5, 5, 1, None)[i, j]) - 1.0) < 1e-7
+
+
+def test_decays_match_closed_forms():
+    assert O.asymptotic_decay(2.0, 9, 5, 10) == 1.0
+    assert O.linear_decay(3.0, 1.0, 9, 10) == 1.0 and O.linear_decay(3.0, 1.0, 0, 1) == 3.0
+    assert abs(O.exponential_decay(8.0, 1.0, 10, 10) - 1.0) < 1e-12
+    assert abs(O.exponential_decay(1.0, 0, 10, 10) - 0.1) < 1e-12
+    assert isinstance(O.exponential_decay(8.0, 1.0, 3, 10), np.float64)
+    assert isinstance(O.linear_decay(8.0, 1.0, 3, 10), float)
