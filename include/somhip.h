@@ -1,0 +1,121 @@
+/*
+ * somhip.h -- C ABI of the MI355X-native batch-SOM engine (libsomhip.so).
+ *
+ * The reference (jcfaracco/xpysom-dask) has no FFI layer of its own: its hot
+ * path is reached through `xp.*` array calls inside the Python class XPySom.
+ * This header is the boundary a drop-in replaces those calls with.  Every entry
+ * point below names the reference code it stands in for (file:line under
+ * /root/reference/xpysom_dask/).  The Python host (xpysom_dask_amd/xpysom.py)
+ * binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - Every call returns 0 on success, non-zero on failure; the message is
+ *     available from som_last_error(handle) (or som_last_error(NULL) when
+ *     som_create itself failed).  Nothing throws across the ABI.
+ *   - The caller owns all host buffers; the library owns all device buffers.
+ *   - One handle = one GPU = one host thread at a time (not locked).
+ *   - Codebook layout: float32 [K][D] row-major, K = X*Y, unit k = i*Y + j
+ *     (xpysom.py:240 unravel table; distances.py:185 reshape).
+ *   - Data layout: float32 [N][D] row-major (xpysom.py:510).
+ */
+#ifndef SOMHIP_H
+#define SOMHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct som_handle som_handle;
+
+/* activation distance: distances.py:162-170 registry (names kept) */
+enum { SOM_DIST_EUCLIDEAN = 0,        /* 'euclidean'  -> euclidean_squared_distance_part, distances.py:11-23 */
+       SOM_DIST_EUCLIDEAN_NO_OPT = 1, /* 'euclidean_no_opt' -> euclidean_squared_distance, distances.py:25-31 */
+       SOM_DIST_COSINE = 2 };         /* 'cosine'     -> cosine_distance, distances.py:45-59 */
+
+/* neighbourhood function on the rectangular topology: neighborhoods.py:14-33, :57-74, :99-130 */
+enum { SOM_NEIGH_GAUSSIAN = 0, SOM_NEIGH_MEXICAN_HAT = 1, SOM_NEIGH_BUBBLE = 2, SOM_NEIGH_TRIANGLE = 3 };
+
+/* arithmetic of the distance GEMM (the -2 x.w^T term, distances.py:22):
+ *   F32  : v_mfma_f32_32x32x2_f32, exact float32 fma chain -- the parity mode
+ *   BF16 : v_mfma_f32_32x32x16_bf16 on bf16-rounded x and w, f32 accumulate -- the throughput mode */
+enum { SOM_PREC_F32 = 0, SOM_PREC_BF16 = 1 };
+
+/* which BMU rule som_bmu applies */
+enum { SOM_BMU_ACTIVATION = 0,   /* configured activation distance: XPySom._winner, xpysom.py:410-417 */
+       SOM_BMU_QUANTIZATION = 1  /* full sqrt'd Euclidean + nan_to_num: _quantization, xpysom.py:640,670 */ };
+
+/* timed kernels for som_profile_get */
+enum { SOM_K_BMU = 0, SOM_K_SEGSUM = 1, SOM_K_KRON = 2, SOM_K_MERGE = 3, SOM_K_PREP = 4, SOM_K_COUNT = 5 };
+
+typedef struct som_config {
+    int32_t x, y, input_len;     /* map rows, cols, features: XPySom.__init__, xpysom.py:73 */
+    int32_t distance;            /* SOM_DIST_*  */
+    int32_t neighborhood;        /* SOM_NEIGH_* */
+    int32_t compact_support;     /* neighborhoods.py:29-31 */
+    int32_t precision;           /* SOM_PREC_*  */
+    int32_t device;              /* HIP device ordinal */
+    double  std_coeff;           /* d = 2*std_coeff^2*sigma^2, neighborhoods.py:19 */
+    void*   stream;              /* hipStream_t to launch on; NULL = the library creates its own */
+} som_config;
+
+const char* som_version(void);
+int         som_device_count(void);                      /* replaces utils.find_max_cuda_threads' device probe, utils.py:4-13 */
+const char* som_last_error(const som_handle* h);
+
+int  som_create(const som_config* cfg, som_handle** out); /* XPySom.__init__ device-side state, xpysom.py:193-240 */
+void som_destroy(som_handle* h);
+
+/* host <-> device codebook: train() entry/exit copies, xpysom.py:485, :580-583 */
+int som_set_weights(som_handle* h, const float* w_host);
+int som_get_weights(som_handle* h, float* w_host);
+
+/* resident training data: xp.asarray(data, float32), xpysom.py:510.  The rows
+ * stay on the device for all epochs.  _device: rows already in HBM (borrowed,
+ * must outlive the handle's use of them). */
+int som_set_data(som_handle* h, const float* x_host, int64_t n_rows);
+int som_set_data_device(som_handle* h, const void* x_dev, int64_t n_rows);
+
+/* One epoch over the resident rows = the body of the epoch loop, xpysom.py:515-577:
+ *   som_epoch_accumulate: w_sq cache (:529-537), every _update (:560-569 -> :420-443:
+ *       BMU, neighbourhood*eta, sum_g, g^T x) summed into the fused float32
+ *       accumulator [K][D+1] (numerator | denominator), left on the device;
+ *   (multi-GPU: the host all-reduces the accumulator here -- replaces the Dask
+ *       gather/sum, xpysom.py:545-558)
+ *   som_epoch_merge: _merge_updates, xpysom.py:446-455.
+ *   som_epoch = accumulate + merge.
+ * sigma, eta: this epoch's schedule values (decays.py).  neigh_f64 != 0 evaluates
+ * the neighbourhood in float64 (what NumPy >= 2 does when the schedule returns
+ * numpy.float64, i.e. 'exponential'); 0 mimics the float32 evaluation. */
+int som_epoch_accumulate(som_handle* h, double sigma, double eta, int neigh_f64);
+int som_epoch_merge(som_handle* h);
+int som_epoch(som_handle* h, double sigma, double eta, int neigh_f64);
+
+/* device address and length (floats) of the fused accumulator, for an in-place
+ * all-reduce by the host (RCCL via torch.distributed). */
+int som_accum_device_ptr(som_handle* h, void** dev_ptr, int64_t* n_floats);
+/* teacher-forced parity: copy the last accumulate's results to the host.
+ * Any pointer may be NULL.  num [K][D], den [K], bmu [n_rows] (raveled ids). */
+int som_epoch_fetch(som_handle* h, float* num, float* den, int32_t* bmu);
+/* teacher-forcing the other way: run the accumulate with these BMU ids instead
+ * of computing them (isolates the update path in tests). */
+int som_epoch_accumulate_forced(som_handle* h, const int32_t* bmu_host, double sigma, double eta, int neigh_f64);
+
+/* BMU ids for arbitrary rows: XPySom.winner, xpysom.py:370-408 (mode ACTIVATION)
+ * and XPySom._quantization, xpysom.py:632-645 (mode QUANTIZATION). */
+int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, int32_t* ids_out);
+/* mean_n |x_n - W[bmu_n]|: XPySom.quantization_error, xpysom.py:673-707 */
+int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, double* qe_out);
+
+/* stream / timing plumbing */
+int som_sync(som_handle* h);
+int som_profile_enable(som_handle* h, int32_t on);          /* hipEvent pairs around each kernel family */
+int som_profile_get(som_handle* h, int32_t kernel, double* total_ms, int64_t* launches);
+int som_profile_reset(som_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOMHIP_H */

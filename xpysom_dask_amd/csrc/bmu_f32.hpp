@@ -1,0 +1,149 @@
+// Fused distance + BMU argmin, float32 parity mode.
+//
+// Replaces, per mini-batch, the reference chain
+//   DistanceFunction.__call__      distances.py:184-191
+//   euclidean_squared_distance_part distances.py:11-23   (-2 x.w^T + w_sq^T)
+//   euclidean_distance             distances.py:33-43   (QE path, xpysom.py:640,670)
+//   cosine_distance                distances.py:45-59
+//   argmin(axis=1)                 xpysom.py:416
+// without ever writing the (n, K) distance matrix.
+//
+// Arithmetic: the cross term runs on v_mfma_f32_32x32x2_f32, which is bit-for-bit a
+// k-ordered float32 fmaf chain, so identical codebook rows give identical distances
+// and exact ties resolve to the lowest raveled unit id exactly as numpy.argmin does.
+//
+// Mapping: A operand = codebook rows (units), B operand = samples, so a lane owns one
+// sample (column) and its 16 accumulator registers are 16 different units: the running
+// argmin is pure per-lane VALU; one __shfl_xor(…,32) at the very end joins the two lane
+// halves.  A workgroup = 4 waves x 32 samples and scans the whole codebook in tiles of
+// 128 units staged through LDS (coalesced rows, +1 padded so fragment reads are
+// conflict-free).
+#pragma once
+#include "som_common.hpp"
+
+namespace somhip {
+
+constexpr int F32_SB = 128;   // samples per workgroup
+constexpr int F32_UB = 128;   // units per codebook tile
+constexpr int F32_KC = 32;    // features per LDS chunk
+
+enum { SCORE_EUCLID_PART = 0, SCORE_EUCLID_SQRT = 1, SCORE_COSINE = 2, SCORE_EUCLID_SQ = 3 };
+
+template <int MODE>
+__device__ __forceinline__ float score_f32(float cross, float wsq, float xsq) {
+    if (MODE == SCORE_EUCLID_PART) {
+        return __builtin_fmaf(-2.0f, cross, wsq);                 // -2*cross exact, one rounding: == numpy
+    } else if (MODE == SCORE_EUCLID_SQ) {
+        return __builtin_fmaf(-2.0f, cross, wsq) + xsq;           // distances.py:30-31
+    } else if (MODE == SCORE_EUCLID_SQRT) {
+        float t = __builtin_fmaf(-2.0f, cross, wsq) + xsq;        // distances.py:38-43
+        return nan_to_num_f32(__builtin_sqrtf(t));
+    } else {
+        float den = __builtin_sqrtf(xsq * wsq);                   // distances.py:56-59
+        return 1.0f - nan_to_num_f32(cross / den);
+    }
+}
+
+// X: [N][D] row-major f32.  W: [K][D] row-major f32.  wsq: [K].  xsq: [N] (unused for MODE 0).
+// x_resident != 0: the workgroup's whole sample block stays in LDS (needs SB*(Dp+1)*4 bytes).
+template <int MODE>
+__global__ __launch_bounds__(256) void bmu_f32_kernel(const float* __restrict__ X, long N, int D, int Dp,
+                                                      const float* __restrict__ W, const float* __restrict__ wsq,
+                                                      int K, const float* __restrict__ xsq, int x_resident,
+                                                      int* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* Ws = smem_f;                                // [UB][KC+1]
+    float* wq = Ws + F32_UB * (F32_KC + 1);            // [UB]
+    float* Xs = wq + F32_UB;                           // [SB][xw+1]
+    const int xstride = (x_resident ? Dp : F32_KC) + 1;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const long s0 = (long)blockIdx.x * F32_SB;
+    const long my_sample = s0 + wave * 32 + col;
+
+    float best = __builtin_inff();
+    int bidx = 0;
+    float xs = 0.0f;
+    if (MODE != SCORE_EUCLID_PART) xs = (my_sample < N) ? xsq[my_sample] : 0.0f;
+
+    if (x_resident) {
+        for (int idx = tid; idx < F32_SB * Dp; idx += 256) {
+            int r = idx / Dp, k = idx - r * Dp;
+            float v = 0.0f;
+            if (s0 + r < N && k < D) v = X[(s0 + r) * (long)D + k];
+            Xs[r * xstride + k] = v;
+        }
+    }
+
+    for (int u0 = 0; u0 < K; u0 += F32_UB) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
+
+        for (int kc = 0; kc < Dp; kc += F32_KC) {
+            __syncthreads();
+            for (int idx = tid; idx < F32_UB * F32_KC; idx += 256) {
+                int r = idx >> 5, k = idx & 31;
+                float v = 0.0f;
+                if (u0 + r < K && kc + k < D) v = W[(long)(u0 + r) * D + kc + k];
+                Ws[r * (F32_KC + 1) + k] = v;
+            }
+            if (kc == 0 && tid < F32_UB) wq[tid] = (u0 + tid < K) ? wsq[u0 + tid] : __builtin_inff();
+            if (!x_resident) {
+                for (int idx = tid; idx < F32_SB * F32_KC; idx += 256) {
+                    int r = idx >> 5, k = idx & 31;
+                    float v = 0.0f;
+                    if (s0 + r < N && kc + k < D) v = X[(s0 + r) * (long)D + kc + k];
+                    Xs[r * xstride + k] = v;
+                }
+            }
+            __syncthreads();
+            const float* xrow = Xs + (wave * 32 + col) * xstride + (x_resident ? kc : 0) + half;
+            const float* wrow = Ws + col * (F32_KC + 1) + half;
+#pragma unroll
+            for (int k = 0; k < F32_KC; k += 2) {
+                float b = xrow[k];
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    float a = wrow[rb * 32 * (F32_KC + 1) + k];
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[rb], 0, 0, 0);
+                }
+            }
+        }
+        // epilogue: units ascend with (rb, r) for a fixed lane half, '<' keeps the first minimum
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = rb * 32 + mfma32_row(r, half);
+                int u = u0 + row;
+                float v = score_f32<MODE>(acc[rb][r], wq[row], xs);
+                if (u < K && v < best) { best = v; bidx = u; }
+            }
+        }
+    }
+    // join the two lane halves (same sample, disjoint units): smaller value, then smaller id
+    float ob = __shfl_xor(best, 32, 64);
+    int oi = __shfl_xor(bidx, 32, 64);
+    if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    if (half == 0 && my_sample < N) out[my_sample] = bidx;
+}
+
+// sum of squares of each row, float32, one wave per row (lanes stride the features).
+// Stands in for xp.power(a, 2).sum(axis=1): xpysom.py:529-537 (w_sq), distances.py:30,53 (x_sq).
+__global__ __launch_bounds__(256) void row_sq_f32_kernel(const float* __restrict__ A, long rows, int D,
+                                                         float* __restrict__ out) {
+    long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* a = A + row * (long)D;
+    float s = 0.0f;
+    for (int k = lane; k < D; k += 64) s = __builtin_fmaf(a[k], a[k], s);
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s;
+}
+
+}  // namespace somhip

@@ -1,0 +1,34 @@
+// Shared device-side types and helpers for libsomhip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+#define SOM_WAVE 64
+
+// C/D register -> row of a 32x32 MFMA accumulator tile (dtype independent on gfx950):
+// lane l holds column l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15.
+__device__ __forceinline__ int mfma32_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// numpy.nan_to_num on float32: NaN -> 0, +inf -> FLT_MAX, -inf -> -FLT_MAX
+__device__ __forceinline__ float nan_to_num_f32(float v) {
+    if (v != v) return 0.0f;
+    if (v == __builtin_inff()) return 3.402823466e+38f;
+    if (v == -__builtin_inff()) return -3.402823466e+38f;
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

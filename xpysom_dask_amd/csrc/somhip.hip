@@ -1,0 +1,553 @@
+// libsomhip.so -- C ABI over the gfx950 kernels (include/somhip.h).
+// Host side only orchestrates: buffers, launch geometry checks, the per-epoch kernel
+// sequence on one HIP stream, hipEvent timing.  No compute happens on the host and
+// there is no CPU fallback: every path either launches the HIP kernels or fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/somhip.h"
+#include "bmu_bf16.hpp"
+#include "bmu_f32.hpp"
+#include "update.hpp"
+
+using namespace somhip;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct EventPair { hipEvent_t a, b; int kernel; };
+
+}  // namespace
+
+struct som_handle {
+    som_config cfg{};
+    int X = 0, Y = 0, K = 0, D = 0, D1p = 0;
+    int ksteps = 0;          // bf16: ceil(D/16)
+    int nt = 1;              // neighbourhood terms
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    float *W = nullptr, *wsq = nullptr, *SC = nullptr, *T = nullptr, *ACC = nullptr, *P1 = nullptr, *P2 = nullptr;
+    char* Wst = nullptr;
+    int n_stages = 0;
+    bool w_dirty = true;     // wsq / bf16 stage image out of date w.r.t. W
+
+    // resident training rows
+    const float* Xd = nullptr;
+    float* X_owned = nullptr;
+    long N = 0, Np = 0;
+    int* bmu = nullptr;
+    float* xsq = nullptr;
+    __bf16* Xb = nullptr;
+    float* xsqh = nullptr;
+
+    // scratch for som_bmu / som_quantization_error
+    float* qX = nullptr; int* qbmu = nullptr; float* qxsq = nullptr; __bf16* qXb = nullptr; float* qxsqh = nullptr;
+    long qcap = 0;
+    double* dsum = nullptr;
+
+    bool prof = false;
+    std::vector<EventPair> pending, pool;
+    double ms[SOM_K_COUNT] = {0};
+    int64_t launches[SOM_K_COUNT] = {0};
+
+    std::string err;
+};
+
+namespace {
+
+int fail(som_handle* h, const std::string& msg) {
+    if (h) h->err = msg; else g_create_error = msg;
+    return 1;
+}
+int fail_hip(som_handle* h, const char* what, hipError_t e) {
+    return fail(h, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIPCHK(h, call)                                              \
+    do {                                                             \
+        hipError_t e_ = (call);                                      \
+        if (e_ != hipSuccess) return fail_hip((h), #call, e_);       \
+    } while (0)
+
+template <typename T>
+int dev_alloc(som_handle* h, T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIPCHK(h, hipMalloc((void**)p, count * sizeof(T)));
+    return 0;
+}
+
+inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+inline long round_up(long a, long b) { return cdiv(a, b) * b; }
+
+// ---- profiling: event pairs recorded around kernel families, resolved lazily ---------------
+struct Timed {
+    som_handle* h; int kernel; EventPair ep{}; bool on;
+    Timed(som_handle* h_, int k) : h(h_), kernel(k), on(h_->prof) {
+        if (!on) return;
+        if (!h->pool.empty()) { ep = h->pool.back(); h->pool.pop_back(); }
+        else { (void)hipEventCreate(&ep.a); (void)hipEventCreate(&ep.b); }
+        ep.kernel = kernel;
+        (void)hipEventRecord(ep.a, h->stream);
+    }
+    ~Timed() {
+        if (!on) return;
+        (void)hipEventRecord(ep.b, h->stream);
+        h->pending.push_back(ep);
+    }
+};
+
+int resolve_profile(som_handle* h) {
+    if (h->pending.empty()) return 0;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (auto& ep : h->pending) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, ep.a, ep.b));
+        h->ms[ep.kernel] += ms;
+        h->launches[ep.kernel] += 1;
+        h->pool.push_back(ep);
+    }
+    h->pending.clear();
+    return 0;
+}
+
+// ---- codebook-derived operands (w_sq cache, xpysom.py:529-537; bf16 stage image) ------------
+template <int KS>
+void launch_prep_w(som_handle* h) {
+    long total = (long)h->n_stages * BF_UT * KS * 64;
+    prep_w_bf16_kernel<KS><<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->Wst,
+                                                                                        h->n_stages);
+}
+
+int refresh_codebook_operands(som_handle* h) {
+    if (!h->w_dirty) return 0;
+    Timed t(h, SOM_K_PREP);
+    row_sq_f32_kernel<<<dim3((unsigned)cdiv(h->K, 4)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->wsq);
+    if (h->cfg.precision == SOM_PREC_BF16) {
+        switch (h->ksteps) {
+        case 1: launch_prep_w<1>(h); break;
+        case 2: launch_prep_w<2>(h); break;
+        case 3: launch_prep_w<3>(h); break;
+        case 4: launch_prep_w<4>(h); break;
+        case 5: launch_prep_w<5>(h); break;
+        case 6: launch_prep_w<6>(h); break;
+        case 7: launch_prep_w<7>(h); break;
+        case 8: launch_prep_w<8>(h); break;
+        default: return fail(h, "bf16 precision supports input_len <= 128");
+        }
+        long units = (long)h->n_stages * BF_STAGE_UNITS;
+        prep_wsqh_kernel<<<dim3((unsigned)cdiv(units, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->Wst,
+                                                                                      h->n_stages, h->ksteps);
+    }
+    HIPCHK(h, hipGetLastError());
+    h->w_dirty = false;
+    return 0;
+}
+
+// ---- BMU launches ----------------------------------------------------------------------------
+template <int MODE>
+int launch_bmu_f32(som_handle* h, const float* X, long N, const float* xsq, int* out) {
+    const int Dp = (int)round_up(h->D, F32_KC);
+    size_t base = (size_t)(F32_UB * (F32_KC + 1) + F32_UB) * sizeof(float);
+    size_t res = base + (size_t)F32_SB * (Dp + 1) * sizeof(float);
+    size_t chunked = base + (size_t)F32_SB * (F32_KC + 1) * sizeof(float);
+    int x_resident = res <= 150 * 1024;
+    size_t lds = x_resident ? res : chunked;
+    HIPCHK(h, hipFuncSetAttribute((const void*)bmu_f32_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+    long grid = cdiv(N, F32_SB);
+    if (grid <= 0 || grid > 0x7fffffffL) return fail(h, "bmu_f32: row count out of range");
+    bmu_f32_kernel<MODE><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, N, h->D, Dp, h->W, h->wsq, h->K, xsq,
+                                                                             x_resident, out);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+template <int KS>
+int launch_bmu_bf16_ks(som_handle* h, const __bf16* Xb, const float* xsqh, long N, int* out) {
+    size_t lds = 2 * (size_t)bf_stage_bytes(KS);
+    HIPCHK(h, hipFuncSetAttribute((const void*)bmu_bf16_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+    long grid = cdiv(N, BF_WG_SAMPLES);
+    if (grid <= 0 || grid > 0x7fffffffL) return fail(h, "bmu_bf16: row count out of range");
+    bmu_bf16_kernel<KS><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(Xb, xsqh, N, h->Wst, h->n_stages, h->K,
+                                                                            out);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int launch_bmu_bf16(som_handle* h, const __bf16* Xb, const float* xsqh, long N, int* out) {
+    switch (h->ksteps) {
+    case 1: return launch_bmu_bf16_ks<1>(h, Xb, xsqh, N, out);
+    case 2: return launch_bmu_bf16_ks<2>(h, Xb, xsqh, N, out);
+    case 3: return launch_bmu_bf16_ks<3>(h, Xb, xsqh, N, out);
+    case 4: return launch_bmu_bf16_ks<4>(h, Xb, xsqh, N, out);
+    case 5: return launch_bmu_bf16_ks<5>(h, Xb, xsqh, N, out);
+    case 6: return launch_bmu_bf16_ks<6>(h, Xb, xsqh, N, out);
+    case 7: return launch_bmu_bf16_ks<7>(h, Xb, xsqh, N, out);
+    case 8: return launch_bmu_bf16_ks<8>(h, Xb, xsqh, N, out);
+    }
+    return fail(h, "bf16 precision supports input_len <= 128");
+}
+
+int prep_rows_bf16(som_handle* h, const float* X, long N, long Np, __bf16* Xb, float* xsqh) {
+    const int Dp = 16 * h->ksteps;
+    prep_x_bf16_kernel<<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, Dp, Np, Xb, xsqh);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// BMU of `N` device rows with the configured activation distance (xpysom.py:410-417)
+int run_activation_bmu(som_handle* h, const float* X, long N, const float* xsq, const __bf16* Xb, const float* xsqh,
+                       int* out) {
+    if (N == 0) return 0;
+    if (int rc = refresh_codebook_operands(h)) return rc;
+    Timed t(h, SOM_K_BMU);
+    if (h->cfg.precision == SOM_PREC_BF16) return launch_bmu_bf16(h, Xb, xsqh, N, out);
+    switch (h->cfg.distance) {
+    case SOM_DIST_EUCLIDEAN: return launch_bmu_f32<SCORE_EUCLID_PART>(h, X, N, xsq, out);
+    case SOM_DIST_EUCLIDEAN_NO_OPT: return launch_bmu_f32<SCORE_EUCLID_SQ>(h, X, N, xsq, out);
+    case SOM_DIST_COSINE: return launch_bmu_f32<SCORE_COSINE>(h, X, N, xsq, out);
+    }
+    return fail(h, "unknown distance id");
+}
+
+bool needs_xsq(const som_handle* h) {
+    return h->cfg.precision == SOM_PREC_F32 && h->cfg.distance != SOM_DIST_EUCLIDEAN;
+}
+
+int row_sq(som_handle* h, const float* X, long N, float* out) {
+    if (N == 0) return 0;
+    row_sq_f32_kernel<<<dim3((unsigned)cdiv(N, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, out);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// ---- update path: segment sum + separable neighbourhood transform --------------------------
+int run_update(som_handle* h, double sigma, double eta, int neigh_f64) {
+    const long KD1 = (long)h->K * h->D1p;
+    {
+        Timed t(h, SOM_K_SEGSUM);
+        HIPCHK(h, hipMemsetAsync(h->SC, 0, KD1 * sizeof(float), h->stream));
+        if (h->N > 0) {
+            long total = h->N * (h->D + 1);
+            long grid = cdiv(total, 256);
+            if (grid > 0x7fffffffL) return fail(h, "segsum: too many rows for one launch");
+            segsum_kernel<<<dim3((unsigned)grid), dim3(256), 0, h->stream>>>(h->Xd, h->bmu, h->N, h->D, h->D1p, h->SC);
+            HIPCHK(h, hipGetLastError());
+        }
+    }
+    Timed t(h, SOM_K_KRON);
+    NeighParams p{};
+    p.sigma = sigma; p.eta = eta;
+    p.d = 2.0 * (h->cfg.std_coeff * h->cfg.std_coeff) * (sigma * sigma);
+    p.kind = h->cfg.neighborhood; p.compact = h->cfg.compact_support; p.wide = neigh_f64 ? 1 : 0;
+    p.X = h->X; p.Y = h->Y; p.nt = h->nt;
+    long ntab = (long)h->nt * h->Y * h->Y + (long)h->X * h->nt * h->X;
+    neigh_tables_kernel<<<dim3((unsigned)cdiv(ntab, 256)), dim3(256), 0, h->stream>>>(p, h->P1, h->P2);
+    HIPCHK(h, hipGetLastError());
+    // stage 1: T_t[a] = Py_t (Y x Y) * SC[a] (Y x D1p), batched over the X map rows
+    const long slab = (long)h->Y * h->D1p;
+    for (int t1 = 0; t1 < h->nt; ++t1) {
+        dim3 grid((unsigned)cdiv(h->D1p, LM_BN), (unsigned)cdiv(h->Y, LM_BM), (unsigned)h->X);
+        leftmul_f32_kernel<<<grid, dim3(256), 0, h->stream>>>(h->P1 + (long)t1 * h->Y * h->Y, h->Y, h->Y, h->SC, slab,
+                                                             h->T + (long)t1 * h->X * slab, slab, h->D1p);
+    }
+    // stage 2: ACC = [Px_0 | Px_1 ...] (X x nt*X) * T (nt*X x Y*D1p)
+    {
+        dim3 grid((unsigned)cdiv(slab, LM_BN), (unsigned)cdiv(h->X, LM_BM), 1);
+        leftmul_f32_kernel<<<grid, dim3(256), 0, h->stream>>>(h->P2, h->X, h->nt * h->X, h->T, 0, h->ACC, 0, slab);
+    }
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int ensure_query_scratch(som_handle* h, long n) {
+    if (n <= h->qcap) return 0;
+    long cap = round_up(n, 1024);
+    (void)hipFree(h->qX); (void)hipFree(h->qbmu); (void)hipFree(h->qxsq); (void)hipFree(h->qXb); (void)hipFree(h->qxsqh);
+    h->qX = nullptr; h->qbmu = nullptr; h->qxsq = nullptr; h->qXb = nullptr; h->qxsqh = nullptr; h->qcap = 0;
+    if (int rc = dev_alloc(h, &h->qX, (size_t)cap * h->D)) return rc;
+    if (int rc = dev_alloc(h, &h->qbmu, (size_t)cap)) return rc;
+    if (int rc = dev_alloc(h, &h->qxsq, (size_t)cap)) return rc;
+    if (h->cfg.precision == SOM_PREC_BF16) {
+        long capp = round_up(cap, BF_WG_SAMPLES);
+        if (int rc = dev_alloc(h, &h->qXb, (size_t)capp * 16 * h->ksteps)) return rc;
+        if (int rc = dev_alloc(h, &h->qxsqh, (size_t)capp)) return rc;
+    }
+    h->qcap = cap;
+    return 0;
+}
+
+}  // namespace
+
+// ==============================================================================================
+extern "C" {
+
+const char* som_version(void) { return "somhip 0.1 (gfx950)"; }
+
+int som_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* som_last_error(const som_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int som_create(const som_config* cfg, som_handle** out) {
+    if (!out) return fail(nullptr, "som_create: out is NULL");
+    *out = nullptr;
+    if (!cfg) return fail(nullptr, "som_create: cfg is NULL");
+    if (cfg->x < 1 || cfg->y < 1 || cfg->input_len < 1) return fail(nullptr, "som_create: x, y, input_len must be >= 1");
+    if ((long)cfg->x * cfg->y > (1L << 30)) return fail(nullptr, "som_create: map too large");
+    if (cfg->distance < 0 || cfg->distance > SOM_DIST_COSINE) return fail(nullptr, "som_create: unknown distance id");
+    if (cfg->neighborhood < 0 || cfg->neighborhood > SOM_NEIGH_TRIANGLE)
+        return fail(nullptr, "som_create: unknown neighbourhood id");
+    if (cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT && cfg->compact_support)
+        return fail(nullptr, "som_create: mexican_hat with compact_support is not separable (reference bug "
+                             "neighborhoods.py:69-71) and is not supported");
+    if (cfg->precision != SOM_PREC_F32 && cfg->precision != SOM_PREC_BF16)
+        return fail(nullptr, "som_create: unknown precision id");
+    if (cfg->precision == SOM_PREC_BF16) {
+        if (cfg->distance != SOM_DIST_EUCLIDEAN)
+            return fail(nullptr, "som_create: bf16 precision implements the 'euclidean' distance only");
+        if (cfg->input_len > 128) return fail(nullptr, "som_create: bf16 precision supports input_len <= 128");
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) return fail(nullptr, "som_create: no HIP device available");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, "som_create: device ordinal out of range");
+
+    som_handle* h = new som_handle();
+    h->cfg = *cfg;
+    h->X = cfg->x; h->Y = cfg->y; h->K = cfg->x * cfg->y; h->D = cfg->input_len;
+    h->D1p = (int)round_up(h->D + 1, 4);
+    h->ksteps = (int)cdiv(h->D, 16);
+    h->nt = cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT ? 2 : 1;
+    int rc = 0;
+    auto bail = [&](int code) { g_create_error = h->err; som_destroy(h); return code; };
+    if (hipSetDevice(cfg->device) != hipSuccess) return bail(fail(h, "hipSetDevice failed"));
+    if (cfg->stream) { h->stream = (hipStream_t)cfg->stream; }
+    else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
+            return bail(fail(h, "hipStreamCreate failed"));
+        h->own_stream = true;
+    }
+    const size_t KD1 = (size_t)h->K * h->D1p;
+    if ((rc = dev_alloc(h, &h->W, (size_t)h->K * h->D))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->wsq, (size_t)h->K))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->SC, KD1))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->T, KD1 * h->nt))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->ACC, KD1))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->P1, (size_t)h->nt * h->Y * h->Y))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->P2, (size_t)h->X * h->nt * h->X))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->dsum, 1))) return bail(rc);
+    if (hipMemsetAsync(h->W, 0, (size_t)h->K * h->D * sizeof(float), h->stream) != hipSuccess ||
+        hipMemsetAsync(h->ACC, 0, KD1 * sizeof(float), h->stream) != hipSuccess)
+        return bail(fail(h, "hipMemsetAsync failed"));
+    if (cfg->precision == SOM_PREC_BF16) {
+        h->n_stages = (int)cdiv(h->K, BF_STAGE_UNITS);
+        size_t bytes = (size_t)h->n_stages * bf_stage_bytes(h->ksteps);
+        if ((rc = dev_alloc(h, &h->Wst, bytes))) return bail(rc);
+        if (hipMemsetAsync(h->Wst, 0, bytes, h->stream) != hipSuccess) return bail(fail(h, "hipMemsetAsync failed"));
+    }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(fail(h, "hipStreamSynchronize failed"));
+    *out = h;
+    return 0;
+}
+
+void som_destroy(som_handle* h) {
+    if (!h) return;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    for (auto& ep : h->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    void* bufs[] = {h->W, h->wsq, h->SC, h->T, h->ACC, h->P1, h->P2, h->Wst, h->X_owned, h->bmu, h->xsq, h->Xb,
+                    h->xsqh, h->qX, h->qbmu, h->qxsq, h->qXb, h->qxsqh, h->dsum};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int som_set_weights(som_handle* h, const float* w_host) {
+    if (!h || !w_host) return fail(h, "som_set_weights: NULL argument");
+    HIPCHK(h, hipMemcpyAsync(h->W, w_host, (size_t)h->K * h->D * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->w_dirty = true;
+    return 0;
+}
+
+int som_get_weights(som_handle* h, float* w_host) {
+    if (!h || !w_host) return fail(h, "som_get_weights: NULL argument");
+    HIPCHK(h, hipMemcpyAsync(w_host, h->W, (size_t)h->K * h->D * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static int adopt_rows(som_handle* h, int64_t n_rows) {
+    (void)hipFree(h->bmu); (void)hipFree(h->xsq); (void)hipFree(h->Xb); (void)hipFree(h->xsqh);
+    h->bmu = nullptr; h->xsq = nullptr; h->Xb = nullptr; h->xsqh = nullptr;
+    h->N = n_rows;
+    h->Np = round_up(n_rows, BF_WG_SAMPLES);
+    if (int rc = dev_alloc(h, &h->bmu, (size_t)n_rows)) return rc;
+    if (needs_xsq(h)) {
+        if (int rc = dev_alloc(h, &h->xsq, (size_t)n_rows)) return rc;
+        if (int rc = row_sq(h, h->Xd, n_rows, h->xsq)) return rc;
+    }
+    if (h->cfg.precision == SOM_PREC_BF16 && n_rows > 0) {
+        if (int rc = dev_alloc(h, &h->Xb, (size_t)h->Np * 16 * h->ksteps)) return rc;
+        if (int rc = dev_alloc(h, &h->xsqh, (size_t)h->Np)) return rc;
+        if (int rc = prep_rows_bf16(h, h->Xd, n_rows, h->Np, h->Xb, h->xsqh)) return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int som_set_data(som_handle* h, const float* x_host, int64_t n_rows) {
+    if (!h || n_rows < 0 || (!x_host && n_rows > 0)) return fail(h, "som_set_data: bad argument");
+    (void)hipFree(h->X_owned);
+    h->X_owned = nullptr; h->Xd = nullptr;
+    if (int rc = dev_alloc(h, &h->X_owned, (size_t)n_rows * h->D)) return rc;
+    if (n_rows > 0)
+        HIPCHK(h, hipMemcpyAsync(h->X_owned, x_host, (size_t)n_rows * h->D * sizeof(float), hipMemcpyHostToDevice,
+                                 h->stream));
+    h->Xd = h->X_owned;
+    return adopt_rows(h, n_rows);
+}
+
+int som_set_data_device(som_handle* h, const void* x_dev, int64_t n_rows) {
+    if (!h || n_rows < 0 || (!x_dev && n_rows > 0)) return fail(h, "som_set_data_device: bad argument");
+    (void)hipFree(h->X_owned);
+    h->X_owned = nullptr;
+    h->Xd = (const float*)x_dev;
+    return adopt_rows(h, n_rows);
+}
+
+int som_epoch_accumulate(som_handle* h, double sigma, double eta, int neigh_f64) {
+    if (!h) return 1;
+    if (!h->Xd && h->N > 0) return fail(h, "som_epoch_accumulate: no resident data (call som_set_data)");
+    if (int rc = run_activation_bmu(h, h->Xd, h->N, h->xsq, h->Xb, h->xsqh, h->bmu)) return rc;
+    return run_update(h, sigma, eta, neigh_f64);
+}
+
+int som_epoch_accumulate_forced(som_handle* h, const int32_t* bmu_host, double sigma, double eta, int neigh_f64) {
+    if (!h || (!bmu_host && h->N > 0)) return fail(h, "som_epoch_accumulate_forced: bad argument");
+    for (long i = 0; i < h->N; ++i)
+        if (bmu_host[i] < 0 || bmu_host[i] >= h->K) return fail(h, "som_epoch_accumulate_forced: id out of range");
+    if (h->N > 0)
+        HIPCHK(h, hipMemcpyAsync(h->bmu, bmu_host, (size_t)h->N * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    return run_update(h, sigma, eta, neigh_f64);
+}
+
+int som_epoch_merge(som_handle* h) {
+    if (!h) return 1;
+    Timed t(h, SOM_K_MERGE);
+    long total = (long)h->K * h->D;
+    merge_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p);
+    HIPCHK(h, hipGetLastError());
+    h->w_dirty = true;
+    return 0;
+}
+
+int som_epoch(som_handle* h, double sigma, double eta, int neigh_f64) {
+    if (int rc = som_epoch_accumulate(h, sigma, eta, neigh_f64)) return rc;
+    return som_epoch_merge(h);
+}
+
+int som_accum_device_ptr(som_handle* h, void** dev_ptr, int64_t* n_floats) {
+    if (!h || !dev_ptr || !n_floats) return fail(h, "som_accum_device_ptr: NULL argument");
+    *dev_ptr = h->ACC;
+    *n_floats = (int64_t)h->K * h->D1p;
+    return 0;
+}
+
+int som_epoch_fetch(som_handle* h, float* num, float* den, int32_t* bmu) {
+    if (!h) return 1;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (num || den) {
+        std::vector<float> acc((size_t)h->K * h->D1p);
+        HIPCHK(h, hipMemcpy(acc.data(), h->ACC, acc.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (long k = 0; k < h->K; ++k) {
+            if (num) std::memcpy(num + k * h->D, acc.data() + k * h->D1p, (size_t)h->D * sizeof(float));
+            if (den) den[k] = acc[k * h->D1p + h->D];
+        }
+    }
+    if (bmu && h->N > 0) HIPCHK(h, hipMemcpy(bmu, h->bmu, (size_t)h->N * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, int32_t* ids_out) {
+    if (!h || n_rows < 0 || (n_rows > 0 && (!x_host || !ids_out))) return fail(h, "som_bmu: bad argument");
+    if (mode != SOM_BMU_ACTIVATION && mode != SOM_BMU_QUANTIZATION) return fail(h, "som_bmu: unknown mode");
+    if (n_rows == 0) return 0;
+    if (int rc = ensure_query_scratch(h, n_rows)) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->qX, x_host, (size_t)n_rows * h->D * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (mode == SOM_BMU_QUANTIZATION) {
+        if (int rc = refresh_codebook_operands(h)) return rc;
+        if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
+        Timed t(h, SOM_K_BMU);
+        if (int rc = launch_bmu_f32<SCORE_EUCLID_SQRT>(h, h->qX, n_rows, h->qxsq, h->qbmu)) return rc;
+    } else {
+        if (needs_xsq(h)) if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
+        if (h->cfg.precision == SOM_PREC_BF16)
+            if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, BF_WG_SAMPLES), h->qXb, h->qxsqh)) return rc;
+        if (int rc = run_activation_bmu(h, h->qX, n_rows, h->qxsq, h->qXb, h->qxsqh, h->qbmu)) return rc;
+    }
+    HIPCHK(h, hipMemcpyAsync(ids_out, h->qbmu, (size_t)n_rows * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, double* qe_out) {
+    if (!h || !qe_out || n_rows < 0 || (n_rows > 0 && !x_host)) return fail(h, "som_quantization_error: bad argument");
+    if (n_rows == 0) { *qe_out = NAN; return 0; }     // numpy: mean of an empty array
+    if (int rc = ensure_query_scratch(h, n_rows)) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->qX, x_host, (size_t)n_rows * h->D * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (int rc = refresh_codebook_operands(h)) return rc;
+    if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
+    if (int rc = launch_bmu_f32<SCORE_EUCLID_SQRT>(h, h->qX, n_rows, h->qxsq, h->qbmu)) return rc;
+    HIPCHK(h, hipMemsetAsync(h->dsum, 0, sizeof(double), h->stream));
+    qe_kernel<<<dim3((unsigned)cdiv(n_rows, 4)), dim3(256), 0, h->stream>>>(h->qX, h->qbmu, h->W, n_rows, h->D, h->dsum);
+    HIPCHK(h, hipGetLastError());
+    double s = 0.0;
+    HIPCHK(h, hipMemcpyAsync(&s, h->dsum, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *qe_out = s / (double)n_rows;
+    return 0;
+}
+
+int som_sync(som_handle* h) {
+    if (!h) return 1;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int som_profile_enable(som_handle* h, int32_t on) {
+    if (!h) return 1;
+    if (!on) if (int rc = resolve_profile(h)) return rc;
+    h->prof = on != 0;
+    return 0;
+}
+
+int som_profile_get(som_handle* h, int32_t kernel, double* total_ms, int64_t* launches) {
+    if (!h || kernel < 0 || kernel >= SOM_K_COUNT) return fail(h, "som_profile_get: bad argument");
+    if (int rc = resolve_profile(h)) return rc;
+    if (total_ms) *total_ms = h->ms[kernel];
+    if (launches) *launches = h->launches[kernel];
+    return 0;
+}
+
+int som_profile_reset(som_handle* h) {
+    if (!h) return 1;
+    if (int rc = resolve_profile(h)) return rc;
+    for (int i = 0; i < SOM_K_COUNT; ++i) { h->ms[i] = 0; h->launches[i] = 0; }
+    return 0;
+}
+
+}  // extern "C"

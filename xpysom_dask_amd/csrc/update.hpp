@@ -1,0 +1,189 @@
+// The update half of XPySom._update / _merge_updates (xpysom.py:420-455), restructured.
+//
+// The reference materialises g[n,i,j] = h(bmu_n -> (i,j)) * eta for every sample and
+// multiplies g^T (K x n) by x (n x D).  h depends on n only through bmu_n, and on the
+// rectangular topology every neighbourhood of neighborhoods.py is a short sum of
+// products of a function of the row offset and a function of the column offset:
+//     g[n,i,j] = sum_t  Px_t[i, ci_n] * Py_t[j, cj_n]
+//   gaussian     (:14-33)   t=1 : ex * ey                      ex = exp(-(i-a)^2/d) [* box mask]
+//   mexican_hat  (:57-74)   t=2 : ex(1-2px/d) * ey  -  ex * (2py/d)ey
+//   bubble       (:99-112)  t=1 : box * box
+//   triangle     (:114-130) t=1 : tri * tri
+// Hence, exactly (only the float summation order differs):
+//     S[b,:] = sum_{n: bmu_n = b} x_n,  c[b] = #{n: bmu_n = b}          (segment sum, HBM/atomic bound)
+//     [num|den](i,j,:) = sum_t sum_a Px_t[i,a] sum_b Py_t[j,b] [S|c](a,b,:)   (two small exact-f32 MFMA GEMMs)
+// which replaces the 2*N*K*D-flop GEMM of xpysom.py:437-438 by 2*K*(X+Y)*(D+1) flops.
+#pragma once
+#include "som_common.hpp"
+
+namespace somhip {
+
+// ---- segment sum: SC[bmu[n]][0..D-1] += x_n ; SC[bmu[n]][D] += 1 ------------------------------
+// One thread per (sample, feature): a wave-instruction adds 256 contiguous bytes of one or a
+// few accumulator rows (the shape global_atomic_add_f32 runs at full rate with).
+__global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ X, const int* __restrict__ bmu,
+                                                     long N, int D, int D1p, float* __restrict__ SC) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int D1 = D + 1;
+    if (i >= N * D1) return;
+    long n = i / D1;
+    int d = (int)(i - n * D1);
+    float v = d < D ? X[n * D + d] : 1.0f;
+    unsafeAtomicAdd(&SC[(long)bmu[n] * D1p + d], v);
+}
+
+// ---- neighbourhood factor tables ---------------------------------------------------------------
+// P1: stage-1 matrices  [nt][Y][Y]   (Py_t[j][b])
+// P2: stage-2 matrix    [X][nt*X]    (Px_t[i][a] at column t*X + a), carries eta.
+// wide != 0: float64 evaluation rounded once to float32 (NumPy >= 2 with a numpy.float64 sigma);
+// wide == 0: mimic the float32 evaluation: the exponent argument is rounded to float32
+// (the dominant error term) before a correctly rounded exp.
+struct NeighParams {
+    double sigma, eta, d;   // d = 2*std_coeff^2*sigma^2 (host, double)
+    int kind, compact, wide, X, Y, nt;
+};
+
+__device__ __forceinline__ double neigh_exp(double delta2, const NeighParams& p) {
+    if (p.wide) return exp(-delta2 / p.d);
+    float a = -(float)delta2 / (float)p.d;
+    return (double)(float)exp((double)a);
+}
+__device__ __forceinline__ double neigh_box(int i, int a, const NeighParams& p) {
+    return ((double)i > (double)a - p.sigma && (double)i < (double)a + p.sigma) ? 1.0 : 0.0;
+}
+__device__ __forceinline__ double neigh_round(double v, const NeighParams& p) { return p.wide ? v : (double)(float)v; }
+
+// value of factor `which` (0 = row factor Px, 1 = column factor Py) of term t at (i, a)
+__device__ double neigh_factor(int which, int t, int i, int a, const NeighParams& p) {
+    const double dl = (double)(i - a);
+    const double d2 = dl * dl;
+    switch (p.kind) {
+    case 0: {   // gaussian
+        double e = neigh_exp(d2, p);
+        if (p.compact) e *= neigh_box(i, a, p);
+        return e;
+    }
+    case 1: {   // mexican hat: (ex(1-2px/d)) * ey  -  ex * ((2py/d) ey)
+        double e = neigh_exp(d2, p);
+        double q = p.wide ? (2.0 / p.d) * d2 : (double)((float)(2.0 / p.d) * (float)d2);
+        if (t == 0) return which == 0 ? neigh_round(e * (1.0 - q), p) : e;
+        return which == 0 ? -e : neigh_round(q * e, p);
+    }
+    case 2:     // bubble
+        return neigh_box(i, a, p);
+    default: {  // triangle
+        double v = p.sigma - fabs(dl);
+        if (v < 0.0) v = 0.0;
+        if (p.compact) v *= neigh_box(i, a, p);
+        return neigh_round(v, p);
+    }
+    }
+}
+
+__global__ __launch_bounds__(256) void neigh_tables_kernel(NeighParams p, float* __restrict__ P1,
+                                                           float* __restrict__ P2) {
+    long id = (long)blockIdx.x * 256 + threadIdx.x;
+    const long n1 = (long)p.nt * p.Y * p.Y;
+    const long n2 = (long)p.X * p.nt * p.X;
+    if (id < n1) {
+        int b = id % p.Y;
+        long r = id / p.Y;
+        int j = r % p.Y;
+        int t = r / p.Y;
+        P1[id] = (float)neigh_factor(1, t, j, b, p);
+    } else if (id < n1 + n2) {
+        long q = id - n1;
+        int col = q % ((long)p.nt * p.X);
+        int i = q / ((long)p.nt * p.X);
+        int t = col / p.X, a = col % p.X;
+        double v = neigh_factor(0, t, i, a, p);
+        P2[q] = p.wide ? (float)(v * p.eta) : (float)v * (float)p.eta;
+    }
+}
+
+// ---- OUT[b] = H (Ro x Ri) * M[b] (Ri x C), exact float32 on v_mfma_f32_32x32x2_f32 ---------------
+// Workgroup = 4 waves as 2 (rows) x 2 (cols); wave tile 32 x 64; block tile 64 x 128; k chunk 32.
+constexpr int LM_BM = 64, LM_BN = 128, LM_BK = 32;
+
+__global__ __launch_bounds__(256) void leftmul_f32_kernel(const float* __restrict__ H, int Ro, int Ri,
+                                                          const float* __restrict__ M, long m_batch_stride,
+                                                          float* __restrict__ OUT, long o_batch_stride, long C) {
+    __shared__ float Hs[LM_BM][LM_BK + 1];
+    __shared__ float Ms[LM_BK][LM_BN + 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int wr = wave >> 1, wc = wave & 1;
+    const long c0 = (long)blockIdx.x * LM_BN;
+    const int i0 = blockIdx.y * LM_BM;
+    const float* Mb = M + (long)blockIdx.z * m_batch_stride;
+    float* Ob = OUT + (long)blockIdx.z * o_batch_stride;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    for (int r0 = 0; r0 < Ri; r0 += LM_BK) {
+        __syncthreads();
+        for (int idx = tid; idx < LM_BM * LM_BK; idx += 256) {
+            int i = idx >> 5, k = idx & 31;
+            Hs[i][k] = (i0 + i < Ro && r0 + k < Ri) ? H[(long)(i0 + i) * Ri + r0 + k] : 0.0f;
+        }
+        for (int idx = tid; idx < LM_BK * LM_BN; idx += 256) {
+            int k = idx >> 7, c = idx & 127;
+            Ms[k][c] = (r0 + k < Ri && c0 + c < C) ? Mb[(long)(r0 + k) * C + c0 + c] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LM_BK; k += 2) {
+            float a = Hs[wr * 32 + col][k + half];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float b = Ms[k + half][wc * 64 + t * 32 + col];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        long c = c0 + wc * 64 + t * 32 + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int i = i0 + wr * 32 + mfma32_row(r, half);
+            if (i < Ro && c < C) Ob[(long)i * C + c] = acc[t][r];
+        }
+    }
+}
+
+// ---- merge: W = where(den != 0, num/den, W)  (xpysom.py:446-455) ---------------------------------
+__global__ __launch_bounds__(256) void merge_kernel(float* __restrict__ W, const float* __restrict__ ACC,
+                                                    long K, int D, int D1p) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= K * D) return;
+    long k = i / D;
+    int d = (int)(i - k * D);
+    float den = ACC[k * D1p + D];
+    if (den != 0.0f) W[i] = ACC[k * D1p + d] / den;
+}
+
+// ---- quantization error: sum_n |x_n - W[bmu_n]|  (xpysom.py:703-705) -----------------------------
+__global__ __launch_bounds__(256) void qe_kernel(const float* __restrict__ X, const int* __restrict__ bmu,
+                                                 const float* __restrict__ W, long N, int D,
+                                                 double* __restrict__ sum_out) {
+    __shared__ double part[4];
+    long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float s = 0.0f;
+    if (row < N) {
+        const float* x = X + row * D;
+        const float* w = W + (long)bmu[row] * D;
+        for (int k = lane; k < D; k += 64) { float df = x[k] - w[k]; s = __builtin_fmaf(df, df, s); }
+    }
+    s = wave_sum(s);
+    if (lane == 0) part[wave] = (row < N) ? (double)__builtin_sqrtf(s) : 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sum_out, part[0] + part[1] + part[2] + part[3]);
+}
+
+}  // namespace somhip

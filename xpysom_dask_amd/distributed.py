@@ -1,0 +1,47 @@
+"""Sample-sharded data parallelism: one process per GPU, one all-reduce per epoch.
+
+Replaces the reference's Dask fan-out / gather-sum (xpysom.py:545-558): every rank holds a
+contiguous shard of the rows resident on its GPU and the full codebook; per epoch each
+rank accumulates its local [numerator | denominator] buffer, ONE all-reduce(sum) over the
+fused float32 buffer (RCCL over xGMI when the backend is 'nccl') makes every rank hold the
+global sums, and every rank applies the identical merge -- no broadcast of the codebook.
+"""
+
+
+def dist_info():
+    """(rank, world_size) of the default process group, or (0, 1) when there is none."""
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return 0, 1
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(n_rows, rank, world):
+    """Contiguous, balanced split (the first n_rows % world ranks get one extra row)."""
+    base, extra = divmod(int(n_rows), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def allreduce_accumulator(engine):
+    """Sum the engine's fused accumulator across ranks, in place."""
+    rank, world = dist_info()
+    if world == 1:
+        return
+    import torch.distributed as dist
+    engine.sync()                      # the engine may run on its own stream
+    t = engine.accum_tensor()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if t.is_cuda:
+        import torch
+        torch.cuda.current_stream(t.device).synchronize()
+
+
+def epoch(engine, sigma, eta, neigh_f64):
+    """One data-parallel epoch on this rank's shard."""
+    engine.epoch_accumulate(sigma, eta, neigh_f64)
+    allreduce_accumulator(engine)
+    engine.epoch_merge()

@@ -1,0 +1,161 @@
+"""Thin object wrapper over the C handle of libsomhip (include/somhip.h).
+
+`HipEngine` is the only thing the host class talks to.  Its method set is the engine
+interface the distributed driver (distributed.py) relies on:
+    set_weights / get_weights / set_data / epoch_accumulate / accum_tensor / epoch_merge
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class SomHipError(RuntimeError):
+    pass
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class HipEngine:
+    def __init__(self, x, y, input_len, *, distance="euclidean", neighborhood="gaussian",
+                 std_coeff=0.5, compact_support=False, precision="f32", device=0, stream=None):
+        self._lib = _lib.load()
+        self._h = None
+        self.K, self.D = int(x) * int(y), int(input_len)
+        self.x, self.y = int(x), int(y)
+        self.n_rows = 0
+        self._keepalive = None
+        cfg = _lib.SomConfig(int(x), int(y), int(input_len), _lib.SOM_DIST[distance],
+                             _lib.SOM_NEIGH[neighborhood], int(bool(compact_support)),
+                             _lib.SOM_PREC[precision], int(device), float(std_coeff),
+                             C.c_void_p(stream) if stream else None)
+        h = C.c_void_p()
+        if self._lib.som_create(C.byref(cfg), C.byref(h)) != 0:
+            raise SomHipError(self._lib.som_last_error(None).decode())
+        self._h = h
+        self.device = int(device)
+        self.precision = precision
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise SomHipError(self._lib.som_last_error(self._h).decode())
+
+    def close(self):
+        if self._h is not None:
+            self._lib.som_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _fp(a):
+        return a.ctypes.data_as(C.POINTER(C.c_float))
+
+    @staticmethod
+    def _ip(a):
+        return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+    # -- codebook / data --------------------------------------------------------------------
+    def set_weights(self, w):
+        w = _f32(w).reshape(self.K, self.D)
+        self._check(self._lib.som_set_weights(self._h, self._fp(w)))
+
+    def get_weights(self):
+        w = np.empty((self.K, self.D), dtype=np.float32)
+        self._check(self._lib.som_get_weights(self._h, self._fp(w)))
+        return w
+
+    def set_data(self, data):
+        data = _f32(data)
+        if data.ndim != 2 or data.shape[1] != self.D:
+            raise ValueError("data must be (n, %d), got %r" % (self.D, data.shape))
+        self._check(self._lib.som_set_data(self._h, self._fp(data), data.shape[0]))
+        self.n_rows = data.shape[0]
+        self._keepalive = None
+
+    def set_data_device(self, dev_ptr, n_rows, keepalive=None):
+        """Rows already resident in HBM (float32 [n][D]); `keepalive` is whatever owns them."""
+        self._check(self._lib.som_set_data_device(self._h, C.c_void_p(dev_ptr), int(n_rows)))
+        self.n_rows = int(n_rows)
+        self._keepalive = keepalive
+
+    # -- one epoch --------------------------------------------------------------------------
+    def epoch_accumulate(self, sigma, eta, neigh_f64):
+        self._check(self._lib.som_epoch_accumulate(self._h, float(sigma), float(eta), int(bool(neigh_f64))))
+
+    def epoch_accumulate_forced(self, bmu, sigma, eta, neigh_f64):
+        bmu = np.ascontiguousarray(bmu, dtype=np.int32)
+        if bmu.shape != (self.n_rows,):
+            raise ValueError("bmu must have one id per resident row")
+        self._check(self._lib.som_epoch_accumulate_forced(self._h, self._ip(bmu), float(sigma), float(eta),
+                                                          int(bool(neigh_f64))))
+
+    def epoch_merge(self):
+        self._check(self._lib.som_epoch_merge(self._h))
+
+    def epoch(self, sigma, eta, neigh_f64):
+        self._check(self._lib.som_epoch(self._h, float(sigma), float(eta), int(bool(neigh_f64))))
+
+    def epoch_fetch(self, want_bmu=True):
+        """(num (K,D), den (K,), bmu (n,) or None) of the last accumulate."""
+        num = np.empty((self.K, self.D), dtype=np.float32)
+        den = np.empty((self.K,), dtype=np.float32)
+        bmu = np.empty((self.n_rows,), dtype=np.int32) if want_bmu else None
+        self._check(self._lib.som_epoch_fetch(self._h, self._fp(num), self._fp(den),
+                                              self._ip(bmu) if want_bmu else None))
+        return num, den, bmu
+
+    def accum_device_ptr(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._check(self._lib.som_accum_device_ptr(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def accum_tensor(self):
+        """The fused [num|den] accumulator as a torch CUDA tensor aliasing the engine's
+        HBM buffer (zero copy) -- what the RCCL all-reduce runs on in place."""
+        import torch
+        ptr, n = self.accum_device_ptr()
+
+        class _Alias:
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False),
+                                        "version": 2, "strides": None}
+        return torch.as_tensor(_Alias(), device=torch.device("cuda", self.device))
+
+    # -- inference --------------------------------------------------------------------------
+    def bmu(self, x, quantization=False):
+        x = _f32(x)
+        if x.ndim != 2 or x.shape[1] != self.D:
+            raise ValueError("x must be (n, %d), got %r" % (self.D, x.shape))
+        ids = np.empty((x.shape[0],), dtype=np.int32)
+        mode = _lib.SOM_BMU_QUANTIZATION if quantization else _lib.SOM_BMU_ACTIVATION
+        self._check(self._lib.som_bmu(self._h, self._fp(x), x.shape[0], mode, self._ip(ids)))
+        return ids
+
+    def quantization_error(self, x):
+        x = _f32(x)
+        out = C.c_double()
+        self._check(self._lib.som_quantization_error(self._h, self._fp(x), x.shape[0], C.byref(out)))
+        return out.value
+
+    # -- timing -----------------------------------------------------------------------------
+    def sync(self):
+        self._check(self._lib.som_sync(self._h))
+
+    def profile_enable(self, on=True):
+        self._check(self._lib.som_profile_enable(self._h, int(bool(on))))
+
+    def profile_reset(self):
+        self._check(self._lib.som_profile_reset(self._h))
+
+    def profile_get(self, kernel):
+        ms, n = C.c_double(), C.c_int64()
+        self._check(self._lib.som_profile_get(self._h, _lib.SOM_KERNELS[kernel], C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,301 @@
+"""XPySom -- the reference's class surface over the MI355X HIP engine.
+
+Drop-in for ``xpysom_dask.XPySom`` (reference xpysom_dask/xpysom.py:72-892) on its hot path:
+``__init__``, ``train``, ``winner``, ``quantization_error`` (+ the thin consumers of those).
+The host keeps what the reference keeps on the host -- argument validation and error
+strings, the seeded default codebook, the sigma/eta schedules, the epoch loop, result
+formatting, pickling -- and hands everything below ``_update``/``_winner``/``_merge_updates``
+to libsomhip through ctypes.  There is no ``xp=`` dispatch and no CPU path: without the HIP
+library (or a GPU) the compute methods raise.
+"""
+from collections import Counter, defaultdict
+from warnings import warn
+
+import numpy as np
+
+from . import distributed as _dist
+from .decays import DECAY_FUNCTIONS
+
+TOPOLOGIES = ("hexagonal", "rectangular")
+# name -> implemented in the HIP engine?   (registry order follows xpysom.py:260-283)
+NEIGHBORHOODS = {"gaussian": True, "mexican_hat": True, "bubble": True, "triangle": True}
+# distances.py:162-170 registry; False = valid reference name the engine does not cover yet
+DISTANCES = {"euclidean": True, "euclidean_no_opt": True, "manhattan": False, "manhattan_no_opt": False,
+             "cosine": True, "norm_p": False, "norm_p_no_opt": False}
+DEFAULT_BATCH_ROWS = 65536
+
+
+class XPySom:
+    def __init__(self, x, y, input_len,
+                 sigma=0, sigmaN=1,
+                 learning_rate=0.5, learning_rateN=0.01, decay_function='exponential',
+                 neighborhood_function='gaussian', std_coeff=0.5,
+                 topology='rectangular',
+                 activation_distance='euclidean',
+                 activation_distance_kwargs={},
+                 random_seed=None, n_parallel=0, compact_support=False,
+                 xp=None,
+                 use_dask=False, dask_chunks='auto',
+                 *, precision='f32', device=None, sharded_input=False, _engine_factory=None):
+        """Same positional/keyword surface as the reference constructor (xpysom.py:73-82).
+
+        ``xp``, ``use_dask`` and ``dask_chunks`` are accepted for source compatibility and
+        ignored: there is one backend (HIP) and multi-GPU runs use torch.distributed, not Dask.
+        Extra keyword-only arguments:
+          precision      'f32' (exact-float32 MFMA, parity mode) or 'bf16' (bf16 MFMA distance GEMM)
+          device         HIP device ordinal (default: LOCAL_RANK or 0)
+          sharded_input  under an initialised process group: ``train(data)`` receives only this
+                         rank's rows (default: every rank passes the full array and takes its slice)
+        """
+        if sigma >= x or sigma >= y:
+            warn('Warning: sigma is too high for the dimension of the map.')
+
+        self._random_generator = np.random.RandomState(random_seed)
+        self.use_dask = False
+        self.dask_chunks = dask_chunks
+
+        self._learning_rate = learning_rate
+        self._learning_rateN = learning_rateN
+        self._sigma = min(x, y) / 2 if sigma == 0 else sigma
+        self._std_coeff = std_coeff
+        self._sigmaN = sigmaN
+        self._input_len = input_len
+
+        # seeded default codebook, float64 on the host exactly as xpysom.py:189-190
+        self._weights = self._random_generator.rand(x, y, input_len) * 2 - 1
+        self._weights /= np.linalg.norm(self._weights, axis=-1, keepdims=True)
+
+        self._neigx = np.arange(x)
+        self._neigy = np.arange(y)
+
+        if topology not in TOPOLOGIES:
+            msg = '%s not supported only hexagonal and rectangular available'
+            raise ValueError(msg % topology)
+        self.topology = topology
+
+        if decay_function not in DECAY_FUNCTIONS:
+            msg = '%s not supported. Functions available: %s'
+            raise ValueError(msg % (decay_function, ', '.join(DECAY_FUNCTIONS.keys())))
+        self._decay_function = DECAY_FUNCTIONS[decay_function]
+        self._decay_function_name = decay_function
+
+        self.compact_support = compact_support
+        available = [n for n in NEIGHBORHOODS if not (topology == 'hexagonal' and n == 'triangle')]
+        if neighborhood_function not in available:
+            msg = '%s not supported. Functions available: %s'
+            raise ValueError(msg % (neighborhood_function, ', '.join(available)))
+        self.neighborhood_func_name = neighborhood_function
+
+        if activation_distance not in DISTANCES:
+            msg = '%s not supported. Distances available: %s'
+            raise ValueError(msg % (activation_distance, ', '.join(DISTANCES.keys())))
+        self._activation_distance_name = activation_distance
+        self._activation_distance_kwargs = activation_distance_kwargs
+
+        if topology == 'hexagonal':
+            raise NotImplementedError('hexagonal topology is not in the HIP engine yet (SURVEY 8(f) rank 2)')
+        if not DISTANCES[activation_distance]:
+            raise NotImplementedError("activation_distance '%s' is not in the HIP engine yet "
+                                      "(SURVEY 8(f) rank 3)" % activation_distance)
+        if precision not in ('f32', 'bf16'):
+            raise ValueError("precision must be 'f32' or 'bf16'")
+
+        # n_parallel bounded the (n,K) temporaries of the reference (xpysom.py:242-251); nothing of
+        # that size exists here, it only sizes host->device staging of winner()/quantization_error().
+        if n_parallel == 0:
+            n_parallel = DEFAULT_BATCH_ROWS
+        self._n_parallel = n_parallel
+
+        self._precision = precision
+        self._device = device
+        self._sharded_input = sharded_input
+        self._engine_factory = _engine_factory
+        self._engine_obj = None
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _engine(self):
+        if self._engine_obj is None:
+            x, y, _ = self._weights.shape
+            kw = dict(distance=self._activation_distance_name, neighborhood=self.neighborhood_func_name,
+                      std_coeff=self._std_coeff, compact_support=self.compact_support,
+                      precision=self._precision)
+            if self._engine_factory is not None:
+                self._engine_obj = self._engine_factory(x, y, self._input_len, **kw)
+            else:
+                from .engine import HipEngine
+                dev = self._device
+                if dev is None:
+                    import os
+                    dev = int(os.environ.get('LOCAL_RANK', '0'))
+                self._engine_obj = HipEngine(x, y, self._input_len, device=dev, **kw)
+        return self._engine_obj
+
+    def _upload_weights(self):
+        eng = self._engine()
+        eng.set_weights(np.asarray(self._weights, dtype=np.float32))
+        return eng
+
+    def get_weights(self):
+        """Returns the weights of the neural network."""
+        return self._weights
+
+    def _check_input_len(self, data):
+        """Checks that the data in input is of the correct shape (xpysom.py:360-366)."""
+        data_len = len(data[0])
+        if self._input_len != data_len:
+            msg = 'Received %d features, expected %d.' % (data_len, self._input_len)
+            raise ValueError(msg)
+
+    # ------------------------------------------------------------------ training
+    def train(self, data, num_epochs, iter_beg=0, iter_end=None, verbose=False):
+        """Trains the SOM (batch algorithm); same contract as xpysom.py:458-594.
+
+        ``iter_beg``/``iter_end`` resume the schedule mid-run (decays are pure functions of
+        (iteration, num_epochs)).  Under an initialised torch.distributed group the rows are
+        sharded contiguously over the ranks and the per-epoch numerator/denominator are
+        all-reduced before the merge.  Returns ``self``; ``_weights`` is float32 afterwards."""
+        if iter_end is None:
+            iter_end = num_epochs
+
+        data = np.asarray(data, dtype=np.float32)
+        if data.ndim != 2:
+            raise ValueError('data must be 2-dimensional (n_samples, input_len)')
+        rank, world = _dist.dist_info()
+        if world > 1 and not self._sharded_input:
+            lo, hi = _dist.shard_bounds(len(data), rank, world)
+            data = data[lo:hi]
+
+        eng = self._upload_weights()
+        eng.set_data(data)
+
+        for iteration in range(iter_beg, iter_end):
+            eta = self._decay_function(self._learning_rate, self._learning_rateN, iteration, num_epochs)
+            # sigma and learning rate decrease with the same rule
+            sig = self._decay_function(self._sigma, self._sigmaN, iteration, num_epochs)
+            # NumPy >= 2: a numpy scalar sigma makes the reference's neighbourhood float64
+            neigh_f64 = isinstance(sig, np.generic)
+            _dist.epoch(eng, sig, eta, neigh_f64)
+            if verbose:
+                print('\r [ %d / %d ] %3.0f%%' % (iteration + 1, num_epochs, 100 * (iteration + 1) / num_epochs),
+                      end='')
+
+        self._weights = eng.get_weights().reshape(self._weights.shape)
+
+        if verbose:
+            print('\n quantization error:', self.quantization_error(data))
+        return self
+
+    def train_batch(self, data, num_iteration, verbose=False):
+        """Compatibility with MiniSom, alias for train"""
+        return self.train(data, num_iteration, verbose=verbose)
+
+    def train_random(self, data, num_iteration, verbose=False):
+        """Compatibility with MiniSom, alias for train"""
+        print("WARNING: due to batch SOM algorithm, random order is not supported. Falling back to train_batch.")
+        return self.train(data, num_iteration, verbose=verbose)
+
+    # ------------------------------------------------------------------ inference
+    def _winner_ids(self, x2d, quantization=False):
+        eng = self._upload_weights()
+        out = [eng.bmu(x2d[s:s + self._n_parallel], quantization=quantization)
+               for s in range(0, len(x2d), self._n_parallel)]
+        return np.concatenate(out) if out else np.zeros(0, dtype=np.int32)
+
+    def winner(self, x):
+        """Coordinates of the winning neuron(s): ``(i, j)`` for one sample, a list of
+        ``(i, j)`` tuples (numpy.int64) for a matrix -- xpysom.py:370-408."""
+        x = np.asarray(x, dtype=np.float32)
+        one = x.ndim == 1
+        if one:
+            x = x[None, :]
+        ids = self._winner_ids(x).astype(np.int64)
+        wi, wj = np.divmod(ids, self._weights.shape[1])
+        if one:
+            return (wi[0].item(), wj[0].item())
+        return list(map(tuple, np.vstack([wi, wj]).T))
+
+    def quantization(self, data):
+        """Assigns a code book (weights vector of the winning neuron) to each sample in data."""
+        self._check_input_len(data)
+        data = np.asarray(data, dtype=np.float32)
+        ids = self._winner_ids(data, quantization=True)
+        w = np.asarray(self._weights)
+        return w.reshape(-1, w.shape[2])[ids]
+
+    def quantization_error(self, data):
+        """Average distance between each input sample and its best matching unit
+        (always Euclidean, xpysom.py:673-707).  Returns a Python float."""
+        self._check_input_len(data)
+        data = np.asarray(data, dtype=np.float32)
+        eng = self._upload_weights()
+        total, n = 0.0, 0
+        for s in range(0, len(data), self._n_parallel):
+            chunk = data[s:s + self._n_parallel]
+            total += eng.quantization_error(chunk) * len(chunk)
+            n += len(chunk)
+        return total / n if n else float('nan')
+
+    def predict(self, data):
+        """Raveled BMU index of every sample (xpysom.py:608-617), batched."""
+        data = np.asarray(data, dtype=np.float32)
+        return self._winner_ids(data).astype(np.int64)
+
+    def activation_response(self, data):
+        """Matrix where element i,j is the number of times neuron i,j won (xpysom.py:819-829)."""
+        self._check_input_len(data)
+        a = np.zeros(self._weights.shape[:2])
+        ids = self._winner_ids(np.asarray(data, dtype=np.float32))
+        np.add.at(a.reshape(-1), ids, 1)
+        return a
+
+    def win_map(self, data):
+        """Dictionary wm where wm[(i,j)] lists the patterns mapped to i,j (xpysom.py:831-840)."""
+        self._check_input_len(data)
+        winmap = defaultdict(list)
+        for x, win in zip(data, self.winner(data)):
+            winmap[win].append(x)
+        return winmap
+
+    def labels_map(self, data, labels):
+        """Dictionary wm where wm[(i,j)] counts the labels mapped to i,j (xpysom.py:842-865)."""
+        self._check_input_len(data)
+        if not len(data) == len(labels):
+            raise ValueError('data and labels must have the same length.')
+        winmap = defaultdict(list)
+        for win, lab in zip(self.winner(data), labels):
+            winmap[win].append(lab)
+        for position in winmap:
+            winmap[position] = Counter(winmap[position])
+        return winmap
+
+    # ------------------------------------------------------------------ host-side initialisers
+    def random_weights_init(self, data):
+        """Initializes the weights picking random samples from data (xpysom.py:749-759)."""
+        self._check_input_len(data)
+        x, y, _ = self._weights.shape
+        for i in range(x):
+            for j in range(y):
+                self._weights[i, j] = data[self._random_generator.randint(len(data))]
+
+    def pca_weights_init(self, data):
+        """Initializes the weights to span the first two principal components (xpysom.py:762-785)."""
+        if self._input_len == 1:
+            raise ValueError('The data needs at least 2 features for pca initialization')
+        self._check_input_len(data)
+        if len(self._neigx) == 1 or len(self._neigy) == 1:
+            warn('PCA initialization inappropriate:One of the dimensions of the map is 1.')
+        pc_length, pc = np.linalg.eig(np.cov(np.transpose(data)))
+        order = np.argsort(-pc_length)
+        for i, c1 in enumerate(np.linspace(-1, 1, len(self._neigx))):
+            for j, c2 in enumerate(np.linspace(-1, 1, len(self._neigy))):
+                self._weights[i, j] = c1 * pc[order[0]] + c2 * pc[order[1]]
+
+    # ------------------------------------------------------------------ pickling (xpysom.py:868-892)
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state['_engine_obj'] = None          # device handle: rebuilt lazily from (config, weights)
+        state['_engine_factory'] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
