@@ -206,8 +206,18 @@ def g6():
                 som.pca_weights_init(z)
             out[f"{decay}_{init}_w0"] = np.array(som._weights, dtype=np.float64)
             out[f"{decay}_{init}_qe0"] = np.float64(som.quantization_error(z))
-            with np.errstate(all="ignore"):
-                som.train(z, 100)
+            if init == "random":
+                # exact ties in the data make this run chaotic beyond float32 noise (hard
+                # part 1): record the whole trajectory so parity can be checked one epoch at a time
+                traj = []
+                for t in range(100):
+                    with np.errstate(all="ignore"):
+                        som.train(z, 100, iter_beg=t, iter_end=t + 1)
+                    traj.append(som._weights.astype(F32))
+                out[f"{decay}_{init}_traj"] = np.stack(traj)
+            else:
+                with np.errstate(all="ignore"):
+                    som.train(z, 100)
             out[f"{decay}_{init}_w"] = som._weights.astype(F32)
             out[f"{decay}_{init}_bmu"] = ref_winner_ids(som, z)
             out[f"{decay}_{init}_qe"] = np.float64(som.quantization_error(z))

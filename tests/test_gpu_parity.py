@@ -139,15 +139,37 @@ def test_g7_shard_partials_add_up(decay):
 
 # ----------------------------------------------------------------------------- G6 end to end
 @pytest.mark.parametrize("decay", ["linear", "exponential"])
-@pytest.mark.parametrize("init", ["default", "random", "pca"])
+def test_g6_iris_random_init_trajectory(decay):
+    """random_weights_init copies data rows into the codebook; iris has exact distance ties, so
+    the 100-epoch run is chaotic beyond float32 noise.  Parity is checked the well-posed way:
+    every epoch teacher-forced from the reference's own codebook (iter_beg=t, iter_end=t+1)."""
+    from xpysom_dask_amd import XPySom
+    g = load_golden("g6_iris")
+    z = g["iris_z"]
+    traj = g[f"{decay}_random_traj"]
+    som = XPySom(6, 6, 4, random_seed=10, decay_function=decay)
+    som.random_weights_init(z)
+    np.testing.assert_array_equal(som._weights, g[f"{decay}_random_w0"])
+    prev = g[f"{decay}_random_w0"]
+    worst = 0.0
+    for t in range(100):
+        som._weights = np.array(prev)
+        som.train(z, 100, iter_beg=t, iter_end=t + 1)
+        worst = max(worst, rel_err(som._weights, traj[t]))
+        prev = traj[t]
+    assert worst < 1e-5, worst
+    ids = np.array([i * 6 + j for i, j in som.winner(z)])
+    assert np.array_equal(ids, g[f"{decay}_random_bmu"])
+
+
+@pytest.mark.parametrize("decay", ["linear", "exponential"])
+@pytest.mark.parametrize("init", ["default", "pca"])
 def test_g6_iris_end_to_end(decay, init):
     from xpysom_dask_amd import XPySom
     g = load_golden("g6_iris")
     z = g["iris_z"]
     som = XPySom(6, 6, 4, random_seed=10, decay_function=decay)
-    if init == "random":
-        som.random_weights_init(z)
-    elif init == "pca":
+    if init == "pca":
         som.pca_weights_init(z)
     np.testing.assert_array_equal(som._weights, g[f"{decay}_{init}_w0"])     # host init bit-exact
     assert abs(som.quantization_error(z) - float(g[f"{decay}_{init}_qe0"])) < 1e-5

@@ -132,18 +132,43 @@ __global__ __launch_bounds__(256) void bmu_f32_kernel(const float* __restrict__ 
     if (half == 0 && my_sample < N) out[my_sample] = bidx;
 }
 
-// sum of squares of each row, float32, one wave per row (lanes stride the features).
-// Stands in for xp.power(a, 2).sum(axis=1): xpysom.py:529-537 (w_sq), distances.py:30,53 (x_sq).
+// sum of squares of each row, float32: xp.power(a, 2).sum(axis=1) -- xpysom.py:529-537 (w_sq),
+// distances.py:30,53 (x_sq).  The squares are rounded to float32 first and then added in
+// NumPy's pairwise order (n < 8 sequential; n <= 128 eight strided accumulators joined as a
+// tree plus a sequential tail; larger n split in halves), so the result is bit-identical to
+// NumPy's and, with the k-ordered fma chain of the MFMA (== OpenBLAS' sgemm micro-kernel for
+// one K block), so is every distance and therefore every BMU, near-ties included.
+// __fmul_rn/__fadd_rn keep hipcc from contracting the square into the add.
+__device__ float np_pairwise_sq_sum(const float* __restrict__ a, int n) {
+    if (n < 8) {
+        float res = 0.0f;
+        for (int i = 0; i < n; ++i) res = __fadd_rn(res, __fmul_rn(a[i], a[i]));
+        return res;
+    }
+    if (n <= 128) {
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = __fmul_rn(a[j], a[j]);
+        int i = 8;
+        for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], __fmul_rn(a[i + j], a[i + j]));
+        }
+        float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                              __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+        for (; i < n; ++i) res = __fadd_rn(res, __fmul_rn(a[i], a[i]));
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return __fadd_rn(np_pairwise_sq_sum(a, n2), np_pairwise_sq_sum(a + n2, n - n2));
+}
+
 __global__ __launch_bounds__(256) void row_sq_f32_kernel(const float* __restrict__ A, long rows, int D,
                                                          float* __restrict__ out) {
-    long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
+    long row = (long)blockIdx.x * 256 + threadIdx.x;
     if (row >= rows) return;
-    const float* a = A + row * (long)D;
-    float s = 0.0f;
-    for (int k = lane; k < D; k += 64) s = __builtin_fmaf(a[k], a[k], s);
-    s = wave_sum(s);
-    if (lane == 0) out[row] = s;
+    out[row] = np_pairwise_sq_sum(A + row * (long)D, D);
 }
 
 }  // namespace somhip

@@ -129,7 +129,7 @@ void launch_prep_w(som_handle* h) {
 int refresh_codebook_operands(som_handle* h) {
     if (!h->w_dirty) return 0;
     Timed t(h, SOM_K_PREP);
-    row_sq_f32_kernel<<<dim3((unsigned)cdiv(h->K, 4)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->wsq);
+    row_sq_f32_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->wsq);
     if (h->cfg.precision == SOM_PREC_BF16) {
         switch (h->ksteps) {
         case 1: launch_prep_w<1>(h); break;
@@ -225,7 +225,7 @@ bool needs_xsq(const som_handle* h) {
 
 int row_sq(som_handle* h, const float* X, long N, float* out) {
     if (N == 0) return 0;
-    row_sq_f32_kernel<<<dim3((unsigned)cdiv(N, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, out);
+    row_sq_f32_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(X, N, h->D, out);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
