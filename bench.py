@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Headline benchmark: samples/sec/epoch of the batch-SOM hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2]/[3]): 256x256 map, 128 features, 1,048,576 synthetic
+Gaussian-blob rows PER GPU resident in HBM, bf16 MFMA distance GEMM, default schedule.
+A step = one full epoch over the resident rows: codebook prep, fused distance+BMU, segment
+sum, separable neighbourhood transform, (N > 1: one RCCL all-reduce of the fused
+numerator|denominator buffer), merge.  Weak scaling: rows per GPU are fixed.
+
+One JSON line on rank 0: the driver's contract fields + `roofline` (dominant kernel = the
+fused distance+BMU kernel, MFMA-bound, hipEvent-timed inside the timed region) +
+`cpu_baseline` (the NumPy port of the reference path, timed on this host's cores, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+MAP_X, MAP_Y, FEATURES = 256, 256, 128
+ROWS_PER_GPU = 1 << 20
+MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(rows=8192):
+    """The oracle (NumPy port of xpysom.py:515-577, float64 neighbourhood as with the default
+    'exponential' decay) on a truncated epoch of the same workload; throughput is N-independent
+    once rows >> n_parallel would be reached, so samples/s transfers."""
+    from oracle import som_oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        from threadpoolctl import threadpool_info
+        th = [p.get("num_threads") for p in threadpool_info() if p.get("user_api") == "blas"]
+        if th:
+            cores = int(max(th))
+    except Exception:
+        pass
+    data = O.gaussian_blobs(rows, FEATURES, seed=1234)
+    w = O.default_codebook(MAP_X, MAP_Y, FEATURES, 1234).astype(np.float32)
+    n_par = max(1, (os.cpu_count() or 1) * 500)       # the reference's CPU rule, xpysom.py:45,246
+    sig, eta = O.exponential_decay(128.0, 1, 0, 10), O.exponential_decay(0.5, 0.01, 0, 10)
+    t0 = time.perf_counter()
+    O.epoch(data, w, eta, sig, wide=True, n_parallel=n_par)
+    dt = time.perf_counter() - t0
+    return {"value": rows / dt, "unit": "samples/sec/epoch", "cores": cores, "kind": "port",
+            "sample": "%d rows of the same 256x256x128 workload, 1 epoch, n_parallel=%d, NumPy+OpenBLAS, "
+                      "float64 neighbourhood (exponential decay)" % (rows, n_par)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+
+    from xpysom_dask_amd import distributed as D
+    from xpysom_dask_amd.decays import exponential_decay
+    from xpysom_dask_amd.engine import HipEngine
+    from xpysom_dask_amd.synthetic import gaussian_blobs
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    eng = HipEngine(MAP_X, MAP_Y, FEATURES, precision=args.precision, device=local)
+    rs = np.random.RandomState(1234)                  # default codebook init, xpysom.py:189-190
+    w = rs.rand(MAP_X, MAP_Y, FEATURES) * 2 - 1
+    w /= np.linalg.norm(w, axis=-1, keepdims=True)
+    eng.set_weights(w.astype(np.float32))
+    eng.set_data(gaussian_blobs(args.rows, FEATURES, seed=1234 + rank))
+
+    total = args.warmup + args.steps
+    sched = [(exponential_decay(min(MAP_X, MAP_Y) / 2, 1, t, total), exponential_decay(0.5, 0.01, t, total))
+             for t in range(total)]
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for t in range(args.warmup):
+        D.epoch(eng, sched[t][0], sched[t][1], True)
+    fence()
+    eng.profile_reset()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for t in range(args.warmup, total):
+        D.epoch(eng, sched[t][0], sched[t][1], True)
+    fence()
+    dt = time.perf_counter() - t0
+    eng.profile_enable(False)
+
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    bmu_ms, bmu_n = eng.profile_get("bmu")
+    parts = {k: eng.profile_get(k)[0] / max(1, args.steps) for k in ("prep", "bmu", "segsum", "kron", "merge")}
+    w_end = eng.get_weights()
+    assert np.isfinite(w_end).all()
+
+    if rank == 0:
+        ms_step = 1e3 * dt / args.steps
+        flops_launch = 2.0 * args.rows * (MAP_X * MAP_Y) * FEATURES      # 2*K*D per sample
+        achieved = flops_launch / (bmu_ms / max(1, bmu_n) * 1e-3) / 1e12
+        out = {
+            "metric": "samples/sec/epoch", "value": world * args.rows / (dt / args.steps), "unit": "samples/sec/epoch",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "batch-SOM epoch, %dx%d map, %d features, %d Gaussian-blob rows per GPU resident "
+                                   "in HBM (BASELINE configs[2]/[3]), one launch over all resident rows"
+                                   % (MAP_X, MAP_Y, FEATURES, args.rows),
+                       "map": [MAP_X, MAP_Y], "features": FEATURES, "rows_per_gpu": args.rows,
+                       "precision": args.precision, "parallelism": "dp%d (sample shards, 1 all-reduce/epoch)" % world,
+                       "epochs_per_sec": args.steps / dt},
+            "roofline": {"bound": "mfma", "kernel": "bmu_%s_kernel (fused distance GEMM + argmin)" % args.precision,
+                         "achieved": achieved,
+                         "peak": MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else 157.3,
+                         "unit": "TFLOP/s",
+                         "frac": achieved / (MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else 157.3),
+                         "traffic": None, "avg_launch_ms": bmu_ms / max(1, bmu_n), "launches": bmu_n,
+                         "flops_per_launch": flops_launch},
+            "ms_per_step_by_kernel": parts,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
