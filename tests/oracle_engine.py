@@ -1,0 +1,57 @@
+"""An engine with the HipEngine interface backed by the NumPy oracle -- TEST DOUBLE ONLY.
+It lets the CPU suite drive the product's host logic (XPySom.train, shard split,
+all-reduce, merge ordering) under gloo without a GPU.  The product never constructs it."""
+import numpy as np
+
+from oracle import som_oracle as O
+
+
+class OracleEngine:
+    def __init__(self, x, y, input_len, *, distance="euclidean", neighborhood="gaussian",
+                 std_coeff=0.5, compact_support=False, precision="f32"):
+        self.x, self.y, self.D = x, y, input_len
+        self.K = x * y
+        self.kw = dict(distance=distance, neighbourhood=neighborhood, std_coeff=std_coeff, compact=compact_support)
+        self.W = np.zeros((self.K, self.D), np.float32)
+        self.acc = np.zeros((self.K, self.D + 1), np.float32)
+        self.data = np.zeros((0, self.D), np.float32)
+        self.n_rows = 0
+
+    def set_weights(self, w):
+        self.W = np.array(w, dtype=np.float32).reshape(self.K, self.D)
+
+    def get_weights(self):
+        return self.W.copy()
+
+    def set_data(self, data):
+        self.data = np.ascontiguousarray(data, dtype=np.float32)
+        self.n_rows = len(self.data)
+
+    def epoch_accumulate(self, sigma, eta, neigh_f64):
+        self.acc[:] = 0
+        if self.n_rows:
+            W3 = self.W.reshape(self.x, self.y, self.D)
+            _, num, den = O.update(self.data, W3, eta, sigma, wide=bool(neigh_f64), **self.kw)
+            self.acc[:, :self.D] = num.reshape(self.K, self.D)
+            self.acc[:, self.D] = den.reshape(self.K)
+
+    def accum_tensor(self):
+        import torch
+        return torch.from_numpy(self.acc.reshape(-1))
+
+    def epoch_merge(self):
+        den = self.acc[:, self.D:self.D + 1]
+        with np.errstate(all="ignore"):
+            self.W = np.where(den != 0, self.acc[:, :self.D] / den, self.W).astype(np.float32)
+
+    def sync(self):
+        pass
+
+    def bmu(self, x, quantization=False):
+        W3 = self.W.reshape(self.x, self.y, self.D)
+        if quantization:
+            return O.quantization_ids(np.asarray(x, np.float32), W3).astype(np.int32)
+        return O.winner_ids(np.asarray(x, np.float32), W3, self.kw["distance"]).astype(np.int32)
+
+    def quantization_error(self, x):
+        return O.quantization_error(x, self.W.reshape(self.x, self.y, self.D))

@@ -1,0 +1,64 @@
+"""The N > 1 path on CPU: two gloo ranks run XPySom.train through the product's host code
+(shard split -> per-rank accumulate -> ONE all-reduce of the fused numerator|denominator ->
+identical merge on every rank), with the oracle standing in for the device engine."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import som_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, sharded_input, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from tests.oracle_engine import OracleEngine
+    from xpysom_dask_amd import XPySom
+    from xpysom_dask_amd import distributed as D
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert D.dist_info() == (rank, world)
+        data = O.gaussian_blobs(601, 5, seed=11)
+        som = XPySom(7, 6, 5, random_seed=3, decay_function="linear", sharded_input=sharded_input,
+                     _engine_factory=OracleEngine)
+        mine = data
+        if sharded_input:
+            lo, hi = D.shard_bounds(len(data), rank, world)
+            mine = data[lo:hi]
+        som.train(mine, 6)
+        np.save(os.path.join(out_dir, "w%d.npy" % rank), som._weights)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sharded_input", [False, True])
+def test_two_rank_training_equals_single_process(tmp_path, sharded_input):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), sharded_input, str(tmp_path)), nprocs=world, join=True)
+    w0, w1 = np.load(tmp_path / "w0.npy"), np.load(tmp_path / "w1.npy")
+    assert np.array_equal(w0, w1)                       # every rank holds the same codebook, bit for bit
+    data = O.gaussian_blobs(601, 5, seed=11)
+    ref = O.train(data, O.default_codebook(7, 6, 5, 3), 6, sigma0=3.0, decay="linear", n_parallel=4000)
+    np.testing.assert_allclose(w0, ref, rtol=2e-5, atol=2e-6)   # sum order differs with the shard count
+
+
+def test_shard_bounds_cover_and_balance():
+    from xpysom_dask_amd.distributed import shard_bounds
+    for n in (0, 1, 7, 8, 1000, 1 << 20):
+        for world in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1

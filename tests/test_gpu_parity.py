@@ -379,3 +379,55 @@ def test_64x64x32_epoch_f32_and_bf16():
         _, onum, oden = O.update(data, w, eta, sig, wide=True, forced_bmu=bmu)
         assert rel_err(num, onum.reshape(-1, D)) < 1e-5
         assert rel_err(den, oden.reshape(-1)) < 1e-5
+
+
+# ----------------------------------------------------------------------------- RCCL plumbing on one GPU
+_NCCL_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["SOM_REPO"])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ["SOM_PORT"], RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                  SOM_FORCE_ALLREDUCE="1")
+import torch, torch.distributed as dist
+from oracle import som_oracle as O
+from xpysom_dask_amd.engine import HipEngine
+from xpysom_dask_amd import distributed as D
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+data = O.gaussian_blobs(500, 6, seed=1)
+w = O.default_codebook(9, 8, 6, 2).astype(np.float32)
+e = HipEngine(9, 8, 6)
+e.set_weights(w); e.set_data(data)
+e.epoch_accumulate(3.0, 0.4, True)
+num0, den0, _ = e.epoch_fetch()
+t = e.accum_tensor()
+assert t.is_cuda and t.dtype == torch.float32 and t.numel() == 72 * 8
+D.allreduce_accumulator(e)                     # RCCL all-reduce over 1 rank: values unchanged
+num1, den1, _ = e.epoch_fetch()
+assert np.array_equal(num0, num1) and np.array_equal(den0, den1)
+t.mul_(2.0); torch.cuda.synchronize()          # the tensor IS the engine's buffer
+num2, den2, _ = e.epoch_fetch()
+assert np.array_equal(num2, 2 * num0) and np.array_equal(den2, 2 * den0)
+t.mul_(0.5); torch.cuda.synchronize()
+D.epoch(e, 3.0, 0.4, True)
+_, _, _, want = O.epoch(data, w.reshape(9, 8, 6), 0.4, 3.0, wide=True, n_parallel=500)
+assert np.abs(e.get_weights().reshape(9, 8, 6) - want).max() < 1e-5
+dist.destroy_process_group()
+print("nccl-path-ok")
+"""
+
+
+def test_rccl_allreduce_runs_in_place_on_the_engine_buffer(tmp_path):
+    """One rank, backend 'nccl' (= RCCL): the fused accumulator is handed to torch.distributed
+    zero-copy (one HIP runtime shared by torch and libsomhip) and reduced in place."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from tests.conftest import REPO
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "nccl_path.py"
+    script.write_text(_NCCL_SCRIPT)
+    env = dict(os.environ, SOM_REPO=REPO, SOM_PORT=str(port))
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "nccl-path-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

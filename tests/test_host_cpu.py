@@ -1,0 +1,109 @@
+"""Host-side behaviour that needs no GPU: constructor validation and error strings
+(xpysom.py:164-165,196-198,217-220,228-231; distances.py:172-175), the seeded default
+codebook, schedules, the C-ABI library's exported surface, fail-loud without a device."""
+import ctypes as C
+import pickle
+import re
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import som_oracle as O
+from tests.conftest import REPO, _gpu_present
+
+
+def test_constructor_mirrors_reference_validation():
+    from xpysom_dask_amd import XPySom
+    with pytest.raises(ValueError, match="boooom not supported. Functions available"):
+        XPySom(5, 5, 1, neighborhood_function='boooom')
+    with pytest.raises(ValueError, match="ridethewave not supported. Distances available"):
+        XPySom(5, 5, 1, activation_distance='ridethewave')
+    with pytest.raises(ValueError, match="not supported only hexagonal and rectangular available"):
+        XPySom(5, 5, 1, topology='triangular')
+    with pytest.raises(ValueError, match="sqrt not supported. Functions available"):
+        XPySom(5, 5, 1, decay_function='sqrt')
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        XPySom(5, 5, 1, sigma=5)
+        assert any("sigma is too high" in str(x.message) for x in w)
+    som = XPySom(6, 4, 3)
+    assert som._sigma == 2.0 and som._n_parallel == 65536
+    with pytest.raises(ValueError, match=r"Received 2 features, expected 3\."):
+        som.quantization_error([[1, 2]])
+    # valid reference names the engine does not implement yet say so instead of mis-training
+    with pytest.raises(NotImplementedError):
+        XPySom(5, 5, 1, activation_distance='manhattan')
+    with pytest.raises(NotImplementedError):
+        XPySom(5, 5, 1, topology='hexagonal')
+
+
+def test_default_codebook_is_the_reference_formula():
+    from xpysom_dask_amd import XPySom
+    som = XPySom(7, 5, 3, random_seed=1234)
+    np.testing.assert_array_equal(som._weights, O.default_codebook(7, 5, 3, 1234))
+    assert som._weights.dtype == np.float64
+    np.testing.assert_allclose(np.linalg.norm(som._weights, axis=-1), 1.0, atol=1e-12)
+
+
+def test_schedules_equal_the_oracle_bit_for_bit():
+    from xpysom_dask_amd.decays import DECAY_FUNCTIONS
+    for name, f in DECAY_FUNCTIONS.items():
+        g = O.DECAYS[name]
+        for T in (1, 10, 100):
+            for t in range(0, T, max(1, T // 7)):
+                for v0, vN in ((8.0, 1), (0.5, 0.01), (3.0, 0)):
+                    a, b = f(v0, vN, t, T), g(v0, vN, t, T)
+                    assert a == b and type(a) is type(b)
+
+
+def test_synthetic_generator_is_the_oracles():
+    from xpysom_dask_amd.synthetic import gaussian_blobs
+    np.testing.assert_array_equal(gaussian_blobs(100, 7, seed=5), O.gaussian_blobs(100, 7, seed=5))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from xpysom_dask_amd import _lib
+    lib = _lib.load()
+    header = open(REPO + "/include/somhip.h").read()
+    declared = set(re.findall(r"\b(som_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.som_version().startswith(b"somhip")
+
+
+@pytest.mark.skipif(_gpu_present(), reason="checks the no-GPU failure mode")
+def test_compute_fails_loudly_without_a_gpu():
+    from xpysom_dask_amd import XPySom
+    from xpysom_dask_amd.engine import SomHipError
+    som = XPySom(4, 4, 2, random_seed=0)
+    with pytest.raises(SomHipError, match="no HIP device"):
+        som.train(np.zeros((8, 2)), 1)
+    with pytest.raises(SomHipError):
+        som.winner(np.zeros((3, 2)))
+
+
+def test_host_logic_end_to_end_with_the_test_double():
+    """XPySom's epoch loop / schedule plumbing / result formatting, engine replaced by the oracle."""
+    from tests.oracle_engine import OracleEngine
+    from xpysom_dask_amd import XPySom
+    data = O.gaussian_blobs(300, 4, seed=2)
+    for decay in ("linear", "exponential", "asymptotic"):
+        som = XPySom(6, 5, 4, random_seed=9, decay_function=decay, _engine_factory=OracleEngine)
+        w0 = som._weights.copy()
+        assert som.train(data, 7) is som
+        ref = O.train(data, w0, 7, sigma0=2.5, decay=decay)
+        np.testing.assert_allclose(som._weights, ref, rtol=1e-6, atol=1e-7)
+        # resume: 0..3 then 3..7 equals one run
+        som2 = XPySom(6, 5, 4, random_seed=9, decay_function=decay, _engine_factory=OracleEngine)
+        som2.train(data, 7, iter_beg=0, iter_end=3)
+        som2.train(data, 7, iter_beg=3)
+        np.testing.assert_array_equal(som2._weights, som._weights)
+    w = som.winner(data[:5])
+    assert isinstance(w, list) and len(w) == 5 and isinstance(w[0][0], np.int64)
+    assert isinstance(som.winner(data[0]), tuple)
+    blob = pickle.dumps(som)
+    back = pickle.loads(blob)
+    np.testing.assert_array_equal(back._weights, som._weights)
+    assert back._engine_obj is None

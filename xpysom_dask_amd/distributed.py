@@ -6,6 +6,7 @@ rank accumulates its local [numerator | denominator] buffer, ONE all-reduce(sum)
 fused float32 buffer (RCCL over xGMI when the backend is 'nccl') makes every rank hold the
 global sums, and every rank applies the identical merge -- no broadcast of the codebook.
 """
+import os
 
 
 def dist_info():
@@ -29,7 +30,7 @@ def shard_bounds(n_rows, rank, world):
 def allreduce_accumulator(engine):
     """Sum the engine's fused accumulator across ranks, in place."""
     rank, world = dist_info()
-    if world == 1:
+    if world == 1 and not os.environ.get("SOM_FORCE_ALLREDUCE"):   # (the env var lets a 1-GPU box exercise the path)
         return
     import torch.distributed as dist
     engine.sync()                      # the engine may run on its own stream
