@@ -376,6 +376,7 @@ void som_destroy(som_handle* h) {
 }
 
 int som_set_weights(som_handle* h, const float* w_host) {
+    if (h) (void)hipSetDevice(h->cfg.device);
     if (!h || !w_host) return fail(h, "som_set_weights: NULL argument");
     HIPCHK(h, hipMemcpyAsync(h->W, w_host, (size_t)h->K * h->D * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -384,6 +385,7 @@ int som_set_weights(som_handle* h, const float* w_host) {
 }
 
 int som_get_weights(som_handle* h, float* w_host) {
+    if (h) (void)hipSetDevice(h->cfg.device);
     if (!h || !w_host) return fail(h, "som_get_weights: NULL argument");
     HIPCHK(h, hipMemcpyAsync(w_host, h->W, (size_t)h->K * h->D * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -410,6 +412,7 @@ static int adopt_rows(som_handle* h, int64_t n_rows) {
 }
 
 int som_set_data(som_handle* h, const float* x_host, int64_t n_rows) {
+    if (h) (void)hipSetDevice(h->cfg.device);
     if (!h || n_rows < 0 || (!x_host && n_rows > 0)) return fail(h, "som_set_data: bad argument");
     (void)hipFree(h->X_owned);
     h->X_owned = nullptr; h->Xd = nullptr;
@@ -422,6 +425,7 @@ int som_set_data(som_handle* h, const float* x_host, int64_t n_rows) {
 }
 
 int som_set_data_device(som_handle* h, const void* x_dev, int64_t n_rows) {
+    if (h) (void)hipSetDevice(h->cfg.device);
     if (!h || n_rows < 0 || (!x_dev && n_rows > 0)) return fail(h, "som_set_data_device: bad argument");
     (void)hipFree(h->X_owned);
     h->X_owned = nullptr;
@@ -430,6 +434,7 @@ int som_set_data_device(som_handle* h, const void* x_dev, int64_t n_rows) {
 }
 
 int som_epoch_accumulate(som_handle* h, double sigma, double eta, int neigh_f64) {
+    if (h) (void)hipSetDevice(h->cfg.device);
     if (!h) return 1;
     if (!h->Xd && h->N > 0) return fail(h, "som_epoch_accumulate: no resident data (call som_set_data)");
     if (int rc = run_activation_bmu(h, h->Xd, h->N, h->xsq, h->Xb, h->xsqh, h->bmu)) return rc;
@@ -437,6 +442,7 @@ int som_epoch_accumulate(som_handle* h, double sigma, double eta, int neigh_f64)
 }
 
 int som_epoch_accumulate_forced(som_handle* h, const int32_t* bmu_host, double sigma, double eta, int neigh_f64) {
+    if (h) (void)hipSetDevice(h->cfg.device);
     if (!h || (!bmu_host && h->N > 0)) return fail(h, "som_epoch_accumulate_forced: bad argument");
     for (long i = 0; i < h->N; ++i)
         if (bmu_host[i] < 0 || bmu_host[i] >= h->K) return fail(h, "som_epoch_accumulate_forced: id out of range");
@@ -446,6 +452,7 @@ int som_epoch_accumulate_forced(som_handle* h, const int32_t* bmu_host, double s
 }
 
 int som_epoch_merge(som_handle* h) {
+    if (h) (void)hipSetDevice(h->cfg.device);
     if (!h) return 1;
     Timed t(h, SOM_K_MERGE);
     long total = (long)h->K * h->D;
@@ -468,6 +475,7 @@ int som_accum_device_ptr(som_handle* h, void** dev_ptr, int64_t* n_floats) {
 }
 
 int som_epoch_fetch(som_handle* h, float* num, float* den, int32_t* bmu) {
+    if (h) (void)hipSetDevice(h->cfg.device);
     if (!h) return 1;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (num || den) {
@@ -483,6 +491,7 @@ int som_epoch_fetch(som_handle* h, float* num, float* den, int32_t* bmu) {
 }
 
 int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, int32_t* ids_out) {
+    if (h) (void)hipSetDevice(h->cfg.device);
     if (!h || n_rows < 0 || (n_rows > 0 && (!x_host || !ids_out))) return fail(h, "som_bmu: bad argument");
     if (mode != SOM_BMU_ACTIVATION && mode != SOM_BMU_QUANTIZATION) return fail(h, "som_bmu: unknown mode");
     if (n_rows == 0) return 0;
@@ -505,6 +514,7 @@ int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, in
 }
 
 int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, double* qe_out) {
+    if (h) (void)hipSetDevice(h->cfg.device);
     if (!h || !qe_out || n_rows < 0 || (n_rows > 0 && !x_host)) return fail(h, "som_quantization_error: bad argument");
     if (n_rows == 0) { *qe_out = NAN; return 0; }     // numpy: mean of an empty array
     if (int rc = ensure_query_scratch(h, n_rows)) return rc;
@@ -523,12 +533,14 @@ int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, d
 }
 
 int som_sync(som_handle* h) {
+    if (h) (void)hipSetDevice(h->cfg.device);
     if (!h) return 1;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 
 int som_profile_enable(som_handle* h, int32_t on) {
+    if (h) (void)hipSetDevice(h->cfg.device);
     if (!h) return 1;
     if (!on) if (int rc = resolve_profile(h)) return rc;
     h->prof = on != 0;
@@ -536,6 +548,7 @@ int som_profile_enable(som_handle* h, int32_t on) {
 }
 
 int som_profile_get(som_handle* h, int32_t kernel, double* total_ms, int64_t* launches) {
+    if (h) (void)hipSetDevice(h->cfg.device);
     if (!h || kernel < 0 || kernel >= SOM_K_COUNT) return fail(h, "som_profile_get: bad argument");
     if (int rc = resolve_profile(h)) return rc;
     if (total_ms) *total_ms = h->ms[kernel];
@@ -544,6 +557,7 @@ int som_profile_get(som_handle* h, int32_t kernel, double* total_ms, int64_t* la
 }
 
 int som_profile_reset(som_handle* h) {
+    if (h) (void)hipSetDevice(h->cfg.device);
     if (!h) return 1;
     if (int rc = resolve_profile(h)) return rc;
     for (int i = 0; i < SOM_K_COUNT; ++i) { h->ms[i] = 0; h->launches[i] = 0; }
