@@ -1,17 +1,17 @@
 // Fused distance + BMU argmin, bf16 MFMA throughput mode (euclidean).
 //
 // Same reference chain as bmu_f32.hpp (distances.py:11-23 + xpysom.py:416), computed as
-//     d'(n,k) = |x~_n|^2/2 + |w~_k|^2/2 - x~_n . w~_k  =  |x~_n - w~_k|^2 / 2  >= 0
-// on bf16-rounded x~, w~ with float32 accumulation in v_mfma_f32_32x32x16_bf16.  Rounding
-// BOTH norms from the same bf16 values keeps d' a true distance in the rounded space (its
-// error shrinks with the distance, which is what matters for picking the nearest unit) and
-// keeps it non-negative up to float32 rounding noise around an exact match, so its bits
-// order like SIGNED integers (a slightly negative value is such a match and rightly wins).
+//     d'(n,k) = B + |w~_k|^2/2 - x~_n . w~_k          (argmin_k d' == argmin_k |x~_n - w~_k|^2)
+// on bf16-rounded x~, w~ with float32 accumulation in v_mfma_f32_32x32x16_bf16.  The norm
+// is taken from the SAME bf16 values as the products, so d' is a true distance in the rounded
+// space.  B = max_n|x~_n| * max_k|w~_k| (Cauchy-Schwarz) makes every d' positive, so its bit
+// pattern orders like an integer and B + |w~|^2/2 is simply the MFMA's initial accumulator,
+// read from LDS straight into the C registers: no per-element VALU besides the argmin.
 //
 // Layout in HBM (built once per epoch by prep_w_bf16 / prep_wsqh):
 //   the codebook as a sequence of STAGES of 128 units; each stage is one contiguous block
 //     [ut=0..3][kstep][lane 0..63][8 bf16]   A-operand fragments of -w~, 1 KiB per (ut,kstep)
-//     [128 x f32 |w~|^2/2]  (+ pad to 1 KiB)
+//     [128 x f32  B + |w~|^2/2]  (+ pad to 1 KiB)
 //   i.e. exactly the image the kernel wants in LDS, so staging is a linear LDS-DMA copy
 //   (global_load_lds_dwordx4) and every ds_read_b128 is lane-linear (conflict free).
 //
@@ -63,27 +63,45 @@ __global__ __launch_bounds__(256) void prep_w_bf16_kernel(const float* __restric
     *(bf16x8*)(Wst + stage * bf_stage_bytes(KSTEPS) + ((long)(ut * KSTEPS + ks) * 64 + lane) * 16) = v;
 }
 
-// |w~|^2/2 (of the bf16-rounded values) per unit, written behind each stage's fragments.
-__global__ __launch_bounds__(256) void prep_wsqh_kernel(const float* __restrict__ W, int K, int D,
-                                                        char* __restrict__ Wst, int n_stages, int ksteps) {
+// positive floats order like their bit patterns: a float max through an integer atomic
+__device__ __forceinline__ void atomic_max_pos_f32(float* addr, float v) {
+    atomicMax((unsigned int*)addr, __float_as_uint(v));
+}
+
+// |w~|^2 of every unit (bf16-rounded values) and its maximum over the codebook
+__global__ __launch_bounds__(256) void prep_wnorm_kernel(const float* __restrict__ W, int K, int D,
+                                                         float* __restrict__ wn, float* __restrict__ wmax2) {
+    long u = (long)blockIdx.x * 256 + threadIdx.x;
+    float s = 0.0f;
+    if (u < K) {
+        for (int k = 0; k < D; ++k) { float f = (float)(__bf16)W[u * D + k]; s = __builtin_fmaf(f, f, s); }
+        wn[u] = s;
+    }
+    float m = s;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomic_max_pos_f32(wmax2, m);
+}
+
+// initial accumulators  B + |w~|^2/2  written behind each stage's fragments; B from the two maxima
+__global__ __launch_bounds__(256) void prep_wsqh_kernel(const float* __restrict__ wn, int K,
+                                                        const float* __restrict__ wmax2,
+                                                        const float* __restrict__ xmax2, char* __restrict__ Wst,
+                                                        int n_stages, int ksteps) {
     long u = (long)blockIdx.x * 256 + threadIdx.x;
     if (u >= (long)n_stages * BF_STAGE_UNITS) return;
-    float s = BF_PAD_NORM;
-    if (u < K) {
-        s = 0.0f;
-        for (int k = 0; k < D; ++k) { float f = (float)(__bf16)W[u * D + k]; s = __builtin_fmaf(f, f, s); }
-        s = 0.5f * s;
-    }
+    const float big = __builtin_sqrtf(*wmax2) * __builtin_sqrtf(*xmax2) * (1.0f + 1.0f / 1024.0f);
+    float s = (u < K) ? __builtin_fmaf(0.5f, wn[u], big) : BF_PAD_NORM;
     long stage = u / BF_STAGE_UNITS;
     int within = u % BF_STAGE_UNITS;
     float* dst = (float*)(Wst + stage * bf_stage_bytes(ksteps) + (long)BF_UT * ksteps * 1024);
     dst[within] = s;
 }
 
-// samples -> bf16 rows [Np][Dp] (zero padded) and |x~|^2/2 per row.  One wave per row.
+// samples -> bf16 rows [Np][Dp] (zero padded) and max_n |x~_n|^2.  One wave per row.
 __global__ __launch_bounds__(256) void prep_x_bf16_kernel(const float* __restrict__ X, long N, int D, int Dp,
                                                           long Np, __bf16* __restrict__ Xb,
-                                                          float* __restrict__ xsqh) {
+                                                          float* __restrict__ xmax2) {
     long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (row >= Np) return;
@@ -96,13 +114,12 @@ __global__ __launch_bounds__(256) void prep_x_bf16_kernel(const float* __restric
         s = __builtin_fmaf(fb, fb, s);
     }
     s = wave_sum(s);
-    if (lane == 0) xsqh[row] = 0.5f * s;
+    if (lane == 0) atomic_max_pos_f32(xmax2, s);
 }
 
 // --------------------------------------------------------------------------------------
 template <int KSTEPS>
-__global__ __launch_bounds__(256, 2) void bmu_bf16_kernel(const __bf16* __restrict__ Xb,
-                                                          const float* __restrict__ xsqh, long N,
+__global__ __launch_bounds__(256, 2) void bmu_bf16_kernel(const __bf16* __restrict__ Xb, long N,
                                                           const char* __restrict__ Wst, int n_stages, int K,
                                                           int* __restrict__ out) {
     constexpr int DP = 16 * KSTEPS;
@@ -118,11 +135,9 @@ __global__ __launch_bounds__(256, 2) void bmu_bf16_kernel(const __bf16* __restri
 
     // B-operand fragments of this wave's samples: lane holds X~[sample col][16*ks + 8*half + j]
     bf16x8 xf[BF_SBW][KSTEPS];
-    float xq[BF_SBW];
 #pragma unroll
     for (int sb = 0; sb < BF_SBW; ++sb) {
         const long row = wave_s0 + sb * 32 + col;          // rows are padded to a multiple of the WG size
-        xq[sb] = xsqh[row];
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) xf[sb][ks] = *(const bf16x8*)(Xb + row * DP + ks * 16 + half * 8);
     }
@@ -132,8 +147,46 @@ __global__ __launch_bounds__(256, 2) void bmu_bf16_kernel(const __bf16* __restri
 #pragma unroll
     for (int sb = 0; sb < BF_SBW; ++sb) { gbest[sb] = 0x7FFFFFFF; gstage[sb] = 0; }
 
+    // Software pipeline inside the wave: while the 16 MFMAs of tile t run, the VALU reduces tile
+    // t-1 (accP) and the LDS fetches the fragments of tile t+1, so the matrix pipe never waits for
+    // this wave's own epilogue.  accP starts as +inf: its keys lose against every real distance.
+    f32x16 accP[BF_SBW];
+#pragma unroll
+    for (int sb = 0; sb < BF_SBW; ++sb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accP[sb][r] = __builtin_inff();
+    int32_t cbest[BF_SBW], cbest2[BF_SBW];
+#pragma unroll
+    for (int sb = 0; sb < BF_SBW; ++sb) { cbest[sb] = 0x7FFFFFFF; cbest2[sb] = 0x7FFFFFFF; }
+
     // stage 0 -> ring slot 0
     for (int p = wave; p < PIECES; p += 4) lds_dma_16(Wst + (long)p * 1024 + lane * 16, smem + p * 1024);
+
+    auto reduce_tile = [&](const f32x16 (&acc)[BF_SBW], int ut) {
+#pragma unroll
+        for (int sb = 0; sb < BF_SBW; ++sb) {
+            int32_t key[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float f = acc[sb][r];               // (bit_cast straight from a vector element reads lane 0)
+                key[r] = (int32_t)((__float_as_uint(f) & ~IDX_MASK) | (uint32_t)(ut * 16 + r));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+                cbest[sb] = min(min(cbest[sb], key[r]), key[r + 1]);
+                cbest2[sb] = min(min(cbest2[sb], key[r + 2]), key[r + 3]);
+            }
+        }
+    };
+    auto fold_stage = [&](int stage) {
+#pragma unroll
+        for (int sb = 0; sb < BF_SBW; ++sb) {
+            const int32_t c = min(cbest[sb], cbest2[sb]);
+            if (c < gbest[sb]) { gbest[sb] = c; gstage[sb] = stage; }
+            cbest[sb] = 0x7FFFFFFF;
+            cbest2[sb] = 0x7FFFFFFF;
+        }
+    };
 
     for (int s = 0; s < n_stages; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of stage s have landed
@@ -147,40 +200,57 @@ __global__ __launch_bounds__(256, 2) void bmu_bf16_kernel(const __bf16* __restri
         const char* st = smem + (s & 1) * STAGE;
         const float* wq = (const float*)(st + BF_UT * KSTEPS * 1024);
 
-        int32_t cbest[BF_SBW];
+        f32x4 wv[4];
+        bf16x8 a[KSTEPS];
 #pragma unroll
-        for (int sb = 0; sb < BF_SBW; ++sb) cbest[sb] = 0x7FFFFFFF;
+        for (int g = 0; g < 4; ++g) wv[g] = *(const f32x4*)(wq + 8 * g + 4 * half);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) a[ks] = *(const bf16x8*)(st + ks * 1024 + lane * 16);
 
 #pragma unroll
         for (int ut = 0; ut < BF_UT; ++ut) {
-            f32x4 wv[4];
+            f32x4 wvN[4];
+            bf16x8 aN[KSTEPS];
+            if (ut + 1 < BF_UT) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) wv[g] = *(const f32x4*)(wq + ut * 32 + 8 * g + 4 * half);
-            bf16x8 a[KSTEPS];
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) a[ks] = *(const bf16x8*)(st + (ut * KSTEPS + ks) * 1024 + lane * 16);
-#pragma unroll
-            for (int sb = 0; sb < BF_SBW; ++sb) {
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = wv[r >> 2][r & 3] + xq[sb];
+                for (int g = 0; g < 4; ++g) wvN[g] = *(const f32x4*)(wq + (ut + 1) * 32 + 8 * g + 4 * half);
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], xf[sb][ks], acc, 0, 0, 0);
+                    aN[ks] = *(const bf16x8*)(st + ((ut + 1) * KSTEPS + ks) * 1024 + lane * 16);
+            }
+            f32x16 accT[BF_SBW];
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const float f0 = acc[r], f1 = acc[r + 1];   // (bit_cast straight from a vector element reads lane 0)
-                    int32_t k0 = (int32_t)((__float_as_uint(f0) & ~IDX_MASK) | (uint32_t)(ut * 16 + r));
-                    int32_t k1 = (int32_t)((__float_as_uint(f1) & ~IDX_MASK) | (uint32_t)(ut * 16 + r + 1));
-                    int32_t m = k0 < k1 ? k0 : k1;
-                    cbest[sb] = cbest[sb] < m ? cbest[sb] : m;
-                }
+            for (int sb = 0; sb < BF_SBW; ++sb) {          // C-in = B + |w~|^2/2, as read from LDS
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accT[sb][r] = wv[r >> 2][r & 3];
+            }
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+                for (int sb = 0; sb < BF_SBW; ++sb)
+                    accT[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], xf[sb][ks], accT[sb], 0, 0, 0);
+            // the pending tile: tile ut-1 of this stage, or tile 3 of the previous stage
+            reduce_tile(accP, (ut + BF_UT - 1) % BF_UT);
+            if (ut == 0) fold_stage(s - 1);
+#pragma unroll
+            for (int sb = 0; sb < BF_SBW; ++sb) accP[sb] = accT[sb];
+            if (ut + 1 < BF_UT) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) wv[g] = wvN[g];
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) a[ks] = aN[ks];
             }
         }
+        // interleave request for the whole stage body: per MFMA, three epilogue VALU and one LDS read
 #pragma unroll
-        for (int sb = 0; sb < BF_SBW; ++sb)
-            if (cbest[sb] < gbest[sb]) { gbest[sb] = cbest[sb]; gstage[sb] = s; }
+        for (int i = 0; i < BF_UT * BF_SBW * KSTEPS; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // VALU
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+        }
     }
+    reduce_tile(accP, BF_UT - 1);
+    fold_stage(n_stages - 1);
 
 #pragma unroll
     for (int sb = 0; sb < BF_SBW; ++sb) {

@@ -45,10 +45,12 @@ struct som_handle {
     int* bmu = nullptr;
     float* xsq = nullptr;
     __bf16* Xb = nullptr;
-    float* xsqh = nullptr;
+    float* xmax2 = nullptr;  // [0] resident rows, [1] query scratch: max_n |x~_n|^2
+    float* wn = nullptr;     // |w~_k|^2 per unit
+    float* wmax2 = nullptr;
 
     // scratch for som_bmu / som_quantization_error
-    float* qX = nullptr; int* qbmu = nullptr; float* qxsq = nullptr; __bf16* qXb = nullptr; float* qxsqh = nullptr;
+    float* qX = nullptr; int* qbmu = nullptr; float* qxsq = nullptr; __bf16* qXb = nullptr;
     long qcap = 0;
     double* dsum = nullptr;
 
@@ -142,9 +144,8 @@ int refresh_codebook_operands(som_handle* h) {
         case 8: launch_prep_w<8>(h); break;
         default: return fail(h, "bf16 precision supports input_len <= 128");
         }
-        long units = (long)h->n_stages * BF_STAGE_UNITS;
-        prep_wsqh_kernel<<<dim3((unsigned)cdiv(units, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->Wst,
-                                                                                      h->n_stages, h->ksteps);
+        HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
+        prep_wnorm_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->wn, h->wmax2);
     }
     HIPCHK(h, hipGetLastError());
     h->w_dirty = false;
@@ -171,46 +172,50 @@ int launch_bmu_f32(som_handle* h, const float* X, long N, const float* xsq, int*
 }
 
 template <int KS>
-int launch_bmu_bf16_ks(som_handle* h, const __bf16* Xb, const float* xsqh, long N, int* out) {
+int launch_bmu_bf16_ks(som_handle* h, const __bf16* Xb, long N, int* out) {
     size_t lds = 2 * (size_t)bf_stage_bytes(KS);
     HIPCHK(h, hipFuncSetAttribute((const void*)bmu_bf16_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
     long grid = cdiv(N, BF_WG_SAMPLES);
     if (grid <= 0 || grid > 0x7fffffffL) return fail(h, "bmu_bf16: row count out of range");
-    bmu_bf16_kernel<KS><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(Xb, xsqh, N, h->Wst, h->n_stages, h->K,
-                                                                            out);
+    bmu_bf16_kernel<KS><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(Xb, N, h->Wst, h->n_stages, h->K, out);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
 
-int launch_bmu_bf16(som_handle* h, const __bf16* Xb, const float* xsqh, long N, int* out) {
+int launch_bmu_bf16(som_handle* h, const __bf16* Xb, const float* xmax2, long N, int* out) {
+    // the stage image's initial accumulators depend on the row set through B = xmax * wmax
+    long units = (long)h->n_stages * BF_STAGE_UNITS;
+    prep_wsqh_kernel<<<dim3((unsigned)cdiv(units, 256)), dim3(256), 0, h->stream>>>(h->wn, h->K, h->wmax2, xmax2, h->Wst,
+                                                                                  h->n_stages, h->ksteps);
     switch (h->ksteps) {
-    case 1: return launch_bmu_bf16_ks<1>(h, Xb, xsqh, N, out);
-    case 2: return launch_bmu_bf16_ks<2>(h, Xb, xsqh, N, out);
-    case 3: return launch_bmu_bf16_ks<3>(h, Xb, xsqh, N, out);
-    case 4: return launch_bmu_bf16_ks<4>(h, Xb, xsqh, N, out);
-    case 5: return launch_bmu_bf16_ks<5>(h, Xb, xsqh, N, out);
-    case 6: return launch_bmu_bf16_ks<6>(h, Xb, xsqh, N, out);
-    case 7: return launch_bmu_bf16_ks<7>(h, Xb, xsqh, N, out);
-    case 8: return launch_bmu_bf16_ks<8>(h, Xb, xsqh, N, out);
+    case 1: return launch_bmu_bf16_ks<1>(h, Xb, N, out);
+    case 2: return launch_bmu_bf16_ks<2>(h, Xb, N, out);
+    case 3: return launch_bmu_bf16_ks<3>(h, Xb, N, out);
+    case 4: return launch_bmu_bf16_ks<4>(h, Xb, N, out);
+    case 5: return launch_bmu_bf16_ks<5>(h, Xb, N, out);
+    case 6: return launch_bmu_bf16_ks<6>(h, Xb, N, out);
+    case 7: return launch_bmu_bf16_ks<7>(h, Xb, N, out);
+    case 8: return launch_bmu_bf16_ks<8>(h, Xb, N, out);
     }
     return fail(h, "bf16 precision supports input_len <= 128");
 }
 
-int prep_rows_bf16(som_handle* h, const float* X, long N, long Np, __bf16* Xb, float* xsqh) {
+int prep_rows_bf16(som_handle* h, const float* X, long N, long Np, __bf16* Xb, float* xmax2) {
     const int Dp = 16 * h->ksteps;
-    prep_x_bf16_kernel<<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, Dp, Np, Xb, xsqh);
+    HIPCHK(h, hipMemsetAsync(xmax2, 0, sizeof(float), h->stream));
+    prep_x_bf16_kernel<<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, Dp, Np, Xb, xmax2);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
 
 // BMU of `N` device rows with the configured activation distance (xpysom.py:410-417)
-int run_activation_bmu(som_handle* h, const float* X, long N, const float* xsq, const __bf16* Xb, const float* xsqh,
+int run_activation_bmu(som_handle* h, const float* X, long N, const float* xsq, const __bf16* Xb, const float* xmax2,
                        int* out) {
     if (N == 0) return 0;
     if (int rc = refresh_codebook_operands(h)) return rc;
     Timed t(h, SOM_K_BMU);
-    if (h->cfg.precision == SOM_PREC_BF16) return launch_bmu_bf16(h, Xb, xsqh, N, out);
+    if (h->cfg.precision == SOM_PREC_BF16) return launch_bmu_bf16(h, Xb, xmax2, N, out);
     switch (h->cfg.distance) {
     case SOM_DIST_EUCLIDEAN: return launch_bmu_f32<SCORE_EUCLID_PART>(h, X, N, xsq, out);
     case SOM_DIST_EUCLIDEAN_NO_OPT: return launch_bmu_f32<SCORE_EUCLID_SQ>(h, X, N, xsq, out);
@@ -272,15 +277,14 @@ int run_update(som_handle* h, double sigma, double eta, int neigh_f64) {
 int ensure_query_scratch(som_handle* h, long n) {
     if (n <= h->qcap) return 0;
     long cap = round_up(n, 1024);
-    (void)hipFree(h->qX); (void)hipFree(h->qbmu); (void)hipFree(h->qxsq); (void)hipFree(h->qXb); (void)hipFree(h->qxsqh);
-    h->qX = nullptr; h->qbmu = nullptr; h->qxsq = nullptr; h->qXb = nullptr; h->qxsqh = nullptr; h->qcap = 0;
+    (void)hipFree(h->qX); (void)hipFree(h->qbmu); (void)hipFree(h->qxsq); (void)hipFree(h->qXb);
+    h->qX = nullptr; h->qbmu = nullptr; h->qxsq = nullptr; h->qXb = nullptr; h->qcap = 0;
     if (int rc = dev_alloc(h, &h->qX, (size_t)cap * h->D)) return rc;
     if (int rc = dev_alloc(h, &h->qbmu, (size_t)cap)) return rc;
     if (int rc = dev_alloc(h, &h->qxsq, (size_t)cap)) return rc;
     if (h->cfg.precision == SOM_PREC_BF16) {
         long capp = round_up(cap, BF_WG_SAMPLES);
         if (int rc = dev_alloc(h, &h->qXb, (size_t)capp * 16 * h->ksteps)) return rc;
-        if (int rc = dev_alloc(h, &h->qxsqh, (size_t)capp)) return rc;
     }
     h->qcap = cap;
     return 0;
@@ -356,6 +360,9 @@ int som_create(const som_config* cfg, som_handle** out) {
         h->n_stages = (int)cdiv(h->K, BF_STAGE_UNITS);
         size_t bytes = (size_t)h->n_stages * bf_stage_bytes(h->ksteps);
         if ((rc = dev_alloc(h, &h->Wst, bytes))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->xmax2, 2))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->wn, (size_t)h->K))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->wmax2, 1))) return bail(rc);
         if (hipMemsetAsync(h->Wst, 0, bytes, h->stream) != hipSuccess) return bail(fail(h, "hipMemsetAsync failed"));
     }
     if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(fail(h, "hipStreamSynchronize failed"));
@@ -369,7 +376,7 @@ void som_destroy(som_handle* h) {
     for (auto& ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto& ep : h->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     void* bufs[] = {h->W, h->wsq, h->SC, h->T, h->ACC, h->P1, h->P2, h->Wst, h->X_owned, h->bmu, h->xsq, h->Xb,
-                    h->xsqh, h->qX, h->qbmu, h->qxsq, h->qXb, h->qxsqh, h->dsum};
+                    h->xmax2, h->wn, h->wmax2, h->qX, h->qbmu, h->qxsq, h->qXb, h->dsum};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -393,8 +400,8 @@ int som_get_weights(som_handle* h, float* w_host) {
 }
 
 static int adopt_rows(som_handle* h, int64_t n_rows) {
-    (void)hipFree(h->bmu); (void)hipFree(h->xsq); (void)hipFree(h->Xb); (void)hipFree(h->xsqh);
-    h->bmu = nullptr; h->xsq = nullptr; h->Xb = nullptr; h->xsqh = nullptr;
+    (void)hipFree(h->bmu); (void)hipFree(h->xsq); (void)hipFree(h->Xb);
+    h->bmu = nullptr; h->xsq = nullptr; h->Xb = nullptr;
     h->N = n_rows;
     h->Np = round_up(n_rows, BF_WG_SAMPLES);
     if (int rc = dev_alloc(h, &h->bmu, (size_t)n_rows)) return rc;
@@ -404,8 +411,7 @@ static int adopt_rows(som_handle* h, int64_t n_rows) {
     }
     if (h->cfg.precision == SOM_PREC_BF16 && n_rows > 0) {
         if (int rc = dev_alloc(h, &h->Xb, (size_t)h->Np * 16 * h->ksteps)) return rc;
-        if (int rc = dev_alloc(h, &h->xsqh, (size_t)h->Np)) return rc;
-        if (int rc = prep_rows_bf16(h, h->Xd, n_rows, h->Np, h->Xb, h->xsqh)) return rc;
+        if (int rc = prep_rows_bf16(h, h->Xd, n_rows, h->Np, h->Xb, h->xmax2)) return rc;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
@@ -437,7 +443,7 @@ int som_epoch_accumulate(som_handle* h, double sigma, double eta, int neigh_f64)
     if (h) (void)hipSetDevice(h->cfg.device);
     if (!h) return 1;
     if (!h->Xd && h->N > 0) return fail(h, "som_epoch_accumulate: no resident data (call som_set_data)");
-    if (int rc = run_activation_bmu(h, h->Xd, h->N, h->xsq, h->Xb, h->xsqh, h->bmu)) return rc;
+    if (int rc = run_activation_bmu(h, h->Xd, h->N, h->xsq, h->Xb, h->xmax2, h->bmu)) return rc;
     return run_update(h, sigma, eta, neigh_f64);
 }
 
@@ -505,8 +511,8 @@ int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, in
     } else {
         if (needs_xsq(h)) if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
         if (h->cfg.precision == SOM_PREC_BF16)
-            if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, BF_WG_SAMPLES), h->qXb, h->qxsqh)) return rc;
-        if (int rc = run_activation_bmu(h, h->qX, n_rows, h->qxsq, h->qXb, h->qxsqh, h->qbmu)) return rc;
+            if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, BF_WG_SAMPLES), h->qXb, h->xmax2 + 1)) return rc;
+        if (int rc = run_activation_bmu(h, h->qX, n_rows, h->qxsq, h->qXb, h->xmax2 + 1, h->qbmu)) return rc;
     }
     HIPCHK(h, hipMemcpyAsync(ids_out, h->qbmu, (size_t)n_rows * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
