@@ -1,0 +1,172 @@
+// Fused distance + BMU argmin, bf16, on v_mfma_f32_16x16x32_bf16.
+//
+// Same arithmetic and the same stage-image idea as bmu_bf16.hpp; only the MFMA shape (and so the
+// fragment geometry) differs.  On random data MI355X holds a higher clock on the 16x16x32 shape
+// than on 32x32x16 at equal cycles per flop (MI355X_MICROARCH.md, DVFS give-back item 7), and
+// this kernel is power/clock-limited, so the shape is a throughput lever by itself.
+//
+// Geometry: A = 16 units x 32 features (lane l: unit l&15, features 8*(l>>4)+j), B = 32 features x
+// 16 samples (lane l: sample l&15), C/D: lane holds sample l&15, units 4*(l>>4)+reg, reg 0..3.
+// A wave keeps 4 x 16 samples' B fragments in registers; one A fragment read from LDS feeds 4 MFMAs.
+// Stage image (128 units): [t16 0..7][kstep32][lane 0..63][8 bf16 of -w~] + [128 x f32 B+|w~|^2/2].
+// Key = (bits & ~31) | (t16<<2 | reg): 5 index bits.
+#pragma once
+#include "bmu_bf16.hpp"
+
+namespace somhip {
+
+constexpr int K16_T = 8;              // 16-unit tiles per 128-unit stage
+constexpr int K16_SB = 4;             // 16-sample blocks per wave (64 samples, as the 32x32 kernel)
+
+__host__ __device__ constexpr int k16_stage_bytes(int ks32) { return (K16_T * ks32 + 1) * 1024; }
+
+template <int KS32>
+__global__ __launch_bounds__(256) void prep_w_bf16_k16_kernel(const float* __restrict__ W, int K, int D,
+                                                              char* __restrict__ Wst, int n_stages) {
+    long id = (long)blockIdx.x * 256 + threadIdx.x;
+    long total = (long)n_stages * K16_T * KS32 * 64;
+    if (id >= total) return;
+    int lane = id & 63;
+    long t = id >> 6;
+    int ks = t % KS32; t /= KS32;
+    int t16 = t % K16_T;
+    long stage = t / K16_T;
+    long u = stage * BF_STAGE_UNITS + t16 * 16 + (lane & 15);
+    int k0 = ks * 32 + (lane >> 4) * 8;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float f = (u < K && k0 + j < D) ? W[u * D + k0 + j] : 0.0f;
+        v[j] = (__bf16)(-f);
+    }
+    *(bf16x8*)(Wst + stage * k16_stage_bytes(KS32) + ((long)(t16 * KS32 + ks) * 64 + lane) * 16) = v;
+}
+
+template <int KS32>
+__global__ __launch_bounds__(256, 2) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
+                                                              const char* __restrict__ Wst, int n_stages, int K,
+                                                              int* __restrict__ out) {
+    constexpr int DP = 32 * KS32;
+    constexpr int STAGE = k16_stage_bytes(KS32);
+    constexpr int PIECES = K16_T * KS32 + 1;
+    constexpr uint32_t IDX_MASK = 31u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int quad = lane >> 4, col = lane & 15;
+    const long wave_s0 = (long)blockIdx.x * BF_WG_SAMPLES + wave * 64;
+
+    bf16x8 xf[K16_SB][KS32];
+#pragma unroll
+    for (int sb = 0; sb < K16_SB; ++sb) {
+        const long row = wave_s0 + sb * 16 + col;
+#pragma unroll
+        for (int ks = 0; ks < KS32; ++ks) xf[sb][ks] = *(const bf16x8*)(Xb + row * DP + ks * 32 + quad * 8);
+    }
+
+    int32_t gbest[K16_SB], cbest[K16_SB];
+    int gstage[K16_SB];
+    f32x4 accP[K16_SB];
+#pragma unroll
+    for (int sb = 0; sb < K16_SB; ++sb) {
+        gbest[sb] = 0x7FFFFFFF; cbest[sb] = 0x7FFFFFFF; gstage[sb] = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accP[sb][r] = __builtin_inff();
+    }
+
+    for (int p = wave; p < PIECES; p += 4) lds_dma_16(Wst + (long)p * 1024 + lane * 16, smem + p * 1024);
+
+    auto reduce_tile = [&](const f32x4 (&acc)[K16_SB], int t16) {
+#pragma unroll
+        for (int sb = 0; sb < K16_SB; ++sb) {
+            int32_t key[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float f = acc[sb][r];
+                key[r] = (int32_t)((__float_as_uint(f) & ~IDX_MASK) | (uint32_t)(t16 * 4 + r));
+            }
+            cbest[sb] = min(min(cbest[sb], key[0]), key[1]);
+            cbest[sb] = min(min(cbest[sb], key[2]), key[3]);
+        }
+    };
+    auto fold_stage = [&](int stage) {
+#pragma unroll
+        for (int sb = 0; sb < K16_SB; ++sb) {
+            if (cbest[sb] < gbest[sb]) { gbest[sb] = cbest[sb]; gstage[sb] = stage; }
+            cbest[sb] = 0x7FFFFFFF;
+        }
+    };
+
+    for (int s = 0; s < n_stages; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + 1 < n_stages) {
+            const char* src = Wst + (long)(s + 1) * STAGE;
+            char* dst = smem + ((s + 1) & 1) * STAGE;
+            for (int p = wave; p < PIECES; p += 4) lds_dma_16(src + (long)p * 1024 + lane * 16, dst + p * 1024);
+        }
+        const char* st = smem + (s & 1) * STAGE;
+        const float* wq = (const float*)(st + K16_T * KS32 * 1024);
+
+        f32x4 wv = *(const f32x4*)(wq + 4 * quad);
+        bf16x8 a[KS32];
+#pragma unroll
+        for (int ks = 0; ks < KS32; ++ks) a[ks] = *(const bf16x8*)(st + ks * 1024 + lane * 16);
+
+#pragma unroll
+        for (int t16 = 0; t16 < K16_T; ++t16) {
+            f32x4 wvN;
+            bf16x8 aN[KS32];
+            if (t16 + 1 < K16_T) {
+                wvN = *(const f32x4*)(wq + (t16 + 1) * 16 + 4 * quad);
+#pragma unroll
+                for (int ks = 0; ks < KS32; ++ks)
+                    aN[ks] = *(const bf16x8*)(st + ((t16 + 1) * KS32 + ks) * 1024 + lane * 16);
+            }
+            f32x4 accT[K16_SB];
+#pragma unroll
+            for (int sb = 0; sb < K16_SB; ++sb) accT[sb] = wv;
+#pragma unroll
+            for (int ks = 0; ks < KS32; ++ks)
+#pragma unroll
+                for (int sb = 0; sb < K16_SB; ++sb)
+                    accT[sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], xf[sb][ks], accT[sb], 0, 0, 0);
+            reduce_tile(accP, (t16 + K16_T - 1) % K16_T);
+            if (t16 == 0) fold_stage(s - 1);
+#pragma unroll
+            for (int sb = 0; sb < K16_SB; ++sb) accP[sb] = accT[sb];
+            if (t16 + 1 < K16_T) {
+                wv = wvN;
+#pragma unroll
+                for (int ks = 0; ks < KS32; ++ks) a[ks] = aN[ks];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < K16_T * K16_SB * KS32; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            if (i % 4 != 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    }
+    reduce_tile(accP, K16_T - 1);
+    fold_stage(n_stages - 1);
+
+#pragma unroll
+    for (int sb = 0; sb < K16_SB; ++sb) {
+        uint32_t code = (uint32_t)gbest[sb] & IDX_MASK;
+        uint32_t unit = (uint32_t)gstage[sb] * BF_STAGE_UNITS + (code >> 2) * 16 + quad * 4 + (code & 3);
+        long long comp = (long long)(((unsigned long long)((uint32_t)gbest[sb] & ~IDX_MASK) << 32) | unit);
+        long long o = __shfl_xor(comp, 16, 64);
+        if (o < comp) comp = o;
+        o = __shfl_xor(comp, 32, 64);
+        if (o < comp) comp = o;
+        uint32_t u = (uint32_t)comp;
+        if (u >= (uint32_t)K) u = 0;
+        const long row = wave_s0 + sb * 16 + col;
+        if (quad == 0 && row < N) out[row] = (int)u;
+    }
+}
+
+}  // namespace somhip

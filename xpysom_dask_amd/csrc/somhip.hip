@@ -6,12 +6,14 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/somhip.h"
 #include "bmu_bf16.hpp"
+#include "bmu_bf16_k16.hpp"
 #include "bmu_f32.hpp"
 #include "update.hpp"
 
@@ -28,7 +30,11 @@ struct EventPair { hipEvent_t a, b; int kernel; };
 struct som_handle {
     som_config cfg{};
     int X = 0, Y = 0, K = 0, D = 0, D1p = 0;
-    int ksteps = 0;          // bf16: ceil(D/16)
+    int ksteps = 0;          // bf16, 32x32x16 shape: ceil(D/16)
+    int ks32 = 0;            // bf16, 16x16x32 shape: ceil(D/32)
+    bool shape16 = true;     // which MFMA shape the bf16 kernel uses
+    int dp = 0;              // feature stride of the bf16 row image
+    int stage_bytes = 0;     // bytes of one 128-unit codebook stage image
     int nt = 1;              // neighbourhood terms
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -121,6 +127,13 @@ int resolve_profile(som_handle* h) {
 }
 
 // ---- codebook-derived operands (w_sq cache, xpysom.py:529-537; bf16 stage image) ------------
+template <int KS32>
+void launch_prep_w_k16(som_handle* h) {
+    long total = (long)h->n_stages * K16_T * KS32 * 64;
+    prep_w_bf16_k16_kernel<KS32><<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->Wst,
+                                                                                             h->n_stages);
+}
+
 template <int KS>
 void launch_prep_w(som_handle* h) {
     long total = (long)h->n_stages * BF_UT * KS * 64;
@@ -132,7 +145,15 @@ int refresh_codebook_operands(som_handle* h) {
     if (!h->w_dirty) return 0;
     Timed t(h, SOM_K_PREP);
     row_sq_f32_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->wsq);
-    if (h->cfg.precision == SOM_PREC_BF16) {
+    if (h->cfg.precision == SOM_PREC_BF16 && h->shape16) {
+        switch (h->ks32) {
+        case 1: launch_prep_w_k16<1>(h); break;
+        case 2: launch_prep_w_k16<2>(h); break;
+        case 3: launch_prep_w_k16<3>(h); break;
+        case 4: launch_prep_w_k16<4>(h); break;
+        default: return fail(h, "bf16 precision supports input_len <= 128");
+        }
+    } else if (h->cfg.precision == SOM_PREC_BF16) {
         switch (h->ksteps) {
         case 1: launch_prep_w<1>(h); break;
         case 2: launch_prep_w<2>(h); break;
@@ -144,6 +165,8 @@ int refresh_codebook_operands(som_handle* h) {
         case 8: launch_prep_w<8>(h); break;
         default: return fail(h, "bf16 precision supports input_len <= 128");
         }
+    }
+    if (h->cfg.precision == SOM_PREC_BF16) {
         HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
         prep_wnorm_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->wn, h->wmax2);
     }
@@ -183,11 +206,32 @@ int launch_bmu_bf16_ks(som_handle* h, const __bf16* Xb, long N, int* out) {
     return 0;
 }
 
+template <int KS32>
+int launch_bmu_bf16_k16(som_handle* h, const __bf16* Xb, long N, int* out) {
+    size_t lds = 2 * (size_t)k16_stage_bytes(KS32);
+    HIPCHK(h, hipFuncSetAttribute((const void*)bmu_bf16_k16_kernel<KS32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+    long grid = cdiv(N, BF_WG_SAMPLES);
+    if (grid <= 0 || grid > 0x7fffffffL) return fail(h, "bmu_bf16: row count out of range");
+    bmu_bf16_k16_kernel<KS32><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(Xb, N, h->Wst, h->n_stages, h->K, out);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 int launch_bmu_bf16(som_handle* h, const __bf16* Xb, const float* xmax2, long N, int* out) {
     // the stage image's initial accumulators depend on the row set through B = xmax * wmax
     long units = (long)h->n_stages * BF_STAGE_UNITS;
     prep_wsqh_kernel<<<dim3((unsigned)cdiv(units, 256)), dim3(256), 0, h->stream>>>(h->wn, h->K, h->wmax2, xmax2, h->Wst,
-                                                                                  h->n_stages, h->ksteps);
+                                                                                  h->n_stages, h->stage_bytes);
+    if (h->shape16) {
+        switch (h->ks32) {
+        case 1: return launch_bmu_bf16_k16<1>(h, Xb, N, out);
+        case 2: return launch_bmu_bf16_k16<2>(h, Xb, N, out);
+        case 3: return launch_bmu_bf16_k16<3>(h, Xb, N, out);
+        case 4: return launch_bmu_bf16_k16<4>(h, Xb, N, out);
+        }
+        return fail(h, "bf16 precision supports input_len <= 128");
+    }
     switch (h->ksteps) {
     case 1: return launch_bmu_bf16_ks<1>(h, Xb, N, out);
     case 2: return launch_bmu_bf16_ks<2>(h, Xb, N, out);
@@ -202,7 +246,7 @@ int launch_bmu_bf16(som_handle* h, const __bf16* Xb, const float* xmax2, long N,
 }
 
 int prep_rows_bf16(som_handle* h, const float* X, long N, long Np, __bf16* Xb, float* xmax2) {
-    const int Dp = 16 * h->ksteps;
+    const int Dp = h->dp;
     HIPCHK(h, hipMemsetAsync(xmax2, 0, sizeof(float), h->stream));
     prep_x_bf16_kernel<<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, Dp, Np, Xb, xmax2);
     HIPCHK(h, hipGetLastError());
@@ -284,7 +328,7 @@ int ensure_query_scratch(som_handle* h, long n) {
     if (int rc = dev_alloc(h, &h->qxsq, (size_t)cap)) return rc;
     if (h->cfg.precision == SOM_PREC_BF16) {
         long capp = round_up(cap, BF_WG_SAMPLES);
-        if (int rc = dev_alloc(h, &h->qXb, (size_t)capp * 16 * h->ksteps)) return rc;
+        if (int rc = dev_alloc(h, &h->qXb, (size_t)capp * h->dp)) return rc;
     }
     h->qcap = cap;
     return 0;
@@ -334,6 +378,13 @@ int som_create(const som_config* cfg, som_handle** out) {
     h->X = cfg->x; h->Y = cfg->y; h->K = cfg->x * cfg->y; h->D = cfg->input_len;
     h->D1p = (int)round_up(h->D + 1, 4);
     h->ksteps = (int)cdiv(h->D, 16);
+    h->ks32 = (int)cdiv(h->D, 32);
+    {   // SOM_BF16_SHAPE=32 selects the 32x32x16 kernel (A/B against the default 16x16x32)
+        const char* e = std::getenv("SOM_BF16_SHAPE");
+        h->shape16 = !(e && std::atoi(e) == 32);
+    }
+    h->dp = h->shape16 ? 32 * h->ks32 : 16 * h->ksteps;
+    h->stage_bytes = h->shape16 ? k16_stage_bytes(h->ks32) : bf_stage_bytes(h->ksteps);
     h->nt = cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT ? 2 : 1;
     int rc = 0;
     auto bail = [&](int code) { g_create_error = h->err; som_destroy(h); return code; };
@@ -358,7 +409,7 @@ int som_create(const som_config* cfg, som_handle** out) {
         return bail(fail(h, "hipMemsetAsync failed"));
     if (cfg->precision == SOM_PREC_BF16) {
         h->n_stages = (int)cdiv(h->K, BF_STAGE_UNITS);
-        size_t bytes = (size_t)h->n_stages * bf_stage_bytes(h->ksteps);
+        size_t bytes = (size_t)h->n_stages * h->stage_bytes;
         if ((rc = dev_alloc(h, &h->Wst, bytes))) return bail(rc);
         if ((rc = dev_alloc(h, &h->xmax2, 2))) return bail(rc);
         if ((rc = dev_alloc(h, &h->wn, (size_t)h->K))) return bail(rc);
@@ -410,7 +461,7 @@ static int adopt_rows(som_handle* h, int64_t n_rows) {
         if (int rc = row_sq(h, h->Xd, n_rows, h->xsq)) return rc;
     }
     if (h->cfg.precision == SOM_PREC_BF16 && n_rows > 0) {
-        if (int rc = dev_alloc(h, &h->Xb, (size_t)h->Np * 16 * h->ksteps)) return rc;
+        if (int rc = dev_alloc(h, &h->Xb, (size_t)h->Np * h->dp)) return rc;
         if (int rc = prep_rows_bf16(h, h->Xd, n_rows, h->Np, h->Xb, h->xmax2)) return rc;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
