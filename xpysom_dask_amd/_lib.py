@@ -5,7 +5,7 @@ import importlib.util
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsomhip.so")
+LIB_PATH = os.environ.get("SOM_LIB_PATH") or os.path.join(HERE, "libsomhip.so")   # override: kernel A/B builds
 
 SOM_DIST = {"euclidean": 0, "euclidean_no_opt": 1, "cosine": 2}
 SOM_NEIGH = {"gaussian": 0, "mexican_hat": 1, "bubble": 2, "triangle": 3}

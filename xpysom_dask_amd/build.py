@@ -29,16 +29,17 @@ def up_to_date():
     return all(os.path.getmtime(d) <= t for d in DEPS)
 
 
-def build(force=False, verbose=True):
-    if not force and up_to_date():
+def build(force=False, verbose=True, extra=(), out=None):
+    """`extra`/`out` build experiment variants (e.g. -DSOM_K16_SB=8) next to the product library."""
+    if not force and not extra and up_to_date():
         return OUT
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-munsafe-fp-atomics", "-Wall", "-Wno-unused-command-line-argument",
-           SRC, "-o", OUT, "-Wl,-rpath,/opt/rocm/lib"]
+           SRC, "-o", out or OUT, "-Wl,-rpath,/opt/rocm/lib"] + list(extra)
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return OUT
+    return out or OUT
 
 
 if __name__ == "__main__":

@@ -87,13 +87,13 @@ __global__ __launch_bounds__(256) void prep_wnorm_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void prep_wsqh_kernel(const float* __restrict__ wn, int K,
                                                         const float* __restrict__ wmax2,
                                                         const float* __restrict__ xmax2, char* __restrict__ Wst,
-                                                        int n_stages, int stage_bytes) {
+                                                        int n_stages, int stage_bytes, int stage_units) {
     long u = (long)blockIdx.x * 256 + threadIdx.x;
-    if (u >= (long)n_stages * BF_STAGE_UNITS) return;
+    if (u >= (long)n_stages * stage_units) return;
     const float big = __builtin_sqrtf(*wmax2) * __builtin_sqrtf(*xmax2) * (1.0f + 1.0f / 1024.0f);
     float s = (u < K) ? __builtin_fmaf(0.5f, wn[u], big) : BF_PAD_NORM;
-    long stage = u / BF_STAGE_UNITS;
-    int within = u % BF_STAGE_UNITS;
+    long stage = u / stage_units;
+    int within = u % stage_units;
     float* dst = (float*)(Wst + (stage + 1) * (long)stage_bytes - 1024);   // the stage's last KiB
     dst[within] = s;
 }

@@ -15,8 +15,16 @@
 
 namespace somhip {
 
-constexpr int K16_T = 8;              // 16-unit tiles per 128-unit stage
-constexpr int K16_SB = 4;             // 16-sample blocks per wave (64 samples, as the 32x32 kernel)
+#ifndef SOM_K16_T
+#define SOM_K16_T 4
+#endif
+constexpr int K16_T = SOM_K16_T;      // 16-unit tiles per stage
+constexpr int K16_STAGE_UNITS = 16 * K16_T;
+#ifndef SOM_K16_SB
+#define SOM_K16_SB 4
+#endif
+constexpr int K16_SB = SOM_K16_SB;    // 16-sample blocks per wave
+constexpr int K16_WG_SAMPLES = 4 * 16 * K16_SB;
 
 __host__ __device__ constexpr int k16_stage_bytes(int ks32) { return (K16_T * ks32 + 1) * 1024; }
 
@@ -31,7 +39,7 @@ __global__ __launch_bounds__(256) void prep_w_bf16_k16_kernel(const float* __res
     int ks = t % KS32; t /= KS32;
     int t16 = t % K16_T;
     long stage = t / K16_T;
-    long u = stage * BF_STAGE_UNITS + t16 * 16 + (lane & 15);
+    long u = stage * K16_STAGE_UNITS + t16 * 16 + (lane & 15);
     int k0 = ks * 32 + (lane >> 4) * 8;
     bf16x8 v;
 #pragma unroll
@@ -49,13 +57,13 @@ __global__ __launch_bounds__(256, 2) void bmu_bf16_k16_kernel(const __bf16* __re
     constexpr int DP = 32 * KS32;
     constexpr int STAGE = k16_stage_bytes(KS32);
     constexpr int PIECES = K16_T * KS32 + 1;
-    constexpr uint32_t IDX_MASK = 31u;
+    constexpr uint32_t IDX_MASK = 4 * K16_T - 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int quad = lane >> 4, col = lane & 15;
-    const long wave_s0 = (long)blockIdx.x * BF_WG_SAMPLES + wave * 64;
+    const long wave_s0 = (long)blockIdx.x * K16_WG_SAMPLES + wave * (16 * K16_SB);
 
     bf16x8 xf[K16_SB][KS32];
 #pragma unroll
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void bmu_bf16_k16_kernel(const __bf16* __re
 #pragma unroll
     for (int sb = 0; sb < K16_SB; ++sb) {
         uint32_t code = (uint32_t)gbest[sb] & IDX_MASK;
-        uint32_t unit = (uint32_t)gstage[sb] * BF_STAGE_UNITS + (code >> 2) * 16 + quad * 4 + (code & 3);
+        uint32_t unit = (uint32_t)gstage[sb] * K16_STAGE_UNITS + (code >> 2) * 16 + quad * 4 + (code & 3);
         long long comp = (long long)(((unsigned long long)((uint32_t)gbest[sb] & ~IDX_MASK) << 32) | unit);
         long long o = __shfl_xor(comp, 16, 64);
         if (o < comp) comp = o;

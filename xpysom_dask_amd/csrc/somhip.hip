@@ -4,6 +4,9 @@
 // there is no CPU fallback: every path either launches the HIP kernels or fails.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -34,7 +37,8 @@ struct som_handle {
     int ks32 = 0;            // bf16, 16x16x32 shape: ceil(D/32)
     bool shape16 = true;     // which MFMA shape the bf16 kernel uses
     int dp = 0;              // feature stride of the bf16 row image
-    int stage_bytes = 0;     // bytes of one 128-unit codebook stage image
+    int stage_bytes = 0;     // bytes of one codebook stage image
+    int stage_units = 0;     // units per stage
     int nt = 1;              // neighbourhood terms
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -49,6 +53,9 @@ struct som_handle {
     float* X_owned = nullptr;
     long N = 0, Np = 0;
     int* bmu = nullptr;
+    int *iota = nullptr, *skey = nullptr, *srow = nullptr;   // BMU-ordered view of the rows (segment sum)
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
     float* xsq = nullptr;
     __bf16* Xb = nullptr;
     float* xmax2 = nullptr;  // [0] resident rows, [1] query scratch: max_n |x~_n|^2
@@ -94,6 +101,7 @@ int dev_alloc(som_handle* h, T** p, size_t count) {
 
 inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 inline long round_up(long a, long b) { return cdiv(a, b) * b; }
+constexpr long ROW_PAD = 1024;   // bf16 row images are padded to a multiple of every kernel's workgroup tile
 
 // ---- profiling: event pairs recorded around kernel families, resolved lazily ---------------
 struct Timed {
@@ -213,6 +221,7 @@ int launch_bmu_bf16_k16(som_handle* h, const __bf16* Xb, long N, int* out) {
                                   (int)lds));
     long grid = cdiv(N, BF_WG_SAMPLES);
     if (grid <= 0 || grid > 0x7fffffffL) return fail(h, "bmu_bf16: row count out of range");
+    grid = cdiv(N, K16_WG_SAMPLES);
     bmu_bf16_k16_kernel<KS32><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(Xb, N, h->Wst, h->n_stages, h->K, out);
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -220,9 +229,9 @@ int launch_bmu_bf16_k16(som_handle* h, const __bf16* Xb, long N, int* out) {
 
 int launch_bmu_bf16(som_handle* h, const __bf16* Xb, const float* xmax2, long N, int* out) {
     // the stage image's initial accumulators depend on the row set through B = xmax * wmax
-    long units = (long)h->n_stages * BF_STAGE_UNITS;
+    long units = (long)h->n_stages * h->stage_units;
     prep_wsqh_kernel<<<dim3((unsigned)cdiv(units, 256)), dim3(256), 0, h->stream>>>(h->wn, h->K, h->wmax2, xmax2, h->Wst,
-                                                                                  h->n_stages, h->stage_bytes);
+                                                                                  h->n_stages, h->stage_bytes, h->stage_units);
     if (h->shape16) {
         switch (h->ks32) {
         case 1: return launch_bmu_bf16_k16<1>(h, Xb, N, out);
@@ -286,10 +295,14 @@ int run_update(som_handle* h, double sigma, double eta, int neigh_f64) {
         Timed t(h, SOM_K_SEGSUM);
         HIPCHK(h, hipMemsetAsync(h->SC, 0, KD1 * sizeof(float), h->stream));
         if (h->N > 0) {
-            long total = h->N * (h->D + 1);
-            long grid = cdiv(total, 256);
-            if (grid > 0x7fffffffL) return fail(h, "segsum: too many rows for one launch");
-            segsum_kernel<<<dim3((unsigned)grid), dim3(256), 0, h->stream>>>(h->Xd, h->bmu, h->N, h->D, h->D1p, h->SC);
+            int bits = 1;
+            while ((1L << bits) < h->K) ++bits;
+            hipError_t e = rocprim::radix_sort_pairs(h->sort_tmp, h->sort_tmp_bytes, h->bmu, h->skey, h->iota, h->srow,
+                                                     (size_t)h->N, 0u, (unsigned)bits, h->stream);
+            if (e != hipSuccess) return fail_hip(h, "rocprim::radix_sort_pairs", e);
+            long waves = cdiv(h->N, SEG_CHUNK);
+            segsum_sorted_kernel<<<dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, h->stream>>>(h->Xd, h->skey, h->srow, h->N,
+                                                                                           h->D, h->D1p, h->SC);
             HIPCHK(h, hipGetLastError());
         }
     }
@@ -327,7 +340,7 @@ int ensure_query_scratch(som_handle* h, long n) {
     if (int rc = dev_alloc(h, &h->qbmu, (size_t)cap)) return rc;
     if (int rc = dev_alloc(h, &h->qxsq, (size_t)cap)) return rc;
     if (h->cfg.precision == SOM_PREC_BF16) {
-        long capp = round_up(cap, BF_WG_SAMPLES);
+        long capp = round_up(cap, ROW_PAD);
         if (int rc = dev_alloc(h, &h->qXb, (size_t)capp * h->dp)) return rc;
     }
     h->qcap = cap;
@@ -385,6 +398,7 @@ int som_create(const som_config* cfg, som_handle** out) {
     }
     h->dp = h->shape16 ? 32 * h->ks32 : 16 * h->ksteps;
     h->stage_bytes = h->shape16 ? k16_stage_bytes(h->ks32) : bf_stage_bytes(h->ksteps);
+    h->stage_units = h->shape16 ? K16_STAGE_UNITS : BF_STAGE_UNITS;
     h->nt = cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT ? 2 : 1;
     int rc = 0;
     auto bail = [&](int code) { g_create_error = h->err; som_destroy(h); return code; };
@@ -408,7 +422,7 @@ int som_create(const som_config* cfg, som_handle** out) {
         hipMemsetAsync(h->ACC, 0, KD1 * sizeof(float), h->stream) != hipSuccess)
         return bail(fail(h, "hipMemsetAsync failed"));
     if (cfg->precision == SOM_PREC_BF16) {
-        h->n_stages = (int)cdiv(h->K, BF_STAGE_UNITS);
+        h->n_stages = (int)cdiv(h->K, h->stage_units);
         size_t bytes = (size_t)h->n_stages * h->stage_bytes;
         if ((rc = dev_alloc(h, &h->Wst, bytes))) return bail(rc);
         if ((rc = dev_alloc(h, &h->xmax2, 2))) return bail(rc);
@@ -427,7 +441,8 @@ void som_destroy(som_handle* h) {
     for (auto& ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto& ep : h->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     void* bufs[] = {h->W, h->wsq, h->SC, h->T, h->ACC, h->P1, h->P2, h->Wst, h->X_owned, h->bmu, h->xsq, h->Xb,
-                    h->xmax2, h->wn, h->wmax2, h->qX, h->qbmu, h->qxsq, h->qXb, h->dsum};
+                    h->xmax2, h->wn, h->wmax2, h->qX, h->qbmu, h->qxsq, h->qXb, h->dsum, h->iota, h->skey, h->srow,
+                    h->sort_tmp};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -452,10 +467,25 @@ int som_get_weights(som_handle* h, float* w_host) {
 
 static int adopt_rows(som_handle* h, int64_t n_rows) {
     (void)hipFree(h->bmu); (void)hipFree(h->xsq); (void)hipFree(h->Xb);
+    (void)hipFree(h->iota); (void)hipFree(h->skey); (void)hipFree(h->srow); (void)hipFree(h->sort_tmp);
     h->bmu = nullptr; h->xsq = nullptr; h->Xb = nullptr;
+    h->iota = nullptr; h->skey = nullptr; h->srow = nullptr; h->sort_tmp = nullptr; h->sort_tmp_bytes = 0;
     h->N = n_rows;
-    h->Np = round_up(n_rows, BF_WG_SAMPLES);
+    h->Np = round_up(n_rows, ROW_PAD);
     if (int rc = dev_alloc(h, &h->bmu, (size_t)n_rows)) return rc;
+    if (n_rows > 0) {
+        if (n_rows > 0x7fffffffL) return fail(h, "som_set_data: more than 2^31-1 rows per GPU");
+        if (int rc = dev_alloc(h, &h->iota, (size_t)n_rows)) return rc;
+        if (int rc = dev_alloc(h, &h->skey, (size_t)n_rows)) return rc;
+        if (int rc = dev_alloc(h, &h->srow, (size_t)n_rows)) return rc;
+        iota_kernel<<<dim3((unsigned)cdiv(n_rows, 256)), dim3(256), 0, h->stream>>>(h->iota, n_rows);
+        size_t bytes = 0;
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, h->bmu, h->skey, h->iota, h->srow, (size_t)n_rows, 0u,
+                                                 32u, h->stream);
+        if (e != hipSuccess) return fail_hip(h, "rocprim::radix_sort_pairs(size query)", e);
+        if (int rc = dev_alloc(h, (char**)&h->sort_tmp, bytes)) return rc;
+        h->sort_tmp_bytes = bytes;
+    }
     if (needs_xsq(h)) {
         if (int rc = dev_alloc(h, &h->xsq, (size_t)n_rows)) return rc;
         if (int rc = row_sq(h, h->Xd, n_rows, h->xsq)) return rc;
@@ -562,7 +592,7 @@ int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, in
     } else {
         if (needs_xsq(h)) if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
         if (h->cfg.precision == SOM_PREC_BF16)
-            if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, BF_WG_SAMPLES), h->qXb, h->xmax2 + 1)) return rc;
+            if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1)) return rc;
         if (int rc = run_activation_bmu(h, h->qX, n_rows, h->qxsq, h->qXb, h->xmax2 + 1, h->qbmu)) return rc;
     }
     HIPCHK(h, hipMemcpyAsync(ids_out, h->qbmu, (size_t)n_rows * sizeof(int), hipMemcpyDeviceToHost, h->stream));

@@ -18,18 +18,66 @@
 
 namespace somhip {
 
-// ---- segment sum: SC[bmu[n]][0..D-1] += x_n ; SC[bmu[n]][D] += 1 ------------------------------
-// One thread per (sample, feature): a wave-instruction adds 256 contiguous bytes of one or a
-// few accumulator rows (the shape global_atomic_add_f32 runs at full rate with).
-__global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ X, const int* __restrict__ bmu,
-                                                     long N, int D, int D1p, float* __restrict__ SC) {
+// ---- segment sum: SC[b][0..D-1] = sum_{bmu_n = b} x_n ; SC[b][D] = #{bmu_n = b} ------------------
+// The rows are first ordered by BMU (stable radix sort of (bmu_n, n) pairs, rocPRIM), then every
+// wave walks a chunk of SEG_CHUNK consecutive sorted positions, keeps the running sum of the
+// current unit in registers (lane = feature) and adds it to HBM only when the unit changes or the
+// chunk ends.  Row gathers are whole 4*D-byte rows (coalesced per row); float atomics shrink from
+// N rows to about K + N/SEG_CHUNK rows, so the pass is bound by reading X once (N*D*4 bytes).
+// A unit whose run lies inside one chunk (the common case) gets exactly one add onto the zeroed
+// accumulator, a run cut by one chunk boundary two (commutative): those sums are reproducible.
+constexpr int SEG_CHUNK = 32;
+
+__global__ __launch_bounds__(256) void iota_kernel(int* __restrict__ v, long n) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const int D1 = D + 1;
-    if (i >= N * D1) return;
-    long n = i / D1;
-    int d = (int)(i - n * D1);
-    float v = d < D ? X[n * D + d] : 1.0f;
-    unsafeAtomicAdd(&SC[(long)bmu[n] * D1p + d], v);
+    if (i < n) v[i] = (int)i;
+}
+
+__global__ __launch_bounds__(256) void segsum_sorted_kernel(const float* __restrict__ X,
+                                                            const int* __restrict__ skey,
+                                                            const int* __restrict__ srow, long N, int D, int D1p,
+                                                            float* __restrict__ SC) {
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long p0 = wid * SEG_CHUNK;
+    if (p0 >= N) return;
+    const int cnt_here = (int)((N - p0 < SEG_CHUNK) ? (N - p0) : SEG_CHUNK);
+    // lane i < cnt_here holds the i-th (unit, row) pair of the chunk
+    const int my_key = lane < cnt_here ? skey[p0 + lane] : -1;
+    const int my_row = lane < cnt_here ? srow[p0 + lane] : 0;
+    for (int f0 = 0; f0 < D; f0 += 256) {                 // 4 features per lane per sweep
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int cur = __builtin_amdgcn_readfirstlane(my_key);
+        int run = 0;
+        for (int i = 0; i < cnt_here; ++i) {
+            const int b = __builtin_amdgcn_readlane(my_key, i);
+            const long row = __builtin_amdgcn_readlane(my_row, i);
+            if (b != cur) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int d = f0 + lane + 64 * j;
+                    if (d < D) unsafeAtomicAdd(&SC[(long)cur * D1p + d], acc[j]);
+                    acc[j] = 0.f;
+                }
+                if (f0 == 0 && lane == 0) unsafeAtomicAdd(&SC[(long)cur * D1p + D], (float)run);
+                cur = b;
+                run = 0;
+            }
+            const float* x = X + row * D;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int d = f0 + lane + 64 * j;
+                if (d < D) acc[j] += x[d];
+            }
+            ++run;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int d = f0 + lane + 64 * j;
+            if (d < D) unsafeAtomicAdd(&SC[(long)cur * D1p + d], acc[j]);
+        }
+        if (f0 == 0 && lane == 0) unsafeAtomicAdd(&SC[(long)cur * D1p + D], (float)run);
+    }
 }
 
 // ---- neighbourhood factor tables ---------------------------------------------------------------
