@@ -9,7 +9,12 @@
 // 16 samples (lane l: sample l&15), C/D: lane holds sample l&15, units 4*(l>>4)+reg, reg 0..3.
 // A wave keeps 4 x 16 samples' B fragments in registers; one A fragment read from LDS feeds 4 MFMAs.
 // Stage image (128 units): [t16 0..7][kstep32][lane 0..63][8 bf16 of -w~] + [128 x f32 B+|w~|^2/2].
-// Key = (bits & ~31) | (t16<<2 | reg): 5 index bits.
+// Key = (bits & ~mask) | (t16<<2 | reg).
+//
+// Grid = (sample blocks) x (codebook parts): a workgroup scans only its part of the stages and
+// merges its winner into out64[n] = (value bits << 32 | unit) with a 64-bit atomicMin.  The host
+// picks the number of parts so that the grid fills whole rounds of the resident workgroup slots
+// (4096 blocks on 768 slots would idle 11 % in the last round; 4096 x 3 parts is exactly 16).
 #pragma once
 #include "bmu_bf16.hpp"
 
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(256) void prep_w_bf16_k16_kernel(const float* __res
 template <int KS32>
 __global__ __launch_bounds__(256, 2) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
                                                               const char* __restrict__ Wst, int n_stages, int K,
-                                                              int* __restrict__ out) {
+                                                              unsigned long long* __restrict__ out64) {
     constexpr int DP = 32 * KS32;
     constexpr int STAGE = k16_stage_bytes(KS32);
     constexpr int PIECES = K16_T * KS32 + 1;
@@ -83,7 +88,11 @@ __global__ __launch_bounds__(256, 2) void bmu_bf16_k16_kernel(const __bf16* __re
         for (int r = 0; r < 4; ++r) accP[sb][r] = __builtin_inff();
     }
 
-    for (int p = wave; p < PIECES; p += 4) lds_dma_16(Wst + (long)p * 1024 + lane * 16, smem + p * 1024);
+    // this workgroup's share of the codebook stages
+    const int s_begin = (int)((long)n_stages * blockIdx.y / gridDim.y);
+    const int s_end = (int)((long)n_stages * (blockIdx.y + 1) / gridDim.y);
+    for (int p = wave; p < PIECES; p += 4)
+        lds_dma_16(Wst + (long)s_begin * STAGE + (long)p * 1024 + lane * 16, smem + p * 1024);
 
     auto reduce_tile = [&](const f32x4 (&acc)[K16_SB], int t16) {
 #pragma unroll
@@ -106,16 +115,16 @@ __global__ __launch_bounds__(256, 2) void bmu_bf16_k16_kernel(const __bf16* __re
         }
     };
 
-    for (int s = 0; s < n_stages; ++s) {
+    for (int s = s_begin; s < s_end; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + 1 < n_stages) {
+        if (s + 1 < s_end) {
             const char* src = Wst + (long)(s + 1) * STAGE;
-            char* dst = smem + ((s + 1) & 1) * STAGE;
+            char* dst = smem + ((s + 1 - s_begin) & 1) * STAGE;
             for (int p = wave; p < PIECES; p += 4) lds_dma_16(src + (long)p * 1024 + lane * 16, dst + p * 1024);
         }
-        const char* st = smem + (s & 1) * STAGE;
+        const char* st = smem + ((s - s_begin) & 1) * STAGE;
         const float* wq = (const float*)(st + K16_T * KS32 * 1024);
 
         f32x4 wv = *(const f32x4*)(wq + 4 * quad);
@@ -159,22 +168,30 @@ __global__ __launch_bounds__(256, 2) void bmu_bf16_k16_kernel(const __bf16* __re
         }
     }
     reduce_tile(accP, K16_T - 1);
-    fold_stage(n_stages - 1);
+    fold_stage(s_end - 1);
 
 #pragma unroll
     for (int sb = 0; sb < K16_SB; ++sb) {
         uint32_t code = (uint32_t)gbest[sb] & IDX_MASK;
         uint32_t unit = (uint32_t)gstage[sb] * K16_STAGE_UNITS + (code >> 2) * 16 + quad * 4 + (code & 3);
-        long long comp = (long long)(((unsigned long long)((uint32_t)gbest[sb] & ~IDX_MASK) << 32) | unit);
-        long long o = __shfl_xor(comp, 16, 64);
+        // all distances are positive floats: (value bits, unit) orders as one unsigned 64-bit key
+        unsigned long long comp = ((unsigned long long)((uint32_t)gbest[sb] & ~IDX_MASK) << 32) | unit;
+        unsigned long long o = __shfl_xor(comp, 16, 64);
         if (o < comp) comp = o;
         o = __shfl_xor(comp, 32, 64);
         if (o < comp) comp = o;
-        uint32_t u = (uint32_t)comp;
-        if (u >= (uint32_t)K) u = 0;
         const long row = wave_s0 + sb * 16 + col;
-        if (quad == 0 && row < N) out[row] = (int)u;
+        if (quad == 0 && row < N) atomicMin(out64 + row, comp);
     }
+}
+
+// out64 -> raveled ids (a padding unit can only win on a NaN row: numpy's argmin gives 0 there)
+__global__ __launch_bounds__(256) void bmu_finalize_kernel(const unsigned long long* __restrict__ out64, long N, int K,
+                                                           int* __restrict__ out) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    uint32_t u = (uint32_t)out64[i];
+    out[i] = u < (uint32_t)K ? (int)u : 0;
 }
 
 }  // namespace somhip

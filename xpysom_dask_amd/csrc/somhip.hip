@@ -53,6 +53,9 @@ struct som_handle {
     float* X_owned = nullptr;
     long N = 0, Np = 0;
     int* bmu = nullptr;
+    unsigned long long* best64 = nullptr;   // bf16 path: per-row (value bits | unit) merged across codebook parts
+    long best64_cap = 0;
+    int n_cus = 0;
     int *iota = nullptr, *skey = nullptr, *srow = nullptr;   // BMU-ordered view of the rows (segment sum)
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
@@ -219,10 +222,40 @@ int launch_bmu_bf16_k16(som_handle* h, const __bf16* Xb, long N, int* out) {
     size_t lds = 2 * (size_t)k16_stage_bytes(KS32);
     HIPCHK(h, hipFuncSetAttribute((const void*)bmu_bf16_k16_kernel<KS32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
-    long grid = cdiv(N, BF_WG_SAMPLES);
-    if (grid <= 0 || grid > 0x7fffffffL) return fail(h, "bmu_bf16: row count out of range");
-    grid = cdiv(N, K16_WG_SAMPLES);
-    bmu_bf16_k16_kernel<KS32><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(Xb, N, h->Wst, h->n_stages, h->K, out);
+    long blocks = cdiv(N, K16_WG_SAMPLES);
+    if (blocks <= 0 || blocks > 0x7fffffffL) return fail(h, "bmu_bf16: row count out of range");
+    // split the codebook scan into `parts` so the grid fills whole rounds of resident workgroups
+    int per_cu = 0;
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)bmu_bf16_k16_kernel<KS32>, 256, lds));
+    const long slots = (long)(per_cu > 0 ? per_cu : 1) * (h->n_cus > 0 ? h->n_cus : 256);
+    int parts = 1;
+    if (blocks < slots) {                       // few rows (winner / small data): spread the scan itself
+        parts = (int)(slots / blocks);
+        if (parts > 8) parts = 8;
+    } else {
+        double best_eff = 0.0;
+        for (int p = 1; p <= 4; ++p) {
+            long wgs = blocks * p;
+            double eff = (double)wgs / (double)(cdiv(wgs, slots) * slots);
+            if (eff > best_eff + 0.02) { best_eff = eff; parts = p; }
+        }
+    }
+    if (parts > h->n_stages) parts = h->n_stages;
+    if (parts < 1) parts = 1;
+    if (const char* e = std::getenv("SOM_BF16_PARTS")) parts = std::atoi(e) > 0 ? std::atoi(e) : parts;   // experiments
+    if (std::getenv("SOM_DEBUG"))
+        std::fprintf(stderr, "[somhip] bmu_bf16_k16: blocks=%ld per_cu=%d cus=%d slots=%ld parts=%d stages=%d\n", blocks,
+                     per_cu, h->n_cus, slots, parts, h->n_stages);
+    if (N > h->best64_cap) {
+        (void)hipFree(h->best64);
+        h->best64 = nullptr; h->best64_cap = 0;
+        if (int rc = dev_alloc(h, &h->best64, (size_t)round_up(N, 1024))) return rc;
+        h->best64_cap = round_up(N, 1024);
+    }
+    HIPCHK(h, hipMemsetAsync(h->best64, 0xFF, (size_t)N * sizeof(unsigned long long), h->stream));
+    bmu_bf16_k16_kernel<KS32><<<dim3((unsigned)blocks, (unsigned)parts), dim3(256), lds, h->stream>>>(
+        Xb, N, h->Wst, h->n_stages, h->K, h->best64);
+    bmu_finalize_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(h->best64, N, h->K, out);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -403,6 +436,10 @@ int som_create(const som_config* cfg, som_handle** out) {
     int rc = 0;
     auto bail = [&](int code) { g_create_error = h->err; som_destroy(h); return code; };
     if (hipSetDevice(cfg->device) != hipSuccess) return bail(fail(h, "hipSetDevice failed"));
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) h->n_cus = prop.multiProcessorCount;
+    }
     if (cfg->stream) { h->stream = (hipStream_t)cfg->stream; }
     else {
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
@@ -442,7 +479,7 @@ void som_destroy(som_handle* h) {
     for (auto& ep : h->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     void* bufs[] = {h->W, h->wsq, h->SC, h->T, h->ACC, h->P1, h->P2, h->Wst, h->X_owned, h->bmu, h->xsq, h->Xb,
                     h->xmax2, h->wn, h->wmax2, h->qX, h->qbmu, h->qxsq, h->qXb, h->dsum, h->iota, h->skey, h->srow,
-                    h->sort_tmp};
+                    h->sort_tmp, h->best64};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
