@@ -431,3 +431,29 @@ def test_rccl_allreduce_runs_in_place_on_the_engine_buffer(tmp_path):
     env = dict(os.environ, SOM_REPO=REPO, SOM_PORT=str(port))
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "nccl-path-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bf16_cosine_picks_near_best_similarity():
+    """'cosine' in bf16 mode (BASELINE configs[4] semantics at D <= 128): unit-length codebook
+    image, argmax of x~.w^~.  Exactly the reference's pick unless two similarities are closer than
+    the bf16 operand rounding."""
+    X, Y, D, n = 20, 20, 24, 2000
+    data = np.abs(O.gaussian_blobs(n, D, seed=21))
+    data[7] = 0.0                                             # zero row: all distances 1 -> unit 0
+    w = np.abs(O.default_codebook(X, Y, D, 4)).astype(F32) * 2.5
+    w[3, 3] = 0.0                                             # zero unit: similarity nan_to_num(0/0) = 0
+    ref = O.bmu_ids(data, w.reshape(-1, D), "cosine")
+    e = engine(X, Y, D, distance="cosine", precision="bf16")
+    e.set_weights(w)
+    got = e.bmu(data)
+    assert got[7] == ref[7] == 0
+    x64, w64 = data.astype(np.float64), w.reshape(-1, D).astype(np.float64)
+    with np.errstate(all="ignore"):
+        sim = np.nan_to_num((x64 @ w64.T) / np.sqrt((x64 ** 2).sum(1)[:, None] * (w64 ** 2).sum(1)[None, :]))
+    chosen = sim[np.arange(n), got]
+    assert (chosen >= sim.max(1) - 2.0 ** -7).all()
+    assert (got != ref).mean() < 0.2
+    # and a full epoch runs through the same update path
+    e.set_data(data)
+    e.epoch(5.0, 0.5, False)
+    assert np.isfinite(e.get_weights()).all()

@@ -72,12 +72,15 @@ __device__ __forceinline__ void atomic_max_pos_f32(float* addr, float v) {
 
 // |w~|^2 of every unit (bf16-rounded values) and its maximum over the codebook
 __global__ __launch_bounds__(256) void prep_wnorm_kernel(const float* __restrict__ W, int K, int D,
-                                                         float* __restrict__ wn, float* __restrict__ wmax2) {
+                                                         float* __restrict__ wn, float* __restrict__ wmax2,
+                                                         const float* __restrict__ unit_wsq) {
     long u = (long)blockIdx.x * 256 + threadIdx.x;
     float s = 0.0f;
     if (u < K) {
-        for (int k = 0; k < D; ++k) { float f = (float)(__bf16)W[u * D + k]; s = __builtin_fmaf(f, f, s); }
-        wn[u] = s;
+        float scale = 1.0f;       // cosine: the stage image holds unit-length rows and no norm term
+        if (unit_wsq != nullptr) { float q = unit_wsq[u]; scale = q > 0.0f ? 1.0f / __builtin_sqrtf(q) : 0.0f; }
+        for (int k = 0; k < D; ++k) { float f = (float)(__bf16)(W[u * D + k] * scale); s = __builtin_fmaf(f, f, s); }
+        wn[u] = unit_wsq != nullptr ? 0.0f : s;
     }
     float m = s;
 #pragma unroll

@@ -35,7 +35,8 @@ __host__ __device__ constexpr int k16_stage_bytes(int ks32) { return (K16_T * ks
 
 template <int KS32>
 __global__ __launch_bounds__(256) void prep_w_bf16_k16_kernel(const float* __restrict__ W, int K, int D,
-                                                              char* __restrict__ Wst, int n_stages) {
+                                                              char* __restrict__ Wst, int n_stages,
+                                                              const float* __restrict__ unit_wsq) {
     long id = (long)blockIdx.x * 256 + threadIdx.x;
     long total = (long)n_stages * K16_T * KS32 * 64;
     if (id >= total) return;
@@ -46,10 +47,15 @@ __global__ __launch_bounds__(256) void prep_w_bf16_k16_kernel(const float* __res
     long stage = t / K16_T;
     long u = stage * K16_STAGE_UNITS + t16 * 16 + (lane & 15);
     int k0 = ks * 32 + (lane >> 4) * 8;
+    // cosine distance (distances.py:45-59): rows are scaled to unit length, so that
+    // argmin_k (B - x~ . w^~_k) == argmin_k (1 - x.w_k/(|x||w_k|)); a zero row stays zero
+    // (its similarity is nan_to_num(0/0) = 0 in the reference, and x~ . 0 = 0 here).
+    float scale = 1.0f;
+    if (unit_wsq != nullptr && u < K) { float q = unit_wsq[u]; scale = q > 0.0f ? 1.0f / __builtin_sqrtf(q) : 0.0f; }
     bf16x8 v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        float f = (u < K && k0 + j < D) ? W[u * D + k0 + j] : 0.0f;
+        float f = (u < K && k0 + j < D) ? W[u * D + k0 + j] * scale : 0.0f;
         v[j] = (__bf16)(-f);
     }
     *(bf16x8*)(Wst + stage * k16_stage_bytes(KS32) + ((long)(t16 * KS32 + ks) * 64 + lane) * 16) = v;

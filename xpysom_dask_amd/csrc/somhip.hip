@@ -141,8 +141,8 @@ int resolve_profile(som_handle* h) {
 template <int KS32>
 void launch_prep_w_k16(som_handle* h) {
     long total = (long)h->n_stages * K16_T * KS32 * 64;
-    prep_w_bf16_k16_kernel<KS32><<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->Wst,
-                                                                                             h->n_stages);
+    prep_w_bf16_k16_kernel<KS32><<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
+        h->W, h->K, h->D, h->Wst, h->n_stages, h->cfg.distance == SOM_DIST_COSINE ? h->wsq : nullptr);
 }
 
 template <int KS>
@@ -179,7 +179,8 @@ int refresh_codebook_operands(som_handle* h) {
     }
     if (h->cfg.precision == SOM_PREC_BF16) {
         HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
-        prep_wnorm_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->wn, h->wmax2);
+        prep_wnorm_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(
+            h->W, h->K, h->D, h->wn, h->wmax2, h->cfg.distance == SOM_DIST_COSINE ? h->wsq : nullptr);
     }
     HIPCHK(h, hipGetLastError());
     h->w_dirty = false;
@@ -410,8 +411,11 @@ int som_create(const som_config* cfg, som_handle** out) {
     if (cfg->precision != SOM_PREC_F32 && cfg->precision != SOM_PREC_BF16)
         return fail(nullptr, "som_create: unknown precision id");
     if (cfg->precision == SOM_PREC_BF16) {
-        if (cfg->distance != SOM_DIST_EUCLIDEAN)
-            return fail(nullptr, "som_create: bf16 precision implements the 'euclidean' distance only");
+        if (cfg->distance == SOM_DIST_EUCLIDEAN_NO_OPT)
+            return fail(nullptr, "som_create: bf16 precision implements 'euclidean' and 'cosine' "
+                                 "('euclidean_no_opt' has the same argmin as 'euclidean')");
+        if (cfg->distance == SOM_DIST_COSINE && std::getenv("SOM_BF16_SHAPE") && std::atoi(std::getenv("SOM_BF16_SHAPE")) == 32)
+            return fail(nullptr, "som_create: cosine in bf16 needs the default 16x16x32 kernel");
         if (cfg->input_len > 128) return fail(nullptr, "som_create: bf16 precision supports input_len <= 128");
     }
     int ndev = 0;
