@@ -18,6 +18,7 @@
 #include "bmu_bf16.hpp"
 #include "bmu_bf16_k16.hpp"
 #include "bmu_f32.hpp"
+#include "bmu_f32_res.hpp"
 #include "update.hpp"
 
 using namespace somhip;
@@ -45,6 +46,8 @@ struct som_handle {
 
     float *W = nullptr, *wsq = nullptr, *SC = nullptr, *T = nullptr, *ACC = nullptr, *P1 = nullptr, *P2 = nullptr;
     char* Wst = nullptr;
+    char* Wfst = nullptr;    // f32 parity mode, input_len <= 128: float32 stage image (bmu_f32_res.hpp)
+    int fr_kg = 0, fr_stages = 0;
     int n_stages = 0;
     bool w_dirty = true;     // wsq / bf16 stage image out of date w.r.t. W
 
@@ -156,6 +159,11 @@ int refresh_codebook_operands(som_handle* h) {
     if (!h->w_dirty) return 0;
     Timed t(h, SOM_K_PREP);
     row_sq_f32_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->wsq);
+    if (h->Wfst) {
+        long total = (long)h->fr_stages * ((long)FR_UT * h->fr_kg * 64 + 64);
+        prep_w_f32_res_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(h->W, h->wsq, h->K, h->D,
+                                                                                          h->fr_kg, h->Wfst, h->fr_stages);
+    }
     if (h->cfg.precision == SOM_PREC_BF16 && h->shape16) {
         switch (h->ks32) {
         case 1: launch_prep_w_k16<1>(h); break;
@@ -204,6 +212,32 @@ int launch_bmu_f32(som_handle* h, const float* X, long N, const float* xsq, int*
                                                                              x_resident, out);
     HIPCHK(h, hipGetLastError());
     return 0;
+}
+
+template <int MODE, int KG>
+int launch_bmu_f32_res_kg(som_handle* h, const float* X, long N, const float* xsq, int* out) {
+    size_t lds = 2 * (size_t)fr_stage_bytes(KG);
+    HIPCHK(h, hipFuncSetAttribute((const void*)bmu_f32_res_kernel<MODE, KG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+    long grid = cdiv(N, FR_WG_SAMPLES);
+    if (grid <= 0 || grid > 0x7fffffffL) return fail(h, "bmu_f32: row count out of range");
+    bmu_f32_res_kernel<MODE, KG><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, N, h->D, xsq, h->Wfst,
+                                                                                     h->fr_stages, h->K, out);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+template <int MODE>
+int launch_bmu_f32_any(som_handle* h, const float* X, long N, const float* xsq, int* out) {
+    if (!h->Wfst) return launch_bmu_f32<MODE>(h, X, N, xsq, out);     // input_len > 128: LDS-chunked kernel
+    switch (h->fr_kg) {
+    case 1: return launch_bmu_f32_res_kg<MODE, 1>(h, X, N, xsq, out);
+    case 2: return launch_bmu_f32_res_kg<MODE, 2>(h, X, N, xsq, out);
+    case 4: return launch_bmu_f32_res_kg<MODE, 4>(h, X, N, xsq, out);
+    case 8: return launch_bmu_f32_res_kg<MODE, 8>(h, X, N, xsq, out);
+    case 16: return launch_bmu_f32_res_kg<MODE, 16>(h, X, N, xsq, out);
+    }
+    return fail(h, "bmu_f32: bad k-group count");
 }
 
 template <int KS>
@@ -304,9 +338,9 @@ int run_activation_bmu(som_handle* h, const float* X, long N, const float* xsq, 
     Timed t(h, SOM_K_BMU);
     if (h->cfg.precision == SOM_PREC_BF16) return launch_bmu_bf16(h, Xb, xmax2, N, out);
     switch (h->cfg.distance) {
-    case SOM_DIST_EUCLIDEAN: return launch_bmu_f32<SCORE_EUCLID_PART>(h, X, N, xsq, out);
-    case SOM_DIST_EUCLIDEAN_NO_OPT: return launch_bmu_f32<SCORE_EUCLID_SQ>(h, X, N, xsq, out);
-    case SOM_DIST_COSINE: return launch_bmu_f32<SCORE_COSINE>(h, X, N, xsq, out);
+    case SOM_DIST_EUCLIDEAN: return launch_bmu_f32_any<SCORE_EUCLID_PART>(h, X, N, xsq, out);
+    case SOM_DIST_EUCLIDEAN_NO_OPT: return launch_bmu_f32_any<SCORE_EUCLID_SQ>(h, X, N, xsq, out);
+    case SOM_DIST_COSINE: return launch_bmu_f32_any<SCORE_COSINE>(h, X, N, xsq, out);
     }
     return fail(h, "unknown distance id");
 }
@@ -462,6 +496,13 @@ int som_create(const som_config* cfg, som_handle** out) {
     if (hipMemsetAsync(h->W, 0, (size_t)h->K * h->D * sizeof(float), h->stream) != hipSuccess ||
         hipMemsetAsync(h->ACC, 0, KD1 * sizeof(float), h->stream) != hipSuccess)
         return bail(fail(h, "hipMemsetAsync failed"));
+    if (h->D <= 128 && !std::getenv("SOM_F32_GENERIC")) {
+        int kg = 1;
+        while (kg * 8 < h->D) kg *= 2;                      // 8, 16, 32, 64 or 128 features per row image
+        h->fr_kg = kg;
+        h->fr_stages = (int)cdiv(h->K, FR_STAGE_UNITS);
+        if ((rc = dev_alloc(h, &h->Wfst, (size_t)h->fr_stages * fr_stage_bytes(kg)))) return bail(rc);
+    }
     if (cfg->precision == SOM_PREC_BF16) {
         h->n_stages = (int)cdiv(h->K, h->stage_units);
         size_t bytes = (size_t)h->n_stages * h->stage_bytes;
@@ -483,7 +524,7 @@ void som_destroy(som_handle* h) {
     for (auto& ep : h->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     void* bufs[] = {h->W, h->wsq, h->SC, h->T, h->ACC, h->P1, h->P2, h->Wst, h->X_owned, h->bmu, h->xsq, h->Xb,
                     h->xmax2, h->wn, h->wmax2, h->qX, h->qbmu, h->qxsq, h->qXb, h->dsum, h->iota, h->skey, h->srow,
-                    h->sort_tmp, h->best64};
+                    h->sort_tmp, h->best64, h->Wfst};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -629,7 +670,7 @@ int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, in
         if (int rc = refresh_codebook_operands(h)) return rc;
         if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
         Timed t(h, SOM_K_BMU);
-        if (int rc = launch_bmu_f32<SCORE_EUCLID_SQRT>(h, h->qX, n_rows, h->qxsq, h->qbmu)) return rc;
+        if (int rc = launch_bmu_f32_any<SCORE_EUCLID_SQRT>(h, h->qX, n_rows, h->qxsq, h->qbmu)) return rc;
     } else {
         if (needs_xsq(h)) if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
         if (h->cfg.precision == SOM_PREC_BF16)
@@ -649,7 +690,7 @@ int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, d
     HIPCHK(h, hipMemcpyAsync(h->qX, x_host, (size_t)n_rows * h->D * sizeof(float), hipMemcpyHostToDevice, h->stream));
     if (int rc = refresh_codebook_operands(h)) return rc;
     if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
-    if (int rc = launch_bmu_f32<SCORE_EUCLID_SQRT>(h, h->qX, n_rows, h->qxsq, h->qbmu)) return rc;
+    if (int rc = launch_bmu_f32_any<SCORE_EUCLID_SQRT>(h, h->qX, n_rows, h->qxsq, h->qbmu)) return rc;
     HIPCHK(h, hipMemsetAsync(h->dsum, 0, sizeof(double), h->stream));
     qe_kernel<<<dim3((unsigned)cdiv(n_rows, 4)), dim3(256), 0, h->stream>>>(h->qX, h->qbmu, h->W, n_rows, h->D, h->dsum);
     HIPCHK(h, hipGetLastError());
