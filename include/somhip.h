@@ -106,6 +106,9 @@ int som_epoch_accumulate_forced(som_handle* h, const int32_t* bmu_host, double s
 /* BMU ids for arbitrary rows: XPySom.winner, xpysom.py:370-408 (mode ACTIVATION)
  * and XPySom._quantization, xpysom.py:632-645 (mode QUANTIZATION). */
 int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, int32_t* ids_out);
+/* best and second-best unit per row under the full Euclidean distance (sqrt + nan_to_num):
+ * what XPySom.topographic_error takes from argsort(distances)[:, :2], xpysom.py:727-734 */
+int som_bmu_top2(som_handle* h, const float* x_host, int64_t n_rows, int32_t* ids1_out, int32_t* ids2_out);
 /* mean_n |x_n - W[bmu_n]|: XPySom.quantization_error, xpysom.py:673-707 */
 int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, double* qe_out);
 

@@ -279,7 +279,11 @@ def g9():
          winner=ref_winner_ids(som, probe),
          winner64=ref_winner_ids(som, probe.astype(np.float64)),
          qe=np.float64(som.quantization_error(probe)),
-         qe_train=np.float64(som.quantization_error(data)))
+         qe_train=np.float64(som.quantization_error(data)),
+         # best-2 matching units exactly as topographic_error finds them (xpysom.py:727-734)
+         top2=np.argsort(som._distance_from_weights(probe.astype(F32), som._weights), axis=1)[:, :2].astype(np.int32),
+         te=np.float64(som.topographic_error(probe)),
+         te_train=np.float64(som.topographic_error(data)))
 
 
 if __name__ == "__main__":

@@ -270,6 +270,22 @@ def quantization_error(data, W3, n_parallel=4000):
     return np.linalg.norm(x, axis=1).mean().item()
 
 
+def top2_ids(x32, W3):
+    """Best and second-best unit under the full Euclidean distance (xpysom.py:727-734)."""
+    d = dist_euclid(np.asarray(x32, dtype=F32), W3.reshape(-1, W3.shape[2]))
+    return np.argsort(d, axis=1)[:, :2]
+
+
+def topographic_error(data, W3):
+    """xpysom.py:709-746, rectangular branch: share of samples whose two best units are not
+    adjacent (|di| > 1 or |dj| > 1)."""
+    Y = W3.shape[1]
+    b = top2_ids(np.array(data, dtype=F32), np.asarray(W3))
+    di = np.abs(b[:, 0] // Y - b[:, 1] // Y)
+    dj = np.abs(b[:, 0] % Y - b[:, 1] % Y)
+    return ((di > 1) | (dj > 1)).mean().item()
+
+
 # --------------------------------------------------------------------------
 # synthetic workload shared by bench.py and the tests (SURVEY 8(d))
 # --------------------------------------------------------------------------

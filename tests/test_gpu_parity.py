@@ -457,3 +457,29 @@ def test_bf16_cosine_picks_near_best_similarity():
     e.set_data(data)
     e.epoch(5.0, 0.5, False)
     assert np.isfinite(e.get_weights()).all()
+
+
+def test_top2_and_topographic_error():
+    from xpysom_dask_amd import XPySom
+    g = load_golden("g9_inference")
+    probe = O.gaussian_blobs(700, 10, seed=int(g["probe_seed"]))
+    som = XPySom(16, 12, 10, random_seed=5, decay_function="linear")
+    som._weights = g["w"]
+    b1, b2 = som._upload_weights().bmu_top2(probe)
+    assert np.array_equal(b1, g["top2"][:, 0]) and np.array_equal(b2, g["top2"][:, 1])
+    assert som.topographic_error(probe) == float(g["te"])
+    # known answers of the reference's unit test (xpysom_dask/tests.py:81-90)
+    som = XPySom(5, 5, 1, std_coeff=1)
+    som._weights = np.zeros((5, 5, 1))
+    for (i, j), v in {(2, 3): 5.0, (1, 1): 2.0, (2, 4): 6.0, (4, 4): 15.0, (0, 0): 14.0}.items():
+        som._weights[i, j] = v
+    assert som.topographic_error([[5]]) == 0.0
+    assert som.topographic_error([[15]]) == 1.0
+    # the generic (input_len > 128) kernel's top-2 against the oracle
+    data = O.gaussian_blobs(300, 130, seed=8)
+    w = O.default_codebook(9, 7, 130, 2).astype(F32) * 4
+    e = engine(9, 7, 130)
+    e.set_weights(w)
+    a, b = e.bmu_top2(data)
+    ref = O.top2_ids(data, w)
+    assert np.array_equal(a, ref[:, 0]) and np.array_equal(b, ref[:, 1])

@@ -66,7 +66,7 @@ def test_c_abi_exports_every_declared_symbol():
     from xpysom_dask_amd import _lib
     lib = _lib.load()
     header = open(REPO + "/include/somhip.h").read()
-    declared = set(re.findall(r"\b(som_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(som_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)

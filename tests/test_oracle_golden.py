@@ -207,3 +207,15 @@ def test_decays_match_closed_forms():
     assert abs(O.exponential_decay(1.0, 0, 10, 10) - 0.1) < 1e-12
     assert isinstance(O.exponential_decay(8.0, 1.0, 3, 10), np.float64)
     assert isinstance(O.linear_decay(8.0, 1.0, 3, 10), float)
+
+
+def test_g9_topographic_error():
+    g = load_golden("g9_inference")
+    probe = O.gaussian_blobs(700, 10, seed=int(g["probe_seed"]))
+    assert np.array_equal(O.top2_ids(probe, g["w"]), g["top2"])
+    assert O.topographic_error(probe, g["w"]) == float(g["te"])
+    # known answers of the reference's unit test (xpysom_dask/tests.py:81-90)
+    w = np.zeros((5, 5, 1))
+    w[2, 3], w[1, 1], w[2, 4], w[4, 4], w[0, 0] = 5.0, 2.0, 6.0, 15.0, 14.0
+    assert O.topographic_error([[5]], w) == 0.0
+    assert O.topographic_error([[15]], w) == 1.0

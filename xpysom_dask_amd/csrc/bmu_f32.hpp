@@ -46,11 +46,11 @@ __device__ __forceinline__ float score_f32(float cross, float wsq, float xsq) {
 
 // X: [N][D] row-major f32.  W: [K][D] row-major f32.  wsq: [K].  xsq: [N] (unused for MODE 0).
 // x_resident != 0: the workgroup's whole sample block stays in LDS (needs SB*(Dp+1)*4 bytes).
-template <int MODE>
+template <int MODE, bool TOP2 = false>
 __global__ __launch_bounds__(256) void bmu_f32_kernel(const float* __restrict__ X, long N, int D, int Dp,
                                                       const float* __restrict__ W, const float* __restrict__ wsq,
                                                       int K, const float* __restrict__ xsq, int x_resident,
-                                                      int* __restrict__ out) {
+                                                      int* __restrict__ out, int* __restrict__ out2) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     float* Ws = smem_f;                                // [UB][KC+1]
     float* wq = Ws + F32_UB * (F32_KC + 1);            // [UB]
@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void bmu_f32_kernel(const float* __restrict__ 
     const long s0 = (long)blockIdx.x * F32_SB;
     const long my_sample = s0 + wave * 32 + col;
 
-    float best = __builtin_inff();
-    int bidx = 0;
+    float best = __builtin_inff(), sec = __builtin_inff();
+    int bidx = 0, sidx = 0;
     float xs = 0.0f;
     if (MODE != SCORE_EUCLID_PART) xs = (my_sample < N) ? xsq[my_sample] : 0.0f;
 
@@ -121,15 +121,31 @@ __global__ __launch_bounds__(256) void bmu_f32_kernel(const float* __restrict__ 
                 int row = rb * 32 + mfma32_row(r, half);
                 int u = u0 + row;
                 float v = score_f32<MODE>(acc[rb][r], wq[row], xs);
-                if (u < K && v < best) { best = v; bidx = u; }
+                if (TOP2) {
+                    if (u < K && v < sec) {
+                        if (v < best) { sec = best; sidx = bidx; best = v; bidx = u; }
+                        else { sec = v; sidx = u; }
+                    }
+                } else if (u < K && v < best) { best = v; bidx = u; }
             }
         }
     }
     // join the two lane halves (same sample, disjoint units): smaller value, then smaller id
     float ob = __shfl_xor(best, 32, 64);
     int oi = __shfl_xor(bidx, 32, 64);
-    if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-    if (half == 0 && my_sample < N) out[my_sample] = bidx;
+    if (TOP2) {
+        float os = __shfl_xor(sec, 32, 64);
+        int osi = __shfl_xor(sidx, 32, 64);
+        const bool other_first = ob < best || (ob == best && oi < bidx);
+        int i1 = other_first ? oi : bidx;
+        float c1 = other_first ? best : ob;  int j1 = other_first ? bidx : oi;
+        float c2 = other_first ? os : sec;   int j2 = other_first ? osi : sidx;
+        const bool take_c1 = c1 < c2 || (c1 == c2 && j1 < j2);
+        if (half == 0 && my_sample < N) { out[my_sample] = i1; out2[my_sample] = take_c1 ? j1 : j2; }
+    } else {
+        if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+        if (half == 0 && my_sample < N) out[my_sample] = bidx;
+    }
 }
 
 // sum of squares of each row, float32: xp.power(a, 2).sum(axis=1) -- xpysom.py:529-537 (w_sq),

@@ -53,11 +53,13 @@ __global__ __launch_bounds__(256) void prep_w_f32_res_kernel(const float* __rest
     *(f32x4*)(base + ((long)(ut * kg + g) * 64 + lane) * 16) = v;
 }
 
-template <int MODE, int KG>
+// TOP2: also report the second-best unit (out2) -- the pair XPySom.topographic_error needs
+// (xpysom.py:709-746 takes it from a full argsort of the (n, K) distance matrix).
+template <int MODE, int KG, bool TOP2 = false>
 __global__ __launch_bounds__(256, 2) void bmu_f32_res_kernel(const float* __restrict__ X, long N, int D,
                                                              const float* __restrict__ xsq,
                                                              const char* __restrict__ Wst, int n_stages, int K,
-                                                             int* __restrict__ out) {
+                                                             int* __restrict__ out, int* __restrict__ out2) {
     constexpr int STAGE = fr_stage_bytes(KG);
     constexpr int PIECES = FR_UT * KG + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -92,10 +94,10 @@ __global__ __launch_bounds__(256, 2) void bmu_f32_res_kernel(const float* __rest
         }
     }
 
-    float best[FR_SBW];
-    int bidx[FR_SBW];
+    float best[FR_SBW], sec[FR_SBW];
+    int bidx[FR_SBW], sidx[FR_SBW];
 #pragma unroll
-    for (int sb = 0; sb < FR_SBW; ++sb) { best[sb] = __builtin_inff(); bidx[sb] = 0; }
+    for (int sb = 0; sb < FR_SBW; ++sb) { best[sb] = sec[sb] = __builtin_inff(); bidx[sb] = sidx[sb] = 0; }
 
     for (int p = wave; p < PIECES; p += 4) lds_dma_16(Wst + (long)p * 1024 + lane * 16, smem + p * 1024);
 
@@ -136,7 +138,12 @@ __global__ __launch_bounds__(256, 2) void bmu_f32_res_kernel(const float* __rest
                 for (int r = 0; r < 16; ++r) {           // units ascend with r for a fixed lane half
                     const int u = s * FR_STAGE_UNITS + ut * 32 + mfma32_row(r, half);
                     const float v = score_f32<MODE>(acc[sb][r], wv[r >> 2][r & 3], xs[sb]);
-                    if (u < K && v < best[sb]) { best[sb] = v; bidx[sb] = u; }
+                    if (TOP2) {
+                        if (u < K && v < sec[sb]) {
+                            if (v < best[sb]) { sec[sb] = best[sb]; sidx[sb] = bidx[sb]; best[sb] = v; bidx[sb] = u; }
+                            else { sec[sb] = v; sidx[sb] = u; }
+                        }
+                    } else if (u < K && v < best[sb]) { best[sb] = v; bidx[sb] = u; }
                 }
             }
         }
@@ -145,9 +152,21 @@ __global__ __launch_bounds__(256, 2) void bmu_f32_res_kernel(const float* __rest
     for (int sb = 0; sb < FR_SBW; ++sb) {
         float ob = __shfl_xor(best[sb], 32, 64);
         int oi = __shfl_xor(bidx[sb], 32, 64);
-        if (ob < best[sb] || (ob == best[sb] && oi < bidx[sb])) { best[sb] = ob; bidx[sb] = oi; }
         const long row = wave_s0 + sb * 32 + col;
-        if (half == 0 && row < N) out[row] = bidx[sb];
+        if (TOP2) {   // merge two sorted pairs (value, then lower id): keep the two smallest
+            float os = __shfl_xor(sec[sb], 32, 64);
+            int osi = __shfl_xor(sidx[sb], 32, 64);
+            const bool other_first = ob < best[sb] || (ob == best[sb] && oi < bidx[sb]);
+            float b1 = other_first ? ob : best[sb];  int i1 = other_first ? oi : bidx[sb];
+            float c1 = other_first ? best[sb] : ob;  int j1 = other_first ? bidx[sb] : oi;   // loser of the firsts
+            float c2 = other_first ? os : sec[sb];   int j2 = other_first ? osi : sidx[sb];  // winner's own second
+            const bool take_c1 = c1 < c2 || (c1 == c2 && j1 < j2);
+            if (half == 0 && row < N) { out[row] = i1; out2[row] = take_c1 ? j1 : j2; }
+            (void)b1;
+        } else {
+            if (ob < best[sb] || (ob == best[sb] && oi < bidx[sb])) { best[sb] = ob; bidx[sb] = oi; }
+            if (half == 0 && row < N) out[row] = bidx[sb];
+        }
     }
 }
 

@@ -69,7 +69,7 @@ struct som_handle {
     float* wmax2 = nullptr;
 
     // scratch for som_bmu / som_quantization_error
-    float* qX = nullptr; int* qbmu = nullptr; float* qxsq = nullptr; __bf16* qXb = nullptr;
+    float* qX = nullptr; int* qbmu = nullptr; int* qbmu2 = nullptr; float* qxsq = nullptr; __bf16* qXb = nullptr;
     long qcap = 0;
     double* dsum = nullptr;
 
@@ -196,33 +196,33 @@ int refresh_codebook_operands(som_handle* h) {
 }
 
 // ---- BMU launches ----------------------------------------------------------------------------
-template <int MODE>
-int launch_bmu_f32(som_handle* h, const float* X, long N, const float* xsq, int* out) {
+template <int MODE, bool TOP2 = false>
+int launch_bmu_f32(som_handle* h, const float* X, long N, const float* xsq, int* out, int* out2 = nullptr) {
     const int Dp = (int)round_up(h->D, F32_KC);
     size_t base = (size_t)(F32_UB * (F32_KC + 1) + F32_UB) * sizeof(float);
     size_t res = base + (size_t)F32_SB * (Dp + 1) * sizeof(float);
     size_t chunked = base + (size_t)F32_SB * (F32_KC + 1) * sizeof(float);
     int x_resident = res <= 150 * 1024;
     size_t lds = x_resident ? res : chunked;
-    HIPCHK(h, hipFuncSetAttribute((const void*)bmu_f32_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIPCHK(h, hipFuncSetAttribute((const void*)bmu_f32_kernel<MODE, TOP2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
     long grid = cdiv(N, F32_SB);
     if (grid <= 0 || grid > 0x7fffffffL) return fail(h, "bmu_f32: row count out of range");
-    bmu_f32_kernel<MODE><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, N, h->D, Dp, h->W, h->wsq, h->K, xsq,
-                                                                             x_resident, out);
+    bmu_f32_kernel<MODE, TOP2><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, N, h->D, Dp, h->W, h->wsq, h->K,
+                                                                                   xsq, x_resident, out, out2);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
 
-template <int MODE, int KG>
-int launch_bmu_f32_res_kg(som_handle* h, const float* X, long N, const float* xsq, int* out) {
+template <int MODE, int KG, bool TOP2 = false>
+int launch_bmu_f32_res_kg(som_handle* h, const float* X, long N, const float* xsq, int* out, int* out2 = nullptr) {
     size_t lds = 2 * (size_t)fr_stage_bytes(KG);
-    HIPCHK(h, hipFuncSetAttribute((const void*)bmu_f32_res_kernel<MODE, KG>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)bmu_f32_res_kernel<MODE, KG, TOP2>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     long grid = cdiv(N, FR_WG_SAMPLES);
     if (grid <= 0 || grid > 0x7fffffffL) return fail(h, "bmu_f32: row count out of range");
-    bmu_f32_res_kernel<MODE, KG><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, N, h->D, xsq, h->Wfst,
-                                                                                     h->fr_stages, h->K, out);
+    bmu_f32_res_kernel<MODE, KG, TOP2><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(
+        X, N, h->D, xsq, h->Wfst, h->fr_stages, h->K, out, out2);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -236,6 +236,20 @@ int launch_bmu_f32_any(som_handle* h, const float* X, long N, const float* xsq, 
     case 4: return launch_bmu_f32_res_kg<MODE, 4>(h, X, N, xsq, out);
     case 8: return launch_bmu_f32_res_kg<MODE, 8>(h, X, N, xsq, out);
     case 16: return launch_bmu_f32_res_kg<MODE, 16>(h, X, N, xsq, out);
+    }
+    return fail(h, "bmu_f32: bad k-group count");
+}
+
+// best AND second-best unit under the sqrt'd Euclidean distance (topographic error)
+int launch_bmu_top2(som_handle* h, const float* X, long N, const float* xsq, int* out, int* out2) {
+    constexpr int M = SCORE_EUCLID_SQRT;
+    if (!h->Wfst) return launch_bmu_f32<M, true>(h, X, N, xsq, out, out2);
+    switch (h->fr_kg) {
+    case 1: return launch_bmu_f32_res_kg<M, 1, true>(h, X, N, xsq, out, out2);
+    case 2: return launch_bmu_f32_res_kg<M, 2, true>(h, X, N, xsq, out, out2);
+    case 4: return launch_bmu_f32_res_kg<M, 4, true>(h, X, N, xsq, out, out2);
+    case 8: return launch_bmu_f32_res_kg<M, 8, true>(h, X, N, xsq, out, out2);
+    case 16: return launch_bmu_f32_res_kg<M, 16, true>(h, X, N, xsq, out, out2);
     }
     return fail(h, "bmu_f32: bad k-group count");
 }
@@ -402,10 +416,11 @@ int run_update(som_handle* h, double sigma, double eta, int neigh_f64) {
 int ensure_query_scratch(som_handle* h, long n) {
     if (n <= h->qcap) return 0;
     long cap = round_up(n, 1024);
-    (void)hipFree(h->qX); (void)hipFree(h->qbmu); (void)hipFree(h->qxsq); (void)hipFree(h->qXb);
-    h->qX = nullptr; h->qbmu = nullptr; h->qxsq = nullptr; h->qXb = nullptr; h->qcap = 0;
+    (void)hipFree(h->qX); (void)hipFree(h->qbmu); (void)hipFree(h->qbmu2); (void)hipFree(h->qxsq); (void)hipFree(h->qXb);
+    h->qX = nullptr; h->qbmu = nullptr; h->qbmu2 = nullptr; h->qxsq = nullptr; h->qXb = nullptr; h->qcap = 0;
     if (int rc = dev_alloc(h, &h->qX, (size_t)cap * h->D)) return rc;
     if (int rc = dev_alloc(h, &h->qbmu, (size_t)cap)) return rc;
+    if (int rc = dev_alloc(h, &h->qbmu2, (size_t)cap)) return rc;
     if (int rc = dev_alloc(h, &h->qxsq, (size_t)cap)) return rc;
     if (h->cfg.precision == SOM_PREC_BF16) {
         long capp = round_up(cap, ROW_PAD);
@@ -523,7 +538,7 @@ void som_destroy(som_handle* h) {
     for (auto& ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto& ep : h->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     void* bufs[] = {h->W, h->wsq, h->SC, h->T, h->ACC, h->P1, h->P2, h->Wst, h->X_owned, h->bmu, h->xsq, h->Xb,
-                    h->xmax2, h->wn, h->wmax2, h->qX, h->qbmu, h->qxsq, h->qXb, h->dsum, h->iota, h->skey, h->srow,
+                    h->xmax2, h->wn, h->wmax2, h->qX, h->qbmu, h->qbmu2, h->qxsq, h->qXb, h->dsum, h->iota, h->skey, h->srow,
                     h->sort_tmp, h->best64, h->Wfst};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -678,6 +693,24 @@ int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, in
         if (int rc = run_activation_bmu(h, h->qX, n_rows, h->qxsq, h->qXb, h->xmax2 + 1, h->qbmu)) return rc;
     }
     HIPCHK(h, hipMemcpyAsync(ids_out, h->qbmu, (size_t)n_rows * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int som_bmu_top2(som_handle* h, const float* x_host, int64_t n_rows, int32_t* ids1_out, int32_t* ids2_out) {
+    if (h) (void)hipSetDevice(h->cfg.device);
+    if (!h || n_rows < 0 || (n_rows > 0 && (!x_host || !ids1_out || !ids2_out))) return fail(h, "som_bmu_top2: bad argument");
+    if (n_rows == 0) return 0;
+    if (int rc = ensure_query_scratch(h, n_rows)) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->qX, x_host, (size_t)n_rows * h->D * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (int rc = refresh_codebook_operands(h)) return rc;
+    if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
+    {
+        Timed t(h, SOM_K_BMU);
+        if (int rc = launch_bmu_top2(h, h->qX, n_rows, h->qxsq, h->qbmu, h->qbmu2)) return rc;
+    }
+    HIPCHK(h, hipMemcpyAsync(ids1_out, h->qbmu, (size_t)n_rows * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(ids2_out, h->qbmu2, (size_t)n_rows * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }

@@ -139,6 +139,16 @@ class HipEngine:
         self._check(self._lib.som_bmu(self._h, self._fp(x), x.shape[0], mode, self._ip(ids)))
         return ids
 
+    def bmu_top2(self, x):
+        """(best, second-best) raveled ids under the full Euclidean distance."""
+        x = _f32(x)
+        if x.ndim != 2 or x.shape[1] != self.D:
+            raise ValueError("x must be (n, %d), got %r" % (self.D, x.shape))
+        a = np.empty((x.shape[0],), dtype=np.int32)
+        b = np.empty((x.shape[0],), dtype=np.int32)
+        self._check(self._lib.som_bmu_top2(self._h, self._fp(x), x.shape[0], self._ip(a), self._ip(b)))
+        return a, b
+
     def quantization_error(self, x):
         x = _f32(x)
         out = C.c_double()

@@ -235,6 +235,26 @@ class XPySom:
             n += len(chunk)
         return total / n if n else float('nan')
 
+    def topographic_error(self, data):
+        """Share of samples whose best and second-best matching units are not adjacent on the map
+        (xpysom.py:709-746, rectangular branch: |di| > 1 or |dj| > 1).  The reference sorts the whole
+        (n, K) distance matrix; here a fused top-2 variant of the BMU kernel returns the pair."""
+        self._check_input_len(data)
+        if np.prod(self._weights.shape) == 1:
+            warn('The topographic error is not defined for a 1-by-1 map.')
+            return np.nan
+        data = np.asarray(data, dtype=np.float32)
+        eng = self._upload_weights()
+        Y = self._weights.shape[1]
+        bad, n = 0, 0
+        for s in range(0, len(data), self._n_parallel):
+            b1, b2 = eng.bmu_top2(data[s:s + self._n_parallel])
+            di = np.abs(b1 // Y - b2 // Y)
+            dj = np.abs(b1 % Y - b2 % Y)
+            bad += int(((di > 1) | (dj > 1)).sum())
+            n += len(b1)
+        return bad / n if n else float('nan')
+
     def predict(self, data):
         """Raveled BMU index of every sample (xpysom.py:608-617), batched."""
         data = np.asarray(data, dtype=np.float32)
