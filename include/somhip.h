@@ -38,6 +38,10 @@ enum { SOM_DIST_EUCLIDEAN = 0,        /* 'euclidean'  -> euclidean_squared_dista
 /* neighbourhood function on the rectangular topology: neighborhoods.py:14-33, :57-74, :99-130 */
 enum { SOM_NEIGH_GAUSSIAN = 0, SOM_NEIGH_MEXICAN_HAT = 1, SOM_NEIGH_BUBBLE = 2, SOM_NEIGH_TRIANGLE = 3 };
 
+/* map topology: xpysom.py:196-206.  HEXAGONAL selects the *_generic neighbourhoods
+ * (neighborhoods.py:35-55, :76-97) on the shifted-row coordinates; bubble ignores the shift. */
+enum { SOM_TOPO_RECTANGULAR = 0, SOM_TOPO_HEXAGONAL = 1 };
+
 /* arithmetic of the distance GEMM (the -2 x.w^T term, distances.py:22):
  *   F32  : v_mfma_f32_32x32x2_f32, exact float32 fma chain -- the parity mode
  *   BF16 : v_mfma_f32_32x32x16_bf16 on bf16-rounded x and w, f32 accumulate -- the throughput mode */
@@ -59,6 +63,8 @@ typedef struct som_config {
     int32_t device;              /* HIP device ordinal */
     double  std_coeff;           /* d = 2*std_coeff^2*sigma^2, neighborhoods.py:19 */
     void*   stream;              /* hipStream_t to launch on; NULL = the library creates its own */
+    int32_t topology;            /* SOM_TOPO_* */
+    int32_t reserved;            /* must be 0 */
 } som_config;
 
 const char* som_version(void);

@@ -286,8 +286,43 @@ def g9():
          te_train=np.float64(som.topographic_error(data)))
 
 
+# ---------------------------------------------------------------- G10 hexagonal topology (generic neighbourhoods)
+def g10():
+    out = {}
+    for (X, Y, D, n) in ((6, 5, 3, 200), (9, 8, 4, 400)):
+        data = gaussian_blobs(n, D, seed=300 + X)
+        for neigh in ("gaussian", "mexican_hat", "bubble"):
+            for decay in ("linear", "exponential"):
+                som = RefSom(X, Y, D, random_seed=77, decay_function=decay, n_parallel=n, topology="hexagonal",
+                             neighborhood_function=neigh, xp=np)
+                w0 = som._weights.astype(F32)
+                t, T = 2, 6
+                eta = som._decay_function(som._learning_rate, som._learning_rateN, t, T)
+                sig = som._decay_function(som._sigma, som._sigmaN, t, T)
+                wins = som._winner(data, w0)
+                num, den = som._update(data, w0, eta, sig)
+                key = f"{X}x{Y}_{neigh}_{decay}"
+                out[key + "_bmu"] = (wins[0] * Y + wins[1]).astype(np.int32)
+                out[key + "_num"] = num.astype(F32)
+                out[key + "_den"] = den.astype(F32)
+                out[key + "_eta"] = np.float64(eta)
+                out[key + "_sig"] = np.float64(sig)
+        # the raw neighbourhood tensors for every centre, compact support included
+        ci, cj = np.divmod(np.arange(X * Y), Y)
+        c = (ci.astype(np.int64), cj.astype(np.int64))
+        som = RefSom(X, Y, D, topology="hexagonal", xp=np)
+        for sig in (0.8, 2.5):
+            for wide in (False, True):
+                s = np.float64(sig) if wide else float(sig)
+                tag = f"{X}x{Y}_s{sig}_{'f64' if wide else 'f32'}"
+                out["gauss_" + tag] = rneigh.gaussian_generic(som._xx, som._yy, 0.5, False, c, s, xp=np)
+                out["gausscs_" + tag] = rneigh.gaussian_generic(som._xx, som._yy, 0.5, True, c, s, xp=np)
+                out["mex_" + tag] = rneigh.mexican_hat_generic(som._xx, som._yy, 0.5, False, c, s, xp=np)
+    save("g10_hexagonal", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     with contextlib.redirect_stdout(io.StringIO()) as _:
         pass
-    g1(); g2(); g3(); g4_g5_g7(); g6(); g8(); g9()
+    g1(); g2(); g3(); g4_g5_g7(); g6(); g8(); g9(); g10()

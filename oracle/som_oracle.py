@@ -168,9 +168,61 @@ def neigh_mexican_hat(X, Y, std_coeff, compact, ci, cj, sigma, wide):
     return np.exp(-p / d) * (1 - 2 / d * p)
 
 
+def neigh_bubble(X, Y, std_coeff, compact, ci, cj, sigma, wide):
+    """neighborhoods.py:99-112: 1 inside the open box |di| < sigma, |dj| < sigma (float32)."""
+    ni, nj = np.arange(X)[None, :], np.arange(Y)[None, :]
+    ci, cj = np.asarray(ci)[:, None], np.asarray(cj)[:, None]
+    return (_support(ni, ci, sigma)[:, :, None] * _support(nj, cj, sigma)[:, None, :]).astype(F32)
+
+
+def hex_coords(X, Y):
+    """Euclidean unit coordinates of the hexagonal topology (xpysom.py:201-206):
+    meshgrid (shape (Y, X)), every second row counted from the LAST one shifted by -0.5."""
+    xx, yy = np.meshgrid(np.arange(X), np.arange(Y))
+    xx, yy = xx.astype(float), yy.astype(float)
+    xx[::-2] -= 0.5
+    return xx, yy
+
+
+def _generic_terms(X, Y, ci, cj):
+    xx, yy = hex_coords(X, Y)
+    nx, ny = xx[None, :, :], yy[None, :, :]
+    cx = xx.T[(ci, cj)][:, None, None]
+    cy = yy.T[(ci, cj)][:, None, None]
+    return nx, ny, cx, cy
+
+
+def neigh_gaussian_hex(X, Y, std_coeff, compact, ci, cj, sigma, wide):
+    """gaussian_generic on the hexagonal grid, neighborhoods.py:35-55; (n, X, Y)."""
+    sigma = F64(sigma) if wide else float(sigma)
+    d = 2 * std_coeff ** 2 * sigma ** 2
+    nx, ny, cx, cy = _generic_terms(X, Y, np.asarray(ci), np.asarray(cj))
+    ax = np.exp(-np.power(nx - cx, 2, dtype=F32) / d)
+    ay = np.exp(-np.power(ny - cy, 2, dtype=F32) / d)
+    if compact:
+        ax *= np.logical_and(nx > cx - sigma, nx < cx + sigma)
+        ay *= np.logical_and(ny > cy - sigma, ny < cy + sigma)
+    return (ax * ay).transpose((0, 2, 1))
+
+
+def neigh_mexican_hat_hex(X, Y, std_coeff, compact, ci, cj, sigma, wide):
+    """mexican_hat_generic on the hexagonal grid, neighborhoods.py:76-97 (no compact support)."""
+    if compact:
+        raise NotImplementedError("mexican_hat with compact_support is not restated")
+    sigma = F64(sigma) if wide else float(sigma)
+    d = 2 * std_coeff ** 2 * sigma ** 2
+    nx, ny, cx, cy = _generic_terms(X, Y, np.asarray(ci), np.asarray(cj))
+    p = np.power(nx - cx, 2, dtype=F32) + np.power(ny - cy, 2, dtype=F32)
+    return (np.exp(-p / d) * (1 - 2 / d * p)).transpose((0, 2, 1))
+
+
 NEIGHBOURHOODS = {
     "gaussian": neigh_gaussian,
     "mexican_hat": neigh_mexican_hat,
+    "bubble": neigh_bubble,
+    "gaussian_hex": neigh_gaussian_hex,          # topology='hexagonal' registry, xpysom.py:271-279
+    "mexican_hat_hex": neigh_mexican_hat_hex,
+    "bubble_hex": neigh_bubble,
 }
 
 

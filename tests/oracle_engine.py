@@ -8,9 +8,11 @@ from oracle import som_oracle as O
 
 class OracleEngine:
     def __init__(self, x, y, input_len, *, distance="euclidean", neighborhood="gaussian",
-                 std_coeff=0.5, compact_support=False, precision="f32"):
+                 std_coeff=0.5, compact_support=False, precision="f32", topology="rectangular"):
         self.x, self.y, self.D = x, y, input_len
         self.K = x * y
+        if topology == "hexagonal":
+            neighborhood += "_hex"
         self.kw = dict(distance=distance, neighbourhood=neighborhood, std_coeff=std_coeff, compact=compact_support)
         self.W = np.zeros((self.K, self.D), np.float32)
         self.acc = np.zeros((self.K, self.D + 1), np.float32)

@@ -483,3 +483,32 @@ def test_top2_and_topographic_error():
     a, b = e.bmu_top2(data)
     ref = O.top2_ids(data, w)
     assert np.array_equal(a, ref[:, 0]) and np.array_equal(b, ref[:, 1])
+
+
+@pytest.mark.parametrize("XY", [(6, 5, 3, 200), (9, 8, 4, 400)])
+def test_g10_hexagonal_topology(XY):
+    """topology='hexagonal' (gaussian_generic / mexican_hat_generic / bubble) against the reference's
+    own _update outputs: the 3-class separable form is exact algebra."""
+    g = load_golden("g10_hexagonal")
+    X, Y, D, n = XY
+    data = O.gaussian_blobs(n, D, seed=300 + X)
+    w0 = O.default_codebook(X, Y, D, 77).astype(F32)
+    for neigh in ("gaussian", "mexican_hat", "bubble"):
+        e = engine(X, Y, D, neighborhood=neigh, topology="hexagonal")
+        e.set_weights(w0)
+        e.set_data(data)
+        for decay in ("linear", "exponential"):
+            key = f"{X}x{Y}_{neigh}_{decay}"
+            e.epoch_accumulate(float(g[key + "_sig"]), float(g[key + "_eta"]), O.decay_is_wide(decay))
+            num, den, bmu = e.epoch_fetch()
+            assert np.array_equal(bmu, g[key + "_bmu"])
+            assert rel_err(num, g[key + "_num"].reshape(-1, D)) < 1e-5, key
+            assert rel_err(den, g[key + "_den"].reshape(-1)) < 1e-5, key
+    # compact support on the generic gaussian, against the oracle (pinned bit-exactly by the same fixture)
+    e = engine(X, Y, D, neighborhood="gaussian", topology="hexagonal", compact_support=True)
+    e.set_weights(w0)
+    e.set_data(data)
+    e.epoch_accumulate(2.5, 0.3, True)
+    num, den, bmu = e.epoch_fetch()
+    _, onum, oden = O.update(data, w0, 0.3, 2.5, wide=True, neighbourhood="gaussian_hex", compact=True, forced_bmu=bmu)
+    assert rel_err(num, onum.reshape(-1, D)) < 1e-5 and rel_err(den, oden.reshape(-1)) < 1e-5

@@ -34,8 +34,8 @@ def test_constructor_mirrors_reference_validation():
     # valid reference names the engine does not implement yet say so instead of mis-training
     with pytest.raises(NotImplementedError):
         XPySom(5, 5, 1, activation_distance='manhattan')
-    with pytest.raises(NotImplementedError):
-        XPySom(5, 5, 1, topology='hexagonal')
+    with pytest.raises(ValueError, match="triangle not supported"):
+        XPySom(5, 5, 1, topology='hexagonal', neighborhood_function='triangle')
 
 
 def test_default_codebook_is_the_reference_formula():

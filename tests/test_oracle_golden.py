@@ -219,3 +219,28 @@ def test_g9_topographic_error():
     w[2, 3], w[1, 1], w[2, 4], w[4, 4], w[0, 0] = 5.0, 2.0, 6.0, 15.0, 14.0
     assert O.topographic_error([[5]], w) == 0.0
     assert O.topographic_error([[15]], w) == 1.0
+
+
+@pytest.mark.parametrize("XY", [(6, 5, 3, 200), (9, 8, 4, 400)])
+def test_g10_hexagonal_topology(XY):
+    g = load_golden("g10_hexagonal")
+    X, Y, D, n = XY
+    ci, cj = np.divmod(np.arange(X * Y), Y)
+    for sig in (0.8, 2.5):
+        for wide in (False, True):
+            tag = f"{X}x{Y}_s{sig}_{'f64' if wide else 'f32'}"
+            np.testing.assert_array_equal(O.neigh_gaussian_hex(X, Y, 0.5, False, ci, cj, sig, wide), g["gauss_" + tag])
+            np.testing.assert_array_equal(O.neigh_gaussian_hex(X, Y, 0.5, True, ci, cj, sig, wide), g["gausscs_" + tag])
+            np.testing.assert_array_equal(O.neigh_mexican_hat_hex(X, Y, 0.5, False, ci, cj, sig, wide), g["mex_" + tag])
+    data = O.gaussian_blobs(n, D, seed=300 + X)
+    w0 = O.default_codebook(X, Y, D, 77).astype(F32)
+    for neigh in ("gaussian", "mexican_hat", "bubble"):
+        for decay in ("linear", "exponential"):
+            key = f"{X}x{Y}_{neigh}_{decay}"
+            f = O.DECAYS[decay]
+            eta, sig = f(0.5, 0.01, 2, 6), f(min(X, Y) / 2, 1, 2, 6)
+            assert float(eta) == float(g[key + "_eta"]) and float(sig) == float(g[key + "_sig"])
+            bmu, num, den = O.update(data, w0, eta, sig, wide=O.decay_is_wide(decay), neighbourhood=neigh + "_hex")
+            assert np.array_equal(bmu, g[key + "_bmu"])
+            np.testing.assert_allclose(num, g[key + "_num"], rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(den, g[key + "_den"], rtol=1e-5, atol=1e-6)

@@ -10,6 +10,7 @@ LIB_PATH = os.environ.get("SOM_LIB_PATH") or os.path.join(HERE, "libsomhip.so") 
 SOM_DIST = {"euclidean": 0, "euclidean_no_opt": 1, "cosine": 2}
 SOM_NEIGH = {"gaussian": 0, "mexican_hat": 1, "bubble": 2, "triangle": 3}
 SOM_PREC = {"f32": 0, "bf16": 1}
+SOM_TOPO = {"rectangular": 0, "hexagonal": 1}
 SOM_BMU_ACTIVATION, SOM_BMU_QUANTIZATION = 0, 1
 SOM_KERNELS = {"bmu": 0, "segsum": 1, "kron": 2, "merge": 3, "prep": 4}
 
@@ -18,7 +19,8 @@ class SomConfig(C.Structure):
     _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("input_len", C.c_int32),
                 ("distance", C.c_int32), ("neighborhood", C.c_int32),
                 ("compact_support", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32),
-                ("std_coeff", C.c_double), ("stream", C.c_void_p)]
+                ("std_coeff", C.c_double), ("stream", C.c_void_p),
+                ("topology", C.c_int32), ("reserved", C.c_int32)]
 
 
 _F = C.POINTER(C.c_float)

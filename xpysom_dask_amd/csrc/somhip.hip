@@ -394,6 +394,8 @@ int run_update(som_handle* h, double sigma, double eta, int neigh_f64) {
     p.d = 2.0 * (h->cfg.std_coeff * h->cfg.std_coeff) * (sigma * sigma);
     p.kind = h->cfg.neighborhood; p.compact = h->cfg.compact_support; p.wide = neigh_f64 ? 1 : 0;
     p.X = h->X; p.Y = h->Y; p.nt = h->nt;
+    p.hex = h->cfg.topology == SOM_TOPO_HEXAGONAL && h->cfg.neighborhood != SOM_NEIGH_BUBBLE;
+    p.base_nt = p.hex ? h->nt / 3 : h->nt;
     long ntab = (long)h->nt * h->Y * h->Y + (long)h->X * h->nt * h->X;
     neigh_tables_kernel<<<dim3((unsigned)cdiv(ntab, 256)), dim3(256), 0, h->stream>>>(p, h->P1, h->P2);
     HIPCHK(h, hipGetLastError());
@@ -457,6 +459,10 @@ int som_create(const som_config* cfg, som_handle** out) {
     if (cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT && cfg->compact_support)
         return fail(nullptr, "som_create: mexican_hat with compact_support is not separable (reference bug "
                              "neighborhoods.py:69-71) and is not supported");
+    if (cfg->topology != SOM_TOPO_RECTANGULAR && cfg->topology != SOM_TOPO_HEXAGONAL)
+        return fail(nullptr, "som_create: unknown topology id");
+    if (cfg->topology == SOM_TOPO_HEXAGONAL && cfg->neighborhood == SOM_NEIGH_TRIANGLE)
+        return fail(nullptr, "som_create: the hexagonal topology has no triangle neighbourhood (xpysom.py:271-279)");
     if (cfg->precision != SOM_PREC_F32 && cfg->precision != SOM_PREC_BF16)
         return fail(nullptr, "som_create: unknown precision id");
     if (cfg->precision == SOM_PREC_BF16) {
@@ -486,6 +492,7 @@ int som_create(const som_config* cfg, som_handle** out) {
     h->stage_bytes = h->shape16 ? k16_stage_bytes(h->ks32) : bf_stage_bytes(h->ksteps);
     h->stage_units = h->shape16 ? K16_STAGE_UNITS : BF_STAGE_UNITS;
     h->nt = cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT ? 2 : 1;
+    if (cfg->topology == SOM_TOPO_HEXAGONAL && cfg->neighborhood != SOM_NEIGH_BUBBLE) h->nt *= 3;
     int rc = 0;
     auto bail = [&](int code) { g_create_error = h->err; som_destroy(h); return code; };
     if (hipSetDevice(cfg->device) != hipSuccess) return bail(fail(h, "hipSetDevice failed"));

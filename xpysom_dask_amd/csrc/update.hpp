@@ -9,6 +9,12 @@
 //   mexican_hat  (:57-74)   t=2 : ex(1-2px/d) * ey  -  ex * (2py/d)ey
 //   bubble       (:99-112)  t=1 : box * box
 //   triangle     (:114-130) t=1 : tri * tri
+// The hexagonal topology (gaussian_generic / mexican_hat_generic, :35-97; coordinates xpysom.py:201-206)
+// shifts every second map column-index row j by -0.5 in x: xx[j,i] = i - s(j)/2, s(j) = 1 iff (Y-1-j) even.
+// The x offset between unit (i,j) and BMU (ci,cj) is then (i - ci) + (s(cj) - s(j))/2: one of three values
+// per (s(j), s(cj)) class, so the hexagonal neighbourhood is the rectangular one summed over 3 classes
+//   {s(j)=s(cj): +0}, {s(j)=0,s(cj)=1: +1/2}, {s(j)=1,s(cj)=0: -1/2}
+// with the class indicator folded into the column factor: nt = 3 (gaussian), 6 (mexican hat).
 // Hence, exactly (only the float summation order differs):
 //     S[b,:] = sum_{n: bmu_n = b} x_n,  c[b] = #{n: bmu_n = b}          (segment sum, HBM/atomic bound)
 //     [num|den](i,j,:) = sum_t sum_a Px_t[i,a] sum_b Py_t[j,b] [S|c](a,b,:)   (two small exact-f32 MFMA GEMMs)
@@ -89,6 +95,7 @@ __global__ __launch_bounds__(256) void segsum_sorted_kernel(const float* __restr
 struct NeighParams {
     double sigma, eta, d;   // d = 2*std_coeff^2*sigma^2 (host, double)
     int kind, compact, wide, X, Y, nt;
+    int hex, base_nt;       // hexagonal topology: nt = 3 * base_nt
 };
 
 __device__ __forceinline__ double neigh_exp(double delta2, const NeighParams& p) {
@@ -96,19 +103,18 @@ __device__ __forceinline__ double neigh_exp(double delta2, const NeighParams& p)
     float a = -(float)delta2 / (float)p.d;
     return (double)(float)exp((double)a);
 }
-__device__ __forceinline__ double neigh_box(int i, int a, const NeighParams& p) {
-    return ((double)i > (double)a - p.sigma && (double)i < (double)a + p.sigma) ? 1.0 : 0.0;
+__device__ __forceinline__ double neigh_box(double dl, const NeighParams& p) {   // n > c - sigma  and  n < c + sigma
+    return (dl > -p.sigma && dl < p.sigma) ? 1.0 : 0.0;
 }
 __device__ __forceinline__ double neigh_round(double v, const NeighParams& p) { return p.wide ? v : (double)(float)v; }
 
-// value of factor `which` (0 = row factor Px, 1 = column factor Py) of term t at (i, a)
-__device__ double neigh_factor(int which, int t, int i, int a, const NeighParams& p) {
-    const double dl = (double)(i - a);
+// value of factor `which` (0 = row factor Px, 1 = column factor Py) of base term t at offset dl
+__device__ double neigh_factor(int which, int t, double dl, const NeighParams& p) {
     const double d2 = dl * dl;
     switch (p.kind) {
     case 0: {   // gaussian
         double e = neigh_exp(d2, p);
-        if (p.compact) e *= neigh_box(i, a, p);
+        if (p.compact) e *= neigh_box(dl, p);
         return e;
     }
     case 1: {   // mexican hat: (ex(1-2px/d)) * ey  -  ex * ((2py/d) ey)
@@ -118,11 +124,11 @@ __device__ double neigh_factor(int which, int t, int i, int a, const NeighParams
         return which == 0 ? -e : neigh_round(q * e, p);
     }
     case 2:     // bubble
-        return neigh_box(i, a, p);
+        return neigh_box(dl, p);
     default: {  // triangle
         double v = p.sigma - fabs(dl);
         if (v < 0.0) v = 0.0;
-        if (p.compact) v *= neigh_box(i, a, p);
+        if (p.compact) v *= neigh_box(dl, p);
         return neigh_round(v, p);
     }
     }
@@ -138,13 +144,22 @@ __global__ __launch_bounds__(256) void neigh_tables_kernel(NeighParams p, float*
         long r = id / p.Y;
         int j = r % p.Y;
         int t = r / p.Y;
-        P1[id] = (float)neigh_factor(1, t, j, b, p);
+        double v = neigh_factor(1, t % p.base_nt, (double)(j - b), p);
+        if (p.hex) {                                   // class indicator on (s(j), s(cj))
+            const int cls = t / p.base_nt;
+            const int sj = ((p.Y - 1 - j) & 1) == 0, sb = ((p.Y - 1 - b) & 1) == 0;
+            const bool in = cls == 0 ? sj == sb : cls == 1 ? (sj == 0 && sb == 1) : (sj == 1 && sb == 0);
+            if (!in) v = 0.0;
+        }
+        P1[id] = (float)v;
     } else if (id < n1 + n2) {
         long q = id - n1;
         int col = q % ((long)p.nt * p.X);
         int i = q / ((long)p.nt * p.X);
         int t = col / p.X, a = col % p.X;
-        double v = neigh_factor(0, t, i, a, p);
+        const int cls = t / p.base_nt;
+        const double shift = !p.hex ? 0.0 : cls == 1 ? 0.5 : cls == 2 ? -0.5 : 0.0;
+        double v = neigh_factor(0, t % p.base_nt, (double)(i - a) + shift, p);
         P2[q] = p.wide ? (float)(v * p.eta) : (float)v * (float)p.eta;
     }
 }

@@ -92,8 +92,9 @@ class XPySom:
         self._activation_distance_name = activation_distance
         self._activation_distance_kwargs = activation_distance_kwargs
 
-        if topology == 'hexagonal':
-            raise NotImplementedError('hexagonal topology is not in the HIP engine yet (SURVEY 8(f) rank 2)')
+        if topology == 'hexagonal' and neighborhood_function == 'mexican_hat' and compact_support:
+            raise NotImplementedError('mexican_hat with compact_support is not separable (reference bug, '
+                                      'neighborhoods.py:91-93)')
         if not DISTANCES[activation_distance]:
             raise NotImplementedError("activation_distance '%s' is not in the HIP engine yet "
                                       "(SURVEY 8(f) rank 3)" % activation_distance)
@@ -118,7 +119,7 @@ class XPySom:
             x, y, _ = self._weights.shape
             kw = dict(distance=self._activation_distance_name, neighborhood=self.neighborhood_func_name,
                       std_coeff=self._std_coeff, compact_support=self.compact_support,
-                      precision=self._precision)
+                      precision=self._precision, topology=self.topology)
             if self._engine_factory is not None:
                 self._engine_obj = self._engine_factory(x, y, self._input_len, **kw)
             else:
@@ -249,9 +250,15 @@ class XPySom:
         bad, n = 0, 0
         for s in range(0, len(data), self._n_parallel):
             b1, b2 = eng.bmu_top2(data[s:s + self._n_parallel])
-            di = np.abs(b1 // Y - b2 // Y)
-            dj = np.abs(b1 % Y - b2 % Y)
-            bad += int(((di > 1) | (dj > 1)).sum())
+            i1, j1, i2, j2 = b1 // Y, b1 % Y, b2 // Y, b2 % Y
+            if self.topology == 'hexagonal':
+                # euclidean unit coordinates (xpysom.py:201-206): every second row from the last is
+                # shifted by -0.5; not adjacent = farther apart than 1.5 (xpysom.py:739-746)
+                x1 = i1 - 0.5 * ((Y - 1 - j1) % 2 == 0)
+                x2 = i2 - 0.5 * ((Y - 1 - j2) % 2 == 0)
+                bad += int((np.hypot(x1 - x2, (j1 - j2).astype(float)) > 1.5).sum())
+            else:
+                bad += int(((np.abs(i1 - i2) > 1) | (np.abs(j1 - j2) > 1)).sum())
             n += len(b1)
         return bad / n if n else float('nan')
 
