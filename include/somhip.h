@@ -33,7 +33,10 @@ typedef struct som_handle som_handle;
 /* activation distance: distances.py:162-170 registry (names kept) */
 enum { SOM_DIST_EUCLIDEAN = 0,        /* 'euclidean'  -> euclidean_squared_distance_part, distances.py:11-23 */
        SOM_DIST_EUCLIDEAN_NO_OPT = 1, /* 'euclidean_no_opt' -> euclidean_squared_distance, distances.py:25-31 */
-       SOM_DIST_COSINE = 2 };         /* 'cosine'     -> cosine_distance, distances.py:45-59 */
+       SOM_DIST_COSINE = 2,           /* 'cosine'     -> cosine_distance, distances.py:45-59 */
+       SOM_DIST_MANHATTAN = 3,        /* 'manhattan', 'manhattan_no_opt' -> distances.py:109-158 (incl. the `l1norm` CUDA kernel) */
+       SOM_DIST_NORM_P = 4,           /* 'norm_p' -> norm_p_power_distance, distances.py:98-107 (even p: binomial form :77-96) */
+       SOM_DIST_NORM_P_NO_OPT = 5 };  /* 'norm_p_no_opt' -> norm_p_power_distance_generic, distances.py:61-75 */
 
 /* neighbourhood function on the rectangular topology: neighborhoods.py:14-33, :57-74, :99-130 */
 enum { SOM_NEIGH_GAUSSIAN = 0, SOM_NEIGH_MEXICAN_HAT = 1, SOM_NEIGH_BUBBLE = 2, SOM_NEIGH_TRIANGLE = 3 };
@@ -64,7 +67,7 @@ typedef struct som_config {
     double  std_coeff;           /* d = 2*std_coeff^2*sigma^2, neighborhoods.py:19 */
     void*   stream;              /* hipStream_t to launch on; NULL = the library creates its own */
     int32_t topology;            /* SOM_TOPO_* */
-    int32_t reserved;            /* must be 0 */
+    int32_t norm_p;              /* exponent p of SOM_DIST_NORM_P* (activation_distance_kwargs={'p': ...}); 0 = default 2 */
 } som_config;
 
 const char* som_version(void);

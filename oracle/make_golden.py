@@ -108,6 +108,10 @@ def g2():
             out[f"c{c:03d}_sq"] = rdist.euclidean_squared_distance(xa, wa, xp=np)
             out[f"c{c:03d}_l2"] = rdist.euclidean_distance(xa, wa, xp=np)
             out[f"c{c:03d}_cos"] = rdist.cosine_distance(xa, wa, xp=np)
+            out[f"c{c:03d}_l1"] = rdist.manhattan_distance(xa, wa, xp=np)
+            out[f"c{c:03d}_p2"] = rdist.norm_p_power_distance(xa, wa, p=2, xp=np)
+            out[f"c{c:03d}_p3"] = rdist.norm_p_power_distance(xa, wa, p=3, xp=np)
+            out[f"c{c:03d}_p4"] = rdist.norm_p_power_distance(xa, wa, p=4, xp=np)
     out["n_cases"] = np.array(len(cases))
     save("g2_distances", **out)
 
@@ -274,7 +278,14 @@ def g9():
     som = RefSom(X, Y, D, random_seed=5, decay_function="linear", xp=np)
     som.train(data, 8)
     probe = gaussian_blobs(700, D, seed=78)
-    save("g9_inference", data_seed=np.array(77), probe_seed=np.array(78),
+    # BMUs under the remaining activation distances, float32 data as train()/winner() see it
+    extra = {}
+    for name, kw in (("manhattan", {}), ("norm_p", {"p": 2}), ("norm_p", {"p": 3}), ("norm_p", {"p": 4}),
+                     ("norm_p_no_opt", {"p": 2})):
+        s2 = RefSom(X, Y, D, random_seed=5, activation_distance=name, activation_distance_kwargs=kw, xp=np)
+        s2._weights = som._weights
+        extra["win_%s_p%d" % (name, kw.get("p", 1))] = ref_winner_ids(s2, probe)
+    save("g9_inference", **extra, data_seed=np.array(77), probe_seed=np.array(78),
          w=som._weights.astype(F32),
          winner=ref_winner_ids(som, probe),
          winner64=ref_winner_ids(som, probe.astype(np.float64)),

@@ -112,11 +112,47 @@ def dist_cosine(x, w, w_sq=None):
     return 1 - sim
 
 
+def dist_norm_p_generic(x, w, p=2):
+    """distances.py:61-75: sum_d |x-w|^p through the (n, K, D) difference tensor."""
+    return np.sum(np.power(np.abs(x[:, None, :] - w[None, :, :]), p), axis=2)
+
+
+def dist_norm_p_even(x, w, p=2):
+    """distances.py:77-96: binomial expansion, p+1 dot products accumulated in float64."""
+    acc = np.zeros((len(x), len(w)))
+    k = 1
+    for e in range(p + 1):
+        acc += (-1 if e % 2 == 1 else 1) * k * np.dot(x ** (p - e), (w ** e).T)
+        k = (k * (p - e)) // (e + 1)
+    return acc
+
+
+def dist_norm_p(x, w, p=2):
+    """distances.py:98-107."""
+    return dist_norm_p_even(x, w, p) if p % 2 == 0 else dist_norm_p_generic(x, w, p)
+
+
+def dist_manhattan(x, w):
+    """distances.py:138-158 (NumPy path: the generic form with p = 1)."""
+    return dist_norm_p_generic(x, w, 1)
+
+
 DISTANCES = {
     "euclidean": dist_euclid_part,       # distances.py:163
     "euclidean_no_opt": dist_euclid_sq,  # distances.py:164
     "cosine": dist_cosine,               # distances.py:167
 }
+
+
+def bmu_ids_pairwise(x, w, name, p=2):
+    """BMU ids for the distances that take no cached w_sq (distances.py:165-169)."""
+    if name in ("manhattan", "manhattan_no_opt"):
+        d = dist_manhattan(x, w)
+    elif name == "norm_p":
+        d = dist_norm_p(x, w, p)
+    else:
+        d = dist_norm_p_generic(x, w, p)
+    return np.argmin(d, axis=1)
 
 
 def bmu_ids(x, w, distance="euclidean", w_sq=None):

@@ -512,3 +512,39 @@ def test_g10_hexagonal_topology(XY):
     num, den, bmu = e.epoch_fetch()
     _, onum, oden = O.update(data, w0, 0.3, 2.5, wide=True, neighbourhood="gaussian_hex", compact=True, forced_bmu=bmu)
     assert rel_err(num, onum.reshape(-1, D)) < 1e-5 and rel_err(den, oden.reshape(-1)) < 1e-5
+
+
+def test_manhattan_and_norm_p_distances():
+    """'manhattan', 'norm_p' (even and odd p), 'norm_p_no_opt': BMUs against the reference's winner()
+    (golden) -- bit-exact for p <= 2 (NumPy's exact power fast paths), near-ties excepted above."""
+    from xpysom_dask_amd import XPySom
+    g = load_golden("g9_inference")
+    probe = O.gaussian_blobs(700, 10, seed=int(g["probe_seed"]))
+    for name, p in (("manhattan", 1), ("norm_p", 2), ("norm_p_no_opt", 2), ("norm_p", 3), ("norm_p", 4)):
+        som = XPySom(16, 12, 10, random_seed=5, activation_distance=name, activation_distance_kwargs={"p": p})
+        som._weights = g["w"]
+        ids = np.array([i * 12 + j for i, j in som.winner(probe)])
+        ref = g["win_%s_p%d" % (name, p)]
+        if p <= 2:
+            assert np.array_equal(ids, ref), (name, p)
+        else:
+            assert (ids != ref).sum() <= 2, (name, p)
+    # exact-arithmetic binary cases of the reference's distance tests: argmin of every matrix
+    gd = load_golden("g2_distances")
+    for c in range(int(gd["n_cases"]) - 8):
+        x, w = gd[f"c{c:03d}_x"].astype(F32), gd[f"c{c:03d}_w"].astype(F32)
+        K, D = w.shape
+        for dist, key, p in (("manhattan", "l1", 0), ("norm_p", "p2", 2), ("norm_p", "p3", 3), ("norm_p", "p4", 4)):
+            e = engine(K, 1, D, distance=dist, norm_p=p)
+            e.set_weights(w)
+            assert np.array_equal(e.bmu(x), np.argmin(gd[f"c{c:03d}_{key}"], axis=1)), (c, dist, p)
+    # and a training epoch runs through the shared update path
+    data = O.gaussian_blobs(400, 6, seed=2)
+    som = XPySom(7, 7, 6, random_seed=1, activation_distance="manhattan", decay_function="linear")
+    w0 = som._weights.astype(F32)
+    som.train(data, 5, iter_beg=0, iter_end=1)
+    bmu = O.bmu_ids_pairwise(data, w0.reshape(-1, 6), "manhattan")
+    _, onum, oden = O.update(data, w0, O.linear_decay(0.5, 0.01, 0, 5), O.linear_decay(3.5, 1, 0, 5), wide=False,
+                             forced_bmu=bmu)
+    want = O.merge(w0, onum, oden)
+    np.testing.assert_allclose(som._weights, want, rtol=1e-5, atol=1e-6)

@@ -31,9 +31,8 @@ def test_constructor_mirrors_reference_validation():
     assert som._sigma == 2.0 and som._n_parallel == 65536
     with pytest.raises(ValueError, match=r"Received 2 features, expected 3\."):
         som.quantization_error([[1, 2]])
-    # valid reference names the engine does not implement yet say so instead of mis-training
-    with pytest.raises(NotImplementedError):
-        XPySom(5, 5, 1, activation_distance='manhattan')
+    for name in ('manhattan', 'manhattan_no_opt', 'norm_p', 'norm_p_no_opt', 'cosine', 'euclidean_no_opt'):
+        XPySom(5, 5, 1, activation_distance=name)                      # the whole distances.py registry
     with pytest.raises(ValueError, match="triangle not supported"):
         XPySom(5, 5, 1, topology='hexagonal', neighborhood_function='triangle')
 

@@ -244,3 +244,28 @@ def test_g10_hexagonal_topology(XY):
             assert np.array_equal(bmu, g[key + "_bmu"])
             np.testing.assert_allclose(num, g[key + "_num"], rtol=1e-5, atol=1e-5)
             np.testing.assert_allclose(den, g[key + "_den"], rtol=1e-5, atol=1e-6)
+
+
+def test_g2_manhattan_and_norm_p():
+    """The remaining registry entries (distances.py:165-169) against the reference's matrices and
+    the closed forms of its own tests (test_distances.py:115-134)."""
+    g = load_golden("g2_distances")
+    for c in range(int(g["n_cases"])):
+        x, w = g[f"c{c:03d}_x"], g[f"c{c:03d}_w"]
+        np.testing.assert_array_equal(O.dist_manhattan(x, w), g[f"c{c:03d}_l1"])
+        np.testing.assert_array_equal(O.dist_norm_p(x, w, 2), g[f"c{c:03d}_p2"])
+        np.testing.assert_array_equal(O.dist_norm_p(x, w, 3), g[f"c{c:03d}_p3"])
+        np.testing.assert_array_equal(O.dist_norm_p(x, w, 4), g[f"c{c:03d}_p4"])
+        for i, vx in enumerate(x):
+            for j, vy in enumerate(w):
+                assert abs(g[f"c{c:03d}_l1"][i, j] - np.abs(vx - vy).sum()) < 1e-7
+                assert abs(g[f"c{c:03d}_p3"][i, j] - (np.abs(vx - vy) ** 3).sum()) < 1e-7
+                assert abs(g[f"c{c:03d}_p4"][i, j] - ((vx - vy) ** 4).sum()) < 1e-7
+
+
+def test_g9_winner_under_the_other_distances():
+    g = load_golden("g9_inference")
+    probe = O.gaussian_blobs(700, 10, seed=int(g["probe_seed"]))
+    w = g["w"].reshape(-1, 10)
+    for name, p in (("manhattan", 1), ("norm_p", 2), ("norm_p", 3), ("norm_p", 4), ("norm_p_no_opt", 2)):
+        assert np.array_equal(O.bmu_ids_pairwise(probe, w, name, p), g["win_%s_p%d" % (name, p)]), (name, p)

@@ -7,7 +7,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SOM_LIB_PATH") or os.path.join(HERE, "libsomhip.so")   # override: kernel A/B builds
 
-SOM_DIST = {"euclidean": 0, "euclidean_no_opt": 1, "cosine": 2}
+SOM_DIST = {"euclidean": 0, "euclidean_no_opt": 1, "cosine": 2, "manhattan": 3, "manhattan_no_opt": 3,
+            "norm_p": 4, "norm_p_no_opt": 5}
 SOM_NEIGH = {"gaussian": 0, "mexican_hat": 1, "bubble": 2, "triangle": 3}
 SOM_PREC = {"f32": 0, "bf16": 1}
 SOM_TOPO = {"rectangular": 0, "hexagonal": 1}
@@ -20,7 +21,7 @@ class SomConfig(C.Structure):
                 ("distance", C.c_int32), ("neighborhood", C.c_int32),
                 ("compact_support", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32),
                 ("std_coeff", C.c_double), ("stream", C.c_void_p),
-                ("topology", C.c_int32), ("reserved", C.c_int32)]
+                ("topology", C.c_int32), ("norm_p", C.c_int32)]
 
 
 _F = C.POINTER(C.c_float)

@@ -19,6 +19,7 @@
 #include "bmu_bf16_k16.hpp"
 #include "bmu_f32.hpp"
 #include "bmu_f32_res.hpp"
+#include "bmu_pairwise.hpp"
 #include "update.hpp"
 
 using namespace somhip;
@@ -41,6 +42,7 @@ struct som_handle {
     int stage_bytes = 0;     // bytes of one codebook stage image
     int stage_units = 0;     // units per stage
     int nt = 1;              // neighbourhood terms
+    int norm_p = 2;          // exponent of the norm_p distances
     hipStream_t stream = nullptr;
     bool own_stream = false;
 
@@ -344,6 +346,25 @@ int prep_rows_bf16(som_handle* h, const float* X, long N, long Np, __bf16* Xb, f
     return 0;
 }
 
+int launch_bmu_pairwise(som_handle* h, const float* X, long N, int p, bool even, int* out) {
+    size_t w_bytes = (size_t)PW_UNITS * h->D * sizeof(float);
+    size_t x_bytes = (size_t)PW_SAMPLES * (h->D + 1) * sizeof(float);
+    int x_in_lds = w_bytes + x_bytes <= 150 * 1024;
+    size_t lds = w_bytes + (x_in_lds ? x_bytes : 0);
+    if (lds > 150 * 1024) return fail(h, "pairwise distance: input_len too large for the LDS unit tile");
+    long grid = cdiv(N, PW_SAMPLES);
+    if (grid <= 0 || grid > 0x7fffffffL) return fail(h, "bmu_pairwise: row count out of range");
+    if (even) {
+        HIPCHK(h, hipFuncSetAttribute((const void*)bmu_pairwise_kernel<PW_EVEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        bmu_pairwise_kernel<PW_EVEN><<<dim3((unsigned)grid), dim3(PW_SAMPLES), lds, h->stream>>>(X, N, h->D, h->W, h->K, p, x_in_lds, out);
+    } else {
+        HIPCHK(h, hipFuncSetAttribute((const void*)bmu_pairwise_kernel<PW_GENERIC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        bmu_pairwise_kernel<PW_GENERIC><<<dim3((unsigned)grid), dim3(PW_SAMPLES), lds, h->stream>>>(X, N, h->D, h->W, h->K, p, x_in_lds, out);
+    }
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 // BMU of `N` device rows with the configured activation distance (xpysom.py:410-417)
 int run_activation_bmu(som_handle* h, const float* X, long N, const float* xsq, const __bf16* Xb, const float* xmax2,
                        int* out) {
@@ -355,12 +376,16 @@ int run_activation_bmu(som_handle* h, const float* X, long N, const float* xsq, 
     case SOM_DIST_EUCLIDEAN: return launch_bmu_f32_any<SCORE_EUCLID_PART>(h, X, N, xsq, out);
     case SOM_DIST_EUCLIDEAN_NO_OPT: return launch_bmu_f32_any<SCORE_EUCLID_SQ>(h, X, N, xsq, out);
     case SOM_DIST_COSINE: return launch_bmu_f32_any<SCORE_COSINE>(h, X, N, xsq, out);
+    case SOM_DIST_MANHATTAN: return launch_bmu_pairwise(h, X, N, 1, false, out);
+    case SOM_DIST_NORM_P_NO_OPT: return launch_bmu_pairwise(h, X, N, h->norm_p, false, out);
+    case SOM_DIST_NORM_P: return launch_bmu_pairwise(h, X, N, h->norm_p, h->norm_p % 2 == 0, out);
     }
     return fail(h, "unknown distance id");
 }
 
 bool needs_xsq(const som_handle* h) {
-    return h->cfg.precision == SOM_PREC_F32 && h->cfg.distance != SOM_DIST_EUCLIDEAN;
+    return h->cfg.precision == SOM_PREC_F32 &&
+           (h->cfg.distance == SOM_DIST_EUCLIDEAN_NO_OPT || h->cfg.distance == SOM_DIST_COSINE);
 }
 
 int row_sq(som_handle* h, const float* X, long N, float* out) {
@@ -453,7 +478,10 @@ int som_create(const som_config* cfg, som_handle** out) {
     if (!cfg) return fail(nullptr, "som_create: cfg is NULL");
     if (cfg->x < 1 || cfg->y < 1 || cfg->input_len < 1) return fail(nullptr, "som_create: x, y, input_len must be >= 1");
     if ((long)cfg->x * cfg->y > (1L << 30)) return fail(nullptr, "som_create: map too large");
-    if (cfg->distance < 0 || cfg->distance > SOM_DIST_COSINE) return fail(nullptr, "som_create: unknown distance id");
+    if (cfg->distance < 0 || cfg->distance > SOM_DIST_NORM_P_NO_OPT) return fail(nullptr, "som_create: unknown distance id");
+    if (cfg->norm_p < 0 || cfg->norm_p > PW_MAX_P) return fail(nullptr, "som_create: norm_p out of range (1..16)");
+    if (cfg->distance >= SOM_DIST_MANHATTAN && cfg->precision != SOM_PREC_F32)
+        return fail(nullptr, "som_create: manhattan / norm_p distances are float32 VALU kernels (precision f32)");
     if (cfg->neighborhood < 0 || cfg->neighborhood > SOM_NEIGH_TRIANGLE)
         return fail(nullptr, "som_create: unknown neighbourhood id");
     if (cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT && cfg->compact_support)
@@ -482,6 +510,7 @@ int som_create(const som_config* cfg, som_handle** out) {
     h->cfg = *cfg;
     h->X = cfg->x; h->Y = cfg->y; h->K = cfg->x * cfg->y; h->D = cfg->input_len;
     h->D1p = (int)round_up(h->D + 1, 4);
+    h->norm_p = cfg->norm_p > 0 ? cfg->norm_p : 2;
     h->ksteps = (int)cdiv(h->D, 16);
     h->ks32 = (int)cdiv(h->D, 32);
     {   // SOM_BF16_SHAPE=32 selects the 32x32x16 kernel (A/B against the default 16x16x32)

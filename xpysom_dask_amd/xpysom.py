@@ -20,8 +20,8 @@ TOPOLOGIES = ("hexagonal", "rectangular")
 # name -> implemented in the HIP engine?   (registry order follows xpysom.py:260-283)
 NEIGHBORHOODS = {"gaussian": True, "mexican_hat": True, "bubble": True, "triangle": True}
 # distances.py:162-170 registry; False = valid reference name the engine does not cover yet
-DISTANCES = {"euclidean": True, "euclidean_no_opt": True, "manhattan": False, "manhattan_no_opt": False,
-             "cosine": True, "norm_p": False, "norm_p_no_opt": False}
+DISTANCES = {"euclidean": True, "euclidean_no_opt": True, "manhattan": True, "manhattan_no_opt": True,
+             "cosine": True, "norm_p": True, "norm_p_no_opt": True}
 DEFAULT_BATCH_ROWS = 65536
 
 
@@ -120,6 +120,8 @@ class XPySom:
             kw = dict(distance=self._activation_distance_name, neighborhood=self.neighborhood_func_name,
                       std_coeff=self._std_coeff, compact_support=self.compact_support,
                       precision=self._precision, topology=self.topology)
+            if self._activation_distance_name.startswith('norm_p'):
+                kw['norm_p'] = int(self._activation_distance_kwargs.get('p', 2))
             if self._engine_factory is not None:
                 self._engine_obj = self._engine_factory(x, y, self._input_len, **kw)
             else:
