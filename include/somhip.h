@@ -118,6 +118,10 @@ int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, in
 /* best and second-best unit per row under the full Euclidean distance (sqrt + nan_to_num):
  * what XPySom.topographic_error takes from argsort(distances)[:, :2], xpysom.py:727-734 */
 int som_bmu_top2(som_handle* h, const float* x_host, int64_t n_rows, int32_t* ids1_out, int32_t* ids2_out);
+/* the (n_rows, K) distance matrix itself, row-major, for the analysis calls that return it:
+ * mode ACTIVATION = XPySom.activate (xpysom.py:323-354, configured GEMM-form distance),
+ * mode QUANTIZATION = XPySom.distance_from_weights (xpysom.py:647-671).  Never used while training. */
+int som_distance_matrix(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, float* dist_out);
 /* mean_n |x_n - W[bmu_n]|: XPySom.quantization_error, xpysom.py:673-707 */
 int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, double* qe_out);
 

@@ -548,3 +548,45 @@ def test_manhattan_and_norm_p_distances():
                              forced_bmu=bmu)
     want = O.merge(w0, onum, oden)
     np.testing.assert_allclose(som._weights, want, rtol=1e-5, atol=1e-6)
+
+
+def test_activate_distance_from_weights_and_distance_map():
+    """The analysis calls that return the (n, K) matrix, with the reference's unit-test answers
+    (xpysom_dask/tests.py:66-75,136-143) and the golden distance matrices (bit-exact)."""
+    from xpysom_dask_amd import XPySom
+    som = XPySom(5, 5, 1, std_coeff=1)
+    som._weights = np.zeros((5, 5, 1))
+    som._weights[2, 3] = 5.0
+    som._weights[1, 1] = 2.0
+    assert som.activate(5.0).argmin() == 13
+    data = np.arange(-5, 5).reshape(-1, 1)
+    d = som.distance_from_weights(data, None)
+    wf = som._weights.reshape(-1, 1)
+    for i in range(len(data)):
+        for j in range(len(wf)):
+            assert d[i][j] == np.linalg.norm(data[i] - wf[j])
+    som2 = XPySom(2, 2, 2, random_seed=1)
+    som2._weights = np.array([[[1., 0.], [0., 1.]], [[1., 0.], [0., 1.]]])
+    np.testing.assert_array_equal(som2.distance_map(), np.array([[1., 1.], [1., 1.]]))
+    g = load_golden("g2_distances")
+    for c in range(int(g["n_cases"])):                           # float64 goldens; float32-exact cases only
+        x, w = g[f"c{c:03d}_x"], g[f"c{c:03d}_w"]
+        if c >= int(g["n_cases"]) - 8:
+            continue
+        K, D = w.shape
+        for dist, key in (("euclidean", "part"), ("euclidean_no_opt", "sq"), ("cosine", "cos")):
+            e = engine(K, 1, D, distance=dist)
+            e.set_weights(w.astype(F32))
+            got, want = e.distance_matrix(x.astype(F32)), g[f"c{c:03d}_{key}"]
+            if key == "cos":                                     # float64 golden: sqrt/divide round differently
+                np.testing.assert_allclose(got, want, rtol=0, atol=2e-7)
+            else:                                                # small integers: exact in any precision
+                np.testing.assert_array_equal(got, want.astype(F32))
+        np.testing.assert_allclose(e.distance_matrix(x.astype(F32), quantization=True), g[f"c{c:03d}_l2"], rtol=0, atol=2e-7)
+    # float data: bit-identical to NumPy float32 on the host the goldens came from; here to rounding
+    rs = np.random.RandomState(3)
+    x, w = rs.randn(70, 9).astype(F32), rs.randn(33, 9).astype(F32)
+    e = engine(33, 1, 9)
+    e.set_weights(w)
+    np.testing.assert_allclose(e.distance_matrix(x), O.dist_euclid_part(x, w), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(e.distance_matrix(x, quantization=True), O.dist_euclid(x, w), rtol=1e-5, atol=1e-5)

@@ -148,6 +148,63 @@ __global__ __launch_bounds__(256) void bmu_f32_kernel(const float* __restrict__ 
     }
 }
 
+// The (n, K) distance matrix itself, for the analysis calls that return it: XPySom.activate
+// (xpysom.py:323-354, configured distance) and distance_from_weights (:647-671, sqrt'd Euclidean).
+// Same tiling and the same bit-exact arithmetic as bmu_f32_kernel; the epilogue stores instead of
+// reducing.  Not on the training path (nothing there materialises (n, K)).
+template <int MODE>
+__global__ __launch_bounds__(256) void dist_matrix_f32_kernel(const float* __restrict__ X, long N, int D, int Dp,
+                                                              const float* __restrict__ W,
+                                                              const float* __restrict__ wsq, int K,
+                                                              const float* __restrict__ xsq,
+                                                              float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* Ws = smem_f;
+    float* wq = Ws + F32_UB * (F32_KC + 1);
+    float* Xs = wq + F32_UB;
+    const int xstride = F32_KC + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const long s0 = (long)blockIdx.x * F32_SB;
+    const long my_sample = s0 + wave * 32 + col;
+    const int u0 = blockIdx.y * F32_UB;
+    float xs = 0.0f;
+    if (MODE != SCORE_EUCLID_PART) xs = (my_sample < N) ? xsq[my_sample] : 0.0f;
+    f32x16 acc[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
+    for (int kc = 0; kc < Dp; kc += F32_KC) {
+        __syncthreads();
+        for (int idx = tid; idx < F32_UB * F32_KC; idx += 256) {
+            int r = idx >> 5, k = idx & 31;
+            Ws[r * (F32_KC + 1) + k] = (u0 + r < K && kc + k < D) ? W[(long)(u0 + r) * D + kc + k] : 0.0f;
+            Xs[r * xstride + k] = (s0 + r < N && kc + k < D) ? X[(s0 + r) * (long)D + kc + k] : 0.0f;
+        }
+        if (kc == 0 && tid < F32_UB) wq[tid] = (u0 + tid < K) ? wsq[u0 + tid] : 0.0f;
+        __syncthreads();
+        const float* xrow = Xs + (wave * 32 + col) * xstride + half;
+        const float* wrow = Ws + col * (F32_KC + 1) + half;
+#pragma unroll
+        for (int k = 0; k < F32_KC; k += 2) {
+            float b = xrow[k];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[rb * 32 * (F32_KC + 1) + k], b, acc[rb], 0, 0, 0);
+        }
+    }
+    if (my_sample < N) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = rb * 32 + mfma32_row(r, half);
+                if (u0 + row < K) out[my_sample * K + u0 + row] = score_f32<MODE>(acc[rb][r], wq[row], xs);
+            }
+    }
+}
+
 // sum of squares of each row, float32: xp.power(a, 2).sum(axis=1) -- xpysom.py:529-537 (w_sq),
 // distances.py:30,53 (x_sq).  The squares are rounded to float32 first and then added in
 // NumPy's pairwise order (n < 8 sequential; n <= 128 eight strided accumulators joined as a

@@ -457,6 +457,16 @@ int ensure_query_scratch(som_handle* h, long n) {
     return 0;
 }
 
+template <int MODE>
+int launch_dist_matrix(som_handle* h, long N, float* out) {
+    const int Dp = (int)round_up(h->D, F32_KC);
+    size_t lds = (size_t)(F32_UB * (F32_KC + 1) + F32_UB + F32_SB * (F32_KC + 1)) * sizeof(float);
+    dim3 grid((unsigned)cdiv(N, F32_SB), (unsigned)cdiv(h->K, F32_UB));
+    dist_matrix_f32_kernel<MODE><<<grid, dim3(256), lds, h->stream>>>(h->qX, N, h->D, Dp, h->W, h->wsq, h->K, h->qxsq, out);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 // ==============================================================================================
@@ -749,6 +759,35 @@ int som_bmu_top2(som_handle* h, const float* x_host, int64_t n_rows, int32_t* id
     HIPCHK(h, hipMemcpyAsync(ids2_out, h->qbmu2, (size_t)n_rows * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
+}
+
+int som_distance_matrix(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, float* dist_out) {
+    if (h) (void)hipSetDevice(h->cfg.device);
+    if (!h || n_rows < 0 || (n_rows > 0 && (!x_host || !dist_out))) return fail(h, "som_distance_matrix: bad argument");
+    if (mode != SOM_BMU_ACTIVATION && mode != SOM_BMU_QUANTIZATION) return fail(h, "som_distance_matrix: unknown mode");
+    if (mode == SOM_BMU_ACTIVATION && h->cfg.distance > SOM_DIST_COSINE)
+        return fail(h, "som_distance_matrix: only the GEMM-form distances (euclidean, euclidean_no_opt, cosine)");
+    if (n_rows == 0) return 0;
+    if ((double)n_rows * h->K > 2.0e9) return fail(h, "som_distance_matrix: n_rows * K too large (analysis call, chunk it)");
+    if (int rc = ensure_query_scratch(h, n_rows)) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->qX, x_host, (size_t)n_rows * h->D * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (int rc = refresh_codebook_operands(h)) return rc;
+    if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
+    float* dm = nullptr;
+    if (int rc = dev_alloc(h, &dm, (size_t)n_rows * h->K)) return rc;
+    int rc = 0;
+    if (mode == SOM_BMU_QUANTIZATION) rc = launch_dist_matrix<SCORE_EUCLID_SQRT>(h, n_rows, dm);
+    else if (h->cfg.distance == SOM_DIST_EUCLIDEAN) rc = launch_dist_matrix<SCORE_EUCLID_PART>(h, n_rows, dm);
+    else if (h->cfg.distance == SOM_DIST_EUCLIDEAN_NO_OPT) rc = launch_dist_matrix<SCORE_EUCLID_SQ>(h, n_rows, dm);
+    else rc = launch_dist_matrix<SCORE_COSINE>(h, n_rows, dm);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(dist_out, dm, (size_t)n_rows * h->K * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail_hip(h, "som_distance_matrix copy", e);
+    }
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(dm);
+    return rc;
 }
 
 int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, double* qe_out) {

@@ -150,6 +150,16 @@ class HipEngine:
         self._check(self._lib.som_bmu_top2(self._h, self._fp(x), x.shape[0], self._ip(a), self._ip(b)))
         return a, b
 
+    def distance_matrix(self, x, quantization=False):
+        """The (n, K) distance matrix (analysis only)."""
+        x = _f32(x)
+        if x.ndim != 2 or x.shape[1] != self.D:
+            raise ValueError("x must be (n, %d), got %r" % (self.D, x.shape))
+        out = np.empty((x.shape[0], self.K), dtype=np.float32)
+        mode = _lib.SOM_BMU_QUANTIZATION if quantization else _lib.SOM_BMU_ACTIVATION
+        self._check(self._lib.som_distance_matrix(self._h, self._fp(x), x.shape[0], mode, self._fp(out)))
+        return out
+
     def quantization_error(self, x):
         x = _f32(x)
         out = C.c_double()

@@ -142,6 +142,55 @@ class XPySom:
         """Returns the weights of the neural network."""
         return self._weights
 
+    def get_euclidean_coordinates(self):
+        """Meshgrids (xx, yy) of the units' positions on the euclidean plane of the chosen topology:
+        unit (i, j) sits at (xx[i, j], yy[i, j]) (xpysom.py:291-305)."""
+        xx, yy = np.meshgrid(self._neigx, self._neigy)
+        xx, yy = xx.astype(float), yy.astype(float)
+        if self.topology == 'hexagonal':
+            xx[::-2] -= 0.5
+        return xx.T, yy.T
+
+    def convert_map_to_euclidean(self, xy):
+        """Map coordinates -> euclidean coordinates of the chosen topology (xpysom.py:308-320)."""
+        xx, yy = self.get_euclidean_coordinates()
+        return xx[xy], yy[xy]
+
+    def activate(self, x):
+        """Activation map of x: its distance to every unit under the configured distance, shape (n, K)
+        (xpysom.py:323-354).  An analysis call: training never materialises this matrix."""
+        x = np.asarray(x, dtype=np.float32)
+        if x.ndim == 0:
+            x = x.reshape(1, 1)
+        elif x.ndim == 1:
+            x = x[None, :]
+        return self._upload_weights().distance_matrix(x)
+
+    def distance_from_weights(self, data, weights_gpu=None):
+        """d[i, j] = euclidean distance between data[i] and the j-th unit (xpysom.py:647-671)."""
+        data = np.asarray(data, dtype=np.float32)
+        return self._upload_weights().distance_matrix(data, quantization=True)
+
+    def distance_map(self):
+        """Normalised sum of the distances between each unit and its neighbours (U-matrix),
+        xpysom.py:788-817; host-side, the codebook is tiny next to the data."""
+        w = np.asarray(self._weights)
+        X, Y = w.shape[:2]
+        um = np.zeros((X, Y, 8))
+        ii = [[0, -1, -1, -1, 0, 1, 1, 1]] * 2
+        jj = [[-1, -1, 0, 1, 1, 1, 0, -1]] * 2
+        if self.topology == 'hexagonal':
+            ii = [[1, 1, 1, 0, -1, 0], [0, 1, 0, -1, -1, -1]]
+            jj = [[1, 0, -1, -1, 0, 1], [1, 0, -1, -1, 0, 1]]
+        for x in range(X):
+            for y in range(Y):
+                e = y % 2 == 0
+                for k, (i, j) in enumerate(zip(ii[e], jj[e])):
+                    if 0 <= x + i < X and 0 <= y + j < Y:
+                        um[x, y, k] = np.linalg.norm(w[x, y] - w[x + i, y + j])
+        um = um.sum(axis=2)
+        return um / um.max()
+
     def _check_input_len(self, data):
         """Checks that the data in input is of the correct shape (xpysom.py:360-366)."""
         data_len = len(data[0])
