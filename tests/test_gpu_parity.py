@@ -590,3 +590,34 @@ def test_activate_distance_from_weights_and_distance_map():
     e.set_weights(w)
     np.testing.assert_allclose(e.distance_matrix(x), O.dist_euclid_part(x, w), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(e.distance_matrix(x, quantization=True), O.dist_euclid(x, w), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("X,Y,D,n", [(12, 11, 200, 700), (6, 7, 784, 300), (20, 13, 130, 1100)])
+def test_bf16_large_input_len_tiled_kernel(X, Y, D, n):
+    """input_len > 128 in bf16 mode (two-sided tiling, BASELINE configs[4] has 784 features):
+    every pick is the float32 BMU or a unit within the bf16 operand rounding of it; the update path
+    is the shared exact-f32 one; cosine runs on the unit-length image."""
+    data = O.gaussian_blobs(n, D, seed=D)
+    w = O.default_codebook(X, Y, D, 9).astype(F32) * 5
+    wf = w.reshape(-1, D)
+    e = engine(X, Y, D, precision="bf16")
+    e.set_weights(w)
+    e.set_data(data)
+    e.epoch_accumulate(3.0, 0.4, True)
+    num, den, bmu = e.epoch_fetch()
+    ref = O.bmu_ids(data, wf)
+    bad = np.flatnonzero(bmu != ref)
+    assert len(bad) <= 0.1 * n
+    assert bf16_misses_are_near_best(data, wf, bmu, bad)
+    _, onum, oden = O.update(data, w, 0.4, 3.0, wide=True, forced_bmu=bmu)
+    assert rel_err(num, onum.reshape(-1, D)) < 1e-5 and rel_err(den, oden.reshape(-1)) < 1e-5
+    assert np.array_equal(e.bmu(data[:37]), bmu[:37]) or (e.bmu(data[:37]) != bmu[:37]).sum() <= 2
+    # cosine
+    pos = np.abs(data)
+    wpos = np.abs(w)
+    ec = engine(X, Y, D, precision="bf16", distance="cosine")
+    ec.set_weights(wpos)
+    got = ec.bmu(pos)
+    x64, w64 = pos.astype(np.float64), wpos.reshape(-1, D).astype(np.float64)
+    sim = (x64 @ w64.T) / np.sqrt((x64 ** 2).sum(1)[:, None] * (w64 ** 2).sum(1)[None, :])
+    assert (sim[np.arange(n), got] >= sim.max(1) - 2.0 ** -7).all()

@@ -1,0 +1,189 @@
+// Fused distance + BMU argmin, bf16, for input_len > 128 (BASELINE configs[4]: 784 features).
+//
+// With more than 128 features a wave can no longer keep its samples' B operands in registers for
+// the whole codebook scan, so this kernel is a classic two-sided GEMM tiling with the same fused
+// argmin epilogue instead of a C write:
+//   * workgroup tile = 128 samples x 128 units, 4 waves as 2 x 2, wave tile 64 x 64
+//     (16 v_mfma_f32_16x16x32_bf16 accumulators = 64 VGPRs), K-loop over the features in chunks of 64;
+//   * BOTH operands are pre-arranged in HBM in MFMA fragment order, per (128-row block, 64-feature
+//     chunk) one contiguous 16 KiB tile [t16 0..7][kstep 0..1][lane 0..63][8 bf16]; the W tiles carry
+//     their 128 initial accumulators (B + |w~|^2/2) behind them.  A stage (X tile + W tile, 33 KiB)
+//     is therefore two linear LDS-DMA bursts, and every fragment read is a lane-linear ds_read_b128;
+//   * 2-slot LDS ring, one barrier per stage, next stage in flight under the 32 MFMAs per wave;
+//   * arithmetic, offset B, key packing, part split and 64-bit atomicMin merge exactly as in
+//     bmu_bf16_k16.hpp (which stays the kernel for input_len <= 128: it reads X once, this one
+//     re-reads the sample tile for every 128-unit block, from L2 / Infinity Cache).
+#pragma once
+#include "bmu_bf16.hpp"
+
+namespace somhip {
+
+constexpr int TL_BM = 128, TL_BN = 128, TL_BK = 64;
+constexpr int TL_TILE = (TL_BM / 16) * (TL_BK / 32) * 1024;     // 16 KiB of fragments
+constexpr int TL_WTILE = TL_TILE + 1024;                        // + 128 initial accumulators (padded)
+constexpr int TL_STAGE = TL_TILE + TL_WTILE;                    // 33 KiB
+constexpr int TL_XPIECES = TL_TILE / 1024, TL_WPIECES = TL_WTILE / 1024;
+
+// rows (samples or units) -> fragment-ordered tiles.  One thread per 16-byte chunk.
+// img layout: [block of 128 rows][kchunk][t16 0..7][ks 0..1][lane][8 bf16]  (tile_bytes per (block,kchunk))
+__global__ __launch_bounds__(256) void prep_tiles_bf16_kernel(const float* __restrict__ A, long rows, int D,
+                                                              int n_kchunks, long n_blocks, int tile_bytes,
+                                                              float sign, const float* __restrict__ unit_sq,
+                                                              char* __restrict__ img) {
+    long id = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per_block = (long)n_kchunks * 8 * 2 * 64;
+    if (id >= n_blocks * per_block) return;
+    long blk = id / per_block;
+    int r = (int)(id - blk * per_block);
+    int lane = r & 63;
+    int t = r >> 6;
+    int ks = t & 1; t >>= 1;
+    int t16 = t & 7;
+    int kc = t >> 3;
+    long row = blk * 128 + t16 * 16 + (lane & 15);
+    int k0 = kc * TL_BK + ks * 32 + (lane >> 4) * 8;
+    float scale = sign;
+    if (unit_sq != nullptr && row < rows) { float q = unit_sq[row]; scale = q > 0.0f ? sign / __builtin_sqrtf(q) : 0.0f; }
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float f = (row < rows && k0 + j < D) ? A[row * D + k0 + j] * scale : 0.0f;
+        v[j] = (__bf16)f;
+    }
+    *(bf16x8*)(img + (blk * n_kchunks + kc) * (long)tile_bytes + ((long)(t16 * 2 + ks) * 64 + lane) * 16) = v;
+}
+
+// |a~_row|^2 of bf16-rounded (optionally unit-scaled) rows and their maximum.  One wave per row.
+__global__ __launch_bounds__(256) void rownorm_bf16_kernel(const float* __restrict__ A, long rows, int D,
+                                                           const float* __restrict__ unit_sq, int zero_norm,
+                                                           float* __restrict__ norm2, float* __restrict__ max2) {
+    long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float scale = 1.0f;
+    if (unit_sq != nullptr) { float q = unit_sq[row]; scale = q > 0.0f ? 1.0f / __builtin_sqrtf(q) : 0.0f; }
+    float s = 0.0f;
+    for (int k = lane; k < D; k += 64) { float f = (float)(__bf16)(A[row * D + k] * scale); s = __builtin_fmaf(f, f, s); }
+    s = wave_sum(s);
+    if (lane == 0) {
+        if (norm2) norm2[row] = zero_norm ? 0.0f : s;
+        atomic_max_pos_f32(max2, s);
+    }
+}
+
+// initial accumulators B + |w~|^2/2 behind every W tile of a unit block
+__global__ __launch_bounds__(256) void prep_tiles_cin_kernel(const float* __restrict__ wn, int K,
+                                                             const float* __restrict__ wmax2,
+                                                             const float* __restrict__ xmax2, int n_kchunks,
+                                                             long n_ublocks, char* __restrict__ Wimg) {
+    long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= n_ublocks * n_kchunks * 128) return;
+    int within = id & 127;
+    long tile = id >> 7;                                   // (ublock * n_kchunks + kc)
+    long u = (tile / n_kchunks) * 128 + within;
+    const float big = __builtin_sqrtf(*wmax2) * __builtin_sqrtf(*xmax2) * (1.0f + 1.0f / 1024.0f);
+    ((float*)(Wimg + tile * (long)TL_WTILE + TL_TILE))[within] = u < K ? __builtin_fmaf(0.5f, wn[u], big) : BF_PAD_NORM;
+}
+
+__global__ __launch_bounds__(256, 2) void bmu_bf16_tiled_kernel(const char* __restrict__ Ximg, long N,
+                                                                const char* __restrict__ Wimg, int n_ublocks,
+                                                                int n_kchunks, int K,
+                                                                unsigned long long* __restrict__ out64) {
+    constexpr uint32_t IDX_MASK = 15u;                   // (tile16 << 2 | reg) in the low mantissa bits
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;             // sample half, unit half
+    const int quad = lane >> 4, col = lane & 15;
+    const long sblock = blockIdx.x;
+
+    const int ub_begin = (int)((long)n_ublocks * blockIdx.y / gridDim.y);
+    const int ub_end = (int)((long)n_ublocks * (blockIdx.y + 1) / gridDim.y);
+    const long n_stages = (long)(ub_end - ub_begin) * n_kchunks;
+
+    auto issue = [&](long q, int slot) {
+        const int ub = ub_begin + (int)(q / n_kchunks);
+        const int kc = (int)(q % n_kchunks);
+        const char* xs = Ximg + (sblock * n_kchunks + kc) * (long)TL_TILE;
+        const char* ws = Wimg + ((long)ub * n_kchunks + kc) * (long)TL_WTILE;
+        char* dst = smem + slot * TL_STAGE;
+        for (int p = wave; p < TL_XPIECES + TL_WPIECES; p += 4) {
+            if (p < TL_XPIECES) lds_dma_16(xs + (long)p * 1024 + lane * 16, dst + p * 1024);
+            else lds_dma_16(ws + (long)(p - TL_XPIECES) * 1024 + lane * 16, dst + p * 1024);
+        }
+    };
+
+    int32_t gbest[4];
+    int gblock[4];
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) { gbest[sb] = 0x7FFFFFFF; gblock[sb] = 0; }
+    f32x4 acc[4][4];                                     // [unit tile16][sample block16]
+
+    if (n_stages > 0) issue(0, 0);
+    int ub = ub_begin, kc = 0;
+    for (long q = 0; q < n_stages; ++q) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (q + 1 < n_stages) issue(q + 1, (int)((q + 1) & 1));
+        const char* xs = smem + (q & 1) * TL_STAGE;
+        const char* ws = xs + TL_TILE;
+
+        if (kc == 0) {                                   // C-in = B + |w~|^2/2 of this wave's 64 units
+            const float* wq = (const float*)(ws + TL_TILE) + wc * 64 + 4 * quad;
+#pragma unroll
+            for (int tu = 0; tu < 4; ++tu) {
+                const f32x4 wv = *(const f32x4*)(wq + tu * 16);
+#pragma unroll
+                for (int sb = 0; sb < 4; ++sb) acc[tu][sb] = wv;
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int tu = 0; tu < 4; ++tu) a[tu] = *(const bf16x8*)(ws + (((wc * 4 + tu) * 2 + ks) * 64 + lane) * 16);
+#pragma unroll
+            for (int sb = 0; sb < 4; ++sb) b[sb] = *(const bf16x8*)(xs + (((wr * 4 + sb) * 2 + ks) * 64 + lane) * 16);
+#pragma unroll
+            for (int tu = 0; tu < 4; ++tu)
+#pragma unroll
+                for (int sb = 0; sb < 4; ++sb)
+                    acc[tu][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tu], b[sb], acc[tu][sb], 0, 0, 0);
+        }
+        if (kc == n_kchunks - 1) {                       // the 64 x 64 block of distances is complete: reduce it
+#pragma unroll
+            for (int sb = 0; sb < 4; ++sb) {
+                int32_t c0 = 0x7FFFFFFF, c1 = 0x7FFFFFFF;
+#pragma unroll
+                for (int tu = 0; tu < 4; ++tu) {
+                    const float f0 = acc[tu][sb][0], f1 = acc[tu][sb][1], f2 = acc[tu][sb][2], f3 = acc[tu][sb][3];
+                    const int32_t k0 = (int32_t)((__float_as_uint(f0) & ~IDX_MASK) | (uint32_t)(tu * 4 + 0));
+                    const int32_t k1 = (int32_t)((__float_as_uint(f1) & ~IDX_MASK) | (uint32_t)(tu * 4 + 1));
+                    const int32_t k2 = (int32_t)((__float_as_uint(f2) & ~IDX_MASK) | (uint32_t)(tu * 4 + 2));
+                    const int32_t k3 = (int32_t)((__float_as_uint(f3) & ~IDX_MASK) | (uint32_t)(tu * 4 + 3));
+                    c0 = min(min(c0, k0), k1);
+                    c1 = min(min(c1, k2), k3);
+                }
+                const int32_t c = min(c0, c1);
+                if (c < gbest[sb]) { gbest[sb] = c; gblock[sb] = ub; }
+            }
+        }
+        if (++kc == n_kchunks) { kc = 0; ++ub; }
+    }
+
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) {
+        const uint32_t code = (uint32_t)gbest[sb] & IDX_MASK;
+        const uint32_t unit = (uint32_t)gblock[sb] * TL_BN + wc * 64 + (code >> 2) * 16 + quad * 4 + (code & 3);
+        unsigned long long comp = ((unsigned long long)((uint32_t)gbest[sb] & ~IDX_MASK) << 32) | unit;
+        unsigned long long o = __shfl_xor(comp, 16, 64);
+        if (o < comp) comp = o;
+        o = __shfl_xor(comp, 32, 64);
+        if (o < comp) comp = o;
+        const long row = sblock * TL_BM + wr * 64 + sb * 16 + col;
+        if (quad == 0 && row < N && n_stages > 0) atomicMin(out64 + row, comp);
+    }
+}
+
+}  // namespace somhip

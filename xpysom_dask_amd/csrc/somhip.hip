@@ -17,6 +17,7 @@
 #include "../../include/somhip.h"
 #include "bmu_bf16.hpp"
 #include "bmu_bf16_k16.hpp"
+#include "bmu_bf16_tiled.hpp"
 #include "bmu_f32.hpp"
 #include "bmu_f32_res.hpp"
 #include "bmu_pairwise.hpp"
@@ -38,6 +39,9 @@ struct som_handle {
     int ksteps = 0;          // bf16, 32x32x16 shape: ceil(D/16)
     int ks32 = 0;            // bf16, 16x16x32 shape: ceil(D/32)
     bool shape16 = true;     // which MFMA shape the bf16 kernel uses
+    bool tiled = false;      // bf16, input_len > 128: two-sided tiling (bmu_bf16_tiled.hpp)
+    int n_kchunks = 0;       // tiled: 64-feature chunks
+    int n_ublocks = 0;       // tiled: 128-unit blocks
     int dp = 0;              // feature stride of the bf16 row image
     int stage_bytes = 0;     // bytes of one codebook stage image
     int stage_units = 0;     // units per stage
@@ -166,6 +170,18 @@ int refresh_codebook_operands(som_handle* h) {
         prep_w_f32_res_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(h->W, h->wsq, h->K, h->D,
                                                                                           h->fr_kg, h->Wfst, h->fr_stages);
     }
+    if (h->cfg.precision == SOM_PREC_BF16 && h->tiled) {
+        const float* unit = h->cfg.distance == SOM_DIST_COSINE ? h->wsq : nullptr;
+        long total = (long)h->n_ublocks * h->n_kchunks * 8 * 2 * 64;
+        prep_tiles_bf16_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
+            h->W, h->K, h->D, h->n_kchunks, h->n_ublocks, TL_WTILE, -1.0f, unit, h->Wst);
+        HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
+        rownorm_bf16_kernel<<<dim3((unsigned)cdiv(h->K, 4)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, unit,
+                                                                                       unit != nullptr, h->wn, h->wmax2);
+        HIPCHK(h, hipGetLastError());
+        h->w_dirty = false;
+        return 0;
+    }
     if (h->cfg.precision == SOM_PREC_BF16 && h->shape16) {
         switch (h->ks32) {
         case 1: launch_prep_w_k16<1>(h); break;
@@ -268,6 +284,27 @@ int launch_bmu_bf16_ks(som_handle* h, const __bf16* Xb, long N, int* out) {
     return 0;
 }
 
+// Number of codebook parts the scan is split into: fill whole rounds of the resident workgroup
+// slots (large inputs) or spread a short scan over the chip (few rows: winner / small data).
+int choose_parts(som_handle* h, long blocks, long slots, int max_parts_hint) {
+    (void)h;
+    int parts = 1;
+    if (blocks < slots) {
+        parts = (int)(slots / blocks);
+        if (parts > 8) parts = 8;
+    } else {
+        double best_eff = 0.0;
+        for (int p = 1; p <= 4; ++p) {
+            long wgs = blocks * p;
+            double eff = (double)wgs / (double)(cdiv(wgs, slots) * slots);
+            if (eff > best_eff + 0.02) { best_eff = eff; parts = p; }
+        }
+    }
+    if (parts > max_parts_hint) parts = max_parts_hint;
+    if (parts < 1) parts = 1;
+    return parts;
+}
+
 template <int KS32>
 int launch_bmu_bf16_k16(som_handle* h, const __bf16* Xb, long N, int* out) {
     size_t lds = 2 * (size_t)k16_stage_bytes(KS32);
@@ -279,20 +316,7 @@ int launch_bmu_bf16_k16(som_handle* h, const __bf16* Xb, long N, int* out) {
     int per_cu = 0;
     HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)bmu_bf16_k16_kernel<KS32>, 256, lds));
     const long slots = (long)(per_cu > 0 ? per_cu : 1) * (h->n_cus > 0 ? h->n_cus : 256);
-    int parts = 1;
-    if (blocks < slots) {                       // few rows (winner / small data): spread the scan itself
-        parts = (int)(slots / blocks);
-        if (parts > 8) parts = 8;
-    } else {
-        double best_eff = 0.0;
-        for (int p = 1; p <= 4; ++p) {
-            long wgs = blocks * p;
-            double eff = (double)wgs / (double)(cdiv(wgs, slots) * slots);
-            if (eff > best_eff + 0.02) { best_eff = eff; parts = p; }
-        }
-    }
-    if (parts > h->n_stages) parts = h->n_stages;
-    if (parts < 1) parts = 1;
+    int parts = choose_parts(h, blocks, slots, h->n_stages);
     if (const char* e = std::getenv("SOM_BF16_PARTS")) parts = std::atoi(e) > 0 ? std::atoi(e) : parts;   // experiments
     if (std::getenv("SOM_DEBUG"))
         std::fprintf(stderr, "[somhip] bmu_bf16_k16: blocks=%ld per_cu=%d cus=%d slots=%ld parts=%d stages=%d\n", blocks,
@@ -311,7 +335,34 @@ int launch_bmu_bf16_k16(som_handle* h, const __bf16* Xb, long N, int* out) {
     return 0;
 }
 
+int launch_bmu_bf16_tiled(som_handle* h, const __bf16* Ximg, const float* xmax2, long N, int* out) {
+    long cin = (long)h->n_ublocks * h->n_kchunks * 128;
+    prep_tiles_cin_kernel<<<dim3((unsigned)cdiv(cin, 256)), dim3(256), 0, h->stream>>>(h->wn, h->K, h->wmax2, xmax2,
+                                                                                     h->n_kchunks, h->n_ublocks, h->Wst);
+    size_t lds = 2 * (size_t)TL_STAGE;
+    HIPCHK(h, hipFuncSetAttribute((const void*)bmu_bf16_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    long blocks = cdiv(N, TL_BM);
+    if (blocks <= 0 || blocks > 0x7fffffffL) return fail(h, "bmu_bf16: row count out of range");
+    int per_cu = 0;
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)bmu_bf16_tiled_kernel, 256, lds));
+    const long slots = (long)(per_cu > 0 ? per_cu : 1) * (h->n_cus > 0 ? h->n_cus : 256);
+    int parts = choose_parts(h, blocks, slots, h->n_ublocks);
+    if (N > h->best64_cap) {
+        (void)hipFree(h->best64);
+        h->best64 = nullptr; h->best64_cap = 0;
+        if (int rc = dev_alloc(h, &h->best64, (size_t)round_up(N, 1024))) return rc;
+        h->best64_cap = round_up(N, 1024);
+    }
+    HIPCHK(h, hipMemsetAsync(h->best64, 0xFF, (size_t)N * sizeof(unsigned long long), h->stream));
+    bmu_bf16_tiled_kernel<<<dim3((unsigned)blocks, (unsigned)parts), dim3(256), lds, h->stream>>>(
+        (const char*)Ximg, N, h->Wst, h->n_ublocks, h->n_kchunks, h->K, h->best64);
+    bmu_finalize_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(h->best64, N, h->K, out);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 int launch_bmu_bf16(som_handle* h, const __bf16* Xb, const float* xmax2, long N, int* out) {
+    if (h->tiled) return launch_bmu_bf16_tiled(h, Xb, xmax2, N, out);
     // the stage image's initial accumulators depend on the row set through B = xmax * wmax
     long units = (long)h->n_stages * h->stage_units;
     prep_wsqh_kernel<<<dim3((unsigned)cdiv(units, 256)), dim3(256), 0, h->stream>>>(h->wn, h->K, h->wmax2, xmax2, h->Wst,
@@ -341,6 +392,16 @@ int launch_bmu_bf16(som_handle* h, const __bf16* Xb, const float* xmax2, long N,
 int prep_rows_bf16(som_handle* h, const float* X, long N, long Np, __bf16* Xb, float* xmax2) {
     const int Dp = h->dp;
     HIPCHK(h, hipMemsetAsync(xmax2, 0, sizeof(float), h->stream));
+    if (h->tiled) {
+        long n_blocks = Np / TL_BM;
+        long total = n_blocks * h->n_kchunks * 8 * 2 * 64;
+        prep_tiles_bf16_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
+            X, N, h->D, h->n_kchunks, n_blocks, TL_TILE, 1.0f, nullptr, (char*)Xb);
+        if (N > 0)
+            rownorm_bf16_kernel<<<dim3((unsigned)cdiv(N, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, nullptr, 0, nullptr, xmax2);
+        HIPCHK(h, hipGetLastError());
+        return 0;
+    }
     prep_x_bf16_kernel<<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, Dp, Np, Xb, xmax2);
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -509,7 +570,6 @@ int som_create(const som_config* cfg, som_handle** out) {
                                  "('euclidean_no_opt' has the same argmin as 'euclidean')");
         if (cfg->distance == SOM_DIST_COSINE && std::getenv("SOM_BF16_SHAPE") && std::atoi(std::getenv("SOM_BF16_SHAPE")) == 32)
             return fail(nullptr, "som_create: cosine in bf16 needs the default 16x16x32 kernel");
-        if (cfg->input_len > 128) return fail(nullptr, "som_create: bf16 precision supports input_len <= 128");
     }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -527,7 +587,12 @@ int som_create(const som_config* cfg, som_handle** out) {
         const char* e = std::getenv("SOM_BF16_SHAPE");
         h->shape16 = !(e && std::atoi(e) == 32);
     }
-    h->dp = h->shape16 ? 32 * h->ks32 : 16 * h->ksteps;
+    h->tiled = cfg->precision == SOM_PREC_BF16 && h->D > 128;
+    if (h->tiled) {
+        h->n_kchunks = (int)cdiv(h->D, TL_BK);
+        h->n_ublocks = (int)cdiv(h->K, TL_BN);
+    }
+    h->dp = h->tiled ? TL_BK * h->n_kchunks : h->shape16 ? 32 * h->ks32 : 16 * h->ksteps;
     h->stage_bytes = h->shape16 ? k16_stage_bytes(h->ks32) : bf_stage_bytes(h->ksteps);
     h->stage_units = h->shape16 ? K16_STAGE_UNITS : BF_STAGE_UNITS;
     h->nt = cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT ? 2 : 1;
@@ -567,6 +632,7 @@ int som_create(const som_config* cfg, som_handle** out) {
     if (cfg->precision == SOM_PREC_BF16) {
         h->n_stages = (int)cdiv(h->K, h->stage_units);
         size_t bytes = (size_t)h->n_stages * h->stage_bytes;
+        if (h->tiled) bytes = (size_t)h->n_ublocks * h->n_kchunks * TL_WTILE;
         if ((rc = dev_alloc(h, &h->Wst, bytes))) return bail(rc);
         if ((rc = dev_alloc(h, &h->xmax2, 2))) return bail(rc);
         if ((rc = dev_alloc(h, &h->wn, (size_t)h->K))) return bail(rc);
