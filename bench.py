@@ -79,12 +79,18 @@ def main():
 
     import torch
     dist = None
+    # one process per GPU; SOM_DIST_BACKEND=gloo lets several ranks rehearse the path on ONE GPU
+    backend = os.environ.get("SOM_DIST_BACKEND", "nccl")
+    dev = local % max(1, torch.cuda.device_count())
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
 
-    eng = HipEngine(MAP_X, MAP_Y, FEATURES, precision=args.precision, device=local)
+    eng = HipEngine(MAP_X, MAP_Y, FEATURES, precision=args.precision, device=dev)
     rs = np.random.RandomState(1234)                  # default codebook init, xpysom.py:189-190
     w = rs.rand(MAP_X, MAP_Y, FEATURES) * 2 - 1
     w /= np.linalg.norm(w, axis=-1, keepdims=True)
