@@ -61,8 +61,11 @@ __global__ __launch_bounds__(256) void prep_w_bf16_k16_kernel(const float* __res
     *(bf16x8*)(Wst + stage * k16_stage_bytes(KS32) + ((long)(t16 * KS32 + ks) * 64 + lane) * 16) = v;
 }
 
+#ifndef SOM_K16_MINWAVES
+#define SOM_K16_MINWAVES 2
+#endif
 template <int KS32>
-__global__ __launch_bounds__(256, 2) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
+__global__ __launch_bounds__(256, SOM_K16_MINWAVES) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
                                                               const char* __restrict__ Wst, int n_stages, int K,
                                                               unsigned long long* __restrict__ out64) {
     constexpr int DP = 32 * KS32;
