@@ -165,8 +165,11 @@ __global__ __launch_bounds__(256) void neigh_tables_kernel(NeighParams p, float*
 }
 
 // ---- OUT[b] = H (Ro x Ri) * M[b] (Ri x C), exact float32 on v_mfma_f32_32x32x2_f32 ---------------
-// Workgroup = 4 waves as 2 (rows) x 2 (cols); wave tile 32 x 64; block tile 64 x 128; k chunk 32.
-constexpr int LM_BM = 64, LM_BN = 128, LM_BK = 32;
+// Workgroup = 4 waves as 2 (rows) x 2 (cols); wave tile 64 x 64 (2 x 2 MFMA tiles); block tile
+// 128 x 128; k chunk 32.  The next chunk's global loads are issued into registers before the MFMAs of
+// the current chunk and written to LDS after them (one LDS buffer, two barriers per chunk), so HBM/L2
+// latency hides under the 64 MFMAs per wave.
+constexpr int LM_BM = 128, LM_BN = 128, LM_BK = 32;
 
 __global__ __launch_bounds__(256) void leftmul_f32_kernel(const float* __restrict__ H, int Ro, int Ri,
                                                           const float* __restrict__ M, long m_batch_stride,
@@ -181,42 +184,65 @@ __global__ __launch_bounds__(256) void leftmul_f32_kernel(const float* __restric
     const float* Mb = M + (long)blockIdx.z * m_batch_stride;
     float* Ob = OUT + (long)blockIdx.z * o_batch_stride;
 
-    f32x16 acc[2];
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.0f;
 
+    float hreg[16], mreg[16];                          // this thread's share of the staged chunk
+    auto fetch = [&](int r0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            int idx = tid + q * 256;
+            int i = idx >> 5, k = idx & 31;            // H tile: 128 x 32
+            hreg[q] = (i0 + i < Ro && r0 + k < Ri) ? H[(long)(i0 + i) * Ri + r0 + k] : 0.0f;
+            int kk = idx >> 7, c = idx & 127;          // M tile: 32 x 128
+            mreg[q] = (r0 + kk < Ri && c0 + c < C) ? Mb[(long)(r0 + kk) * C + c0 + c] : 0.0f;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            int idx = tid + q * 256;
+            Hs[idx >> 5][idx & 31] = hreg[q];
+            Ms[idx >> 7][idx & 127] = mreg[q];
+        }
+    };
+
+    fetch(0);
     for (int r0 = 0; r0 < Ri; r0 += LM_BK) {
+        __syncthreads();                                // everyone is done reading the previous chunk
+        stash();
         __syncthreads();
-        for (int idx = tid; idx < LM_BM * LM_BK; idx += 256) {
-            int i = idx >> 5, k = idx & 31;
-            Hs[i][k] = (i0 + i < Ro && r0 + k < Ri) ? H[(long)(i0 + i) * Ri + r0 + k] : 0.0f;
-        }
-        for (int idx = tid; idx < LM_BK * LM_BN; idx += 256) {
-            int k = idx >> 7, c = idx & 127;
-            Ms[k][c] = (r0 + k < Ri && c0 + c < C) ? Mb[(long)(r0 + k) * C + c0 + c] : 0.0f;
-        }
-        __syncthreads();
+        if (r0 + LM_BK < Ri) fetch(r0 + LM_BK);         // in flight under the MFMAs below
 #pragma unroll
         for (int k = 0; k < LM_BK; k += 2) {
-            float a = Hs[wr * 32 + col][k + half];
+            float av[2], bv[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float b = Ms[k + half][wc * 64 + t * 32 + col];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            for (int a = 0; a < 2; ++a) av[a] = Hs[wr * 64 + a * 32 + col][k + half];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) bv[t] = Ms[k + half][wc * 64 + t * 32 + col];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[t], acc[a][t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            long c = c0 + wc * 64 + t * 32 + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int i = i0 + wr * 64 + a * 32 + mfma32_row(r, half);
+                if (i < Ro && c < C) Ob[(long)i * C + c] = acc[a][t][r];
             }
         }
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        long c = c0 + wc * 64 + t * 32 + col;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int i = i0 + wr * 32 + mfma32_row(r, half);
-            if (i < Ro && c < C) Ob[(long)i * C + c] = acc[t][r];
-        }
-    }
 }
 
 // ---- merge: W = where(den != 0, num/den, W)  (xpysom.py:446-455) ---------------------------------
