@@ -102,6 +102,16 @@ int som_epoch_accumulate(som_handle* h, double sigma, double eta, int neigh_f64)
 int som_epoch_merge(som_handle* h);
 int som_epoch(som_handle* h, double sigma, double eta, int neigh_f64);
 
+/* The same epoch for rows that do NOT stay resident (more rows than HBM holds, or a producer that
+ * hands them over chunk by chunk -- what the reference gets from Dask blocks, xpysom.py:545-556):
+ *   som_stream_begin                  w_sq cache, zero the segment sums
+ *   som_stream_rows(x_host, n) ...    one _update per chunk: BMU + segment sums, added up on the device
+ *   som_stream_end(sigma, eta, f64)   separable transform -> fused accumulator (then all-reduce / merge as above)
+ * The sums of all chunks equal som_epoch_accumulate over their concatenation (float32 add order aside). */
+int som_stream_begin(som_handle* h);
+int som_stream_rows(som_handle* h, const float* x_host, int64_t n_rows);
+int som_stream_end(som_handle* h, double sigma, double eta, int neigh_f64);
+
 /* device address and length (floats) of the fused accumulator, for an in-place
  * all-reduce by the host (RCCL via torch.distributed). */
 int som_accum_device_ptr(som_handle* h, void** dev_ptr, int64_t* n_floats);

@@ -37,6 +37,10 @@ class OracleEngine:
             self.acc[:, :self.D] = num.reshape(self.K, self.D)
             self.acc[:, self.D] = den.reshape(self.K)
 
+    def stream_epoch_accumulate(self, chunks, sigma, eta, neigh_f64):
+        self.set_data(np.concatenate([np.asarray(c, np.float32) for c in chunks]))
+        self.epoch_accumulate(sigma, eta, neigh_f64)
+
     def accum_tensor(self):
         import torch
         return torch.from_numpy(self.acc.reshape(-1))

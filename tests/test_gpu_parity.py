@@ -621,3 +621,34 @@ def test_bf16_large_input_len_tiled_kernel(X, Y, D, n):
     x64, w64 = pos.astype(np.float64), wpos.reshape(-1, D).astype(np.float64)
     sim = (x64 @ w64.T) / np.sqrt((x64 ** 2).sum(1)[:, None] * (w64 ** 2).sum(1)[None, :])
     assert (sim[np.arange(n), got] >= sim.max(1) - 2.0 ** -7).all()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_streamed_epoch_equals_resident_epoch(precision):
+    """Rows handed over in ragged chunks (out-of-core path) give the resident epoch's BMUs, sums and
+    codebook: the segment sums are additive over chunks (float32 add order aside)."""
+    from xpysom_dask_amd import XPySom
+    X, Y, D, n = 14, 9, 20, 5000
+    data = O.gaussian_blobs(n, D, seed=4)
+    w = O.default_codebook(X, Y, D, 6).astype(F32) * 3
+    e = engine(X, Y, D, precision=precision)
+    e.set_weights(w)
+    e.set_data(data)
+    e.epoch_accumulate(3.0, 0.4, True)
+    num, den, _ = e.epoch_fetch()
+    cuts = [0, 1, 130, 131, 2000, 4999, 5000]
+    e2 = engine(X, Y, D, precision=precision)
+    e2.set_weights(w)
+    e2.stream_epoch_accumulate((data[a:b] for a, b in zip(cuts[:-1], cuts[1:])), 3.0, 0.4, True)
+    num2, den2, _ = e2.epoch_fetch(want_bmu=False)
+    tol = 2e-6 if precision == "f32" else 5e-3       # bf16: the offset B is per chunk, near-ties may move
+    assert rel_err(num2, num) < tol and rel_err(den2, den) < tol
+    # the host method, three epochs, against resident training
+    a = XPySom(X, Y, D, random_seed=2, decay_function="linear", precision=precision)
+    b = XPySom(X, Y, D, random_seed=2, decay_function="linear", precision=precision)
+    a.train(data, 3)
+    b.train_streaming(lambda: (data[i:i + 777] for i in range(0, n, 777)), 3)
+    if precision == "f32":
+        np.testing.assert_allclose(b._weights, a._weights, rtol=2e-5, atol=2e-6)
+    else:
+        assert abs(b.quantization_error(data) - a.quantization_error(data)) < 1e-2 * a.quantization_error(data)

@@ -106,3 +106,14 @@ def test_host_logic_end_to_end_with_the_test_double():
     back = pickle.loads(blob)
     np.testing.assert_array_equal(back._weights, som._weights)
     assert back._engine_obj is None
+
+
+def test_train_streaming_host_logic_with_the_test_double():
+    from tests.oracle_engine import OracleEngine
+    from xpysom_dask_amd import XPySom
+    data = O.gaussian_blobs(500, 4, seed=12)
+    a = XPySom(6, 5, 4, random_seed=9, decay_function="linear", _engine_factory=OracleEngine)
+    b = XPySom(6, 5, 4, random_seed=9, decay_function="linear", _engine_factory=OracleEngine)
+    a.train(data, 4)
+    b.train_streaming(lambda: (data[i:i + 123] for i in range(0, 500, 123)), 4)
+    np.testing.assert_array_equal(a._weights, b._weights)

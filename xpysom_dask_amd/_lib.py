@@ -42,6 +42,9 @@ SIGNATURES = {
     "som_epoch_accumulate": (C.c_int, [_H, C.c_double, C.c_double, C.c_int]),
     "som_epoch_merge": (C.c_int, [_H]),
     "som_epoch": (C.c_int, [_H, C.c_double, C.c_double, C.c_int]),
+    "som_stream_begin": (C.c_int, [_H]),
+    "som_stream_rows": (C.c_int, [_H, _F, C.c_int64]),
+    "som_stream_end": (C.c_int, [_H, C.c_double, C.c_double, C.c_int]),
     "som_accum_device_ptr": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "som_epoch_fetch": (C.c_int, [_H, _F, _F, _I]),
     "som_epoch_accumulate_forced": (C.c_int, [_H, _I, C.c_double, C.c_double, C.c_int]),

@@ -78,6 +78,12 @@ struct som_handle {
     float* qX = nullptr; int* qbmu = nullptr; int* qbmu2 = nullptr; float* qxsq = nullptr; __bf16* qXb = nullptr;
     long qcap = 0;
     double* dsum = nullptr;
+    // streamed epochs (rows that do not stay resident): per-chunk sort scratch, grown on demand
+    int *st_iota = nullptr, *st_skey = nullptr, *st_srow = nullptr;
+    void* st_tmp = nullptr;
+    size_t st_tmp_bytes = 0;
+    long st_cap = 0;
+    bool streaming = false;
 
     bool prof = false;
     std::vector<EventPair> pending, pool;
@@ -457,23 +463,35 @@ int row_sq(som_handle* h, const float* X, long N, float* out) {
 }
 
 // ---- update path: segment sum + separable neighbourhood transform --------------------------
-int run_update(som_handle* h, double sigma, double eta, int neigh_f64) {
-    const long KD1 = (long)h->K * h->D1p;
-    {
-        Timed t(h, SOM_K_SEGSUM);
-        HIPCHK(h, hipMemsetAsync(h->SC, 0, KD1 * sizeof(float), h->stream));
-        if (h->N > 0) {
-            int bits = 1;
-            while ((1L << bits) < h->K) ++bits;
-            hipError_t e = rocprim::radix_sort_pairs(h->sort_tmp, h->sort_tmp_bytes, h->bmu, h->skey, h->iota, h->srow,
-                                                     (size_t)h->N, 0u, (unsigned)bits, h->stream);
-            if (e != hipSuccess) return fail_hip(h, "rocprim::radix_sort_pairs", e);
-            long waves = cdiv(h->N, SEG_CHUNK);
-            segsum_sorted_kernel<<<dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, h->stream>>>(h->Xd, h->skey, h->srow, h->N,
-                                                                                           h->D, h->D1p, h->SC);
-            HIPCHK(h, hipGetLastError());
-        }
+// SC[b] += sum of the rows whose BMU is b (and their count): sort by BMU, chunked register sums
+int segsum_rows(som_handle* h, const float* X, const int* bmu, long N, const int* iota, int* skey, int* srow,
+                void* tmp, size_t tmp_bytes, bool zero_first) {
+    Timed t(h, SOM_K_SEGSUM);
+    if (zero_first) HIPCHK(h, hipMemsetAsync(h->SC, 0, (size_t)h->K * h->D1p * sizeof(float), h->stream));
+    if (N > 0) {
+        int bits = 1;
+        while ((1L << bits) < h->K) ++bits;
+        hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, bmu, skey, iota, srow, (size_t)N, 0u, (unsigned)bits,
+                                                 h->stream);
+        if (e != hipSuccess) return fail_hip(h, "rocprim::radix_sort_pairs", e);
+        long waves = cdiv(N, SEG_CHUNK);
+        segsum_sorted_kernel<<<dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, h->stream>>>(X, skey, srow, N, h->D, h->D1p,
+                                                                                       h->SC);
+        HIPCHK(h, hipGetLastError());
     }
+    return 0;
+}
+
+int run_transform(som_handle* h, double sigma, double eta, int neigh_f64);
+
+int run_update(som_handle* h, double sigma, double eta, int neigh_f64) {
+    if (int rc = segsum_rows(h, h->Xd, h->bmu, h->N, h->iota, h->skey, h->srow, h->sort_tmp, h->sort_tmp_bytes, true))
+        return rc;
+    return run_transform(h, sigma, eta, neigh_f64);
+}
+
+// [num|den] = sum_t (Px_t (x) Py_t) [S|c]
+int run_transform(som_handle* h, double sigma, double eta, int neigh_f64) {
     Timed t(h, SOM_K_KRON);
     NeighParams p{};
     p.sigma = sigma; p.eta = eta;
@@ -651,7 +669,7 @@ void som_destroy(som_handle* h) {
     for (auto& ep : h->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     void* bufs[] = {h->W, h->wsq, h->SC, h->T, h->ACC, h->P1, h->P2, h->Wst, h->X_owned, h->bmu, h->xsq, h->Xb,
                     h->xmax2, h->wn, h->wmax2, h->qX, h->qbmu, h->qbmu2, h->qxsq, h->qXb, h->dsum, h->iota, h->skey, h->srow,
-                    h->sort_tmp, h->best64, h->Wfst};
+                    h->sort_tmp, h->best64, h->Wfst, h->st_iota, h->st_skey, h->st_srow, h->st_tmp};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -745,6 +763,61 @@ int som_epoch_accumulate_forced(som_handle* h, const int32_t* bmu_host, double s
     if (h->N > 0)
         HIPCHK(h, hipMemcpyAsync(h->bmu, bmu_host, (size_t)h->N * sizeof(int), hipMemcpyHostToDevice, h->stream));
     return run_update(h, sigma, eta, neigh_f64);
+}
+
+// ---- streamed epoch: rows pass through HBM chunk by chunk (out-of-core data) ------------------
+int som_stream_begin(som_handle* h) {
+    if (h) (void)hipSetDevice(h->cfg.device);
+    if (!h) return 1;
+    if (int rc = refresh_codebook_operands(h)) return rc;
+    HIPCHK(h, hipMemsetAsync(h->SC, 0, (size_t)h->K * h->D1p * sizeof(float), h->stream));
+    h->streaming = true;
+    return 0;
+}
+
+int som_stream_rows(som_handle* h, const float* x_host, int64_t n_rows) {
+    if (h) (void)hipSetDevice(h->cfg.device);
+    if (!h || n_rows < 0 || (n_rows > 0 && !x_host)) return fail(h, "som_stream_rows: bad argument");
+    if (!h->streaming) return fail(h, "som_stream_rows: call som_stream_begin first");
+    if (n_rows == 0) return 0;
+    if (n_rows > 0x7fffffffL) return fail(h, "som_stream_rows: more than 2^31-1 rows in one chunk");
+    if (int rc = ensure_query_scratch(h, n_rows)) return rc;
+    if (n_rows > h->st_cap) {
+        (void)hipFree(h->st_iota); (void)hipFree(h->st_skey); (void)hipFree(h->st_srow); (void)hipFree(h->st_tmp);
+        h->st_iota = h->st_skey = h->st_srow = nullptr; h->st_tmp = nullptr; h->st_cap = 0; h->st_tmp_bytes = 0;
+        long cap = round_up(n_rows, 1024);
+        if (int rc = dev_alloc(h, &h->st_iota, (size_t)cap)) return rc;
+        if (int rc = dev_alloc(h, &h->st_skey, (size_t)cap)) return rc;
+        if (int rc = dev_alloc(h, &h->st_srow, (size_t)cap)) return rc;
+        iota_kernel<<<dim3((unsigned)cdiv(cap, 256)), dim3(256), 0, h->stream>>>(h->st_iota, cap);
+        size_t bytes = 0;
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, h->qbmu, h->st_skey, h->st_iota, h->st_srow, (size_t)cap,
+                                                 0u, 32u, h->stream);
+        if (e != hipSuccess) return fail_hip(h, "rocprim::radix_sort_pairs(size query)", e);
+        if (int rc = dev_alloc(h, (char**)&h->st_tmp, bytes)) return rc;
+        h->st_tmp_bytes = bytes;
+        h->st_cap = cap;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->qX, x_host, (size_t)n_rows * h->D * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (needs_xsq(h)) if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
+    if (h->cfg.precision == SOM_PREC_BF16)
+        if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1)) return rc;
+    if (int rc = run_activation_bmu(h, h->qX, n_rows, h->qxsq, h->qXb, h->xmax2 + 1, h->qbmu)) return rc;
+    if (int rc = segsum_rows(h, h->qX, h->qbmu, n_rows, h->st_iota, h->st_skey, h->st_srow, h->st_tmp, h->st_tmp_bytes,
+                             false))
+        return rc;
+    // the staging buffer is reused by the next chunk: the host copy above is ordered on the stream,
+    // but the caller's buffer must stay valid until the copy has run
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int som_stream_end(som_handle* h, double sigma, double eta, int neigh_f64) {
+    if (h) (void)hipSetDevice(h->cfg.device);
+    if (!h) return 1;
+    if (!h->streaming) return fail(h, "som_stream_end: call som_stream_begin first");
+    h->streaming = false;
+    return run_transform(h, sigma, eta, neigh_f64);
 }
 
 int som_epoch_merge(som_handle* h) {

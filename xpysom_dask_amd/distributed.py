@@ -41,8 +41,11 @@ def allreduce_accumulator(engine):
         torch.cuda.current_stream(t.device).synchronize()
 
 
-def epoch(engine, sigma, eta, neigh_f64):
-    """One data-parallel epoch on this rank's shard."""
-    engine.epoch_accumulate(sigma, eta, neigh_f64)
+def epoch(engine, sigma, eta, neigh_f64, chunks=None):
+    """One data-parallel epoch on this rank's shard (resident rows, or `chunks` streamed through)."""
+    if chunks is None:
+        engine.epoch_accumulate(sigma, eta, neigh_f64)
+    else:
+        engine.stream_epoch_accumulate(chunks, sigma, eta, neigh_f64)
     allreduce_accumulator(engine)
     engine.epoch_merge()

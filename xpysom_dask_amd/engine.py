@@ -105,6 +105,16 @@ class HipEngine:
     def epoch(self, sigma, eta, neigh_f64):
         self._check(self._lib.som_epoch(self._h, float(sigma), float(eta), int(bool(neigh_f64))))
 
+    def stream_epoch_accumulate(self, chunks, sigma, eta, neigh_f64):
+        """epoch_accumulate for rows handed over chunk by chunk (an iterable of (n_i, D) arrays)."""
+        self._check(self._lib.som_stream_begin(self._h))
+        for chunk in chunks:
+            chunk = _f32(chunk)
+            if chunk.ndim != 2 or chunk.shape[1] != self.D:
+                raise ValueError("chunk must be (n, %d), got %r" % (self.D, chunk.shape))
+            self._check(self._lib.som_stream_rows(self._h, self._fp(chunk), chunk.shape[0]))
+        self._check(self._lib.som_stream_end(self._h, float(sigma), float(eta), int(bool(neigh_f64))))
+
     def epoch_fetch(self, want_bmu=True):
         """(num (K,D), den (K,), bmu (n,) or None) of the last accumulate."""
         num = np.empty((self.K, self.D), dtype=np.float32)

@@ -237,6 +237,24 @@ class XPySom:
             print('\n quantization error:', self.quantization_error(data))
         return self
 
+    def train_streaming(self, chunks, num_epochs, iter_beg=0, iter_end=None):
+        """``train`` for data that does not stay resident in HBM (or in host memory as one array).
+
+        ``chunks`` is a callable returning a fresh iterable of ``(n_i, input_len)`` row blocks for each
+        epoch (e.g. slices of a ``numpy.memmap``) -- the role Dask blocks play in the reference
+        (xpysom.py:545-556).  Every block goes host -> HBM, through the BMU kernel and into the same
+        segment sums; the epoch ends with the usual transform, all-reduce and merge.  Under a process
+        group each rank streams its own blocks."""
+        if iter_end is None:
+            iter_end = num_epochs
+        eng = self._upload_weights()
+        for iteration in range(iter_beg, iter_end):
+            eta = self._decay_function(self._learning_rate, self._learning_rateN, iteration, num_epochs)
+            sig = self._decay_function(self._sigma, self._sigmaN, iteration, num_epochs)
+            _dist.epoch(eng, sig, eta, isinstance(sig, np.generic), chunks=chunks())
+        self._weights = eng.get_weights().reshape(self._weights.shape)
+        return self
+
     def train_batch(self, data, num_iteration, verbose=False):
         """Compatibility with MiniSom, alias for train"""
         return self.train(data, num_iteration, verbose=verbose)
