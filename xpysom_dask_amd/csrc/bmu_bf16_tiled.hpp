@@ -18,29 +18,39 @@
 
 namespace somhip {
 
-constexpr int TL_BM = 128, TL_BN = 128, TL_BK = 64;
-constexpr int TL_TILE = (TL_BM / 16) * (TL_BK / 32) * 1024;     // 16 KiB of fragments
-constexpr int TL_WTILE = TL_TILE + 1024;                        // + 128 initial accumulators (padded)
-constexpr int TL_STAGE = TL_TILE + TL_WTILE;                    // 33 KiB
-constexpr int TL_XPIECES = TL_TILE / 1024, TL_WPIECES = TL_WTILE / 1024;
+constexpr int TL_BK = 64;
+// Tile geometry: a wave owns WS sample blocks of 16 x 64 units; the workgroup is NWR x NWC waves.
+//   <4,2,2>: 128 samples x 128 units, 4 waves (small maps / few rows)
+//   <8,2,4>: 256 samples x 256 units, 8 waves: twice the flops per staged byte -- the staged operands come
+//            from L2 / Infinity Cache, and at 128 x 128 that traffic (12 TB/s at 0.8 PFLOP/s) is the limit.
+template <int WS, int NWR, int NWC>
+struct TileCfg {
+    static constexpr int BM = NWR * WS * 16, BN = NWC * 64, WAVES = NWR * NWC;
+    static constexpr int XTILE = (BM / 16) * (TL_BK / 32) * 1024;        // sample fragments per stage
+    static constexpr int WFRAG = (BN / 16) * (TL_BK / 32) * 1024;        // unit fragments per stage
+    static constexpr int WTILE = WFRAG + ((BN * 4 + 1023) / 1024) * 1024; // + BN initial accumulators (padded)
+    static constexpr int STAGE = XTILE + WTILE;
+    static constexpr int XPIECES = XTILE / 1024, WPIECES = WTILE / 1024;
+};
 
 // rows (samples or units) -> fragment-ordered tiles.  One thread per 16-byte chunk.
-// img layout: [block of 128 rows][kchunk][t16 0..7][ks 0..1][lane][8 bf16]  (tile_bytes per (block,kchunk))
+// img layout: [block of `brows` rows][kchunk][t16][ks 0..1][lane][8 bf16]  (tile_bytes per (block,kchunk))
 __global__ __launch_bounds__(256) void prep_tiles_bf16_kernel(const float* __restrict__ A, long rows, int D,
-                                                              int n_kchunks, long n_blocks, int tile_bytes,
+                                                              int n_kchunks, long n_blocks, int brows, int tile_bytes,
                                                               float sign, const float* __restrict__ unit_sq,
                                                               char* __restrict__ img) {
     long id = (long)blockIdx.x * 256 + threadIdx.x;
-    const long per_block = (long)n_kchunks * 8 * 2 * 64;
+    const int nt16 = brows / 16;
+    const long per_block = (long)n_kchunks * nt16 * 2 * 64;
     if (id >= n_blocks * per_block) return;
     long blk = id / per_block;
     int r = (int)(id - blk * per_block);
     int lane = r & 63;
     int t = r >> 6;
     int ks = t & 1; t >>= 1;
-    int t16 = t & 7;
-    int kc = t >> 3;
-    long row = blk * 128 + t16 * 16 + (lane & 15);
+    int t16 = t % nt16;
+    int kc = t / nt16;
+    long row = blk * brows + t16 * 16 + (lane & 15);
     int k0 = kc * TL_BK + ks * 32 + (lane >> 4) * 8;
     float scale = sign;
     if (unit_sq != nullptr && row < rows) { float q = unit_sq[row]; scale = q > 0.0f ? sign / __builtin_sqrtf(q) : 0.0f; }
@@ -75,25 +85,30 @@ __global__ __launch_bounds__(256) void rownorm_bf16_kernel(const float* __restri
 __global__ __launch_bounds__(256) void prep_tiles_cin_kernel(const float* __restrict__ wn, int K,
                                                              const float* __restrict__ wmax2,
                                                              const float* __restrict__ xmax2, int n_kchunks,
-                                                             long n_ublocks, char* __restrict__ Wimg) {
+                                                             long n_ublocks, int bn, int wfrag, int wtile,
+                                                             char* __restrict__ Wimg) {
     long id = (long)blockIdx.x * 256 + threadIdx.x;
-    if (id >= n_ublocks * n_kchunks * 128) return;
-    int within = id & 127;
-    long tile = id >> 7;                                   // (ublock * n_kchunks + kc)
-    long u = (tile / n_kchunks) * 128 + within;
+    if (id >= n_ublocks * n_kchunks * bn) return;
+    int within = (int)(id % bn);
+    long tile = id / bn;                                   // (ublock * n_kchunks + kc)
+    long u = (tile / n_kchunks) * bn + within;
     const float big = __builtin_sqrtf(*wmax2) * __builtin_sqrtf(*xmax2) * (1.0f + 1.0f / 1024.0f);
-    ((float*)(Wimg + tile * (long)TL_WTILE + TL_TILE))[within] = u < K ? __builtin_fmaf(0.5f, wn[u], big) : BF_PAD_NORM;
+    ((float*)(Wimg + tile * (long)wtile + wfrag))[within] = u < K ? __builtin_fmaf(0.5f, wn[u], big) : BF_PAD_NORM;
 }
 
-__global__ __launch_bounds__(256, 2) void bmu_bf16_tiled_kernel(const char* __restrict__ Ximg, long N,
-                                                                const char* __restrict__ Wimg, int n_ublocks,
-                                                                int n_kchunks, int K,
-                                                                unsigned long long* __restrict__ out64) {
+template <int WS, int NWR, int NWC>
+__global__ __launch_bounds__(64 * NWR * NWC, 2) void bmu_bf16_tiled_kernel(const char* __restrict__ Ximg, long N,
+                                                                           const char* __restrict__ Wimg,
+                                                                           int n_ublocks, int n_kchunks, int K,
+                                                                           unsigned long long* __restrict__ out64) {
+    using C = TileCfg<WS, NWR, NWC>;
+    constexpr int TL_BM = C::BM, TL_BN = C::BN, TL_TILE = C::XTILE, TL_WFRAG = C::WFRAG, TL_WTILE = C::WTILE;
+    constexpr int TL_STAGE = C::STAGE, TL_XPIECES = C::XPIECES, TL_WPIECES = C::WPIECES, NW = C::WAVES;
     constexpr uint32_t IDX_MASK = 15u;                   // (tile16 << 2 | reg) in the low mantissa bits
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;             // sample half, unit half
+    const int wr = wave / NWC, wc = wave % NWC;          // sample part, unit part
     const int quad = lane >> 4, col = lane & 15;
     const long sblock = blockIdx.x;
 
@@ -101,59 +116,62 @@ __global__ __launch_bounds__(256, 2) void bmu_bf16_tiled_kernel(const char* __re
     const int ub_end = (int)((long)n_ublocks * (blockIdx.y + 1) / gridDim.y);
     const long n_stages = (long)(ub_end - ub_begin) * n_kchunks;
 
-    auto issue = [&](long q, int slot) {
-        const int ub = ub_begin + (int)(q / n_kchunks);
-        const int kc = (int)(q % n_kchunks);
-        const char* xs = Ximg + (sblock * n_kchunks + kc) * (long)TL_TILE;
-        const char* ws = Wimg + ((long)ub * n_kchunks + kc) * (long)TL_WTILE;
+    // Stage pointers advance incrementally (no division in the loop): the sample tile of k-chunk kc
+    // and the unit tile of (ublock, kc).  Stages are issued one ahead of their use.
+    const char* xbase = Ximg + sblock * (long)n_kchunks * TL_TILE;
+    const char* wnext = Wimg + (long)ub_begin * n_kchunks * TL_WTILE;   // W tile of the next stage to issue
+    int kc_issue = 0;
+    const int lane16 = lane * 16;
+    auto issue = [&](int slot) {
+        const char* xs = xbase + (long)kc_issue * TL_TILE + lane16;
+        const char* ws = wnext + lane16;
         char* dst = smem + slot * TL_STAGE;
-        for (int p = wave; p < TL_XPIECES + TL_WPIECES; p += 4) {
-            if (p < TL_XPIECES) lds_dma_16(xs + (long)p * 1024 + lane * 16, dst + p * 1024);
-            else lds_dma_16(ws + (long)(p - TL_XPIECES) * 1024 + lane * 16, dst + p * 1024);
+#pragma unroll
+        for (int i = 0; i < (TL_XPIECES + TL_WPIECES + NW - 1) / NW; ++i) {
+            const int p = wave + NW * i;
+            if (p < TL_XPIECES) lds_dma_16(xs + p * 1024, dst + p * 1024);
+            else if (p < TL_XPIECES + TL_WPIECES) lds_dma_16(ws + (p - TL_XPIECES) * 1024, dst + p * 1024);
         }
+        wnext += TL_WTILE;
+        if (++kc_issue == n_kchunks) kc_issue = 0;
     };
 
-    int32_t gbest[4];
-    int gblock[4];
+    int32_t gbest[WS];
+    int gblock[WS];
 #pragma unroll
-    for (int sb = 0; sb < 4; ++sb) { gbest[sb] = 0x7FFFFFFF; gblock[sb] = 0; }
-    f32x4 acc[4][4];                                     // [unit tile16][sample block16]
+    for (int sb = 0; sb < WS; ++sb) { gbest[sb] = 0x7FFFFFFF; gblock[sb] = 0; }
+    f32x4 acc[4][WS];                                    // [unit tile16][sample block16]
 
-    if (n_stages > 0) issue(0, 0);
-    int ub = ub_begin, kc = 0;
-    for (long q = 0; q < n_stages; ++q) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (q + 1 < n_stages) issue(q + 1, (int)((q + 1) & 1));
-        const char* xs = smem + (q & 1) * TL_STAGE;
-        const char* ws = xs + TL_TILE;
+    // per-lane fragment offsets inside a stage (constant over the whole scan)
+    const int a_off = TL_TILE + (wc * 4 * 2 * 64 + lane) * 16;         // + (tu*2 + ks) * 1024
+    const int b_off = (wr * WS * 2 * 64 + lane) * 16;                  // + (sb*2 + ks) * 1024
+    const int c_off = TL_TILE + TL_WFRAG + (wc * 64 + 4 * quad) * 4;   // + tu * 64
 
+    auto compute = [&](const char* st, int ub, int kc) {
         if (kc == 0) {                                   // C-in = B + |w~|^2/2 of this wave's 64 units
-            const float* wq = (const float*)(ws + TL_TILE) + wc * 64 + 4 * quad;
 #pragma unroll
             for (int tu = 0; tu < 4; ++tu) {
-                const f32x4 wv = *(const f32x4*)(wq + tu * 16);
+                const f32x4 wv = *(const f32x4*)(st + c_off + tu * 64);
 #pragma unroll
-                for (int sb = 0; sb < 4; ++sb) acc[tu][sb] = wv;
+                for (int sb = 0; sb < WS; ++sb) acc[tu][sb] = wv;
             }
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[4], b[4];
+            bf16x8 a[4], b[WS];
 #pragma unroll
-            for (int tu = 0; tu < 4; ++tu) a[tu] = *(const bf16x8*)(ws + (((wc * 4 + tu) * 2 + ks) * 64 + lane) * 16);
+            for (int tu = 0; tu < 4; ++tu) a[tu] = *(const bf16x8*)(st + a_off + (tu * 2 + ks) * 1024);
 #pragma unroll
-            for (int sb = 0; sb < 4; ++sb) b[sb] = *(const bf16x8*)(xs + (((wr * 4 + sb) * 2 + ks) * 64 + lane) * 16);
+            for (int sb = 0; sb < WS; ++sb) b[sb] = *(const bf16x8*)(st + b_off + (sb * 2 + ks) * 1024);
 #pragma unroll
             for (int tu = 0; tu < 4; ++tu)
 #pragma unroll
-                for (int sb = 0; sb < 4; ++sb)
+                for (int sb = 0; sb < WS; ++sb)
                     acc[tu][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tu], b[sb], acc[tu][sb], 0, 0, 0);
         }
         if (kc == n_kchunks - 1) {                       // the 64 x 64 block of distances is complete: reduce it
 #pragma unroll
-            for (int sb = 0; sb < 4; ++sb) {
+            for (int sb = 0; sb < WS; ++sb) {
                 int32_t c0 = 0x7FFFFFFF, c1 = 0x7FFFFFFF;
 #pragma unroll
                 for (int tu = 0; tu < 4; ++tu) {
@@ -169,11 +187,28 @@ __global__ __launch_bounds__(256, 2) void bmu_bf16_tiled_kernel(const char* __re
                 if (c < gbest[sb]) { gbest[sb] = c; gblock[sb] = ub; }
             }
         }
+    };
+
+    if (n_stages > 0) issue(0);
+    int ub = ub_begin, kc = 0;
+    for (long q = 0; q < n_stages; q += 2) {             // two stages per trip: ring slots are compile-time
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (q + 1 < n_stages) issue(1);
+        compute(smem, ub, kc);
+        if (++kc == n_kchunks) { kc = 0; ++ub; }
+        if (q + 1 >= n_stages) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (q + 2 < n_stages) issue(0);
+        compute(smem + TL_STAGE, ub, kc);
         if (++kc == n_kchunks) { kc = 0; ++ub; }
     }
 
 #pragma unroll
-    for (int sb = 0; sb < 4; ++sb) {
+    for (int sb = 0; sb < WS; ++sb) {
         const uint32_t code = (uint32_t)gbest[sb] & IDX_MASK;
         const uint32_t unit = (uint32_t)gblock[sb] * TL_BN + wc * 64 + (code >> 2) * 16 + quad * 4 + (code & 3);
         unsigned long long comp = ((unsigned long long)((uint32_t)gbest[sb] & ~IDX_MASK) << 32) | unit;
@@ -181,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void bmu_bf16_tiled_kernel(const char* __re
         if (o < comp) comp = o;
         o = __shfl_xor(comp, 32, 64);
         if (o < comp) comp = o;
-        const long row = sblock * TL_BM + wr * 64 + sb * 16 + col;
+        const long row = sblock * TL_BM + wr * (WS * 16) + sb * 16 + col;
         if (quad == 0 && row < N && n_stages > 0) atomicMin(out64 + row, comp);
     }
 }

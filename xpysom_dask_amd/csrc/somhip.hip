@@ -41,7 +41,9 @@ struct som_handle {
     bool shape16 = true;     // which MFMA shape the bf16 kernel uses
     bool tiled = false;      // bf16, input_len > 128: two-sided tiling (bmu_bf16_tiled.hpp)
     int n_kchunks = 0;       // tiled: 64-feature chunks
-    int n_ublocks = 0;       // tiled: 128-unit blocks
+    int n_ublocks = 0;       // tiled: unit blocks of tl_bn
+    bool tl_big = false;     // tiled: 256 x 256 workgroup tiles (8 waves) instead of 128 x 128
+    int tl_bm = 128, tl_bn = 128, tl_xtile = 0, tl_wfrag = 0, tl_wtile = 0;
     int dp = 0;              // feature stride of the bf16 row image
     int stage_bytes = 0;     // bytes of one codebook stage image
     int stage_units = 0;     // units per stage
@@ -178,9 +180,9 @@ int refresh_codebook_operands(som_handle* h) {
     }
     if (h->cfg.precision == SOM_PREC_BF16 && h->tiled) {
         const float* unit = h->cfg.distance == SOM_DIST_COSINE ? h->wsq : nullptr;
-        long total = (long)h->n_ublocks * h->n_kchunks * 8 * 2 * 64;
+        long total = (long)h->n_ublocks * h->n_kchunks * (h->tl_bn / 16) * 2 * 64;
         prep_tiles_bf16_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
-            h->W, h->K, h->D, h->n_kchunks, h->n_ublocks, TL_WTILE, -1.0f, unit, h->Wst);
+            h->W, h->K, h->D, h->n_kchunks, h->n_ublocks, h->tl_bn, h->tl_wtile, -1.0f, unit, h->Wst);
         HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
         rownorm_bf16_kernel<<<dim3((unsigned)cdiv(h->K, 4)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, unit,
                                                                                        unit != nullptr, h->wn, h->wmax2);
@@ -341,16 +343,16 @@ int launch_bmu_bf16_k16(som_handle* h, const __bf16* Xb, long N, int* out) {
     return 0;
 }
 
-int launch_bmu_bf16_tiled(som_handle* h, const __bf16* Ximg, const float* xmax2, long N, int* out) {
-    long cin = (long)h->n_ublocks * h->n_kchunks * 128;
-    prep_tiles_cin_kernel<<<dim3((unsigned)cdiv(cin, 256)), dim3(256), 0, h->stream>>>(h->wn, h->K, h->wmax2, xmax2,
-                                                                                     h->n_kchunks, h->n_ublocks, h->Wst);
-    size_t lds = 2 * (size_t)TL_STAGE;
-    HIPCHK(h, hipFuncSetAttribute((const void*)bmu_bf16_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    long blocks = cdiv(N, TL_BM);
+template <int WS, int NWR, int NWC>
+int launch_bmu_bf16_tiled_cfg(som_handle* h, const __bf16* Ximg, long N, int* out) {
+    using C = TileCfg<WS, NWR, NWC>;
+    auto kern = bmu_bf16_tiled_kernel<WS, NWR, NWC>;
+    size_t lds = 2 * (size_t)C::STAGE;
+    HIPCHK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    long blocks = cdiv(N, C::BM);
     if (blocks <= 0 || blocks > 0x7fffffffL) return fail(h, "bmu_bf16: row count out of range");
     int per_cu = 0;
-    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)bmu_bf16_tiled_kernel, 256, lds));
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 64 * C::WAVES, lds));
     const long slots = (long)(per_cu > 0 ? per_cu : 1) * (h->n_cus > 0 ? h->n_cus : 256);
     int parts = choose_parts(h, blocks, slots, h->n_ublocks);
     if (N > h->best64_cap) {
@@ -360,11 +362,19 @@ int launch_bmu_bf16_tiled(som_handle* h, const __bf16* Ximg, const float* xmax2,
         h->best64_cap = round_up(N, 1024);
     }
     HIPCHK(h, hipMemsetAsync(h->best64, 0xFF, (size_t)N * sizeof(unsigned long long), h->stream));
-    bmu_bf16_tiled_kernel<<<dim3((unsigned)blocks, (unsigned)parts), dim3(256), lds, h->stream>>>(
+    kern<<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * C::WAVES), lds, h->stream>>>(
         (const char*)Ximg, N, h->Wst, h->n_ublocks, h->n_kchunks, h->K, h->best64);
     bmu_finalize_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(h->best64, N, h->K, out);
     HIPCHK(h, hipGetLastError());
     return 0;
+}
+
+int launch_bmu_bf16_tiled(som_handle* h, const __bf16* Ximg, const float* xmax2, long N, int* out) {
+    long cin = (long)h->n_ublocks * h->n_kchunks * h->tl_bn;
+    prep_tiles_cin_kernel<<<dim3((unsigned)cdiv(cin, 256)), dim3(256), 0, h->stream>>>(
+        h->wn, h->K, h->wmax2, xmax2, h->n_kchunks, h->n_ublocks, h->tl_bn, h->tl_wfrag, h->tl_wtile, h->Wst);
+    if (h->tl_big) return launch_bmu_bf16_tiled_cfg<8, 2, 4>(h, Ximg, N, out);
+    return launch_bmu_bf16_tiled_cfg<4, 2, 2>(h, Ximg, N, out);
 }
 
 int launch_bmu_bf16(som_handle* h, const __bf16* Xb, const float* xmax2, long N, int* out) {
@@ -399,10 +409,10 @@ int prep_rows_bf16(som_handle* h, const float* X, long N, long Np, __bf16* Xb, f
     const int Dp = h->dp;
     HIPCHK(h, hipMemsetAsync(xmax2, 0, sizeof(float), h->stream));
     if (h->tiled) {
-        long n_blocks = Np / TL_BM;
-        long total = n_blocks * h->n_kchunks * 8 * 2 * 64;
+        long n_blocks = Np / h->tl_bm;
+        long total = n_blocks * h->n_kchunks * (h->tl_bm / 16) * 2 * 64;
         prep_tiles_bf16_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
-            X, N, h->D, h->n_kchunks, n_blocks, TL_TILE, 1.0f, nullptr, (char*)Xb);
+            X, N, h->D, h->n_kchunks, n_blocks, h->tl_bm, h->tl_xtile, 1.0f, nullptr, (char*)Xb);
         if (N > 0)
             rownorm_bf16_kernel<<<dim3((unsigned)cdiv(N, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, nullptr, 0, nullptr, xmax2);
         HIPCHK(h, hipGetLastError());
@@ -607,8 +617,18 @@ int som_create(const som_config* cfg, som_handle** out) {
     }
     h->tiled = cfg->precision == SOM_PREC_BF16 && h->D > 128;
     if (h->tiled) {
+        // 256 x 256 tiles need enough units to amortise them; SOM_BF16_TILE=128|256 overrides
+        h->tl_big = h->K >= 4096;
+        if (const char* e = std::getenv("SOM_BF16_TILE")) h->tl_big = std::atoi(e) == 256;
+        if (h->tl_big) {
+            using C = TileCfg<8, 2, 4>;
+            h->tl_bm = C::BM; h->tl_bn = C::BN; h->tl_xtile = C::XTILE; h->tl_wfrag = C::WFRAG; h->tl_wtile = C::WTILE;
+        } else {
+            using C = TileCfg<4, 2, 2>;
+            h->tl_bm = C::BM; h->tl_bn = C::BN; h->tl_xtile = C::XTILE; h->tl_wfrag = C::WFRAG; h->tl_wtile = C::WTILE;
+        }
         h->n_kchunks = (int)cdiv(h->D, TL_BK);
-        h->n_ublocks = (int)cdiv(h->K, TL_BN);
+        h->n_ublocks = (int)cdiv(h->K, h->tl_bn);
     }
     h->dp = h->tiled ? TL_BK * h->n_kchunks : h->shape16 ? 32 * h->ks32 : 16 * h->ksteps;
     h->stage_bytes = h->shape16 ? k16_stage_bytes(h->ks32) : bf_stage_bytes(h->ksteps);
@@ -650,7 +670,7 @@ int som_create(const som_config* cfg, som_handle** out) {
     if (cfg->precision == SOM_PREC_BF16) {
         h->n_stages = (int)cdiv(h->K, h->stage_units);
         size_t bytes = (size_t)h->n_stages * h->stage_bytes;
-        if (h->tiled) bytes = (size_t)h->n_ublocks * h->n_kchunks * TL_WTILE;
+        if (h->tiled) bytes = (size_t)h->n_ublocks * h->n_kchunks * h->tl_wtile;
         if ((rc = dev_alloc(h, &h->Wst, bytes))) return bail(rc);
         if ((rc = dev_alloc(h, &h->xmax2, 2))) return bail(rc);
         if ((rc = dev_alloc(h, &h->wn, (size_t)h->K))) return bail(rc);
