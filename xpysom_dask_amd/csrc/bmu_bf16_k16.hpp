@@ -29,7 +29,11 @@ constexpr int K16_STAGE_UNITS = 16 * K16_T;
 #define SOM_K16_SB 4
 #endif
 constexpr int K16_SB = SOM_K16_SB;    // 16-sample blocks per wave
-constexpr int K16_WG_SAMPLES = 4 * 16 * K16_SB;
+#ifndef SOM_K16_NW
+#define SOM_K16_NW 4
+#endif
+constexpr int K16_NW = SOM_K16_NW;    // waves per workgroup (they share one LDS ring)
+constexpr int K16_WG_SAMPLES = K16_NW * 16 * K16_SB;
 
 __host__ __device__ constexpr int k16_stage_bytes(int ks32) { return (K16_T * ks32 + 1) * 1024; }
 
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) void prep_w_bf16_k16_kernel(const float* __res
 #define SOM_K16_MINWAVES 2
 #endif
 template <int KS32>
-__global__ __launch_bounds__(256, SOM_K16_MINWAVES) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
+__global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
                                                               const char* __restrict__ Wst, int n_stages, int K,
                                                               unsigned long long* __restrict__ out64) {
     constexpr int DP = 32 * KS32;
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256, SOM_K16_MINWAVES) void bmu_bf16_k16_kernel(con
     // this workgroup's share of the codebook stages
     const int s_begin = (int)((long)n_stages * blockIdx.y / gridDim.y);
     const int s_end = (int)((long)n_stages * (blockIdx.y + 1) / gridDim.y);
-    for (int p = wave; p < PIECES; p += 4)
+    for (int p = wave; p < PIECES; p += K16_NW)
         lds_dma_16(Wst + (long)s_begin * STAGE + (long)p * 1024 + lane * 16, smem + p * 1024);
 
     auto reduce_tile = [&](const f32x4 (&acc)[K16_SB], int t16) {
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256, SOM_K16_MINWAVES) void bmu_bf16_k16_kernel(con
         if (s + 1 < s_end) {
             const char* src = Wst + (long)(s + 1) * STAGE;
             char* dst = smem + ((s + 1 - s_begin) & 1) * STAGE;
-            for (int p = wave; p < PIECES; p += 4) lds_dma_16(src + (long)p * 1024 + lane * 16, dst + p * 1024);
+            for (int p = wave; p < PIECES; p += K16_NW) lds_dma_16(src + (long)p * 1024 + lane * 16, dst + p * 1024);
         }
         const char* st = smem + ((s - s_begin) & 1) * STAGE;
         const float* wq = (const float*)(st + K16_T * KS32 * 1024);

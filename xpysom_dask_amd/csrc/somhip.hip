@@ -121,7 +121,7 @@ int dev_alloc(som_handle* h, T** p, size_t count) {
 
 inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 inline long round_up(long a, long b) { return cdiv(a, b) * b; }
-constexpr long ROW_PAD = 1024;   // bf16 row images are padded to a multiple of every kernel's workgroup tile
+constexpr long ROW_PAD = 3072;   // bf16 row images are padded to a multiple of every kernel's workgroup tile
 
 // ---- profiling: event pairs recorded around kernel families, resolved lazily ---------------
 struct Timed {
@@ -322,7 +322,7 @@ int launch_bmu_bf16_k16(som_handle* h, const __bf16* Xb, long N, int* out) {
     if (blocks <= 0 || blocks > 0x7fffffffL) return fail(h, "bmu_bf16: row count out of range");
     // split the codebook scan into `parts` so the grid fills whole rounds of resident workgroups
     int per_cu = 0;
-    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)bmu_bf16_k16_kernel<KS32>, 256, lds));
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)bmu_bf16_k16_kernel<KS32>, 64 * K16_NW, lds));
     const long slots = (long)(per_cu > 0 ? per_cu : 1) * (h->n_cus > 0 ? h->n_cus : 256);
     int parts = choose_parts(h, blocks, slots, h->n_stages);
     if (const char* e = std::getenv("SOM_BF16_PARTS")) parts = std::atoi(e) > 0 ? std::atoi(e) : parts;   // experiments
@@ -336,7 +336,7 @@ int launch_bmu_bf16_k16(som_handle* h, const __bf16* Xb, long N, int* out) {
         h->best64_cap = round_up(N, 1024);
     }
     HIPCHK(h, hipMemsetAsync(h->best64, 0xFF, (size_t)N * sizeof(unsigned long long), h->stream));
-    bmu_bf16_k16_kernel<KS32><<<dim3((unsigned)blocks, (unsigned)parts), dim3(256), lds, h->stream>>>(
+    bmu_bf16_k16_kernel<KS32><<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * K16_NW), lds, h->stream>>>(
         Xb, N, h->Wst, h->n_stages, h->K, h->best64);
     bmu_finalize_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(h->best64, N, h->K, out);
     HIPCHK(h, hipGetLastError());
