@@ -108,6 +108,12 @@ int som_epoch(som_handle* h, double sigma, double eta, int neigh_f64);
  *   som_stream_rows(x_host, n) ...    one _update per chunk: BMU + segment sums, added up on the device
  *   som_stream_end(sigma, eta, f64)   separable transform -> fused accumulator (then all-reduce / merge as above)
  * The sums of all chunks equal som_epoch_accumulate over their concatenation (float32 add order aside). */
+/* A chunk in PINNED host memory (som_pinned_alloc, hipHostMalloc, hipHostRegister) is copied on a second
+ * stream into one of two device slots, so its transfer overlaps the previous chunk's kernels; the buffer of
+ * call i may be reused once call i+1 has returned (or after som_stream_end + som_sync).  A pageable chunk is
+ * copied synchronously and is free on return. */
+int som_pinned_alloc(uint64_t bytes, void** out);
+int som_pinned_free(void* p);
 int som_stream_begin(som_handle* h);
 int som_stream_rows(som_handle* h, const float* x_host, int64_t n_rows);
 int som_stream_end(som_handle* h, double sigma, double eta, int neigh_f64);

@@ -652,3 +652,29 @@ def test_streamed_epoch_equals_resident_epoch(precision):
         np.testing.assert_allclose(b._weights, a._weights, rtol=2e-5, atol=2e-6)
     else:
         assert abs(b.quantization_error(data) - a.quantization_error(data)) < 1e-2 * a.quantization_error(data)
+
+
+def test_streamed_epoch_from_pinned_double_buffers():
+    """Chunks handed over in two alternating PINNED buffers take the asynchronous path (copy on a second
+    stream under the previous chunk's kernels) and still give the resident epoch's sums."""
+    X, Y, D, n = 16, 16, 24, 9000
+    data = O.gaussian_blobs(n, D, seed=14)
+    w = O.default_codebook(X, Y, D, 3).astype(F32) * 3
+    e = engine(X, Y, D)
+    e.set_weights(w)
+    e.set_data(data)
+    e.epoch_accumulate(4.0, 0.3, True)
+    num, den, _ = e.epoch_fetch()
+    e2 = engine(X, Y, D)
+    e2.set_weights(w)
+    bufs = [e2.pinned_empty((1000, D)), e2.pinned_empty((1000, D))]
+
+    def chunks():
+        for i, lo in enumerate(range(0, n, 1000)):
+            b = bufs[i & 1]
+            b[:] = data[lo:lo + 1000]        # reuse is safe: call i+1 has returned before buffer i is rewritten
+            yield b
+    for _ in range(2):                       # twice: slot reuse across epochs
+        e2.stream_epoch_accumulate(chunks(), 4.0, 0.3, True)
+        num2, den2, _ = e2.epoch_fetch(want_bmu=False)
+        assert rel_err(num2, num) < 2e-6 and rel_err(den2, den) < 2e-6

@@ -42,6 +42,8 @@ SIGNATURES = {
     "som_epoch_accumulate": (C.c_int, [_H, C.c_double, C.c_double, C.c_int]),
     "som_epoch_merge": (C.c_int, [_H]),
     "som_epoch": (C.c_int, [_H, C.c_double, C.c_double, C.c_int]),
+    "som_pinned_alloc": (C.c_int, [C.c_uint64, C.POINTER(C.c_void_p)]),
+    "som_pinned_free": (C.c_int, [C.c_void_p]),
     "som_stream_begin": (C.c_int, [_H]),
     "som_stream_rows": (C.c_int, [_H, _F, C.c_int64]),
     "som_stream_end": (C.c_int, [_H, C.c_double, C.c_double, C.c_int]),

@@ -86,6 +86,15 @@ struct som_handle {
     size_t st_tmp_bytes = 0;
     long st_cap = 0;
     bool streaming = false;
+    // double-buffered device staging for chunks that arrive in pinned host memory
+    struct Slot {
+        float* dX = nullptr; __bf16* dXb = nullptr; float* dxsq = nullptr; int* dbmu = nullptr;
+        long cap = 0;
+        hipEvent_t copied = nullptr, consumed = nullptr;
+        bool used = false;
+    } slot[2];
+    hipStream_t copy_stream = nullptr;
+    int slot_idx = 0;
 
     bool prof = false;
     std::vector<EventPair> pending, pool;
@@ -691,6 +700,13 @@ void som_destroy(som_handle* h) {
                     h->xmax2, h->wn, h->wmax2, h->qX, h->qbmu, h->qbmu2, h->qxsq, h->qXb, h->dsum, h->iota, h->skey, h->srow,
                     h->sort_tmp, h->best64, h->Wfst, h->st_iota, h->st_skey, h->st_srow, h->st_tmp};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    for (auto& sl : h->slot) {
+        void* sb[] = {sl.dX, sl.dXb, sl.dxsq, sl.dbmu};
+        for (void* b : sb) if (b) (void)hipFree(b);
+        if (sl.copied) (void)hipEventDestroy(sl.copied);
+        if (sl.consumed) (void)hipEventDestroy(sl.consumed);
+    }
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -795,13 +811,39 @@ int som_stream_begin(som_handle* h) {
     return 0;
 }
 
+static int ensure_slot(som_handle* h, som_handle::Slot& sl, long n) {
+    if (!sl.copied) {
+        HIPCHK(h, hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming));
+    }
+    if (n <= sl.cap) return 0;
+    if (sl.used) HIPCHK(h, hipEventSynchronize(sl.consumed));
+    (void)hipFree(sl.dX); (void)hipFree(sl.dXb); (void)hipFree(sl.dxsq); (void)hipFree(sl.dbmu);
+    sl.dX = nullptr; sl.dXb = nullptr; sl.dxsq = nullptr; sl.dbmu = nullptr; sl.cap = 0;
+    long cap = round_up(n, ROW_PAD);
+    if (int rc = dev_alloc(h, &sl.dX, (size_t)cap * h->D)) return rc;
+    if (int rc = dev_alloc(h, &sl.dbmu, (size_t)cap)) return rc;
+    if (int rc = dev_alloc(h, &sl.dxsq, (size_t)cap)) return rc;
+    if (h->cfg.precision == SOM_PREC_BF16)
+        if (int rc = dev_alloc(h, &sl.dXb, (size_t)cap * h->dp)) return rc;
+    sl.cap = cap;
+    return 0;
+}
+
+static bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeHost;
+}
+
 int som_stream_rows(som_handle* h, const float* x_host, int64_t n_rows) {
     if (h) (void)hipSetDevice(h->cfg.device);
     if (!h || n_rows < 0 || (n_rows > 0 && !x_host)) return fail(h, "som_stream_rows: bad argument");
     if (!h->streaming) return fail(h, "som_stream_rows: call som_stream_begin first");
     if (n_rows == 0) return 0;
     if (n_rows > 0x7fffffffL) return fail(h, "som_stream_rows: more than 2^31-1 rows in one chunk");
-    if (int rc = ensure_query_scratch(h, n_rows)) return rc;
+    const bool pinned = is_pinned_host(x_host);
+    if (!pinned) if (int rc = ensure_query_scratch(h, n_rows)) return rc;
     if (n_rows > h->st_cap) {
         (void)hipFree(h->st_iota); (void)hipFree(h->st_skey); (void)hipFree(h->st_srow); (void)hipFree(h->st_tmp);
         h->st_iota = h->st_skey = h->st_srow = nullptr; h->st_tmp = nullptr; h->st_cap = 0; h->st_tmp_bytes = 0;
@@ -818,7 +860,34 @@ int som_stream_rows(som_handle* h, const float* x_host, int64_t n_rows) {
         h->st_tmp_bytes = bytes;
         h->st_cap = cap;
     }
-    HIPCHK(h, hipMemcpyAsync(h->qX, x_host, (size_t)n_rows * h->D * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    const size_t bytes = (size_t)n_rows * h->D * sizeof(float);
+    if (pinned) {
+        // Pinned chunk: copy on a second stream into one of two device slots, so the transfer of
+        // chunk i+1 runs under the kernels of chunk i.  The caller may reuse the buffer of call i
+        // once call i+1 has returned (its copy is waited for here).
+        if (!h->copy_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        som_handle::Slot& prev = h->slot[h->slot_idx ^ 1];
+        if (prev.used) HIPCHK(h, hipEventSynchronize(prev.copied));
+        som_handle::Slot& sl = h->slot[h->slot_idx];
+        h->slot_idx ^= 1;
+        if (int rc = ensure_slot(h, sl, n_rows)) return rc;
+        if (sl.used) HIPCHK(h, hipEventSynchronize(sl.consumed));     // the kernels that read this slot are done
+        HIPCHK(h, hipMemcpyAsync(sl.dX, x_host, bytes, hipMemcpyHostToDevice, h->copy_stream));
+        HIPCHK(h, hipEventRecord(sl.copied, h->copy_stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, sl.copied, 0));
+        if (needs_xsq(h)) if (int rc = row_sq(h, sl.dX, n_rows, sl.dxsq)) return rc;
+        if (h->cfg.precision == SOM_PREC_BF16)
+            if (int rc = prep_rows_bf16(h, sl.dX, n_rows, round_up(n_rows, ROW_PAD), sl.dXb, h->xmax2 + 1)) return rc;
+        if (int rc = run_activation_bmu(h, sl.dX, n_rows, sl.dxsq, sl.dXb, h->xmax2 + 1, sl.dbmu)) return rc;
+        if (int rc = segsum_rows(h, sl.dX, sl.dbmu, n_rows, h->st_iota, h->st_skey, h->st_srow, h->st_tmp,
+                                 h->st_tmp_bytes, false))
+            return rc;
+        HIPCHK(h, hipEventRecord(sl.consumed, h->stream));
+        sl.used = true;
+        return 0;
+    }
+    // pageable chunk: staged by the runtime, synchronous; the caller's buffer is free on return
+    HIPCHK(h, hipMemcpyAsync(h->qX, x_host, bytes, hipMemcpyHostToDevice, h->stream));
     if (needs_xsq(h)) if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
     if (h->cfg.precision == SOM_PREC_BF16)
         if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1)) return rc;
@@ -826,9 +895,19 @@ int som_stream_rows(som_handle* h, const float* x_host, int64_t n_rows) {
     if (int rc = segsum_rows(h, h->qX, h->qbmu, n_rows, h->st_iota, h->st_skey, h->st_srow, h->st_tmp, h->st_tmp_bytes,
                              false))
         return rc;
-    // the staging buffer is reused by the next chunk: the host copy above is ordered on the stream,
-    // but the caller's buffer must stay valid until the copy has run
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int som_pinned_alloc(uint64_t bytes, void** out) {
+    if (!out) return 1;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    return 0;
+}
+
+int som_pinned_free(void* p) {
+    if (p && hipHostFree(p) != hipSuccess) { (void)hipGetLastError(); return 1; }
     return 0;
 }
 

@@ -105,6 +105,19 @@ class HipEngine:
     def epoch(self, sigma, eta, neigh_f64):
         self._check(self._lib.som_epoch(self._h, float(sigma), float(eta), int(bool(neigh_f64))))
 
+    def pinned_empty(self, shape):
+        """A float32 array in pinned host memory: chunks streamed from such arrays are copied
+        asynchronously and overlap the previous chunk's kernels (use two and alternate)."""
+        import weakref
+        n = int(np.prod(shape))
+        p = C.c_void_p()
+        if self._lib.som_pinned_alloc(C.c_uint64(max(1, n) * 4), C.byref(p)) != 0:
+            raise SomHipError("som_pinned_alloc failed")
+        buf = (C.c_float * max(1, n)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=np.float32, count=n).reshape(shape)
+        weakref.finalize(buf, self._lib.som_pinned_free, p)
+        return arr
+
     def stream_epoch_accumulate(self, chunks, sigma, eta, neigh_f64):
         """epoch_accumulate for rows handed over chunk by chunk (an iterable of (n_i, D) arrays)."""
         self._check(self._lib.som_stream_begin(self._h))
@@ -114,6 +127,7 @@ class HipEngine:
                 raise ValueError("chunk must be (n, %d), got %r" % (self.D, chunk.shape))
             self._check(self._lib.som_stream_rows(self._h, self._fp(chunk), chunk.shape[0]))
         self._check(self._lib.som_stream_end(self._h, float(sigma), float(eta), int(bool(neigh_f64))))
+        self.sync()                       # pinned chunks are copied asynchronously: their buffers are free now
 
     def epoch_fetch(self, want_bmu=True):
         """(num (K,D), den (K,), bmu (n,) or None) of the last accumulate."""
