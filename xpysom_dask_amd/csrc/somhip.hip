@@ -20,6 +20,7 @@
 #include "bmu_bf16_tiled.hpp"
 #include "bmu_f32.hpp"
 #include "bmu_f32_res.hpp"
+#include "bmu_f32_tiled.hpp"
 #include "bmu_pairwise.hpp"
 #include "update.hpp"
 
@@ -56,6 +57,10 @@ struct som_handle {
     char* Wst = nullptr;
     char* Wfst = nullptr;    // f32 parity mode, input_len <= 128: float32 stage image (bmu_f32_res.hpp)
     int fr_kg = 0, fr_stages = 0;
+    char* Wfimg = nullptr;   // f32 parity mode, input_len > 128: float32 tile image (bmu_f32_tiled.hpp)
+    char* ftX = nullptr;     //   sample tile image of the rows being scanned (scratch, grown on demand)
+    long ftX_cap = 0;
+    int ft_kchunks = 0, ft_ublocks = 0;
     int n_stages = 0;
     bool w_dirty = true;     // wsq / bf16 stage image out of date w.r.t. W
 
@@ -182,6 +187,11 @@ int refresh_codebook_operands(som_handle* h) {
     if (!h->w_dirty) return 0;
     Timed t(h, SOM_K_PREP);
     row_sq_f32_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->wsq);
+    if (h->Wfimg) {
+        long total = (long)h->ft_ublocks * h->ft_kchunks * (4 * 4 * 64 + 128);
+        prep_tiles_f32_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
+            h->W, h->K, h->D, h->ft_kchunks, h->ft_ublocks, FT_WTILE, h->wsq, h->Wfimg);
+    }
     if (h->Wfst) {
         long total = (long)h->fr_stages * ((long)FR_UT * h->fr_kg * 64 + 64);
         prep_w_f32_res_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(h->W, h->wsq, h->K, h->D,
@@ -262,9 +272,32 @@ int launch_bmu_f32_res_kg(som_handle* h, const float* X, long N, const float* xs
     return 0;
 }
 
+template <int MODE, bool TOP2>
+int launch_bmu_f32_tiled(som_handle* h, const float* X, long N, const float* xsq, int* out, int* out2) {
+    const long n_blocks = cdiv(N, FT_BM);
+    if (n_blocks <= 0 || n_blocks > 0x7fffffffL) return fail(h, "bmu_f32: row count out of range");
+    if (n_blocks > h->ftX_cap) {
+        (void)hipFree(h->ftX);
+        h->ftX = nullptr; h->ftX_cap = 0;
+        if (int rc = dev_alloc(h, &h->ftX, (size_t)n_blocks * h->ft_kchunks * FT_TILE)) return rc;
+        h->ftX_cap = n_blocks;
+    }
+    long total = n_blocks * h->ft_kchunks * (4 * 4 * 64);
+    prep_tiles_f32_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
+        X, N, h->D, h->ft_kchunks, n_blocks, FT_TILE, nullptr, h->ftX);
+    size_t lds = 2 * (size_t)FT_STAGE;
+    HIPCHK(h, hipFuncSetAttribute((const void*)bmu_f32_tiled_kernel<MODE, TOP2>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    bmu_f32_tiled_kernel<MODE, TOP2><<<dim3((unsigned)n_blocks), dim3(256), lds, h->stream>>>(
+        h->ftX, N, xsq, h->Wfimg, h->ft_ublocks, h->ft_kchunks, h->K, out, out2);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 template <int MODE>
 int launch_bmu_f32_any(som_handle* h, const float* X, long N, const float* xsq, int* out) {
-    if (!h->Wfst) return launch_bmu_f32<MODE>(h, X, N, xsq, out);     // input_len > 128: LDS-chunked kernel
+    if (h->Wfimg) return launch_bmu_f32_tiled<MODE, false>(h, X, N, xsq, out, nullptr);   // input_len > 128
+    if (!h->Wfst) return launch_bmu_f32<MODE>(h, X, N, xsq, out);     // (SOM_F32_GENERIC) LDS-chunked kernel
     switch (h->fr_kg) {
     case 1: return launch_bmu_f32_res_kg<MODE, 1>(h, X, N, xsq, out);
     case 2: return launch_bmu_f32_res_kg<MODE, 2>(h, X, N, xsq, out);
@@ -278,6 +311,7 @@ int launch_bmu_f32_any(som_handle* h, const float* X, long N, const float* xsq, 
 // best AND second-best unit under the sqrt'd Euclidean distance (topographic error)
 int launch_bmu_top2(som_handle* h, const float* X, long N, const float* xsq, int* out, int* out2) {
     constexpr int M = SCORE_EUCLID_SQRT;
+    if (h->Wfimg) return launch_bmu_f32_tiled<M, true>(h, X, N, xsq, out, out2);
     if (!h->Wfst) return launch_bmu_f32<M, true>(h, X, N, xsq, out, out2);
     switch (h->fr_kg) {
     case 1: return launch_bmu_f32_res_kg<M, 1, true>(h, X, N, xsq, out, out2);
@@ -669,6 +703,11 @@ int som_create(const som_config* cfg, som_handle** out) {
     if (hipMemsetAsync(h->W, 0, (size_t)h->K * h->D * sizeof(float), h->stream) != hipSuccess ||
         hipMemsetAsync(h->ACC, 0, KD1 * sizeof(float), h->stream) != hipSuccess)
         return bail(fail(h, "hipMemsetAsync failed"));
+    if (h->D > 128 && !std::getenv("SOM_F32_GENERIC")) {
+        h->ft_kchunks = (int)cdiv(h->D, FT_BK);
+        h->ft_ublocks = (int)cdiv(h->K, FT_BN);
+        if ((rc = dev_alloc(h, &h->Wfimg, (size_t)h->ft_ublocks * h->ft_kchunks * FT_WTILE))) return bail(rc);
+    }
     if (h->D <= 128 && !std::getenv("SOM_F32_GENERIC")) {
         int kg = 1;
         while (kg * 8 < h->D) kg *= 2;                      // 8, 16, 32, 64 or 128 features per row image
@@ -698,7 +737,7 @@ void som_destroy(som_handle* h) {
     for (auto& ep : h->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     void* bufs[] = {h->W, h->wsq, h->SC, h->T, h->ACC, h->P1, h->P2, h->Wst, h->X_owned, h->bmu, h->xsq, h->Xb,
                     h->xmax2, h->wn, h->wmax2, h->qX, h->qbmu, h->qbmu2, h->qxsq, h->qXb, h->dsum, h->iota, h->skey, h->srow,
-                    h->sort_tmp, h->best64, h->Wfst, h->st_iota, h->st_skey, h->st_srow, h->st_tmp};
+                    h->sort_tmp, h->best64, h->Wfst, h->Wfimg, h->ftX, h->st_iota, h->st_skey, h->st_srow, h->st_tmp};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& sl : h->slot) {
         void* sb[] = {sl.dX, sl.dXb, sl.dxsq, sl.dbmu};
