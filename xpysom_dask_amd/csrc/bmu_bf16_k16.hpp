@@ -173,12 +173,8 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
                 for (int ks = 0; ks < KS32; ++ks) a[ks] = aN[ks];
             }
         }
-#pragma unroll
-        for (int i = 0; i < K16_T * K16_SB * KS32; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-            if (i % 4 != 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
+        // (explicit sched_group_barrier / iglp_opt interleave requests were measured: equal or worse than
+        //  hipcc's own schedule of this block -- DESIGN.md 3.4)
     }
     reduce_tile(accP, K16_T - 1);
     fold_stage(s_end - 1);
