@@ -19,3 +19,5 @@ run(128,128,784,65536,"bf16")
 run(256,256,784,65536,"bf16","cosine","mexican_hat")
 run(512,512,784,32768,"bf16","cosine","mexican_hat",epochs=1)
 run(128,128,784,16384,"f32",epochs=1)
+if "--full" in sys.argv:      # the per-GPU shard of BASELINE configs[4]: 2M rows / 8 GPUs
+    run(512,512,784,250000,"bf16","cosine","mexican_hat",epochs=2)

@@ -100,7 +100,8 @@ template <int WS, int NWR, int NWC>
 __global__ __launch_bounds__(64 * NWR * NWC, 2) void bmu_bf16_tiled_kernel(const char* __restrict__ Ximg, long N,
                                                                            const char* __restrict__ Wimg,
                                                                            int n_ublocks, int n_kchunks, int K,
-                                                                           unsigned long long* __restrict__ out64) {
+                                                                           unsigned long long* __restrict__ out64,
+                                                                           int n_sblocks, int n_parts) {
     using C = TileCfg<WS, NWR, NWC>;
     constexpr int TL_BM = C::BM, TL_BN = C::BN, TL_TILE = C::XTILE, TL_WFRAG = C::WFRAG, TL_WTILE = C::WTILE;
     constexpr int TL_STAGE = C::STAGE, TL_XPIECES = C::XPIECES, TL_WPIECES = C::WPIECES, NW = C::WAVES;
@@ -110,10 +111,19 @@ __global__ __launch_bounds__(64 * NWR * NWC, 2) void bmu_bf16_tiled_kernel(const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / NWC, wc = wave % NWC;          // sample part, unit part
     const int quad = lane >> 4, col = lane & 15;
-    const long sblock = blockIdx.x;
+    // XCD-aware block order (speed only).  Workgroups are dealt round-robin over the 8 XCDs and each
+    // XCD has its own L2: give the ~32 workgroups resident on one XCD a (few sample blocks) x (all
+    // codebook parts) patch, so a sample tile is shared by n_parts workgroups through that L2 and a unit
+    // tile by the workgroups of the patch that run the same part -- instead of every workgroup of the
+    // XCD streaming a private sample block.
+    const int b = blockIdx.x;
+    const int xcd = b & 7, li = b >> 3;
+    const int part = li % n_parts;
+    const long sblock = (long)(li / n_parts) * 8 + xcd;
+    if (sblock >= n_sblocks) return;                      // whole workgroup: no barrier is left behind
 
-    const int ub_begin = (int)((long)n_ublocks * blockIdx.y / gridDim.y);
-    const int ub_end = (int)((long)n_ublocks * (blockIdx.y + 1) / gridDim.y);
+    const int ub_begin = (int)((long)n_ublocks * part / n_parts);
+    const int ub_end = (int)((long)n_ublocks * (part + 1) / n_parts);
     const long n_stages = (long)(ub_end - ub_begin) * n_kchunks;
 
     // Stage pointers advance incrementally (no division in the loop): the sample tile of k-chunk kc

@@ -398,6 +398,10 @@ int launch_bmu_bf16_tiled_cfg(som_handle* h, const __bf16* Ximg, long N, int* ou
     HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 64 * C::WAVES, lds));
     const long slots = (long)(per_cu > 0 ? per_cu : 1) * (h->n_cus > 0 ? h->n_cus : 256);
     int parts = choose_parts(h, blocks, slots, h->n_ublocks);
+    // with many unit blocks, 8 parts let one XCD's resident workgroups share sample tiles through its L2
+    if (h->n_ublocks >= 64 && blocks * 8 >= slots) parts = 8;
+    if (const char* e = std::getenv("SOM_BF16_PARTS")) parts = std::atoi(e) > 0 ? std::atoi(e) : parts;
+    if (parts > h->n_ublocks) parts = h->n_ublocks;
     if (N > h->best64_cap) {
         (void)hipFree(h->best64);
         h->best64 = nullptr; h->best64_cap = 0;
@@ -405,8 +409,10 @@ int launch_bmu_bf16_tiled_cfg(som_handle* h, const __bf16* Ximg, long N, int* ou
         h->best64_cap = round_up(N, 1024);
     }
     HIPCHK(h, hipMemsetAsync(h->best64, 0xFF, (size_t)N * sizeof(unsigned long long), h->stream));
-    kern<<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * C::WAVES), lds, h->stream>>>(
-        (const char*)Ximg, N, h->Wst, h->n_ublocks, h->n_kchunks, h->K, h->best64);
+    const long grid = round_up(blocks, 8) * parts;
+    if (grid > 0x7fffffffL) return fail(h, "bmu_bf16: grid too large");
+    kern<<<dim3((unsigned)grid), dim3(64 * C::WAVES), lds, h->stream>>>(
+        (const char*)Ximg, N, h->Wst, h->n_ublocks, h->n_kchunks, h->K, h->best64, (int)blocks, parts);
     bmu_finalize_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(h->best64, N, h->K, out);
     HIPCHK(h, hipGetLastError());
     return 0;
