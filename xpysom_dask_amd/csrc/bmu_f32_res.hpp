@@ -10,7 +10,11 @@
 //     MFMA wants -- [tile 0..1][group g][lane 0..63][4 floats = the lane's A operand of k-steps
 //     4g..4g+3] followed by the 64 |w|^2 -- so a stage is one linear LDS-DMA burst and every
 //     fragment read is a conflict-free lane-linear ds_read_b128;
-//   * 2-slot ring, one barrier per stage, the next stage's DMA in flight under this stage's MFMAs.
+//   * 2-slot ring, one barrier per stage, the next stage's DMA in flight under this stage's MFMAs;
+//   * grid = (sample blocks) x (codebook parts), as in the bf16 kernel: few rows (winner(),
+//     quantization_error()) spread the scan itself over the chip.  Parts merge through a 64-bit
+//     atomicMin of (order-preserving float key << 32 | unit): smaller value first, then the lower unit
+//     id -- exactly the '<' / first-minimum rule.  (The top-2 variant runs with one part.)
 #pragma once
 #include "bmu_bf16.hpp"
 #include "bmu_f32.hpp"
@@ -59,7 +63,8 @@ template <int MODE, int KG, bool TOP2 = false>
 __global__ __launch_bounds__(256, 2) void bmu_f32_res_kernel(const float* __restrict__ X, long N, int D,
                                                              const float* __restrict__ xsq,
                                                              const char* __restrict__ Wst, int n_stages, int K,
-                                                             int* __restrict__ out, int* __restrict__ out2) {
+                                                             int* __restrict__ out, int* __restrict__ out2,
+                                                             unsigned long long* __restrict__ out64) {
     constexpr int STAGE = fr_stage_bytes(KG);
     constexpr int PIECES = FR_UT * KG + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -99,18 +104,21 @@ __global__ __launch_bounds__(256, 2) void bmu_f32_res_kernel(const float* __rest
 #pragma unroll
     for (int sb = 0; sb < FR_SBW; ++sb) { best[sb] = sec[sb] = __builtin_inff(); bidx[sb] = sidx[sb] = 0; }
 
-    for (int p = wave; p < PIECES; p += 4) lds_dma_16(Wst + (long)p * 1024 + lane * 16, smem + p * 1024);
+    const int s_begin = (int)((long)n_stages * blockIdx.y / gridDim.y);
+    const int s_end = (int)((long)n_stages * (blockIdx.y + 1) / gridDim.y);
+    for (int p = wave; p < PIECES; p += 4)
+        lds_dma_16(Wst + (long)s_begin * STAGE + (long)p * 1024 + lane * 16, smem + p * 1024);
 
-    for (int s = 0; s < n_stages; ++s) {
+    for (int s = s_begin; s < s_end; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + 1 < n_stages) {
+        if (s + 1 < s_end) {
             const char* src = Wst + (long)(s + 1) * STAGE;
-            char* dst = smem + ((s + 1) & 1) * STAGE;
+            char* dst = smem + ((s + 1 - s_begin) & 1) * STAGE;
             for (int p = wave; p < PIECES; p += 4) lds_dma_16(src + (long)p * 1024 + lane * 16, dst + p * 1024);
         }
-        const char* st = smem + (s & 1) * STAGE;
+        const char* st = smem + ((s - s_begin) & 1) * STAGE;
         const float* wq = (const float*)(st + FR_UT * KG * 1024);
 
 #pragma unroll
@@ -165,7 +173,14 @@ __global__ __launch_bounds__(256, 2) void bmu_f32_res_kernel(const float* __rest
             (void)b1;
         } else {
             if (ob < best[sb] || (ob == best[sb] && oi < bidx[sb])) { best[sb] = ob; bidx[sb] = oi; }
-            if (half == 0 && row < N) out[row] = bidx[sb];
+            if (half == 0 && row < N) {
+                if (out64 == nullptr) out[row] = bidx[sb];
+                else {   // order-preserving key: negative floats reversed, positive above them
+                    const uint32_t bits = __float_as_uint(best[sb]);
+                    const uint32_t key = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+                    atomicMin(out64 + row, ((unsigned long long)key << 32) | (uint32_t)bidx[sb]);
+                }
+            }
         }
     }
 }

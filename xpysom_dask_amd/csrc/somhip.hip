@@ -259,15 +259,37 @@ int launch_bmu_f32(som_handle* h, const float* X, long N, const float* xsq, int*
     return 0;
 }
 
+int choose_parts(som_handle* h, long blocks, long slots, int max_parts_hint);
+
 template <int MODE, int KG, bool TOP2 = false>
 int launch_bmu_f32_res_kg(som_handle* h, const float* X, long N, const float* xsq, int* out, int* out2 = nullptr) {
+    auto kern = bmu_f32_res_kernel<MODE, KG, TOP2>;
     size_t lds = 2 * (size_t)fr_stage_bytes(KG);
-    HIPCHK(h, hipFuncSetAttribute((const void*)bmu_f32_res_kernel<MODE, KG, TOP2>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     long grid = cdiv(N, FR_WG_SAMPLES);
     if (grid <= 0 || grid > 0x7fffffffL) return fail(h, "bmu_f32: row count out of range");
-    bmu_f32_res_kernel<MODE, KG, TOP2><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(
-        X, N, h->D, xsq, h->Wfst, h->fr_stages, h->K, out, out2);
+    int parts = 1;
+    if (!TOP2) {
+        int per_cu = 0;
+        HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, lds));
+        const long slots = (long)(per_cu > 0 ? per_cu : 1) * (h->n_cus > 0 ? h->n_cus : 256);
+        parts = choose_parts(h, grid, slots, h->fr_stages);
+    }
+    if (parts == 1) {
+        kern<<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, N, h->D, xsq, h->Wfst, h->fr_stages, h->K, out, out2,
+                                                                 nullptr);
+    } else {
+        if (N > h->best64_cap) {
+            (void)hipFree(h->best64);
+            h->best64 = nullptr; h->best64_cap = 0;
+            if (int rc = dev_alloc(h, &h->best64, (size_t)round_up(N, 1024))) return rc;
+            h->best64_cap = round_up(N, 1024);
+        }
+        HIPCHK(h, hipMemsetAsync(h->best64, 0xFF, (size_t)N * sizeof(unsigned long long), h->stream));
+        kern<<<dim3((unsigned)grid, (unsigned)parts), dim3(256), lds, h->stream>>>(X, N, h->D, xsq, h->Wfst, h->fr_stages,
+                                                                                  h->K, out, out2, h->best64);
+        bmu_finalize_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(h->best64, N, h->K, out);
+    }
     HIPCHK(h, hipGetLastError());
     return 0;
 }
