@@ -47,8 +47,10 @@ enum { SOM_TOPO_RECTANGULAR = 0, SOM_TOPO_HEXAGONAL = 1 };
 
 /* arithmetic of the distance GEMM (the -2 x.w^T term, distances.py:22):
  *   F32  : v_mfma_f32_32x32x2_f32, exact float32 fma chain -- the parity mode
- *   BF16 : v_mfma_f32_32x32x16_bf16 on bf16-rounded x and w, f32 accumulate -- the throughput mode */
-enum { SOM_PREC_F32 = 0, SOM_PREC_BF16 = 1 };
+ *   BF16 : v_mfma_f32_16x16x32_bf16 on bf16-rounded x and w, f32 accumulate -- the throughput mode
+ *   BF16X3: the same MFMA on hi/lo-split operands (x_hi.w_hi + x_hi.w_lo + x_lo.w_hi, exact float32
+ *           |w|^2): ~2^-16 relative error in x.w at 3x the bf16 work -- near-f32 BMUs, faster than F32 */
+enum { SOM_PREC_F32 = 0, SOM_PREC_BF16 = 1, SOM_PREC_BF16X3 = 2 };
 
 /* which BMU rule som_bmu applies */
 enum { SOM_BMU_ACTIVATION = 0,   /* configured activation distance: XPySom._winner, xpysom.py:410-417 */

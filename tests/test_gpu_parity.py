@@ -678,3 +678,53 @@ def test_streamed_epoch_from_pinned_double_buffers():
         e2.stream_epoch_accumulate(chunks(), 4.0, 0.3, True)
         num2, den2, _ = e2.epoch_fetch(want_bmu=False)
         assert rel_err(num2, num) < 2e-6 and rel_err(den2, den) < 2e-6
+
+
+# ----------------------------------------------------------------------------- bf16x3 precision
+@pytest.mark.parametrize("X,Y,D,n", [(6, 6, 4, 150), (24, 24, 16, 4096), (20, 30, 12, 3000), (12, 11, 200, 700),
+                                     (64, 64, 32, 20000), (40, 52, 128, 6000)])
+def test_bf16x3_bmus_are_float32_quality(X, Y, D, n):
+    """precision='bf16x3' (hi/lo-split operands, SURVEY §8(b) precision modes): x.w is good to
+    ~2^-16, so a pick differs from the float32 BMU only on float32-scale near-ties, and a differing
+    pick is within 2^-15 (|x| + |w|) of the best distance.  The update path is the shared exact one."""
+    data = O.gaussian_blobs(n, D, seed=D + 1)
+    w = O.default_codebook(X, Y, D, 5).astype(F32) * 3
+    wf = w.reshape(-1, D)
+    e = engine(X, Y, D, precision="bf16x3")
+    e.set_weights(w)
+    e.set_data(data)
+    e.epoch_accumulate(2.0, 0.3, True)
+    num, den, bmu = e.epoch_fetch()
+    ref = O.bmu_ids(data, wf)
+    bad = np.flatnonzero(bmu != ref)
+    assert len(bad) <= max(1, 2e-3 * n), len(bad)
+    if len(bad):
+        x64, w64 = data[bad].astype(np.float64), wf.astype(np.float64)
+        dd = np.sqrt(((x64[:, None, :] - w64[None, :, :]) ** 2).sum(-1))
+        got = dd[np.arange(len(bad)), bmu[bad]]
+        slack = 2.0 ** -15 * (np.linalg.norm(x64, axis=1) + np.linalg.norm(w64, axis=1).max())
+        assert (got <= dd.min(1) + slack).all()
+    _, onum, oden = O.update(data, w, 0.3, 2.0, wide=True, forced_bmu=bmu)
+    assert rel_err(num, onum.reshape(-1, D)) < 1e-5 and rel_err(den, oden.reshape(-1)) < 1e-5
+    q = e.bmu(data[:97])
+    assert (q != bmu[:97]).sum() <= 1
+
+
+def test_bf16x3_exact_ties_and_cosine():
+    g = load_golden("g1_ties")
+    x, w = g["x"].astype(F32), g["w"].astype(F32)
+    X, Y, D = w.shape
+    e = engine(X, Y, D, precision="bf16x3")
+    e.set_weights(w)
+    assert np.array_equal(e.bmu(x), g["ids"])            # small integers: hi is exact, lo is zero
+    e.set_weights(np.zeros_like(w))
+    assert np.array_equal(e.bmu(x), g["ids_zero"])
+    n, D2 = 2000, 48
+    pos = np.abs(O.gaussian_blobs(n, D2, seed=3))
+    wpos = np.abs(O.default_codebook(16, 16, D2, 2).astype(F32))
+    ec = engine(16, 16, D2, precision="bf16x3", distance="cosine")
+    ec.set_weights(wpos)
+    got = ec.bmu(pos)
+    x64, w64 = pos.astype(np.float64), wpos.reshape(-1, D2).astype(np.float64)
+    sim = (x64 @ w64.T) / np.sqrt((x64 ** 2).sum(1)[:, None] * (w64 ** 2).sum(1)[None, :])
+    assert (sim[np.arange(n), got] >= sim.max(1) - 2.0 ** -14).all()

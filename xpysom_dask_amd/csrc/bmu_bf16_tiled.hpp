@@ -35,10 +35,15 @@ struct TileCfg {
 
 // rows (samples or units) -> fragment-ordered tiles.  One thread per 16-byte chunk.
 // img layout: [block of `brows` rows][kchunk][t16][ks 0..1][lane][8 bf16]  (tile_bytes per (block,kchunk))
+//
+// split (precision 'bf16x3'): every value is split into hi = bf16(v), lo = bf16(v - hi) and the
+// feature axis is tripled -- samples carry [hi | hi | lo], units [hi | lo | hi] -- so the same MFMA
+// contraction yields x_hi.w_hi + x_hi.w_lo + x_lo.w_hi, i.e. x.w to ~2^-16 relative (only lo.lo is
+// dropped) at three times the bf16 work.  split: 0 = plain bf16, 1 = sample pattern, 2 = unit pattern.
 __global__ __launch_bounds__(256) void prep_tiles_bf16_kernel(const float* __restrict__ A, long rows, int D,
                                                               int n_kchunks, long n_blocks, int brows, int tile_bytes,
                                                               float sign, const float* __restrict__ unit_sq,
-                                                              char* __restrict__ img) {
+                                                              char* __restrict__ img, int split) {
     long id = (long)blockIdx.x * 256 + threadIdx.x;
     const int nt16 = brows / 16;
     const long per_block = (long)n_kchunks * nt16 * 2 * 64;
@@ -57,23 +62,37 @@ __global__ __launch_bounds__(256) void prep_tiles_bf16_kernel(const float* __res
     bf16x8 v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        float f = (row < rows && k0 + j < D) ? A[row * D + k0 + j] * scale : 0.0f;
-        v[j] = (__bf16)f;
+        if (split == 0) {
+            float f = (row < rows && k0 + j < D) ? A[row * D + k0 + j] * scale : 0.0f;
+            v[j] = (__bf16)f;
+        } else {
+            const int kv = k0 + j, seg = kv / D, k = kv - seg * D;
+            float f = (row < rows && seg < 3) ? A[row * D + k] * scale : 0.0f;
+            const __bf16 hi = (__bf16)f;
+            const bool want_lo = split == 1 ? seg == 2 : seg == 1;
+            v[j] = want_lo ? (__bf16)(f - (float)hi) : hi;
+        }
     }
     *(bf16x8*)(img + (blk * n_kchunks + kc) * (long)tile_bytes + ((long)(t16 * 2 + ks) * 64 + lane) * 16) = v;
 }
 
 // |a~_row|^2 of bf16-rounded (optionally unit-scaled) rows and their maximum.  One wave per row.
+// exact != 0 ('bf16x3'): the float32 rows themselves, not their bf16 roundings.
 __global__ __launch_bounds__(256) void rownorm_bf16_kernel(const float* __restrict__ A, long rows, int D,
                                                            const float* __restrict__ unit_sq, int zero_norm,
-                                                           float* __restrict__ norm2, float* __restrict__ max2) {
+                                                           float* __restrict__ norm2, float* __restrict__ max2,
+                                                           int exact) {
     long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (row >= rows) return;
     float scale = 1.0f;
     if (unit_sq != nullptr) { float q = unit_sq[row]; scale = q > 0.0f ? 1.0f / __builtin_sqrtf(q) : 0.0f; }
     float s = 0.0f;
-    for (int k = lane; k < D; k += 64) { float f = (float)(__bf16)(A[row * D + k] * scale); s = __builtin_fmaf(f, f, s); }
+    for (int k = lane; k < D; k += 64) {
+        float f = A[row * D + k] * scale;
+        if (!exact) f = (float)(__bf16)f;
+        s = __builtin_fmaf(f, f, s);
+    }
     s = wave_sum(s);
     if (lane == 0) {
         if (norm2) norm2[row] = zero_norm ? 0.0f : s;

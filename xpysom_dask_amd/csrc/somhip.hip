@@ -40,7 +40,8 @@ struct som_handle {
     int ksteps = 0;          // bf16, 32x32x16 shape: ceil(D/16)
     int ks32 = 0;            // bf16, 16x16x32 shape: ceil(D/32)
     bool shape16 = true;     // which MFMA shape the bf16 kernel uses
-    bool tiled = false;      // bf16, input_len > 128: two-sided tiling (bmu_bf16_tiled.hpp)
+    bool tiled = false;      // bf16, input_len > 128 (and bf16x3 always): two-sided tiling (bmu_bf16_tiled.hpp)
+    int x3 = 0;              // precision bf16x3: hi/lo split operands, tripled feature axis
     int n_kchunks = 0;       // tiled: 64-feature chunks
     int n_ublocks = 0;       // tiled: unit blocks of tl_bn
     bool tl_big = false;     // tiled: 256 x 256 workgroup tiles (8 waves) instead of 128 x 128
@@ -197,19 +198,19 @@ int refresh_codebook_operands(som_handle* h) {
         prep_w_f32_res_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(h->W, h->wsq, h->K, h->D,
                                                                                           h->fr_kg, h->Wfst, h->fr_stages);
     }
-    if (h->cfg.precision == SOM_PREC_BF16 && h->tiled) {
+    if (h->cfg.precision != SOM_PREC_F32 && h->tiled) {
         const float* unit = h->cfg.distance == SOM_DIST_COSINE ? h->wsq : nullptr;
         long total = (long)h->n_ublocks * h->n_kchunks * (h->tl_bn / 16) * 2 * 64;
         prep_tiles_bf16_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
-            h->W, h->K, h->D, h->n_kchunks, h->n_ublocks, h->tl_bn, h->tl_wtile, -1.0f, unit, h->Wst);
+            h->W, h->K, h->D, h->n_kchunks, h->n_ublocks, h->tl_bn, h->tl_wtile, -1.0f, unit, h->Wst, h->x3 ? 2 : 0);
         HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
-        rownorm_bf16_kernel<<<dim3((unsigned)cdiv(h->K, 4)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, unit,
-                                                                                       unit != nullptr, h->wn, h->wmax2);
+        rownorm_bf16_kernel<<<dim3((unsigned)cdiv(h->K, 4)), dim3(256), 0, h->stream>>>(
+            h->W, h->K, h->D, unit, unit != nullptr, h->wn, h->wmax2, h->x3);
         HIPCHK(h, hipGetLastError());
         h->w_dirty = false;
         return 0;
     }
-    if (h->cfg.precision == SOM_PREC_BF16 && h->shape16) {
+    if (h->cfg.precision != SOM_PREC_F32 && h->shape16) {
         switch (h->ks32) {
         case 1: launch_prep_w_k16<1>(h); break;
         case 2: launch_prep_w_k16<2>(h); break;
@@ -217,7 +218,7 @@ int refresh_codebook_operands(som_handle* h) {
         case 4: launch_prep_w_k16<4>(h); break;
         default: return fail(h, "bf16 precision supports input_len <= 128");
         }
-    } else if (h->cfg.precision == SOM_PREC_BF16) {
+    } else if (h->cfg.precision != SOM_PREC_F32) {
         switch (h->ksteps) {
         case 1: launch_prep_w<1>(h); break;
         case 2: launch_prep_w<2>(h); break;
@@ -230,7 +231,7 @@ int refresh_codebook_operands(som_handle* h) {
         default: return fail(h, "bf16 precision supports input_len <= 128");
         }
     }
-    if (h->cfg.precision == SOM_PREC_BF16) {
+    if (h->cfg.precision != SOM_PREC_F32) {
         HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
         prep_wnorm_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(
             h->W, h->K, h->D, h->wn, h->wmax2, h->cfg.distance == SOM_DIST_COSINE ? h->wsq : nullptr);
@@ -364,7 +365,7 @@ int choose_parts(som_handle* h, long blocks, long slots, int max_parts_hint) {
     int parts = 1;
     if (blocks < slots) {
         parts = (int)(slots / blocks);
-        if (parts > 8) parts = 8;
+        if (parts > 32) parts = 32;                      // a handful of query rows: spread the scan itself
     } else {
         double best_eff = 0.0;
         for (int p = 1; p <= 4; ++p) {
@@ -483,9 +484,10 @@ int prep_rows_bf16(som_handle* h, const float* X, long N, long Np, __bf16* Xb, f
         long n_blocks = Np / h->tl_bm;
         long total = n_blocks * h->n_kchunks * (h->tl_bm / 16) * 2 * 64;
         prep_tiles_bf16_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
-            X, N, h->D, h->n_kchunks, n_blocks, h->tl_bm, h->tl_xtile, 1.0f, nullptr, (char*)Xb);
+            X, N, h->D, h->n_kchunks, n_blocks, h->tl_bm, h->tl_xtile, 1.0f, nullptr, (char*)Xb, h->x3 ? 1 : 0);
         if (N > 0)
-            rownorm_bf16_kernel<<<dim3((unsigned)cdiv(N, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, nullptr, 0, nullptr, xmax2);
+            rownorm_bf16_kernel<<<dim3((unsigned)cdiv(N, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, nullptr, 0, nullptr,
+                                                                                        xmax2, h->x3);
         HIPCHK(h, hipGetLastError());
         return 0;
     }
@@ -519,7 +521,7 @@ int run_activation_bmu(som_handle* h, const float* X, long N, const float* xsq, 
     if (N == 0) return 0;
     if (int rc = refresh_codebook_operands(h)) return rc;
     Timed t(h, SOM_K_BMU);
-    if (h->cfg.precision == SOM_PREC_BF16) return launch_bmu_bf16(h, Xb, xmax2, N, out);
+    if (h->cfg.precision != SOM_PREC_F32) return launch_bmu_bf16(h, Xb, xmax2, N, out);
     switch (h->cfg.distance) {
     case SOM_DIST_EUCLIDEAN: return launch_bmu_f32_any<SCORE_EUCLID_PART>(h, X, N, xsq, out);
     case SOM_DIST_EUCLIDEAN_NO_OPT: return launch_bmu_f32_any<SCORE_EUCLID_SQ>(h, X, N, xsq, out);
@@ -609,7 +611,7 @@ int ensure_query_scratch(som_handle* h, long n) {
     if (int rc = dev_alloc(h, &h->qbmu, (size_t)cap)) return rc;
     if (int rc = dev_alloc(h, &h->qbmu2, (size_t)cap)) return rc;
     if (int rc = dev_alloc(h, &h->qxsq, (size_t)cap)) return rc;
-    if (h->cfg.precision == SOM_PREC_BF16) {
+    if (h->cfg.precision != SOM_PREC_F32) {
         long capp = round_up(cap, ROW_PAD);
         if (int rc = dev_alloc(h, &h->qXb, (size_t)capp * h->dp)) return rc;
     }
@@ -661,9 +663,9 @@ int som_create(const som_config* cfg, som_handle** out) {
         return fail(nullptr, "som_create: unknown topology id");
     if (cfg->topology == SOM_TOPO_HEXAGONAL && cfg->neighborhood == SOM_NEIGH_TRIANGLE)
         return fail(nullptr, "som_create: the hexagonal topology has no triangle neighbourhood (xpysom.py:271-279)");
-    if (cfg->precision != SOM_PREC_F32 && cfg->precision != SOM_PREC_BF16)
+    if (cfg->precision != SOM_PREC_F32 && cfg->precision != SOM_PREC_BF16 && cfg->precision != SOM_PREC_BF16X3)
         return fail(nullptr, "som_create: unknown precision id");
-    if (cfg->precision == SOM_PREC_BF16) {
+    if (cfg->precision != SOM_PREC_F32) {
         if (cfg->distance == SOM_DIST_EUCLIDEAN_NO_OPT)
             return fail(nullptr, "som_create: bf16 precision implements 'euclidean' and 'cosine' "
                                  "('euclidean_no_opt' has the same argmin as 'euclidean')");
@@ -686,7 +688,8 @@ int som_create(const som_config* cfg, som_handle** out) {
         const char* e = std::getenv("SOM_BF16_SHAPE");
         h->shape16 = !(e && std::atoi(e) == 32);
     }
-    h->tiled = cfg->precision == SOM_PREC_BF16 && h->D > 128;
+    h->x3 = cfg->precision == SOM_PREC_BF16X3;
+    h->tiled = (cfg->precision == SOM_PREC_BF16 && h->D > 128) || h->x3;
     if (h->tiled) {
         // 256 x 256 tiles need enough units to amortise them; SOM_BF16_TILE=128|256 overrides
         h->tl_big = h->K >= 4096;
@@ -698,7 +701,7 @@ int som_create(const som_config* cfg, som_handle** out) {
             using C = TileCfg<4, 2, 2>;
             h->tl_bm = C::BM; h->tl_bn = C::BN; h->tl_xtile = C::XTILE; h->tl_wfrag = C::WFRAG; h->tl_wtile = C::WTILE;
         }
-        h->n_kchunks = (int)cdiv(h->D, TL_BK);
+        h->n_kchunks = (int)cdiv(h->x3 ? 3L * h->D : (long)h->D, TL_BK);
         h->n_ublocks = (int)cdiv(h->K, h->tl_bn);
     }
     h->dp = h->tiled ? TL_BK * h->n_kchunks : h->shape16 ? 32 * h->ks32 : 16 * h->ksteps;
@@ -743,7 +746,7 @@ int som_create(const som_config* cfg, som_handle** out) {
         h->fr_stages = (int)cdiv(h->K, FR_STAGE_UNITS);
         if ((rc = dev_alloc(h, &h->Wfst, (size_t)h->fr_stages * fr_stage_bytes(kg)))) return bail(rc);
     }
-    if (cfg->precision == SOM_PREC_BF16) {
+    if (cfg->precision != SOM_PREC_F32) {
         h->n_stages = (int)cdiv(h->K, h->stage_units);
         size_t bytes = (size_t)h->n_stages * h->stage_bytes;
         if (h->tiled) bytes = (size_t)h->n_ublocks * h->n_kchunks * h->tl_wtile;
@@ -820,7 +823,7 @@ static int adopt_rows(som_handle* h, int64_t n_rows) {
         if (int rc = dev_alloc(h, &h->xsq, (size_t)n_rows)) return rc;
         if (int rc = row_sq(h, h->Xd, n_rows, h->xsq)) return rc;
     }
-    if (h->cfg.precision == SOM_PREC_BF16 && n_rows > 0) {
+    if (h->cfg.precision != SOM_PREC_F32 && n_rows > 0) {
         if (int rc = dev_alloc(h, &h->Xb, (size_t)h->Np * h->dp)) return rc;
         if (int rc = prep_rows_bf16(h, h->Xd, n_rows, h->Np, h->Xb, h->xmax2)) return rc;
     }
@@ -891,7 +894,7 @@ static int ensure_slot(som_handle* h, som_handle::Slot& sl, long n) {
     if (int rc = dev_alloc(h, &sl.dX, (size_t)cap * h->D)) return rc;
     if (int rc = dev_alloc(h, &sl.dbmu, (size_t)cap)) return rc;
     if (int rc = dev_alloc(h, &sl.dxsq, (size_t)cap)) return rc;
-    if (h->cfg.precision == SOM_PREC_BF16)
+    if (h->cfg.precision != SOM_PREC_F32)
         if (int rc = dev_alloc(h, &sl.dXb, (size_t)cap * h->dp)) return rc;
     sl.cap = cap;
     return 0;
@@ -943,7 +946,7 @@ int som_stream_rows(som_handle* h, const float* x_host, int64_t n_rows) {
         HIPCHK(h, hipEventRecord(sl.copied, h->copy_stream));
         HIPCHK(h, hipStreamWaitEvent(h->stream, sl.copied, 0));
         if (needs_xsq(h)) if (int rc = row_sq(h, sl.dX, n_rows, sl.dxsq)) return rc;
-        if (h->cfg.precision == SOM_PREC_BF16)
+        if (h->cfg.precision != SOM_PREC_F32)
             if (int rc = prep_rows_bf16(h, sl.dX, n_rows, round_up(n_rows, ROW_PAD), sl.dXb, h->xmax2 + 1)) return rc;
         if (int rc = run_activation_bmu(h, sl.dX, n_rows, sl.dxsq, sl.dXb, h->xmax2 + 1, sl.dbmu)) return rc;
         if (int rc = segsum_rows(h, sl.dX, sl.dbmu, n_rows, h->st_iota, h->st_skey, h->st_srow, h->st_tmp,
@@ -956,7 +959,7 @@ int som_stream_rows(som_handle* h, const float* x_host, int64_t n_rows) {
     // pageable chunk: staged by the runtime, synchronous; the caller's buffer is free on return
     HIPCHK(h, hipMemcpyAsync(h->qX, x_host, bytes, hipMemcpyHostToDevice, h->stream));
     if (needs_xsq(h)) if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
-    if (h->cfg.precision == SOM_PREC_BF16)
+    if (h->cfg.precision != SOM_PREC_F32)
         if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1)) return rc;
     if (int rc = run_activation_bmu(h, h->qX, n_rows, h->qxsq, h->qXb, h->xmax2 + 1, h->qbmu)) return rc;
     if (int rc = segsum_rows(h, h->qX, h->qbmu, n_rows, h->st_iota, h->st_skey, h->st_srow, h->st_tmp, h->st_tmp_bytes,
@@ -1039,7 +1042,7 @@ int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, in
         if (int rc = launch_bmu_f32_any<SCORE_EUCLID_SQRT>(h, h->qX, n_rows, h->qxsq, h->qbmu)) return rc;
     } else {
         if (needs_xsq(h)) if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
-        if (h->cfg.precision == SOM_PREC_BF16)
+        if (h->cfg.precision != SOM_PREC_F32)
             if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1)) return rc;
         if (int rc = run_activation_bmu(h, h->qX, n_rows, h->qxsq, h->qXb, h->xmax2 + 1, h->qbmu)) return rc;
     }

@@ -42,7 +42,8 @@ class XPySom:
         ``xp``, ``use_dask`` and ``dask_chunks`` are accepted for source compatibility and
         ignored: there is one backend (HIP) and multi-GPU runs use torch.distributed, not Dask.
         Extra keyword-only arguments:
-          precision      'f32' (exact-float32 MFMA, parity mode) or 'bf16' (bf16 MFMA distance GEMM)
+          precision      'f32' (exact-float32 MFMA, parity mode), 'bf16' (bf16 MFMA distance GEMM) or
+                         'bf16x3' (hi/lo-split bf16 MFMA: near-float32 BMUs at a third of the bf16 rate)
           device         HIP device ordinal (default: LOCAL_RANK or 0)
           sharded_input  under an initialised process group: ``train(data)`` receives only this
                          rank's rows (default: every rank passes the full array and takes its slice)
@@ -98,8 +99,8 @@ class XPySom:
         if not DISTANCES[activation_distance]:
             raise NotImplementedError("activation_distance '%s' is not in the HIP engine yet "
                                       "(SURVEY 8(f) rank 3)" % activation_distance)
-        if precision not in ('f32', 'bf16'):
-            raise ValueError("precision must be 'f32' or 'bf16'")
+        if precision not in ('f32', 'bf16', 'bf16x3'):
+            raise ValueError("precision must be 'f32', 'bf16' or 'bf16x3'")
 
         # n_parallel bounded the (n,K) temporaries of the reference (xpysom.py:242-251); nothing of
         # that size exists here, it only sizes host->device staging of winner()/quantization_error().
