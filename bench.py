@@ -156,7 +156,7 @@ def main():
                        "map": [MAP_X, MAP_Y], "features": FEATURES, "rows_per_gpu": args.rows,
                        "precision": args.precision, "parallelism": "dp%d (sample shards, 1 all-reduce/epoch)" % world,
                        "epochs_per_sec": args.steps / dt},
-            "roofline": {"bound": "mfma", "kernel": ("bmu_bf16_k16_kernel" if args.precision == "bf16" else "bmu_f32_kernel") + " (fused distance GEMM + argmin)",
+            "roofline": {"bound": "mfma", "kernel": ("bmu_bf16_k16_kernel" if args.precision == "bf16" else "bmu_f32_res_kernel") + " (fused distance GEMM + argmin)",
                          "achieved": achieved,
                          "peak": MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else 157.3,
                          "unit": "TFLOP/s",
