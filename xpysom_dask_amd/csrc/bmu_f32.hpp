@@ -44,6 +44,36 @@ __device__ __forceinline__ float score_f32(float cross, float wsq, float xsq) {
     }
 }
 
+// Running first-minimum over one 32x32 MFMA output tile, without a compare-and-branch per value.
+// A lane holds 16 scores of its sample (acc register r <-> unit tile*32 + mfma32_row(r, half), ascending
+// in r).  The 16 scores are formed, reduced with fminf (v_min3_f32; NaN never wins, as with '<'), and
+// only lanes whose tile minimum beats their running best recover WHICH register held it -- the lowest
+// r that compares equal, i.e. exactly the unit a sequential `if (v < best)` scan would have kept.
+// key = tile << 4 | r; f32_key_unit() turns it back into the unit id.
+// TAIL: the tile may hold padding units (>= K), which must not compete (only the last stage).
+template <int MODE, bool TAIL>
+__device__ __forceinline__ void f32_tile_argmin(const f32x16& acc, const f32x4 (&wv)[4], float xsq, int tile, int half,
+                                                int K, float& best, int& bkey) {
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        v[r] = score_f32<MODE>(acc[r], wv[r >> 2][r & 3], xsq);
+        if (TAIL && tile * 32 + mfma32_row(r, half) >= K) v[r] = __builtin_inff();
+    }
+    float m = __builtin_fminf(v[0], v[1]);
+#pragma unroll
+    for (int r = 2; r < 16; ++r) m = __builtin_fminf(m, v[r]);
+    if (m < best) {
+        int code = 15;
+#pragma unroll
+        for (int r = 14; r >= 0; --r) code = (v[r] == m) ? r : code;
+        best = m;
+        bkey = (tile << 4) | code;
+    }
+}
+
+__device__ __forceinline__ int f32_key_unit(int key, int half) { return (key >> 4) * 32 + mfma32_row(key & 15, half); }
+
 // X: [N][D] row-major f32.  W: [K][D] row-major f32.  wsq: [K].  xsq: [N] (unused for MODE 0).
 // x_resident != 0: the workgroup's whole sample block stays in LDS (needs SB*(Dp+1)*4 bytes).
 template <int MODE, bool TOP2 = false>

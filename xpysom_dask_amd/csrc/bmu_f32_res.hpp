@@ -140,24 +140,36 @@ __global__ __launch_bounds__(256, 2) void bmu_f32_res_kernel(const float* __rest
             f32x4 wv[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) wv[q] = *(const f32x4*)(wq + ut * 32 + 8 * q + 4 * half);
+            if (!TOP2) {                                 // bidx holds f32_tile_argmin keys until the end
+                const int tile = s * FR_UT + ut;
+                if ((tile + 1) * 32 > K) {
+#pragma unroll
+                    for (int sb = 0; sb < FR_SBW; ++sb)
+                        f32_tile_argmin<MODE, true>(acc[sb], wv, xs[sb], tile, half, K, best[sb], bidx[sb]);
+                } else {
+#pragma unroll
+                    for (int sb = 0; sb < FR_SBW; ++sb)
+                        f32_tile_argmin<MODE, false>(acc[sb], wv, xs[sb], tile, half, K, best[sb], bidx[sb]);
+                }
+                continue;
+            }
 #pragma unroll
             for (int sb = 0; sb < FR_SBW; ++sb) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {           // units ascend with r for a fixed lane half
                     const int u = s * FR_STAGE_UNITS + ut * 32 + mfma32_row(r, half);
                     const float v = score_f32<MODE>(acc[sb][r], wv[r >> 2][r & 3], xs[sb]);
-                    if (TOP2) {
-                        if (u < K && v < sec[sb]) {
-                            if (v < best[sb]) { sec[sb] = best[sb]; sidx[sb] = bidx[sb]; best[sb] = v; bidx[sb] = u; }
-                            else { sec[sb] = v; sidx[sb] = u; }
-                        }
-                    } else if (u < K && v < best[sb]) { best[sb] = v; bidx[sb] = u; }
+                    if (u < K && v < sec[sb]) {
+                        if (v < best[sb]) { sec[sb] = best[sb]; sidx[sb] = bidx[sb]; best[sb] = v; bidx[sb] = u; }
+                        else { sec[sb] = v; sidx[sb] = u; }
+                    }
                 }
             }
         }
     }
 #pragma unroll
     for (int sb = 0; sb < FR_SBW; ++sb) {
+        if (!TOP2) bidx[sb] = f32_key_unit(bidx[sb], half);
         float ob = __shfl_xor(best[sb], 32, 64);
         int oi = __shfl_xor(bidx[sb], 32, 64);
         const long row = wave_s0 + sb * 32 + col;

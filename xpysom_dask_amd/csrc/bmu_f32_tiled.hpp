@@ -133,18 +133,29 @@ __global__ __launch_bounds__(256, 2) void bmu_f32_tiled_kernel(const char* __res
                 f32x4 wv[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) wv[q] = *(const f32x4*)(st + c_off + (tu * 32 + 8 * q) * 4);
+                if (!TOP2) {                             // bidx holds f32_tile_argmin keys until the end
+                    const int tile = ub * (FT_BN / 32) + wc * 2 + tu;
+                    if ((tile + 1) * 32 > K) {
+#pragma unroll
+                        for (int sb = 0; sb < 2; ++sb)
+                            f32_tile_argmin<MODE, true>(acc[tu][sb], wv, xs[sb], tile, half, K, best[sb], bidx[sb]);
+                    } else {
+#pragma unroll
+                        for (int sb = 0; sb < 2; ++sb)
+                            f32_tile_argmin<MODE, false>(acc[tu][sb], wv, xs[sb], tile, half, K, best[sb], bidx[sb]);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int sb = 0; sb < 2; ++sb) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {       // units ascend with (ub, tu, r) for a fixed lane half
                         const int u = ub * FT_BN + wc * 64 + tu * 32 + mfma32_row(r, half);
                         const float v = score_f32<MODE>(acc[tu][sb][r], wv[r >> 2][r & 3], xs[sb]);
-                        if (TOP2) {
-                            if (u < K && v < sec[sb]) {
-                                if (v < best[sb]) { sec[sb] = best[sb]; sidx[sb] = bidx[sb]; best[sb] = v; bidx[sb] = u; }
-                                else { sec[sb] = v; sidx[sb] = u; }
-                            }
-                        } else if (u < K && v < best[sb]) { best[sb] = v; bidx[sb] = u; }
+                        if (u < K && v < sec[sb]) {
+                            if (v < best[sb]) { sec[sb] = best[sb]; sidx[sb] = bidx[sb]; best[sb] = v; bidx[sb] = u; }
+                            else { sec[sb] = v; sidx[sb] = u; }
+                        }
                     }
                 }
             }
@@ -179,6 +190,10 @@ __global__ __launch_bounds__(256, 2) void bmu_f32_tiled_kernel(const char* __res
         s1 = take_c1 ? c1 : c2;
         j1 = take_c1 ? k1 : k2;
     };
+    if (!TOP2) {
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) bidx[sb] = f32_key_unit(bidx[sb], half);
+    }
     __syncthreads();                                     // the ring is no longer read
     float* sv = (float*)smem;                            // [wr][sb][col]{best, sec}, then ids
     int* si = (int*)(smem + 2 * 2 * 32 * 2 * sizeof(float));
