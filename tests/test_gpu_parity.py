@@ -728,3 +728,30 @@ def test_bf16x3_exact_ties_and_cosine():
     x64, w64 = pos.astype(np.float64), wpos.reshape(-1, D2).astype(np.float64)
     sim = (x64 @ w64.T) / np.sqrt((x64 ** 2).sum(1)[:, None] * (w64 ** 2).sum(1)[None, :])
     assert (sim[np.arange(n), got] >= sim.max(1) - 2.0 ** -14).all()
+
+
+# ----------------------------------------------------------------------------- opt-in epoch hipGraph
+def test_epoch_graph_replay_matches_eager_launches(monkeypatch):
+    """SOM_GRAPH=1 replays a captured hipGraph of the whole epoch from the third epoch on; sigma/eta
+    travel through device memory.  Same BMUs and accumulators as the eager launches, epoch by epoch
+    (teacher-forced from the same codebook, so float-atomic order is the only difference)."""
+    X, Y, D, n = 12, 9, 7, 1500
+    data = O.gaussian_blobs(n, D, seed=11)
+    w0 = O.default_codebook(X, Y, D, 3).astype(F32)
+    sched = [(3.0, 0.5), (2.5, 0.45), (2.0, 0.4), (1.5, 0.3), (1.0, 0.2)]
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SOM_GRAPH", mode)
+        e = engine(X, Y, D)
+        e.set_data(data)
+        res = []
+        for t, (sig, eta) in enumerate(sched):
+            e.set_weights(w0 * (1.0 + 0.1 * t))
+            e.epoch_accumulate(sig, eta, t % 2 == 0)
+            res.append(e.epoch_fetch())
+            e.epoch_merge()
+        outs[mode] = res
+    for (n0, d0, b0), (n1, d1, b1) in zip(outs["0"], outs["1"]):
+        assert np.array_equal(b0, b1)
+        np.testing.assert_allclose(n1, n0, rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(d1, d0, rtol=2e-6, atol=1e-6)

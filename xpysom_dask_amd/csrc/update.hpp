@@ -134,8 +134,15 @@ __device__ double neigh_factor(int which, int t, double dl, const NeighParams& p
     }
 }
 
-__global__ __launch_bounds__(256) void neigh_tables_kernel(NeighParams p, float* __restrict__ P1,
-                                                           float* __restrict__ P2) {
+// p_dev != nullptr: the parameters are read from device memory instead (a captured hipGraph replays
+// this launch with new sigma / eta every epoch; store_params_kernel refreshes them before the replay).
+__global__ void store_params_kernel(NeighParams p, NeighParams* __restrict__ dst) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = p;
+}
+
+__global__ __launch_bounds__(256) void neigh_tables_kernel(NeighParams p_val, const NeighParams* __restrict__ p_dev,
+                                                           float* __restrict__ P1, float* __restrict__ P2) {
+    const NeighParams p = p_dev ? *p_dev : p_val;
     long id = (long)blockIdx.x * 256 + threadIdx.x;
     const long n1 = (long)p.nt * p.Y * p.Y;
     const long n2 = (long)p.X * p.nt * p.X;
