@@ -756,3 +756,30 @@ def test_epoch_graph_replay_matches_eager_launches(monkeypatch):
         assert np.array_equal(b0, b1)
         np.testing.assert_allclose(n1, n0, rtol=2e-6, atol=1e-6)
         np.testing.assert_allclose(d1, d0, rtol=2e-6, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- tiled kernel: schedule races
+@pytest.mark.parametrize("X,Y,D,n,precision", [(64, 64, 784, 5000, "bf16"), (100, 90, 257, 7000, "bf16"),
+                                               (256, 256, 128, 20000, "bf16x3"), (2, 2, 129, 257, "bf16"),
+                                               (256, 16, 640, 3333, "bf16")])
+def test_tiled_kernel_is_repeatable_and_near_best(X, Y, D, n, precision):
+    """bmu_bf16_tiled_kernel runs two wave groups one barrier apart over a 4-slot LDS-DMA ring with
+    counted vmcnt waits.  A mis-ordered read or refill would show up as run-to-run differences or as
+    picks outside the operand-rounding bound, so: six launches agree bit for bit, the resident-row
+    path (different padding and grid) agrees with the query path, and every pick is near-best."""
+    rs = np.random.RandomState(n)
+    data = O.gaussian_blobs(n, D, seed=n % 97)
+    w = (rs.rand(X, Y, D) * 2 - 1).astype(F32) * 2
+    e = engine(X, Y, D, precision=precision)
+    e.set_weights(w)
+    outs = [e.bmu(data) for _ in range(6)]
+    for o in outs[1:]:
+        assert np.array_equal(outs[0], o)
+    e.set_data(data)
+    e.epoch_accumulate(2.0, 0.3, True)
+    assert np.array_equal(e.epoch_fetch()[2], outs[0])
+    idx = rs.choice(n, size=min(n, 1500), replace=False)
+    x64, w64 = data[idx].astype(np.float64), w.reshape(-1, D).astype(np.float64)
+    dd = np.sqrt(np.maximum((x64 ** 2).sum(1)[:, None] - 2 * x64 @ w64.T + (w64 ** 2).sum(1)[None, :], 0))
+    slack = (2.0 ** -8 if precision == "bf16" else 2.0 ** -15) * (np.linalg.norm(x64, axis=1) + np.linalg.norm(w64, axis=1).max())
+    assert (dd[np.arange(len(idx)), outs[0][idx]] <= dd.min(1) + slack).all()

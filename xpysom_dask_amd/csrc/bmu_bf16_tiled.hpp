@@ -14,11 +14,14 @@
 //     bmu_bf16_k16.hpp (which stays the kernel for input_len <= 128: it reads X once, this one
 //     re-reads the sample tile for every 128-unit block, from L2 / Infinity Cache).
 #pragma once
+#include <type_traits>
 #include "bmu_bf16.hpp"
 
 namespace somhip {
 
-constexpr int TL_BK = 64;
+constexpr int TL_BK = 32;                      // features per stage = one MFMA k-step
+constexpr int TL_KS = TL_BK / 32;
+constexpr int TL_SLOTS = 4;                    // ring depth in stages (power of two)
 // Tile geometry: a wave owns WS sample blocks of 16 x 64 units; the workgroup is NWR x NWC waves.
 //   <4,2,2>: 128 samples x 128 units, 4 waves (small maps / few rows)
 //   <8,2,4>: 256 samples x 256 units, 8 waves: twice the flops per staged byte -- the staged operands come
@@ -26,11 +29,11 @@ constexpr int TL_BK = 64;
 template <int WS, int NWR, int NWC>
 struct TileCfg {
     static constexpr int BM = NWR * WS * 16, BN = NWC * 64, WAVES = NWR * NWC;
-    static constexpr int XTILE = (BM / 16) * (TL_BK / 32) * 1024;        // sample fragments per stage
-    static constexpr int WFRAG = (BN / 16) * (TL_BK / 32) * 1024;        // unit fragments per stage
+    static constexpr int XTILE = (BM / 16) * TL_KS * 1024;               // sample fragments per stage
+    static constexpr int WFRAG = (BN / 16) * TL_KS * 1024;               // unit fragments per stage
     static constexpr int WTILE = WFRAG + ((BN * 4 + 1023) / 1024) * 1024; // + BN initial accumulators (padded)
-    static constexpr int STAGE = XTILE + WTILE;
     static constexpr int XPIECES = XTILE / 1024, WPIECES = WTILE / 1024;
+    static constexpr int LDS_BYTES = TL_SLOTS * (XTILE + WTILE);
 };
 
 // rows (samples or units) -> fragment-ordered tiles.  One thread per 16-byte chunk.
@@ -46,13 +49,13 @@ __global__ __launch_bounds__(256) void prep_tiles_bf16_kernel(const float* __res
                                                               char* __restrict__ img, int split) {
     long id = (long)blockIdx.x * 256 + threadIdx.x;
     const int nt16 = brows / 16;
-    const long per_block = (long)n_kchunks * nt16 * 2 * 64;
+    const long per_block = (long)n_kchunks * nt16 * TL_KS * 64;
     if (id >= n_blocks * per_block) return;
     long blk = id / per_block;
     int r = (int)(id - blk * per_block);
     int lane = r & 63;
     int t = r >> 6;
-    int ks = t & 1; t >>= 1;
+    int ks = t % TL_KS; t /= TL_KS;
     int t16 = t % nt16;
     int kc = t / nt16;
     long row = blk * brows + t16 * 16 + (lane & 15);
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void prep_tiles_bf16_kernel(const float* __res
             v[j] = want_lo ? (__bf16)(f - (float)hi) : hi;
         }
     }
-    *(bf16x8*)(img + (blk * n_kchunks + kc) * (long)tile_bytes + ((long)(t16 * 2 + ks) * 64 + lane) * 16) = v;
+    *(bf16x8*)(img + (blk * n_kchunks + kc) * (long)tile_bytes + ((long)(t16 * TL_KS + ks) * 64 + lane) * 16) = v;
 }
 
 // |a~_row|^2 of bf16-rounded (optionally unit-scaled) rows and their maximum.  One wave per row.
@@ -122,13 +125,21 @@ __global__ __launch_bounds__(64 * NWR * NWC, 2) void bmu_bf16_tiled_kernel(const
                                                                            unsigned long long* __restrict__ out64,
                                                                            int n_sblocks, int n_parts) {
     using C = TileCfg<WS, NWR, NWC>;
+    static_assert(NWR == 2 && TL_KS == 1, "two wave groups (sample halves), one MFMA k-step per stage");
     constexpr int TL_BM = C::BM, TL_BN = C::BN, TL_TILE = C::XTILE, TL_WFRAG = C::WFRAG, TL_WTILE = C::WTILE;
-    constexpr int TL_STAGE = C::STAGE, TL_XPIECES = C::XPIECES, TL_WPIECES = C::WPIECES, NW = C::WAVES;
+    constexpr int NG = NWC;                                                // waves per group
+    constexpr int XPW = C::XPIECES / NG, WPW = (TL_WFRAG / 1024) / NG;     // 1 KiB DMA pieces per wave and stage
+    constexpr int CIN_BYTES = TL_BN * 4 / NG, CIN_LANES = CIN_BYTES / 16;  // the wave's share of the C-in row
+    static_assert(XPW * NG * 1024 == TL_TILE && WPW * NG * 1024 == TL_WFRAG && CIN_LANES >= 1 && CIN_LANES <= 64,
+                  "stage pieces must divide evenly over a group's waves");
+    constexpr int LOADS_X = XPW, LOADS_W = WPW + 1;
     constexpr uint32_t IDX_MASK = 15u;                   // (tile16 << 2 | reg) in the low mantissa bits
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const xring = smem;                            // TL_SLOTS sample tiles
+    char* const wring = smem + TL_SLOTS * TL_TILE;       // TL_SLOTS unit tiles (+ their C-in rows)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave / NWC, wc = wave % NWC;          // sample part, unit part
+    const int wr = wave / NWC, wc = wave % NWC;          // sample half = wave group, unit part
     const int quad = lane >> 4, col = lane & 15;
     // XCD-aware block order (speed only).  Workgroups are dealt round-robin over the 8 XCDs and each
     // XCD has its own L2: give the ~32 workgroups resident on one XCD a (few sample blocks) x (all
@@ -144,25 +155,43 @@ __global__ __launch_bounds__(64 * NWR * NWC, 2) void bmu_bf16_tiled_kernel(const
     const int ub_begin = (int)((long)n_ublocks * part / n_parts);
     const int ub_end = (int)((long)n_ublocks * (part + 1) / n_parts);
     const long n_stages = (long)(ub_end - ub_begin) * n_kchunks;
+    if (n_stages <= 0) return;
 
-    // Stage pointers advance incrementally (no division in the loop): the sample tile of k-chunk kc
-    // and the unit tile of (ublock, kc).  Stages are issued one ahead of their use.
-    const char* xbase = Ximg + sblock * (long)n_kchunks * TL_TILE;
-    const char* wnext = Wimg + (long)ub_begin * n_kchunks * TL_WTILE;   // W tile of the next stage to issue
-    int kc_issue = 0;
-    const int lane16 = lane * 16;
-    auto issue = [&](int slot) {
-        const char* xs = xbase + (long)kc_issue * TL_TILE + lane16;
-        const char* ws = wnext + lane16;
-        char* dst = smem + slot * TL_STAGE;
+    // ---- schedule ---------------------------------------------------------------------------------
+    // Stage p = (unit block, 32-feature chunk): a sample tile X(p) and a unit tile W(p), ring slot p & 3.
+    // The two waves of a SIMD (wave i and i + NWC: the two sample halves) alternate roles, one barrier
+    // apart: while group 0 runs the 32 MFMAs of stage p, group 1 fetches its fragments of stage p from
+    // LDS, issues LDS-DMA for stage p + 3 and reduces a finished unit block -- then they swap.  Group 1
+    // passes one extra barrier up front (group 0 one at the end), which is all that skews them; every
+    // segment is bounded by barriers, so the alternation holds for the whole scan.
+    //   interval I(2p)   : group 0 LOAD(p)   | group 1 MFMA(p-1)
+    //   interval I(2p+1) : group 0 MFMA(p)   | group 1 LOAD(p)
+    // Group 0 streams the sample tiles (L2 hits), group 1 the unit tiles (+ C-in rows).  VMEM retires in
+    // order, so a counted wait leaves the two youngest stages of a wave's own stream in flight:
+    //   group 0, end of MFMA(p): vmcnt(2 LOADS_X) -> X(p+1) landed, one barrier before anyone reads it;
+    //   group 1, end of LOAD(p): vmcnt(2 LOADS_W) -> W(p+1) landed, likewise.
+    // A slot is re-filled (stage p+3 -> the slot of stage p-1) only after both groups' reads of it have
+    // retired behind an lgkmcnt(0) and a barrier.  Past the last stage the issue pointers stop advancing
+    // (the last tile is re-fetched into a slot nobody reads), so the counts stay uniform.
+    const char* xsrc = Ximg + sblock * (long)n_kchunks * TL_TILE + lane * 16;
+    const char* wsrc = Wimg + (long)ub_begin * n_kchunks * TL_WTILE + lane * 16;
+    int kc_i = 0, slot_i = 0;                            // next stage to issue: its chunk (samples) and slot
+    long left_i = n_stages;
+    auto issue_x = [&]() {
+        const char* src = xsrc + (long)kc_i * TL_TILE;
+        char* dst = xring + slot_i * TL_TILE;
 #pragma unroll
-        for (int i = 0; i < (TL_XPIECES + TL_WPIECES + NW - 1) / NW; ++i) {
-            const int p = wave + NW * i;
-            if (p < TL_XPIECES) lds_dma_16(xs + p * 1024, dst + p * 1024);
-            else if (p < TL_XPIECES + TL_WPIECES) lds_dma_16(ws + (p - TL_XPIECES) * 1024, dst + p * 1024);
-        }
-        wnext += TL_WTILE;
-        if (++kc_issue == n_kchunks) kc_issue = 0;
+        for (int i = 0; i < XPW; ++i) lds_dma_16(src + (wc + NG * i) * 1024, dst + (wc + NG * i) * 1024);
+        if (left_i > 1) { --left_i; if (++kc_i == n_kchunks) kc_i = 0; }
+        slot_i = (slot_i + 1) & (TL_SLOTS - 1);
+    };
+    auto issue_w = [&]() {
+        char* dst = wring + slot_i * TL_WTILE;
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) lds_dma_16(wsrc + (wc + NG * i) * 1024, dst + (wc + NG * i) * 1024);
+        if (lane < CIN_LANES) lds_dma_16(wsrc + TL_WFRAG + wc * CIN_BYTES, dst + TL_WFRAG + wc * CIN_BYTES);
+        if (left_i > 1) { --left_i; wsrc += TL_WTILE; }
+        slot_i = (slot_i + 1) & (TL_SLOTS - 1);
     };
 
     int32_t gbest[WS];
@@ -170,71 +199,90 @@ __global__ __launch_bounds__(64 * NWR * NWC, 2) void bmu_bf16_tiled_kernel(const
 #pragma unroll
     for (int sb = 0; sb < WS; ++sb) { gbest[sb] = 0x7FFFFFFF; gblock[sb] = 0; }
     f32x4 acc[4][WS];                                    // [unit tile16][sample block16]
+    bf16x8 fa[4], fb[WS];                                // fragments of the stage about to be multiplied
+    f32x4 cin[4];                                        // C-in rows of the unit block that starts with it
 
-    // per-lane fragment offsets inside a stage (constant over the whole scan)
-    const int a_off = TL_TILE + (wc * 4 * 2 * 64 + lane) * 16;         // + (tu*2 + ks) * 1024
-    const int b_off = (wr * WS * 2 * 64 + lane) * 16;                  // + (sb*2 + ks) * 1024
-    const int c_off = TL_TILE + TL_WFRAG + (wc * 64 + 4 * quad) * 4;   // + tu * 64
+    // per-lane fragment offsets inside a tile (constant over the whole scan)
+    const int a_off = (wc * 4 * 64 + lane) * 16;                     // + tu * 1024
+    const int b_off = (wr * WS * 64 + lane) * 16;                    // + sb * 1024
+    const int c_off = TL_WFRAG + (wc * 64 + 4 * quad) * 4;           // + tu * 64
 
-    auto compute = [&](const char* st, int ub, int kc) {
-        if (kc == 0) {                                   // C-in = B + |w~|^2/2 of this wave's 64 units
+    auto load_frags = [&](int slot, int kc) {
+        const char* xs = xring + slot * TL_TILE;
+        const char* ws = wring + slot * TL_WTILE;
+#pragma unroll
+        for (int tu = 0; tu < 4; ++tu) fa[tu] = *(const bf16x8*)(ws + a_off + tu * 1024);
+#pragma unroll
+        for (int sb = 0; sb < WS; ++sb) fb[sb] = *(const bf16x8*)(xs + b_off + sb * 1024);
+        if (kc == 0) {
+#pragma unroll
+            for (int tu = 0; tu < 4; ++tu) cin[tu] = *(const f32x4*)(ws + c_off + tu * 64);
+        }
+    };
+    auto reduce_block = [&](int ub) {                    // the 64 x 64 blocks of distances are complete
+#pragma unroll
+        for (int sb = 0; sb < WS; ++sb) {
+            int32_t c0 = 0x7FFFFFFF, c1 = 0x7FFFFFFF;
 #pragma unroll
             for (int tu = 0; tu < 4; ++tu) {
-                const f32x4 wv = *(const f32x4*)(st + c_off + tu * 64);
-#pragma unroll
-                for (int sb = 0; sb < WS; ++sb) acc[tu][sb] = wv;
+                const float f0 = acc[tu][sb][0], f1 = acc[tu][sb][1], f2 = acc[tu][sb][2], f3 = acc[tu][sb][3];
+                const int32_t k0 = (int32_t)((__float_as_uint(f0) & ~IDX_MASK) | (uint32_t)(tu * 4 + 0));
+                const int32_t k1 = (int32_t)((__float_as_uint(f1) & ~IDX_MASK) | (uint32_t)(tu * 4 + 1));
+                const int32_t k2 = (int32_t)((__float_as_uint(f2) & ~IDX_MASK) | (uint32_t)(tu * 4 + 2));
+                const int32_t k3 = (int32_t)((__float_as_uint(f3) & ~IDX_MASK) | (uint32_t)(tu * 4 + 3));
+                c0 = min(min(c0, k0), k1);
+                c1 = min(min(c1, k2), k3);
             }
+            const int32_t c = min(c0, c1);
+            if (c < gbest[sb]) { gbest[sb] = c; gblock[sb] = ub; }
         }
+    };
+
+    auto run = [&](auto group_tag) {
+        constexpr bool G1 = decltype(group_tag)::value;  // group 1: unit-tile stream, one barrier behind
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[4], b[WS];
+        for (int i = 0; i < TL_SLOTS - 1; ++i) { if (G1) issue_w(); else issue_x(); }
+        if (G1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS_W) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS_X) : "memory");
+        __builtin_amdgcn_s_barrier();                    // stage 0 is in LDS
+        if (G1) __builtin_amdgcn_s_barrier();            // group 1 idles through group 0's LOAD(0)
+        asm volatile("" ::: "memory");
+        int ub = ub_begin, kc = 0, slot = 0, done_ub = -1;
+        for (long p = 0; p < n_stages; ++p) {
+            // ---- LOAD(p): fragments to registers, next DMA, reduction of a finished unit block ----
+            load_frags(slot, kc);
+            if (G1) issue_w(); else issue_x();           // stage p+3 -> the slot stage p-1 was read from
+            if (done_ub >= 0) { reduce_block(done_ub); done_ub = -1; }
+            if (G1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LOADS_W) : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // ---- MFMA(p) ---------------------------------------------------------------------------
+            if (kc == 0) {                               // C-in = B + |w~|^2/2 of this wave's 64 units
 #pragma unroll
-            for (int tu = 0; tu < 4; ++tu) a[tu] = *(const bf16x8*)(st + a_off + (tu * 2 + ks) * 1024);
+                for (int tu = 0; tu < 4; ++tu)
 #pragma unroll
-            for (int sb = 0; sb < WS; ++sb) b[sb] = *(const bf16x8*)(st + b_off + (sb * 2 + ks) * 1024);
+                    for (int sb = 0; sb < WS; ++sb) acc[tu][sb] = cin[tu];
+            }
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int tu = 0; tu < 4; ++tu)
 #pragma unroll
                 for (int sb = 0; sb < WS; ++sb)
-                    acc[tu][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tu], b[sb], acc[tu][sb], 0, 0, 0);
+                    acc[tu][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tu], fb[sb], acc[tu][sb], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            if (kc == n_kchunks - 1) done_ub = ub;
+            if (!G1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS_X) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (++kc == n_kchunks) { kc = 0; ++ub; }
+            slot = (slot + 1) & (TL_SLOTS - 1);
         }
-        if (kc == n_kchunks - 1) {                       // the 64 x 64 block of distances is complete: reduce it
-#pragma unroll
-            for (int sb = 0; sb < WS; ++sb) {
-                int32_t c0 = 0x7FFFFFFF, c1 = 0x7FFFFFFF;
-#pragma unroll
-                for (int tu = 0; tu < 4; ++tu) {
-                    const float f0 = acc[tu][sb][0], f1 = acc[tu][sb][1], f2 = acc[tu][sb][2], f3 = acc[tu][sb][3];
-                    const int32_t k0 = (int32_t)((__float_as_uint(f0) & ~IDX_MASK) | (uint32_t)(tu * 4 + 0));
-                    const int32_t k1 = (int32_t)((__float_as_uint(f1) & ~IDX_MASK) | (uint32_t)(tu * 4 + 1));
-                    const int32_t k2 = (int32_t)((__float_as_uint(f2) & ~IDX_MASK) | (uint32_t)(tu * 4 + 2));
-                    const int32_t k3 = (int32_t)((__float_as_uint(f3) & ~IDX_MASK) | (uint32_t)(tu * 4 + 3));
-                    c0 = min(min(c0, k0), k1);
-                    c1 = min(min(c1, k2), k3);
-                }
-                const int32_t c = min(c0, c1);
-                if (c < gbest[sb]) { gbest[sb] = c; gblock[sb] = ub; }
-            }
-        }
+        if (done_ub >= 0) reduce_block(done_ub);
+        if (!G1) __builtin_amdgcn_s_barrier();           // pairs with group 1's last barrier
     };
-
-    if (n_stages > 0) issue(0);
-    int ub = ub_begin, kc = 0;
-    for (long q = 0; q < n_stages; q += 2) {             // two stages per trip: ring slots are compile-time
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (q + 1 < n_stages) issue(1);
-        compute(smem, ub, kc);
-        if (++kc == n_kchunks) { kc = 0; ++ub; }
-        if (q + 1 >= n_stages) break;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (q + 2 < n_stages) issue(0);
-        compute(smem + TL_STAGE, ub, kc);
-        if (++kc == n_kchunks) { kc = 0; ++ub; }
-    }
+    if (wr == 0) run(std::false_type{}); else run(std::true_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no LDS-DMA may land after the workgroup's LDS is released
 
 #pragma unroll
     for (int sb = 0; sb < WS; ++sb) {
@@ -246,7 +294,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, 2) void bmu_bf16_tiled_kernel(const
         o = __shfl_xor(comp, 32, 64);
         if (o < comp) comp = o;
         const long row = sblock * TL_BM + wr * (WS * 16) + sb * 16 + col;
-        if (quad == 0 && row < N && n_stages > 0) atomicMin(out64 + row, comp);
+        if (quad == 0 && row < N) atomicMin(out64 + row, comp);
     }
 }
 

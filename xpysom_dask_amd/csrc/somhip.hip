@@ -215,7 +215,7 @@ int refresh_codebook_operands(som_handle* h) {
     }
     if (h->cfg.precision != SOM_PREC_F32 && h->tiled) {
         const float* unit = h->cfg.distance == SOM_DIST_COSINE ? h->wsq : nullptr;
-        long total = (long)h->n_ublocks * h->n_kchunks * (h->tl_bn / 16) * 2 * 64;
+        long total = (long)h->n_ublocks * h->n_kchunks * (h->tl_bn / 16) * TL_KS * 64;
         prep_tiles_bf16_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
             h->W, h->K, h->D, h->n_kchunks, h->n_ublocks, h->tl_bn, h->tl_wtile, -1.0f, unit, h->Wst, h->x3 ? 2 : 0);
         HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
@@ -436,7 +436,7 @@ template <int WS, int NWR, int NWC>
 int launch_bmu_bf16_tiled_cfg(som_handle* h, const __bf16* Ximg, long N, int* out) {
     using C = TileCfg<WS, NWR, NWC>;
     auto kern = bmu_bf16_tiled_kernel<WS, NWR, NWC>;
-    size_t lds = 2 * (size_t)C::STAGE;
+    size_t lds = (size_t)C::LDS_BYTES;
     HIPCHK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     long blocks = cdiv(N, C::BM);
     if (blocks <= 0 || blocks > 0x7fffffffL) return fail(h, "bmu_bf16: row count out of range");
@@ -505,7 +505,7 @@ int prep_rows_bf16(som_handle* h, const float* X, long N, long Np, __bf16* Xb, f
     HIPCHK(h, hipMemsetAsync(xmax2, 0, sizeof(float), h->stream));
     if (h->tiled) {
         long n_blocks = Np / h->tl_bm;
-        long total = n_blocks * h->n_kchunks * (h->tl_bm / 16) * 2 * 64;
+        long total = n_blocks * h->n_kchunks * (h->tl_bm / 16) * TL_KS * 64;
         prep_tiles_bf16_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
             X, N, h->D, h->n_kchunks, n_blocks, h->tl_bm, h->tl_xtile, 1.0f, nullptr, (char*)Xb, h->x3 ? 1 : 0);
         if (N > 0)
