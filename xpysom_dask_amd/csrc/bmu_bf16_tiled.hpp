@@ -1,18 +1,20 @@
 // Fused distance + BMU argmin, bf16, for input_len > 128 (BASELINE configs[4]: 784 features).
 //
 // With more than 128 features a wave can no longer keep its samples' B operands in registers for
-// the whole codebook scan, so this kernel is a classic two-sided GEMM tiling with the same fused
-// argmin epilogue instead of a C write:
-//   * workgroup tile = 128 samples x 128 units, 4 waves as 2 x 2, wave tile 64 x 64
-//     (16 v_mfma_f32_16x16x32_bf16 accumulators = 64 VGPRs), K-loop over the features in chunks of 64;
-//   * BOTH operands are pre-arranged in HBM in MFMA fragment order, per (128-row block, 64-feature
-//     chunk) one contiguous 16 KiB tile [t16 0..7][kstep 0..1][lane 0..63][8 bf16]; the W tiles carry
-//     their 128 initial accumulators (B + |w~|^2/2) behind them.  A stage (X tile + W tile, 33 KiB)
-//     is therefore two linear LDS-DMA bursts, and every fragment read is a lane-linear ds_read_b128;
-//   * 2-slot LDS ring, one barrier per stage, next stage in flight under the 32 MFMAs per wave;
+// the whole codebook scan, so this kernel is a two-sided GEMM tiling with the same fused argmin
+// epilogue instead of a C write:
+//   * workgroup tile = 256 samples x 256 units, 8 waves as 2 (sample halves) x 4 (unit quarters), wave
+//     tile 128 x 64 (32 v_mfma_f32_16x16x32_bf16 accumulators = 128 VGPRs); 128 x 128 with 4 waves for
+//     small maps; K-loop over the features in stages of 32 (one MFMA k-step);
+//   * BOTH operands are pre-arranged in HBM in MFMA fragment order, per (block of rows, 32-feature
+//     chunk) one contiguous tile [t16][lane 0..63][8 bf16]; the W tiles carry their initial
+//     accumulators (B + |w~|^2/2) behind them.  A stage is therefore linear 1 KiB LDS-DMA bursts, and
+//     every fragment read is a conflict-free lane-linear ds_read_b128;
+//   * 4-slot LDS ring; the two waves of a SIMD run one barrier apart (one in its MFMA segment, the
+//     other fetching fragments / issuing DMA / reducing) -- see the schedule comment in the kernel;
 //   * arithmetic, offset B, key packing, part split and 64-bit atomicMin merge exactly as in
 //     bmu_bf16_k16.hpp (which stays the kernel for input_len <= 128: it reads X once, this one
-//     re-reads the sample tile for every 128-unit block, from L2 / Infinity Cache).
+//     re-reads the sample tile for every unit block, from L2 / Infinity Cache).
 #pragma once
 #include <type_traits>
 #include "bmu_bf16.hpp"
