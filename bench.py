@@ -25,16 +25,38 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-MAP_X, MAP_Y, FEATURES = 256, 256, 128
-ROWS_PER_GPU = 1 << 20
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32
+
+# `c3` is the configuration BASELINE.json's metric is quoted on and the default; the other two put the
+# remaining GPU configs through the same harness (python bench.py --workload c5).
+WORKLOADS = {
+    "c3": dict(map=(256, 256), features=128, rows=1 << 20, precision="bf16", distance="euclidean",
+               neighborhood="gaussian", cpu_rows=8192, label="BASELINE configs[2]/[3]", kernel="bmu_bf16_k16_kernel"),
+    "c2": dict(map=(64, 64), features=32, rows=100000, precision="f32", distance="euclidean",
+               neighborhood="gaussian", cpu_rows=100000, label="BASELINE configs[1]", kernel="bmu_f32_res_kernel"),
+    "c5": dict(map=(512, 512), features=784, rows=250000, precision="bf16", distance="cosine",
+               neighborhood="mexican_hat", cpu_rows=256, label="BASELINE configs[4], one GPU's shard of 2M rows",
+               kernel="bmu_bf16_tiled_kernel"),
+}
+
+def workload_rows(name, n, seed):
+    """Synthetic rows of SURVEY 8(d): Gaussian blobs; for c5 non-negative and L2-normalised (MNIST-like)."""
+    from xpysom_dask_amd.synthetic import gaussian_blobs
+    x = gaussian_blobs(n, WORKLOADS[name]["features"], seed=seed)
+    if name == "c5":
+        x = np.abs(x)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x
 
 
-def cpu_baseline(rows=8192):
+def cpu_baseline(name="c3"):
     """The oracle (NumPy port of xpysom.py:515-577, float64 neighbourhood as with the default
     'exponential' decay) on a truncated epoch of the same workload; throughput is N-independent
     once rows >> n_parallel would be reached, so samples/s transfers."""
     from oracle import som_oracle as O
+    wl = WORKLOADS[name]
+    (MAP_X, MAP_Y), FEATURES, rows = wl["map"], wl["features"], wl["cpu_rows"]
     cores = os.cpu_count() or 1
     try:
         from threadpoolctl import threadpool_info
@@ -43,16 +65,18 @@ def cpu_baseline(rows=8192):
             cores = int(max(th))
     except Exception:
         pass
-    data = O.gaussian_blobs(rows, FEATURES, seed=1234)
+    data = workload_rows(name, rows, 1234)
     w = O.default_codebook(MAP_X, MAP_Y, FEATURES, 1234).astype(np.float32)
+    if name == "c5":
+        w = np.abs(w)
     n_par = max(1, (os.cpu_count() or 1) * 500)       # the reference's CPU rule, xpysom.py:45,246
-    sig, eta = O.exponential_decay(128.0, 1, 0, 10), O.exponential_decay(0.5, 0.01, 0, 10)
+    sig, eta = O.exponential_decay(min(MAP_X, MAP_Y) / 2, 1, 0, 10), O.exponential_decay(0.5, 0.01, 0, 10)
     t0 = time.perf_counter()
-    O.epoch(data, w, eta, sig, wide=True, n_parallel=n_par)
+    O.epoch(data, w, eta, sig, wide=True, n_parallel=n_par, distance=wl["distance"], neighbourhood=wl["neighborhood"])
     dt = time.perf_counter() - t0
     return {"value": rows / dt, "unit": "samples/sec/epoch", "cores": cores, "kind": "port",
-            "sample": "%d rows of the same 256x256x128 workload, 1 epoch, n_parallel=%d, NumPy+OpenBLAS, "
-                      "float64 neighbourhood (exponential decay)" % (rows, n_par)}
+            "sample": "%d rows of the same %dx%dx%d workload, 1 epoch, n_parallel=%d, NumPy+OpenBLAS, "
+                      "float64 neighbourhood (exponential decay)" % (rows, MAP_X, MAP_Y, FEATURES, n_par)}
 
 
 def main():
@@ -60,10 +84,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS), help="c3 = the metric's configuration (default)")
+    ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default: the workload's)")
+    ap.add_argument("--precision", default=None, choices=["bf16", "f32", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    (MAP_X, MAP_Y), FEATURES = wl["map"], wl["features"]
+    if args.rows is None:
+        args.rows = wl["rows"]
+    if args.precision is None:
+        args.precision = wl["precision"]
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -75,8 +106,6 @@ def main():
     from xpysom_dask_amd import distributed as D
     from xpysom_dask_amd.decays import exponential_decay
     from xpysom_dask_amd.engine import HipEngine
-    from xpysom_dask_amd.synthetic import gaussian_blobs
-
     import torch
     dist = None
     # one process per GPU; SOM_DIST_BACKEND=gloo lets several ranks rehearse the path on ONE GPU
@@ -90,12 +119,15 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    eng = HipEngine(MAP_X, MAP_Y, FEATURES, precision=args.precision, device=dev)
+    eng = HipEngine(MAP_X, MAP_Y, FEATURES, precision=args.precision, device=dev, distance=wl["distance"],
+                    neighborhood=wl["neighborhood"])
     rs = np.random.RandomState(1234)                  # default codebook init, xpysom.py:189-190
     w = rs.rand(MAP_X, MAP_Y, FEATURES) * 2 - 1
     w /= np.linalg.norm(w, axis=-1, keepdims=True)
+    if args.workload == "c5":
+        w = np.abs(w)
     eng.set_weights(w.astype(np.float32))
-    eng.set_data(gaussian_blobs(args.rows, FEATURES, seed=1234 + rank))
+    eng.set_data(workload_rows(args.workload, args.rows, 1234 + rank))
 
     total = args.warmup + args.steps
     sched = [(exponential_decay(min(MAP_X, MAP_Y) / 2, 1, t, total), exponential_decay(0.5, 0.01, t, total))
@@ -131,7 +163,7 @@ def main():
     try:
         with open(os.path.join(REPO, "profiles", "r01_v2_pmc_traffic.json")) as f:
             pm = json.load(f)
-        if pm.get("rows_per_launch") == args.rows and args.precision == "bf16":
+        if pm.get("rows_per_launch") == args.rows and args.precision == "bf16" and args.workload == "c3":
             traffic = pm["bmu_bf16_k16_kernel"]["fabric_bytes_corrected"]
     except Exception:
         traffic = None
@@ -145,28 +177,37 @@ def main():
         ms_step = 1e3 * dt / args.steps
         flops_launch = 2.0 * args.rows * (MAP_X * MAP_Y) * FEATURES      # 2*K*D per sample
         achieved = flops_launch / (bmu_ms / max(1, bmu_n) * 1e-3) / 1e12
+        # algorithmic flops against the peak of the pipe the kernel runs on; bf16x3 executes 3x them
+        peak = MFMA_F32_PEAK_TFLOPS if args.precision == "f32" else MFMA_BF16_PEAK_TFLOPS
+        kernel_name = wl["kernel"]
+        if args.precision == "f32" and FEATURES > 128:
+            kernel_name = "bmu_f32_tiled_kernel"
+        elif args.precision == "f32":
+            kernel_name = "bmu_f32_res_kernel"
+        elif args.precision == "bf16x3" or FEATURES > 128:
+            kernel_name = "bmu_bf16_tiled_kernel"
+        else:
+            kernel_name = "bmu_bf16_k16_kernel"
         out = {
             "metric": "samples/sec/epoch", "value": world * args.rows / (dt / args.steps), "unit": "samples/sec/epoch",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "f32" else "bf16", "data": "synthetic",
             "config": {"workload": "batch-SOM epoch, %dx%d map, %d features, %d Gaussian-blob rows per GPU resident "
-                                   "in HBM (BASELINE configs[2]/[3]), one launch over all resident rows"
-                                   % (MAP_X, MAP_Y, FEATURES, args.rows),
+                                   "in HBM (%s), one launch over all resident rows"
+                                   % (MAP_X, MAP_Y, FEATURES, args.rows, wl["label"]),
                        "map": [MAP_X, MAP_Y], "features": FEATURES, "rows_per_gpu": args.rows,
-                       "precision": args.precision, "parallelism": "dp%d (sample shards, 1 all-reduce/epoch)" % world,
+                       "precision": args.precision, "distance": wl["distance"], "neighborhood": wl["neighborhood"],
+                       "parallelism": "dp%d (sample shards, 1 all-reduce/epoch)" % world,
                        "epochs_per_sec": args.steps / dt},
-            "roofline": {"bound": "mfma", "kernel": ("bmu_bf16_k16_kernel" if args.precision == "bf16" else "bmu_f32_res_kernel") + " (fused distance GEMM + argmin)",
-                         "achieved": achieved,
-                         "peak": MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else 157.3,
-                         "unit": "TFLOP/s",
-                         "frac": achieved / (MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else 157.3),
+            "roofline": {"bound": "mfma", "kernel": kernel_name + " (fused distance GEMM + argmin)",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "avg_launch_ms": bmu_ms / max(1, bmu_n), "launches": bmu_n,
                          "flops_per_launch": flops_launch},
             "ms_per_step_by_kernel": parts,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
