@@ -127,3 +127,72 @@ def test_full_size_quantization_error_and_winner_c2():
     np.testing.assert_allclose(d[rows, b2], two[:, 1], rtol=2e-6)
     assert (b1 != b2).all()
     assert abs(som.topographic_error(data[pick]) - O.topographic_error(data[pick], som._weights)) < 0.05
+
+
+def test_full_size_c5_shard_properties():
+    """BASELINE configs[4] (512 x 512 map, 784 features, cosine + mexican_hat, bf16): a quarter of one
+    GPU's shard through the tiled kernel, checked by size-independent properties -- every BMU is the
+    best or a near-best cosine match, the denominator and a random set of numerator columns are the
+    two-term separable mexican-hat transform of the segment sums of the engine's own BMUs, the
+    merge is num/den, and two half-shards add up to the whole."""
+    X = Y = 512
+    D, N = 784, 65536
+    K = X * Y
+    rs = np.random.RandomState(5)
+    data = np.abs(O.gaussian_blobs(N, D, seed=4321))
+    data /= np.linalg.norm(data, axis=1, keepdims=True)
+    w = np.abs(rs.rand(K, D).astype(F32))
+    sigma, eta = 40.0, 0.3
+    e = engine(X, Y, D, precision="bf16", distance="cosine", neighborhood="mexican_hat")
+    e.set_weights(w.reshape(X, Y, D))
+    e.set_data(data)
+    e.epoch_accumulate(sigma, eta, True)
+    num, den, bmu = e.epoch_fetch()
+    assert bmu.min() >= 0 and bmu.max() < K
+
+    # 1. cosine optimality on a subset (float32 similarities are ample against the 2^-7 bf16 bound)
+    pick = rs.choice(N, 256, replace=False)
+    wn = w / np.linalg.norm(w, axis=1, keepdims=True)
+    sim = data[pick] @ wn.T
+    assert (sim[np.arange(len(pick)), bmu[pick]] >= sim.max(1) - 2.0 ** -7).all()
+    del sim, wn
+
+    # 2. separable two-term mexican hat: h = ex*ey*(1 - 2dx^2/d - 2dy^2/d) = A (x) ey + ex (x) B
+    d = 2 * 0.5 ** 2 * sigma ** 2
+    ix = np.arange(X, dtype=np.float64)
+    dx2 = (ix[:, None] - ix[None, :]) ** 2
+    ex = np.exp(-dx2 / d)
+    A, B = ex * (1 - 2 * dx2 / d), ex * (-2 * dx2 / d)
+    c = np.bincount(bmu, minlength=K).astype(np.float64).reshape(X, Y)
+    oden = eta * (A @ c @ ex.T + ex @ c @ B.T)
+    assert rel_err(den.reshape(X, Y), oden) < 1e-5
+    cols = rs.choice(D, 6, replace=False)
+    S = np.zeros((K, len(cols)))
+    np.add.at(S, bmu, data[:, cols].astype(np.float64))
+    S = S.reshape(X, Y, len(cols))
+    onum = eta * (np.einsum("ia,jb,abd->ijd", A, ex, S, optimize=True) + np.einsum("ia,jb,abd->ijd", ex, B, S, optimize=True))
+    assert rel_err(num[:, cols], onum.reshape(K, -1)) < 1e-5
+
+    # 3. merge
+    e.epoch_merge()
+    w1 = e.get_weights()
+    live = den != 0
+    np.testing.assert_array_equal(w1[live][:, cols], (num[live][:, cols] / den[live, None]).astype(F32))
+    np.testing.assert_array_equal(w1[~live], w[~live])
+    del w1
+
+    # 4. shard linearity on the denominator and the sampled numerator columns
+    tot_den = np.zeros(K)
+    tot_num = np.zeros((K, len(cols)))
+    moved = 0
+    for lo, hi in ((0, N // 2), (N // 2, N)):
+        e.set_weights(w.reshape(X, Y, D))
+        e.set_data(data[lo:hi])
+        e.epoch_accumulate(sigma, eta, True)
+        pn, pd, pb = e.epoch_fetch()
+        moved += int((pb != bmu[lo:hi]).sum())
+        tot_den += pd
+        tot_num += pn[:, cols]
+    # the positivity offset B = max|x~| max|w~| belongs to the shard, so a near-tie may round the other way
+    assert moved < 1e-3 * N
+    assert rel_err(tot_den, den) < 2e-3 and rel_err(tot_num, num[:, cols]) < 2e-3
