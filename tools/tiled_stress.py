@@ -1,0 +1,36 @@
+import sys, numpy as np, time
+sys.path.insert(0,'.')
+from xpysom_dask_amd.engine import HipEngine
+from xpysom_dask_amd.synthetic import gaussian_blobs
+rs = np.random.RandomState(7)
+bad_total = 0
+t0 = time.time()
+cases = [(8,8,130,300,"bf16"),(20,13,200,1100,"bf16"),(64,64,784,5000,"bf16"),(100,90,257,7000,"bf16"),
+         (256,256,784,20000,"bf16"),(128,128,1000,9000,"bf16"),(30,30,33,4000,"bf16x3"),(64,64,128,30000,"bf16x3"),
+         (256,256,128,40000,"bf16x3"),(300,200,160,12345,"bf16"),(512,512,784,8192,"bf16"),(70,70,4,50000,"bf16x3"),
+         (1,5,300,100,"bf16"),(2,2,129,257,"bf16"),(256,16,640,3333,"bf16")]
+for (X,Y,D,N,prec) in cases:
+    data = gaussian_blobs(N, D, seed=N % 97)
+    w = (rs.rand(X,Y,D)*2-1).astype(np.float32) * 2
+    e = HipEngine(X,Y,D,precision=prec)
+    e.set_weights(w)
+    outs = [e.bmu(data) for _ in range(6)]
+    same = all(np.array_equal(outs[0], o) for o in outs[1:])
+    # reference in float64 on a subsample
+    idx = rs.choice(N, size=min(N, 1500), replace=False)
+    x64 = data[idx].astype(np.float64); w64 = w.reshape(-1, D).astype(np.float64)
+    d = (x64**2).sum(1)[:,None] - 2*x64@w64.T + (w64**2).sum(1)[None,:]
+    ref = d.argmin(1)
+    got = outs[0][idx]
+    miss = got != ref
+    dd = np.sqrt(np.maximum(d, 0))
+    slack = (2.0**-8 if prec=="bf16" else 2.0**-15) * (np.linalg.norm(x64,axis=1) + np.linalg.norm(w64,axis=1).max())
+    near = (dd[np.arange(len(idx)), got] <= dd.min(1) + slack).all()
+    # resident-path epochs too (different row padding / grid)
+    e.set_data(data)
+    e.epoch_accumulate(2.0, 0.3, True); b1 = e.epoch_fetch()[2]
+    e.epoch_accumulate(2.0, 0.3, True); b2 = e.epoch_fetch()[2]
+    ok = same and near and np.array_equal(b1, b2) and (np.mean(b1 != outs[0]) < 0.02)
+    bad_total += (not ok)
+    print(f"{X}x{Y}x{D} N={N} {prec}: repeatable={same} near_best={near} miss={miss.mean():.4f} resident_equal={np.array_equal(b1,b2)} vs_query_diff={np.mean(b1!=outs[0]):.5f} {'OK' if ok else 'FAIL'}", flush=True)
+print("failures:", bad_total, "elapsed", round(time.time()-t0,1))
