@@ -783,3 +783,34 @@ def test_tiled_kernel_is_repeatable_and_near_best(X, Y, D, n, precision):
     dd = np.sqrt(np.maximum((x64 ** 2).sum(1)[:, None] - 2 * x64 @ w64.T + (w64 ** 2).sum(1)[None, :], 0))
     slack = (2.0 ** -8 if precision == "bf16" else 2.0 ** -15) * (np.linalg.norm(x64, axis=1) + np.linalg.norm(w64, axis=1).max())
     assert (dd[np.arange(len(idx)), outs[0][idx]] <= dd.min(1) + slack).all()
+
+
+# ----------------------------------------------------------------------------- banded transform
+@pytest.mark.parametrize("X,Y,neigh,topo,sigma", [(300, 260, "gaussian", "rectangular", 1.5),
+                                                  (300, 260, "mexican_hat", "rectangular", 2.0),
+                                                  (257, 300, "gaussian", "hexagonal", 1.2),
+                                                  (280, 129, "bubble", "rectangular", 3.0),
+                                                  (200, 270, "triangle", "rectangular", 4.0),
+                                                  (300, 260, "gaussian", "rectangular", 80.0)])
+def test_banded_transform_is_bit_identical(monkeypatch, X, Y, neigh, topo, sigma):
+    """Small sigma leaves the neighbourhood tables exact float32 zeros away from the diagonal; the
+    transform GEMMs then walk only the nonzero bands (update.hpp).  Skipped chunks would have added
+    0 * m, so numerator and denominator must equal the full walk (SOM_NO_BANDS=1) bit for bit."""
+    D, n = 5, 4000
+    data = O.gaussian_blobs(n, D, seed=X)
+    w = O.default_codebook(X, Y, D, 8).astype(F32)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SOM_NO_BANDS", mode)
+        e = engine(X, Y, D, neighborhood=neigh, topology=topo)
+        e.set_weights(w)
+        e.set_data(data)
+        e.epoch_accumulate(sigma, 0.4, True)
+        num, den, bmu = e.epoch_fetch()
+        outs[mode] = (num.copy(), den.copy(), bmu.copy())
+        if mode == "0" and neigh == "gaussian" and topo == "rectangular":
+            _, onum, oden = O.update(data, w, 0.4, sigma, wide=True, forced_bmu=bmu)
+            assert rel_err(num, onum.reshape(-1, D)) < 1e-5 and rel_err(den, oden.reshape(-1)) < 1e-5
+    assert np.array_equal(outs["0"][2], outs["1"][2])
+    assert np.array_equal(outs["0"][0], outs["1"][0])
+    assert np.array_equal(outs["0"][1], outs["1"][1])

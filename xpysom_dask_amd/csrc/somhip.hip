@@ -114,6 +114,8 @@ struct som_handle {
     long gexec_n = -1;
     int graph_warm = 0;
     void* np_dev = nullptr;  // NeighParams read by the captured neigh_tables_kernel
+    int2* bands = nullptr;   // nonzero column ranges of the neighbourhood tables per 128-row block (update.hpp)
+    bool use_bands = true;
 
     bool prof = false;
     std::vector<EventPair> pending, pool;
@@ -615,17 +617,30 @@ int run_transform(som_handle* h, double sigma, double eta, int neigh_f64) {
     neigh_tables_kernel<<<dim3((unsigned)cdiv(ntab, 256)), dim3(256), 0, h->stream>>>(
         p, h->capturing ? (const NeighParams*)h->np_dev : nullptr, h->P1, h->P2);
     HIPCHK(h, hipGetLastError());
+    // nonzero bands of the tables (late epochs: most of Px, Py is exact zeros); SOM_NO_BANDS=1 walks everything
+    const int nyb = (int)cdiv(h->Y, LM_BM), nxb = (int)cdiv(h->X, LM_BM);
+    int2* bands1 = h->use_bands ? h->bands : nullptr;                   // [nt][nyb]
+    int2* bands2 = h->use_bands ? h->bands + (long)h->nt * nyb : nullptr;   // [nxb][nt]
+    if (h->use_bands) {
+        HIPCHK(h, hipMemsetAsync(h->bands, 0, (size_t)h->nt * (nyb + nxb) * sizeof(int2), h->stream));
+        band_ranges_kernel<<<dim3((unsigned)nyb, (unsigned)cdiv(h->Y, 64), (unsigned)h->nt), dim3(256), 0, h->stream>>>(
+            h->P1, h->Y, h->Y, 1, h->Y, bands1, (long)h->Y * h->Y, nyb);
+        band_ranges_kernel<<<dim3((unsigned)nxb, (unsigned)(h->nt * cdiv(h->X, 64)), 1), dim3(256), 0, h->stream>>>(
+            h->P2, h->X, h->nt * h->X, h->nt, h->X, bands2, 0, 0);
+    }
     // stage 1: T_t[a] = Py_t (Y x Y) * SC[a] (Y x D1p), batched over the X map rows
     const long slab = (long)h->Y * h->D1p;
     for (int t1 = 0; t1 < h->nt; ++t1) {
-        dim3 grid((unsigned)cdiv(h->D1p, LM_BN), (unsigned)cdiv(h->Y, LM_BM), (unsigned)h->X);
+        dim3 grid((unsigned)cdiv(h->D1p, LM_BN), (unsigned)nyb, (unsigned)h->X);
         leftmul_f32_kernel<<<grid, dim3(256), 0, h->stream>>>(h->P1 + (long)t1 * h->Y * h->Y, h->Y, h->Y, h->SC, slab,
-                                                             h->T + (long)t1 * h->X * slab, slab, h->D1p);
+                                                             h->T + (long)t1 * h->X * slab, slab, h->D1p,
+                                                             bands1 ? bands1 + (long)t1 * nyb : nullptr, 1, h->Y);
     }
     // stage 2: ACC = [Px_0 | Px_1 ...] (X x nt*X) * T (nt*X x Y*D1p)
     {
-        dim3 grid((unsigned)cdiv(slab, LM_BN), (unsigned)cdiv(h->X, LM_BM), 1);
-        leftmul_f32_kernel<<<grid, dim3(256), 0, h->stream>>>(h->P2, h->X, h->nt * h->X, h->T, 0, h->ACC, 0, slab);
+        dim3 grid((unsigned)cdiv(slab, LM_BN), (unsigned)nxb, 1);
+        leftmul_f32_kernel<<<grid, dim3(256), 0, h->stream>>>(h->P2, h->X, h->nt * h->X, h->T, 0, h->ACC, 0, slab, bands2,
+                                                             h->nt, h->X);
     }
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -765,6 +780,9 @@ int som_create(const som_config* cfg, som_handle** out) {
         if ((rc = dev_alloc(h, &npd, 1))) return bail(rc);
         h->np_dev = npd;
         if (const char* e = std::getenv("SOM_GRAPH")) h->use_graph = std::atoi(e) != 0;
+        if (const char* e = std::getenv("SOM_NO_BANDS")) h->use_bands = std::atoi(e) == 0;
+        const size_t nb = (size_t)h->nt * (cdiv(h->Y, LM_BM) + cdiv(h->X, LM_BM));
+        if ((rc = dev_alloc(h, &h->bands, nb))) return bail(rc);
     }
     if (hipMemsetAsync(h->W, 0, (size_t)h->K * h->D * sizeof(float), h->stream) != hipSuccess ||
         hipMemsetAsync(h->ACC, 0, KD1 * sizeof(float), h->stream) != hipSuccess)
@@ -801,6 +819,7 @@ void som_destroy(som_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->np_dev) (void)hipFree(h->np_dev);
+    if (h->bands) (void)hipFree(h->bands);
     for (auto& ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto& ep : h->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     void* bufs[] = {h->W, h->wsq, h->SC, h->T, h->ACC, h->P1, h->P2, h->Wst, h->X_owned, h->bmu, h->xsq, h->Xb,
