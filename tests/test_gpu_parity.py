@@ -814,3 +814,25 @@ def test_banded_transform_is_bit_identical(monkeypatch, X, Y, neigh, topo, sigma
     assert np.array_equal(outs["0"][2], outs["1"][2])
     assert np.array_equal(outs["0"][0], outs["1"][0])
     assert np.array_equal(outs["0"][1], outs["1"][1])
+
+
+# ----------------------------------------------------------------------------- rows already in HBM
+def test_train_accepts_device_resident_rows():
+    """A torch CUDA tensor (what a CuPy array is to the reference, xpysom.py:487-510) is trained on in
+    place -- no host round trip -- and gives the codebook the same rows give from the host; analysis
+    calls accept it too."""
+    import torch
+    from xpysom_dask_amd import XPySom
+    X, Y, D, n = 12, 10, 6, 3000
+    data = O.gaussian_blobs(n, D, seed=21)
+    a = XPySom(X, Y, D, sigma=3.0, random_seed=5).train(data, 6)
+    t = torch.from_numpy(data).cuda()
+    b = XPySom(X, Y, D, sigma=3.0, random_seed=5).train(t, 6)
+    np.testing.assert_allclose(b._weights, a._weights, rtol=2e-5, atol=1e-6)
+    assert b.winner(t[:50]) == a.winner(data[:50])
+    assert abs(b.quantization_error(t) - a.quantization_error(data)) < 1e-5
+    t64 = torch.from_numpy(data.astype(np.float64)).cuda()[:, :]       # other dtypes are converted on the device
+    c = XPySom(X, Y, D, sigma=3.0, random_seed=5).train(t64, 6)
+    np.testing.assert_allclose(c._weights, a._weights, rtol=2e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        XPySom(X, Y, D + 1, random_seed=5).train(t, 1)

@@ -25,6 +25,41 @@ DISTANCES = {"euclidean": True, "euclidean_no_opt": True, "manhattan": True, "ma
 DEFAULT_BATCH_ROWS = 65536
 
 
+def _device_rows(data):
+    """Rows that already live in HBM (the role CuPy arrays play in the reference, xpysom.py:487-510):
+    a torch CUDA tensor, or any object with ``__cuda_array_interface__``, as a contiguous float32
+    ``(n, input_len)`` block.  Returns ``(pointer, n_rows, n_cols, device_index, owner)`` or ``None``
+    for host data."""
+    try:
+        import torch
+    except ImportError:
+        torch = None
+    if torch is not None and isinstance(data, torch.Tensor):
+        if not data.is_cuda:
+            return None
+        t = data.detach()
+        if t.dim() != 2:
+            raise ValueError('data must be 2-dimensional (n_samples, input_len)')
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.to(torch.float32).contiguous()
+        torch.cuda.current_stream(t.device).synchronize()      # the engine reads it on its own stream
+        return t.data_ptr(), t.shape[0], t.shape[1], t.device.index, t
+    cai = getattr(data, "__cuda_array_interface__", None)
+    if cai is not None:
+        shape = tuple(cai["shape"])
+        if len(shape) != 2 or cai["typestr"] != "<f4" or cai.get("strides") is not None:
+            raise ValueError('device data must be a C-contiguous float32 (n_samples, input_len) array')
+        return int(cai["data"][0]), shape[0], shape[1], None, data
+    return None
+
+
+def _host_rows(x):
+    """float32 host view of array-like input; device tensors are copied back (analysis calls only)."""
+    if hasattr(x, "is_cuda") and getattr(x, "is_cuda"):
+        x = x.detach().cpu().numpy()
+    return np.asarray(x, dtype=np.float32)
+
+
 class XPySom:
     def __init__(self, x, y, input_len,
                  sigma=0, sigmaN=1,
@@ -160,7 +195,7 @@ class XPySom:
     def activate(self, x):
         """Activation map of x: its distance to every unit under the configured distance, shape (n, K)
         (xpysom.py:323-354).  An analysis call: training never materialises this matrix."""
-        x = np.asarray(x, dtype=np.float32)
+        x = _host_rows(x)
         if x.ndim == 0:
             x = x.reshape(1, 1)
         elif x.ndim == 1:
@@ -169,7 +204,7 @@ class XPySom:
 
     def distance_from_weights(self, data, weights_gpu=None):
         """d[i, j] = euclidean distance between data[i] and the j-th unit (xpysom.py:647-671)."""
-        data = np.asarray(data, dtype=np.float32)
+        data = _host_rows(data)
         return self._upload_weights().distance_matrix(data, quantization=True)
 
     def distance_map(self):
@@ -210,16 +245,27 @@ class XPySom:
         if iter_end is None:
             iter_end = num_epochs
 
-        data = np.asarray(data, dtype=np.float32)
-        if data.ndim != 2:
-            raise ValueError('data must be 2-dimensional (n_samples, input_len)')
         rank, world = _dist.dist_info()
-        if world > 1 and not self._sharded_input:
-            lo, hi = _dist.shard_bounds(len(data), rank, world)
-            data = data[lo:hi]
-
-        eng = self._upload_weights()
-        eng.set_data(data)
+        if _device_rows(data) is not None:               # rows already in HBM: no host round trip
+            if world > 1 and not self._sharded_input:
+                lo, hi = _dist.shard_bounds(len(data), rank, world)
+                data = data[lo:hi]
+            ptr, n, d, dev_index, owner = _device_rows(data)
+            eng = self._upload_weights()
+            if dev_index is not None and dev_index != eng.device:
+                raise ValueError('device data lives on cuda:%d, the engine on cuda:%d' % (dev_index, eng.device))
+            if d != self._input_len:
+                raise ValueError('Received %d features, expected %d.' % (d, self._input_len))
+            eng.set_data_device(ptr, n, keepalive=owner)
+        else:
+            data = np.asarray(data, dtype=np.float32)
+            if data.ndim != 2:
+                raise ValueError('data must be 2-dimensional (n_samples, input_len)')
+            if world > 1 and not self._sharded_input:
+                lo, hi = _dist.shard_bounds(len(data), rank, world)
+                data = data[lo:hi]
+            eng = self._upload_weights()
+            eng.set_data(data)
 
         for iteration in range(iter_beg, iter_end):
             eta = self._decay_function(self._learning_rate, self._learning_rateN, iteration, num_epochs)
@@ -275,7 +321,7 @@ class XPySom:
     def winner(self, x):
         """Coordinates of the winning neuron(s): ``(i, j)`` for one sample, a list of
         ``(i, j)`` tuples (numpy.int64) for a matrix -- xpysom.py:370-408."""
-        x = np.asarray(x, dtype=np.float32)
+        x = _host_rows(x)
         one = x.ndim == 1
         if one:
             x = x[None, :]
@@ -288,7 +334,7 @@ class XPySom:
     def quantization(self, data):
         """Assigns a code book (weights vector of the winning neuron) to each sample in data."""
         self._check_input_len(data)
-        data = np.asarray(data, dtype=np.float32)
+        data = _host_rows(data)
         ids = self._winner_ids(data, quantization=True)
         w = np.asarray(self._weights)
         return w.reshape(-1, w.shape[2])[ids]
@@ -297,7 +343,7 @@ class XPySom:
         """Average distance between each input sample and its best matching unit
         (always Euclidean, xpysom.py:673-707).  Returns a Python float."""
         self._check_input_len(data)
-        data = np.asarray(data, dtype=np.float32)
+        data = _host_rows(data)
         eng = self._upload_weights()
         total, n = 0.0, 0
         for s in range(0, len(data), self._n_parallel):
@@ -314,7 +360,7 @@ class XPySom:
         if np.prod(self._weights.shape) == 1:
             warn('The topographic error is not defined for a 1-by-1 map.')
             return np.nan
-        data = np.asarray(data, dtype=np.float32)
+        data = _host_rows(data)
         eng = self._upload_weights()
         Y = self._weights.shape[1]
         bad, n = 0, 0
@@ -334,14 +380,14 @@ class XPySom:
 
     def predict(self, data):
         """Raveled BMU index of every sample (xpysom.py:608-617), batched."""
-        data = np.asarray(data, dtype=np.float32)
+        data = _host_rows(data)
         return self._winner_ids(data).astype(np.int64)
 
     def activation_response(self, data):
         """Matrix where element i,j is the number of times neuron i,j won (xpysom.py:819-829)."""
         self._check_input_len(data)
         a = np.zeros(self._weights.shape[:2])
-        ids = self._winner_ids(np.asarray(data, dtype=np.float32))
+        ids = self._winner_ids(_host_rows(data))
         np.add.at(a.reshape(-1), ids, 1)
         return a
 
