@@ -117,3 +117,22 @@ def test_train_streaming_host_logic_with_the_test_double():
     a.train(data, 4)
     b.train_streaming(lambda: (data[i:i + 123] for i in range(0, 500, 123)), 4)
     np.testing.assert_array_equal(a._weights, b._weights)
+
+
+def test_device_rows_detection_and_validation():
+    """Host arrays are not device rows; a __cuda_array_interface__ object must be C-contiguous float32 2-D."""
+    from xpysom_dask_amd.xpysom import _device_rows
+
+    class Fake:
+        def __init__(self, shape, typestr="<f4", strides=None):
+            self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (4096, False),
+                                             "version": 2, "strides": strides}
+    assert _device_rows(np.zeros((3, 2), dtype=np.float32)) is None
+    assert _device_rows([[1.0, 2.0]]) is None
+    ptr, n, d, dev, owner = _device_rows(Fake((7, 5)))
+    assert (ptr, n, d, dev) == (4096, 7, 5, None) and isinstance(owner, Fake)
+    for bad in (Fake((7,)), Fake((7, 5), typestr="<f8"), Fake((7, 5), strides=(40, 4))):
+        with pytest.raises(ValueError):
+            _device_rows(bad)
+    import torch
+    assert _device_rows(torch.zeros(4, 3)) is None          # CPU tensor: host path
