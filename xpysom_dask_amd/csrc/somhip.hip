@@ -583,8 +583,12 @@ int segsum_rows(som_handle* h, const float* X, const int* bmu, long N, const int
                                                  h->stream);
         if (e != hipSuccess) return fail_hip(h, "rocprim::radix_sort_pairs", e);
         long waves = cdiv(N, SEG_CHUNK);
-        segsum_sorted_kernel<<<dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, h->stream>>>(X, skey, srow, N, h->D, h->D1p,
-                                                                                       h->SC);
+        if ((h->D & 1) == 0)
+            segsum_sorted_kernel<true><<<dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, h->stream>>>(X, skey, srow, N, h->D,
+                                                                                                 h->D1p, h->SC);
+        else
+            segsum_sorted_kernel<false><<<dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, h->stream>>>(X, skey, srow, N, h->D,
+                                                                                                  h->D1p, h->SC);
         HIPCHK(h, hipGetLastError());
     }
     return 0;
@@ -780,6 +784,8 @@ int som_create(const som_config* cfg, som_handle** out) {
         if ((rc = dev_alloc(h, &npd, 1))) return bail(rc);
         h->np_dev = npd;
         if (const char* e = std::getenv("SOM_GRAPH")) h->use_graph = std::atoi(e) != 0;
+        // a 128-row block of a table already spans most of a map side up to 256: nothing to skip there
+        h->use_bands = h->X > 256 || h->Y > 256;
         if (const char* e = std::getenv("SOM_NO_BANDS")) h->use_bands = std::atoi(e) == 0;
         const size_t nb = (size_t)h->nt * (cdiv(h->Y, LM_BM) + cdiv(h->X, LM_BM));
         if ((rc = dev_alloc(h, &h->bands, nb))) return bail(rc);

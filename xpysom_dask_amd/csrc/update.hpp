@@ -39,6 +39,10 @@ __global__ __launch_bounds__(256) void iota_kernel(int* __restrict__ v, long n) 
     if (i < n) v[i] = (int)i;
 }
 
+// VEC2 (D even): a lane owns feature pairs (8-byte loads, one instruction per 128 features of a row) and
+// the rows are fetched eight at a time before the run logic consumes them, so eight rows' loads are in
+// flight per wave.  The additions happen in the same sorted order either way.
+template <bool VEC2>
 __global__ __launch_bounds__(256) void segsum_sorted_kernel(const float* __restrict__ X,
                                                             const int* __restrict__ skey,
                                                             const int* __restrict__ srow, long N, int D, int D1p,
@@ -55,34 +59,60 @@ __global__ __launch_bounds__(256) void segsum_sorted_kernel(const float* __restr
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         int cur = __builtin_amdgcn_readfirstlane(my_key);
         int run = 0;
-        for (int i = 0; i < cnt_here; ++i) {
-            const int b = __builtin_amdgcn_readlane(my_key, i);
-            const long row = __builtin_amdgcn_readlane(my_row, i);
-            if (b != cur) {
+        // feature of acc[j]: VEC2: f0 + 128*(j>>1) + 2*lane + (j&1);  scalar: f0 + lane + 64*j
+        auto feat = [&](int j) { return VEC2 ? f0 + 128 * (j >> 1) + 2 * lane + (j & 1) : f0 + lane + 64 * j; };
+        auto flush = [&]() {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = feat(j);
+                if (d < D) unsafeAtomicAdd(&SC[(long)cur * D1p + d], acc[j]);
+                acc[j] = 0.f;
+            }
+            if (f0 == 0 && lane == 0) unsafeAtomicAdd(&SC[(long)cur * D1p + D], (float)run);
+        };
+        if (VEC2) {
+            for (int i0 = 0; i0 < cnt_here; i0 += 8) {
+                float v[8][4];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u;
+                    const long row = __builtin_amdgcn_readlane(my_row, i < cnt_here ? i : 0);
+                    const float* x = X + row * D;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int d = f0 + 128 * jj + 2 * lane;
+                        float2 t = make_float2(0.f, 0.f);
+                        if (i < cnt_here && d < D) t = *(const float2*)(x + d);   // D even: d + 1 < D, 8-byte aligned
+                        v[u][2 * jj] = t.x; v[u][2 * jj + 1] = t.y;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u;
+                    if (i < cnt_here) {
+                        const int b = __builtin_amdgcn_readlane(my_key, i);
+                        if (b != cur) { flush(); cur = b; run = 0; }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j] += v[u][j];
+                        ++run;
+                    }
+                }
+            }
+        } else {
+            for (int i = 0; i < cnt_here; ++i) {
+                const int b = __builtin_amdgcn_readlane(my_key, i);
+                const long row = __builtin_amdgcn_readlane(my_row, i);
+                if (b != cur) { flush(); cur = b; run = 0; }
+                const float* x = X + row * D;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     int d = f0 + lane + 64 * j;
-                    if (d < D) unsafeAtomicAdd(&SC[(long)cur * D1p + d], acc[j]);
-                    acc[j] = 0.f;
+                    if (d < D) acc[j] += x[d];
                 }
-                if (f0 == 0 && lane == 0) unsafeAtomicAdd(&SC[(long)cur * D1p + D], (float)run);
-                cur = b;
-                run = 0;
+                ++run;
             }
-            const float* x = X + row * D;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int d = f0 + lane + 64 * j;
-                if (d < D) acc[j] += x[d];
-            }
-            ++run;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int d = f0 + lane + 64 * j;
-            if (d < D) unsafeAtomicAdd(&SC[(long)cur * D1p + d], acc[j]);
-        }
-        if (f0 == 0 && lane == 0) unsafeAtomicAdd(&SC[(long)cur * D1p + D], (float)run);
+        flush();
     }
 }
 
