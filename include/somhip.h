@@ -140,7 +140,11 @@ int som_bmu_top2(som_handle* h, const float* x_host, int64_t n_rows, int32_t* id
  * mode ACTIVATION = XPySom.activate (xpysom.py:323-354, configured GEMM-form distance),
  * mode QUANTIZATION = XPySom.distance_from_weights (xpysom.py:647-671).  Never used while training. */
 int som_distance_matrix(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, float* dist_out);
-/* mean_n |x_n - W[bmu_n]|: XPySom.quantization_error, xpysom.py:673-707 */
+/* mean_n |x_n - W[bmu_n]|: XPySom.quantization_error, xpysom.py:673-707.  The distance to the chosen unit is
+ * always evaluated exactly (float32 differences, float64 sum).  The BMU search is the reference's sqrt'd
+ * Euclidean argmin in F32 precision; in BF16 / BF16X3 precision with the 'euclidean' activation distance it
+ * runs through the configured MFMA path (same argmin up to the operand rounding), as does som_bmu's
+ * QUANTIZATION mode. */
 int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, double* qe_out);
 
 /* stream / timing plumbing */

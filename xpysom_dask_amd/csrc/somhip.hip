@@ -1159,6 +1159,23 @@ int som_epoch_fetch(som_handle* h, float* num, float* den, int32_t* bmu) {
     return 0;
 }
 
+namespace {
+// BMU under the full Euclidean distance for quantization / quantization_error (xpysom.py:632-645, 699-707)
+// of the n_rows rows in the query scratch.  f32 precision: the reference's sqrt'd distance, bit for bit.
+// bf16 / bf16x3 precision with the 'euclidean' activation distance: the same argmin through the configured
+// MFMA path (the squared distance is monotone in it); the caller evaluates the distance itself exactly.
+int run_quantization_bmu(som_handle* h, long n_rows) {
+    if (int rc = refresh_codebook_operands(h)) return rc;
+    if (h->cfg.precision != SOM_PREC_F32 && h->cfg.distance == SOM_DIST_EUCLIDEAN) {
+        if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1)) return rc;
+        return run_activation_bmu(h, h->qX, n_rows, h->qxsq, h->qXb, h->xmax2 + 1, h->qbmu);
+    }
+    if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
+    Timed t(h, SOM_K_BMU);
+    return launch_bmu_f32_any<SCORE_EUCLID_SQRT>(h, h->qX, n_rows, h->qxsq, h->qbmu);
+}
+}  // namespace
+
 int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, int32_t* ids_out) {
     if (h) (void)hipSetDevice(h->cfg.device);
     if (!h || n_rows < 0 || (n_rows > 0 && (!x_host || !ids_out))) return fail(h, "som_bmu: bad argument");
@@ -1167,10 +1184,7 @@ int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, in
     if (int rc = ensure_query_scratch(h, n_rows)) return rc;
     HIPCHK(h, hipMemcpyAsync(h->qX, x_host, (size_t)n_rows * h->D * sizeof(float), hipMemcpyHostToDevice, h->stream));
     if (mode == SOM_BMU_QUANTIZATION) {
-        if (int rc = refresh_codebook_operands(h)) return rc;
-        if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
-        Timed t(h, SOM_K_BMU);
-        if (int rc = launch_bmu_f32_any<SCORE_EUCLID_SQRT>(h, h->qX, n_rows, h->qxsq, h->qbmu)) return rc;
+        if (int rc = run_quantization_bmu(h, n_rows)) return rc;
     } else {
         if (needs_xsq(h)) if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
         if (h->cfg.precision != SOM_PREC_F32)
@@ -1235,9 +1249,7 @@ int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, d
     if (n_rows == 0) { *qe_out = NAN; return 0; }     // numpy: mean of an empty array
     if (int rc = ensure_query_scratch(h, n_rows)) return rc;
     HIPCHK(h, hipMemcpyAsync(h->qX, x_host, (size_t)n_rows * h->D * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    if (int rc = refresh_codebook_operands(h)) return rc;
-    if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
-    if (int rc = launch_bmu_f32_any<SCORE_EUCLID_SQRT>(h, h->qX, n_rows, h->qxsq, h->qbmu)) return rc;
+    if (int rc = run_quantization_bmu(h, n_rows)) return rc;
     HIPCHK(h, hipMemsetAsync(h->dsum, 0, sizeof(double), h->stream));
     qe_kernel<<<dim3((unsigned)cdiv(n_rows, 4)), dim3(256), 0, h->stream>>>(h->qX, h->qbmu, h->W, n_rows, h->D, h->dsum);
     HIPCHK(h, hipGetLastError());
