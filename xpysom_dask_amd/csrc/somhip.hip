@@ -63,7 +63,9 @@ struct som_handle {
     long ftX_cap = 0;
     int ft_kchunks = 0, ft_ublocks = 0;
     int n_stages = 0;
-    bool w_dirty = true;     // wsq / bf16 stage image out of date w.r.t. W
+    // operands derived from W, rebuilt lazily: the bf16 stage image (w_dirty), |w|^2 (wsq_dirty) and the
+    // float32 stage / tile images (wf_dirty).  Training in bf16 precision never touches the float32 images.
+    bool w_dirty = true, wsq_dirty = true, wf_dirty = true;
 
     // resident training rows
     const float* Xd = nullptr;
@@ -201,19 +203,36 @@ void launch_prep_w(som_handle* h) {
                                                                                         h->n_stages);
 }
 
-int refresh_codebook_operands(som_handle* h) {
-    if (!h->w_dirty) return 0;
+void mark_codebook_changed(som_handle* h) { h->w_dirty = h->wsq_dirty = h->wf_dirty = true; }
+
+// need_f32: the caller is about to run a float32 kernel (parity-mode BMU, top-2, distance matrix).
+int refresh_codebook_operands(som_handle* h, bool need_f32) {
+    const bool bf = h->cfg.precision != SOM_PREC_F32;
+    const bool do_f32 = (need_f32 || !bf) && h->wf_dirty;
+    const bool do_wsq = h->wsq_dirty && (need_f32 || !bf || h->cfg.distance == SOM_DIST_COSINE);
+    const bool do_bf = bf && h->w_dirty;
+    if (!do_f32 && !do_wsq && !do_bf) return 0;
     Timed t(h, SOM_K_PREP);
-    row_sq_f32_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->wsq);
-    if (h->Wfimg) {
-        long total = (long)h->ft_ublocks * h->ft_kchunks * (4 * 4 * 64 + 128);
-        prep_tiles_f32_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
-            h->W, h->K, h->D, h->ft_kchunks, h->ft_ublocks, FT_WTILE, h->wsq, h->Wfimg);
+    if (do_wsq) {
+        row_sq_f32_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->wsq);
+        h->wsq_dirty = false;
     }
-    if (h->Wfst) {
-        long total = (long)h->fr_stages * ((long)FR_UT * h->fr_kg * 64 + 64);
-        prep_w_f32_res_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(h->W, h->wsq, h->K, h->D,
-                                                                                          h->fr_kg, h->Wfst, h->fr_stages);
+    if (do_f32) {
+        if (h->Wfimg) {
+            long total = (long)h->ft_ublocks * h->ft_kchunks * (4 * 4 * 64 + 128);
+            prep_tiles_f32_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
+                h->W, h->K, h->D, h->ft_kchunks, h->ft_ublocks, FT_WTILE, h->wsq, h->Wfimg);
+        }
+        if (h->Wfst) {
+            long total = (long)h->fr_stages * ((long)FR_UT * h->fr_kg * 64 + 64);
+            prep_w_f32_res_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
+                h->W, h->wsq, h->K, h->D, h->fr_kg, h->Wfst, h->fr_stages);
+        }
+        h->wf_dirty = false;
+    }
+    if (!do_bf) {
+        HIPCHK(h, hipGetLastError());
+        return 0;
     }
     if (h->cfg.precision != SOM_PREC_F32 && h->tiled) {
         const float* unit = h->cfg.distance == SOM_DIST_COSINE ? h->wsq : nullptr;
@@ -544,7 +563,7 @@ int launch_bmu_pairwise(som_handle* h, const float* X, long N, int p, bool even,
 int run_activation_bmu(som_handle* h, const float* X, long N, const float* xsq, const __bf16* Xb, const float* xmax2,
                        int* out) {
     if (N == 0) return 0;
-    if (int rc = refresh_codebook_operands(h)) return rc;
+    if (int rc = refresh_codebook_operands(h, h->cfg.precision == SOM_PREC_F32)) return rc;
     Timed t(h, SOM_K_BMU);
     if (h->cfg.precision != SOM_PREC_F32) return launch_bmu_bf16(h, Xb, xmax2, N, out);
     switch (h->cfg.distance) {
@@ -848,7 +867,7 @@ int som_set_weights(som_handle* h, const float* w_host) {
     if (!h || !w_host) return fail(h, "som_set_weights: NULL argument");
     HIPCHK(h, hipMemcpyAsync(h->W, w_host, (size_t)h->K * h->D * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->w_dirty = true;
+    mark_codebook_changed(h);
     return 0;
 }
 
@@ -940,7 +959,7 @@ int capture_epoch_graph(som_handle* h) {
         return 0;
     }
     h->capturing = true;
-    h->w_dirty = true;                                  // the replayed epoch always rebuilds the codebook operands
+    mark_codebook_changed(h);                           // the replayed epoch always rebuilds the operands its BMU kernel needs
     const std::string saved_err = h->err;
     int rc = epoch_accumulate_eager(h, 1.0, 1.0, 1);
     h->capturing = false;
@@ -952,7 +971,7 @@ int capture_epoch_graph(som_handle* h) {
         h->gexec = nullptr;
         h->use_graph = false;                           // this handle stays on the eager path
         h->err = saved_err;
-        h->w_dirty = true;
+        mark_codebook_changed(h);
         if (std::getenv("SOM_DEBUG")) std::fprintf(stderr, "[somhip] epoch graph capture failed; eager launches\n");
         return 0;
     }
@@ -985,7 +1004,11 @@ int som_epoch_accumulate(som_handle* h, double sigma, double eta, int neigh_f64)
             const NeighParams p = make_neigh_params(h, sigma, eta, neigh_f64);
             store_params_kernel<<<dim3(1), dim3(64), 0, h->stream>>>(p, (NeighParams*)h->np_dev);
             HIPCHK(h, hipGraphLaunch(h->gexec, h->stream));
+            // what the captured refresh_codebook_operands(h, precision == F32) rebuilt
+            const bool bf = h->cfg.precision != SOM_PREC_F32;
             h->w_dirty = false;
+            if (!bf) h->wf_dirty = false;
+            if (!bf || h->cfg.distance == SOM_DIST_COSINE) h->wsq_dirty = false;
             return 0;
         }
     }
@@ -1006,7 +1029,7 @@ int som_epoch_accumulate_forced(som_handle* h, const int32_t* bmu_host, double s
 int som_stream_begin(som_handle* h) {
     if (h) (void)hipSetDevice(h->cfg.device);
     if (!h) return 1;
-    if (int rc = refresh_codebook_operands(h)) return rc;
+    if (int rc = refresh_codebook_operands(h, h->cfg.precision == SOM_PREC_F32)) return rc;
     HIPCHK(h, hipMemsetAsync(h->SC, 0, (size_t)h->K * h->D1p * sizeof(float), h->stream));
     h->streaming = true;
     return 0;
@@ -1127,7 +1150,7 @@ int som_epoch_merge(som_handle* h) {
     long total = (long)h->K * h->D;
     merge_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p);
     HIPCHK(h, hipGetLastError());
-    h->w_dirty = true;
+    mark_codebook_changed(h);
     return 0;
 }
 
@@ -1165,11 +1188,11 @@ namespace {
 // bf16 / bf16x3 precision with the 'euclidean' activation distance: the same argmin through the configured
 // MFMA path (the squared distance is monotone in it); the caller evaluates the distance itself exactly.
 int run_quantization_bmu(som_handle* h, long n_rows) {
-    if (int rc = refresh_codebook_operands(h)) return rc;
     if (h->cfg.precision != SOM_PREC_F32 && h->cfg.distance == SOM_DIST_EUCLIDEAN) {
         if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1)) return rc;
         return run_activation_bmu(h, h->qX, n_rows, h->qxsq, h->qXb, h->xmax2 + 1, h->qbmu);
     }
+    if (int rc = refresh_codebook_operands(h, true)) return rc;
     if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
     Timed t(h, SOM_K_BMU);
     return launch_bmu_f32_any<SCORE_EUCLID_SQRT>(h, h->qX, n_rows, h->qxsq, h->qbmu);
@@ -1202,7 +1225,7 @@ int som_bmu_top2(som_handle* h, const float* x_host, int64_t n_rows, int32_t* id
     if (n_rows == 0) return 0;
     if (int rc = ensure_query_scratch(h, n_rows)) return rc;
     HIPCHK(h, hipMemcpyAsync(h->qX, x_host, (size_t)n_rows * h->D * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    if (int rc = refresh_codebook_operands(h)) return rc;
+    if (int rc = refresh_codebook_operands(h, true)) return rc;
     if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
     {
         Timed t(h, SOM_K_BMU);
@@ -1224,7 +1247,7 @@ int som_distance_matrix(som_handle* h, const float* x_host, int64_t n_rows, int3
     if ((double)n_rows * h->K > 2.0e9) return fail(h, "som_distance_matrix: n_rows * K too large (analysis call, chunk it)");
     if (int rc = ensure_query_scratch(h, n_rows)) return rc;
     HIPCHK(h, hipMemcpyAsync(h->qX, x_host, (size_t)n_rows * h->D * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    if (int rc = refresh_codebook_operands(h)) return rc;
+    if (int rc = refresh_codebook_operands(h, true)) return rc;
     if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
     float* dm = nullptr;
     if (int rc = dev_alloc(h, &dm, (size_t)n_rows * h->K)) return rc;
