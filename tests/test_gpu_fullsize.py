@@ -122,9 +122,10 @@ def test_full_size_quantization_error_and_winner_c2():
     d = O.dist_euclid(data[pick], w)
     two = np.sort(d, axis=1)[:, :2]
     rows = np.arange(len(pick))
-    # (to 2e-6: the oracle's sgemm on THIS host need not sum in the order the golden vectors' host did)
-    np.testing.assert_allclose(d[rows, b1], two[:, 0], rtol=2e-6)
-    np.testing.assert_allclose(d[rows, b2], two[:, 1], rtol=2e-6)
+    # (to 5e-6: the oracle's sgemm on THIS host need not sum in the order the golden vectors' host did,
+    #  and sqrt(a - b) amplifies the cancellation in the squared distance)
+    np.testing.assert_allclose(d[rows, b1], two[:, 0], rtol=5e-6)
+    np.testing.assert_allclose(d[rows, b2], two[:, 1], rtol=5e-6)
     assert (b1 != b2).all()
     assert abs(som.topographic_error(data[pick]) - O.topographic_error(data[pick], som._weights)) < 0.05
 

@@ -589,6 +589,28 @@ int row_sq(som_handle* h, const float* X, long N, float* out) {
     return 0;
 }
 
+// BMU ids are <= 20-bit keys in 4-byte ints: rocPRIM's default picks its merge sort up to 1 Mi items for
+// 4-byte keys (ten merge passes at 1 Mi rows: 0.16 ms); two 8-bit Onesweep passes take half of that, but lose
+// to the merge sort at 100 k rows -- so Onesweep from SORT_ONESWEEP_ROWS rows on.
+using SortOnesweep = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 1024>;
+constexpr long SORT_ONESWEEP_ROWS = 262144;
+
+template <typename... Args>
+hipError_t sort_bmu_pairs(long n, Args... args) {
+    if (n >= SORT_ONESWEEP_ROWS) return rocprim::radix_sort_pairs<SortOnesweep>(args...);
+    return rocprim::radix_sort_pairs(args...);
+}
+// temporary storage that serves both algorithms for up to n rows
+template <typename K, typename V>
+hipError_t sort_bmu_pairs_storage(size_t& bytes, K* kin, K* kout, V* vin, V* vout, long n, unsigned bits, hipStream_t st) {
+    size_t b1 = 0, b2 = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, b1, kin, kout, vin, vout, (size_t)n, 0u, bits, st);
+    if (e != hipSuccess) return e;
+    e = rocprim::radix_sort_pairs<SortOnesweep>(nullptr, b2, kin, kout, vin, vout, (size_t)n, 0u, bits, st);
+    bytes = b1 > b2 ? b1 : b2;
+    return e;
+}
+
 // ---- update path: segment sum + separable neighbourhood transform --------------------------
 // SC[b] += sum of the rows whose BMU is b (and their count): sort by BMU, chunked register sums
 int segsum_rows(som_handle* h, const float* X, const int* bmu, long N, const int* iota, int* skey, int* srow,
@@ -598,8 +620,7 @@ int segsum_rows(som_handle* h, const float* X, const int* bmu, long N, const int
     if (N > 0) {
         int bits = 1;
         while ((1L << bits) < h->K) ++bits;
-        hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, bmu, skey, iota, srow, (size_t)N, 0u, (unsigned)bits,
-                                                 h->stream);
+        hipError_t e = sort_bmu_pairs(N, tmp, tmp_bytes, bmu, skey, iota, srow, (size_t)N, 0u, (unsigned)bits, h->stream);
         if (e != hipSuccess) return fail_hip(h, "rocprim::radix_sort_pairs", e);
         long waves = cdiv(N, SEG_CHUNK);
         if ((h->D & 1) == 0)
@@ -894,8 +915,7 @@ static int adopt_rows(som_handle* h, int64_t n_rows) {
         if (int rc = dev_alloc(h, &h->srow, (size_t)n_rows)) return rc;
         iota_kernel<<<dim3((unsigned)cdiv(n_rows, 256)), dim3(256), 0, h->stream>>>(h->iota, n_rows);
         size_t bytes = 0;
-        hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, h->bmu, h->skey, h->iota, h->srow, (size_t)n_rows, 0u,
-                                                 32u, h->stream);
+        hipError_t e = sort_bmu_pairs_storage(bytes, h->bmu, h->skey, h->iota, h->srow, n_rows, 32u, h->stream);
         if (e != hipSuccess) return fail_hip(h, "rocprim::radix_sort_pairs(size query)", e);
         if (int rc = dev_alloc(h, (char**)&h->sort_tmp, bytes)) return rc;
         h->sort_tmp_bytes = bytes;
@@ -1077,8 +1097,7 @@ int som_stream_rows(som_handle* h, const float* x_host, int64_t n_rows) {
         if (int rc = dev_alloc(h, &h->st_srow, (size_t)cap)) return rc;
         iota_kernel<<<dim3((unsigned)cdiv(cap, 256)), dim3(256), 0, h->stream>>>(h->st_iota, cap);
         size_t bytes = 0;
-        hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, h->qbmu, h->st_skey, h->st_iota, h->st_srow, (size_t)cap,
-                                                 0u, 32u, h->stream);
+        hipError_t e = sort_bmu_pairs_storage(bytes, h->qbmu, h->st_skey, h->st_iota, h->st_srow, cap, 32u, h->stream);
         if (e != hipSuccess) return fail_hip(h, "rocprim::radix_sort_pairs(size query)", e);
         if (int rc = dev_alloc(h, (char**)&h->st_tmp, bytes)) return rc;
         h->st_tmp_bytes = bytes;
