@@ -111,7 +111,7 @@ def main():
     # one process per GPU; SOM_DIST_BACKEND=gloo lets several ranks rehearse the path on ONE GPU
     backend = os.environ.get("SOM_DIST_BACKEND", "nccl")
     dev = local % max(1, torch.cuda.device_count())
-    if world > 1:
+    if world > 1 or os.environ.get("SOM_FORCE_ALLREDUCE"):   # (the env var: a 1-rank group, to rehearse the collective path)
         import torch.distributed as dist
         torch.cuda.set_device(dev)
         if backend == "nccl":

@@ -123,6 +123,9 @@ int som_stream_end(som_handle* h, double sigma, double eta, int neigh_f64);
 /* device address and length (floats) of the fused accumulator, for an in-place
  * all-reduce by the host (RCCL via torch.distributed). */
 int som_accum_device_ptr(som_handle* h, void** dev_ptr, int64_t* n_floats);
+/* the HIP stream every launch of this handle goes to (som_config.stream, or the handle's own): lets the caller
+ * order foreign work -- e.g. the RCCL all-reduce of the accumulator -- on it instead of synchronising the host */
+int som_get_stream(som_handle* h, void** stream_out);
 /* teacher-forced parity: copy the last accumulate's results to the host.
  * Any pointer may be NULL.  num [K][D], den [K], bmu [n_rows] (raveled ids). */
 int som_epoch_fetch(som_handle* h, float* num, float* den, int32_t* bmu);

@@ -48,6 +48,7 @@ SIGNATURES = {
     "som_stream_rows": (C.c_int, [_H, _F, C.c_int64]),
     "som_stream_end": (C.c_int, [_H, C.c_double, C.c_double, C.c_int]),
     "som_accum_device_ptr": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "som_get_stream": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
     "som_epoch_fetch": (C.c_int, [_H, _F, _F, _I]),
     "som_epoch_accumulate_forced": (C.c_int, [_H, _I, C.c_double, C.c_double, C.c_int]),
     "som_bmu": (C.c_int, [_H, _F, C.c_int64, C.c_int32, _I]),

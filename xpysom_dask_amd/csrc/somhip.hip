@@ -1185,6 +1185,12 @@ int som_accum_device_ptr(som_handle* h, void** dev_ptr, int64_t* n_floats) {
     return 0;
 }
 
+int som_get_stream(som_handle* h, void** stream_out) {
+    if (!h || !stream_out) return fail(h, "som_get_stream: NULL argument");
+    *stream_out = (void*)h->stream;
+    return 0;
+}
+
 int som_epoch_fetch(som_handle* h, float* num, float* den, int32_t* bmu) {
     if (h) (void)hipSetDevice(h->cfg.device);
     if (!h) return 1;

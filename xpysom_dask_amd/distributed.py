@@ -33,8 +33,17 @@ def allreduce_accumulator(engine):
     if world == 1 and not os.environ.get("SOM_FORCE_ALLREDUCE"):   # (the env var lets a 1-GPU box exercise the path)
         return
     import torch.distributed as dist
-    engine.sync()                      # the engine may run on its own stream
     t = engine.accum_tensor()
+    if t.is_cuda and dist.get_backend() == "nccl":
+        # RCCL: stream-ordered, no host synchronisation.  The collective is issued with the engine's own
+        # stream current, so it starts after the accumulate kernels queued there, and the merge kernel
+        # queued next waits for it; the host runs ahead into the next epoch's launches.
+        import torch
+        ext = torch.cuda.ExternalStream(engine.stream_ptr(), device=t.device)
+        with torch.cuda.stream(ext):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return
+    engine.sync()                      # host-staged backends (gloo): the engine runs on its own stream
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     if t.is_cuda:
         import torch

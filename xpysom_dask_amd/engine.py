@@ -143,6 +143,12 @@ class HipEngine:
         self._check(self._lib.som_accum_device_ptr(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def stream_ptr(self):
+        """The HIP stream the engine launches on (an integer handle, for torch.cuda.ExternalStream)."""
+        p = C.c_void_p()
+        self._check(self._lib.som_get_stream(self._h, C.byref(p)))
+        return int(p.value or 0)
+
     def accum_tensor(self):
         """The fused [num|den] accumulator as a torch CUDA tensor aliasing the engine's
         HBM buffer (zero copy) -- what the RCCL all-reduce runs on in place."""
