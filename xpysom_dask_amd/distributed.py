@@ -39,10 +39,14 @@ def allreduce_accumulator(engine):
         # stream current, so it starts after the accumulate kernels queued there, and the merge kernel
         # queued next waits for it; the host runs ahead into the next epoch's launches.
         import torch
-        ext = torch.cuda.ExternalStream(engine.stream_ptr(), device=t.device)
-        with torch.cuda.stream(ext):
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        return
+        try:
+            ext = torch.cuda.ExternalStream(engine.stream_ptr(), device=t.device)
+        except Exception:              # no ExternalStream in this torch build: the synchronising form below
+            ext = None
+        if ext is not None:
+            with torch.cuda.stream(ext):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return
     engine.sync()                      # host-staged backends (gloo): the engine runs on its own stream
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     if t.is_cuda:
