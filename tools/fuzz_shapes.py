@@ -1,0 +1,53 @@
+"""Randomised shape fuzz of the C ABI against the oracle: map sides 1..40, 1..300 features, 1..3000 rows, every
+precision, euclidean and cosine.  BMUs must be the oracle's or near-best within the precision's bound; the
+accumulators must match the oracle's update from the engine's own BMUs to 1e-5."""
+import sys, time, numpy as np
+sys.path.insert(0, '.')
+from oracle import som_oracle as O
+from xpysom_dask_amd.engine import HipEngine
+
+F32 = np.float32
+rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+bad = 0
+t0 = time.time()
+for case in range(n_cases):
+    X, Y = int(rs.randint(1, 41)), int(rs.randint(1, 41))
+    D = int(rs.choice([1, 2, 3, 7, 16, 31, 32, 33, 64, 100, 128, 129, 130, 200, 257, 300]))
+    n = int(rs.choice([1, 2, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1000, 3000]))
+    prec = str(rs.choice(["f32", "bf16", "bf16x3"]))
+    dist = str(rs.choice(["euclidean", "cosine"]))
+    data = O.gaussian_blobs(n, D, seed=case)
+    w = O.default_codebook(X, Y, D, case + 1).astype(F32) * 3
+    if dist == "cosine":
+        data, w = np.abs(data), np.abs(w)
+    try:
+        e = HipEngine(X, Y, D, precision=prec, distance=dist)
+        e.set_weights(w); e.set_data(data)
+        sig, eta = max(min(X, Y) / 2, 1.0), 0.5
+        e.epoch_accumulate(sig, eta, True)
+        num, den, bmu = e.epoch_fetch()
+        q = e.bmu(data)
+        wf = w.reshape(-1, D)
+        x64, w64 = data.astype(np.float64), wf.astype(np.float64)
+        if dist == "euclidean":
+            # squared distances: the operand rounding perturbs x.w by eps |x||w|, i.e. d^2 by that much
+            dd = np.maximum((x64 ** 2).sum(1)[:, None] - 2 * x64 @ w64.T + (w64 ** 2).sum(1)[None, :], 0)
+            scale = (np.linalg.norm(x64, axis=1) + np.linalg.norm(w64, axis=1).max()) ** 2
+        else:
+            with np.errstate(all="ignore"):
+                dd = 1 - np.nan_to_num((x64 @ w64.T) / np.sqrt((x64 ** 2).sum(1)[:, None] * (w64 ** 2).sum(1)[None, :]))
+            scale = np.ones(n)
+        tol = {"f32": 2.0 ** -18, "bf16x3": 2.0 ** -14, "bf16": 2.0 ** -7}[prec]
+        ok_bmu = (dd[np.arange(n), bmu] <= dd.min(1) + tol * scale).all() and (dd[np.arange(n), q] <= dd.min(1) + tol * scale).all()
+        _, onum, oden = O.update(data, w, np.float64(eta), np.float64(sig), wide=True, forced_bmu=bmu, distance=dist)
+        en = np.abs(num - onum.reshape(-1, D)).max() / max(np.abs(onum).max(), 1e-30)
+        ed = np.abs(den - oden.reshape(-1)).max() / max(np.abs(oden).max(), 1e-30)
+        ok = ok_bmu and en < 1e-5 and ed < 1e-5 and (q != bmu).mean() <= 0.02
+    except Exception as ex:                      # noqa: BLE001
+        ok, en, ed = False, -1, -1
+        print("EXC", repr(ex)[:200])
+    if not ok:
+        bad += 1
+        print(f"FAIL case {case}: {X}x{Y}x{D} n={n} {prec} {dist} num {en:.2e} den {ed:.2e}", flush=True)
+print(f"{n_cases} cases, {bad} failures, {time.time()-t0:.1f} s")
