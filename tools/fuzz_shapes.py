@@ -1,5 +1,5 @@
 """Randomised shape fuzz of the C ABI against the oracle: map sides 1..40, 1..300 features, 1..3000 rows, every
-precision, euclidean and cosine.  BMUs must be the oracle's or near-best within the precision's bound; the
+precision, every distance / neighbourhood / topology the engine implements.  BMUs must be the oracle's or near-best within the precision's bound; the
 accumulators must match the oracle's update from the engine's own BMUs to 1e-5."""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
@@ -17,12 +17,19 @@ for case in range(n_cases):
     n = int(rs.choice([1, 2, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1000, 3000]))
     prec = str(rs.choice(["f32", "bf16", "bf16x3"]))
     dist = str(rs.choice(["euclidean", "cosine"]))
+    neigh = str(rs.choice(["gaussian", "gaussian", "mexican_hat", "bubble"]))   # (triangle: no oracle restatement)
+    topo = str(rs.choice(["rectangular", "rectangular", "hexagonal"]))
+    p_norm = 2
+    if prec == "f32" and rs.rand() < 0.3:                     # the VALU distances exist in f32 only
+        dist = str(rs.choice(["manhattan", "norm_p", "norm_p_no_opt", "euclidean_no_opt"]))
+        p_norm = int(rs.choice([1, 2, 3, 4]))
+        D = min(D, 64)
     data = O.gaussian_blobs(n, D, seed=case)
     w = O.default_codebook(X, Y, D, case + 1).astype(F32) * 3
     if dist == "cosine":
         data, w = np.abs(data), np.abs(w)
     try:
-        e = HipEngine(X, Y, D, precision=prec, distance=dist)
+        e = HipEngine(X, Y, D, precision=prec, distance=dist, neighborhood=neigh, topology=topo, norm_p=p_norm)
         e.set_weights(w); e.set_data(data)
         sig, eta = max(min(X, Y) / 2, 1.0), 0.5
         e.epoch_accumulate(sig, eta, True)
@@ -30,7 +37,11 @@ for case in range(n_cases):
         q = e.bmu(data)
         wf = w.reshape(-1, D)
         x64, w64 = data.astype(np.float64), wf.astype(np.float64)
-        if dist == "euclidean":
+        if dist in ("manhattan", "norm_p", "norm_p_no_opt"):
+            pp = 1 if dist == "manhattan" else p_norm
+            dd = (np.abs(x64[:, None, :] - w64[None, :, :]) ** pp).sum(-1)
+            scale = dd.max(1) + 1e-30
+        elif dist in ("euclidean", "euclidean_no_opt"):
             # squared distances: the operand rounding perturbs x.w by eps |x||w|, i.e. d^2 by that much
             dd = np.maximum((x64 ** 2).sum(1)[:, None] - 2 * x64 @ w64.T + (w64 ** 2).sum(1)[None, :], 0)
             scale = (np.linalg.norm(x64, axis=1) + np.linalg.norm(w64, axis=1).max()) ** 2
@@ -40,7 +51,8 @@ for case in range(n_cases):
             scale = np.ones(n)
         tol = {"f32": 2.0 ** -18, "bf16x3": 2.0 ** -14, "bf16": 2.0 ** -7}[prec]
         ok_bmu = (dd[np.arange(n), bmu] <= dd.min(1) + tol * scale).all() and (dd[np.arange(n), q] <= dd.min(1) + tol * scale).all()
-        _, onum, oden = O.update(data, w, np.float64(eta), np.float64(sig), wide=True, forced_bmu=bmu, distance=dist)
+        _, onum, oden = O.update(data, w, np.float64(eta), np.float64(sig), wide=True, forced_bmu=bmu,
+                                 neighbourhood=neigh + ("_hex" if topo == "hexagonal" else ""))
         en = np.abs(num - onum.reshape(-1, D)).max() / max(np.abs(onum).max(), 1e-30)
         ed = np.abs(den - oden.reshape(-1)).max() / max(np.abs(oden).max(), 1e-30)
         ok = ok_bmu and en < 1e-5 and ed < 1e-5 and (q != bmu).mean() <= 0.02
@@ -49,5 +61,5 @@ for case in range(n_cases):
         print("EXC", repr(ex)[:200])
     if not ok:
         bad += 1
-        print(f"FAIL case {case}: {X}x{Y}x{D} n={n} {prec} {dist} num {en:.2e} den {ed:.2e}", flush=True)
+        print(f"FAIL case {case}: {X}x{Y}x{D} n={n} {prec} {dist}(p={p_norm}) {neigh} {topo} num {en:.2e} den {ed:.2e} bmu_ok {ok_bmu if en >= 0 else None}", flush=True)
 print(f"{n_cases} cases, {bad} failures, {time.time()-t0:.1f} s")
