@@ -836,3 +836,22 @@ def test_train_accepts_device_resident_rows():
     np.testing.assert_allclose(c._weights, a._weights, rtol=2e-5, atol=1e-6)
     with pytest.raises(ValueError):
         XPySom(X, Y, D + 1, random_seed=5).train(t, 1)
+
+
+def test_cosine_resolves_short_rows_as_well_as_long_ones():
+    """Cosine does not depend on |x|, but the bf16 kernels compare B - x~.w^~ with B = max|x~| max|w~|: a short
+    row next to long ones would be resolved at B's absolute precision.  The row images therefore go in at
+    unit length (found by tools/fuzz_shapes.py: 19x4 map, 2 features, a row of norm 0.1 among norms up to 12)."""
+    X, Y, D, n = 19, 4, 2, 3000
+    data = np.abs(O.gaussian_blobs(n, D, seed=405))
+    data[::7] *= 1e-3                                          # rows four orders of magnitude shorter than the rest
+    w = np.abs(O.default_codebook(X, Y, D, 406).astype(F32) * 3)
+    x64, w64 = data.astype(np.float64), w.reshape(-1, D).astype(np.float64)
+    dd = 1 - (x64 @ w64.T) / np.sqrt((x64 ** 2).sum(1)[:, None] * (w64 ** 2).sum(1)[None, :])
+    for precision, tol in (("bf16x3", 2.0 ** -14), ("bf16", 2.0 ** -6)):
+        e = engine(X, Y, D, precision=precision, distance="cosine")
+        e.set_weights(w)
+        got = e.bmu(data)
+        gap = dd[np.arange(n), got] - dd.min(1)
+        assert gap.max() <= tol, (precision, gap.max())
+        assert gap[::7].max() <= tol

@@ -104,15 +104,23 @@ __global__ __launch_bounds__(256) void prep_wsqh_kernel(const float* __restrict_
 }
 
 // samples -> bf16 rows [Np][Dp] (zero padded) and max_n |x~_n|^2.  One wave per row.
+// unit != 0 (cosine): the row is scaled to unit length first (a zero row stays zero).
 __global__ __launch_bounds__(256) void prep_x_bf16_kernel(const float* __restrict__ X, long N, int D, int Dp,
                                                           long Np, __bf16* __restrict__ Xb,
-                                                          float* __restrict__ xmax2) {
+                                                          float* __restrict__ xmax2, int unit) {
     long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (row >= Np) return;
+    float scale = 1.0f;
+    if (unit) {
+        float q = 0.0f;
+        for (int k = lane; k < D; k += 64) { float f = row < N ? X[row * D + k] : 0.0f; q = __builtin_fmaf(f, f, q); }
+        q = wave_sum(q);
+        scale = q > 0.0f ? 1.0f / __builtin_sqrtf(q) : 0.0f;
+    }
     float s = 0.0f;
     for (int k = lane; k < Dp; k += 64) {
-        float f = (row < N && k < D) ? X[row * D + k] : 0.0f;
+        float f = (row < N && k < D) ? X[row * D + k] * scale : 0.0f;
         __bf16 b = (__bf16)f;
         Xb[row * Dp + k] = b;
         float fb = (float)b;

@@ -521,21 +521,31 @@ int launch_bmu_bf16(som_handle* h, const __bf16* Xb, const float* xmax2, long N,
     return fail(h, "bf16 precision supports input_len <= 128");
 }
 
-int prep_rows_bf16(som_handle* h, const float* X, long N, long Np, __bf16* Xb, float* xmax2) {
+// rows -> bf16 operand image (+ max |x~|^2 for the offset B).  Cosine: the rows go in at unit length -- the
+// argmin does not depend on |x|, and B = max|x~| max|w~| then resolves every row alike (a short row next to
+// long ones would otherwise be compared at B's absolute precision).  xsq_scratch: N floats, cosine + tiled only.
+int prep_rows_bf16(som_handle* h, const float* X, long N, long Np, __bf16* Xb, float* xmax2, float* xsq_scratch) {
     const int Dp = h->dp;
+    const bool unit = h->cfg.distance == SOM_DIST_COSINE;
     HIPCHK(h, hipMemsetAsync(xmax2, 0, sizeof(float), h->stream));
     if (h->tiled) {
+        const float* usq = nullptr;
+        if (unit && N > 0) {
+            if (!xsq_scratch) return fail(h, "prep_rows_bf16: no row-norm scratch");
+            row_sq_f32_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(X, N, h->D, xsq_scratch);
+            usq = xsq_scratch;
+        }
         long n_blocks = Np / h->tl_bm;
         long total = n_blocks * h->n_kchunks * (h->tl_bm / 16) * TL_KS * 64;
         prep_tiles_bf16_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
-            X, N, h->D, h->n_kchunks, n_blocks, h->tl_bm, h->tl_xtile, 1.0f, nullptr, (char*)Xb, h->x3 ? 1 : 0);
+            X, N, h->D, h->n_kchunks, n_blocks, h->tl_bm, h->tl_xtile, 1.0f, usq, (char*)Xb, h->x3 ? 1 : 0);
         if (N > 0)
-            rownorm_bf16_kernel<<<dim3((unsigned)cdiv(N, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, nullptr, 0, nullptr,
-                                                                                        xmax2, h->x3);
+            rownorm_bf16_kernel<<<dim3((unsigned)cdiv(N, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, usq, 0, nullptr, xmax2,
+                                                                                        h->x3);
         HIPCHK(h, hipGetLastError());
         return 0;
     }
-    prep_x_bf16_kernel<<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, Dp, Np, Xb, xmax2);
+    prep_x_bf16_kernel<<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, Dp, Np, Xb, xmax2, unit ? 1 : 0);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -920,13 +930,14 @@ static int adopt_rows(som_handle* h, int64_t n_rows) {
         if (int rc = dev_alloc(h, (char**)&h->sort_tmp, bytes)) return rc;
         h->sort_tmp_bytes = bytes;
     }
-    if (needs_xsq(h)) {
+    const bool bf_cos_tiled = h->cfg.precision != SOM_PREC_F32 && h->cfg.distance == SOM_DIST_COSINE && h->tiled;
+    if (needs_xsq(h) || bf_cos_tiled) {
         if (int rc = dev_alloc(h, &h->xsq, (size_t)n_rows)) return rc;
-        if (int rc = row_sq(h, h->Xd, n_rows, h->xsq)) return rc;
+        if (needs_xsq(h)) if (int rc = row_sq(h, h->Xd, n_rows, h->xsq)) return rc;
     }
     if (h->cfg.precision != SOM_PREC_F32 && n_rows > 0) {
         if (int rc = dev_alloc(h, &h->Xb, (size_t)h->Np * h->dp)) return rc;
-        if (int rc = prep_rows_bf16(h, h->Xd, n_rows, h->Np, h->Xb, h->xmax2)) return rc;
+        if (int rc = prep_rows_bf16(h, h->Xd, n_rows, h->Np, h->Xb, h->xmax2, h->xsq)) return rc;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
@@ -1120,7 +1131,7 @@ int som_stream_rows(som_handle* h, const float* x_host, int64_t n_rows) {
         HIPCHK(h, hipStreamWaitEvent(h->stream, sl.copied, 0));
         if (needs_xsq(h)) if (int rc = row_sq(h, sl.dX, n_rows, sl.dxsq)) return rc;
         if (h->cfg.precision != SOM_PREC_F32)
-            if (int rc = prep_rows_bf16(h, sl.dX, n_rows, round_up(n_rows, ROW_PAD), sl.dXb, h->xmax2 + 1)) return rc;
+            if (int rc = prep_rows_bf16(h, sl.dX, n_rows, round_up(n_rows, ROW_PAD), sl.dXb, h->xmax2 + 1, sl.dxsq)) return rc;
         if (int rc = run_activation_bmu(h, sl.dX, n_rows, sl.dxsq, sl.dXb, h->xmax2 + 1, sl.dbmu)) return rc;
         if (int rc = segsum_rows(h, sl.dX, sl.dbmu, n_rows, h->st_iota, h->st_skey, h->st_srow, h->st_tmp,
                                  h->st_tmp_bytes, false))
@@ -1133,7 +1144,7 @@ int som_stream_rows(som_handle* h, const float* x_host, int64_t n_rows) {
     HIPCHK(h, hipMemcpyAsync(h->qX, x_host, bytes, hipMemcpyHostToDevice, h->stream));
     if (needs_xsq(h)) if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
     if (h->cfg.precision != SOM_PREC_F32)
-        if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1)) return rc;
+        if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1, h->qxsq)) return rc;
     if (int rc = run_activation_bmu(h, h->qX, n_rows, h->qxsq, h->qXb, h->xmax2 + 1, h->qbmu)) return rc;
     if (int rc = segsum_rows(h, h->qX, h->qbmu, n_rows, h->st_iota, h->st_skey, h->st_srow, h->st_tmp, h->st_tmp_bytes,
                              false))
@@ -1214,7 +1225,7 @@ namespace {
 // MFMA path (the squared distance is monotone in it); the caller evaluates the distance itself exactly.
 int run_quantization_bmu(som_handle* h, long n_rows) {
     if (h->cfg.precision != SOM_PREC_F32 && h->cfg.distance == SOM_DIST_EUCLIDEAN) {
-        if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1)) return rc;
+        if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1, h->qxsq)) return rc;
         return run_activation_bmu(h, h->qX, n_rows, h->qxsq, h->qXb, h->xmax2 + 1, h->qbmu);
     }
     if (int rc = refresh_codebook_operands(h, true)) return rc;
@@ -1236,7 +1247,7 @@ int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, in
     } else {
         if (needs_xsq(h)) if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
         if (h->cfg.precision != SOM_PREC_F32)
-            if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1)) return rc;
+            if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1, h->qxsq)) return rc;
         if (int rc = run_activation_bmu(h, h->qX, n_rows, h->qxsq, h->qXb, h->xmax2 + 1, h->qbmu)) return rc;
     }
     HIPCHK(h, hipMemcpyAsync(ids_out, h->qbmu, (size_t)n_rows * sizeof(int), hipMemcpyDeviceToHost, h->stream));
