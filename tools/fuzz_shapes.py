@@ -26,6 +26,14 @@ for case in range(n_cases):
         D = min(D, 64)
     data = O.gaussian_blobs(n, D, seed=case)
     w = O.default_codebook(X, Y, D, case + 1).astype(F32) * 3
+    # magnitudes, zero rows, duplicated units
+    data = data * F32(rs.choice([1e-3, 1.0, 1.0, 1e3]))
+    w = w * F32(rs.choice([1e-2, 1.0, 1.0, 1e2]))
+    if n > 4 and rs.rand() < 0.3:
+        data[rs.randint(0, n, size=max(1, n // 50))] = 0
+    if X * Y > 3 and rs.rand() < 0.3:
+        wf0 = w.reshape(-1, D)
+        wf0[rs.randint(0, X * Y)] = wf0[rs.randint(0, X * Y)]
     if dist == "cosine":
         data, w = np.abs(data), np.abs(w)
     try:
