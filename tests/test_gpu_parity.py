@@ -841,7 +841,7 @@ def test_train_accepts_device_resident_rows():
 def test_cosine_resolves_short_rows_as_well_as_long_ones():
     """Cosine does not depend on |x|, but the bf16 kernels compare B - x~.w^~ with B = max|x~| max|w~|: a short
     row next to long ones would be resolved at B's absolute precision.  The row images therefore go in at
-    unit length (found by tools/fuzz_shapes.py: 19x4 map, 2 features, a row of norm 0.1 among norms up to 12)."""
+    unit length (found by tests/fuzz/fuzz_shapes.py: 19x4 map, 2 features, a row of norm 0.1 among norms up to 12)."""
     X, Y, D, n = 19, 4, 2, 3000
     data = np.abs(O.gaussian_blobs(n, D, seed=405))
     data[::7] *= 1e-3                                          # rows four orders of magnitude shorter than the rest
