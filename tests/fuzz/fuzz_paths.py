@@ -74,5 +74,12 @@ for case in range(n_cases):
         msgs.append("EXC " + repr(ex)[:200])
     if msgs:
         bad += 1
+        try:                                         # diagnostics: which engine disagrees with the oracle's BMUs?
+            ref = O.bmu_ids(data, w.reshape(-1, D))
+            e.epoch_accumulate(sig, eta, wide); again = e.epoch_fetch()[2]
+            msgs.append("[diag: first-epoch BMUs != oracle in %d rows, re-run != oracle in %d, blocks of 128 hit: %s]"
+                        % (int((bmu != ref).sum()), int((again != ref).sum()), sorted(set(np.flatnonzero(bmu != ref) // 128))[:16]))
+        except Exception as ex:                      # noqa: BLE001
+            msgs.append("[diag failed: %r]" % (ex,))
         print(f"FAIL case {case}: {X}x{Y}x{D} n={n} {prec} {neigh} {topo} sig={sig} wide={wide}: {'; '.join(msgs)}", flush=True)
 print(f"{n_cases} cases, {bad} failures, {time.time()-t0:.1f} s")

@@ -153,6 +153,23 @@ int dev_alloc(som_handle* h, T** p, size_t count) {
     return 0;
 }
 
+// Host -> device copy of caller-owned (usually pageable) memory.  Blocking on purpose: the runtime stages
+// pageable sources through its own pinned buffers, and nothing in the API orders the tail of that staging
+// against kernels queued next on a non-blocking stream, so the copy is complete before anything that reads
+// `dst` is launched.  (A wrong tail of the resident rows -- whole 128-row blocks of BMUs off, once, on a fresh
+// box -- is what an early read looks like.)  The stream is drained first: nothing of ours still touches dst.
+int h2d_blocking(som_handle* h, void* dst, const void* src, size_t bytes) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+// ... and results back to caller-owned memory, the same way: drain the stream, then a blocking copy.
+int d2h_blocking(som_handle* h, void* dst, const void* src, size_t bytes) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 inline long round_up(long a, long b) { return cdiv(a, b) * b; }
 constexpr long ROW_PAD = 3072;   // bf16 row images are padded to a multiple of every kernel's workgroup tile
@@ -896,7 +913,7 @@ void som_destroy(som_handle* h) {
 int som_set_weights(som_handle* h, const float* w_host) {
     if (h) (void)hipSetDevice(h->cfg.device);
     if (!h || !w_host) return fail(h, "som_set_weights: NULL argument");
-    HIPCHK(h, hipMemcpyAsync(h->W, w_host, (size_t)h->K * h->D * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (int rc = h2d_blocking(h, h->W, w_host, (size_t)h->K * h->D * sizeof(float))) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     mark_codebook_changed(h);
     return 0;
@@ -905,9 +922,7 @@ int som_set_weights(som_handle* h, const float* w_host) {
 int som_get_weights(som_handle* h, float* w_host) {
     if (h) (void)hipSetDevice(h->cfg.device);
     if (!h || !w_host) return fail(h, "som_get_weights: NULL argument");
-    HIPCHK(h, hipMemcpyAsync(w_host, h->W, (size_t)h->K * h->D * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return 0;
+    return d2h_blocking(h, w_host, h->W, (size_t)h->K * h->D * sizeof(float));
 }
 
 static int adopt_rows(som_handle* h, int64_t n_rows) {
@@ -950,8 +965,7 @@ int som_set_data(som_handle* h, const float* x_host, int64_t n_rows) {
     h->X_owned = nullptr; h->Xd = nullptr;
     if (int rc = dev_alloc(h, &h->X_owned, (size_t)n_rows * h->D)) return rc;
     if (n_rows > 0)
-        HIPCHK(h, hipMemcpyAsync(h->X_owned, x_host, (size_t)n_rows * h->D * sizeof(float), hipMemcpyHostToDevice,
-                                 h->stream));
+        if (int rc = h2d_blocking(h, h->X_owned, x_host, (size_t)n_rows * h->D * sizeof(float))) return rc;
     h->Xd = h->X_owned;
     return adopt_rows(h, n_rows);
 }
@@ -1052,7 +1066,7 @@ int som_epoch_accumulate_forced(som_handle* h, const int32_t* bmu_host, double s
     for (long i = 0; i < h->N; ++i)
         if (bmu_host[i] < 0 || bmu_host[i] >= h->K) return fail(h, "som_epoch_accumulate_forced: id out of range");
     if (h->N > 0)
-        HIPCHK(h, hipMemcpyAsync(h->bmu, bmu_host, (size_t)h->N * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        if (int rc = h2d_blocking(h, h->bmu, bmu_host, (size_t)h->N * sizeof(int))) return rc;
     return run_update(h, sigma, eta, neigh_f64);
 }
 
@@ -1141,7 +1155,7 @@ int som_stream_rows(som_handle* h, const float* x_host, int64_t n_rows) {
         return 0;
     }
     // pageable chunk: staged by the runtime, synchronous; the caller's buffer is free on return
-    HIPCHK(h, hipMemcpyAsync(h->qX, x_host, bytes, hipMemcpyHostToDevice, h->stream));
+    if (int rc = h2d_blocking(h, h->qX, x_host, bytes)) return rc;
     if (needs_xsq(h)) if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
     if (h->cfg.precision != SOM_PREC_F32)
         if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1, h->qxsq)) return rc;
@@ -1241,7 +1255,7 @@ int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, in
     if (mode != SOM_BMU_ACTIVATION && mode != SOM_BMU_QUANTIZATION) return fail(h, "som_bmu: unknown mode");
     if (n_rows == 0) return 0;
     if (int rc = ensure_query_scratch(h, n_rows)) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->qX, x_host, (size_t)n_rows * h->D * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (int rc = h2d_blocking(h, h->qX, x_host, (size_t)n_rows * h->D * sizeof(float))) return rc;
     if (mode == SOM_BMU_QUANTIZATION) {
         if (int rc = run_quantization_bmu(h, n_rows)) return rc;
     } else {
@@ -1250,9 +1264,7 @@ int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, in
             if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1, h->qxsq)) return rc;
         if (int rc = run_activation_bmu(h, h->qX, n_rows, h->qxsq, h->qXb, h->xmax2 + 1, h->qbmu)) return rc;
     }
-    HIPCHK(h, hipMemcpyAsync(ids_out, h->qbmu, (size_t)n_rows * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return 0;
+    return d2h_blocking(h, ids_out, h->qbmu, (size_t)n_rows * sizeof(int));
 }
 
 int som_bmu_top2(som_handle* h, const float* x_host, int64_t n_rows, int32_t* ids1_out, int32_t* ids2_out) {
@@ -1260,17 +1272,15 @@ int som_bmu_top2(som_handle* h, const float* x_host, int64_t n_rows, int32_t* id
     if (!h || n_rows < 0 || (n_rows > 0 && (!x_host || !ids1_out || !ids2_out))) return fail(h, "som_bmu_top2: bad argument");
     if (n_rows == 0) return 0;
     if (int rc = ensure_query_scratch(h, n_rows)) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->qX, x_host, (size_t)n_rows * h->D * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (int rc = h2d_blocking(h, h->qX, x_host, (size_t)n_rows * h->D * sizeof(float))) return rc;
     if (int rc = refresh_codebook_operands(h, true)) return rc;
     if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
     {
         Timed t(h, SOM_K_BMU);
         if (int rc = launch_bmu_top2(h, h->qX, n_rows, h->qxsq, h->qbmu, h->qbmu2)) return rc;
     }
-    HIPCHK(h, hipMemcpyAsync(ids1_out, h->qbmu, (size_t)n_rows * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(ids2_out, h->qbmu2, (size_t)n_rows * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return 0;
+    if (int rc = d2h_blocking(h, ids1_out, h->qbmu, (size_t)n_rows * sizeof(int))) return rc;
+    return d2h_blocking(h, ids2_out, h->qbmu2, (size_t)n_rows * sizeof(int));
 }
 
 int som_distance_matrix(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, float* dist_out) {
@@ -1282,7 +1292,7 @@ int som_distance_matrix(som_handle* h, const float* x_host, int64_t n_rows, int3
     if (n_rows == 0) return 0;
     if ((double)n_rows * h->K > 2.0e9) return fail(h, "som_distance_matrix: n_rows * K too large (analysis call, chunk it)");
     if (int rc = ensure_query_scratch(h, n_rows)) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->qX, x_host, (size_t)n_rows * h->D * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (int rc = h2d_blocking(h, h->qX, x_host, (size_t)n_rows * h->D * sizeof(float))) return rc;
     if (int rc = refresh_codebook_operands(h, true)) return rc;
     if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
     float* dm = nullptr;
@@ -1293,9 +1303,7 @@ int som_distance_matrix(som_handle* h, const float* x_host, int64_t n_rows, int3
     else if (h->cfg.distance == SOM_DIST_EUCLIDEAN_NO_OPT) rc = launch_dist_matrix<SCORE_EUCLID_SQ>(h, n_rows, dm);
     else rc = launch_dist_matrix<SCORE_COSINE>(h, n_rows, dm);
     if (!rc) {
-        hipError_t e = hipMemcpyAsync(dist_out, dm, (size_t)n_rows * h->K * sizeof(float), hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-        if (e != hipSuccess) rc = fail_hip(h, "som_distance_matrix copy", e);
+        rc = d2h_blocking(h, dist_out, dm, (size_t)n_rows * h->K * sizeof(float));
     }
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(dm);
@@ -1307,14 +1315,13 @@ int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, d
     if (!h || !qe_out || n_rows < 0 || (n_rows > 0 && !x_host)) return fail(h, "som_quantization_error: bad argument");
     if (n_rows == 0) { *qe_out = NAN; return 0; }     // numpy: mean of an empty array
     if (int rc = ensure_query_scratch(h, n_rows)) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->qX, x_host, (size_t)n_rows * h->D * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (int rc = h2d_blocking(h, h->qX, x_host, (size_t)n_rows * h->D * sizeof(float))) return rc;
     if (int rc = run_quantization_bmu(h, n_rows)) return rc;
     HIPCHK(h, hipMemsetAsync(h->dsum, 0, sizeof(double), h->stream));
     qe_kernel<<<dim3((unsigned)cdiv(n_rows, 4)), dim3(256), 0, h->stream>>>(h->qX, h->qbmu, h->W, n_rows, h->D, h->dsum);
     HIPCHK(h, hipGetLastError());
     double s = 0.0;
-    HIPCHK(h, hipMemcpyAsync(&s, h->dsum, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (int rc = d2h_blocking(h, &s, h->dsum, sizeof(double))) return rc;
     *qe_out = s / (double)n_rows;
     return 0;
 }
