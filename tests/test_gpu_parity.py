@@ -855,3 +855,26 @@ def test_cosine_resolves_short_rows_as_well_as_long_ones():
         gap = dd[np.arange(n), got] - dd.min(1)
         assert gap.max() <= tol, (precision, gap.max())
         assert gap[::7].max() <= tol
+
+
+def test_support_mask_at_a_sigma_one_ulp_off_an_integer():
+    """bubble / compact_support use the reference's mask literally -- n > c - sigma and n < c + sigma in float64
+    (neighborhoods.py:29-31, 105-110).  With sigma = 5 / (1 + 2/3) = 3.0000000000000004 (what the asymptotic
+    decay yields at t = 1 of 3) c - sigma rounds to an integer and the unit at distance exactly 3 is OUT, whereas
+    |n - c| < sigma would let it in (found by tests/fuzz/fuzz_train.py)."""
+    sigma = 5.0 / (1.0 + 1.0 / 1.5)
+    assert sigma > 3.0 and sigma - 3.0 < 1e-15
+    X, Y, D, n = 10, 24, 5, 300
+    data = O.gaussian_blobs(n, D, seed=12)
+    w = O.default_codebook(X, Y, D, 4).astype(F32)
+    for neigh, compact in (("bubble", False), ("gaussian", True), ("triangle", True)):
+        e = engine(X, Y, D, neighborhood=neigh, compact_support=compact)
+        e.set_weights(w)
+        e.set_data(data)
+        e.epoch_accumulate(sigma, 0.5, False)
+        num, den, bmu = e.epoch_fetch()
+        if neigh == "triangle":
+            continue                                           # (no oracle restatement; it shares neigh_box)
+        _, onum, oden = O.update(data, w, 0.5, sigma, wide=False, neighbourhood=neigh, compact=compact, forced_bmu=bmu)
+        assert rel_err(num, onum.reshape(-1, D)) < 1e-5, neigh
+        assert rel_err(den, oden.reshape(-1)) < 1e-5, neigh

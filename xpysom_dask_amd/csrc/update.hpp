@@ -133,18 +133,26 @@ __device__ __forceinline__ double neigh_exp(double delta2, const NeighParams& p)
     float a = -(float)delta2 / (float)p.d;
     return (double)(float)exp((double)a);
 }
-__device__ __forceinline__ double neigh_box(double dl, const NeighParams& p) {   // n > c - sigma  and  n < c + sigma
-    return (dl > -p.sigma && dl < p.sigma) ? 1.0 : 0.0;
+// the reference's support mask, literally: n > c - sigma  and  n < c + sigma  in float64 (neighborhoods.py:29-31,
+// 105-110).  c -/+ sigma is rounded before the compare, so a sigma within an ulp of an integer (asymptotic decay
+// produces them: 5 / (1 + 2/3) = 3.0000000000000004) decides the boundary unit differently than |n - c| < sigma.
+// (The hexagonal classes carry only the coordinate DIFFERENCE, half-unit shift included, so their mask compares
+// that: the generic functions' mask, neighborhoods.py:50-54, up to the rounding of c -/+ sigma.)
+__device__ __forceinline__ double neigh_box(double n, double c, double dl, const NeighParams& p) {
+    if (p.hex) return (dl > -p.sigma && dl < p.sigma) ? 1.0 : 0.0;
+    return (n > c - p.sigma && n < c + p.sigma) ? 1.0 : 0.0;
 }
 __device__ __forceinline__ double neigh_round(double v, const NeighParams& p) { return p.wide ? v : (double)(float)v; }
 
-// value of factor `which` (0 = row factor Px, 1 = column factor Py) of base term t at offset dl
-__device__ double neigh_factor(int which, int t, double dl, const NeighParams& p) {
+// value of factor `which` (0 = row factor Px, 1 = column factor Py) of base term t for unit coordinate n and
+// BMU coordinate c (`shift`: the hexagonal classes' half-unit offset, added to n - c)
+__device__ double neigh_factor(int which, int t, double n, double c, double shift, const NeighParams& p) {
+    const double dl = (n - c) + shift;
     const double d2 = dl * dl;
     switch (p.kind) {
     case 0: {   // gaussian
         double e = neigh_exp(d2, p);
-        if (p.compact) e *= neigh_box(dl, p);
+        if (p.compact) e *= neigh_box(n, c, dl, p);
         return e;
     }
     case 1: {   // mexican hat: (ex(1-2px/d)) * ey  -  ex * ((2py/d) ey)
@@ -154,11 +162,11 @@ __device__ double neigh_factor(int which, int t, double dl, const NeighParams& p
         return which == 0 ? -e : neigh_round(q * e, p);
     }
     case 2:     // bubble
-        return neigh_box(dl, p);
+        return neigh_box(n, c, dl, p);
     default: {  // triangle
         double v = p.sigma - fabs(dl);
         if (v < 0.0) v = 0.0;
-        if (p.compact) v *= neigh_box(dl, p);
+        if (p.compact) v *= neigh_box(n, c, dl, p);
         return neigh_round(v, p);
     }
     }
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(256) void neigh_tables_kernel(NeighParams p_val, co
         long r = id / p.Y;
         int j = r % p.Y;
         int t = r / p.Y;
-        double v = neigh_factor(1, t % p.base_nt, (double)(j - b), p);
+        double v = neigh_factor(1, t % p.base_nt, (double)j, (double)b, 0.0, p);
         if (p.hex) {                                   // class indicator on (s(j), s(cj))
             const int cls = t / p.base_nt;
             const int sj = ((p.Y - 1 - j) & 1) == 0, sb = ((p.Y - 1 - b) & 1) == 0;
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(256) void neigh_tables_kernel(NeighParams p_val, co
         int t = col / p.X, a = col % p.X;
         const int cls = t / p.base_nt;
         const double shift = !p.hex ? 0.0 : cls == 1 ? 0.5 : cls == 2 ? -0.5 : 0.0;
-        double v = neigh_factor(0, t % p.base_nt, (double)(i - a) + shift, p);
+        double v = neigh_factor(0, t % p.base_nt, (double)i, (double)a, shift, p);
         P2[q] = p.wide ? (float)(v * p.eta) : (float)v * (float)p.eta;
     }
 }
