@@ -22,6 +22,8 @@ for case in range(n_cases):
     dist = str(rs.choice(["euclidean", "euclidean", "cosine", "euclidean_no_opt"]))
     sigma = float(rs.choice([0, 1.5, 3.0])) or min(X, Y) / 2
     lr = float(rs.choice([0.5, 0.1, 1.0]))
+    compact = bool(neigh == "gaussian" and topo == "rectangular" and rs.rand() < 0.4)
+    std_coeff = float(rs.choice([0.5, 0.5, 0.25, 1.0]))
     T = int(rs.choice([1, 3, 10]))                 # schedule length; ONE epoch of it is run and compared
     t_at = int(rs.randint(0, T))
     data = O.gaussian_blobs(n, D, seed=case + 1000)
@@ -29,7 +31,7 @@ for case in range(n_cases):
         data = np.abs(data)
     try:
         som = XPySom(X, Y, D, sigma=sigma, learning_rate=lr, decay_function=decay, neighborhood_function=neigh,
-                     topology=topo, activation_distance=dist, random_seed=case)
+                     topology=topo, activation_distance=dist, random_seed=case, compact_support=compact, std_coeff=std_coeff)
         w0 = som._weights.copy()
         ids = som._upload_weights().bmu(data)               # the engine's BMUs from the initial codebook
         ref = O.bmu_ids(data, w0.astype(np.float32).reshape(-1, D), dist)
@@ -49,7 +51,7 @@ for case in range(n_cases):
         f = O.DECAYS[decay]
         sig_t, eta_t = f(sigma, 1, t_at, T), f(lr, 0.01, t_at, T)
         bmu, num, den, want = O.epoch(data, w0.astype(np.float32), eta_t, sig_t, wide=O.decay_is_wide(decay),
-                                      n_parallel=max(n, 1), distance=dist, forced_bmu=ids,
+                                      n_parallel=max(n, 1), distance=dist, forced_bmu=ids, compact=compact, std_coeff=std_coeff,
                                       neighbourhood=neigh + ("_hex" if topo == "hexagonal" else ""))
         # units whose denominator is far from the float32 underflow / cancellation zone (elsewhere
         # `den != 0` and num/den are decided by rounding noise in the reference itself)
@@ -65,5 +67,5 @@ for case in range(n_cases):
         print("EXC", repr(ex)[:300])
     if not ok:
         bad += 1
-        print(f"FAIL case {case}: {X}x{Y}x{D} n={n} {decay} {neigh} {topo} {dist} sigma={sigma} lr={lr}: w err {err:.2e} qe {qe:.6f} vs {oqe:.6f}", flush=True)
+        print(f"FAIL case {case}: {X}x{Y}x{D} n={n} {decay} {neigh} {topo} {dist} sigma={sigma} lr={lr} compact={compact} std={std_coeff}: w err {err:.2e} qe {qe:.6f} vs {oqe:.6f}", flush=True)
 print(f"{n_cases} cases, {bad} failures, {time.time()-t0:.1f} s")
