@@ -1,7 +1,7 @@
 """Randomised shape fuzz of the C ABI against the oracle: map sides 1..40, 1..300 features, 1..3000 rows, every
 precision, every distance / neighbourhood / topology the engine implements.  BMUs must be the oracle's or near-best within the precision's bound; the
 accumulators must match the oracle's update from the engine's own BMUs to 1e-5."""
-import sys, time, numpy as np
+import os, sys, time, numpy as np
 sys.path.insert(0, '.')
 from oracle import som_oracle as O
 from xpysom_dask_amd.engine import HipEngine
@@ -12,7 +12,8 @@ n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 bad = 0
 t0 = time.time()
 for case in range(n_cases):
-    X, Y = int(rs.randint(1, 41)), int(rs.randint(1, 41))
+    side = int(os.environ.get("FUZZ_MAXSIDE", "40"))      # > 64 reaches the 256 x 256 tiles of the tiled kernel (K >= 4096)
+    X, Y = int(rs.randint(1, side + 1)), int(rs.randint(1, side + 1))
     D = int(rs.choice([1, 2, 3, 7, 16, 31, 32, 33, 64, 100, 128, 129, 130, 200, 257, 300]))
     n = int(rs.choice([1, 2, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1000, 3000]))
     prec = str(rs.choice(["f32", "bf16", "bf16x3"]))
