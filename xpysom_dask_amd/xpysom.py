@@ -30,10 +30,9 @@ def _device_rows(data):
     a torch CUDA tensor, or any object with ``__cuda_array_interface__``, as a contiguous float32
     ``(n, input_len)`` block.  Returns ``(pointer, n_rows, n_cols, device_index, owner)`` or ``None``
     for host data."""
-    try:
+    torch = None
+    if type(data).__module__.split(".")[0] == "torch":   # (torch is imported only when a tensor is actually passed)
         import torch
-    except ImportError:
-        torch = None
     if torch is not None and isinstance(data, torch.Tensor):
         if not data.is_cuda:
             return None
