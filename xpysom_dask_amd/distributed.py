@@ -11,6 +11,9 @@ import os
 
 def dist_info():
     """(rank, world_size) of the default process group, or (0, 1) when there is none."""
+    import sys
+    if "torch" not in sys.modules:     # nobody imported torch, so no process group exists: do not pay for the import
+        return 0, 1
     try:
         import torch.distributed as dist
     except ImportError:
