@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
 """Headline benchmark: samples/sec/epoch of the batch-SOM hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
 
-Workload (BASELINE.json configs[2]/[3]): 256x256 map, 128 features, 1,048,576 synthetic
-Gaussian-blob rows PER GPU resident in HBM, bf16 MFMA distance GEMM, default schedule.
-A step = one full epoch over the resident rows: codebook prep, fused distance+BMU, segment
-sum, separable neighbourhood transform, (N > 1: one RCCL all-reduce of the fused
-numerator|denominator buffer), merge.  Weak scaling: rows per GPU are fixed.
+`--gpus N` (N > 1) needs no launcher: when no rank environment is present this process starts its own N rank
+processes (`python -m torch.distributed.run`, one per GPU) BEFORE it touches the GPU, relays their output and
+exits with their code.  Under an external launcher (the driver's `torch.distributed.run ... bench.py --gpus N`)
+it is a rank and reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
 
-One JSON line on rank 0: the driver's contract fields + `roofline` (dominant kernel = the
-fused distance+BMU kernel, MFMA-bound, hipEvent-timed inside the timed region) +
-`cpu_baseline` (the NumPy port of the reference path, timed on this host's cores, N = 1 only).
+Workload (BASELINE.json configs[2]/[3]): 256x256 map, 128 features, synthetic Gaussian-blob rows resident in HBM,
+bf16 MFMA distance GEMM, default schedule.  A step = one full epoch over the resident rows: codebook prep, fused
+distance+BMU, segment sum, separable neighbourhood transform, (N > 1: one RCCL all-reduce of the fused
+numerator|denominator buffer), merge.
+  --scaling weak   (default) 1,048,576 rows PER GPU: N = 1 is configs[2], N = 8 is configs[3] (8 Mi rows on 8 GPUs)
+  --scaling strong configs[3]'s 8,388,608 rows IN TOTAL split over the N ranks (N = 1 holds all of them)
+
+One JSON line on rank 0: the driver's contract fields + `roofline` (dominant kernel = the fused distance+BMU
+kernel, MFMA-bound, hipEvent-timed inside the timed region; `roofline.batch65536` = the same kernel at the
+north-star's batch of 65 536 rows, timed in the same process) + `cpu_baseline` (the NumPy port of the reference
+path, timed on this host's cores, N = 1 only).
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,27 +36,56 @@ sys.path.insert(0, REPO)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32
+STRONG_TOTAL_ROWS = 8 * (1 << 20)     # BASELINE configs[3]
+NORTH_STAR_BATCH = 65536
 
 # `c3` is the configuration BASELINE.json's metric is quoted on and the default; the other two put the
 # remaining GPU configs through the same harness (python bench.py --workload c5).
 WORKLOADS = {
     "c3": dict(map=(256, 256), features=128, rows=1 << 20, precision="bf16", distance="euclidean",
-               neighborhood="gaussian", cpu_rows=8192, label="BASELINE configs[2]/[3]", kernel="bmu_bf16_k16_kernel"),
+               neighborhood="gaussian", cpu_rows=8192, label="BASELINE configs[2]/[3]"),
     "c2": dict(map=(64, 64), features=32, rows=100000, precision="f32", distance="euclidean",
-               neighborhood="gaussian", cpu_rows=100000, label="BASELINE configs[1]", kernel="bmu_f32_res_kernel"),
+               neighborhood="gaussian", cpu_rows=100000, label="BASELINE configs[1]"),
     "c5": dict(map=(512, 512), features=784, rows=250000, precision="bf16", distance="cosine",
-               neighborhood="mexican_hat", cpu_rows=256, label="BASELINE configs[4], one GPU's shard of 2M rows",
-               kernel="bmu_bf16_tiled_kernel"),
+               neighborhood="mexican_hat", cpu_rows=256, label="BASELINE configs[4], one GPU's shard of 2M rows"),
 }
 
+
 def workload_rows(name, n, seed):
-    """Synthetic rows of SURVEY 8(d): Gaussian blobs; for c5 non-negative and L2-normalised (MNIST-like)."""
+    """Synthetic rows of SURVEY 8(d): Gaussian blobs; for c5 non-negative and L2-normalised (MNIST-like).
+    Generated a million rows at a time so that 8 Mi rows never hold a float64 copy of themselves."""
     from xpysom_dask_amd.synthetic import gaussian_blobs
-    x = gaussian_blobs(n, WORKLOADS[name]["features"], seed=seed)
-    if name == "c5":
-        x = np.abs(x)
-        x /= np.linalg.norm(x, axis=1, keepdims=True)
-    return x
+    d = WORKLOADS[name]["features"]
+    out = np.empty((n, d), dtype=np.float32)
+    step = 1 << 20
+    for i, lo in enumerate(range(0, n, step)):
+        hi = min(n, lo + step)
+        # chunk 0 of seed s is exactly gaussian_blobs(n, d, seed=s) for n <= 2^20 (the round-1 workload)
+        x = gaussian_blobs(hi - lo, d, seed=seed if i == 0 else seed + 7919 * i, centre_seed=1234)
+        if name == "c5":
+            x = np.abs(x)
+            x /= np.linalg.norm(x, axis=1, keepdims=True)
+        out[lo:hi] = x
+    return out
+
+
+def kernel_name_for(precision, features):
+    if precision == "f32":
+        return "bmu_f32_tiled_kernel" if features > 128 else "bmu_f32_res_kernel"
+    if precision == "bf16x3" or features > 128:
+        return "bmu_bf16_tiled_kernel"
+    return "bmu_bf16_k16_kernel"
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(name="c3"):
@@ -74,9 +112,46 @@ def cpu_baseline(name="c3"):
     t0 = time.perf_counter()
     O.epoch(data, w, eta, sig, wide=True, n_parallel=n_par, distance=wl["distance"], neighbourhood=wl["neighborhood"])
     dt = time.perf_counter() - t0
-    return {"value": rows / dt, "unit": "samples/sec/epoch", "cores": cores, "kind": "port",
+    return {"value": rows / dt, "unit": "samples/sec/epoch", "cores": cores, "cpu_model": cpu_model(),
+            "host_cpus": os.cpu_count(), "kind": "port",
             "sample": "%d rows of the same %dx%dx%d workload, 1 epoch, n_parallel=%d, NumPy+OpenBLAS, "
                       "float64 neighbourhood (exponential decay)" % (rows, MAP_X, MAP_Y, FEATURES, n_par)}
+
+
+def pmc_traffic(workload, rows, precision, kernel, build_hash):
+    """Fabric bytes per launch of the dominant kernel from committed `rocprofv3 --pmc` passes of this same
+    command (a process cannot profile itself): the newest profiles/*pmc_traffic*.json whose workload, rows per
+    launch and precision match, preferring one collected on THIS build (tools/traffic.sh writes them)."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_traffic*.json"))):
+        try:
+            with open(path) as f:
+                pm = json.load(f)
+            k = pm[kernel]
+            if pm.get("rows_per_launch") != rows or pm.get("workload", "c3") != workload \
+                    or pm.get("precision", "bf16") != precision:
+                continue
+            cand = {"bytes": k["fabric_bytes_corrected"], "file": os.path.basename(path), "build": pm.get("build")}
+        except Exception:
+            continue
+        if best is None or cand["build"] == build_hash or best["build"] != build_hash:
+            best = cand
+    return best
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as CHILD processes of a parent
+    that never touches the GPU (no exec from a GPU-initialised process), relay their output, return their code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes on this host driver)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -85,14 +160,21 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS), help="c3 = the metric's configuration (default)")
-    ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default: the workload's)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --rows per GPU (default); strong: --total-rows split over the ranks")
+    ap.add_argument("--rows", type=int, default=None, help="weak scaling: rows per GPU (default: the workload's)")
+    ap.add_argument("--total-rows", type=int, default=STRONG_TOTAL_ROWS, help="strong scaling: rows of the whole job")
     ap.add_argument("--precision", default=None, choices=["bf16", "f32", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch65536", action="store_true")
     args = ap.parse_args()
+
+    have_rank_env = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not have_rank_env:
+        raise SystemExit(self_launch(args))
+
     wl = WORKLOADS[args.workload]
     (MAP_X, MAP_Y), FEATURES = wl["map"], wl["features"]
-    if args.rows is None:
-        args.rows = wl["rows"]
     if args.precision is None:
         args.precision = wl["precision"]
 
@@ -100,9 +182,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
+    from xpysom_dask_amd import build as B
     from xpysom_dask_amd import distributed as D
     from xpysom_dask_amd.decays import exponential_decay
     from xpysom_dask_amd.engine import HipEngine
@@ -110,7 +192,11 @@ def main():
     dist = None
     # one process per GPU; SOM_DIST_BACKEND=gloo lets several ranks rehearse the path on ONE GPU
     backend = os.environ.get("SOM_DIST_BACKEND", "nccl")
-    dev = local % max(1, torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > max(1, ndev):
+        raise SystemExit("--gpus %d but this node shows %d GPU(s) (SOM_DIST_BACKEND=gloo rehearses ranks on one GPU)"
+                         % (world, ndev))
+    dev = local % max(1, ndev)
     if world > 1 or os.environ.get("SOM_FORCE_ALLREDUCE"):   # (the env var: a 1-rank group, to rehearse the collective path)
         import torch.distributed as dist
         torch.cuda.set_device(dev)
@@ -119,6 +205,13 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if args.scaling == "strong":
+        lo, hi = D.shard_bounds(args.total_rows, rank, world)
+        my_rows, total_rows = hi - lo, args.total_rows
+    else:
+        my_rows = args.rows if args.rows is not None else wl["rows"]
+        total_rows = my_rows * world
+
     eng = HipEngine(MAP_X, MAP_Y, FEATURES, precision=args.precision, device=dev, distance=wl["distance"],
                     neighborhood=wl["neighborhood"])
     rs = np.random.RandomState(1234)                  # default codebook init, xpysom.py:189-190
@@ -126,8 +219,10 @@ def main():
     w /= np.linalg.norm(w, axis=-1, keepdims=True)
     if args.workload == "c5":
         w = np.abs(w)
-    eng.set_weights(w.astype(np.float32))
-    eng.set_data(workload_rows(args.workload, args.rows, 1234 + rank))
+    w = w.astype(np.float32)
+    eng.set_weights(w)
+    rows_host = workload_rows(args.workload, my_rows, 1234 + rank)
+    eng.set_data(rows_host)
 
     total = args.warmup + args.steps
     sched = [(exponential_decay(min(MAP_X, MAP_Y) / 2, 1, t, total), exponential_decay(0.5, 0.01, t, total))
@@ -157,55 +252,73 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # HBM/fabric bytes of the dominant kernel come from separate rocprofv3 --pmc passes of this same
-    # command (a process cannot profile itself); the committed summary is quoted when the workload matches
-    traffic = None
-    try:
-        with open(os.path.join(REPO, "profiles", "r01_v2_pmc_traffic.json")) as f:
-            pm = json.load(f)
-        if pm.get("rows_per_launch") == args.rows and args.precision == "bf16" and args.workload == "c3":
-            traffic = pm["bmu_bf16_k16_kernel"]["fabric_bytes_corrected"]
-    except Exception:
-        traffic = None
-
     bmu_ms, bmu_n = eng.profile_get("bmu")
     parts = {k: eng.profile_get(k)[0] / max(1, args.steps) for k in ("prep", "bmu", "segsum", "kron", "merge")}
     w_end = eng.get_weights()
     assert np.isfinite(w_end).all()
 
+    kernel_name = kernel_name_for(args.precision, FEATURES)
+    peak = MFMA_F32_PEAK_TFLOPS if args.precision == "f32" else MFMA_BF16_PEAK_TFLOPS
+    KD2 = 2.0 * (MAP_X * MAP_Y) * FEATURES            # 2*K*D flop per sample
+
+    # the north-star's launch: the same kernel over a batch of 65 536 resident rows, same process, same engine
+    batch = None
+    if rank == 0 and world == 1 and not args.no_batch65536 and my_rows >= NORTH_STAR_BATCH:
+        eng.set_weights(w)
+        eng.set_data(rows_host[:NORTH_STAR_BATCH])
+        reps = 30
+        for t in range(3):
+            D.epoch(eng, sched[0][0], sched[0][1], True)
+        eng.sync()
+        eng.profile_reset()
+        eng.profile_enable(True)
+        tb = time.perf_counter()
+        for t in range(reps):
+            D.epoch(eng, sched[t % total][0], sched[t % total][1], True)
+        eng.sync()
+        tb = time.perf_counter() - tb
+        eng.profile_enable(False)
+        b_ms, b_n = eng.profile_get("bmu")
+        b_avg = b_ms / max(1, b_n)
+        b_ach = KD2 * NORTH_STAR_BATCH / (b_avg * 1e-3) / 1e12
+        batch = {"rows": NORTH_STAR_BATCH, "avg_launch_ms": b_avg, "launches": b_n, "achieved": b_ach,
+                 "frac": b_ach / peak, "epoch_ms": 1e3 * tb / reps,
+                 "ms_per_epoch_by_kernel": {k: eng.profile_get(k)[0] / reps for k in ("prep", "bmu", "segsum", "kron", "merge")}}
+
     if rank == 0:
         ms_step = 1e3 * dt / args.steps
-        flops_launch = 2.0 * args.rows * (MAP_X * MAP_Y) * FEATURES      # 2*K*D per sample
+        flops_launch = KD2 * my_rows
         achieved = flops_launch / (bmu_ms / max(1, bmu_n) * 1e-3) / 1e12
         # algorithmic flops against the peak of the pipe the kernel runs on; bf16x3 executes 3x them
-        peak = MFMA_F32_PEAK_TFLOPS if args.precision == "f32" else MFMA_BF16_PEAK_TFLOPS
-        kernel_name = wl["kernel"]
-        if args.precision == "f32" and FEATURES > 128:
-            kernel_name = "bmu_f32_tiled_kernel"
-        elif args.precision == "f32":
-            kernel_name = "bmu_f32_res_kernel"
-        elif args.precision == "bf16x3" or FEATURES > 128:
-            kernel_name = "bmu_bf16_tiled_kernel"
-        else:
-            kernel_name = "bmu_bf16_k16_kernel"
+        build_hash = B.built_hash()
+        tr = pmc_traffic(args.workload, my_rows, args.precision, kernel_name, build_hash)
         out = {
-            "metric": "samples/sec/epoch", "value": world * args.rows / (dt / args.steps), "unit": "samples/sec/epoch",
+            "metric": "samples/sec/epoch", "value": total_rows / (dt / args.steps), "unit": "samples/sec/epoch",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if args.precision == "f32" else "bf16", "data": "synthetic",
-            "config": {"workload": "batch-SOM epoch, %dx%d map, %d features, %d Gaussian-blob rows per GPU resident "
+            "config": {"workload": "batch-SOM epoch, %dx%d map, %d features, %d Gaussian-blob rows %s resident "
                                    "in HBM (%s), one launch over all resident rows"
-                                   % (MAP_X, MAP_Y, FEATURES, args.rows, wl["label"]),
-                       "map": [MAP_X, MAP_Y], "features": FEATURES, "rows_per_gpu": args.rows,
+                                   % (MAP_X, MAP_Y, FEATURES, my_rows if args.scaling == "weak" else total_rows,
+                                      "per GPU" if args.scaling == "weak" else "in total (split over the GPUs)",
+                                      wl["label"] if args.scaling == "weak" else "BASELINE configs[3] rows, strong scaling"),
+                       "map": [MAP_X, MAP_Y], "features": FEATURES, "rows_per_gpu": my_rows, "rows_total": total_rows,
                        "precision": args.precision, "distance": wl["distance"], "neighborhood": wl["neighborhood"],
+                       "update": "bucketed (segment sum by BMU + separable neighbourhood transform; exact algebra of "
+                                 "the reference's g^T.x GEMM, xpysom.py:434-438)",
                        "parallelism": "dp%d (sample shards, 1 all-reduce/epoch)" % world,
-                       "epochs_per_sec": args.steps / dt},
+                       "epochs_per_sec": args.steps / dt, "build": build_hash},
             "roofline": {"bound": "mfma", "kernel": kernel_name + " (fused distance GEMM + argmin)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "avg_launch_ms": bmu_ms / max(1, bmu_n), "launches": bmu_n,
+                         "traffic": tr["bytes"] if tr else None,
+                         "traffic_source": ({"file": "profiles/" + tr["file"], "build": tr["build"],
+                                             "same_build": tr["build"] == build_hash} if tr else None),
+                         "avg_launch_ms": bmu_ms / max(1, bmu_n), "launches": bmu_n,
                          "flops_per_launch": flops_launch},
             "ms_per_step_by_kernel": parts,
         }
+        if batch is not None:
+            out["roofline"]["batch65536"] = batch
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)

@@ -88,6 +88,14 @@ int som_get_weights(som_handle* h, float* w_host);
  * must outlive the handle's use of them). */
 int som_set_data(som_handle* h, const float* x_host, int64_t n_rows);
 int som_set_data_device(som_handle* h, const void* x_dev, int64_t n_rows);
+/* ... whose producer may still be running: wait for it first.  `stream` is the producer's stream as the
+ * __cuda_array_interface__ protocol names it (1 = legacy default, 2 = per-thread default, otherwise a
+ * hipStream_t); has_stream == 0 = unknown producer, wait for the whole device.  (The reference's CuPy arrays
+ * share CuPy's current stream with the kernels that read them, xpysom.py:487-510; here the engine owns a stream.) */
+int som_sync_producer(som_handle* h, uint64_t stream, int32_t has_stream);
+/* device rows of the caller copied to host memory (quantization_error(data) after train(device_rows, verbose=True),
+ * xpysom.py:589-592 on a CuPy array) */
+int som_copy_to_host(som_handle* h, const void* x_dev, uint64_t bytes, void* dst_host);
 
 /* One epoch over the resident rows = the body of the epoch loop, xpysom.py:515-577:
  *   som_epoch_accumulate: w_sq cache (:529-537), every _update (:560-569 -> :420-443:

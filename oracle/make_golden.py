@@ -332,8 +332,125 @@ def g10():
     save("g10_hexagonal", **out)
 
 
+# ---------------------------------------------------------------- G11 bubble / triangle on the rectangular topology
+def g11():
+    """neighborhoods.py:99-130 pinned directly (round 1 had bubble only through the hexagonal set and triangle
+    through an in-test formula): raw tensors for every centre, then one _update per neighbourhood."""
+    out = {}
+    for (X, Y) in ((5, 5), (3, 4)):
+        ci, cj = np.divmod(np.arange(X * Y), Y)
+        c = (ci.astype(np.int64), cj.astype(np.int64))
+        ni, nj = np.arange(X), np.arange(Y)
+        # 2.0 and 3.0000000000000004 (= 5 / (1 + 2/3), an asymptotic-decay value): the open box's edge cases
+        for sig in (0.3, 1.0, 2.0, 2.5, 3.0000000000000004):
+            for wide in (False, True):
+                s = np.float64(sig) if wide else float(sig)
+                key = f"{X}x{Y}_s{sig!r}_{'f64' if wide else 'f32'}"
+                out["bubble_" + key] = rneigh.bubble(ni, nj, c, s, xp=np)
+                out["tri_" + key + "_nc"] = rneigh.triangle(ni, nj, False, c, s, xp=np)
+                out["tri_" + key + "_cs"] = rneigh.triangle(ni, nj, True, c, s, xp=np)
+    for (X, Y, D, n) in ((8, 8, 3, 500), (5, 7, 4, 300)):
+        data = gaussian_blobs(n, D, seed=400 + X)
+        for neigh, compact in (("bubble", False), ("triangle", False), ("triangle", True)):
+            for decay in ("linear", "exponential", "asymptotic"):
+                som = RefSom(X, Y, D, random_seed=21, decay_function=decay, n_parallel=n,
+                             neighborhood_function=neigh, compact_support=compact, xp=np)
+                w0 = som._weights.astype(F32)
+                t, T = 1, 6
+                eta = som._decay_function(som._learning_rate, som._learning_rateN, t, T)
+                sig = som._decay_function(som._sigma, som._sigmaN, t, T)
+                wins = som._winner(data, w0)
+                num, den = som._update(data, w0, eta, sig)
+                key = f"{X}x{Y}x{D}_{neigh}{'_cs' if compact else ''}_{decay}"
+                out[key + "_bmu"] = (wins[0] * Y + wins[1]).astype(np.int32)
+                out[key + "_num"] = num.astype(F32)
+                out[key + "_den"] = den.astype(F32)
+                out[key + "_numdtype"] = np.array(str(num.dtype))
+                out[key + "_eta"] = np.float64(eta)
+                out[key + "_sig"] = np.float64(sig)
+                e = RefSom(X, Y, D, random_seed=21, decay_function=decay, n_parallel=n,
+                           neighborhood_function=neigh, compact_support=compact, xp=np)
+                with np.errstate(all="ignore"):
+                    e.train(data, T, iter_beg=t, iter_end=t + 1)
+                out[key + "_wout"] = e._weights.astype(F32)
+    save("g11_bubble_triangle", **out)
+
+
+# ---------------------------------------------------------------- G12 the configs[1] map: 64x64x32, one _update of 4096 rows
+def g12():
+    """SURVEY 8(c) G4 lists (64,64,32,4096); kept small: the inputs are seeds (default codebook + blobs), the
+    outputs are the full BMU / denominator vectors and every 16th unit's numerator / merged row."""
+    X, Y, D, n, T = 64, 64, 32, 4096, 10
+    data = gaussian_blobs(n, D, seed=164)
+    out = {"shape": np.array([X, Y, D, n]), "data_seed": np.array(164), "T": np.array(T), "stride": np.array(16)}
+    for decay in ("linear", "exponential"):
+        som = RefSom(X, Y, D, random_seed=1234, decay_function=decay, n_parallel=n, xp=np)
+        w0 = som._weights.astype(F32)
+        # a mid-training state of the reference itself (5 epochs), stored for the exponential schedule only
+        states = [("init", w0, 0)]
+        if decay == "exponential":
+            mid = RefSom(X, Y, D, random_seed=1234, decay_function=decay, n_parallel=n, xp=np)
+            mid.train(data, T, iter_beg=0, iter_end=T // 2)
+            wmid = mid._weights.astype(F32)
+            out["exponential_wmid"] = wmid
+            states.append(("mid", wmid, T // 2))
+        for tag, w, t in states:
+            eta = som._decay_function(som._learning_rate, som._learning_rateN, t, T)
+            sig = som._decay_function(som._sigma, som._sigmaN, t, T)
+            som._sq_weights_gpu = np.power(w.reshape(-1, D), 2).sum(axis=1, keepdims=True)
+            num, den = som._update(data, w, eta, sig)
+            som._sq_weights_gpu = None
+            wins = som._winner(data, w)
+            e = RefSom(X, Y, D, random_seed=1234, decay_function=decay, n_parallel=n, xp=np)
+            e._weights = w.copy()
+            with np.errstate(all="ignore"):
+                e.train(data, T, iter_beg=t, iter_end=t + 1)
+            key = f"{decay}_{tag}"
+            out[key + "_bmu"] = (wins[0] * Y + wins[1]).astype(np.int32)
+            out[key + "_den"] = den.astype(F32)
+            out[key + "_num16"] = num.astype(F32).reshape(X * Y, D)[::16]
+            out[key + "_wout16"] = e._weights.astype(F32).reshape(X * Y, D)[::16]
+            out[key + "_eta"] = np.float64(eta)
+            out[key + "_sig"] = np.float64(sig)
+    save("g12_update_64x64x32", **out)
+
+
+# ---------------------------------------------------------------- G13 topographic error on the hexagonal topology
+def g13():
+    """xpysom.py:739-746 as the reference evaluates it (it indexes the (Y, X) meshgrids with (i, j), so the map
+    must be square for the call to be well defined): best-2 units and the error, trained hexagonal maps."""
+    out = {}
+    for (X, D, n) in ((5, 3, 300), (12, 6, 1500)):
+        data = gaussian_blobs(n, D, seed=500 + X)
+        som = RefSom(X, X, D, random_seed=8, decay_function="linear", topology="hexagonal", xp=np)
+        som.train(data, 6)
+        probe = gaussian_blobs(400, D, seed=501 + X)
+        key = f"{X}x{X}x{D}"
+        out[key + "_w"] = som._weights.astype(F32)
+        out[key + "_top2"] = np.argsort(som._distance_from_weights(probe.astype(F32), som._weights), axis=1)[:, :2].astype(np.int32)
+        out[key + "_te"] = np.float64(som.topographic_error(probe))
+        out[key + "_te_train"] = np.float64(som.topographic_error(data))
+        out[key + "_seeds"] = np.array([500 + X, 501 + X])
+    save("g13_hex_topographic", **out)
+
+
+# ---------------------------------------------------------------- G14 distance_map (U-matrix), both topologies
+def g14():
+    out = {}
+    for topo in ("rectangular", "hexagonal"):
+        for (X, Y, D) in ((7, 6, 3), (4, 9, 5), (1, 5, 2)):
+            som = RefSom(X, Y, D, random_seed=31, topology=topo, xp=np)
+            out[f"{topo}_{X}x{Y}x{D}"] = som.distance_map()
+    save("g14_distance_map", **out)
+
+
+FAMILIES = {"g1": g1, "g2": g2, "g3": g3, "g4": g4_g5_g7, "g6": g6, "g8": g8, "g9": g9, "g10": g10, "g11": g11,
+            "g12": g12, "g13": g13, "g14": g14}
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     with contextlib.redirect_stdout(io.StringIO()) as _:
         pass
-    g1(); g2(); g3(); g4_g5_g7(); g6(); g8(); g9(); g10()
+    # `make_golden.py g11 g12` regenerates only the named families (the others stay byte-identical in history)
+    for name in (sys.argv[1:] or list(FAMILIES)):
+        FAMILIES[name]()

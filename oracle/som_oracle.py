@@ -211,6 +211,23 @@ def neigh_bubble(X, Y, std_coeff, compact, ci, cj, sigma, wide):
     return (_support(ni, ci, sigma)[:, :, None] * _support(nj, cj, sigma)[:, None, :]).astype(F32)
 
 
+def neigh_triangle(X, Y, std_coeff, compact, ci, cj, sigma, wide):
+    """neighborhoods.py:114-130: (sigma - |di|)+ * (sigma - |dj|)+, optionally masked to the open box.
+    ``-abs(int64) + sigma`` is float64 for a Python-float sigma and for a numpy.float64 one alike, so the
+    result is float64 whatever ``wide`` says (and so are g, num and den of the update that uses it)."""
+    ni, nj = np.arange(X)[None, :], np.arange(Y)[None, :]
+    ci, cj = np.asarray(ci)[:, None], np.asarray(cj)[:, None]
+    sigma = F64(sigma) if wide else float(sigma)
+    tx = (-np.abs(ci - ni)) + sigma
+    ty = (-np.abs(cj - nj)) + sigma
+    tx[tx < 0] = 0.
+    ty[ty < 0] = 0.
+    if compact:
+        tx *= _support(ni, ci, sigma)
+        ty *= _support(nj, cj, sigma)
+    return tx[:, :, None] * ty[:, None, :]
+
+
 def hex_coords(X, Y):
     """Euclidean unit coordinates of the hexagonal topology (xpysom.py:201-206):
     meshgrid (shape (Y, X)), every second row counted from the LAST one shifted by -0.5."""
@@ -256,6 +273,7 @@ NEIGHBOURHOODS = {
     "gaussian": neigh_gaussian,
     "mexican_hat": neigh_mexican_hat,
     "bubble": neigh_bubble,
+    "triangle": neigh_triangle,
     "gaussian_hex": neigh_gaussian_hex,          # topology='hexagonal' registry, xpysom.py:271-279
     "mexican_hat_hex": neigh_mexican_hat_hex,
     "bubble_hex": neigh_bubble,
@@ -364,13 +382,19 @@ def top2_ids(x32, W3):
     return np.argsort(d, axis=1)[:, :2]
 
 
-def topographic_error(data, W3):
-    """xpysom.py:709-746, rectangular branch: share of samples whose two best units are not
-    adjacent (|di| > 1 or |dj| > 1)."""
-    Y = W3.shape[1]
+def topographic_error(data, W3, topology="rectangular"):
+    """xpysom.py:709-746: share of samples whose two best units are not adjacent -- rectangular: |di| > 1 or
+    |dj| > 1; hexagonal (:739-746): farther apart than 1.5 in the coordinates ``_xx[i, j], _yy[i, j]``.  The
+    reference indexes its UNtransposed (Y, X) meshgrids with the map index (i, j), i.e. it reads
+    ``x = j - s(i)/2, y = i`` (s: the shifted rows of xpysom.py:201-206); only square maps are well defined."""
+    X, Y = W3.shape[:2]
     b = top2_ids(np.array(data, dtype=F32), np.asarray(W3))
-    di = np.abs(b[:, 0] // Y - b[:, 1] // Y)
-    dj = np.abs(b[:, 0] % Y - b[:, 1] % Y)
+    i, j = b // Y, b % Y
+    if topology == "hexagonal":
+        xx, yy = hex_coords(X, Y)
+        dx, dy = np.diff(xx[i, j]), np.diff(yy[i, j])
+        return (np.linalg.norm(np.hstack([dx, dy]), axis=1) > 1.5).mean().item()
+    di, dj = np.abs(i[:, 0] - i[:, 1]), np.abs(j[:, 0] - j[:, 1])
     return ((di > 1) | (dj > 1)).mean().item()
 
 

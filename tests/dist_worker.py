@@ -1,0 +1,71 @@
+"""One rank of the N > 1 GPU tests (tests/test_gpu_distributed.py): launched by torch.distributed.run,
+trains through the PRODUCT path (XPySom -> HipEngine -> libsomhip) and saves what the test compares.
+
+    dist_worker.py <backend> <out_dir> <mode>     mode: full | sharded | stream | bf16
+"""
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main():
+    backend, out_dir, mode = sys.argv[1], sys.argv[2], sys.argv[3]
+    rank, world, local = (int(os.environ[k]) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"))
+    import torch
+    import torch.distributed as dist
+    from oracle import som_oracle as O                       # (seeded test data only)
+    from xpysom_dask_amd import XPySom
+    from xpysom_dask_amd import distributed as D
+    # gloo: every rank shares GPU 0 (a one-GPU box rehearses the N > 1 path); nccl (= RCCL): one GPU per rank
+    dev = local if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group(backend)
+    try:
+        assert D.dist_info() == (rank, world)
+        prec = "bf16" if mode == "bf16" else "f32"
+        sharded = mode in ("sharded", "stream")
+
+        def feed(som, data, T, **kw):
+            lo, hi = D.shard_bounds(len(data), rank, world)
+            if mode in ("full", "bf16"):
+                som.train(data, T, **kw)                      # every rank passes all rows and keeps its slice
+            elif mode == "sharded":
+                som.train(data[lo:hi], T, **kw)
+            else:                                             # streamed epochs: this rank's rows in three chunks
+                mine = data[lo:hi]
+                cuts = [0, len(mine) // 3, len(mine) // 2, len(mine)]
+                som.train_streaming(lambda: (mine[a:b] for a, b in zip(cuts[:-1], cuts[1:])), T, **kw)
+
+        # (a) a small well-conditioned run end to end (SURVEY 7 hard part 1: only such runs are stable over epochs)
+        small = O.gaussian_blobs(601, 5, seed=11)
+        som = XPySom(7, 6, 5, random_seed=3, decay_function="linear", device=dev, precision=prec, sharded_input=sharded)
+        feed(som, small, 6)
+        np.save(os.path.join(out_dir, "ws_%s_%d.npy" % (mode, rank)), som._weights)
+        # (b) one teacher-forced epoch (iteration 2 of 5) of a mid-size map from the seeded codebook
+        X, Y, Dm, n, T = 24, 20, 16, 6001, 5
+        data = O.gaussian_blobs(n, Dm, seed=11)
+        som = XPySom(X, Y, Dm, random_seed=3, decay_function="linear", device=dev, precision=prec, sharded_input=sharded)
+        feed(som, data, T, iter_beg=2, iter_end=3)
+        np.save(os.path.join(out_dir, "w_%s_%d.npy" % (mode, rank)), som._weights)
+        lo, hi = D.shard_bounds(n, rank, world)
+        # the collective really summed over the ranks: one more accumulate + all-reduce, fetched raw
+        eng = som._engine()
+        eng.set_data(data[lo:hi])
+        eng.epoch_accumulate(2.0, 0.3, False)
+        D.allreduce_accumulator(eng)
+        num, den, _ = eng.epoch_fetch(want_bmu=False)
+        np.save(os.path.join(out_dir, "den_%s_%d.npy" % (mode, rank)), den)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,8 +18,10 @@ for case in range(n_cases):
     n = int(rs.choice([1, 2, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1000, 3000]))
     prec = str(rs.choice(["f32", "bf16", "bf16x3"]))
     dist = str(rs.choice(["euclidean", "cosine"]))
-    neigh = str(rs.choice(["gaussian", "gaussian", "mexican_hat", "bubble"]))   # (triangle: no oracle restatement)
+    neigh = str(rs.choice(["gaussian", "gaussian", "mexican_hat", "bubble", "triangle"]))
     topo = str(rs.choice(["rectangular", "rectangular", "hexagonal"]))
+    if neigh == "triangle":
+        topo = "rectangular"                                  # (the hexagonal registry has no triangle, xpysom.py:271-279)
     p_norm = 2
     if prec == "f32" and rs.rand() < 0.3:                     # the VALU distances exist in f32 only
         dist = str(rs.choice(["manhattan", "norm_p", "norm_p_no_opt", "euclidean_no_opt"]))

@@ -17,12 +17,12 @@ for case in range(n_cases):
     D = int(rs.choice([1, 2, 3, 8, 17, 32, 64, 129, 200]))
     n = int(rs.choice([5, 64, 257, 1000, 2500]))
     decay = str(rs.choice(["linear", "exponential", "asymptotic"]))
-    neigh = str(rs.choice(["gaussian", "mexican_hat", "bubble"]))
-    topo = str(rs.choice(["rectangular", "hexagonal"]))
+    neigh = str(rs.choice(["gaussian", "mexican_hat", "bubble", "triangle"]))
+    topo = "rectangular" if neigh == "triangle" else str(rs.choice(["rectangular", "hexagonal"]))
     dist = str(rs.choice(["euclidean", "euclidean", "cosine", "euclidean_no_opt"]))
     sigma = float(rs.choice([0, 1.5, 3.0])) or min(X, Y) / 2
     lr = float(rs.choice([0.5, 0.1, 1.0]))
-    compact = bool(neigh == "gaussian" and topo == "rectangular" and rs.rand() < 0.4)
+    compact = bool(neigh in ("gaussian", "triangle") and topo == "rectangular" and rs.rand() < 0.4)
     std_coeff = float(rs.choice([0.5, 0.5, 0.25, 1.0]))
     T = int(rs.choice([1, 3, 10]))                 # schedule length; ONE epoch of it is run and compared
     t_at = int(rs.randint(0, T))

@@ -8,7 +8,7 @@ from oracle import som_oracle as O
 
 class OracleEngine:
     def __init__(self, x, y, input_len, *, distance="euclidean", neighborhood="gaussian",
-                 std_coeff=0.5, compact_support=False, precision="f32", topology="rectangular", norm_p=0):
+                 std_coeff=0.5, compact_support=False, precision="f32", topology="rectangular", norm_p=0, device=0):
         self.x, self.y, self.D = x, y, input_len
         self.K = x * y
         if topology == "hexagonal":

@@ -25,12 +25,13 @@ def _worker(rank, world, port, sharded_input, out_dir):
     from tests.oracle_engine import OracleEngine
     from xpysom_dask_amd import XPySom
     from xpysom_dask_amd import distributed as D
+    from xpysom_dask_amd import engine
+    engine.HipEngine = OracleEngine                     # test double in THIS worker process only (no GPU here)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         assert D.dist_info() == (rank, world)
         data = O.gaussian_blobs(601, 5, seed=11)
-        som = XPySom(7, 6, 5, random_seed=3, decay_function="linear", sharded_input=sharded_input,
-                     _engine_factory=OracleEngine)
+        som = XPySom(7, 6, 5, random_seed=3, decay_function="linear", sharded_input=sharded_input)
         mine = data
         if sharded_input:
             lo, hi = D.shard_bounds(len(data), rank, world)

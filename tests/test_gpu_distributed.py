@@ -1,0 +1,111 @@
+"""The N > 1 path on the REAL engine: two ranks of XPySom -> HipEngine -> libsomhip.
+
+* gloo, both ranks on GPU 0: runs on the one-GPU box; the all-reduce goes through the product's host-staged branch
+  of `distributed.allreduce_accumulator` on the engine's own HBM buffer.
+* nccl (= RCCL), one GPU per rank: the stream-ordered branch; needs two GPUs, skipped otherwise.
+* `python bench.py --gpus 2` from plain python (no launcher): the self-launching harness, weak and strong scaling.
+
+Reference seam: the Dask fan-out / `delayed(sum)` / merge of xpysom.py:545-558,577.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import som_oracle as O
+from tests.conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(backend, out_dir, mode, world=2):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(REPO, "tests", "dist_worker.py"), backend, str(out_dir), mode]
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-5000:]
+
+
+def _check(out_dir, mode, world=2):
+    """Every rank holds the same results, bit for bit; returns rank 0's (small-run codebook, epoch codebook, den)."""
+    got = []
+    for stem in ("ws", "w", "den"):
+        a = [np.load(os.path.join(out_dir, "%s_%s_%d.npy" % (stem, mode, r))) for r in range(world)]
+        for b in a[1:]:
+            assert np.array_equal(a[0], b)
+        got.append(a[0])
+    return got
+
+
+def _references():
+    small = O.gaussian_blobs(601, 5, seed=11)
+    ref_small = O.train(small, O.default_codebook(7, 6, 5, 3), 6, sigma0=3.0, decay="linear", n_parallel=4000)
+    data = O.gaussian_blobs(6001, 16, seed=11)
+    w0 = O.default_codebook(24, 20, 16, 3).astype(np.float32)
+    f = O.DECAYS["linear"]
+    _, _, _, ref_epoch = O.epoch(data, w0, f(0.5, 0.01, 2, 5), f(10.0, 1, 2, 5), wide=False, n_parallel=6001)
+    return data, ref_small, ref_epoch
+
+
+@pytest.mark.parametrize("mode", ["full", "sharded", "stream"])
+def test_two_ranks_of_the_hip_engine_under_gloo(tmp_path, mode):
+    _launch("gloo", tmp_path, mode)
+    ws, w, den = _check(tmp_path, mode)
+    data, ref_small, ref_epoch = _references()
+    np.testing.assert_allclose(ws, ref_small, rtol=2e-5, atol=2e-6)    # float32 sum order differs with the shard count
+    np.testing.assert_allclose(w, ref_epoch, rtol=2e-5, atol=2e-6)
+    # the all-reduced denominator covers ALL rows, not one shard's
+    _, _, den_all = O.update(data, w.astype(np.float32), 0.3, 2.0, wide=False)
+    np.testing.assert_allclose(den.reshape(-1), den_all.reshape(-1), rtol=2e-5, atol=1e-6)
+
+
+def test_two_ranks_bf16_precision_under_gloo(tmp_path):
+    _launch("gloo", tmp_path, "bf16")
+    ws, w, _ = _check(tmp_path, "bf16")
+    _, ref_small, ref_epoch = _references()
+    # bf16 BMUs: near-tie picks may differ from float32, the epoch's result barely moves
+    assert np.abs(w - ref_epoch).max() < 0.02 * np.abs(ref_epoch).max()
+    assert np.abs(ws - ref_small).max() < 0.05 * np.abs(ref_small).max()
+
+
+def test_two_ranks_under_rccl(tmp_path):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the driver's multi-GPU node)")
+    for mode in ("full", "stream"):
+        _launch("nccl", tmp_path, mode)
+        ws, w, _ = _check(tmp_path, mode)
+        _, ref_small, ref_epoch = _references()
+        np.testing.assert_allclose(ws, ref_small, rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(w, ref_epoch, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_launches_its_own_ranks(scaling):
+    """`python bench.py --gpus 2` with no launcher and no rank environment: exit 0 and one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SOM_DIST_BACKEND"] = "gloo"                           # two ranks on this box's one GPU
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--scaling", scaling]
+    cmd += ["--rows", "65536"] if scaling == "weak" else ["--total-rows", "131073"]
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-5000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling
+    assert out["config"]["rows_total"] == (131072 if scaling == "weak" else 131073)
+    assert out["value"] > 0 and 0 < out["roofline"]["frac"] < 1

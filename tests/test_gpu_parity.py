@@ -320,6 +320,83 @@ def test_ragged_shapes_against_oracle(X, Y, D, n, precision):
     assert e.bmu(data[:0]).shape == (0,)                      # empty input
 
 
+# ----------------------------------------------------------------------------- G11 bubble / triangle, rectangular
+@pytest.mark.parametrize("shape", [(8, 8, 3, 500), (5, 7, 4, 300)])
+@pytest.mark.parametrize("neigh,compact", [("bubble", False), ("triangle", False), ("triangle", True)])
+def test_g11_bubble_triangle_against_the_reference(shape, neigh, compact):
+    """neighborhoods.py:99-130 through the table-driven transform, against the reference's own _update and
+    one-epoch outputs for all three schedules (the triangle is float64 in the reference whatever sigma's type)."""
+    g = load_golden("g11_bubble_triangle")
+    X, Y, D, n = shape
+    data = O.gaussian_blobs(n, D, seed=400 + X)
+    w0 = O.default_codebook(X, Y, D, 21).astype(F32)
+    e = engine(X, Y, D, neighborhood=neigh, compact_support=compact)
+    e.set_data(data)
+    for decay in ("linear", "exponential", "asymptotic"):
+        key = f"{X}x{Y}x{D}_{neigh}{'_cs' if compact else ''}_{decay}"
+        e.set_weights(w0)
+        e.epoch_accumulate(float(g[key + "_sig"]), float(g[key + "_eta"]), O.decay_is_wide(decay))
+        num, den, bmu = e.epoch_fetch()
+        assert np.array_equal(bmu, g[key + "_bmu"]), key
+        assert rel_err(num, g[key + "_num"].reshape(-1, D)) < 1e-5, key
+        assert rel_err(den, g[key + "_den"].reshape(-1)) < 1e-5, key
+        e.epoch_merge()
+        gw = g[key + "_wout"].reshape(-1, D)
+        ok = g[key + "_den"].reshape(-1) > 1e-30
+        np.testing.assert_allclose(e.get_weights()[ok], gw[ok], rtol=1e-5, atol=1e-5 * np.abs(gw).max())
+        keep = g[key + "_den"].reshape(-1) == 0                  # outside every box: the old weights stay
+        assert np.array_equal(e.get_weights()[keep], w0.reshape(-1, D)[keep])
+
+
+@pytest.mark.parametrize("decay,tag", [("linear", "init"), ("exponential", "init"), ("exponential", "mid")])
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_g12_configs1_map_against_the_reference(decay, tag, precision):
+    """64x64x32 (BASELINE configs[1]'s map), one _update of 4096 rows: BMUs, denominator, strided numerator and
+    merged rows of the reference itself."""
+    g = load_golden("g12_update_64x64x32")
+    X, Y, D, n = (int(v) for v in g["shape"])
+    st = int(g["stride"])
+    data = O.gaussian_blobs(n, D, seed=int(g["data_seed"]))
+    w = O.default_codebook(X, Y, D, 1234).astype(F32) if tag == "init" else g["exponential_wmid"]
+    key = f"{decay}_{tag}"
+    e = engine(X, Y, D, precision=precision)
+    e.set_weights(w)
+    e.set_data(data)
+    e.epoch_accumulate(float(g[key + "_sig"]), float(g[key + "_eta"]), O.decay_is_wide(decay))
+    num, den, bmu = e.epoch_fetch()
+    diff = np.flatnonzero(bmu != g[key + "_bmu"])
+    if precision == "f32":
+        assert len(diff) == 0                                 # the float32 distance matrix is the reference's, bit for bit
+    else:
+        assert len(diff) <= n // 20 and bf16_misses_are_near_best(data, w.reshape(-1, D), bmu, diff)
+        return
+    gden = g[key + "_den"].reshape(-1)
+    ok = gden > 1e-30
+    np.testing.assert_allclose(den[ok], gden[ok], rtol=1e-5)
+    assert rel_err(num[::st], g[key + "_num16"]) < 1e-5
+    e.epoch_merge()
+    gw = g[key + "_wout16"]
+    np.testing.assert_allclose(e.get_weights()[::st][ok[::st]], gw[ok[::st]], rtol=1e-5, atol=1e-5 * np.abs(gw).max())
+
+
+@pytest.mark.parametrize("XD", [(5, 3), (12, 6)])
+def test_g13_hexagonal_topographic_error(XD):
+    """topographic_error on topology='hexagonal' as the reference evaluates it (xpysom.py:739-746) on square maps."""
+    from xpysom_dask_amd import XPySom
+    g = load_golden("g13_hex_topographic")
+    X, D = XD
+    key = f"{X}x{X}x{D}"
+    seeds = g[key + "_seeds"]
+    probe = O.gaussian_blobs(400, D, seed=int(seeds[1]))
+    som = XPySom(X, X, D, topology="hexagonal", random_seed=8, decay_function="linear")
+    som._weights = g[key + "_w"]
+    b1, b2 = som._upload_weights().bmu_top2(probe)
+    assert np.array_equal(b1, g[key + "_top2"][:, 0]) and np.array_equal(b2, g[key + "_top2"][:, 1])
+    assert som.topographic_error(probe) == float(g[key + "_te"])
+    train = O.gaussian_blobs({5: 300, 12: 1500}[X], D, seed=int(seeds[0]))
+    assert som.topographic_error(train) == float(g[key + "_te_train"])
+
+
 @pytest.mark.parametrize("neigh", ["bubble", "triangle"])
 def test_other_separable_neighbourhoods(neigh):
     """bubble / triangle (neighborhoods.py:99-130) through the same table-driven transform,
@@ -837,6 +914,28 @@ def test_train_accepts_device_resident_rows():
     with pytest.raises(ValueError):
         XPySom(X, Y, D + 1, random_seed=5).train(t, 1)
 
+    # a foreign producer (any __cuda_array_interface__ object, e.g. a CuPy array): rows still being written
+    # on ITS stream when train() is called -- the engine waits for that stream -- and analysis calls copy back
+    class Foreign:
+        def __init__(self, tensor, stream):
+            self.keep = tensor
+            self.__cuda_array_interface__ = {"shape": tuple(tensor.shape), "typestr": "<f4", "strides": None,
+                                             "data": (tensor.data_ptr(), False), "version": 3, "stream": stream}
+
+        def __len__(self):
+            return self.keep.shape[0]
+    side = torch.cuda.Stream()
+    pinned = torch.from_numpy(data).pin_memory()
+    with torch.cuda.stream(side):
+        big = torch.empty(64 << 20, device="cuda").normal_()   # keeps the side stream busy ahead of the copy
+        late = torch.empty((n, D), dtype=torch.float32, device="cuda")
+        late.copy_(pinned, non_blocking=True)
+    d = XPySom(X, Y, D, sigma=3.0, random_seed=5).train(Foreign(late, side.cuda_stream), 6)
+    np.testing.assert_allclose(d._weights, a._weights, rtol=2e-5, atol=1e-6)
+    assert abs(d.quantization_error(Foreign(late, None)) - a.quantization_error(data)) < 1e-5
+    before = torch.cuda.current_device()
+    assert before == 0 and big.numel() > 0
+
 
 def test_cosine_resolves_short_rows_as_well_as_long_ones():
     """Cosine does not depend on |x|, but the bf16 kernels compare B - x~.w^~ with B = max|x~| max|w~|: a short
@@ -873,8 +972,6 @@ def test_support_mask_at_a_sigma_one_ulp_off_an_integer():
         e.set_data(data)
         e.epoch_accumulate(sigma, 0.5, False)
         num, den, bmu = e.epoch_fetch()
-        if neigh == "triangle":
-            continue                                           # (no oracle restatement; it shares neigh_box)
         _, onum, oden = O.update(data, w, 0.5, sigma, wide=False, neighbourhood=neigh, compact=compact, forced_bmu=bmu)
         assert rel_err(num, onum.reshape(-1, D)) < 1e-5, neigh
         assert rel_err(den, oden.reshape(-1)) < 1e-5, neigh

@@ -83,19 +83,26 @@ def test_compute_fails_loudly_without_a_gpu():
         som.winner(np.zeros((3, 2)))
 
 
-def test_host_logic_end_to_end_with_the_test_double():
-    """XPySom's epoch loop / schedule plumbing / result formatting, engine replaced by the oracle."""
+@pytest.fixture
+def oracle_engine(monkeypatch):
+    """The engine class the host code constructs, swapped for the oracle-backed test double."""
     from tests.oracle_engine import OracleEngine
+    from xpysom_dask_amd import engine
+    monkeypatch.setattr(engine, "HipEngine", OracleEngine)
+
+
+def test_host_logic_end_to_end_with_the_test_double(oracle_engine):
+    """XPySom's epoch loop / schedule plumbing / result formatting, engine replaced by the oracle."""
     from xpysom_dask_amd import XPySom
     data = O.gaussian_blobs(300, 4, seed=2)
     for decay in ("linear", "exponential", "asymptotic"):
-        som = XPySom(6, 5, 4, random_seed=9, decay_function=decay, _engine_factory=OracleEngine)
+        som = XPySom(6, 5, 4, random_seed=9, decay_function=decay)
         w0 = som._weights.copy()
         assert som.train(data, 7) is som
         ref = O.train(data, w0, 7, sigma0=2.5, decay=decay)
         np.testing.assert_allclose(som._weights, ref, rtol=1e-6, atol=1e-7)
         # resume: 0..3 then 3..7 equals one run
-        som2 = XPySom(6, 5, 4, random_seed=9, decay_function=decay, _engine_factory=OracleEngine)
+        som2 = XPySom(6, 5, 4, random_seed=9, decay_function=decay)
         som2.train(data, 7, iter_beg=0, iter_end=3)
         som2.train(data, 7, iter_beg=3)
         np.testing.assert_array_equal(som2._weights, som._weights)
@@ -108,12 +115,11 @@ def test_host_logic_end_to_end_with_the_test_double():
     assert back._engine_obj is None
 
 
-def test_train_streaming_host_logic_with_the_test_double():
-    from tests.oracle_engine import OracleEngine
+def test_train_streaming_host_logic_with_the_test_double(oracle_engine):
     from xpysom_dask_amd import XPySom
     data = O.gaussian_blobs(500, 4, seed=12)
-    a = XPySom(6, 5, 4, random_seed=9, decay_function="linear", _engine_factory=OracleEngine)
-    b = XPySom(6, 5, 4, random_seed=9, decay_function="linear", _engine_factory=OracleEngine)
+    a = XPySom(6, 5, 4, random_seed=9, decay_function="linear")
+    b = XPySom(6, 5, 4, random_seed=9, decay_function="linear")
     a.train(data, 4)
     b.train_streaming(lambda: (data[i:i + 123] for i in range(0, 500, 123)), 4)
     np.testing.assert_array_equal(a._weights, b._weights)
@@ -129,10 +135,40 @@ def test_device_rows_detection_and_validation():
                                              "version": 2, "strides": strides}
     assert _device_rows(np.zeros((3, 2), dtype=np.float32)) is None
     assert _device_rows([[1.0, 2.0]]) is None
-    ptr, n, d, dev, owner = _device_rows(Fake((7, 5)))
-    assert (ptr, n, d, dev) == (4096, 7, 5, None) and isinstance(owner, Fake)
+    ptr, n, d, dev, owner, stream = _device_rows(Fake((7, 5)))
+    assert (ptr, n, d, dev, stream) == (4096, 7, 5, None, None) and isinstance(owner, Fake)
+    f = Fake((7, 5))
+    f.__cuda_array_interface__["stream"] = 1                  # the producer's stream travels with the rows
+    assert _device_rows(f)[5] == 1
     for bad in (Fake((7,)), Fake((7, 5), typestr="<f8"), Fake((7, 5), strides=(40, 4))):
         with pytest.raises(ValueError):
             _device_rows(bad)
     import torch
     assert _device_rows(torch.zeros(4, 3)) is None          # CPU tensor: host path
+
+
+def test_distance_map_matches_the_reference():
+    """The vectorised U-matrix against the reference's own output (xpysom.py:788-817), both topologies,
+    non-square and degenerate (1 x Y) maps -- host-only, no engine involved."""
+    from tests.conftest import load_golden
+    from xpysom_dask_amd import XPySom
+    g = load_golden("g14_distance_map")
+    for topo in ("rectangular", "hexagonal"):
+        for (X, Y, D) in ((7, 6, 3), (4, 9, 5), (1, 5, 2)):
+            som = XPySom(X, Y, D, random_seed=31, topology=topo)
+            np.testing.assert_allclose(som.distance_map(), g[f"{topo}_{X}x{Y}x{D}"], rtol=1e-12, atol=0)
+
+
+def test_constructor_refuses_what_the_engine_would_refuse():
+    from xpysom_dask_amd import XPySom
+    for topo in ("rectangular", "hexagonal"):
+        with pytest.raises(NotImplementedError, match="mexican_hat with compact_support"):
+            XPySom(5, 5, 3, neighborhood_function="mexican_hat", compact_support=True, topology=topo)
+    for dist in ("manhattan", "norm_p", "norm_p_no_opt", "euclidean_no_opt"):
+        with pytest.raises(ValueError, match="needs precision='f32'"):
+            XPySom(5, 5, 3, activation_distance=dist, precision="bf16")
+    for p in (1.5, 0.5, 0, 17, "2"):
+        with pytest.raises(NotImplementedError, match="norm_p"):
+            XPySom(5, 5, 3, activation_distance="norm_p", activation_distance_kwargs={"p": p})
+    XPySom(5, 5, 3, activation_distance="norm_p", activation_distance_kwargs={"p": 3.0})
+    XPySom(5, 5, 3, activation_distance="norm_p_no_opt")

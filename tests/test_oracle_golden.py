@@ -269,3 +269,85 @@ def test_g9_winner_under_the_other_distances():
     w = g["w"].reshape(-1, 10)
     for name, p in (("manhattan", 1), ("norm_p", 2), ("norm_p", 3), ("norm_p", 4), ("norm_p_no_opt", 2)):
         assert np.array_equal(O.bmu_ids_pairwise(probe, w, name, p), g["win_%s_p%d" % (name, p)]), (name, p)
+
+
+# ----------------------------------------------------------------------------- G11 bubble / triangle (rectangular)
+G11_SIGMAS = (0.3, 1.0, 2.0, 2.5, 3.0000000000000004)
+
+
+@pytest.mark.parametrize("XY", [(5, 5), (3, 4)])
+def test_g11_bubble_triangle_tensors(XY):
+    """neighborhoods.py:99-130, every centre, sigma on and next to the open box's edge; the triangle is float64
+    for both sigma types (int64 - ... + sigma), the bubble float32."""
+    g = load_golden("g11_bubble_triangle")
+    X, Y = XY
+    ci, cj = np.divmod(np.arange(X * Y), Y)
+    for sig in G11_SIGMAS:
+        for wide in (False, True):
+            key = f"{X}x{Y}_s{sig!r}_{'f64' if wide else 'f32'}"
+            ref = g["bubble_" + key]
+            got = O.neigh_bubble(X, Y, 0.5, False, ci, cj, sig, wide)
+            assert got.dtype == ref.dtype == np.float32
+            np.testing.assert_array_equal(got, ref)
+            for compact in (False, True):
+                ref = g["tri_" + key + ("_cs" if compact else "_nc")]
+                got = O.neigh_triangle(X, Y, 0.5, compact, ci, cj, sig, wide)
+                assert got.dtype == ref.dtype == np.float64
+                np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 3, 500), (5, 7, 4, 300)])
+@pytest.mark.parametrize("neigh,compact", [("bubble", False), ("triangle", False), ("triangle", True)])
+def test_g11_update_and_epoch(shape, neigh, compact):
+    g = load_golden("g11_bubble_triangle")
+    X, Y, D, n = shape
+    data = O.gaussian_blobs(n, D, seed=400 + X)
+    w0 = O.default_codebook(X, Y, D, 21).astype(F32)
+    for decay in ("linear", "exponential", "asymptotic"):
+        key = f"{X}x{Y}x{D}_{neigh}{'_cs' if compact else ''}_{decay}"
+        f, wide = O.DECAYS[decay], O.decay_is_wide(decay)
+        eta, sig = f(0.5, 0.01, 1, 6), f(min(X, Y) / 2, 1, 1, 6)
+        assert float(eta) == float(g[key + "_eta"]) and float(sig) == float(g[key + "_sig"])
+        bmu, num, den = O.update(data, w0, eta, sig, wide=wide, neighbourhood=neigh, compact=compact)
+        assert np.array_equal(bmu, g[key + "_bmu"])
+        assert str(num.dtype) == str(g[key + "_numdtype"])
+        np.testing.assert_allclose(num, g[key + "_num"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(den, g[key + "_den"], rtol=1e-6, atol=0)
+        _, _, _, wout = O.epoch(data, w0, eta, sig, wide=wide, n_parallel=n, neighbourhood=neigh, compact=compact)
+        np.testing.assert_allclose(wout, g[key + "_wout"], rtol=1e-5, atol=2e-6)
+
+
+# ----------------------------------------------------------------------------- G12 the configs[1] map
+@pytest.mark.parametrize("decay,tag", [("linear", "init"), ("exponential", "init"), ("exponential", "mid")])
+def test_g12_update_64x64x32(decay, tag):
+    g = load_golden("g12_update_64x64x32")
+    X, Y, D, n = (int(v) for v in g["shape"])
+    T, st = int(g["T"]), int(g["stride"])
+    data = O.gaussian_blobs(n, D, seed=int(g["data_seed"]))
+    w = O.default_codebook(X, Y, D, 1234).astype(F32) if tag == "init" else g["exponential_wmid"]
+    t = 0 if tag == "init" else T // 2
+    f, wide = O.DECAYS[decay], O.decay_is_wide(decay)
+    eta, sig = f(0.5, 0.01, t, T), f(min(X, Y) / 2, 1, t, T)
+    key = f"{decay}_{tag}"
+    assert float(eta) == float(g[key + "_eta"]) and float(sig) == float(g[key + "_sig"])
+    bmu, num, den, wout = O.epoch(data, w, eta, sig, wide=wide, n_parallel=n)
+    assert np.array_equal(bmu, g[key + "_bmu"])
+    np.testing.assert_allclose(den[:, :, 0], g[key + "_den"][:, :, 0], rtol=2e-6, atol=0)
+    np.testing.assert_allclose(num.reshape(-1, D)[::st], g[key + "_num16"], rtol=1e-5, atol=1e-6)
+    ok = den.reshape(-1)[::st] > 1e-30
+    np.testing.assert_allclose(wout.reshape(-1, D)[::st][ok], g[key + "_wout16"][ok], rtol=1e-5, atol=2e-6)
+
+
+# ----------------------------------------------------------------------------- G13 hexagonal topographic error
+@pytest.mark.parametrize("XD", [(5, 3), (12, 6)])
+def test_g13_hex_topographic_error(XD):
+    g = load_golden("g13_hex_topographic")
+    X, D = XD
+    key = f"{X}x{X}x{D}"
+    seeds = g[key + "_seeds"]
+    probe = O.gaussian_blobs(400, D, seed=int(seeds[1]))
+    w = g[key + "_w"]
+    assert np.array_equal(O.top2_ids(probe, w), g[key + "_top2"])
+    assert O.topographic_error(probe, w, topology="hexagonal") == float(g[key + "_te"])
+    n = {5: 300, 12: 1500}[X]
+    assert O.topographic_error(O.gaussian_blobs(n, D, seed=int(seeds[0])), w, topology="hexagonal") == float(g[key + "_te_train"])

@@ -39,6 +39,8 @@ SIGNATURES = {
     "som_get_weights": (C.c_int, [_H, _F]),
     "som_set_data": (C.c_int, [_H, _F, C.c_int64]),
     "som_set_data_device": (C.c_int, [_H, C.c_void_p, C.c_int64]),
+    "som_sync_producer": (C.c_int, [_H, C.c_uint64, C.c_int32]),
+    "som_copy_to_host": (C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p]),
     "som_epoch_accumulate": (C.c_int, [_H, C.c_double, C.c_double, C.c_int]),
     "som_epoch_merge": (C.c_int, [_H]),
     "som_epoch": (C.c_int, [_H, C.c_double, C.c_double, C.c_int]),
@@ -92,6 +94,13 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m xpysom_dask_amd.build` "
             "(needs hipcc; there is no CPU fallback)")
+    if not os.environ.get("SOM_LIB_PATH"):             # (an explicit A/B build is the caller's business)
+        from . import build as _build
+        have, want = _build.built_hash(LIB_PATH), _build.source_hash()
+        if have != want:
+            raise ImportError(
+                f"{LIB_PATH} is stale: built from sources {have}, the tree is {want}; "
+                "rebuild with `python -m xpysom_dask_amd.build`")
     _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():

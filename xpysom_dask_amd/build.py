@@ -1,7 +1,13 @@
 """Build libsomhip.so in-tree with hipcc for gfx950 (no JIT cache, no torch extension).
 
     python -m xpysom_dask_amd.build
+
+The library carries a hash of every source it was built from (`som_version()` ends in `src:<hash>`);
+`up_to_date()` and `_lib.load()` compare it with the sources in the tree, so an edit to any kernel
+header can neither be skipped by `build(force=False)` nor be benchmarked through a stale binary.
 """
+import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -10,9 +16,36 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "somhip.hip")
 OUT = os.path.join(HERE, "libsomhip.so")
-DEPS = [os.path.join(HERE, "csrc", f) for f in
-        ("somhip.hip", "som_common.hpp", "bmu_f32.hpp", "bmu_bf16.hpp", "update.hpp")]
-DEPS.append(os.path.join(os.path.dirname(HERE), "include", "somhip.h"))
+HEADER = os.path.join(os.path.dirname(HERE), "include", "somhip.h")
+
+
+def sources():
+    """Every file the library is compiled from: csrc/* and the public header."""
+    return sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")) + glob.glob(os.path.join(HERE, "csrc", "*.hpp"))) + [HEADER]
+
+
+def source_hash():
+    h = hashlib.sha256()
+    for p in sources():
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def built_hash(path=None):
+    """The source hash baked into a built library (read from the file, no dlopen), or None."""
+    path = path or OUT
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    tag = b"somhip-src:"
+    i = blob.find(tag)
+    if i < 0:
+        return None
+    return blob[i + len(tag):i + len(tag) + 16].decode("ascii", "replace")
 
 
 def hipcc():
@@ -23,10 +56,7 @@ def hipcc():
 
 
 def up_to_date():
-    if not os.path.exists(OUT):
-        return False
-    t = os.path.getmtime(OUT)
-    return all(os.path.getmtime(d) <= t for d in DEPS)
+    return os.path.exists(OUT) and built_hash(OUT) == source_hash()
 
 
 def build(force=False, verbose=True, extra=(), out=None):
@@ -35,6 +65,7 @@ def build(force=False, verbose=True, extra=(), out=None):
         return OUT
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-munsafe-fp-atomics", "-Wall", "-Wno-unused-command-line-argument",
+           '-DSOM_SRC_HASH="%s"' % source_hash(),
            SRC, "-o", out or OUT, "-Wl,-rpath,/opt/rocm/lib"] + list(extra)
     if verbose:
         print(" ".join(cmd), flush=True)

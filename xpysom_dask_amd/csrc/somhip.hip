@@ -137,6 +137,21 @@ int fail_hip(som_handle* h, const char* what, hipError_t e) {
     return fail(h, std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// Every entry point runs on the handle's device and leaves the calling thread's current device as it found
+// it (the host process shares this HIP runtime with torch, whose current device must not move under it).
+struct DeviceGuard {
+    int prev = -1;
+    bool moved = false;
+    explicit DeviceGuard(const som_handle* h) {
+        if (!h) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != h->cfg.device) { (void)hipSetDevice(h->cfg.device); moved = true; }
+    }
+    ~DeviceGuard() { if (moved && prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 #define HIPCHK(h, call)                                              \
     do {                                                             \
         hipError_t e_ = (call);                                      \
@@ -668,6 +683,8 @@ NeighParams make_neigh_params(const som_handle* h, double sigma, double eta, int
     p.sigma = sigma; p.eta = eta;
     p.d = 2.0 * (h->cfg.std_coeff * h->cfg.std_coeff) * (sigma * sigma);
     p.kind = h->cfg.neighborhood; p.compact = h->cfg.compact_support; p.wide = neigh_f64 ? 1 : 0;
+    // the reference's triangle is float64 whatever sigma's type (int64 - |...| + sigma, neighborhoods.py:121-122)
+    if (p.kind == SOM_NEIGH_TRIANGLE) p.wide = 1;
     p.X = h->X; p.Y = h->Y; p.nt = h->nt;
     p.hex = h->cfg.topology == SOM_TOPO_HEXAGONAL && h->cfg.neighborhood != SOM_NEIGH_BUBBLE;
     p.base_nt = p.hex ? h->nt / 3 : h->nt;
@@ -749,7 +766,11 @@ int launch_dist_matrix(som_handle* h, long N, float* out) {
 // ==============================================================================================
 extern "C" {
 
-const char* som_version(void) { return "somhip 0.1 (gfx950)"; }
+#ifndef SOM_SRC_HASH
+#define SOM_SRC_HASH "unversioned-build"
+#endif
+// ends in the hash of the sources this binary was built from (xpysom_dask_amd/build.py checks it against the tree)
+const char* som_version(void) { return "somhip 0.2 (gfx950) somhip-src:" SOM_SRC_HASH; }
 
 int som_device_count(void) {
     int n = 0;
@@ -826,7 +847,11 @@ int som_create(const som_config* cfg, som_handle** out) {
     if (cfg->topology == SOM_TOPO_HEXAGONAL && cfg->neighborhood != SOM_NEIGH_BUBBLE) h->nt *= 3;
     int rc = 0;
     auto bail = [&](int code) { g_create_error = h->err; som_destroy(h); return code; };
-    if (hipSetDevice(cfg->device) != hipSuccess) return bail(fail(h, "hipSetDevice failed"));
+    DeviceGuard dev_guard(h);
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != cfg->device) return bail(fail(h, "hipSetDevice failed"));
+    }
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) h->n_cus = prop.multiProcessorCount;
@@ -889,6 +914,7 @@ int som_create(const som_config* cfg, som_handle** out) {
 
 void som_destroy(som_handle* h) {
     if (!h) return;
+    DeviceGuard dev_guard(h);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->np_dev) (void)hipFree(h->np_dev);
@@ -911,7 +937,7 @@ void som_destroy(som_handle* h) {
 }
 
 int som_set_weights(som_handle* h, const float* w_host) {
-    if (h) (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dev_guard(h);
     if (!h || !w_host) return fail(h, "som_set_weights: NULL argument");
     if (int rc = h2d_blocking(h, h->W, w_host, (size_t)h->K * h->D * sizeof(float))) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -920,7 +946,7 @@ int som_set_weights(som_handle* h, const float* w_host) {
 }
 
 int som_get_weights(som_handle* h, float* w_host) {
-    if (h) (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dev_guard(h);
     if (!h || !w_host) return fail(h, "som_get_weights: NULL argument");
     return d2h_blocking(h, w_host, h->W, (size_t)h->K * h->D * sizeof(float));
 }
@@ -959,7 +985,7 @@ static int adopt_rows(som_handle* h, int64_t n_rows) {
 }
 
 int som_set_data(som_handle* h, const float* x_host, int64_t n_rows) {
-    if (h) (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dev_guard(h);
     if (!h || n_rows < 0 || (!x_host && n_rows > 0)) return fail(h, "som_set_data: bad argument");
     (void)hipFree(h->X_owned);
     h->X_owned = nullptr; h->Xd = nullptr;
@@ -971,12 +997,32 @@ int som_set_data(som_handle* h, const float* x_host, int64_t n_rows) {
 }
 
 int som_set_data_device(som_handle* h, const void* x_dev, int64_t n_rows) {
-    if (h) (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dev_guard(h);
     if (!h || n_rows < 0 || (!x_dev && n_rows > 0)) return fail(h, "som_set_data_device: bad argument");
     (void)hipFree(h->X_owned);
     h->X_owned = nullptr;
     h->Xd = (const float*)x_dev;
     return adopt_rows(h, n_rows);
+}
+
+// Order the engine behind whoever produced device rows handed to som_set_data_device: a
+// __cuda_array_interface__ `stream` value (1 = legacy default stream, 2 = per-thread default stream, else a
+// hipStream_t), or -- has_stream == 0, the producer named none -- the whole device.
+int som_sync_producer(som_handle* h, uint64_t stream, int32_t has_stream) {
+    DeviceGuard dev_guard(h);
+    if (!h) return 1;
+    if (!has_stream) { HIPCHK(h, hipDeviceSynchronize()); return 0; }
+    hipStream_t st = stream == 1 ? (hipStream_t)0 : stream == 2 ? hipStreamPerThread : (hipStream_t)(uintptr_t)stream;
+    HIPCHK(h, hipStreamSynchronize(st));
+    return 0;
+}
+
+// Device rows the caller owns, copied back to host memory (analysis calls on data that lives in HBM).
+int som_copy_to_host(som_handle* h, const void* x_dev, uint64_t bytes, void* dst_host) {
+    DeviceGuard dev_guard(h);
+    if (!h || (bytes > 0 && (!x_dev || !dst_host))) return fail(h, "som_copy_to_host: bad argument");
+    if (bytes == 0) return 0;
+    return d2h_blocking(h, dst_host, x_dev, (size_t)bytes);
 }
 
 namespace {
@@ -1029,7 +1075,7 @@ int capture_epoch_graph(som_handle* h) {
 }  // namespace
 
 int som_epoch_accumulate(som_handle* h, double sigma, double eta, int neigh_f64) {
-    if (h) (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dev_guard(h);
     if (!h) return 1;
     if (!h->Xd && h->N > 0) return fail(h, "som_epoch_accumulate: no resident data (call som_set_data)");
     // launch-bound maps (many short kernels per epoch) replay a captured graph; profiling needs the
@@ -1061,7 +1107,7 @@ int som_epoch_accumulate(som_handle* h, double sigma, double eta, int neigh_f64)
 }
 
 int som_epoch_accumulate_forced(som_handle* h, const int32_t* bmu_host, double sigma, double eta, int neigh_f64) {
-    if (h) (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dev_guard(h);
     if (!h || (!bmu_host && h->N > 0)) return fail(h, "som_epoch_accumulate_forced: bad argument");
     for (long i = 0; i < h->N; ++i)
         if (bmu_host[i] < 0 || bmu_host[i] >= h->K) return fail(h, "som_epoch_accumulate_forced: id out of range");
@@ -1072,7 +1118,7 @@ int som_epoch_accumulate_forced(som_handle* h, const int32_t* bmu_host, double s
 
 // ---- streamed epoch: rows pass through HBM chunk by chunk (out-of-core data) ------------------
 int som_stream_begin(som_handle* h) {
-    if (h) (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dev_guard(h);
     if (!h) return 1;
     if (int rc = refresh_codebook_operands(h, h->cfg.precision == SOM_PREC_F32)) return rc;
     HIPCHK(h, hipMemsetAsync(h->SC, 0, (size_t)h->K * h->D1p * sizeof(float), h->stream));
@@ -1106,7 +1152,7 @@ static bool is_pinned_host(const void* p) {
 }
 
 int som_stream_rows(som_handle* h, const float* x_host, int64_t n_rows) {
-    if (h) (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dev_guard(h);
     if (!h || n_rows < 0 || (n_rows > 0 && !x_host)) return fail(h, "som_stream_rows: bad argument");
     if (!h->streaming) return fail(h, "som_stream_rows: call som_stream_begin first");
     if (n_rows == 0) return 0;
@@ -1180,7 +1226,7 @@ int som_pinned_free(void* p) {
 }
 
 int som_stream_end(som_handle* h, double sigma, double eta, int neigh_f64) {
-    if (h) (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dev_guard(h);
     if (!h) return 1;
     if (!h->streaming) return fail(h, "som_stream_end: call som_stream_begin first");
     h->streaming = false;
@@ -1188,7 +1234,7 @@ int som_stream_end(som_handle* h, double sigma, double eta, int neigh_f64) {
 }
 
 int som_epoch_merge(som_handle* h) {
-    if (h) (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dev_guard(h);
     if (!h) return 1;
     Timed t(h, SOM_K_MERGE);
     long total = (long)h->K * h->D;
@@ -1217,7 +1263,7 @@ int som_get_stream(som_handle* h, void** stream_out) {
 }
 
 int som_epoch_fetch(som_handle* h, float* num, float* den, int32_t* bmu) {
-    if (h) (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dev_guard(h);
     if (!h) return 1;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (num || den) {
@@ -1250,7 +1296,7 @@ int run_quantization_bmu(som_handle* h, long n_rows) {
 }  // namespace
 
 int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, int32_t* ids_out) {
-    if (h) (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dev_guard(h);
     if (!h || n_rows < 0 || (n_rows > 0 && (!x_host || !ids_out))) return fail(h, "som_bmu: bad argument");
     if (mode != SOM_BMU_ACTIVATION && mode != SOM_BMU_QUANTIZATION) return fail(h, "som_bmu: unknown mode");
     if (n_rows == 0) return 0;
@@ -1268,7 +1314,7 @@ int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, in
 }
 
 int som_bmu_top2(som_handle* h, const float* x_host, int64_t n_rows, int32_t* ids1_out, int32_t* ids2_out) {
-    if (h) (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dev_guard(h);
     if (!h || n_rows < 0 || (n_rows > 0 && (!x_host || !ids1_out || !ids2_out))) return fail(h, "som_bmu_top2: bad argument");
     if (n_rows == 0) return 0;
     if (int rc = ensure_query_scratch(h, n_rows)) return rc;
@@ -1284,7 +1330,7 @@ int som_bmu_top2(som_handle* h, const float* x_host, int64_t n_rows, int32_t* id
 }
 
 int som_distance_matrix(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, float* dist_out) {
-    if (h) (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dev_guard(h);
     if (!h || n_rows < 0 || (n_rows > 0 && (!x_host || !dist_out))) return fail(h, "som_distance_matrix: bad argument");
     if (mode != SOM_BMU_ACTIVATION && mode != SOM_BMU_QUANTIZATION) return fail(h, "som_distance_matrix: unknown mode");
     if (mode == SOM_BMU_ACTIVATION && h->cfg.distance > SOM_DIST_COSINE)
@@ -1311,7 +1357,7 @@ int som_distance_matrix(som_handle* h, const float* x_host, int64_t n_rows, int3
 }
 
 int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, double* qe_out) {
-    if (h) (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dev_guard(h);
     if (!h || !qe_out || n_rows < 0 || (n_rows > 0 && !x_host)) return fail(h, "som_quantization_error: bad argument");
     if (n_rows == 0) { *qe_out = NAN; return 0; }     // numpy: mean of an empty array
     if (int rc = ensure_query_scratch(h, n_rows)) return rc;
@@ -1327,14 +1373,14 @@ int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, d
 }
 
 int som_sync(som_handle* h) {
-    if (h) (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dev_guard(h);
     if (!h) return 1;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 
 int som_profile_enable(som_handle* h, int32_t on) {
-    if (h) (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dev_guard(h);
     if (!h) return 1;
     if (!on) if (int rc = resolve_profile(h)) return rc;
     h->prof = on != 0;
@@ -1342,7 +1388,7 @@ int som_profile_enable(som_handle* h, int32_t on) {
 }
 
 int som_profile_get(som_handle* h, int32_t kernel, double* total_ms, int64_t* launches) {
-    if (h) (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dev_guard(h);
     if (!h || kernel < 0 || kernel >= SOM_K_COUNT) return fail(h, "som_profile_get: bad argument");
     if (int rc = resolve_profile(h)) return rc;
     if (total_ms) *total_ms = h->ms[kernel];
@@ -1351,7 +1397,7 @@ int som_profile_get(som_handle* h, int32_t kernel, double* total_ms, int64_t* la
 }
 
 int som_profile_reset(som_handle* h) {
-    if (h) (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dev_guard(h);
     if (!h) return 1;
     if (int rc = resolve_profile(h)) return rc;
     for (int i = 0; i < SOM_K_COUNT; ++i) { h->ms[i] = 0; h->launches[i] = 0; }

@@ -88,6 +88,17 @@ class HipEngine:
         self.n_rows = int(n_rows)
         self._keepalive = keepalive
 
+    def sync_producer(self, stream=None):
+        """Wait for the producer of device rows: its `__cuda_array_interface__` stream, or (None) the device."""
+        self._check(self._lib.som_sync_producer(self._h, C.c_uint64(int(stream or 0)), int(stream is not None)))
+
+    def copy_to_host(self, dev_ptr, shape):
+        """float32 device rows of the caller -> a fresh host array."""
+        out = np.empty(shape, dtype=np.float32)
+        self._check(self._lib.som_copy_to_host(self._h, C.c_void_p(dev_ptr), C.c_uint64(out.nbytes),
+                                               out.ctypes.data_as(C.c_void_p)))
+        return out
+
     # -- one epoch --------------------------------------------------------------------------
     def epoch_accumulate(self, sigma, eta, neigh_f64):
         self._check(self._lib.som_epoch_accumulate(self._h, float(sigma), float(eta), int(bool(neigh_f64))))

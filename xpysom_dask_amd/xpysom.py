@@ -28,8 +28,9 @@ DEFAULT_BATCH_ROWS = 65536
 def _device_rows(data):
     """Rows that already live in HBM (the role CuPy arrays play in the reference, xpysom.py:487-510):
     a torch CUDA tensor, or any object with ``__cuda_array_interface__``, as a contiguous float32
-    ``(n, input_len)`` block.  Returns ``(pointer, n_rows, n_cols, device_index, owner)`` or ``None``
-    for host data."""
+    ``(n, input_len)`` block.  Returns ``(pointer, n_rows, n_cols, device_index, owner, stream)`` or ``None``
+    for host data; ``stream`` is the producer's stream in ``__cuda_array_interface__`` terms (``None``: the
+    producer named none -- the engine then waits for the whole device; ``"done"``: already waited for)."""
     torch = None
     if type(data).__module__.split(".")[0] == "torch":   # (torch is imported only when a tensor is actually passed)
         import torch
@@ -42,20 +43,28 @@ def _device_rows(data):
         if t.dtype != torch.float32 or not t.is_contiguous():
             t = t.to(torch.float32).contiguous()
         torch.cuda.current_stream(t.device).synchronize()      # the engine reads it on its own stream
-        return t.data_ptr(), t.shape[0], t.shape[1], t.device.index, t
+        return t.data_ptr(), t.shape[0], t.shape[1], t.device.index, t, "done"
     cai = getattr(data, "__cuda_array_interface__", None)
     if cai is not None:
         shape = tuple(cai["shape"])
         if len(shape) != 2 or cai["typestr"] != "<f4" or cai.get("strides") is not None:
             raise ValueError('device data must be a C-contiguous float32 (n_samples, input_len) array')
-        return int(cai["data"][0]), shape[0], shape[1], None, data
+        return int(cai["data"][0]), shape[0], shape[1], None, data, cai.get("stream")
     return None
 
 
-def _host_rows(x):
-    """float32 host view of array-like input; device tensors are copied back (analysis calls only)."""
+def _host_rows(x, engine=None):
+    """float32 host view of array-like input; device rows are copied back through ``engine()`` (analysis
+    calls only; the engine is not created for host input)."""
     if hasattr(x, "is_cuda") and getattr(x, "is_cuda"):
         x = x.detach().cpu().numpy()
+    elif getattr(x, "__cuda_array_interface__", None) is not None:
+        ptr, n, d, _, _, stream = _device_rows(x)
+        if engine is None:
+            raise TypeError("device rows need an engine to be copied back to the host")
+        eng = engine()
+        eng.sync_producer(stream)
+        return eng.copy_to_host(ptr, (n, d))
     return np.asarray(x, dtype=np.float32)
 
 
@@ -70,7 +79,7 @@ class XPySom:
                  random_seed=None, n_parallel=0, compact_support=False,
                  xp=None,
                  use_dask=False, dask_chunks='auto',
-                 *, precision='f32', device=None, sharded_input=False, _engine_factory=None):
+                 *, precision='f32', device=None, sharded_input=False):
         """Same positional/keyword surface as the reference constructor (xpysom.py:73-82).
 
         ``xp``, ``use_dask`` and ``dask_chunks`` are accepted for source compatibility and
@@ -127,14 +136,26 @@ class XPySom:
         self._activation_distance_name = activation_distance
         self._activation_distance_kwargs = activation_distance_kwargs
 
-        if topology == 'hexagonal' and neighborhood_function == 'mexican_hat' and compact_support:
-            raise NotImplementedError('mexican_hat with compact_support is not separable (reference bug, '
-                                      'neighborhoods.py:91-93)')
         if not DISTANCES[activation_distance]:
             raise NotImplementedError("activation_distance '%s' is not in the HIP engine yet "
                                       "(SURVEY 8(f) rank 3)" % activation_distance)
         if precision not in ('f32', 'bf16', 'bf16x3'):
             raise ValueError("precision must be 'f32', 'bf16' or 'bf16x3'")
+        # what som_create would refuse is refused here, at construction, as the reference raises at
+        # construction (the engine itself is created lazily, on the first train() / winner())
+        if neighborhood_function == 'mexican_hat' and compact_support:
+            raise NotImplementedError('mexican_hat with compact_support is not supported: the reference masks px '
+                                      'twice and py never (neighborhoods.py:69-71, :91-93), which is neither the '
+                                      'documented neighbourhood nor defined on non-square maps')
+        if precision != 'f32' and activation_distance not in ('euclidean', 'cosine'):
+            raise ValueError("precision '%s' implements the GEMM-form distances 'euclidean' and 'cosine'; "
+                             "'%s' needs precision='f32'" % (precision, activation_distance))
+        if activation_distance.startswith('norm_p'):
+            p = activation_distance_kwargs.get('p', 2)
+            if not isinstance(p, (int, np.integer)) and not (isinstance(p, float) and p.is_integer()):
+                raise NotImplementedError("norm_p: the HIP kernels take an integer exponent p, got %r" % (p,))
+            if not 1 <= int(p) <= 16:
+                raise NotImplementedError("norm_p: exponent p must be in 1..16, got %r" % (p,))
 
         # n_parallel bounded the (n,K) temporaries of the reference (xpysom.py:242-251); nothing of
         # that size exists here, it only sizes host->device staging of winner()/quantization_error().
@@ -145,7 +166,6 @@ class XPySom:
         self._precision = precision
         self._device = device
         self._sharded_input = sharded_input
-        self._engine_factory = _engine_factory
         self._engine_obj = None
 
     # ------------------------------------------------------------------ engine plumbing
@@ -157,15 +177,12 @@ class XPySom:
                       precision=self._precision, topology=self.topology)
             if self._activation_distance_name.startswith('norm_p'):
                 kw['norm_p'] = int(self._activation_distance_kwargs.get('p', 2))
-            if self._engine_factory is not None:
-                self._engine_obj = self._engine_factory(x, y, self._input_len, **kw)
-            else:
-                from .engine import HipEngine
-                dev = self._device
-                if dev is None:
-                    import os
-                    dev = int(os.environ.get('LOCAL_RANK', '0'))
-                self._engine_obj = HipEngine(x, y, self._input_len, device=dev, **kw)
+            from . import engine
+            dev = self._device
+            if dev is None:
+                import os
+                dev = int(os.environ.get('LOCAL_RANK', '0'))
+            self._engine_obj = engine.HipEngine(x, y, self._input_len, device=dev, **kw)
         return self._engine_obj
 
     def _upload_weights(self):
@@ -194,36 +211,45 @@ class XPySom:
     def activate(self, x):
         """Activation map of x: its distance to every unit under the configured distance, shape (n, K)
         (xpysom.py:323-354).  An analysis call: training never materialises this matrix."""
-        x = _host_rows(x)
+        x = _host_rows(x, self._engine)
         if x.ndim == 0:
             x = x.reshape(1, 1)
         elif x.ndim == 1:
             x = x[None, :]
+        if self._activation_distance_name not in ('euclidean', 'euclidean_no_opt', 'cosine'):
+            raise NotImplementedError("activate() returns the (n, K) matrix of the GEMM-form distances only; '%s' is "
+                                      "a fused distance+argmin kernel here (use winner())" % self._activation_distance_name)
         return self._upload_weights().distance_matrix(x)
 
     def distance_from_weights(self, data, weights_gpu=None):
         """d[i, j] = euclidean distance between data[i] and the j-th unit (xpysom.py:647-671)."""
-        data = _host_rows(data)
+        data = _host_rows(data, self._engine)
         return self._upload_weights().distance_matrix(data, quantization=True)
 
     def distance_map(self):
-        """Normalised sum of the distances between each unit and its neighbours (U-matrix),
-        xpysom.py:788-817; host-side, the codebook is tiny next to the data."""
-        w = np.asarray(self._weights)
+        """U-matrix: each unit's summed distance to its map neighbours, scaled to a maximum of 1
+        (xpysom.py:788-817: 8 neighbours on the rectangular grid; 6 on the hexagonal one, whose offsets
+        depend on the parity of the unit's column index j).  One shifted difference per neighbour offset over
+        the whole codebook -- host-side, the codebook is tiny next to the data."""
+        w = np.asarray(self._weights, dtype=np.float64)
         X, Y = w.shape[:2]
-        um = np.zeros((X, Y, 8))
-        ii = [[0, -1, -1, -1, 0, 1, 1, 1]] * 2
-        jj = [[-1, -1, 0, 1, 1, 1, 0, -1]] * 2
         if self.topology == 'hexagonal':
-            ii = [[1, 1, 1, 0, -1, 0], [0, 1, 0, -1, -1, -1]]
-            jj = [[1, 0, -1, -1, 0, 1], [1, 0, -1, -1, 0, 1]]
-        for x in range(X):
-            for y in range(Y):
-                e = y % 2 == 0
-                for k, (i, j) in enumerate(zip(ii[e], jj[e])):
-                    if 0 <= x + i < X and 0 <= y + j < Y:
-                        um[x, y, k] = np.linalg.norm(w[x, y] - w[x + i, y + j])
-        um = um.sum(axis=2)
+            offsets = {1: ((0, 1), (1, 0), (0, -1), (-1, -1), (-1, 0), (-1, 1)),      # even j
+                       0: ((1, 1), (1, 0), (1, -1), (0, -1), (-1, 0), (0, 1))}        # odd j
+        else:
+            ring = tuple((di, dj) for di in (-1, 0, 1) for dj in (-1, 0, 1) if (di, dj) != (0, 0))
+            offsets = {0: ring, 1: ring}
+        um = np.zeros((X, Y))
+        even = (np.arange(Y) % 2 == 0)[None, :]
+        for parity, offs in offsets.items():
+            for di, dj in offs:
+                # units (x, y) with an in-range neighbour (x + di, y + dj)
+                xs = slice(max(0, -di), X - max(0, di))
+                ys = slice(max(0, -dj), Y - max(0, dj))
+                xn = slice(max(0, di), X - max(0, -di))
+                yn = slice(max(0, dj), Y - max(0, -dj))
+                d = np.linalg.norm(w[xs, ys] - w[xn, yn], axis=-1)
+                um[xs, ys] += d * (even[:, ys] == bool(parity))
         return um / um.max()
 
     def _check_input_len(self, data):
@@ -249,12 +275,14 @@ class XPySom:
             if world > 1 and not self._sharded_input:
                 lo, hi = _dist.shard_bounds(len(data), rank, world)
                 data = data[lo:hi]
-            ptr, n, d, dev_index, owner = _device_rows(data)
+            ptr, n, d, dev_index, owner, stream = _device_rows(data)
             eng = self._upload_weights()
             if dev_index is not None and dev_index != eng.device:
                 raise ValueError('device data lives on cuda:%d, the engine on cuda:%d' % (dev_index, eng.device))
             if d != self._input_len:
                 raise ValueError('Received %d features, expected %d.' % (d, self._input_len))
+            if stream != "done":                         # rows of a foreign producer: wait for its stream (or the device)
+                eng.sync_producer(stream)
             eng.set_data_device(ptr, n, keepalive=owner)
         else:
             data = np.asarray(data, dtype=np.float32)
@@ -320,7 +348,7 @@ class XPySom:
     def winner(self, x):
         """Coordinates of the winning neuron(s): ``(i, j)`` for one sample, a list of
         ``(i, j)`` tuples (numpy.int64) for a matrix -- xpysom.py:370-408."""
-        x = _host_rows(x)
+        x = _host_rows(x, self._engine)
         one = x.ndim == 1
         if one:
             x = x[None, :]
@@ -332,8 +360,8 @@ class XPySom:
 
     def quantization(self, data):
         """Assigns a code book (weights vector of the winning neuron) to each sample in data."""
+        data = _host_rows(data, self._engine)
         self._check_input_len(data)
-        data = _host_rows(data)
         ids = self._winner_ids(data, quantization=True)
         w = np.asarray(self._weights)
         return w.reshape(-1, w.shape[2])[ids]
@@ -341,8 +369,8 @@ class XPySom:
     def quantization_error(self, data):
         """Average distance between each input sample and its best matching unit
         (always Euclidean, xpysom.py:673-707).  Returns a Python float."""
+        data = _host_rows(data, self._engine)
         self._check_input_len(data)
-        data = _host_rows(data)
         eng = self._upload_weights()
         total, n = 0.0, 0
         for s in range(0, len(data), self._n_parallel):
@@ -359,7 +387,7 @@ class XPySom:
         if np.prod(self._weights.shape) == 1:
             warn('The topographic error is not defined for a 1-by-1 map.')
             return np.nan
-        data = _host_rows(data)
+        data = _host_rows(data, self._engine)
         eng = self._upload_weights()
         Y = self._weights.shape[1]
         bad, n = 0, 0
@@ -367,11 +395,20 @@ class XPySom:
             b1, b2 = eng.bmu_top2(data[s:s + self._n_parallel])
             i1, j1, i2, j2 = b1 // Y, b1 % Y, b2 // Y, b2 % Y
             if self.topology == 'hexagonal':
-                # euclidean unit coordinates (xpysom.py:201-206): every second row from the last is
-                # shifted by -0.5; not adjacent = farther apart than 1.5 (xpysom.py:739-746)
-                x1 = i1 - 0.5 * ((Y - 1 - j1) % 2 == 0)
-                x2 = i2 - 0.5 * ((Y - 1 - j2) % 2 == 0)
-                bad += int((np.hypot(x1 - x2, (j1 - j2).astype(float)) > 1.5).sum())
+                # not adjacent = farther apart than 1.5 in the hexagonal coordinates (xpysom.py:739-746).  The
+                # reference reads them as _xx[i, j], _yy[i, j] from its UNtransposed (Y, X) meshgrids, i.e.
+                # x = j - s(i)/2, y = i with s marking every second row from the last (xpysom.py:201-206) --
+                # reproduced on square maps (pinned by tests/golden/g13); on a non-square map that indexing
+                # runs out of bounds in the reference, and the unit's own coordinates x = i - s(j)/2, y = j
+                # are used instead (deviations).
+                X = self._weights.shape[0]
+                if X == Y:
+                    x1, y1 = j1 - 0.5 * ((Y - 1 - i1) % 2 == 0), i1
+                    x2, y2 = j2 - 0.5 * ((Y - 1 - i2) % 2 == 0), i2
+                else:
+                    x1, y1 = i1 - 0.5 * ((Y - 1 - j1) % 2 == 0), j1
+                    x2, y2 = i2 - 0.5 * ((Y - 1 - j2) % 2 == 0), j2
+                bad += int((np.hypot(x1 - x2, (y1 - y2).astype(float)) > 1.5).sum())
             else:
                 bad += int(((np.abs(i1 - i2) > 1) | (np.abs(j1 - j2) > 1)).sum())
             n += len(b1)
@@ -379,14 +416,15 @@ class XPySom:
 
     def predict(self, data):
         """Raveled BMU index of every sample (xpysom.py:608-617), batched."""
-        data = _host_rows(data)
+        data = _host_rows(data, self._engine)
         return self._winner_ids(data).astype(np.int64)
 
     def activation_response(self, data):
         """Matrix where element i,j is the number of times neuron i,j won (xpysom.py:819-829)."""
+        data = _host_rows(data, self._engine)
         self._check_input_len(data)
         a = np.zeros(self._weights.shape[:2])
-        ids = self._winner_ids(_host_rows(data))
+        ids = self._winner_ids(data)
         np.add.at(a.reshape(-1), ids, 1)
         return a
 
@@ -436,7 +474,6 @@ class XPySom:
     def __getstate__(self):
         state = self.__dict__.copy()
         state['_engine_obj'] = None          # device handle: rebuilt lazily from (config, weights)
-        state['_engine_factory'] = None
         return state
 
     def __setstate__(self, state):
