@@ -119,6 +119,7 @@ struct som_handle {
     int2* bands = nullptr;   // nonzero column ranges of the neighbourhood tables per 128-row block (update.hpp)
     bool use_bands = true;
 
+    bool async_copies = false;   // SOM_ASYNC_COPIES=1: round 1's original copy path (fresh_process_stress.py)
     bool prof = false;
     std::vector<EventPair> pending, pool;
     double ms[SOM_K_COUNT] = {0};
@@ -169,17 +170,27 @@ int dev_alloc(som_handle* h, T** p, size_t count) {
 }
 
 // Host -> device copy of caller-owned (usually pageable) memory.  Blocking on purpose: the runtime stages
-// pageable sources through its own pinned buffers, and nothing in the API orders the tail of that staging
-// against kernels queued next on a non-blocking stream, so the copy is complete before anything that reads
-// `dst` is launched.  (A wrong tail of the resident rows -- whole 128-row blocks of BMUs off, once, on a fresh
-// box -- is what an early read looks like.)  The stream is drained first: nothing of ours still touches dst.
+// pageable sources through its own pinned buffers; the copy is complete before anything that reads `dst` is
+// launched, and the stream is drained first, so nothing of ours still touches dst.
+// SOM_ASYNC_COPIES=1 restores round 1's original form (hipMemcpyAsync on the engine's stream, no host wait)
+// for tools/fresh_process_stress.py, which exists to confirm or kill the hypothesis that that form produced the
+// one wrong-BMU event on record.
 int h2d_blocking(som_handle* h, void* dst, const void* src, size_t bytes) {
+    if (h->async_copies) {
+        HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+        return 0;
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
     return 0;
 }
 // ... and results back to caller-owned memory, the same way: drain the stream, then a blocking copy.
 int d2h_blocking(som_handle* h, void* dst, const void* src, size_t bytes) {
+    if (h->async_copies) {
+        HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return 0;
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return 0;
@@ -876,6 +887,7 @@ int som_create(const som_config* cfg, som_handle** out) {
         if ((rc = dev_alloc(h, &npd, 1))) return bail(rc);
         h->np_dev = npd;
         if (const char* e = std::getenv("SOM_GRAPH")) h->use_graph = std::atoi(e) != 0;
+        if (const char* e = std::getenv("SOM_ASYNC_COPIES")) h->async_copies = std::atoi(e) != 0;
         // a 128-row block of a table already spans most of a map side up to 256: nothing to skip there
         h->use_bands = h->X > 256 || h->Y > 256;
         if (const char* e = std::getenv("SOM_NO_BANDS")) h->use_bands = std::atoi(e) == 0;
