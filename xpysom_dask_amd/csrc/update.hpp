@@ -25,95 +25,155 @@
 namespace somhip {
 
 // ---- segment sum: SC[b][0..D-1] = sum_{bmu_n = b} x_n ; SC[b][D] = #{bmu_n = b} ------------------
-// The rows are first ordered by BMU (stable radix sort of (bmu_n, n) pairs, rocPRIM), then every
-// wave walks a chunk of SEG_CHUNK consecutive sorted positions, keeps the running sum of the
-// current unit in registers (lane = feature) and adds it to HBM only when the unit changes or the
-// chunk ends.  Row gathers are whole 4*D-byte rows (coalesced per row); float atomics shrink from
-// N rows to about K + N/SEG_CHUNK rows, so the pass is bound by reading X once (N*D*4 bytes).
-// A unit whose run lies inside one chunk (the common case) gets exactly one add onto the zeroed
-// accumulator, a run cut by one chunk boundary two (commutative): those sums are reproducible.
-constexpr int SEG_CHUNK = 32;
+// The rows are first ordered by BMU (stable radix sort of (bmu_n, n) pairs, rocPRIM: the sorted order is a
+// function of the BMUs alone).  Level 0: every wave walks a chunk of SEG_CHUNK consecutive sorted positions and
+// keeps the running sum of the current unit in registers (lane = feature pair); row gathers are whole 4*D-byte
+// rows, eight in flight per wave, so the pass is bound by reading X once (N*D*4 bytes).
+//
+// No atomics, fixed order.  A unit's rows are ONE run of the sorted order.  A run that lies inside one chunk
+// is complete there: the wave adds it to SC[unit] with a plain read-modify-write -- it is the only writer of
+// that unit in the launch.  A run cut by a chunk boundary leaves a PARTIAL instead: chunk w owns the two
+// entries 2w (its first run, if that continues the previous chunk) and 2w+1 (its last run, if the next chunk
+// continues it) of the next level's list (key, vector, count); unused entries carry key -1, and a chunk that is
+// one run open on both sides fills 2w and gives 2w+1 the same key with a zero vector, so that the partials of
+// one unit stay adjacent.  The next level is the same kernel over that list (SEG_CHUNK_UP entries per wave),
+// and so on until one wave holds the whole list (1 Mi rows: 1 048 576 -> 65 536 -> 2 048 -> 64 entries).
+// Every unit's sum is therefore formed in ONE order fixed by (N, the BMUs): two epochs from the same state
+// are bitwise equal, and a unit that wins every row costs log-many tiny passes instead of N/32 serialised
+// atomics on one address.
+constexpr int SEG_CHUNK = 32;      // rows per wave, level 0
+constexpr int SEG_CHUNK_UP = 64;   // partial entries per wave, upper levels
 
 __global__ __launch_bounds__(256) void iota_kernel(int* __restrict__ v, long n) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) v[i] = (int)i;
 }
 
-// VEC2 (D even): a lane owns feature pairs (8-byte loads, one instruction per 128 features of a row) and
-// the rows are fetched eight at a time before the run logic consumes them, so eight rows' loads are in
-// flight per wave.  The additions happen in the same sorted order either way.
-template <bool VEC2>
-__global__ __launch_bounds__(256) void segsum_sorted_kernel(const float* __restrict__ X,
-                                                            const int* __restrict__ skey,
-                                                            const int* __restrict__ srow, long N, int D, int D1p,
-                                                            float* __restrict__ SC) {
+// number of entries of the list a level with n entries and chunk c leaves behind
+__host__ __device__ inline long seg_next_entries(long n, int c) { return 2 * ((n + c - 1) / c); }
+
+// LEVEL0: keys = sorted BMUs, srow = sorted row ids, rows gathered from X (count 1 each).
+// !LEVEL0: keys / vin = the previous level's partial list ([n] keys, [n][D1p] vectors, count in column D).
+// VEC2 (D even): a lane owns feature pairs (8-byte accesses, one instruction per 128 features of a row).
+// accumulate == 0: SC was zeroed and every unit is written at most once in the whole pass: plain stores.
+template <bool LEVEL0, bool VEC2>
+__global__ __launch_bounds__(256) void runsum_kernel(const float* __restrict__ X, const int* __restrict__ keys,
+                                                     const int* __restrict__ srow, const float* __restrict__ vin,
+                                                     long n, int D, int D1p, int accumulate, float* __restrict__ SC,
+                                                     int* __restrict__ kout, float* __restrict__ vout) {
+    constexpr int C = LEVEL0 ? SEG_CHUNK : SEG_CHUNK_UP;
     const int lane = threadIdx.x & 63;
     const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long p0 = wid * SEG_CHUNK;
-    if (p0 >= N) return;
-    const int cnt_here = (int)((N - p0 < SEG_CHUNK) ? (N - p0) : SEG_CHUNK);
-    // lane i < cnt_here holds the i-th (unit, row) pair of the chunk
-    const int my_key = lane < cnt_here ? skey[p0 + lane] : -1;
-    const int my_row = lane < cnt_here ? srow[p0 + lane] : 0;
+    const long p0 = wid * C;
+    if (p0 >= n) return;
+    const int cnt_here = (int)((n - p0 < C) ? (n - p0) : C);
+    // lane i < cnt_here holds the i-th (key, row) of the chunk
+    const int my_key = lane < cnt_here ? keys[p0 + lane] : -1;
+    const int my_row = (LEVEL0 && lane < cnt_here) ? srow[p0 + lane] : 0;
+    const float my_cnt = LEVEL0 ? 1.0f : ((lane < cnt_here && my_key >= 0) ? vin[(p0 + lane) * D1p + D] : 0.0f);
+    const int first_key = __builtin_amdgcn_readfirstlane(my_key);
+    const int last_key = __builtin_amdgcn_readlane(my_key, cnt_here - 1);
+    const int prev_key = p0 > 0 ? keys[p0 - 1] : -2;
+    const int next_key = p0 + cnt_here < n ? keys[p0 + cnt_here] : -2;
+    const bool open_left = first_key >= 0 && __builtin_amdgcn_readfirstlane(prev_key) == first_key;
+    const bool open_right = last_key >= 0 && __builtin_amdgcn_readfirstlane(next_key) == last_key;
+    int slot_key[2] = {-1, -1};
+    bool slot1_zero = false;
+
     for (int f0 = 0; f0 < D; f0 += 256) {                 // 4 features per lane per sweep
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        int cur = __builtin_amdgcn_readfirstlane(my_key);
-        int run = 0;
+        int cur = first_key;
+        int run_begin = 0;
+        float run = 0.f;
         // feature of acc[j]: VEC2: f0 + 128*(j>>1) + 2*lane + (j&1);  scalar: f0 + lane + 64*j
         auto feat = [&](int j) { return VEC2 ? f0 + 128 * (j >> 1) + 2 * lane + (j & 1) : f0 + lane + 64 * j; };
-        auto flush = [&]() {
+        auto put = [&](float* dst, bool add) {            // this lane's 4 sums (and the count) into one row
+            if (VEC2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int d = feat(j);
-                if (d < D) unsafeAtomicAdd(&SC[(long)cur * D1p + d], acc[j]);
-                acc[j] = 0.f;
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int d = f0 + 128 * jj + 2 * lane;
+                    if (d < D) {
+                        float2 t = make_float2(acc[2 * jj], acc[2 * jj + 1]);
+                        if (add) { const float2 o = *(const float2*)(dst + d); t.x += o.x; t.y += o.y; }
+                        *(float2*)(dst + d) = t;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int d = feat(j);
+                    if (d < D) dst[d] = add ? dst[d] + acc[j] : acc[j];
+                }
             }
-            if (f0 == 0 && lane == 0) unsafeAtomicAdd(&SC[(long)cur * D1p + D], (float)run);
+            if (f0 == 0 && lane == 0) dst[D] = add ? dst[D] + run : run;
         };
-        if (VEC2) {
-            for (int i0 = 0; i0 < cnt_here; i0 += 8) {
-                float v[8][4];
+        auto flush = [&](int end) {                       // the run [run_begin, end) of unit `cur` is complete in this chunk
+            if (cur >= 0) {
+                const bool first = run_begin == 0, last = end == cnt_here;
+                if (first && open_left) {
+                    put(vout + (2 * wid) * (long)D1p, false);
+                    slot_key[0] = cur;
+                    if (last && open_right) { slot_key[1] = cur; slot1_zero = true; }
+                } else if (last && open_right) {
+                    put(vout + (2 * wid + 1) * (long)D1p, false);
+                    slot_key[1] = cur;
+                } else {
+                    put(SC + (long)cur * D1p, accumulate != 0);
+                }
+            }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = i0 + u;
-                    const long row = __builtin_amdgcn_readlane(my_row, i < cnt_here ? i : 0);
-                    const float* x = X + row * D;
+            for (int j = 0; j < 4; ++j) acc[j] = 0.f;
+            run = 0.f;
+        };
+        auto entry_ptr = [&](int i) -> const float* {     // vector of the chunk's i-th entry (i uniform)
+            if (LEVEL0) return X + (long)__builtin_amdgcn_readlane(my_row, i) * D;
+            return vin + (p0 + i) * (long)D1p;
+        };
+        for (int i0 = 0; i0 < cnt_here; i0 += 8) {
+            float v[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u;
+                const int ii = i < cnt_here ? i : 0;
+                const bool live = i < cnt_here && __builtin_amdgcn_readlane(my_key, ii) >= 0;
+                const float* x = entry_ptr(ii);
+                if (VEC2) {
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         const int d = f0 + 128 * jj + 2 * lane;
                         float2 t = make_float2(0.f, 0.f);
-                        if (i < cnt_here && d < D) t = *(const float2*)(x + d);   // D even: d + 1 < D, 8-byte aligned
+                        if (live && d < D) t = *(const float2*)(x + d);   // D even: d + 1 < D, 8-byte aligned
                         v[u][2 * jj] = t.x; v[u][2 * jj + 1] = t.y;
                     }
-                }
+                } else {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = i0 + u;
-                    if (i < cnt_here) {
-                        const int b = __builtin_amdgcn_readlane(my_key, i);
-                        if (b != cur) { flush(); cur = b; run = 0; }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[j] += v[u][j];
-                        ++run;
+                    for (int j = 0; j < 4; ++j) {
+                        const int d = f0 + lane + 64 * j;
+                        v[u][j] = (live && d < D) ? x[d] : 0.f;
                     }
                 }
             }
-        } else {
-            for (int i = 0; i < cnt_here; ++i) {
-                const int b = __builtin_amdgcn_readlane(my_key, i);
-                const long row = __builtin_amdgcn_readlane(my_row, i);
-                if (b != cur) { flush(); cur = b; run = 0; }
-                const float* x = X + row * D;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int d = f0 + lane + 64 * j;
-                    if (d < D) acc[j] += x[d];
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u;
+                if (i < cnt_here) {
+                    const int b = __builtin_amdgcn_readlane(my_key, i);
+                    if (b != cur) { flush(i); cur = b; run_begin = i; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] += v[u][j];
+                    run += __builtin_amdgcn_readlane(my_cnt, i);
                 }
-                ++run;
             }
         }
-        flush();
+        flush(cnt_here);
+        if (slot1_zero) {                                 // one run, open on both sides: entry 2w+1 = (key, 0)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = 0.f;
+            run = 0.f;
+            put(vout + (2 * wid + 1) * (long)D1p, false);
+        }
     }
+    if (lane == 0) { kout[2 * wid] = slot_key[0]; kout[2 * wid + 1] = slot_key[1]; }
 }
 
 // ---- neighbourhood factor tables ---------------------------------------------------------------
