@@ -985,3 +985,53 @@ def test_support_mask_at_a_sigma_one_ulp_off_an_integer():
         _, onum, oden = O.update(data, w, 0.5, sigma, wide=False, neighbourhood=neigh, compact=compact, forced_bmu=bmu)
         assert rel_err(num, onum.reshape(-1, D)) < 1e-5, neigh
         assert rel_err(den, oden.reshape(-1)) < 1e-5, neigh
+
+
+# ----------------------------------------------------------------------------- segment sum: fixed order, no atomics
+@pytest.mark.parametrize("D", [6, 7, 130])
+def test_segment_sum_is_bitwise_reproducible_and_skew_proof(D):
+    """The BMU-ordered segment sum forms every unit's sum in ONE order fixed by (N, the BMUs) (csrc/update.hpp):
+    two passes over the same state are bitwise equal, whatever the run lengths -- runs inside one 32-row chunk,
+    runs cut by one or many chunk boundaries, one unit winning every row, units with no rows."""
+    X, Y, n = 9, 8, 20000
+    K = X * Y
+    data = O.gaussian_blobs(n, D, seed=31)
+    w = O.default_codebook(X, Y, D, 3).astype(F32)
+    rs = np.random.RandomState(5)
+    lengths = [1, 31, 32, 33, 63, 64, 65, 1, 1, 2047, 2048, 2049, 4096 + 17, 3, 700]
+    units = rs.permutation(K)[:len(lengths)]
+    cut = np.repeat(units, lengths)
+    patterns = {
+        "one unit wins all": np.full(n, 37),
+        "long and short runs": np.concatenate([cut, rs.randint(0, K, size=n - len(cut))]),
+        "random": rs.randint(0, K, size=n),
+        "two units": np.where(np.arange(n) % 3 == 0, 5, 70),
+    }
+    e = engine(X, Y, D)
+    e.set_weights(w)
+    e.set_data(data)
+    for name, bmu in patterns.items():
+        bmu = rs.permutation(bmu).astype(np.int32) if name == "long and short runs" else bmu.astype(np.int32)
+        e.epoch_accumulate_forced(bmu, 2.0, 0.4, True)
+        num1, den1, _ = e.epoch_fetch(want_bmu=False)
+        e.epoch_accumulate_forced(bmu, 2.0, 0.4, True)
+        num2, den2, _ = e.epoch_fetch(want_bmu=False)
+        assert np.array_equal(num1, num2) and np.array_equal(den1, den2), name
+        _, onum, oden = O.update(data, w, np.float64(0.4), np.float64(2.0), wide=True, forced_bmu=bmu)
+        assert rel_err(num1, onum.reshape(-1, D)) < 2e-6, name
+        assert rel_err(den1, oden.reshape(-1)) < 2e-6, name
+    # the same sums when the rows arrive as streamed chunks (added to the running sums, chunk after chunk)
+    bmu = patterns["random"].astype(np.int32)
+    e.epoch_accumulate_forced(bmu, 2.0, 0.4, True)
+    num1, den1, _ = e.epoch_fetch(want_bmu=False)
+    e2 = engine(X, Y, D)
+    e2.set_weights(w)
+    e2.set_data(data)
+    e2.epoch_accumulate(2.0, 0.4, True)
+    numr, denr, bmur = e2.epoch_fetch()
+    e2.stream_epoch_accumulate([data[:7001], data[7001:7002], data[7002:]], 2.0, 0.4, True)
+    nums, dens, _ = e2.epoch_fetch(want_bmu=False)
+    assert rel_err(nums, numr) < 2e-6 and rel_err(dens, denr) < 2e-6
+    e2.stream_epoch_accumulate([data[:7001], data[7001:7002], data[7002:]], 2.0, 0.4, True)
+    nums2, dens2, _ = e2.epoch_fetch(want_bmu=False)
+    assert np.array_equal(nums, nums2) and np.array_equal(dens, dens2)

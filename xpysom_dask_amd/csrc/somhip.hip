@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/somhip.h"
@@ -75,9 +76,16 @@ struct som_handle {
     unsigned long long* best64 = nullptr;   // bf16 path: per-row (value bits | unit) merged across codebook parts
     long best64_cap = 0;
     int n_cus = 0;
-    int *iota = nullptr, *skey = nullptr, *srow = nullptr;   // BMU-ordered view of the rows (segment sum)
-    void* sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
+    // BMU-ordered view of a row set + the partial lists of the segment sum's upper levels (update.hpp)
+    struct SegScratch {
+        int *iota = nullptr, *skey = nullptr, *srow = nullptr;
+        void* tmp = nullptr;
+        size_t tmp_bytes = 0;
+        int *kA = nullptr, *kB = nullptr;        // keys of the level-1 / level-2 lists (ping-pong from there on)
+        float *vA = nullptr, *vB = nullptr;      // their vectors [entries][D1p]
+        long cap = 0;                            // rows this scratch serves
+    };
+    SegScratch seg;                              // resident rows
     float* xsq = nullptr;
     __bf16* Xb = nullptr;
     float* xmax2 = nullptr;  // [0] resident rows, [1] query scratch: max_n |x~_n|^2
@@ -89,10 +97,7 @@ struct som_handle {
     long qcap = 0;
     double* dsum = nullptr;
     // streamed epochs (rows that do not stay resident): per-chunk sort scratch, grown on demand
-    int *st_iota = nullptr, *st_skey = nullptr, *st_srow = nullptr;
-    void* st_tmp = nullptr;
-    size_t st_tmp_bytes = 0;
-    long st_cap = 0;
+    SegScratch st_seg;
     bool streaming = false;
     // double-buffered device staging for chunks that arrive in pinned host memory
     struct Slot {
@@ -666,22 +671,71 @@ hipError_t sort_bmu_pairs_storage(size_t& bytes, K* kin, K* kout, V* vin, V* vou
 
 // ---- update path: segment sum + separable neighbourhood transform --------------------------
 // SC[b] += sum of the rows whose BMU is b (and their count): sort by BMU, chunked register sums
-int segsum_rows(som_handle* h, const float* X, const int* bmu, long N, const int* iota, int* skey, int* srow,
-                void* tmp, size_t tmp_bytes, bool zero_first) {
+void seg_free(som_handle::SegScratch& sg) {
+    void* b[] = {sg.iota, sg.skey, sg.srow, sg.tmp, sg.kA, sg.kB, sg.vA, sg.vB};
+    for (void* p : b) if (p) (void)hipFree(p);
+    sg = som_handle::SegScratch();
+}
+
+// scratch for the segment sum of up to `rows` rows (sort buffers + the partial lists of levels 1 and 2;
+// level 3 reuses level 1's, and so on)
+int seg_reserve(som_handle* h, som_handle::SegScratch& sg, long rows) {
+    if (rows <= sg.cap) return 0;
+    seg_free(sg);
+    if (rows > 0x7fffffffL) return fail(h, "more than 2^31-1 rows per GPU in one row set");
+    if (int rc = dev_alloc(h, &sg.iota, (size_t)rows)) return rc;
+    if (int rc = dev_alloc(h, &sg.skey, (size_t)rows)) return rc;
+    if (int rc = dev_alloc(h, &sg.srow, (size_t)rows)) return rc;
+    iota_kernel<<<dim3((unsigned)cdiv(rows, 256)), dim3(256), 0, h->stream>>>(sg.iota, rows);
+    size_t bytes = 0;
+    hipError_t e = sort_bmu_pairs_storage(bytes, sg.skey, sg.skey, sg.iota, sg.srow, rows, 32u, h->stream);
+    if (e != hipSuccess) return fail_hip(h, "rocprim::radix_sort_pairs(size query)", e);
+    if (int rc = dev_alloc(h, (char**)&sg.tmp, bytes)) return rc;
+    sg.tmp_bytes = bytes;
+    const long n1 = seg_next_entries(rows, SEG_CHUNK), n2 = seg_next_entries(n1, SEG_CHUNK_UP);
+    if (int rc = dev_alloc(h, &sg.kA, (size_t)n1)) return rc;
+    if (int rc = dev_alloc(h, &sg.vA, (size_t)n1 * h->D1p)) return rc;
+    if (int rc = dev_alloc(h, &sg.kB, (size_t)n2)) return rc;
+    if (int rc = dev_alloc(h, &sg.vB, (size_t)n2 * h->D1p)) return rc;
+    sg.cap = rows;
+    return 0;
+}
+
+template <bool LEVEL0>
+void launch_runsum(som_handle* h, const float* X, const int* keys, const int* srow, const float* vin, long n,
+                   int accumulate, int* kout, float* vout) {
+    const long waves = cdiv(n, LEVEL0 ? SEG_CHUNK : SEG_CHUNK_UP);
+    const dim3 grid((unsigned)cdiv(waves, 4)), block(256);
+    if ((h->D & 1) == 0)
+        runsum_kernel<LEVEL0, true><<<grid, block, 0, h->stream>>>(X, keys, srow, vin, n, h->D, h->D1p, accumulate, h->SC, kout, vout);
+    else
+        runsum_kernel<LEVEL0, false><<<grid, block, 0, h->stream>>>(X, keys, srow, vin, n, h->D, h->D1p, accumulate, h->SC, kout, vout);
+}
+
+// SC[b] += sum of the rows whose BMU is b (and their count): sort by BMU, then the levels of update.hpp's
+// run sum (rows -> partial lists) until one wave holds the whole list.  zero_first: SC starts from zero and
+// every unit is written once (plain stores); otherwise the chunk's sums are added to what SC holds.
+int segsum_rows(som_handle* h, const float* X, const int* bmu, long N, som_handle::SegScratch& sg, bool zero_first) {
     Timed t(h, SOM_K_SEGSUM);
     if (zero_first) HIPCHK(h, hipMemsetAsync(h->SC, 0, (size_t)h->K * h->D1p * sizeof(float), h->stream));
     if (N > 0) {
+        if (N > sg.cap) return fail(h, "segment sum: scratch smaller than the row set");
         int bits = 1;
         while ((1L << bits) < h->K) ++bits;
-        hipError_t e = sort_bmu_pairs(N, tmp, tmp_bytes, bmu, skey, iota, srow, (size_t)N, 0u, (unsigned)bits, h->stream);
+        hipError_t e = sort_bmu_pairs(N, sg.tmp, sg.tmp_bytes, bmu, sg.skey, sg.iota, sg.srow, (size_t)N, 0u, (unsigned)bits, h->stream);
         if (e != hipSuccess) return fail_hip(h, "rocprim::radix_sort_pairs", e);
+        const int acc = zero_first ? 0 : 1;
+        launch_runsum<true>(h, X, sg.skey, sg.srow, nullptr, N, acc, sg.kA, sg.vA);
         long waves = cdiv(N, SEG_CHUNK);
-        if ((h->D & 1) == 0)
-            segsum_sorted_kernel<true><<<dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, h->stream>>>(X, skey, srow, N, h->D,
-                                                                                                 h->D1p, h->SC);
-        else
-            segsum_sorted_kernel<false><<<dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, h->stream>>>(X, skey, srow, N, h->D,
-                                                                                                  h->D1p, h->SC);
+        int *kin = sg.kA, *kout = sg.kB;
+        float *vin = sg.vA, *vout = sg.vB;
+        while (waves > 1) {                              // 2 * waves entries are waiting in (kin, vin)
+            const long n = 2 * waves;
+            launch_runsum<false>(h, nullptr, kin, nullptr, vin, n, acc, kout, vout);
+            waves = cdiv(n, SEG_CHUNK_UP);
+            std::swap(kin, kout);
+            std::swap(vin, vout);
+        }
         HIPCHK(h, hipGetLastError());
     }
     return 0;
@@ -703,8 +757,7 @@ NeighParams make_neigh_params(const som_handle* h, double sigma, double eta, int
 }
 
 int run_update(som_handle* h, double sigma, double eta, int neigh_f64) {
-    if (int rc = segsum_rows(h, h->Xd, h->bmu, h->N, h->iota, h->skey, h->srow, h->sort_tmp, h->sort_tmp_bytes, true))
-        return rc;
+    if (int rc = segsum_rows(h, h->Xd, h->bmu, h->N, h->seg, true)) return rc;
     return run_transform(h, sigma, eta, neigh_f64);
 }
 
@@ -934,9 +987,11 @@ void som_destroy(som_handle* h) {
     for (auto& ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto& ep : h->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     void* bufs[] = {h->W, h->wsq, h->SC, h->T, h->ACC, h->P1, h->P2, h->Wst, h->X_owned, h->bmu, h->xsq, h->Xb,
-                    h->xmax2, h->wn, h->wmax2, h->qX, h->qbmu, h->qbmu2, h->qxsq, h->qXb, h->dsum, h->iota, h->skey, h->srow,
-                    h->sort_tmp, h->best64, h->Wfst, h->Wfimg, h->ftX, h->st_iota, h->st_skey, h->st_srow, h->st_tmp};
+                    h->xmax2, h->wn, h->wmax2, h->qX, h->qbmu, h->qbmu2, h->qxsq, h->qXb, h->dsum,
+                    h->best64, h->Wfst, h->Wfimg, h->ftX};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    seg_free(h->seg);
+    seg_free(h->st_seg);
     for (auto& sl : h->slot) {
         void* sb[] = {sl.dX, sl.dXb, sl.dxsq, sl.dbmu};
         for (void* b : sb) if (b) (void)hipFree(b);
@@ -965,24 +1020,14 @@ int som_get_weights(som_handle* h, float* w_host) {
 
 static int adopt_rows(som_handle* h, int64_t n_rows) {
     (void)hipFree(h->bmu); (void)hipFree(h->xsq); (void)hipFree(h->Xb);
-    (void)hipFree(h->iota); (void)hipFree(h->skey); (void)hipFree(h->srow); (void)hipFree(h->sort_tmp);
     h->bmu = nullptr; h->xsq = nullptr; h->Xb = nullptr;
-    h->iota = nullptr; h->skey = nullptr; h->srow = nullptr; h->sort_tmp = nullptr; h->sort_tmp_bytes = 0;
+    seg_free(h->seg);
     h->N = n_rows;
     h->Np = round_up(n_rows, ROW_PAD);
+    if (n_rows > 0x7fffffffL) return fail(h, "som_set_data: more than 2^31-1 rows per GPU");
     if (int rc = dev_alloc(h, &h->bmu, (size_t)n_rows)) return rc;
-    if (n_rows > 0) {
-        if (n_rows > 0x7fffffffL) return fail(h, "som_set_data: more than 2^31-1 rows per GPU");
-        if (int rc = dev_alloc(h, &h->iota, (size_t)n_rows)) return rc;
-        if (int rc = dev_alloc(h, &h->skey, (size_t)n_rows)) return rc;
-        if (int rc = dev_alloc(h, &h->srow, (size_t)n_rows)) return rc;
-        iota_kernel<<<dim3((unsigned)cdiv(n_rows, 256)), dim3(256), 0, h->stream>>>(h->iota, n_rows);
-        size_t bytes = 0;
-        hipError_t e = sort_bmu_pairs_storage(bytes, h->bmu, h->skey, h->iota, h->srow, n_rows, 32u, h->stream);
-        if (e != hipSuccess) return fail_hip(h, "rocprim::radix_sort_pairs(size query)", e);
-        if (int rc = dev_alloc(h, (char**)&h->sort_tmp, bytes)) return rc;
-        h->sort_tmp_bytes = bytes;
-    }
+    if (n_rows > 0)
+        if (int rc = seg_reserve(h, h->seg, n_rows)) return rc;
     const bool bf_cos_tiled = h->cfg.precision != SOM_PREC_F32 && h->cfg.distance == SOM_DIST_COSINE && h->tiled;
     if (needs_xsq(h) || bf_cos_tiled) {
         if (int rc = dev_alloc(h, &h->xsq, (size_t)n_rows)) return rc;
@@ -1171,20 +1216,9 @@ int som_stream_rows(som_handle* h, const float* x_host, int64_t n_rows) {
     if (n_rows > 0x7fffffffL) return fail(h, "som_stream_rows: more than 2^31-1 rows in one chunk");
     const bool pinned = is_pinned_host(x_host);
     if (!pinned) if (int rc = ensure_query_scratch(h, n_rows)) return rc;
-    if (n_rows > h->st_cap) {
-        (void)hipFree(h->st_iota); (void)hipFree(h->st_skey); (void)hipFree(h->st_srow); (void)hipFree(h->st_tmp);
-        h->st_iota = h->st_skey = h->st_srow = nullptr; h->st_tmp = nullptr; h->st_cap = 0; h->st_tmp_bytes = 0;
-        long cap = round_up(n_rows, 1024);
-        if (int rc = dev_alloc(h, &h->st_iota, (size_t)cap)) return rc;
-        if (int rc = dev_alloc(h, &h->st_skey, (size_t)cap)) return rc;
-        if (int rc = dev_alloc(h, &h->st_srow, (size_t)cap)) return rc;
-        iota_kernel<<<dim3((unsigned)cdiv(cap, 256)), dim3(256), 0, h->stream>>>(h->st_iota, cap);
-        size_t bytes = 0;
-        hipError_t e = sort_bmu_pairs_storage(bytes, h->qbmu, h->st_skey, h->st_iota, h->st_srow, cap, 32u, h->stream);
-        if (e != hipSuccess) return fail_hip(h, "rocprim::radix_sort_pairs(size query)", e);
-        if (int rc = dev_alloc(h, (char**)&h->st_tmp, bytes)) return rc;
-        h->st_tmp_bytes = bytes;
-        h->st_cap = cap;
+    if (n_rows > h->st_seg.cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));       // earlier chunks' kernels still read the old scratch
+        if (int rc = seg_reserve(h, h->st_seg, round_up(n_rows, 1024))) return rc;
     }
     const size_t bytes = (size_t)n_rows * h->D * sizeof(float);
     if (pinned) {
@@ -1205,9 +1239,7 @@ int som_stream_rows(som_handle* h, const float* x_host, int64_t n_rows) {
         if (h->cfg.precision != SOM_PREC_F32)
             if (int rc = prep_rows_bf16(h, sl.dX, n_rows, round_up(n_rows, ROW_PAD), sl.dXb, h->xmax2 + 1, sl.dxsq)) return rc;
         if (int rc = run_activation_bmu(h, sl.dX, n_rows, sl.dxsq, sl.dXb, h->xmax2 + 1, sl.dbmu)) return rc;
-        if (int rc = segsum_rows(h, sl.dX, sl.dbmu, n_rows, h->st_iota, h->st_skey, h->st_srow, h->st_tmp,
-                                 h->st_tmp_bytes, false))
-            return rc;
+        if (int rc = segsum_rows(h, sl.dX, sl.dbmu, n_rows, h->st_seg, false)) return rc;
         HIPCHK(h, hipEventRecord(sl.consumed, h->stream));
         sl.used = true;
         return 0;
@@ -1218,9 +1250,7 @@ int som_stream_rows(som_handle* h, const float* x_host, int64_t n_rows) {
     if (h->cfg.precision != SOM_PREC_F32)
         if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1, h->qxsq)) return rc;
     if (int rc = run_activation_bmu(h, h->qX, n_rows, h->qxsq, h->qXb, h->xmax2 + 1, h->qbmu)) return rc;
-    if (int rc = segsum_rows(h, h->qX, h->qbmu, n_rows, h->st_iota, h->st_skey, h->st_srow, h->st_tmp, h->st_tmp_bytes,
-                             false))
-        return rc;
+    if (int rc = segsum_rows(h, h->qX, h->qbmu, n_rows, h->st_seg, false)) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }

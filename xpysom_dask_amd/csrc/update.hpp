@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void runsum_kernel(const float* __restrict__ X
                     if (b != cur) { flush(i); cur = b; run_begin = i; }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[j] += v[u][j];
-                    run += __builtin_amdgcn_readlane(my_cnt, i);
+                    run += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_cnt), i));
                 }
             }
         }
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void runsum_kernel(const float* __restrict__ X
             put(vout + (2 * wid + 1) * (long)D1p, false);
         }
     }
-    if (lane == 0) { kout[2 * wid] = slot_key[0]; kout[2 * wid + 1] = slot_key[1]; }
+    if (lane == 0 && kout != nullptr) { kout[2 * wid] = slot_key[0]; kout[2 * wid + 1] = slot_key[1]; }
 }
 
 // ---- neighbourhood factor tables ---------------------------------------------------------------
