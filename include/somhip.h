@@ -112,6 +112,19 @@ int som_epoch_accumulate(som_handle* h, double sigma, double eta, int neigh_f64)
 int som_epoch_merge(som_handle* h);
 int som_epoch(som_handle* h, double sigma, double eta, int neigh_f64);
 
+/* som_epoch_accumulate in stages, for a host that overlaps the all-reduce with the tail of the epoch (the fused
+ * accumulator is K*(D+1) floats -- 823 MB at 512x512x784 -- and the reference's gather/sum of it, xpysom.py:555-558,
+ * is the one exchange step of the path):
+ *   som_epoch_accumulate_begin    BMUs, segment sums, neighbourhood tables, stage 1 of the separable transform
+ *   som_epoch_block_count         number of map-row blocks of stage 2 (128 map rows each, in order)
+ *   som_epoch_accumulate_block    stage 2 of block b; afterwards floats [offset, offset + n_floats) of the
+ *                                 accumulator (som_accum_device_ptr) are final and may be all-reduced on another
+ *                                 stream (ordered behind som_get_stream's) while the next block is computed.
+ * All blocks, then som_epoch_merge, equal som_epoch_accumulate + som_epoch_merge bit for bit. */
+int som_epoch_accumulate_begin(som_handle* h, double sigma, double eta, int neigh_f64);
+int som_epoch_block_count(som_handle* h, int32_t* n_blocks);
+int som_epoch_accumulate_block(som_handle* h, int32_t block, int64_t* offset, int64_t* n_floats);
+
 /* The same epoch for rows that do NOT stay resident (more rows than HBM holds, or a producer that
  * hands them over chunk by chunk -- what the reference gets from Dask blocks, xpysom.py:545-556):
  *   som_stream_begin                  w_sq cache, zero the segment sums

@@ -1,7 +1,8 @@
 """One rank of the N > 1 GPU tests (tests/test_gpu_distributed.py): launched by torch.distributed.run,
 trains through the PRODUCT path (XPySom -> HipEngine -> libsomhip) and saves what the test compares.
 
-    dist_worker.py <backend> <out_dir> <mode>     mode: full | sharded | stream | bf16
+    dist_worker.py <backend> <out_dir> <mode>     mode: full | sharded | stream | bf16 | wide
+(wide: a 130-row map, i.e. two 128-row blocks of the accumulator, for the blockwise all-reduce: SOM_OVERLAP=0/1)
 """
 import os
 import sys
@@ -34,7 +35,7 @@ def main():
 
         def feed(som, data, T, **kw):
             lo, hi = D.shard_bounds(len(data), rank, world)
-            if mode in ("full", "bf16"):
+            if mode in ("full", "bf16", "wide"):
                 som.train(data, T, **kw)                      # every rank passes all rows and keeps its slice
             elif mode == "sharded":
                 som.train(data[lo:hi], T, **kw)
@@ -49,7 +50,7 @@ def main():
         feed(som, small, 6)
         np.save(os.path.join(out_dir, "ws_%s_%d.npy" % (mode, rank)), som._weights)
         # (b) one teacher-forced epoch (iteration 2 of 5) of a mid-size map from the seeded codebook
-        X, Y, Dm, n, T = 24, 20, 16, 6001, 5
+        X, Y, Dm, n, T = (130, 6, 16, 6001, 5) if mode == "wide" else (24, 20, 16, 6001, 5)
         data = O.gaussian_blobs(n, Dm, seed=11)
         som = XPySom(X, Y, Dm, random_seed=3, decay_function="linear", device=dev, precision=prec, sharded_input=sharded)
         feed(som, data, T, iter_beg=2, iter_end=3)

@@ -30,8 +30,8 @@ def _free_port():
     return p
 
 
-def _launch(backend, out_dir, mode, world=2):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+def _launch(backend, out_dir, mode, world=2, **extra_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(REPO, "tests", "dist_worker.py"), backend, str(out_dir), mode]
@@ -82,16 +82,29 @@ def test_two_ranks_bf16_precision_under_gloo(tmp_path):
     assert np.isfinite(ws).all() and ws.shape == ref_small.shape   # (six bf16 epochs of a 42-unit map wander off f32's)
 
 
+def test_blockwise_allreduce_equals_the_monolithic_one(tmp_path):
+    """The overlapped epoch (all-reduce of finished 128-row blocks of the accumulator while the next block's
+    transform runs; distributed._epoch_overlapped) against one all-reduce of the whole buffer: two ranks, a map of
+    two blocks, results equal bit for bit."""
+    a, b = tmp_path / "mono", tmp_path / "blocks"
+    a.mkdir(); b.mkdir()
+    _launch("gloo", a, "wide", SOM_OVERLAP="0")
+    _launch("gloo", b, "wide", SOM_OVERLAP="1")
+    for x, y in zip(_check(a, "wide"), _check(b, "wide")):
+        assert np.array_equal(x, y)
+
+
 def test_two_ranks_under_rccl(tmp_path):
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (the driver's multi-GPU node)")
-    for mode in ("full", "stream"):
+    for mode in ("full", "stream", "wide"):
         _launch("nccl", tmp_path, mode)
         ws, w, _ = _check(tmp_path, mode)
         _, ref_small, ref_epoch = _references()
         np.testing.assert_allclose(ws, ref_small, rtol=2e-5, atol=2e-6)
-        np.testing.assert_allclose(w, ref_epoch, rtol=2e-5, atol=2e-6)
+        if mode != "wide":                                     # (wide: another map; rank-to-rank equality above)
+            np.testing.assert_allclose(w, ref_epoch, rtol=2e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])

@@ -500,6 +500,19 @@ t.mul_(0.5); torch.cuda.synchronize()
 D.epoch(e, 3.0, 0.4, True)
 _, _, _, want = O.epoch(data, w.reshape(9, 8, 6), 0.4, 3.0, wide=True, n_parallel=500)
 assert np.abs(e.get_weights().reshape(9, 8, 6) - want).max() < 1e-5
+# the blockwise form (all-reduce of finished 128-row blocks on a second stream, under the next block's transform):
+# a 300-row map = three blocks, RCCL on its own stream, same epoch as the monolithic form bit for bit
+data = O.gaussian_blobs(3000, 6, seed=3)
+w = O.default_codebook(300, 5, 6, 4).astype(np.float32)
+outs = []
+for overlap in ("0", "1"):
+    os.environ["SOM_OVERLAP"] = overlap
+    e = HipEngine(300, 5, 6)
+    e.set_weights(w); e.set_data(data)
+    for sig, eta in ((9.0, 0.5), (4.0, 0.3), (2.0, 0.2)):
+        D.epoch(e, sig, eta, True)
+    outs.append(e.get_weights())
+assert np.array_equal(outs[0], outs[1])
 dist.destroy_process_group()
 print("nccl-path-ok")
 """
@@ -1035,3 +1048,76 @@ def test_segment_sum_is_bitwise_reproducible_and_skew_proof(D):
     e2.stream_epoch_accumulate([data[:7001], data[7001:7002], data[7002:]], 2.0, 0.4, True)
     nums2, dens2, _ = e2.epoch_fetch(want_bmu=False)
     assert np.array_equal(nums, nums2) and np.array_equal(dens, dens2)
+
+
+@pytest.mark.parametrize("D", [128, 100, 20])
+def test_fused_merge_and_operand_preparation(D, monkeypatch):
+    """Round 2's launch-level fusion on the bf16 path -- merge + next epoch's operand preparation in one kernel --
+    against the separate launches.  The first epoch
+    (operands prepared the same way on both sides) and its merge are bitwise equal; from then on the fused kernel
+    sums |w~|^2 in another order than prep_wnorm_kernel, so a few bf16 near-ties may fall the other way."""
+    X, Y, n = 20, 24, 5000
+    data = O.gaussian_blobs(n, D, seed=77)
+    w = O.default_codebook(X, Y, D, 9).astype(F32)
+    outs = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("SOM_FUSE_MERGE", fuse)
+        e = engine(X, Y, D, precision="bf16")
+        e.set_weights(w)
+        e.set_data(data)
+        trace = []
+        for t, (sig, eta) in enumerate([(8.0, 0.5), (4.0, 0.3), (1.5, 0.1), (0.4, 0.05)]):   # 0.4: den == 0 for most units
+            e.epoch_accumulate(sig, eta, t % 2 == 0)
+            num, den, bmu = e.epoch_fetch()
+            e.epoch_merge()
+            trace.append((bmu, e.get_weights(), num, den))
+        outs.append(trace)
+    (b0, w0, n0, d0), (b1, w1, n1, d1) = outs[0][0], outs[1][0]
+    assert np.array_equal(b0, b1) and np.array_equal(n0, n1) and np.array_equal(d0, d1) and np.array_equal(w0, w1)
+    for (b0, w0, _, _), (b1, w1, _, _) in zip(outs[0][1:], outs[1][1:]):
+        assert (b0 != b1).mean() < 0.01
+        assert np.abs(w0 - w1).mean() < 2e-3 * np.abs(w0).max()    # (a flipped near-tie moves a small unit's mean)
+    # the fused operands alone: same state in, a second engine's BMUs through freshly prepared operands
+    monkeypatch.setenv("SOM_FUSE_MERGE", "1")
+    e = engine(X, Y, D, precision="bf16")
+    e.set_weights(w)
+    e.set_data(data)
+    e.epoch(8.0, 0.5, True)                                    # merge + fused operand preparation
+    e.epoch_accumulate(4.0, 0.3, True)
+    _, _, bmu_fused = e.epoch_fetch()
+    e2 = engine(X, Y, D, precision="bf16")
+    e2.set_weights(outs[1][0][1])                             # the same merged codebook, prepared the ordinary way
+    e2.set_data(data)
+    e2.epoch_accumulate(4.0, 0.3, True)
+    _, _, bmu_plain = e2.epoch_fetch()
+    diff = np.flatnonzero(bmu_fused != bmu_plain)
+    assert len(diff) <= n // 100 and bf16_misses_are_near_best(data, outs[1][0][1], bmu_fused, diff)
+
+
+def test_staged_epoch_equals_the_monolithic_one():
+    """som_epoch_accumulate_begin + one som_epoch_accumulate_block per 128-row map block (the form the overlapped
+    all-reduce uses) leaves the accumulator of som_epoch_accumulate, bit for bit, and reports disjoint slices that
+    tile it."""
+    for (X, Y, D, neigh, topo) in ((300, 40, 9, "gaussian", "rectangular"), (129, 130, 20, "mexican_hat", "hexagonal"), (20, 24, 128, "gaussian", "rectangular")):
+        n = 4000
+        data = O.gaussian_blobs(n, D, seed=5)
+        w = O.default_codebook(X, Y, D, 6).astype(F32)
+        e = engine(X, Y, D, neighborhood=neigh, topology=topo)
+        e.set_weights(w)
+        e.set_data(data)
+        e.epoch_accumulate(3.0, 0.4, True)
+        num0, den0, bmu0 = e.epoch_fetch()
+        e.epoch_accumulate_begin(3.0, 0.4, True)
+        nb = e.epoch_block_count()
+        assert nb == -(-X // 128)
+        at = 0
+        for b in range(nb):
+            off, cnt = e.epoch_accumulate_block(b)
+            assert off == at and cnt > 0
+            at += cnt
+        assert at == X * Y * (-(-(D + 1) // 4) * 4)
+        num1, den1, bmu1 = e.epoch_fetch()
+        assert np.array_equal(bmu0, bmu1) and np.array_equal(num0, num1) and np.array_equal(den0, den1)
+        from xpysom_dask_amd.engine import SomHipError
+        with pytest.raises(SomHipError):
+            e.epoch_accumulate_block(0)                        # no epoch in progress

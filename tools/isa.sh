@@ -2,7 +2,7 @@
 # usage: scratch/isa.sh <kernel-name-substring>  -> dumps ISA of that kernel to /tmp/somtemps/k.s and prints stats
 set -e
 mkdir -p /tmp/somtemps/b && cd /tmp/somtemps/b
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics /root/repo/xpysom_dask_amd/csrc/somhip.hip -o x.so -save-temps 2>/dev/null
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared /root/repo/xpysom_dask_amd/csrc/somhip.hip -o x.so -save-temps 2>/dev/null
 S=$(ls *gfx950*.s | head -1)
 L=$(grep -n "^_ZN6somhip.*$1.*:" $S | head -1 | cut -d: -f1)
 E=$(awk -v s=$L 'NR>s && /s_endpgm/ {print NR; exit}' $S)

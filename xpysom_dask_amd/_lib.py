@@ -44,6 +44,9 @@ SIGNATURES = {
     "som_epoch_accumulate": (C.c_int, [_H, C.c_double, C.c_double, C.c_int]),
     "som_epoch_merge": (C.c_int, [_H]),
     "som_epoch": (C.c_int, [_H, C.c_double, C.c_double, C.c_int]),
+    "som_epoch_accumulate_begin": (C.c_int, [_H, C.c_double, C.c_double, C.c_int]),
+    "som_epoch_block_count": (C.c_int, [_H, C.POINTER(C.c_int32)]),
+    "som_epoch_accumulate_block": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "som_pinned_alloc": (C.c_int, [C.c_uint64, C.POINTER(C.c_void_p)]),
     "som_pinned_free": (C.c_int, [C.c_void_p]),
     "som_stream_begin": (C.c_int, [_H]),

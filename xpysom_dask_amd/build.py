@@ -64,7 +64,7 @@ def build(force=False, verbose=True, extra=(), out=None):
     if not force and not extra and up_to_date():
         return OUT
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-munsafe-fp-atomics", "-Wall", "-Wno-unused-command-line-argument",
+           "-Wall", "-Wno-unused-command-line-argument",
            '-DSOM_SRC_HASH="%s"' % source_hash(),
            SRC, "-o", out or OUT, "-Wl,-rpath,/opt/rocm/lib"] + list(extra)
     if verbose:

@@ -89,11 +89,14 @@ __global__ __launch_bounds__(256) void prep_wnorm_kernel(const float* __restrict
 }
 
 // initial accumulators  B + |w~|^2/2  written behind each stage's fragments; B from the two maxima
+// (+ the launch's per-row merge keys best64[0..n_rows) = all ones, when given: one launch instead of a memset and a kernel)
 __global__ __launch_bounds__(256) void prep_wsqh_kernel(const float* __restrict__ wn, int K,
                                                         const float* __restrict__ wmax2,
                                                         const float* __restrict__ xmax2, char* __restrict__ Wst,
-                                                        int n_stages, int stage_bytes, int stage_units) {
+                                                        int n_stages, int stage_bytes, int stage_units,
+                                                        unsigned long long* __restrict__ best64, long n_rows) {
     long u = (long)blockIdx.x * 256 + threadIdx.x;
+    if (best64 != nullptr && u < n_rows) best64[u] = ~0ull;
     if (u >= (long)n_stages * stage_units) return;
     const float big = __builtin_sqrtf(*wmax2) * __builtin_sqrtf(*xmax2) * (1.0f + 1.0f / 1024.0f);
     float s = (u < K) ? __builtin_fmaf(0.5f, wn[u], big) : BF_PAD_NORM;

@@ -65,6 +65,73 @@ __global__ __launch_bounds__(256) void prep_w_bf16_k16_kernel(const float* __res
     *(bf16x8*)(Wst + stage * k16_stage_bytes(KS32) + ((long)(t16 * KS32 + ks) * 64 + lane) * 16) = v;
 }
 
+// _merge_updates (xpysom.py:446-455) fused with the NEXT epoch's operand preparation: one pass over the fused
+// accumulator writes the merged float32 codebook, the bf16 stage image of -w~ and |w~_k|^2 (+ its maximum),
+// i.e. merge_kernel + prep_w_bf16_k16_kernel + prep_wnorm_kernel (euclidean) in one launch and one read of
+// the codebook.  Workgroup = one 16-unit tile = KS32 waves; thread = (unit, 8 features), exactly one 16-byte
+// fragment chunk of the image.  W = where(den != 0, num / den, W) as merge_kernel computes it.
+template <int KS32>
+__global__ __launch_bounds__(64 * KS32) void merge_prep_k16_kernel(float* __restrict__ W, const float* __restrict__ ACC,
+                                                                 int K, int D, int D1p, char* __restrict__ Wst,
+                                                                 float* __restrict__ wn, float* __restrict__ wmax2) {
+    __shared__ float red[KS32][16];
+    const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const long tile = blockIdx.x;                     // (stage, t16)
+    const long stage = tile / K16_T;
+    const int t16 = (int)(tile - stage * K16_T);
+    const long u = stage * K16_STAGE_UNITS + t16 * 16 + (lane & 15);
+    const int k0 = ks * 32 + (lane >> 4) * 8;
+    float w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = 0.0f;
+    if (u < K) {
+        const float den = ACC[u * D1p + D];
+        const bool full = k0 + 8 <= D && (D1p & 3) == 0 && (D & 3) == 0;   // 16-byte aligned rows on both sides
+        if (den != 0.0f) {
+            if (full) {
+                const f32x4 a = *(const f32x4*)(ACC + u * D1p + k0), b = *(const f32x4*)(ACC + u * D1p + k0 + 4);
+                f32x4 q0, q1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { q0[j] = a[j] / den; q1[j] = b[j] / den; w[j] = q0[j]; w[4 + j] = q1[j]; }
+                *(f32x4*)(W + u * D + k0) = q0;
+                *(f32x4*)(W + u * D + k0 + 4) = q1;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (k0 + j < D) { w[j] = ACC[u * D1p + k0 + j] / den; W[u * D + k0 + j] = w[j]; }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (k0 + j < D) w[j] = W[u * D + k0 + j];
+        }
+    }
+    bf16x8 v;
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 b = (__bf16)w[j];
+        v[j] = (__bf16)(-w[j]);                       // (rounding is sign-symmetric: -bf16(w) == bf16(-w))
+        const float f = (float)b;
+        s = __builtin_fmaf(f, f, s);
+    }
+    *(bf16x8*)(Wst + stage * k16_stage_bytes(KS32) + ((long)(t16 * KS32 + ks) * 64 + lane) * 16) = v;
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (lane < 16) red[ks][lane] = s;
+    __syncthreads();
+    if (ks == 0 && lane < 16) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < KS32; ++q) t += red[q][lane];
+        if (u < K) wn[u] = t;
+        float m = u < K ? t : 0.0f;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) atomic_max_pos_f32(wmax2, m);
+    }
+}
+
 #ifndef SOM_K16_MINWAVES
 #define SOM_K16_MINWAVES 2
 #endif
@@ -155,6 +222,9 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
                 for (int ks = 0; ks < KS32; ++ks)
                     aN[ks] = *(const bf16x8*)(st + ((t16 + 1) * KS32 + ks) * 1024 + lane * 16);
             }
+#ifdef SOM_K16_SCHEDFENCE
+            __builtin_amdgcn_sched_barrier(0);            // experiment: keep the next tile's fragment reads up here
+#endif
             f32x4 accT[K16_SB];
 #pragma unroll
             for (int sb = 0; sb < K16_SB; ++sb) accT[sb] = wv;

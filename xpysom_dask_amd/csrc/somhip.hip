@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -56,6 +57,7 @@ struct som_handle {
     bool own_stream = false;
 
     float *W = nullptr, *wsq = nullptr, *SC = nullptr, *T = nullptr, *ACC = nullptr, *P1 = nullptr, *P2 = nullptr;
+    float* Ud = nullptr;     // the count column after stage 1 of the transform, dense [nt][X][Y]
     char* Wst = nullptr;
     char* Wfst = nullptr;    // f32 parity mode, input_len <= 128: float32 stage image (bmu_f32_res.hpp)
     int fr_kg = 0, fr_stages = 0;
@@ -124,6 +126,8 @@ struct som_handle {
     int2* bands = nullptr;   // nonzero column ranges of the neighbourhood tables per 128-row block (update.hpp)
     bool use_bands = true;
 
+    bool fuse_merge_prep = true; // SOM_FUSE_MERGE=0: separate merge and operand-preparation launches (A/B)
+    int staged_blocks_done = -1; // som_epoch_accumulate_begin / _block: next block expected, -1 = none pending
     bool async_copies = false;   // SOM_ASYNC_COPIES=1: round 1's original copy path (fresh_process_stress.py)
     bool prof = false;
     std::vector<EventPair> pending, pool;
@@ -487,13 +491,7 @@ int launch_bmu_bf16_k16(som_handle* h, const __bf16* Xb, long N, int* out) {
     if (std::getenv("SOM_DEBUG"))
         std::fprintf(stderr, "[somhip] bmu_bf16_k16: blocks=%ld per_cu=%d cus=%d slots=%ld parts=%d stages=%d\n", blocks,
                      per_cu, h->n_cus, slots, parts, h->n_stages);
-    if (N > h->best64_cap) {
-        (void)hipFree(h->best64);
-        h->best64 = nullptr; h->best64_cap = 0;
-        if (int rc = dev_alloc(h, &h->best64, (size_t)round_up(N, 1024))) return rc;
-        h->best64_cap = round_up(N, 1024);
-    }
-    HIPCHK(h, hipMemsetAsync(h->best64, 0xFF, (size_t)N * sizeof(unsigned long long), h->stream));
+    // (best64[0..N) was reset by prep_wsqh_kernel, launch_bmu_bf16)
     bmu_bf16_k16_kernel<KS32><<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * K16_NW), lds, h->stream>>>(
         Xb, N, h->Wst, h->n_stages, h->K, h->best64);
     bmu_finalize_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(h->best64, N, h->K, out);
@@ -543,10 +541,21 @@ int launch_bmu_bf16_tiled(som_handle* h, const __bf16* Ximg, const float* xmax2,
 
 int launch_bmu_bf16(som_handle* h, const __bf16* Xb, const float* xmax2, long N, int* out) {
     if (h->tiled) return launch_bmu_bf16_tiled(h, Xb, xmax2, N, out);
-    // the stage image's initial accumulators depend on the row set through B = xmax * wmax
+    // the stage image's initial accumulators depend on the row set through B = xmax * wmax; the same launch
+    // resets the per-row merge keys of the 16x16x32 kernel
     long units = (long)h->n_stages * h->stage_units;
-    prep_wsqh_kernel<<<dim3((unsigned)cdiv(units, 256)), dim3(256), 0, h->stream>>>(h->wn, h->K, h->wmax2, xmax2, h->Wst,
-                                                                                  h->n_stages, h->stage_bytes, h->stage_units);
+    unsigned long long* init64 = nullptr;
+    if (h->shape16) {
+        if (N > h->best64_cap) {
+            (void)hipFree(h->best64);
+            h->best64 = nullptr; h->best64_cap = 0;
+            if (int rc = dev_alloc(h, &h->best64, (size_t)round_up(N, 1024))) return rc;
+            h->best64_cap = round_up(N, 1024);
+        }
+        init64 = h->best64;
+    }
+    prep_wsqh_kernel<<<dim3((unsigned)cdiv(init64 ? std::max(units, N) : units, 256)), dim3(256), 0, h->stream>>>(
+        h->wn, h->K, h->wmax2, xmax2, h->Wst, h->n_stages, h->stage_bytes, h->stage_units, init64, N);
     if (h->shape16) {
         switch (h->ks32) {
         case 1: return launch_bmu_bf16_k16<1>(h, Xb, N, out);
@@ -651,7 +660,7 @@ int row_sq(som_handle* h, const float* X, long N, float* out) {
 // 4-byte keys (ten merge passes at 1 Mi rows: 0.16 ms); two 8-bit Onesweep passes take half of that, but lose
 // to the merge sort at 100 k rows -- so Onesweep from SORT_ONESWEEP_ROWS rows on.
 using SortOnesweep = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 1024>;
-constexpr long SORT_ONESWEEP_ROWS = 262144;
+long SORT_ONESWEEP_ROWS = 262144;           // (SOM_SORT_ONESWEEP_ROWS overrides it: experiments)
 
 template <typename... Args>
 hipError_t sort_bmu_pairs(long n, Args... args) {
@@ -692,7 +701,8 @@ int seg_reserve(som_handle* h, som_handle::SegScratch& sg, long rows) {
     if (e != hipSuccess) return fail_hip(h, "rocprim::radix_sort_pairs(size query)", e);
     if (int rc = dev_alloc(h, (char**)&sg.tmp, bytes)) return rc;
     sg.tmp_bytes = bytes;
-    const long n1 = seg_next_entries(rows, SEG_CHUNK), n2 = seg_next_entries(n1, SEG_CHUNK_UP);
+    const int nw = seg_waves_per_block(h->D1p);
+    const long n1 = seg_next_entries(rows, SEG_CHUNK, nw), n2 = seg_next_entries(n1, SEG_CHUNK_UP, nw);
     if (int rc = dev_alloc(h, &sg.kA, (size_t)n1)) return rc;
     if (int rc = dev_alloc(h, &sg.vA, (size_t)n1 * h->D1p)) return rc;
     if (int rc = dev_alloc(h, &sg.kB, (size_t)n2)) return rc;
@@ -701,23 +711,28 @@ int seg_reserve(som_handle* h, som_handle::SegScratch& sg, long rows) {
     return 0;
 }
 
+// one level of the run sum over n entries; returns the number of workgroups it used
 template <bool LEVEL0>
-void launch_runsum(som_handle* h, const float* X, const int* keys, const int* srow, const float* vin, long n,
+long launch_runsum(som_handle* h, const float* X, const int* keys, const int* srow, const float* vin, long n,
                    int accumulate, int* kout, float* vout) {
-    const long waves = cdiv(n, LEVEL0 ? SEG_CHUNK : SEG_CHUNK_UP);
-    const dim3 grid((unsigned)cdiv(waves, 4)), block(256);
+    const int nw = seg_waves_per_block(h->D1p);
+    const int chunk = LEVEL0 ? SEG_CHUNK : seg_chunk_up(n, nw);
+    const long blocks = cdiv(n, (long)nw * chunk);
+    const dim3 grid((unsigned)blocks), block(64 * nw);
+    const size_t lds = nw > 1 ? (size_t)2 * nw * (h->D1p + 1) * sizeof(float) : 0;
     if ((h->D & 1) == 0)
-        runsum_kernel<LEVEL0, true><<<grid, block, 0, h->stream>>>(X, keys, srow, vin, n, h->D, h->D1p, accumulate, h->SC, kout, vout);
+        runsum_kernel<LEVEL0, true><<<grid, block, lds, h->stream>>>(X, keys, srow, vin, n, chunk, h->D, h->D1p, accumulate, h->SC, h->SC + (size_t)h->K * h->D1p, kout, vout);
     else
-        runsum_kernel<LEVEL0, false><<<grid, block, 0, h->stream>>>(X, keys, srow, vin, n, h->D, h->D1p, accumulate, h->SC, kout, vout);
+        runsum_kernel<LEVEL0, false><<<grid, block, lds, h->stream>>>(X, keys, srow, vin, n, chunk, h->D, h->D1p, accumulate, h->SC, h->SC + (size_t)h->K * h->D1p, kout, vout);
+    return blocks;
 }
 
 // SC[b] += sum of the rows whose BMU is b (and their count): sort by BMU, then the levels of update.hpp's
-// run sum (rows -> partial lists) until one wave holds the whole list.  zero_first: SC starts from zero and
+// run sum (rows -> partial lists) until one workgroup holds the whole list.  zero_first: SC starts from zero and
 // every unit is written once (plain stores); otherwise the chunk's sums are added to what SC holds.
 int segsum_rows(som_handle* h, const float* X, const int* bmu, long N, som_handle::SegScratch& sg, bool zero_first) {
     Timed t(h, SOM_K_SEGSUM);
-    if (zero_first) HIPCHK(h, hipMemsetAsync(h->SC, 0, (size_t)h->K * h->D1p * sizeof(float), h->stream));
+    if (zero_first) HIPCHK(h, hipMemsetAsync(h->SC, 0, (size_t)h->K * (h->D1p + 1) * sizeof(float), h->stream));
     if (N > 0) {
         if (N > sg.cap) return fail(h, "segment sum: scratch smaller than the row set");
         int bits = 1;
@@ -725,14 +740,11 @@ int segsum_rows(som_handle* h, const float* X, const int* bmu, long N, som_handl
         hipError_t e = sort_bmu_pairs(N, sg.tmp, sg.tmp_bytes, bmu, sg.skey, sg.iota, sg.srow, (size_t)N, 0u, (unsigned)bits, h->stream);
         if (e != hipSuccess) return fail_hip(h, "rocprim::radix_sort_pairs", e);
         const int acc = zero_first ? 0 : 1;
-        launch_runsum<true>(h, X, sg.skey, sg.srow, nullptr, N, acc, sg.kA, sg.vA);
-        long waves = cdiv(N, SEG_CHUNK);
+        long blocks = launch_runsum<true>(h, X, sg.skey, sg.srow, nullptr, N, acc, sg.kA, sg.vA);
         int *kin = sg.kA, *kout = sg.kB;
         float *vin = sg.vA, *vout = sg.vB;
-        while (waves > 1) {                              // 2 * waves entries are waiting in (kin, vin)
-            const long n = 2 * waves;
-            launch_runsum<false>(h, nullptr, kin, nullptr, vin, n, acc, kout, vout);
-            waves = cdiv(n, SEG_CHUNK_UP);
+        while (blocks > 1) {                             // 2 * blocks entries are waiting in (kin, vin)
+            blocks = launch_runsum<false>(h, nullptr, kin, nullptr, vin, 2 * blocks, acc, kout, vout);
             std::swap(kin, kout);
             std::swap(vin, vout);
         }
@@ -762,40 +774,99 @@ int run_update(som_handle* h, double sigma, double eta, int neigh_f64) {
 }
 
 // [num|den] = sum_t (Px_t (x) Py_t) [S|c]
-int run_transform(som_handle* h, double sigma, double eta, int neigh_f64) {
-    Timed t(h, SOM_K_KRON);
+// the factor tables of this epoch's neighbourhood (+ their nonzero bands)
+int build_tables(som_handle* h, double sigma, double eta, int neigh_f64, hipStream_t st) {
     const NeighParams p = make_neigh_params(h, sigma, eta, neigh_f64);
     long ntab = (long)h->nt * h->Y * h->Y + (long)h->X * h->nt * h->X;
-    neigh_tables_kernel<<<dim3((unsigned)cdiv(ntab, 256)), dim3(256), 0, h->stream>>>(
+    neigh_tables_kernel<<<dim3((unsigned)cdiv(ntab, 256)), dim3(256), 0, st>>>(
         p, h->capturing ? (const NeighParams*)h->np_dev : nullptr, h->P1, h->P2);
     HIPCHK(h, hipGetLastError());
     // nonzero bands of the tables (late epochs: most of Px, Py is exact zeros); SOM_NO_BANDS=1 walks everything
     const int nyb = (int)cdiv(h->Y, LM_BM), nxb = (int)cdiv(h->X, LM_BM);
-    int2* bands1 = h->use_bands ? h->bands : nullptr;                   // [nt][nyb]
-    int2* bands2 = h->use_bands ? h->bands + (long)h->nt * nyb : nullptr;   // [nxb][nt]
     if (h->use_bands) {
-        HIPCHK(h, hipMemsetAsync(h->bands, 0, (size_t)h->nt * (nyb + nxb) * sizeof(int2), h->stream));
-        band_ranges_kernel<<<dim3((unsigned)nyb, (unsigned)cdiv(h->Y, 64), (unsigned)h->nt), dim3(256), 0, h->stream>>>(
+        int2* bands1 = h->bands;                             // [nt][nyb]
+        int2* bands2 = h->bands + (long)h->nt * nyb;         // [nxb][nt]
+        HIPCHK(h, hipMemsetAsync(h->bands, 0, (size_t)h->nt * (nyb + nxb) * sizeof(int2), st));
+        band_ranges_kernel<<<dim3((unsigned)nyb, (unsigned)cdiv(h->Y, 64), (unsigned)h->nt), dim3(256), 0, st>>>(
             h->P1, h->Y, h->Y, 1, h->Y, bands1, (long)h->Y * h->Y, nyb);
-        band_ranges_kernel<<<dim3((unsigned)nxb, (unsigned)(h->nt * cdiv(h->X, 64)), 1), dim3(256), 0, h->stream>>>(
+        band_ranges_kernel<<<dim3((unsigned)nxb, (unsigned)(h->nt * cdiv(h->X, 64)), 1), dim3(256), 0, st>>>(
             h->P2, h->X, h->nt * h->X, h->nt, h->X, bands2, 0, 0);
+        HIPCHK(h, hipGetLastError());
     }
-    // stage 1: T_t[a] = Py_t (Y x Y) * SC[a] (Y x D1p), batched over the X map rows
+    return 0;
+}
+
+// OUT = H * M over C columns (rows of M / OUT ld floats apart): 128-wide MFMA tiles, and a VALU kernel for a last
+// tile of <= LM_NARROW columns
+void launch_leftmul(som_handle* h, const float* H, int Ro, int Ri, const float* M, long mstride, float* OUT, long ostride,
+                    long C, long ld, int row_blocks, int batch, const int2* ranges, int nseg, int segw) {
+    long wide = cdiv(C, LM_BN);
+    const long rem = C - (C / LM_BN) * LM_BN;
+    if (rem > 0 && rem <= LM_NARROW) {
+        --wide;
+        const dim3 g(1, (unsigned)row_blocks, (unsigned)batch), b(256);
+        if (rem <= 4) leftmul_narrow_f32_kernel<2><<<g, b, 0, h->stream>>>(H, Ro, Ri, M, mstride, OUT, ostride, C, ld, C - rem, ranges, nseg, segw);
+        else if (rem <= 8) leftmul_narrow_f32_kernel<4><<<g, b, 0, h->stream>>>(H, Ro, Ri, M, mstride, OUT, ostride, C, ld, C - rem, ranges, nseg, segw);
+        else if (rem <= 16) leftmul_narrow_f32_kernel<8><<<g, b, 0, h->stream>>>(H, Ro, Ri, M, mstride, OUT, ostride, C, ld, C - rem, ranges, nseg, segw);
+        else leftmul_narrow_f32_kernel<16><<<g, b, 0, h->stream>>>(H, Ro, Ri, M, mstride, OUT, ostride, C, ld, C - rem, ranges, nseg, segw);
+    }
+    if (wide > 0)
+        leftmul_f32_kernel<<<dim3((unsigned)wide, (unsigned)row_blocks, (unsigned)batch), dim3(256), 0, h->stream>>>(
+            H, Ro, Ri, M, mstride, OUT, ostride, C, ld, ranges, nseg, segw);
+}
+
+// tables + stage 1: T_t[a] = Py_t (Y x Y) * SC[a] (Y x D), batched
+// over the X map rows; the count column goes its own way: U_t = C Py_t^T (X x Y, update.hpp)
+int run_transform_stage1(som_handle* h, double sigma, double eta, int neigh_f64) {
+    // (built on this stream: handing them to a side stream under the BMU kernel was measured -- the two event
+    //  waits cost more than the 7 us kernel, epoch 1.058 vs 1.035 ms at 65 536 rows)
+    if (int rc = build_tables(h, sigma, eta, neigh_f64, h->stream)) return rc;
+    const int nyb = (int)cdiv(h->Y, LM_BM);
+    const int2* bands1 = h->use_bands ? h->bands : nullptr;             // [nt][nyb]
     const long slab = (long)h->Y * h->D1p;
-    for (int t1 = 0; t1 < h->nt; ++t1) {
-        dim3 grid((unsigned)cdiv(h->D1p, LM_BN), (unsigned)nyb, (unsigned)h->X);
-        leftmul_f32_kernel<<<grid, dim3(256), 0, h->stream>>>(h->P1 + (long)t1 * h->Y * h->Y, h->Y, h->Y, h->SC, slab,
-                                                             h->T + (long)t1 * h->X * slab, slab, h->D1p,
-                                                             bands1 ? bands1 + (long)t1 * nyb : nullptr, 1, h->Y);
-    }
-    // stage 2: ACC = [Px_0 | Px_1 ...] (X x nt*X) * T (nt*X x Y*D1p)
-    {
-        dim3 grid((unsigned)cdiv(slab, LM_BN), (unsigned)nxb, 1);
-        leftmul_f32_kernel<<<grid, dim3(256), 0, h->stream>>>(h->P2, h->X, h->nt * h->X, h->T, 0, h->ACC, 0, slab, bands2,
-                                                             h->nt, h->X);
+    for (int t1 = 0; t1 < h->nt; ++t1)
+        launch_leftmul(h, h->P1 + (long)t1 * h->Y * h->Y, h->Y, h->Y, h->SC, slab, h->T + (long)t1 * h->X * slab, slab,
+                       h->D, h->D1p, nyb, h->X, bands1 ? bands1 + (long)t1 * nyb : nullptr, 1, h->Y);
+    // U_t[a][j] = sum_b C[a][b] Py_t[j][b] from the dense counts; stage 2 reads it densely (Ud) when it batches over
+    // the map columns, or finds it where stage 1 would have put it, T_t[a][j][D], when it runs over whole rows
+    const bool per_column = h->D % LM_BN == 0;
+    strided_gemm_f32_kernel<<<dim3((unsigned)cdiv(h->Y, 32), (unsigned)cdiv(h->X, 32), (unsigned)h->nt), dim3(256), 0, h->stream>>>(
+        h->SC + (size_t)h->K * h->D1p, h->Y, 1, h->P1, 1, h->Y, per_column ? h->Ud : h->T + h->D, per_column ? h->Y : slab,
+        per_column ? 1 : h->D1p, h->X, h->Y, h->Y, 0, (long)h->Y * h->Y, per_column ? (long)h->K : (long)h->X * slab);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// stage 2 for the map-row blocks [b0, b1) of LM_BM rows: ACC = [Px_0 | Px_1 ...] (X x nt*X) * T (nt*X x Y*D1p).
+// input_len a multiple of the 128-column tile: batched over the Y map columns, one exact tile set per (j, features)
+// -- 256 x 2 workgroups at 256 x 256 x 128, one round of the resident slots, where 132-float rows cut into 128-wide
+// tiles made 264 x 2 -- and the count column through the strided kernel.  Otherwise: over the whole Y*D1p-wide rows.
+int run_transform_stage2(som_handle* h, int b0, int b1) {
+    const int nyb = (int)cdiv(h->Y, LM_BM), nxb = (int)cdiv(h->X, LM_BM);
+    if (b0 < 0 || b1 > nxb || b0 >= b1) return fail(h, "transform: map-row block out of range");
+    const int2* bands2 = h->use_bands ? h->bands + (long)h->nt * nyb : nullptr;   // [nxb][nt]
+    const long slab = (long)h->Y * h->D1p;
+    const long i0 = (long)b0 * LM_BM;
+    const int rows = (int)std::min<long>((long)b1 * LM_BM, h->X) - (int)i0;
+    const float* H = h->P2 + i0 * h->nt * h->X;
+    const int2* ranges = bands2 ? bands2 + (long)b0 * h->nt : nullptr;
+    if (h->D % LM_BN == 0) {
+        launch_leftmul(h, H, rows, h->nt * h->X, h->T, h->D1p, h->ACC + i0 * slab, h->D1p, h->D, slab, b1 - b0, h->Y, ranges,
+                       h->nt, h->X);
+        // den[i][j] = sum_k [Px_0 | Px_1 ...][i][k] U[k][j], U = [U_0; U_1; ...] dense (stage 1)
+        strided_gemm_f32_kernel<<<dim3((unsigned)cdiv(h->Y, 32), (unsigned)cdiv(rows, 32), 1), dim3(256), 0, h->stream>>>(
+            H, (long)h->nt * h->X, 1, h->Ud, h->Y, 1, h->ACC + i0 * slab + h->D, slab, h->D1p, rows, h->Y, h->nt * h->X, 0, 0, 0);
+    } else {
+        launch_leftmul(h, H, rows, h->nt * h->X, h->T, 0, h->ACC + i0 * slab, 0, slab, slab, b1 - b0, 1, ranges, h->nt, h->X);
     }
     HIPCHK(h, hipGetLastError());
     return 0;
+}
+
+int run_transform(som_handle* h, double sigma, double eta, int neigh_f64) {
+    Timed t(h, SOM_K_KRON);
+    if (int rc = run_transform_stage1(h, sigma, eta, neigh_f64)) return rc;
+    return run_transform_stage2(h, 0, (int)cdiv(h->X, LM_BM));
 }
 
 int ensure_query_scratch(som_handle* h, long n) {
@@ -929,7 +1000,8 @@ int som_create(const som_config* cfg, som_handle** out) {
     const size_t KD1 = (size_t)h->K * h->D1p;
     if ((rc = dev_alloc(h, &h->W, (size_t)h->K * h->D))) return bail(rc);
     if ((rc = dev_alloc(h, &h->wsq, (size_t)h->K))) return bail(rc);
-    if ((rc = dev_alloc(h, &h->SC, KD1))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->SC, KD1 + (size_t)h->K))) return bail(rc);        // [K][D1p] sums|counts, then the counts densely [K]
+    if ((rc = dev_alloc(h, &h->Ud, (size_t)h->nt * h->K))) return bail(rc);
     if ((rc = dev_alloc(h, &h->T, KD1 * h->nt))) return bail(rc);
     if ((rc = dev_alloc(h, &h->ACC, KD1))) return bail(rc);
     if ((rc = dev_alloc(h, &h->P1, (size_t)h->nt * h->Y * h->Y))) return bail(rc);
@@ -941,6 +1013,8 @@ int som_create(const som_config* cfg, som_handle** out) {
         h->np_dev = npd;
         if (const char* e = std::getenv("SOM_GRAPH")) h->use_graph = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_ASYNC_COPIES")) h->async_copies = std::atoi(e) != 0;
+        if (const char* e = std::getenv("SOM_FUSE_MERGE")) h->fuse_merge_prep = std::atoi(e) != 0;
+        if (const char* e = std::getenv("SOM_SORT_ONESWEEP_ROWS")) SORT_ONESWEEP_ROWS = std::atol(e);
         // a 128-row block of a table already spans most of a map side up to 256: nothing to skip there
         h->use_bands = h->X > 256 || h->Y > 256;
         if (const char* e = std::getenv("SOM_NO_BANDS")) h->use_bands = std::atoi(e) == 0;
@@ -986,7 +1060,7 @@ void som_destroy(som_handle* h) {
     if (h->bands) (void)hipFree(h->bands);
     for (auto& ep : h->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto& ep : h->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-    void* bufs[] = {h->W, h->wsq, h->SC, h->T, h->ACC, h->P1, h->P2, h->Wst, h->X_owned, h->bmu, h->xsq, h->Xb,
+    void* bufs[] = {h->Ud, h->W, h->wsq, h->SC, h->T, h->ACC, h->P1, h->P2, h->Wst, h->X_owned, h->bmu, h->xsq, h->Xb,
                     h->xmax2, h->wn, h->wmax2, h->qX, h->qbmu, h->qbmu2, h->qxsq, h->qXb, h->dsum,
                     h->best64, h->Wfst, h->Wfimg, h->ftX};
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -1178,7 +1252,7 @@ int som_stream_begin(som_handle* h) {
     DeviceGuard dev_guard(h);
     if (!h) return 1;
     if (int rc = refresh_codebook_operands(h, h->cfg.precision == SOM_PREC_F32)) return rc;
-    HIPCHK(h, hipMemsetAsync(h->SC, 0, (size_t)h->K * h->D1p * sizeof(float), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->SC, 0, (size_t)h->K * (h->D1p + 1) * sizeof(float), h->stream));
     h->streaming = true;
     return 0;
 }
@@ -1279,6 +1353,23 @@ int som_epoch_merge(som_handle* h) {
     DeviceGuard dev_guard(h);
     if (!h) return 1;
     Timed t(h, SOM_K_MERGE);
+    // the headline path (bf16, input_len <= 128, euclidean): the merge also writes the next epoch's bf16 operands
+    if (h->cfg.precision == SOM_PREC_BF16 && !h->tiled && h->shape16 && h->cfg.distance == SOM_DIST_EUCLIDEAN &&
+        h->fuse_merge_prep) {
+        HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
+        const dim3 grid((unsigned)((long)h->n_stages * K16_T));
+        switch (h->ks32) {
+        case 1: merge_prep_k16_kernel<1><<<grid, dim3(64), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2); break;
+        case 2: merge_prep_k16_kernel<2><<<grid, dim3(128), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2); break;
+        case 3: merge_prep_k16_kernel<3><<<grid, dim3(192), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2); break;
+        case 4: merge_prep_k16_kernel<4><<<grid, dim3(256), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2); break;
+        default: return fail(h, "bf16 precision supports input_len <= 128");
+        }
+        HIPCHK(h, hipGetLastError());
+        mark_codebook_changed(h);
+        h->w_dirty = false;                              // the bf16 stage image and |w~|^2 are already the new codebook's
+        return 0;
+    }
     long total = (long)h->K * h->D;
     merge_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p);
     HIPCHK(h, hipGetLastError());
@@ -1289,6 +1380,42 @@ int som_epoch_merge(som_handle* h) {
 int som_epoch(som_handle* h, double sigma, double eta, int neigh_f64) {
     if (int rc = som_epoch_accumulate(h, sigma, eta, neigh_f64)) return rc;
     return som_epoch_merge(h);
+}
+
+// ---- the epoch in stages: finished map-row blocks of the accumulator can be all-reduced while the next are computed
+int som_epoch_accumulate_begin(som_handle* h, double sigma, double eta, int neigh_f64) {
+    DeviceGuard dev_guard(h);
+    if (!h) return 1;
+    if (!h->Xd && h->N > 0) return fail(h, "som_epoch_accumulate_begin: no resident data (call som_set_data)");
+    if (int rc = run_activation_bmu(h, h->Xd, h->N, h->xsq, h->Xb, h->xmax2, h->bmu)) return rc;
+    if (int rc = segsum_rows(h, h->Xd, h->bmu, h->N, h->seg, true)) return rc;
+    Timed t(h, SOM_K_KRON);
+    if (int rc = run_transform_stage1(h, sigma, eta, neigh_f64)) return rc;
+    h->staged_blocks_done = 0;
+    return 0;
+}
+
+int som_epoch_block_count(som_handle* h, int32_t* n_blocks) {
+    if (!h || !n_blocks) return fail(h, "som_epoch_block_count: NULL argument");
+    *n_blocks = (int32_t)cdiv(h->X, LM_BM);
+    return 0;
+}
+
+int som_epoch_accumulate_block(som_handle* h, int32_t block, int64_t* offset, int64_t* n_floats) {
+    DeviceGuard dev_guard(h);
+    if (!h) return 1;
+    if (h->staged_blocks_done < 0 || block != h->staged_blocks_done)
+        return fail(h, "som_epoch_accumulate_block: blocks go in order, after som_epoch_accumulate_begin");
+    {
+        Timed t(h, SOM_K_KRON);
+        if (int rc = run_transform_stage2(h, block, block + 1)) return rc;
+    }
+    const long slab = (long)h->Y * h->D1p, i0 = (long)block * LM_BM;
+    const long rows = std::min<long>(i0 + LM_BM, h->X) - i0;
+    if (offset) *offset = i0 * slab;
+    if (n_floats) *n_floats = rows * slab;
+    h->staged_blocks_done = block + 1 == (int)cdiv(h->X, LM_BM) ? -1 : block + 1;
+    return 0;
 }
 
 int som_accum_device_ptr(som_handle* h, void** dev_ptr, int64_t* n_floats) {

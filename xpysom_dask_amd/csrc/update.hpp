@@ -26,68 +26,64 @@ namespace somhip {
 
 // ---- segment sum: SC[b][0..D-1] = sum_{bmu_n = b} x_n ; SC[b][D] = #{bmu_n = b} ------------------
 // The rows are first ordered by BMU (stable radix sort of (bmu_n, n) pairs, rocPRIM: the sorted order is a
-// function of the BMUs alone).  Level 0: every wave walks a chunk of SEG_CHUNK consecutive sorted positions and
-// keeps the running sum of the current unit in registers (lane = feature pair); row gathers are whole 4*D-byte
-// rows, eight in flight per wave, so the pass is bound by reading X once (N*D*4 bytes).
-//
-// No atomics, fixed order.  A unit's rows are ONE run of the sorted order.  A run that lies inside one chunk
-// is complete there: the wave adds it to SC[unit] with a plain read-modify-write -- it is the only writer of
-// that unit in the launch.  A run cut by a chunk boundary leaves a PARTIAL instead: chunk w owns the two
-// entries 2w (its first run, if that continues the previous chunk) and 2w+1 (its last run, if the next chunk
-// continues it) of the next level's list (key, vector, count); unused entries carry key -1, and a chunk that is
-// one run open on both sides fills 2w and gives 2w+1 the same key with a zero vector, so that the partials of
-// one unit stay adjacent.  The next level is the same kernel over that list (SEG_CHUNK_UP entries per wave),
-// and so on until one wave holds the whole list (1 Mi rows: 1 048 576 -> 65 536 -> 2 048 -> 64 entries).
-// Every unit's sum is therefore formed in ONE order fixed by (N, the BMUs): two epochs from the same state
-// are bitwise equal, and a unit that wins every row costs log-many tiny passes instead of N/32 serialised
-// atomics on one address.
+// function of the BMUs alone).  A unit's rows are then ONE run of the sorted order, and the sum of a run is
+// formed by a tree whose shape depends on N only -- no atomics, one fixed order:
+//   wave   walks a chunk of consecutive entries (level 0: SEG_CHUNK sorted rows, gathered as whole 4*D-byte rows,
+//          eight in flight; upper levels: SEG_CHUNK_UP entries of a partial list) with the running sum of the
+//          current unit in registers (lane = feature pair).  A run that begins and ends inside the chunk is
+//          complete: the wave adds it to SC[unit] with a plain read-modify-write (it is that unit's only writer in
+//          the launch).  A run cut by the chunk's edge leaves a PARTIAL (key, vector, count) in one of the wave's
+//          two slots: slot 0 = its first run if that continues the previous chunk, slot 1 = its last run if the
+//          next chunk continues it.  Unused slots carry key -1; a chunk that is one run open on both sides fills
+//          slot 0 and gives slot 1 the same key with a zero vector, so one unit's partials stay adjacent.
+//   block  the slots of a workgroup's waves live in LDS; after a barrier wave 0 walks them the same way.  Only
+//          runs cut by the BLOCK's edges survive, as the two entries 2b, 2b+1 of the next level's list in HBM.
+//   level  the next level is the same kernel over that list, until one block holds the whole list
+//          (1 Mi rows, 16 waves per block: 1 048 576 rows -> 4 096 entries -> 32 entries -> done).
+// So two epochs from the same state are bitwise equal, and a unit that wins every row costs a few tiny
+// passes instead of N/32 serialised atomics on one address.
 constexpr int SEG_CHUNK = 32;      // rows per wave, level 0
-constexpr int SEG_CHUNK_UP = 64;   // partial entries per wave, upper levels
+constexpr int SEG_CHUNK_UP = 16;   // partial entries per wave, upper levels: at least this (two groups of eight loads: a short
+                                   // latency chain), up to 64 when that lets ONE workgroup finish the list (seg_chunk_up)
+constexpr int SEG_MAX_WAVES = 16;  // waves per workgroup (fewer when 2 * waves * D1p floats would not fit in LDS)
 
 __global__ __launch_bounds__(256) void iota_kernel(int* __restrict__ v, long n) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) v[i] = (int)i;
 }
 
-// number of entries of the list a level with n entries and chunk c leaves behind
-__host__ __device__ inline long seg_next_entries(long n, int c) { return 2 * ((n + c - 1) / c); }
+__host__ __device__ inline int seg_waves_per_block(int D1p) {
+    int nw = SEG_MAX_WAVES;
+    while (nw > 1 && (long)2 * nw * (D1p + 1) * 4 > 64 * 1024) nw >>= 1;
+    return nw;
+}
+// upper levels: entries per wave for a list of n entries -- the smallest multiple of 8 in [SEG_CHUNK_UP, 64] with
+// which nw waves cover the list, else SEG_CHUNK_UP
+__host__ __device__ inline int seg_chunk_up(long n, int nw) {
+    long c = ((n + nw - 1) / nw + 7) / 8 * 8;
+    return (c <= 64) ? (int)(c < SEG_CHUNK_UP ? SEG_CHUNK_UP : c) : SEG_CHUNK_UP;
+}
+// entries the list left behind by a level with n entries, chunk c and nw waves per block
+__host__ __device__ inline long seg_next_entries(long n, int c, int nw) { return 2 * ((n + (long)c * nw - 1) / ((long)c * nw)); }
 
-// LEVEL0: keys = sorted BMUs, srow = sorted row ids, rows gathered from X (count 1 each).
-// !LEVEL0: keys / vin = the previous level's partial list ([n] keys, [n][D1p] vectors, count in column D).
-// VEC2 (D even): a lane owns feature pairs (8-byte accesses, one instruction per 128 features of a row).
-// accumulate == 0: SC was zeroed and every unit is written at most once in the whole pass: plain stores.
-template <bool LEVEL0, bool VEC2>
-__global__ __launch_bounds__(256) void runsum_kernel(const float* __restrict__ X, const int* __restrict__ keys,
-                                                     const int* __restrict__ srow, const float* __restrict__ vin,
-                                                     long n, int D, int D1p, int accumulate, float* __restrict__ SC,
-                                                     int* __restrict__ kout, float* __restrict__ vout) {
-    constexpr int C = LEVEL0 ? SEG_CHUNK : SEG_CHUNK_UP;
+// One chunk walk.  Entry i (< cnt <= 64) has key readlane(my_key, i), count readlane(my_cnt, i) and its vector at
+// ROWS ? X + readlane(my_row, i) * D : list + i * D1p.  Complete runs go to SC, the two possible partials to
+// slot0 / slot1 (rows of D1p floats); key0 / key1 return the slots' keys (-1 = unused).
+template <bool ROWS, bool VEC2>
+__device__ __forceinline__ void seg_walk(const float* __restrict__ X, const float* list, int my_key, int my_row,
+                                         float my_cnt, int cnt, bool open_left, bool open_right, int D, int D1p,
+                                         int accumulate, float* __restrict__ SC, float* __restrict__ cnt_dense,
+                                         float* slot0, float* slot1, int& key0, int& key1) {
     const int lane = threadIdx.x & 63;
-    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long p0 = wid * C;
-    if (p0 >= n) return;
-    const int cnt_here = (int)((n - p0 < C) ? (n - p0) : C);
-    // lane i < cnt_here holds the i-th (key, row) of the chunk
-    const int my_key = lane < cnt_here ? keys[p0 + lane] : -1;
-    const int my_row = (LEVEL0 && lane < cnt_here) ? srow[p0 + lane] : 0;
-    const float my_cnt = LEVEL0 ? 1.0f : ((lane < cnt_here && my_key >= 0) ? vin[(p0 + lane) * D1p + D] : 0.0f);
-    const int first_key = __builtin_amdgcn_readfirstlane(my_key);
-    const int last_key = __builtin_amdgcn_readlane(my_key, cnt_here - 1);
-    const int prev_key = p0 > 0 ? keys[p0 - 1] : -2;
-    const int next_key = p0 + cnt_here < n ? keys[p0 + cnt_here] : -2;
-    const bool open_left = first_key >= 0 && __builtin_amdgcn_readfirstlane(prev_key) == first_key;
-    const bool open_right = last_key >= 0 && __builtin_amdgcn_readfirstlane(next_key) == last_key;
-    int slot_key[2] = {-1, -1};
+    key0 = -1; key1 = -1;
     bool slot1_zero = false;
-
     for (int f0 = 0; f0 < D; f0 += 256) {                 // 4 features per lane per sweep
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        int cur = first_key;
+        int cur = __builtin_amdgcn_readfirstlane(my_key);
         int run_begin = 0;
         float run = 0.f;
         // feature of acc[j]: VEC2: f0 + 128*(j>>1) + 2*lane + (j&1);  scalar: f0 + lane + 64*j
-        auto feat = [&](int j) { return VEC2 ? f0 + 128 * (j >> 1) + 2 * lane + (j & 1) : f0 + lane + 64 * j; };
-        auto put = [&](float* dst, bool add) {            // this lane's 4 sums (and the count) into one row
+        auto put = [&](float* dst, bool add, long unit = -1) {   // this lane's 4 sums (and the count) into one row
             if (VEC2) {
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
@@ -101,42 +97,42 @@ __global__ __launch_bounds__(256) void runsum_kernel(const float* __restrict__ X
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int d = feat(j);
+                    const int d = f0 + lane + 64 * j;
                     if (d < D) dst[d] = add ? dst[d] + acc[j] : acc[j];
                 }
             }
-            if (f0 == 0 && lane == 0) dst[D] = add ? dst[D] + run : run;
+            if (f0 == 0 && lane == 0) {
+                const float c = add ? dst[D] + run : run;
+                dst[D] = c;
+                if (unit >= 0) cnt_dense[unit] = c;          // the counts once more, densely (the transform's count path)
+            }
         };
-        auto flush = [&](int end) {                       // the run [run_begin, end) of unit `cur` is complete in this chunk
+        auto flush = [&](int end) {                       // the run [run_begin, end) of unit `cur` ends here
             if (cur >= 0) {
-                const bool first = run_begin == 0, last = end == cnt_here;
+                const bool first = run_begin == 0, last = end == cnt;
                 if (first && open_left) {
-                    put(vout + (2 * wid) * (long)D1p, false);
-                    slot_key[0] = cur;
-                    if (last && open_right) { slot_key[1] = cur; slot1_zero = true; }
+                    put(slot0, false);
+                    key0 = cur;
+                    if (last && open_right) { key1 = cur; slot1_zero = true; }
                 } else if (last && open_right) {
-                    put(vout + (2 * wid + 1) * (long)D1p, false);
-                    slot_key[1] = cur;
+                    put(slot1, false);
+                    key1 = cur;
                 } else {
-                    put(SC + (long)cur * D1p, accumulate != 0);
+                    put(SC + (long)cur * D1p, accumulate != 0, cur);
                 }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = 0.f;
             run = 0.f;
         };
-        auto entry_ptr = [&](int i) -> const float* {     // vector of the chunk's i-th entry (i uniform)
-            if (LEVEL0) return X + (long)__builtin_amdgcn_readlane(my_row, i) * D;
-            return vin + (p0 + i) * (long)D1p;
-        };
-        for (int i0 = 0; i0 < cnt_here; i0 += 8) {
+        for (int i0 = 0; i0 < cnt; i0 += 8) {
             float v[8][4];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + u;
-                const int ii = i < cnt_here ? i : 0;
-                const bool live = i < cnt_here && __builtin_amdgcn_readlane(my_key, ii) >= 0;
-                const float* x = entry_ptr(ii);
+                const int ii = i < cnt ? i : 0;
+                const bool live = i < cnt && __builtin_amdgcn_readlane(my_key, ii) >= 0;
+                const float* x = ROWS ? X + (long)__builtin_amdgcn_readlane(my_row, ii) * D : list + (long)ii * D1p;
                 if (VEC2) {
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
@@ -156,7 +152,7 @@ __global__ __launch_bounds__(256) void runsum_kernel(const float* __restrict__ X
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + u;
-                if (i < cnt_here) {
+                if (i < cnt) {
                     const int b = __builtin_amdgcn_readlane(my_key, i);
                     if (b != cur) { flush(i); cur = b; run_begin = i; }
 #pragma unroll
@@ -165,15 +161,75 @@ __global__ __launch_bounds__(256) void runsum_kernel(const float* __restrict__ X
                 }
             }
         }
-        flush(cnt_here);
-        if (slot1_zero) {                                 // one run, open on both sides: entry 2w+1 = (key, 0)
+        flush(cnt);
+        if (slot1_zero) {                                 // one run, open on both sides: slot 1 = (key, 0)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = 0.f;
             run = 0.f;
-            put(vout + (2 * wid + 1) * (long)D1p, false);
+            put(slot1, false);
         }
     }
-    if (lane == 0 && kout != nullptr) { kout[2 * wid] = slot_key[0]; kout[2 * wid + 1] = slot_key[1]; }
+}
+
+// LEVEL0: keys = sorted BMUs, srow = sorted row ids, rows gathered from X (count 1 each).
+// !LEVEL0: keys / vin = the previous level's partial list ([n] keys, [n][D1p] vectors, count in column D).
+// VEC2 (D even): a lane owns feature pairs (8-byte accesses, one instruction per 128 features of a row).
+// accumulate == 0: SC was zeroed and every unit is written at most once in the whole pass: plain stores.
+// Dynamic LDS: blockDim.x / 64 > 1 ? 2 * waves * (D1p + 1) floats : none (a one-wave block writes its slots
+// straight to the next list).
+template <bool LEVEL0, bool VEC2>
+__global__ __launch_bounds__(64 * SEG_MAX_WAVES) void runsum_kernel(const float* __restrict__ X,
+                                                                   const int* __restrict__ keys,
+                                                                   const int* __restrict__ srow,
+                                                                   const float* __restrict__ vin, long n, int chunk,
+                                                                   int D, int D1p, int accumulate, float* __restrict__ SC,
+                                                                   float* __restrict__ cnt_dense, int* __restrict__ kout,
+                                                                   float* __restrict__ vout) {
+    extern __shared__ __attribute__((aligned(16))) float seg_lds[];
+    const int C = LEVEL0 ? SEG_CHUNK : chunk;             // <= 64: lane i holds entry i
+    const int lane = threadIdx.x & 63;
+    const int nw = blockDim.x >> 6, wave = threadIdx.x >> 6;
+    const long blk = blockIdx.x;
+    const long p0 = (blk * nw + wave) * C;
+    float* slots = seg_lds;                               // [2 * nw][D1p]
+    int* slot_keys = (int*)(seg_lds + (long)2 * nw * D1p);   // [2 * nw]
+    const bool direct = nw == 1;
+    int k0 = -1, k1 = -1;
+    if (p0 < n) {
+        const int cnt = (int)((n - p0 < C) ? (n - p0) : C);
+        // lane i < cnt holds the i-th (key, row, count) of the chunk
+        const int my_key = lane < cnt ? keys[p0 + lane] : -1;
+        const int my_row = (LEVEL0 && lane < cnt) ? srow[p0 + lane] : 0;
+        const float my_cnt = LEVEL0 ? 1.0f : ((lane < cnt && my_key >= 0) ? vin[(p0 + lane) * D1p + D] : 0.0f);
+        const int first_key = __builtin_amdgcn_readfirstlane(my_key);
+        const int last_key = __builtin_amdgcn_readlane(my_key, cnt - 1);
+        const int prev_key = p0 > 0 ? keys[p0 - 1] : -2;
+        const int next_key = p0 + cnt < n ? keys[p0 + cnt] : -2;
+        const bool open_left = first_key >= 0 && __builtin_amdgcn_readfirstlane(prev_key) == first_key;
+        const bool open_right = last_key >= 0 && __builtin_amdgcn_readfirstlane(next_key) == last_key;
+        float* s0 = direct ? vout + (2 * blk) * (long)D1p : slots + (long)(2 * wave) * D1p;
+        float* s1 = direct ? vout + (2 * blk + 1) * (long)D1p : slots + (long)(2 * wave + 1) * D1p;
+        seg_walk<LEVEL0, VEC2>(X, LEVEL0 ? nullptr : vin + p0 * (long)D1p, my_key, my_row, my_cnt, cnt, open_left,
+                               open_right, D, D1p, accumulate, SC, cnt_dense, s0, s1, k0, k1);
+    }
+    if (direct) {
+        if (lane == 0 && p0 < n) { kout[2 * blk] = k0; kout[2 * blk + 1] = k1; }
+        return;
+    }
+    if (lane == 0) { slot_keys[2 * wave] = k0; slot_keys[2 * wave + 1] = k1; }
+    __syncthreads();
+    if (wave != 0) return;
+    // wave 0: the block's 2 * nw slots as one chunk.  A filled slot 0 of the first wave continues the previous
+    // block by construction, a filled slot 1 of the last wave is continued by the next one.
+    const int cnt2 = 2 * nw;
+    const int my_key2 = lane < cnt2 ? slot_keys[lane] : -1;
+    const float my_cnt2 = (lane < cnt2 && my_key2 >= 0) ? slots[(long)lane * D1p + D] : 0.0f;
+    const bool open_left2 = __builtin_amdgcn_readfirstlane(my_key2) >= 0;
+    const bool open_right2 = __builtin_amdgcn_readlane(my_key2, cnt2 - 1) >= 0;
+    int g0 = -1, g1 = -1;
+    seg_walk<false, VEC2>(nullptr, slots, my_key2, 0, my_cnt2, cnt2, open_left2, open_right2, D, D1p, accumulate, SC,
+                          cnt_dense, vout + (2 * blk) * (long)D1p, vout + (2 * blk + 1) * (long)D1p, g0, g1);
+    if (lane == 0) { kout[2 * blk] = g0; kout[2 * blk + 1] = g1; }
 }
 
 // ---- neighbourhood factor tables ---------------------------------------------------------------
@@ -282,6 +338,7 @@ __global__ __launch_bounds__(256) void neigh_tables_kernel(NeighParams p_val, co
 // the GEMM then walks only those chunks.  Skipped chunks would have added 0 * m = 0 to the accumulators,
 // so the result is bit-identical for finite data.
 constexpr int LM_BM = 128, LM_BN = 128, LM_BK = 32;
+constexpr int LM_NARROW = 32;   // column tiles this narrow take the VALU path of leftmul_f32_kernel
 
 // ranges[rb * nseg + s] = {segw - lo, hi}: columns [s*segw + lo, s*segw + hi) of rows [128 rb, 128 rb + 128) hold
 // every nonzero of that segment; both fields only grow (atomicMax from a zeroed buffer: {0, 0} = all zero).
@@ -313,11 +370,12 @@ __global__ __launch_bounds__(256) void band_ranges_kernel(const float* __restric
     }
 }
 
-// ranges == nullptr: the whole of H (one segment [0, Ri)).
+// ranges == nullptr: the whole of H (one segment [0, Ri)).  C columns are computed; rows of M and OUT are ld floats apart.
 __global__ __launch_bounds__(256) void leftmul_f32_kernel(const float* __restrict__ H, int Ro, int Ri,
                                                           const float* __restrict__ M, long m_batch_stride,
                                                           float* __restrict__ OUT, long o_batch_stride, long C,
-                                                          const int2* __restrict__ ranges, int nseg, int segw) {
+                                                          long ld, const int2* __restrict__ ranges, int nseg,
+                                                          int segw) {
     __shared__ float Hs[LM_BM][LM_BK + 1];
     __shared__ float Ms[LM_BK][LM_BN + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -344,7 +402,7 @@ __global__ __launch_bounds__(256) void leftmul_f32_kernel(const float* __restric
             int i = idx >> 5, k = idx & 31;            // H tile: 128 x 32
             hreg[q] = (i0 + i < Ro && r0 + k < kend) ? H[(long)(i0 + i) * Ri + r0 + k] : 0.0f;
             int kk = idx >> 7, c = idx & 127;          // M tile: 32 x 128
-            mreg[q] = (r0 + kk < kend && c0 + c < C) ? Mb[(long)(r0 + kk) * C + c0 + c] : 0.0f;
+            mreg[q] = (r0 + kk < kend && c0 + c < C) ? Mb[(long)(r0 + kk) * ld + c0 + c] : 0.0f;
         }
     };
     auto stash = [&]() {
@@ -402,9 +460,124 @@ __global__ __launch_bounds__(256) void leftmul_f32_kernel(const float* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int i = i0 + wr * 64 + a * 32 + mfma32_row(r, half);
-                if (i < Ro && c < C) Ob[(long)i * C + c] = acc[a][t][r];
+                if (i < Ro && c < C) Ob[(long)i * ld + c] = acc[a][t][r];
             }
         }
+}
+
+// The columns [c_begin, C) of the same product when they are too few for a 128-wide MFMA tile (the count
+// column and its padding behind input_len = 128: D1p = 132 = 128 + 4): a VALU kernel, thread = (row, column
+// parity), k-ordered fmaf chains over the same chunks in the same order -- bit for bit what the MFMA tile
+// computes (v_mfma_f32_32x32x2_f32 is that chain; skipped chunks add exact zeros) at a few percent of its time.
+// Grid = (1, row blocks, batch).
+template <int NQ>                                       // columns handled per thread: live <= 2 * NQ <= LM_NARROW
+__global__ __launch_bounds__(256) void leftmul_narrow_f32_kernel(const float* __restrict__ H, int Ro, int Ri,
+                                                                 const float* __restrict__ M, long m_batch_stride,
+                                                                 float* __restrict__ OUT, long o_batch_stride, long C,
+                                                                 long ld, long c_begin, const int2* __restrict__ ranges,
+                                                                 int nseg, int segw) {
+    __shared__ float Hs[LM_BM][LM_BK + 1];
+    __shared__ float Ms[LM_BK][2 * NQ];
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.y * LM_BM;
+    const float* Mb = M + (long)blockIdx.z * m_batch_stride;
+    float* Ob = OUT + (long)blockIdx.z * o_batch_stride;
+    const int live = (int)(C - c_begin);                // <= LM_NARROW
+    const int row = tid & (LM_BM - 1), par = tid >> 7;  // 256 threads = 128 rows x 2 column parities
+    float acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = 0.0f;
+
+    int lo = 0, hi = Ri, ns = 1, sw = Ri;
+    if (ranges != nullptr) {
+        ns = nseg; sw = segw; lo = segw; hi = 0;
+        for (int sg = 0; sg < nseg; ++sg) {
+            const int2 v = ranges[blockIdx.y * nseg + sg];
+            if (v.y > 0) { lo = min(lo, ((segw - v.x) / LM_BK) * LM_BK); hi = max(hi, min(v.y, segw)); }
+        }
+        if (hi <= lo) lo = hi = 0;
+    }
+    const int per = (hi - lo + LM_BK - 1) / LM_BK;
+    const int total = per * ns;
+    for (int c = 0; c < total; ++c) {
+        const int sg = c / per, j = c - sg * per;
+        const int r0 = sg * sw + lo + j * LM_BK, kend = sg * sw + hi;
+        __syncthreads();
+        for (int idx = tid; idx < LM_BM * LM_BK; idx += 256) {
+            const int i = idx >> 5, k = idx & 31;
+            Hs[i][k] = (i0 + i < Ro && r0 + k < kend) ? H[(long)(i0 + i) * Ri + r0 + k] : 0.0f;
+        }
+        for (int idx = tid; idx < LM_BK * 2 * NQ; idx += 256) {
+            const int k = idx / (2 * NQ), cc = idx - k * (2 * NQ);
+            Ms[k][cc] = (r0 + k < kend && cc < live) ? Mb[(long)(r0 + k) * ld + c_begin + cc] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < LM_BK; ++k) {
+            const float hv = Hs[row][k];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = __builtin_fmaf(hv, Ms[k][2 * q + par], acc[q]);
+        }
+    }
+    const int i = i0 + row;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        if (i < Ro && 2 * q + par < live) Ob[(long)i * ld + c_begin + 2 * q + par] = acc[q];
+}
+
+// ---- the count column's own transform ---------------------------------------------------------------
+// den = sum_t Px_t C Py_t^T with C[a][b] = the count of unit (a, b): two X x Y x {Y, nt X} products, 33 MFLOP each
+// at 256 x 256.  Kept out of the batched MFMA transform, whose column tiles are 128 wide: input_len = 128 would
+// give the count a second, empty tile.  OUT[i*oi + j*oj] = sum_k A[i*ai + k*ak] * B[k*bk + j*bj], k ascending,
+// one fmaf chain per output: exactly the chain the MFMA tiles computed for this column (skipped zero bands
+// add exact zeros), so the denominator is bit for bit what it was.  The operands are columns of wide arrays
+// (one float per 528-byte row), so the kernel is latency-bound: a workgroup (32 x 32 outputs) issues the loads of
+// SG_KC = 256 k-steps of both operands at once -- one round trip per 256 k-steps -- before it multiplies.
+constexpr int SG_KC = 256;
+__global__ __launch_bounds__(256) void strided_gemm_f32_kernel(const float* __restrict__ A, long ai, long ak,
+                                                               const float* __restrict__ B, long bk, long bj,
+                                                               float* __restrict__ OUT, long oi, long oj, int M, int N,
+                                                               int Kd, long a_batch, long b_batch, long o_batch) {
+    __shared__ float As[32][SG_KC + 1];
+    __shared__ float Bs[SG_KC][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    A += (long)blockIdx.z * a_batch; B += (long)blockIdx.z * b_batch; OUT += (long)blockIdx.z * o_batch;
+    // the unit-stride axis of each operand goes along tx (either k or the row / column index)
+    const bool a_k_fast = ak <= ai, b_j_fast = bj <= bk;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < Kd; k0 += SG_KC) {
+        __syncthreads();
+        float ra[SG_KC / 8], rb[SG_KC / 8];
+#pragma unroll
+        for (int q = 0; q < SG_KC / 8; ++q) {                    // 32 * SG_KC elements of each operand, 256 threads
+            const int e = q * 256 + threadIdx.x;
+            const int ar = a_k_fast ? e / SG_KC : e & 31, akk = a_k_fast ? e % SG_KC : e >> 5;
+            ra[q] = (i0 + ar < M && k0 + akk < Kd) ? A[(long)(i0 + ar) * ai + (long)(k0 + akk) * ak] : 0.0f;
+            const int bc = b_j_fast ? e & 31 : e / SG_KC, bkk = b_j_fast ? e >> 5 : e % SG_KC;
+            rb[q] = (k0 + bkk < Kd && j0 + bc < N) ? B[(long)(k0 + bkk) * bk + (long)(j0 + bc) * bj] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < SG_KC / 8; ++q) {
+            const int e = q * 256 + threadIdx.x;
+            const int ar = a_k_fast ? e / SG_KC : e & 31, akk = a_k_fast ? e % SG_KC : e >> 5;
+            As[ar][akk] = ra[q];
+            const int bc = b_j_fast ? e & 31 : e / SG_KC, bkk = b_j_fast ? e >> 5 : e % SG_KC;
+            Bs[bkk][bc] = rb[q];
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < SG_KC; ++k) {
+            const float b = Bs[k][tx];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(As[ty + 8 * r][k], b, acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ty + 8 * r, j = j0 + tx;
+        if (i < M && j < N) OUT[(long)i * oi + (long)j * oj] = acc[r];
+    }
 }
 
 // ---- merge: W = where(den != 0, num/den, W)  (xpysom.py:446-455) ---------------------------------

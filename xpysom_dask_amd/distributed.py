@@ -57,9 +57,65 @@ def allreduce_accumulator(engine):
         torch.cuda.current_stream(t.device).synchronize()
 
 
+_comm_streams = {}
+
+
+def _overlap_wanted(engine, world):
+    """Blockwise all-reduce under the transform's tail: on by default under RCCL with more than one rank when the map
+    has more than one 128-row block; SOM_OVERLAP=0 / 1 forces it off / on (1 also on host-staged backends, where the
+    blocks are reduced one synchronous call at a time -- the equality tests run it under gloo)."""
+    force = os.environ.get("SOM_OVERLAP")
+    if force is not None:
+        return force != "0" and hasattr(engine, "epoch_accumulate_block")
+    if world == 1 or not hasattr(engine, "epoch_accumulate_block"):
+        return False
+    import torch.distributed as dist
+    return dist.get_backend() == "nccl" and engine.epoch_block_count() > 1
+
+
+def _epoch_overlapped(engine, sigma, eta, neigh_f64):
+    """accumulate -> [stage 2 of block b  ||  all-reduce of block b-1] ... -> merge.  The slices of the fused
+    accumulator are disjoint, so the result equals the monolithic all-reduce element for element."""
+    import torch
+    import torch.distributed as dist
+    engine.epoch_accumulate_begin(sigma, eta, neigh_f64)
+    t = engine.accum_tensor()
+    nb = engine.epoch_block_count()
+    stream_ordered = t.is_cuda and dist.get_backend() == "nccl"
+    ext = comm = None
+    if stream_ordered:
+        try:
+            ext = torch.cuda.ExternalStream(engine.stream_ptr(), device=t.device)
+        except Exception:
+            stream_ordered = False
+    if stream_ordered:
+        comm = _comm_streams.get(t.device.index)
+        if comm is None:
+            comm = _comm_streams[t.device.index] = torch.cuda.Stream(device=t.device)
+    for b in range(nb):
+        off, n = engine.epoch_accumulate_block(b)
+        if stream_ordered:
+            ev = torch.cuda.Event()
+            ev.record(ext)                             # block b's kernels are queued on the engine's stream
+            comm.wait_event(ev)
+            with torch.cuda.stream(comm):
+                dist.all_reduce(t[off:off + n], op=dist.ReduceOp.SUM)
+        else:
+            engine.sync()
+            dist.all_reduce(t[off:off + n], op=dist.ReduceOp.SUM)
+            if t.is_cuda:
+                torch.cuda.current_stream(t.device).synchronize()
+    if stream_ordered:
+        ext.wait_stream(comm)                          # the merge queued next waits for the last collective
+    engine.epoch_merge()
+
+
 def epoch(engine, sigma, eta, neigh_f64, chunks=None):
     """One data-parallel epoch on this rank's shard (resident rows, or `chunks` streamed through)."""
     if chunks is None:
+        rank, world = dist_info()
+        if (world > 1 or os.environ.get("SOM_FORCE_ALLREDUCE")) and _overlap_wanted(engine, world):
+            return _epoch_overlapped(engine, sigma, eta, neigh_f64)
         engine.epoch_accumulate(sigma, eta, neigh_f64)
     else:
         engine.stream_epoch_accumulate(chunks, sigma, eta, neigh_f64)

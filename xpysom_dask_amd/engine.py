@@ -110,6 +110,22 @@ class HipEngine:
         self._check(self._lib.som_epoch_accumulate_forced(self._h, self._ip(bmu), float(sigma), float(eta),
                                                           int(bool(neigh_f64))))
 
+    def epoch_accumulate_begin(self, sigma, eta, neigh_f64):
+        """epoch_accumulate up to stage 1 of the transform; `epoch_accumulate_block` finishes the accumulator
+        one map-row block at a time (see include/somhip.h)."""
+        self._check(self._lib.som_epoch_accumulate_begin(self._h, float(sigma), float(eta), int(bool(neigh_f64))))
+
+    def epoch_block_count(self):
+        n = C.c_int32()
+        self._check(self._lib.som_epoch_block_count(self._h, C.byref(n)))
+        return n.value
+
+    def epoch_accumulate_block(self, block):
+        """Stage 2 of map-row block `block`; returns (offset, n_floats) of the now final slice of the accumulator."""
+        off, n = C.c_int64(), C.c_int64()
+        self._check(self._lib.som_epoch_accumulate_block(self._h, int(block), C.byref(off), C.byref(n)))
+        return off.value, n.value
+
     def epoch_merge(self):
         self._check(self._lib.som_epoch_merge(self._h))
 
