@@ -141,6 +141,23 @@ int som_stream_begin(som_handle* h);
 int som_stream_rows(som_handle* h, const float* x_host, int64_t n_rows);
 int som_stream_end(som_handle* h, double sigma, double eta, int neigh_f64);
 
+/* The exchange step inside the library: one process per GPU, RCCL (bound at run time with dlopen -- the copy a host
+ * such as torch already loaded, else librccl.so.1) all-reduces the fused accumulator over xGMI.  Replaces the Dask
+ * gather -> sum -> broadcast of xpysom.py:545-558 for a caller that has nothing but this header:
+ *   rank 0: som_comm_unique_id(id)  -> the host hands the 128 bytes to every rank (MPI, a file, a socket, ...)
+ *   every rank: som_comm_init(h, world, rank, id)   collective; afterwards som_epoch() all-reduces between
+ *                                   accumulate and merge (block by block under the transform when the map has
+ *                                   more than one 128-row block), and som_epoch_allreduce() does the same for a host
+ *                                   that drives accumulate / merge itself
+ *   som_comm_destroy(h)             before som_destroy, on every rank
+ * som_comm_load(path) picks the RCCL library explicitly (optional; NULL = the search described above). */
+#define SOM_COMM_ID_BYTES 128
+int som_comm_load(const char* librccl_path);
+int som_comm_unique_id(void* id_out);
+int som_comm_init(som_handle* h, int32_t world, int32_t rank, const void* id_bytes);
+int som_epoch_allreduce(som_handle* h);
+int som_comm_destroy(som_handle* h);
+
 /* device address and length (floats) of the fused accumulator, for an in-place
  * all-reduce by the host (RCCL via torch.distributed). */
 int som_accum_device_ptr(som_handle* h, void** dev_ptr, int64_t* n_floats);

@@ -513,9 +513,59 @@ for overlap in ("0", "1"):
         D.epoch(e, sig, eta, True)
     outs.append(e.get_weights())
 assert np.array_equal(outs[0], outs[1])
+# SOM_COMM=native: the same epochs with the collective inside libsomhip (torch's copy of RCCL, bound with dlopen)
+os.environ["SOM_COMM"] = "native"
+e = HipEngine(300, 5, 6)
+e.set_weights(w); e.set_data(data)
+for sig, eta in ((9.0, 0.5), (4.0, 0.3), (2.0, 0.2)):
+    D.epoch(e, sig, eta, True)
+assert e.has_comm and np.array_equal(e.get_weights(), outs[0])
+e.comm_destroy()
 dist.destroy_process_group()
 print("nccl-path-ok")
 """
+
+
+_NATIVE_COMM_SCRIPT = r"""
+# a caller with nothing but include/somhip.h (no torch in this process): communicator of one rank, epochs through
+# som_epoch -- whole-buffer all-reduce on a one-block map, block-by-block on a second stream on a three-block map
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["SOM_REPO"])
+from oracle import som_oracle as O
+from xpysom_dask_amd.engine import HipEngine
+assert "torch" not in sys.modules
+for (X, Y, D) in ((9, 8, 6), (300, 5, 6)):
+    data = O.gaussian_blobs(3000, D, seed=3)
+    w = O.default_codebook(X, Y, D, 4).astype(np.float32)
+    outs = []
+    for native in (False, True):
+        e = HipEngine(X, Y, D)
+        if native:
+            e.comm_init(1, 0, e.comm_unique_id())
+        e.set_weights(w); e.set_data(data)
+        for sig, eta in ((4.0, 0.5), (2.0, 0.3), (1.0, 0.2)):
+            e.epoch(sig, eta, True)
+        outs.append(e.get_weights())
+        if native:
+            e.stream_epoch_accumulate([data[:1000], data[1000:]], 1.0, 0.1, True)
+            e.epoch_allreduce(); e.epoch_merge()
+            assert np.isfinite(e.get_weights()).all()
+            e.comm_destroy()
+    assert np.array_equal(outs[0], outs[1])
+print("native-comm-ok")
+"""
+
+
+def test_rccl_inside_the_library(tmp_path):
+    """som_comm_* (include/somhip.h): the collective behind the C ABI, no torch in the process."""
+    import os, subprocess, sys
+    from tests.conftest import REPO
+    script = tmp_path / "native_comm.py"
+    script.write_text(_NATIVE_COMM_SCRIPT)
+    env = dict(os.environ, SOM_REPO=REPO, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "native-comm-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_rccl_allreduce_runs_in_place_on_the_engine_buffer(tmp_path):

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Fold the passes of tools/pmc_all.sh into one JSON per (tag, rows): per kernel the mean counter values per dispatch
+(timed launches only: the first `warmup` dispatches of each kernel are dropped where the kernel runs once per epoch),
+its mean duration from the kernel trace, and the derived figures DESIGN.md quotes:
+  mfma_busy      SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs)
+  clock_ghz      GRBM_GUI_ACTIVE / 8 / duration   (MI355X_MICROARCH.md, DVFS give-back)
+  valu_per_mfma  (SQ_INSTS_VALU - SQ_INSTS_MFMA) / SQ_INSTS_MFMA
+  fabric_bytes_corrected  2 * FETCH_SIZE(KB) * 1024 + WRITE_SIZE(KB) * 1024   (gfx950 counts a 128-B read as 64 B)
+  l2_hit         TCC_HIT / (TCC_HIT + TCC_MISS)
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+out_dir, tag, rows = sys.argv[1], sys.argv[2], int(sys.argv[3])
+extra = sys.argv[4:]
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = name.split("(")[0]
+    name = re.sub(r"^somhip::", "", name)
+    if "rocprim" in name or "ROCPRIM" in name:
+        name = "rocprim::" + ("merge_sort" if "merge" in name else "radix_sort" if "radix" in name or "onesweep" in name else "other")
+    return name
+
+
+counters = collections.defaultdict(lambda: collections.defaultdict(list))
+for sub in ("sq_a", "sq_b", "fetch", "write", "tcc"):
+    for f in glob.glob(os.path.join(out_dir, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            counters[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+dur = {}
+for f in glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3,
+                                 "max_us": float(r["MaxNs"]) / 1e3}
+    stats_copy = os.path.join("gpurun_out", "%s_kernel_stats_rows%d.csv" % (tag, rows))
+    open(stats_copy, "w").write(open(f).read())
+
+from xpysom_dask_amd import build as B  # noqa: E402
+lib = os.environ.get("SOM_LIB_PATH")
+res = {"note": "rocprofv3 --pmc passes (one counter group per pass) of `python3 bench.py --rows %d --steps 3 --warmup 1 "
+               "--no-cpu-baseline --no-batch65536 %s`; per-dispatch means; durations from a separate --kernel-trace pass. "
+               "FETCH_SIZE / WRITE_SIZE are KB; on gfx950 a wide coalesced read is tallied at half its bytes "
+               "(MI355X_MICROARCH.md, HBM): fabric bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024; Infinity-Cache hits "
+               "are included, so this bounds HBM traffic from above." % (rows, " ".join(extra)),
+       "workload": "c3" if "--workload" not in extra else extra[extra.index("--workload") + 1],
+       "rows_per_launch": rows, "precision": "bf16" if "--precision" not in extra else extra[extra.index("--precision") + 1],
+       "build": B.built_hash(lib) if lib else B.built_hash(), "library": os.path.basename(lib) if lib else "libsomhip.so"}
+for k, cs in sorted(counters.items()):
+    d = {c: sum(v) / len(v) for c, v in cs.items()}
+    d["dispatches"] = max(len(v) for v in cs.values())
+    if k in dur:
+        d["duration_us"] = dur[k]["avg_us"]
+    if "GRBM_GUI_ACTIVE" in d and "SQ_VALU_MFMA_BUSY_CYCLES" in d and d["GRBM_GUI_ACTIVE"] > 0:
+        d["mfma_busy"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+    if "GRBM_GUI_ACTIVE" in d and k in dur and dur[k]["avg_us"] > 0:
+        d["clock_ghz"] = d["GRBM_GUI_ACTIVE"] / 8.0 / (dur[k]["avg_us"] * 1e3)
+    if d.get("SQ_INSTS_MFMA", 0) > 0:
+        d["valu_per_mfma"] = (d["SQ_INSTS_VALU"] - d["SQ_INSTS_MFMA"]) / d["SQ_INSTS_MFMA"]
+    if "SQ_WAVE_CYCLES" in d and d["SQ_WAVE_CYCLES"] > 0:
+        for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+            if c in d:
+                d[c.lower() + "_share"] = d[c] / d["SQ_WAVE_CYCLES"]
+    if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
+        d["fabric_bytes_corrected"] = 2.0 * d.get("FETCH_SIZE", 0.0) * 1024.0 + d.get("WRITE_SIZE", 0.0) * 1024.0
+    if d.get("TCC_HIT_sum", 0) + d.get("TCC_MISS_sum", 0) > 0:
+        d["l2_hit"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
+    res[k] = d
+path = os.path.join("gpurun_out", "%s_pmc_traffic_rows%d.json" % (tag, rows))
+json.dump(res, open(path, "w"), indent=1, sort_keys=True)
+print("wrote", path)
+for k in sorted(res):
+    if isinstance(res[k], dict) and ("mfma_busy" in res[k] or "fabric_bytes_corrected" in res[k]):
+        d = res[k]
+        print("%-34s dur %9.1f us  mfma_busy %s clock %s valu/mfma %s fabric %s MB l2hit %s wait %s" % (
+            k, d.get("duration_us", float("nan")), "%.3f" % d["mfma_busy"] if "mfma_busy" in d else "-",
+            "%.2f" % d["clock_ghz"] if "clock_ghz" in d else "-", "%.2f" % d["valu_per_mfma"] if "valu_per_mfma" in d else "-",
+            "%.1f" % (d["fabric_bytes_corrected"] / 1e6) if "fabric_bytes_corrected" in d else "-",
+            "%.3f" % d["l2_hit"] if "l2_hit" in d else "-", "%.3f" % d["sq_wait_any_share"] if "sq_wait_any_share" in d else "-"))

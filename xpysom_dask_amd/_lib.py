@@ -47,6 +47,11 @@ SIGNATURES = {
     "som_epoch_accumulate_begin": (C.c_int, [_H, C.c_double, C.c_double, C.c_int]),
     "som_epoch_block_count": (C.c_int, [_H, C.POINTER(C.c_int32)]),
     "som_epoch_accumulate_block": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "som_comm_load": (C.c_int, [C.c_char_p]),
+    "som_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "som_comm_init": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p]),
+    "som_epoch_allreduce": (C.c_int, [_H]),
+    "som_comm_destroy": (C.c_int, [_H]),
     "som_pinned_alloc": (C.c_int, [C.c_uint64, C.POINTER(C.c_void_p)]),
     "som_pinned_free": (C.c_int, [C.c_void_p]),
     "som_stream_begin": (C.c_int, [_H]),
@@ -67,6 +72,18 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+def torch_lib_file(name):
+    """Path of a library bundled with torch (or None): the copy this process must share with torch."""
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", name)
+    return cand if os.path.exists(cand) else None
 
 
 def _preload_torch_hip_runtime():

@@ -175,8 +175,20 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
         lds_dma_16(Wst + (long)s_begin * STAGE + (long)p * 1024 + lane * 16, smem + p * 1024);
 
     auto reduce_tile = [&](const f32x4 (&acc)[K16_SB], int t16) {
+#if defined(SOM_K16_EXPERIMENT) && SOM_K16_EXPERIMENT == 1
+        // TIMING EXPERIMENT ONLY (wrong unit ids): value-only running minimum, 2 VALU per (tile, sample block)
 #pragma unroll
         for (int sb = 0; sb < K16_SB; ++sb) {
+            cbest[sb] = min(min(cbest[sb], (int32_t)__float_as_uint(acc[sb][0])), (int32_t)__float_as_uint(acc[sb][1]));
+            cbest[sb] = min(min(cbest[sb], (int32_t)__float_as_uint(acc[sb][2])), (int32_t)__float_as_uint(acc[sb][3]));
+        }
+        return;
+#endif
+#pragma unroll
+        for (int sb = 0; sb < K16_SB; ++sb) {
+#if defined(SOM_K16_EXPERIMENT) && SOM_K16_EXPERIMENT == 2
+            if (sb > 0) { cbest[sb] = min(cbest[sb], (int32_t)__float_as_uint(acc[sb][0])); continue; }   // TIMING EXPERIMENT ONLY
+#endif
             int32_t key[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -7,6 +7,8 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -36,8 +38,26 @@ struct EventPair { hipEvent_t a, b; int kernel; };
 
 }  // namespace
 
+// RCCL, bound at run time (dlopen): the library has no link-time dependency on it, and in a process that also
+// runs torch the SAME copy torch loaded is used.  Only what the one exchange step of the path needs.
+struct som_nccl_id { char internal[128]; };
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(som_nccl_id*) = nullptr;
+    int (*CommInitRank)(void**, int, som_nccl_id, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+static std::string g_rccl_error;
+
 struct som_handle {
     som_config cfg{};
+    void* comm = nullptr;        // ncclComm_t of som_comm_init (NULL: single GPU, or the host does the all-reduce)
+    int comm_world = 1;
+    hipStream_t comm_stream = nullptr;   // the blockwise all-reduce runs here, under the transform of the next block
+    hipEvent_t ev_block = nullptr, ev_comm = nullptr;
     int X = 0, Y = 0, K = 0, D = 0, D1p = 0;
     int ksteps = 0;          // bf16, 32x32x16 shape: ceil(D/16)
     int ks32 = 0;            // bf16, 16x16x32 shape: ceil(D/32)
@@ -1054,6 +1074,10 @@ int som_create(const som_config* cfg, som_handle** out) {
 void som_destroy(som_handle* h) {
     if (!h) return;
     DeviceGuard dev_guard(h);
+    (void)som_comm_destroy(h);
+    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+    if (h->ev_block) (void)hipEventDestroy(h->ev_block);
+    if (h->ev_comm) (void)hipEventDestroy(h->ev_comm);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->np_dev) (void)hipFree(h->np_dev);
@@ -1377,8 +1401,123 @@ int som_epoch_merge(som_handle* h) {
     return 0;
 }
 
+int som_epoch_accumulate_begin(som_handle* h, double sigma, double eta, int neigh_f64);
+int som_epoch_accumulate_block(som_handle* h, int32_t block, int64_t* offset, int64_t* n_floats);
+
+// ---- the exchange step inside the library: RCCL all-reduce of the fused accumulator over xGMI ----------------
+namespace {
+int rccl_load(const char* path) {
+    if (g_rccl.lib) return 0;
+    const char* cands[] = {path, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* c : cands) {                       // a copy some other component of the process already loaded, first
+        if (!c) continue;
+        lib = dlopen(c, RTLD_NOW | RTLD_NOLOAD);
+        if (lib) break;
+    }
+    for (const char* c : cands) {
+        if (lib) break;
+        if (c) lib = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+    }
+    if (!lib) { g_rccl_error = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return 1; }
+    RcclApi a;
+    a.lib = lib;
+    a.GetUniqueId = (int (*)(som_nccl_id*))dlsym(lib, "ncclGetUniqueId");
+    a.CommInitRank = (int (*)(void**, int, som_nccl_id, int))dlsym(lib, "ncclCommInitRank");
+    a.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclAllReduce");
+    a.CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+    a.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy) { g_rccl_error = "librccl: symbols missing"; return 1; }
+    g_rccl = a;
+    return 0;
+}
+int fail_rccl(som_handle* h, const char* what, int code) {
+    return fail(h, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(code) : "RCCL error"));
+}
+constexpr int NCCL_FLOAT32 = 7, NCCL_SUM = 0;           // rccl.h: ncclFloat32, ncclSum
+
+int comm_allreduce(som_handle* h, long offset, long n_floats, hipStream_t st) {
+    int rc = g_rccl.AllReduce(h->ACC + offset, h->ACC + offset, (size_t)n_floats, NCCL_FLOAT32, NCCL_SUM, h->comm, st);
+    if (rc != 0) return fail_rccl(h, "ncclAllReduce", rc);
+    return 0;
+}
+}  // namespace
+
+int som_comm_load(const char* librccl_path) {
+    if (rccl_load(librccl_path)) { g_create_error = g_rccl_error; return 1; }
+    return 0;
+}
+
+int som_comm_unique_id(void* id_out) {
+    if (!id_out) return 1;
+    if (rccl_load(nullptr)) { g_create_error = g_rccl_error; return 1; }
+    som_nccl_id id;
+    int rc = g_rccl.GetUniqueId(&id);
+    if (rc != 0) { g_create_error = "ncclGetUniqueId failed"; return 1; }
+    std::memcpy(id_out, id.internal, sizeof(id.internal));
+    return 0;
+}
+
+int som_comm_init(som_handle* h, int32_t world, int32_t rank, const void* id_bytes) {
+    DeviceGuard dev_guard(h);
+    if (!h || !id_bytes || world < 1 || rank < 0 || rank >= world) return fail(h, "som_comm_init: bad argument");
+    if (h->comm) return fail(h, "som_comm_init: this handle already has a communicator");
+    if (rccl_load(nullptr)) return fail(h, g_rccl_error);
+    som_nccl_id id;
+    std::memcpy(id.internal, id_bytes, sizeof(id.internal));
+    int rc = g_rccl.CommInitRank(&h->comm, world, id, rank);
+    if (rc != 0) { h->comm = nullptr; return fail_rccl(h, "ncclCommInitRank", rc); }
+    h->comm_world = world;
+    if (!h->comm_stream) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_block, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_comm, hipEventDisableTiming));
+    }
+    return 0;
+}
+
+int som_comm_destroy(som_handle* h) {
+    DeviceGuard dev_guard(h);
+    if (!h) return 1;
+    if (h->comm) {
+        (void)hipStreamSynchronize(h->stream);
+        if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+        (void)g_rccl.CommDestroy(h->comm);
+        h->comm = nullptr;
+        h->comm_world = 1;
+    }
+    return 0;
+}
+
+int som_epoch_allreduce(som_handle* h) {
+    DeviceGuard dev_guard(h);
+    if (!h) return 1;
+    if (!h->comm) return 0;                             // one GPU: the local sums are the global ones
+    return comm_allreduce(h, 0, (long)h->K * h->D1p, h->stream);
+}
+
+// accumulate (+ all-reduce, when som_comm_init gave this handle a communicator) + merge.  With more than one
+// 128-row block of the map the collective runs block by block on a second stream, each block's all-reduce under
+// the next block's transform; one block: one all-reduce on the handle's own stream.
 int som_epoch(som_handle* h, double sigma, double eta, int neigh_f64) {
-    if (int rc = som_epoch_accumulate(h, sigma, eta, neigh_f64)) return rc;
+    if (!h) return 1;
+    const int nb = (int)cdiv(h->X, LM_BM);
+    if (!h->comm || nb < 2) {
+        if (int rc = som_epoch_accumulate(h, sigma, eta, neigh_f64)) return rc;
+        if (int rc = som_epoch_allreduce(h)) return rc;
+        return som_epoch_merge(h);
+    }
+    DeviceGuard dev_guard(h);
+    if (int rc = som_epoch_accumulate_begin(h, sigma, eta, neigh_f64)) return rc;
+    for (int b = 0; b < nb; ++b) {
+        int64_t off = 0, n = 0;
+        if (int rc = som_epoch_accumulate_block(h, b, &off, &n)) return rc;
+        HIPCHK(h, hipEventRecord(h->ev_block, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_block, 0));
+        if (int rc = comm_allreduce(h, off, n, h->comm_stream)) return rc;
+    }
+    HIPCHK(h, hipEventRecord(h->ev_comm, h->comm_stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_comm, 0));
     return som_epoch_merge(h);
 }
 

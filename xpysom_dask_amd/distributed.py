@@ -110,10 +110,32 @@ def _epoch_overlapped(engine, sigma, eta, neigh_f64):
     engine.epoch_merge()
 
 
+def _native_comm(engine, rank, world):
+    """SOM_COMM=native: the all-reduce runs inside libsomhip (RCCL bound with dlopen, include/somhip.h som_comm_*);
+    torch.distributed only carries rank 0's 128-byte RCCL id to the other ranks, once per engine."""
+    if getattr(engine, "has_comm", False):
+        return
+    ids = [engine.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        import torch.distributed as dist
+        dist.broadcast_object_list(ids, src=0)
+    engine.comm_init(world, rank, ids[0])
+
+
 def epoch(engine, sigma, eta, neigh_f64, chunks=None):
     """One data-parallel epoch on this rank's shard (resident rows, or `chunks` streamed through)."""
+    rank, world = dist_info()
+    if os.environ.get("SOM_COMM") == "native" and hasattr(engine, "comm_init") and \
+            (world > 1 or os.environ.get("SOM_FORCE_ALLREDUCE")):
+        _native_comm(engine, rank, world)
+        if chunks is None:
+            engine.epoch(sigma, eta, neigh_f64)        # accumulate, RCCL all-reduce (blockwise on wide maps), merge
+        else:
+            engine.stream_epoch_accumulate(chunks, sigma, eta, neigh_f64)
+            engine.epoch_allreduce()
+            engine.epoch_merge()
+        return
     if chunks is None:
-        rank, world = dist_info()
         if (world > 1 or os.environ.get("SOM_FORCE_ALLREDUCE")) and _overlap_wanted(engine, world):
             return _epoch_overlapped(engine, sigma, eta, neigh_f64)
         engine.epoch_accumulate(sigma, eta, neigh_f64)

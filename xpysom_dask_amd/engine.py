@@ -37,6 +37,7 @@ class HipEngine:
         if self._lib.som_create(C.byref(cfg), C.byref(h)) != 0:
             raise SomHipError(self._lib.som_last_error(None).decode())
         self._h = h
+        self.has_comm = False
         self.device = int(device)
         self.precision = precision
 
@@ -125,6 +126,36 @@ class HipEngine:
         off, n = C.c_int64(), C.c_int64()
         self._check(self._lib.som_epoch_accumulate_block(self._h, int(block), C.byref(off), C.byref(n)))
         return off.value, n.value
+
+    # -- the collective inside the library (include/somhip.h, som_comm_*) ---------------------------------
+    def comm_unique_id(self):
+        """128 opaque bytes from RCCL: rank 0 creates them, the host hands them to every rank."""
+        import sys
+        if "torch" in sys.modules:                    # share torch's copy of RCCL (and so its HIP runtime)
+            path = _lib.torch_lib_file("librccl.so")
+            if path:
+                self._lib.som_comm_load(path.encode())
+        buf = C.create_string_buffer(128)
+        if self._lib.som_comm_unique_id(buf) != 0:
+            raise SomHipError(self._lib.som_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, world, rank, unique_id):
+        import sys
+        if "torch" in sys.modules:
+            path = _lib.torch_lib_file("librccl.so")
+            if path:
+                self._lib.som_comm_load(path.encode())
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(self._lib.som_comm_init(self._h, int(world), int(rank), buf))
+        self.has_comm = True
+
+    def comm_destroy(self):
+        self._check(self._lib.som_comm_destroy(self._h))
+        self.has_comm = False
+
+    def epoch_allreduce(self):
+        self._check(self._lib.som_epoch_allreduce(self._h))
 
     def epoch_merge(self):
         self._check(self._lib.som_epoch_merge(self._h))
