@@ -1171,3 +1171,32 @@ def test_staged_epoch_equals_the_monolithic_one():
         from xpysom_dask_amd.engine import SomHipError
         with pytest.raises(SomHipError):
             e.epoch_accumulate_block(0)                        # no epoch in progress
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_nan_semantics_documented_in_design(precision):
+    """DESIGN.md 4, known difference: a unit whose distance is NaN never wins (`<` semantics), where numpy.argmin
+    returns the FIRST NaN unit; a row whose distances are ALL NaN returns unit 0, as numpy.argmin does.  Only a
+    codebook (or a row) that already holds NaN can get there; this pins what the engine does."""
+    X, Y, D = 4, 5, 6
+    rs = np.random.RandomState(2)
+    w = rs.randn(X * Y, D).astype(F32)
+    x = rs.randn(50, D).astype(F32)
+    e = engine(X, Y, D, precision=precision)
+    e.set_weights(w)
+    clean = e.bmu(x)
+    wn = w.copy()
+    wn[3] = np.nan                                              # one NaN unit: it never wins, the others keep their order
+    e.set_weights(wn)
+    got = e.bmu(x)
+    assert (got != 3).all()
+    keep = clean != 3
+    if precision == "f32":
+        assert np.array_equal(got[keep], clean[keep])
+    else:                                                       # (bf16: the offset B = max|x~| max|w~| ignores NaN norms)
+        assert (got[keep] == clean[keep]).mean() > 0.9
+    xn = x.copy()
+    xn[7] = np.nan                                              # an all-NaN row: unit 0
+    e.set_weights(w)
+    got = e.bmu(xn)
+    assert got[7] == 0 and np.array_equal(np.delete(got, 7), np.delete(clean, 7))

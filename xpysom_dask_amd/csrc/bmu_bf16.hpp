@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void prep_w_bf16_kernel(const float* __restric
 // positive floats order like their bit patterns: a float max through an integer atomic
 __device__ __forceinline__ void atomic_max_pos_f32(float* addr, float v) {
     // a million waves share one address: only a value that would raise the maximum pays for the atomic
-    if (__float_as_uint(v) > __hip_atomic_load((unsigned int*)addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    // (a NaN norm -- a NaN row or unit -- is left out: the offset B must stay finite for everybody else)
+    if (v == v && __float_as_uint(v) > __hip_atomic_load((unsigned int*)addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         atomicMax((unsigned int*)addr, __float_as_uint(v));
 }
 

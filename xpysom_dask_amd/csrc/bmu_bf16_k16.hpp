@@ -158,12 +158,12 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
         for (int ks = 0; ks < KS32; ++ks) xf[sb][ks] = *(const bf16x8*)(Xb + row * DP + ks * 32 + quad * 8);
     }
 
-    int32_t gbest[K16_SB], cbest[K16_SB];
+    uint32_t gbest[K16_SB], cbest[K16_SB];   // unsigned: a NaN (either sign) is above every finite positive d'
     int gstage[K16_SB];
     f32x4 accP[K16_SB];
 #pragma unroll
     for (int sb = 0; sb < K16_SB; ++sb) {
-        gbest[sb] = 0x7FFFFFFF; cbest[sb] = 0x7FFFFFFF; gstage[sb] = 0;
+        gbest[sb] = 0xFFFFFFFFu; cbest[sb] = 0xFFFFFFFFu; gstage[sb] = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) accP[sb][r] = __builtin_inff();
     }
@@ -179,21 +179,21 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
         // TIMING EXPERIMENT ONLY (wrong unit ids): value-only running minimum, 2 VALU per (tile, sample block)
 #pragma unroll
         for (int sb = 0; sb < K16_SB; ++sb) {
-            cbest[sb] = min(min(cbest[sb], (int32_t)__float_as_uint(acc[sb][0])), (int32_t)__float_as_uint(acc[sb][1]));
-            cbest[sb] = min(min(cbest[sb], (int32_t)__float_as_uint(acc[sb][2])), (int32_t)__float_as_uint(acc[sb][3]));
+            cbest[sb] = min(min(cbest[sb], __float_as_uint(acc[sb][0])), __float_as_uint(acc[sb][1]));
+            cbest[sb] = min(min(cbest[sb], __float_as_uint(acc[sb][2])), __float_as_uint(acc[sb][3]));
         }
         return;
 #endif
 #pragma unroll
         for (int sb = 0; sb < K16_SB; ++sb) {
 #if defined(SOM_K16_EXPERIMENT) && SOM_K16_EXPERIMENT == 2
-            if (sb > 0) { cbest[sb] = min(cbest[sb], (int32_t)__float_as_uint(acc[sb][0])); continue; }   // TIMING EXPERIMENT ONLY
+            if (sb > 0) { cbest[sb] = min(cbest[sb], __float_as_uint(acc[sb][0])); continue; }   // TIMING EXPERIMENT ONLY
 #endif
-            int32_t key[4];
+            uint32_t key[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float f = acc[sb][r];
-                key[r] = (int32_t)((__float_as_uint(f) & ~IDX_MASK) | (uint32_t)(t16 * 4 + r));
+                key[r] = (__float_as_uint(f) & ~IDX_MASK) | (uint32_t)(t16 * 4 + r);
             }
             cbest[sb] = min(min(cbest[sb], key[0]), key[1]);
             cbest[sb] = min(min(cbest[sb], key[2]), key[3]);
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
 #pragma unroll
         for (int sb = 0; sb < K16_SB; ++sb) {
             if (cbest[sb] < gbest[sb]) { gbest[sb] = cbest[sb]; gstage[sb] = stage; }
-            cbest[sb] = 0x7FFFFFFF;
+            cbest[sb] = 0xFFFFFFFFu;
         }
     };
 
@@ -263,10 +263,10 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
 
 #pragma unroll
     for (int sb = 0; sb < K16_SB; ++sb) {
-        uint32_t code = (uint32_t)gbest[sb] & IDX_MASK;
+        uint32_t code = gbest[sb] & IDX_MASK;
         uint32_t unit = (uint32_t)gstage[sb] * K16_STAGE_UNITS + (code >> 2) * 16 + quad * 4 + (code & 3);
         // all distances are positive floats: (value bits, unit) orders as one unsigned 64-bit key
-        unsigned long long comp = ((unsigned long long)((uint32_t)gbest[sb] & ~IDX_MASK) << 32) | unit;
+        unsigned long long comp = ((unsigned long long)(gbest[sb] & ~IDX_MASK) << 32) | unit;
         unsigned long long o = __shfl_xor(comp, 16, 64);
         if (o < comp) comp = o;
         o = __shfl_xor(comp, 32, 64);

@@ -196,10 +196,10 @@ __global__ __launch_bounds__(64 * NWR * NWC, 2) void bmu_bf16_tiled_kernel(const
         slot_i = (slot_i + 1) & (TL_SLOTS - 1);
     };
 
-    int32_t gbest[WS];
+    uint32_t gbest[WS];                                 // unsigned keys: a NaN of either sign never beats a finite d'
     int gblock[WS];
 #pragma unroll
-    for (int sb = 0; sb < WS; ++sb) { gbest[sb] = 0x7FFFFFFF; gblock[sb] = 0; }
+    for (int sb = 0; sb < WS; ++sb) { gbest[sb] = 0xFFFFFFFFu; gblock[sb] = 0; }
     f32x4 acc[4][WS];                                    // [unit tile16][sample block16]
     bf16x8 fa[4], fb[WS];                                // fragments of the stage about to be multiplied
     f32x4 cin[4];                                        // C-in rows of the unit block that starts with it
@@ -224,18 +224,18 @@ __global__ __launch_bounds__(64 * NWR * NWC, 2) void bmu_bf16_tiled_kernel(const
     auto reduce_block = [&](int ub) {                    // the 64 x 64 blocks of distances are complete
 #pragma unroll
         for (int sb = 0; sb < WS; ++sb) {
-            int32_t c0 = 0x7FFFFFFF, c1 = 0x7FFFFFFF;
+            uint32_t c0 = 0xFFFFFFFFu, c1 = 0xFFFFFFFFu;
 #pragma unroll
             for (int tu = 0; tu < 4; ++tu) {
                 const float f0 = acc[tu][sb][0], f1 = acc[tu][sb][1], f2 = acc[tu][sb][2], f3 = acc[tu][sb][3];
-                const int32_t k0 = (int32_t)((__float_as_uint(f0) & ~IDX_MASK) | (uint32_t)(tu * 4 + 0));
-                const int32_t k1 = (int32_t)((__float_as_uint(f1) & ~IDX_MASK) | (uint32_t)(tu * 4 + 1));
-                const int32_t k2 = (int32_t)((__float_as_uint(f2) & ~IDX_MASK) | (uint32_t)(tu * 4 + 2));
-                const int32_t k3 = (int32_t)((__float_as_uint(f3) & ~IDX_MASK) | (uint32_t)(tu * 4 + 3));
+                const uint32_t k0 = (__float_as_uint(f0) & ~IDX_MASK) | (uint32_t)(tu * 4 + 0);
+                const uint32_t k1 = (__float_as_uint(f1) & ~IDX_MASK) | (uint32_t)(tu * 4 + 1);
+                const uint32_t k2 = (__float_as_uint(f2) & ~IDX_MASK) | (uint32_t)(tu * 4 + 2);
+                const uint32_t k3 = (__float_as_uint(f3) & ~IDX_MASK) | (uint32_t)(tu * 4 + 3);
                 c0 = min(min(c0, k0), k1);
                 c1 = min(min(c1, k2), k3);
             }
-            const int32_t c = min(c0, c1);
+            const uint32_t c = min(c0, c1);
             if (c < gbest[sb]) { gbest[sb] = c; gblock[sb] = ub; }
         }
     };
@@ -288,9 +288,9 @@ __global__ __launch_bounds__(64 * NWR * NWC, 2) void bmu_bf16_tiled_kernel(const
 
 #pragma unroll
     for (int sb = 0; sb < WS; ++sb) {
-        const uint32_t code = (uint32_t)gbest[sb] & IDX_MASK;
+        const uint32_t code = gbest[sb] & IDX_MASK;
         const uint32_t unit = (uint32_t)gblock[sb] * TL_BN + wc * 64 + (code >> 2) * 16 + quad * 4 + (code & 3);
-        unsigned long long comp = ((unsigned long long)((uint32_t)gbest[sb] & ~IDX_MASK) << 32) | unit;
+        unsigned long long comp = ((unsigned long long)(gbest[sb] & ~IDX_MASK) << 32) | unit;
         unsigned long long o = __shfl_xor(comp, 16, 64);
         if (o < comp) comp = o;
         o = __shfl_xor(comp, 32, 64);

@@ -147,6 +147,12 @@ struct som_handle {
     bool use_bands = true;
 
     bool fuse_merge_prep = true; // SOM_FUSE_MERGE=0: separate merge and operand-preparation launches (A/B)
+    // read once in som_create (experiments / A-B runs): forced part counts, launch-geometry printing
+    int env_bf16_parts = 0, env_f32_parts = 0;
+    bool debug = false;
+    // per kernel function: the dynamic-LDS attribute is set and the occupancy queried once, not per launch
+    struct KernelSlots { const void* fn; size_t lds; int per_cu; };
+    std::vector<KernelSlots> kernel_slots;
     int staged_blocks_done = -1; // som_epoch_accumulate_begin / _block: next block expected, -1 = none pending
     bool async_copies = false;   // SOM_ASYNC_COPIES=1: round 1's original copy path (fresh_process_stress.py)
     bool prof = false;
@@ -222,6 +228,19 @@ int d2h_blocking(som_handle* h, void* dst, const void* src, size_t bytes) {
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// Workgroups of `fn` (threads per workgroup, dynamic LDS bytes) one CU holds at once; the first call per
+// (function, LDS size) raises the function's dynamic-LDS limit and asks the runtime, later calls read the cache.
+int kernel_per_cu(som_handle* h, const void* fn, int threads, size_t lds, int* per_cu) {
+    for (const auto& k : h->kernel_slots)
+        if (k.fn == fn && k.lds == lds) { *per_cu = k.per_cu; return 0; }
+    HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int n = 0;
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, threads, lds));
+    h->kernel_slots.push_back({fn, lds, n > 0 ? n : 1});
+    *per_cu = n > 0 ? n : 1;
     return 0;
 }
 
@@ -358,8 +377,7 @@ int launch_bmu_f32(som_handle* h, const float* X, long N, const float* xsq, int*
     size_t chunked = base + (size_t)F32_SB * (F32_KC + 1) * sizeof(float);
     int x_resident = res <= 150 * 1024;
     size_t lds = x_resident ? res : chunked;
-    HIPCHK(h, hipFuncSetAttribute((const void*)bmu_f32_kernel<MODE, TOP2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
+    { int pc; if (int rc = kernel_per_cu(h, (const void*)bmu_f32_kernel<MODE, TOP2>, 256, lds, &pc)) return rc; }
     long grid = cdiv(N, F32_SB);
     if (grid <= 0 || grid > 0x7fffffffL) return fail(h, "bmu_f32: row count out of range");
     bmu_f32_kernel<MODE, TOP2><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, N, h->D, Dp, h->W, h->wsq, h->K,
@@ -374,18 +392,17 @@ template <int MODE, int KG, bool TOP2 = false>
 int launch_bmu_f32_res_kg(som_handle* h, const float* X, long N, const float* xsq, int* out, int* out2 = nullptr) {
     auto kern = bmu_f32_res_kernel<MODE, KG, TOP2>;
     size_t lds = 2 * (size_t)fr_stage_bytes(KG);
-    HIPCHK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 1;
+    if (int rc = kernel_per_cu(h, (const void*)kern, 256, lds, &per_cu)) return rc;
     long grid = cdiv(N, FR_WG_SAMPLES);
     if (grid <= 0 || grid > 0x7fffffffL) return fail(h, "bmu_f32: row count out of range");
     int parts = 1;
     if (!TOP2) {
-        int per_cu = 0;
-        HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, lds));
-        const long slots = (long)(per_cu > 0 ? per_cu : 1) * (h->n_cus > 0 ? h->n_cus : 256);
+        const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
         parts = choose_parts(h, grid, slots, h->fr_stages);
-        if (const char* e = std::getenv("SOM_F32_PARTS")) parts = std::atoi(e) > 0 ? std::atoi(e) : parts;   // experiments
+        if (h->env_f32_parts > 0) parts = h->env_f32_parts;   // experiments
         if (parts > h->fr_stages) parts = h->fr_stages;
-        if (std::getenv("SOM_DEBUG"))
+        if (h->debug)
             std::fprintf(stderr, "[somhip] bmu_f32_res: blocks=%ld per_cu=%d slots=%ld parts=%d stages=%d\n", grid, per_cu,
                          slots, parts, h->fr_stages);
     }
@@ -422,8 +439,7 @@ int launch_bmu_f32_tiled(som_handle* h, const float* X, long N, const float* xsq
     prep_tiles_f32_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
         X, N, h->D, h->ft_kchunks, n_blocks, FT_TILE, nullptr, h->ftX);
     size_t lds = 2 * (size_t)FT_STAGE;
-    HIPCHK(h, hipFuncSetAttribute((const void*)bmu_f32_tiled_kernel<MODE, TOP2>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { int pc; if (int rc = kernel_per_cu(h, (const void*)bmu_f32_tiled_kernel<MODE, TOP2>, 256, lds, &pc)) return rc; }
     bmu_f32_tiled_kernel<MODE, TOP2><<<dim3((unsigned)n_blocks), dim3(256), lds, h->stream>>>(
         h->ftX, N, xsq, h->Wfimg, h->ft_ublocks, h->ft_kchunks, h->K, out, out2);
     HIPCHK(h, hipGetLastError());
@@ -462,8 +478,7 @@ int launch_bmu_top2(som_handle* h, const float* X, long N, const float* xsq, int
 template <int KS>
 int launch_bmu_bf16_ks(som_handle* h, const __bf16* Xb, long N, int* out) {
     size_t lds = 2 * (size_t)bf_stage_bytes(KS);
-    HIPCHK(h, hipFuncSetAttribute((const void*)bmu_bf16_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
+    { int pc; if (int rc = kernel_per_cu(h, (const void*)bmu_bf16_kernel<KS>, 256, lds, &pc)) return rc; }
     long grid = cdiv(N, BF_WG_SAMPLES);
     if (grid <= 0 || grid > 0x7fffffffL) return fail(h, "bmu_bf16: row count out of range");
     bmu_bf16_kernel<KS><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(Xb, N, h->Wst, h->n_stages, h->K, out);
@@ -498,17 +513,15 @@ int choose_parts(som_handle* h, long blocks, long slots, int max_parts_hint) {
 template <int KS32>
 int launch_bmu_bf16_k16(som_handle* h, const __bf16* Xb, long N, int* out) {
     size_t lds = 2 * (size_t)k16_stage_bytes(KS32);
-    HIPCHK(h, hipFuncSetAttribute((const void*)bmu_bf16_k16_kernel<KS32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
+    int per_cu = 1;
+    if (int rc = kernel_per_cu(h, (const void*)bmu_bf16_k16_kernel<KS32>, 64 * K16_NW, lds, &per_cu)) return rc;
     long blocks = cdiv(N, K16_WG_SAMPLES);
     if (blocks <= 0 || blocks > 0x7fffffffL) return fail(h, "bmu_bf16: row count out of range");
     // split the codebook scan into `parts` so the grid fills whole rounds of resident workgroups
-    int per_cu = 0;
-    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)bmu_bf16_k16_kernel<KS32>, 64 * K16_NW, lds));
-    const long slots = (long)(per_cu > 0 ? per_cu : 1) * (h->n_cus > 0 ? h->n_cus : 256);
+    const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
     int parts = choose_parts(h, blocks, slots, h->n_stages);
-    if (const char* e = std::getenv("SOM_BF16_PARTS")) parts = std::atoi(e) > 0 ? std::atoi(e) : parts;   // experiments
-    if (std::getenv("SOM_DEBUG"))
+    if (h->env_bf16_parts > 0) parts = h->env_bf16_parts;   // experiments
+    if (h->debug)
         std::fprintf(stderr, "[somhip] bmu_bf16_k16: blocks=%ld per_cu=%d cus=%d slots=%ld parts=%d stages=%d\n", blocks,
                      per_cu, h->n_cus, slots, parts, h->n_stages);
     // (best64[0..N) was reset by prep_wsqh_kernel, launch_bmu_bf16)
@@ -524,16 +537,15 @@ int launch_bmu_bf16_tiled_cfg(som_handle* h, const __bf16* Ximg, long N, int* ou
     using C = TileCfg<WS, NWR, NWC>;
     auto kern = bmu_bf16_tiled_kernel<WS, NWR, NWC>;
     size_t lds = (size_t)C::LDS_BYTES;
-    HIPCHK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 1;
+    if (int rc = kernel_per_cu(h, (const void*)kern, 64 * C::WAVES, lds, &per_cu)) return rc;
     long blocks = cdiv(N, C::BM);
     if (blocks <= 0 || blocks > 0x7fffffffL) return fail(h, "bmu_bf16: row count out of range");
-    int per_cu = 0;
-    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 64 * C::WAVES, lds));
-    const long slots = (long)(per_cu > 0 ? per_cu : 1) * (h->n_cus > 0 ? h->n_cus : 256);
+    const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
     int parts = choose_parts(h, blocks, slots, h->n_ublocks);
     // with many unit blocks, 8 parts let one XCD's resident workgroups share sample tiles through its L2
     if (h->n_ublocks >= 64 && blocks * 8 >= slots) parts = 8;
-    if (const char* e = std::getenv("SOM_BF16_PARTS")) parts = std::atoi(e) > 0 ? std::atoi(e) : parts;
+    if (h->env_bf16_parts > 0) parts = h->env_bf16_parts;
     if (parts > h->n_ublocks) parts = h->n_ublocks;
     if (N > h->best64_cap) {
         (void)hipFree(h->best64);
@@ -636,10 +648,10 @@ int launch_bmu_pairwise(som_handle* h, const float* X, long N, int p, bool even,
     long grid = cdiv(N, PW_SAMPLES);
     if (grid <= 0 || grid > 0x7fffffffL) return fail(h, "bmu_pairwise: row count out of range");
     if (even) {
-        HIPCHK(h, hipFuncSetAttribute((const void*)bmu_pairwise_kernel<PW_EVEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { int pc; if (int rc = kernel_per_cu(h, (const void*)bmu_pairwise_kernel<PW_EVEN>, PW_SAMPLES, lds, &pc)) return rc; }
         bmu_pairwise_kernel<PW_EVEN><<<dim3((unsigned)grid), dim3(PW_SAMPLES), lds, h->stream>>>(X, N, h->D, h->W, h->K, p, x_in_lds, out);
     } else {
-        HIPCHK(h, hipFuncSetAttribute((const void*)bmu_pairwise_kernel<PW_GENERIC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { int pc; if (int rc = kernel_per_cu(h, (const void*)bmu_pairwise_kernel<PW_GENERIC>, PW_SAMPLES, lds, &pc)) return rc; }
         bmu_pairwise_kernel<PW_GENERIC><<<dim3((unsigned)grid), dim3(PW_SAMPLES), lds, h->stream>>>(X, N, h->D, h->W, h->K, p, x_in_lds, out);
     }
     HIPCHK(h, hipGetLastError());
@@ -826,9 +838,7 @@ void launch_leftmul(som_handle* h, const float* H, int Ro, int Ri, const float* 
         --wide;
         const dim3 g(1, (unsigned)row_blocks, (unsigned)batch), b(256);
         if (rem <= 4) leftmul_narrow_f32_kernel<2><<<g, b, 0, h->stream>>>(H, Ro, Ri, M, mstride, OUT, ostride, C, ld, C - rem, ranges, nseg, segw);
-        else if (rem <= 8) leftmul_narrow_f32_kernel<4><<<g, b, 0, h->stream>>>(H, Ro, Ri, M, mstride, OUT, ostride, C, ld, C - rem, ranges, nseg, segw);
-        else if (rem <= 16) leftmul_narrow_f32_kernel<8><<<g, b, 0, h->stream>>>(H, Ro, Ri, M, mstride, OUT, ostride, C, ld, C - rem, ranges, nseg, segw);
-        else leftmul_narrow_f32_kernel<16><<<g, b, 0, h->stream>>>(H, Ro, Ri, M, mstride, OUT, ostride, C, ld, C - rem, ranges, nseg, segw);
+        else leftmul_narrow_f32_kernel<4><<<g, b, 0, h->stream>>>(H, Ro, Ri, M, mstride, OUT, ostride, C, ld, C - rem, ranges, nseg, segw);
     }
     if (wide > 0)
         leftmul_f32_kernel<<<dim3((unsigned)wide, (unsigned)row_blocks, (unsigned)batch), dim3(256), 0, h->stream>>>(
@@ -1032,6 +1042,9 @@ int som_create(const som_config* cfg, som_handle** out) {
         if ((rc = dev_alloc(h, &npd, 1))) return bail(rc);
         h->np_dev = npd;
         if (const char* e = std::getenv("SOM_GRAPH")) h->use_graph = std::atoi(e) != 0;
+        if (const char* e = std::getenv("SOM_BF16_PARTS")) h->env_bf16_parts = std::atoi(e);
+        if (const char* e = std::getenv("SOM_F32_PARTS")) h->env_f32_parts = std::atoi(e);
+        h->debug = std::getenv("SOM_DEBUG") != nullptr;
         if (const char* e = std::getenv("SOM_ASYNC_COPIES")) h->async_copies = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_FUSE_MERGE")) h->fuse_merge_prep = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_SORT_ONESWEEP_ROWS")) SORT_ONESWEEP_ROWS = std::atol(e);
@@ -1218,7 +1231,7 @@ int capture_epoch_graph(som_handle* h) {
         h->use_graph = false;                           // this handle stays on the eager path
         h->err = saved_err;
         mark_codebook_changed(h);
-        if (std::getenv("SOM_DEBUG")) std::fprintf(stderr, "[somhip] epoch graph capture failed; eager launches\n");
+        if (h->debug) std::fprintf(stderr, "[somhip] epoch graph capture failed; eager launches\n");
         return 0;
     }
     h->gexec_gen = h->alloc_gen;

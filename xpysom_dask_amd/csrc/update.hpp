@@ -338,7 +338,8 @@ __global__ __launch_bounds__(256) void neigh_tables_kernel(NeighParams p_val, co
 // the GEMM then walks only those chunks.  Skipped chunks would have added 0 * m = 0 to the accumulators,
 // so the result is bit-identical for finite data.
 constexpr int LM_BM = 128, LM_BN = 128, LM_BK = 32;
-constexpr int LM_NARROW = 32;   // column tiles this narrow take the VALU path of leftmul_f32_kernel
+constexpr int LM_NARROW = 8;    // a last column tile this narrow goes to leftmul_narrow_f32_kernel (VALU) instead of a
+                                // mostly empty 128-wide MFMA tile (64x64x32: 32 columns as a partial MFMA tile 11 us, as VALU 14)
 
 // ranges[rb * nseg + s] = {segw - lo, hi}: columns [s*segw + lo, s*segw + hi) of rows [128 rb, 128 rb + 128) hold
 // every nonzero of that segment; both fields only grow (atomicMax from a zeroed buffer: {0, 0} = all zero).
@@ -566,8 +567,9 @@ __global__ __launch_bounds__(256) void strided_gemm_f32_kernel(const float* __re
             Bs[bkk][bc] = rb[q];
         }
         __syncthreads();
+        const int kn = Kd - k0 < SG_KC ? Kd - k0 : SG_KC;
 #pragma unroll 8
-        for (int k = 0; k < SG_KC; ++k) {
+        for (int k = 0; k < kn; ++k) {
             const float b = Bs[k][tx];
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(As[ty + 8 * r][k], b, acc[r]);
