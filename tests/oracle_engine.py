@@ -41,6 +41,27 @@ class OracleEngine:
         self.set_data(np.concatenate([np.asarray(c, np.float32) for c in chunks]))
         self.epoch_accumulate(sigma, eta, neigh_f64)
 
+    # the staged form of the epoch (include/somhip.h: som_epoch_accumulate_begin / _block): blocks of `BLOCK_ROWS`
+    # map rows (128 in the engine; small here so that a test map has several)
+    BLOCK_ROWS = 3
+
+    def epoch_accumulate_begin(self, sigma, eta, neigh_f64):
+        self.epoch_accumulate(sigma, eta, neigh_f64)
+        self._staged = self.acc.copy()
+        self.acc[:] = np.nan                           # a block is final only after epoch_accumulate_block
+        self._next = 0
+
+    def epoch_block_count(self):
+        return -(-self.x // self.BLOCK_ROWS)
+
+    def epoch_accumulate_block(self, b):
+        assert b == self._next
+        self._next += 1
+        lo = b * self.BLOCK_ROWS * self.y
+        hi = min(self.K, (b + 1) * self.BLOCK_ROWS * self.y)
+        self.acc[lo:hi] = self._staged[lo:hi]
+        return lo * (self.D + 1), (hi - lo) * (self.D + 1)
+
     def accum_tensor(self):
         import torch
         return torch.from_numpy(self.acc.reshape(-1))

@@ -18,9 +18,9 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, sharded_input, out_dir):
+def _worker(rank, world, port, sharded_input, out_dir, overlap="0"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank))
+                      LOCAL_RANK=str(rank), SOM_OVERLAP=overlap)
     import torch.distributed as dist
     from tests.oracle_engine import OracleEngine
     from xpysom_dask_amd import XPySom
@@ -52,6 +52,21 @@ def test_two_rank_training_equals_single_process(tmp_path, sharded_input):
     data = O.gaussian_blobs(601, 5, seed=11)
     ref = O.train(data, O.default_codebook(7, 6, 5, 3), 6, sigma0=3.0, decay="linear", n_parallel=4000)
     np.testing.assert_allclose(w0, ref, rtol=2e-5, atol=2e-6)   # sum order differs with the shard count
+
+
+def test_blockwise_allreduce_host_logic(tmp_path):
+    """distributed._epoch_overlapped (begin -> [block b, all-reduce of its slice] ... -> merge) against the one-shot
+    all-reduce, two gloo ranks, the test-double engine with three-row blocks: same codebook bit for bit."""
+    import torch.multiprocessing as mp
+    outs = []
+    for overlap in ("0", "1"):
+        d = tmp_path / overlap
+        d.mkdir()
+        mp.spawn(_worker, args=(2, _free_port(), False, str(d), overlap), nprocs=2, join=True)
+        w0, w1 = np.load(d / "w0.npy"), np.load(d / "w1.npy")
+        assert np.array_equal(w0, w1)
+        outs.append(w0)
+    assert np.array_equal(outs[0], outs[1])
 
 
 def test_shard_bounds_cover_and_balance():

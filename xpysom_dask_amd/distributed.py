@@ -62,15 +62,17 @@ _comm_streams = {}
 
 def _overlap_wanted(engine, world):
     """Blockwise all-reduce under the transform's tail: on by default under RCCL with more than one rank when the map
-    has more than one 128-row block; SOM_OVERLAP=0 / 1 forces it off / on (1 also on host-staged backends, where the
-    blocks are reduced one synchronous call at a time -- the equality tests run it under gloo)."""
+    has more than two 128-row blocks (configs[4]'s 512-row map: four blocks of 206 MB; at 256 rows the transform is
+    0.15 ms against a 34 MB all-reduce -- nothing to hide it under, and two small collectives are slower than one);
+    SOM_OVERLAP=0 / 1 forces it off / on (1 also on host-staged backends, where the blocks are reduced one
+    synchronous call at a time -- the equality tests run it under gloo)."""
     force = os.environ.get("SOM_OVERLAP")
     if force is not None:
         return force != "0" and hasattr(engine, "epoch_accumulate_block")
     if world == 1 or not hasattr(engine, "epoch_accumulate_block"):
         return False
     import torch.distributed as dist
-    return dist.get_backend() == "nccl" and engine.epoch_block_count() > 1
+    return dist.get_backend() == "nccl" and engine.epoch_block_count() > 2
 
 
 def _epoch_overlapped(engine, sigma, eta, neigh_f64):
