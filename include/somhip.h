@@ -63,7 +63,7 @@ typedef struct som_config {
     int32_t x, y, input_len;     /* map rows, cols, features: XPySom.__init__, xpysom.py:73 */
     int32_t distance;            /* SOM_DIST_*  */
     int32_t neighborhood;        /* SOM_NEIGH_* */
-    int32_t compact_support;     /* neighborhoods.py:29-31 */
+    int32_t compact_support;     /* neighborhoods.py:29-31; with SOM_NEIGH_MEXICAN_HAT: the reference's double mask on px, :69-71 / :91-93 */
     int32_t precision;           /* SOM_PREC_*  */
     int32_t device;              /* HIP device ordinal */
     double  std_coeff;           /* d = 2*std_coeff^2*sigma^2, neighborhoods.py:19 */

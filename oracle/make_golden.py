@@ -444,8 +444,45 @@ def g14():
     save("g14_distance_map", **out)
 
 
+# ---------------------------------------------------------------- G15 mexican_hat with compact_support (as the reference computes it)
+def g15():
+    """neighborhoods.py:69-71 / :91-93: px masked twice, py never.  Rectangular: square maps only (the second mask
+    does not broadcast otherwise).  Raw tensors for every centre and one _update per topology and schedule."""
+    out = {}
+    for topo, (X, Y) in (("rect", (5, 5)), ("hex", (6, 5)), ("hex", (5, 5))):
+        ci, cj = np.divmod(np.arange(X * Y), Y)
+        c = (ci.astype(np.int64), cj.astype(np.int64))
+        som = RefSom(X, Y, 3, topology="hexagonal" if topo == "hex" else "rectangular", xp=np)
+        for sig in (0.8, 1.7, 2.5):
+            for wide in (False, True):
+                s = np.float64(sig) if wide else float(sig)
+                key = f"{topo}_{X}x{Y}_s{sig}_{'f64' if wide else 'f32'}"
+                if topo == "rect":
+                    out["mexcs_" + key] = rneigh.mexican_hat_rect(np.arange(X), np.arange(Y), 0.5, True, c, s, xp=np)
+                else:
+                    out["mexcs_" + key] = rneigh.mexican_hat_generic(som._xx, som._yy, 0.5, True, c, s, xp=np)
+    for topo, (X, Y, D, n) in (("rectangular", (9, 9, 4, 400)), ("hexagonal", (9, 8, 4, 400)), ("hexagonal", (7, 7, 3, 300))):
+        data = gaussian_blobs(n, D, seed=600 + X + Y)
+        for decay in ("linear", "exponential"):
+            som = RefSom(X, Y, D, random_seed=41, decay_function=decay, n_parallel=n, topology=topo,
+                         neighborhood_function="mexican_hat", compact_support=True, xp=np)
+            w0 = som._weights.astype(F32)
+            t, T = 2, 6
+            eta = som._decay_function(som._learning_rate, som._learning_rateN, t, T)
+            sig = som._decay_function(som._sigma, som._sigmaN, t, T)
+            wins = som._winner(data, w0)
+            num, den = som._update(data, w0, eta, sig)
+            key = f"{topo}_{X}x{Y}x{D}_{decay}"
+            out[key + "_bmu"] = (wins[0] * Y + wins[1]).astype(np.int32)
+            out[key + "_num"] = num.astype(F32)
+            out[key + "_den"] = den.astype(F32)
+            out[key + "_eta"] = np.float64(eta)
+            out[key + "_sig"] = np.float64(sig)
+    save("g15_mexican_compact", **out)
+
+
 FAMILIES = {"g1": g1, "g2": g2, "g3": g3, "g4": g4_g5_g7, "g6": g6, "g8": g8, "g9": g9, "g10": g10, "g11": g11,
-            "g12": g12, "g13": g13, "g14": g14}
+            "g12": g12, "g13": g13, "g14": g14, "g15": g15}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

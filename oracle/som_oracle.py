@@ -188,10 +188,10 @@ def neigh_gaussian(X, Y, std_coeff, compact, ci, cj, sigma, wide):
 
 
 def neigh_mexican_hat(X, Y, std_coeff, compact, ci, cj, sigma, wide):
-    """neighborhoods.py:57-74 (compact_support=False only; the reference's
-    compact branch masks px twice and py never, :69-71, and is not restated)."""
-    if compact:
-        raise NotImplementedError("mexican_hat with compact_support is not restated")
+    """neighborhoods.py:57-74.  With compact_support the reference multiplies px by the row mask AND by the
+    column mask -- the latter an (n, Y) array against px's (n, X), so square maps only (NumPy refuses to broadcast
+    otherwise, as in the reference), where it compares the ROW index with the BMU's COLUMN -- and leaves py
+    unmasked (:69-71).  Restated literally: that is what a drop-in has to reproduce."""
     sigma = F64(sigma) if wide else float(sigma)
     d = 2 * std_coeff ** 2 * sigma ** 2
     ni = np.arange(X)[None, :]
@@ -200,6 +200,9 @@ def neigh_mexican_hat(X, Y, std_coeff, compact, ci, cj, sigma, wide):
     cj = np.asarray(cj)[:, None]
     px = np.power(ni - ci, 2, dtype=F32)
     py = np.power(nj - cj, 2, dtype=F32)
+    if compact:
+        px *= _support(ni, ci, sigma)
+        px *= _support(nj, cj, sigma)
     p = px[:, :, None] + py[:, None, :]
     return np.exp(-p / d) * (1 - 2 / d * p)
 
@@ -259,13 +262,17 @@ def neigh_gaussian_hex(X, Y, std_coeff, compact, ci, cj, sigma, wide):
 
 
 def neigh_mexican_hat_hex(X, Y, std_coeff, compact, ci, cj, sigma, wide):
-    """mexican_hat_generic on the hexagonal grid, neighborhoods.py:76-97 (no compact support)."""
-    if compact:
-        raise NotImplementedError("mexican_hat with compact_support is not restated")
+    """mexican_hat_generic on the hexagonal grid, neighborhoods.py:76-97; compact_support masks px by the x box
+    and by the y box and leaves py unmasked (:91-93), restated literally."""
     sigma = F64(sigma) if wide else float(sigma)
     d = 2 * std_coeff ** 2 * sigma ** 2
     nx, ny, cx, cy = _generic_terms(X, Y, np.asarray(ci), np.asarray(cj))
-    p = np.power(nx - cx, 2, dtype=F32) + np.power(ny - cy, 2, dtype=F32)
+    px = np.power(nx - cx, 2, dtype=F32)
+    py = np.power(ny - cy, 2, dtype=F32)
+    if compact:
+        px *= np.logical_and(nx > cx - sigma, nx < cx + sigma)
+        px *= np.logical_and(ny > cy - sigma, ny < cy + sigma)
+    p = px + py
     return (np.exp(-p / d) * (1 - 2 / d * p)).transpose((0, 2, 1))
 
 

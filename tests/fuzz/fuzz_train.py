@@ -23,6 +23,10 @@ for case in range(n_cases):
     sigma = float(rs.choice([0, 1.5, 3.0])) or min(X, Y) / 2
     lr = float(rs.choice([0.5, 0.1, 1.0]))
     compact = bool(neigh in ("gaussian", "triangle") and topo == "rectangular" and rs.rand() < 0.4)
+    if neigh == "mexican_hat" and rs.rand() < 0.4:            # the reference's double mask on px: hexagonal, or square maps
+        compact = True
+        if topo == "rectangular":
+            Y = X
     std_coeff = float(rs.choice([0.5, 0.5, 0.25, 1.0]))
     T = int(rs.choice([1, 3, 10]))                 # schedule length; ONE epoch of it is run and compared
     t_at = int(rs.randint(0, T))

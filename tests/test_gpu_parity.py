@@ -1200,3 +1200,46 @@ def test_nan_semantics_documented_in_design(precision):
     e.set_weights(w)
     got = e.bmu(xn)
     assert got[7] == 0 and np.array_equal(np.delete(got, 7), np.delete(clean, 7))
+
+
+@pytest.mark.parametrize("topo,shape", [("rectangular", (9, 9, 4, 400)), ("hexagonal", (9, 8, 4, 400)), ("hexagonal", (7, 7, 3, 300))])
+def test_g15_mexican_hat_with_compact_support_as_the_reference_computes_it(topo, shape):
+    """neighborhoods.py:69-71 / :91-93: px masked twice (on the rectangular topology the second mask compares the
+    row index with the BMU's column), py never.  Reproduced: four separable terms on the hexagonal grid, row stage ->
+    mask -> column stage on the rectangular one; against the reference's own _update outputs."""
+    g = load_golden("g15_mexican_compact")
+    X, Y, D, n = shape
+    data = O.gaussian_blobs(n, D, seed=600 + X + Y)
+    w0 = O.default_codebook(X, Y, D, 41).astype(F32)
+    e = engine(X, Y, D, neighborhood="mexican_hat", compact_support=True, topology=topo)
+    e.set_weights(w0)
+    e.set_data(data)
+    for decay in ("linear", "exponential"):
+        key = f"{topo}_{X}x{Y}x{D}_{decay}"
+        e.epoch_accumulate(float(g[key + "_sig"]), float(g[key + "_eta"]), O.decay_is_wide(decay))
+        num, den, bmu = e.epoch_fetch()
+        assert np.array_equal(bmu, g[key + "_bmu"])
+        assert rel_err(num, g[key + "_num"].reshape(-1, D)) < 1e-5, key
+        assert rel_err(den, g[key + "_den"].reshape(-1)) < 1e-5, key
+        # the staged form (blocks of map rows) gives the same accumulator
+        e.epoch_accumulate_begin(float(g[key + "_sig"]), float(g[key + "_eta"]), O.decay_is_wide(decay))
+        for b in range(e.epoch_block_count()):
+            e.epoch_accumulate_block(b)
+        num2, den2, _ = e.epoch_fetch(want_bmu=False)
+        assert np.array_equal(num, num2) and np.array_equal(den, den2)
+    if topo == "rectangular":
+        from xpysom_dask_amd.engine import SomHipError
+        with pytest.raises(SomHipError, match="square map"):
+            engine(5, 7, 3, neighborhood="mexican_hat", compact_support=True)
+    # a wider square map: more than one 128-row block in both stages
+    X = Y = 130
+    data = O.gaussian_blobs(500, 5, seed=9)
+    w0 = O.default_codebook(X, Y, 5, 3).astype(F32)
+    e = engine(X, Y, 5, neighborhood="mexican_hat", compact_support=True, topology=topo)
+    e.set_weights(w0)
+    e.set_data(data)
+    e.epoch_accumulate(3.0, 0.4, True)
+    num, den, bmu = e.epoch_fetch()
+    _, onum, oden = O.update(data, w0, np.float64(0.4), np.float64(3.0), wide=True, compact=True, forced_bmu=bmu,
+                             neighbourhood="mexican_hat" + ("_hex" if topo == "hexagonal" else ""))
+    assert rel_err(num, onum.reshape(-1, 5)) < 1e-5 and rel_err(den, oden.reshape(-1)) < 1e-5

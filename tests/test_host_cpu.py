@@ -161,9 +161,10 @@ def test_distance_map_matches_the_reference():
 
 def test_constructor_refuses_what_the_engine_would_refuse():
     from xpysom_dask_amd import XPySom
-    for topo in ("rectangular", "hexagonal"):
-        with pytest.raises(NotImplementedError, match="mexican_hat with compact_support"):
-            XPySom(5, 5, 3, neighborhood_function="mexican_hat", compact_support=True, topology=topo)
+    with pytest.raises(ValueError, match="mexican_hat with compact_support needs a square map"):
+        XPySom(5, 7, 3, neighborhood_function="mexican_hat", compact_support=True)
+    XPySom(5, 5, 3, neighborhood_function="mexican_hat", compact_support=True)
+    XPySom(5, 7, 3, neighborhood_function="mexican_hat", compact_support=True, topology="hexagonal")
     for dist in ("manhattan", "norm_p", "norm_p_no_opt", "euclidean_no_opt"):
         with pytest.raises(ValueError, match="needs precision='f32'"):
             XPySom(5, 5, 3, activation_distance=dist, precision="bf16")

@@ -351,3 +351,40 @@ def test_g13_hex_topographic_error(XD):
     assert O.topographic_error(probe, w, topology="hexagonal") == float(g[key + "_te"])
     n = {5: 300, 12: 1500}[X]
     assert O.topographic_error(O.gaussian_blobs(n, D, seed=int(seeds[0])), w, topology="hexagonal") == float(g[key + "_te_train"])
+
+
+# ----------------------------------------------------------------------------- G15 mexican_hat + compact_support
+@pytest.mark.parametrize("topo,XY", [("rect", (5, 5)), ("hex", (6, 5)), ("hex", (5, 5))])
+def test_g15_mexican_hat_compact_tensors(topo, XY):
+    """The reference's double mask on px (neighborhoods.py:69-71, :91-93), restated literally: bit-exact tensors."""
+    g = load_golden("g15_mexican_compact")
+    X, Y = XY
+    ci, cj = np.divmod(np.arange(X * Y), Y)
+    f = O.neigh_mexican_hat if topo == "rect" else O.neigh_mexican_hat_hex
+    for sig in (0.8, 1.7, 2.5):
+        for wide in (False, True):
+            ref = g[f"mexcs_{topo}_{X}x{Y}_s{sig}_{'f64' if wide else 'f32'}"]
+            got = f(X, Y, 0.5, True, ci, cj, sig, wide)
+            assert got.dtype == ref.dtype
+            np.testing.assert_array_equal(got, ref)
+    if topo == "rect":
+        with pytest.raises(ValueError):                        # non-square: the second mask does not broadcast
+            O.neigh_mexican_hat(5, 7, 0.5, True, np.zeros(3, int), np.zeros(3, int), 1.0, True)
+
+
+@pytest.mark.parametrize("topo,shape", [("rectangular", (9, 9, 4, 400)), ("hexagonal", (9, 8, 4, 400)), ("hexagonal", (7, 7, 3, 300))])
+def test_g15_update(topo, shape):
+    g = load_golden("g15_mexican_compact")
+    X, Y, D, n = shape
+    data = O.gaussian_blobs(n, D, seed=600 + X + Y)
+    w0 = O.default_codebook(X, Y, D, 41).astype(F32)
+    for decay in ("linear", "exponential"):
+        key = f"{topo}_{X}x{Y}x{D}_{decay}"
+        f, wide = O.DECAYS[decay], O.decay_is_wide(decay)
+        eta, sig = f(0.5, 0.01, 2, 6), f(min(X, Y) / 2, 1, 2, 6)
+        assert float(eta) == float(g[key + "_eta"]) and float(sig) == float(g[key + "_sig"])
+        bmu, num, den = O.update(data, w0, eta, sig, wide=wide, compact=True,
+                                 neighbourhood="mexican_hat" + ("_hex" if topo == "hexagonal" else ""))
+        assert np.array_equal(bmu, g[key + "_bmu"])
+        np.testing.assert_allclose(num, g[key + "_num"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(den, g[key + "_den"], rtol=1e-5, atol=1e-5)

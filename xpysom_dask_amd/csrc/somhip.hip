@@ -72,6 +72,7 @@ struct som_handle {
     int stage_bytes = 0;     // bytes of one codebook stage image
     int stage_units = 0;     // units per stage
     int nt = 1;              // neighbourhood terms
+    bool swapped = false;    // mexican_hat + compact_support, rectangular: row stage, mask, column stage (update.hpp)
     int norm_p = 2;          // exponent of the norm_p distances
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -797,6 +798,7 @@ NeighParams make_neigh_params(const som_handle* h, double sigma, double eta, int
     p.X = h->X; p.Y = h->Y; p.nt = h->nt;
     p.hex = h->cfg.topology == SOM_TOPO_HEXAGONAL && h->cfg.neighborhood != SOM_NEIGH_BUBBLE;
     p.base_nt = p.hex ? h->nt / 3 : h->nt;
+    p.swapped = h->swapped ? 1 : 0;
     return p;
 }
 
@@ -831,18 +833,19 @@ int build_tables(som_handle* h, double sigma, double eta, int neigh_f64, hipStre
 // OUT = H * M over C columns (rows of M / OUT ld floats apart): 128-wide MFMA tiles, and a VALU kernel for a last
 // tile of <= LM_NARROW columns
 void launch_leftmul(som_handle* h, const float* H, int Ro, int Ri, const float* M, long mstride, float* OUT, long ostride,
-                    long C, long ld, int row_blocks, int batch, const int2* ranges, int nseg, int segw) {
+                    long C, long ld, int row_blocks, int batch, const int2* ranges, int nseg, int segw, long ldo = 0) {
+    if (ldo == 0) ldo = ld;                              // rows of OUT as far apart as rows of M unless told otherwise
     long wide = cdiv(C, LM_BN);
     const long rem = C - (C / LM_BN) * LM_BN;
     if (rem > 0 && rem <= LM_NARROW) {
         --wide;
         const dim3 g(1, (unsigned)row_blocks, (unsigned)batch), b(256);
-        if (rem <= 4) leftmul_narrow_f32_kernel<2><<<g, b, 0, h->stream>>>(H, Ro, Ri, M, mstride, OUT, ostride, C, ld, C - rem, ranges, nseg, segw);
-        else leftmul_narrow_f32_kernel<4><<<g, b, 0, h->stream>>>(H, Ro, Ri, M, mstride, OUT, ostride, C, ld, C - rem, ranges, nseg, segw);
+        if (rem <= 4) leftmul_narrow_f32_kernel<2><<<g, b, 0, h->stream>>>(H, Ro, Ri, M, mstride, OUT, ostride, C, ld, ldo, C - rem, ranges, nseg, segw);
+        else leftmul_narrow_f32_kernel<4><<<g, b, 0, h->stream>>>(H, Ro, Ri, M, mstride, OUT, ostride, C, ld, ldo, C - rem, ranges, nseg, segw);
     }
     if (wide > 0)
         leftmul_f32_kernel<<<dim3((unsigned)wide, (unsigned)row_blocks, (unsigned)batch), dim3(256), 0, h->stream>>>(
-            H, Ro, Ri, M, mstride, OUT, ostride, C, ld, ranges, nseg, segw);
+            H, Ro, Ri, M, mstride, OUT, ostride, C, ld, ldo, ranges, nseg, segw);
 }
 
 // tables + stage 1: T_t[a] = Py_t (Y x Y) * SC[a] (Y x D), batched
@@ -854,6 +857,21 @@ int run_transform_stage1(som_handle* h, double sigma, double eta, int neigh_f64)
     const int nyb = (int)cdiv(h->Y, LM_BM);
     const int2* bands1 = h->use_bands ? h->bands : nullptr;             // [nt][nyb]
     const long slab = (long)h->Y * h->D1p;
+    if (h->swapped) {
+        // mexican_hat + compact_support, rectangular (X == Y): the row stage first, V_t = Fx_t (X x X) * SC (X x Y*D1p),
+        // laid out T[i][t][b][:] (rows of term t: T + t*slab, nt*slab apart); then the reference's second mask,
+        // m2(i, b), on the three masked terms; the column stage follows in run_transform_stage2
+        const int nxb = (int)cdiv(h->X, LM_BM);
+        for (int t1 = 0; t1 < h->nt; ++t1)
+            launch_leftmul(h, h->P1 + (long)t1 * h->X * h->X, h->X, h->X, h->SC, 0, h->T + (long)t1 * slab, 0, slab, slab, nxb,
+                           1, nullptr, 1, h->X, (long)h->nt * slab);
+        const NeighParams p = make_neigh_params(h, sigma, eta, neigh_f64);
+        const long total = (long)h->X * h->nt * slab;
+        mask_rows_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
+            p, h->capturing ? (const NeighParams*)h->np_dev : nullptr, h->T, h->nt - 1, h->D1p);
+        HIPCHK(h, hipGetLastError());
+        return 0;
+    }
     for (int t1 = 0; t1 < h->nt; ++t1)
         launch_leftmul(h, h->P1 + (long)t1 * h->Y * h->Y, h->Y, h->Y, h->SC, slab, h->T + (long)t1 * h->X * slab, slab,
                        h->D, h->D1p, nyb, h->X, bands1 ? bands1 + (long)t1 * nyb : nullptr, 1, h->Y);
@@ -878,6 +896,13 @@ int run_transform_stage2(som_handle* h, int b0, int b1) {
     const long slab = (long)h->Y * h->D1p;
     const long i0 = (long)b0 * LM_BM;
     const int rows = (int)std::min<long>((long)b1 * LM_BM, h->X) - (int)i0;
+    if (h->swapped) {
+        // the column stage, batched over the block's map rows: ACC[i] = [Gy_0 | Gy_1 ...] (Y x nt*Y) * T[i] (nt*Y x D1p)
+        launch_leftmul(h, h->P2, h->Y, h->nt * h->Y, h->T + i0 * h->nt * slab, (long)h->nt * slab, h->ACC + i0 * slab, slab,
+                       h->D1p, h->D1p, nyb, rows, nullptr, 1, h->nt * h->Y);
+        HIPCHK(h, hipGetLastError());
+        return 0;
+    }
     const float* H = h->P2 + i0 * h->nt * h->X;
     const int2* ranges = bands2 ? bands2 + (long)b0 * h->nt : nullptr;
     if (h->D % LM_BN == 0) {
@@ -957,9 +982,10 @@ int som_create(const som_config* cfg, som_handle** out) {
         return fail(nullptr, "som_create: manhattan / norm_p distances are float32 VALU kernels (precision f32)");
     if (cfg->neighborhood < 0 || cfg->neighborhood > SOM_NEIGH_TRIANGLE)
         return fail(nullptr, "som_create: unknown neighbourhood id");
-    if (cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT && cfg->compact_support)
-        return fail(nullptr, "som_create: mexican_hat with compact_support is not separable (reference bug "
-                             "neighborhoods.py:69-71) and is not supported");
+    if (cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT && cfg->compact_support && cfg->topology == SOM_TOPO_RECTANGULAR &&
+        cfg->x != cfg->y)
+        return fail(nullptr, "som_create: mexican_hat with compact_support needs a square map on the rectangular topology "
+                             "(the reference's second mask on px does not broadcast otherwise, neighborhoods.py:70)");
     if (cfg->topology != SOM_TOPO_RECTANGULAR && cfg->topology != SOM_TOPO_HEXAGONAL)
         return fail(nullptr, "som_create: unknown topology id");
     if (cfg->topology == SOM_TOPO_HEXAGONAL && cfg->neighborhood == SOM_NEIGH_TRIANGLE)
@@ -1008,7 +1034,8 @@ int som_create(const som_config* cfg, som_handle** out) {
     h->dp = h->tiled ? TL_BK * h->n_kchunks : h->shape16 ? 32 * h->ks32 : 16 * h->ksteps;
     h->stage_bytes = h->shape16 ? k16_stage_bytes(h->ks32) : bf_stage_bytes(h->ksteps);
     h->stage_units = h->shape16 ? K16_STAGE_UNITS : BF_STAGE_UNITS;
-    h->nt = cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT ? 2 : 1;
+    h->nt = cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT ? (cfg->compact_support ? 4 : 2) : 1;
+    h->swapped = cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT && cfg->compact_support && cfg->topology == SOM_TOPO_RECTANGULAR;
     if (cfg->topology == SOM_TOPO_HEXAGONAL && cfg->neighborhood != SOM_NEIGH_BUBBLE) h->nt *= 3;
     int rc = 0;
     auto bail = [&](int code) { g_create_error = h->err; som_destroy(h); return code; };

@@ -242,6 +242,7 @@ struct NeighParams {
     double sigma, eta, d;   // d = 2*std_coeff^2*sigma^2 (host, double)
     int kind, compact, wide, X, Y, nt;
     int hex, base_nt;       // hexagonal topology: nt = 3 * base_nt
+    int swapped;            // mexican_hat + compact_support on the rectangular topology: row stage first (see below)
 };
 
 __device__ __forceinline__ double neigh_exp(double delta2, const NeighParams& p) {
@@ -274,8 +275,27 @@ __device__ double neigh_factor(int which, int t, double n, double c, double shif
     case 1: {   // mexican hat: (ex(1-2px/d)) * ey  -  ex * ((2py/d) ey)
         double e = neigh_exp(d2, p);
         double q = p.wide ? (2.0 / p.d) * d2 : (double)((float)(2.0 / p.d) * (float)d2);
-        if (t == 0) return which == 0 ? neigh_round(e * (1.0 - q), p) : e;
-        return which == 0 ? -e : neigh_round(q * e, p);
+        if (!p.compact) {
+            if (t == 0) return which == 0 ? neigh_round(e * (1.0 - q), p) : e;
+            return which == 0 ? -e : neigh_round(q * e, p);
+        }
+        // compact_support as the reference computes it (neighborhoods.py:69-71, :91-93): px is multiplied by a mask M,
+        // py is not, so with A = ex (1 - 2 px / d), Q = (2 py / d) ey:
+        //     h = M (A ey - ex Q) + (1 - M)(ey - Q)
+        // Hexagonal (generic): M = mx(i; ci) my(j; cj), four separable terms
+        //     [mx A][my ey]  +  [-mx ex][my Q]  +  [-mx][my (ey - Q)]  +  [1][ey - Q].
+        // Rectangular: M = m1(i; ci) m2(i; cj) -- the second mask compares the ROW index with the BMU's COLUMN --:
+        // the same four terms with my = 1; m2 is applied between the row stage and the column stage (`swapped`).
+        const double m = neigh_box(n, c, dl, p);
+        if (which == 0) {
+            if (t == 0) return neigh_round(m * e * (1.0 - q), p);
+            return t == 1 ? -m * e : t == 2 ? -m : 1.0;
+        }
+        const double my = p.hex ? m : 1.0;
+        const double qe = neigh_round(q * e, p);
+        if (t == 0) return my * e;
+        if (t == 1) return my * qe;
+        return (t == 2 ? my : 1.0) * neigh_round(e - qe, p);
     }
     case 2:     // bubble
         return neigh_box(n, c, dl, p);
@@ -300,6 +320,25 @@ __global__ __launch_bounds__(256) void neigh_tables_kernel(NeighParams p_val, co
     long id = (long)blockIdx.x * 256 + threadIdx.x;
     const long n1 = (long)p.nt * p.Y * p.Y;
     const long n2 = (long)p.X * p.nt * p.X;
+    if (p.swapped) {
+        // row stage first (X == Y): P1 = the row factors [nt][X][X] (Fx_t[i][a], with eta), P2 = the column factors
+        // [Y][nt*Y] (Gy_t[j][b] at column t*Y + b)
+        if (id < n1) {
+            int a = id % p.X;
+            long r = id / p.X;
+            int i = r % p.X;
+            int t = r / p.X;
+            double v = neigh_factor(0, t, (double)i, (double)a, 0.0, p);
+            P1[id] = p.wide ? (float)(v * p.eta) : (float)v * (float)p.eta;
+        } else if (id < n1 + n2) {
+            long q = id - n1;
+            int col = q % ((long)p.nt * p.Y);
+            int j = q / ((long)p.nt * p.Y);
+            int t = col / p.Y, b = col % p.Y;
+            P2[q] = (float)neigh_factor(1, t, (double)j, (double)b, 0.0, p);
+        }
+        return;
+    }
     if (id < n1) {
         int b = id % p.Y;
         long r = id / p.Y;
@@ -323,6 +362,22 @@ __global__ __launch_bounds__(256) void neigh_tables_kernel(NeighParams p_val, co
         double v = neigh_factor(0, t % p.base_nt, (double)i, (double)a, shift, p);
         P2[q] = p.wide ? (float)(v * p.eta) : (float)v * (float)p.eta;
     }
+}
+
+// `swapped` pipeline, between its two stages: V[i][t][b][:] *= m2(i, b) for the masked terms t < nt_masked, where
+// m2 is the reference's second mask on px -- row index i against BMU column b (neighborhoods.py:70).
+__global__ __launch_bounds__(256) void mask_rows_kernel(NeighParams p_val, const NeighParams* __restrict__ p_dev,
+                                                        float* __restrict__ V, int nt_masked, int D1p) {
+    const NeighParams p = p_dev ? *p_dev : p_val;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per_i = (long)p.nt * p.Y * D1p;
+    const long total = (long)p.X * per_i;
+    if (id >= total) return;
+    const int i = (int)(id / per_i);
+    const long r = id - (long)i * per_i;
+    const int t = (int)(r / ((long)p.Y * D1p));
+    const int b = (int)((r / D1p) % p.Y);
+    if (t < nt_masked && neigh_box((double)i, (double)b, (double)(i - b), p) == 0.0) V[id] = 0.0f;
 }
 
 // ---- OUT[b] = H (Ro x Ri) * M[b] (Ri x C), exact float32 on v_mfma_f32_32x32x2_f32 ---------------
@@ -371,11 +426,11 @@ __global__ __launch_bounds__(256) void band_ranges_kernel(const float* __restric
     }
 }
 
-// ranges == nullptr: the whole of H (one segment [0, Ri)).  C columns are computed; rows of M and OUT are ld floats apart.
+// ranges == nullptr: the whole of H (one segment [0, Ri)).  C columns are computed; rows of M are ld, rows of OUT ldo floats apart.
 __global__ __launch_bounds__(256) void leftmul_f32_kernel(const float* __restrict__ H, int Ro, int Ri,
                                                           const float* __restrict__ M, long m_batch_stride,
                                                           float* __restrict__ OUT, long o_batch_stride, long C,
-                                                          long ld, const int2* __restrict__ ranges, int nseg,
+                                                          long ld, long ldo, const int2* __restrict__ ranges, int nseg,
                                                           int segw) {
     __shared__ float Hs[LM_BM][LM_BK + 1];
     __shared__ float Ms[LM_BK][LM_BN + 4];
@@ -461,7 +516,7 @@ __global__ __launch_bounds__(256) void leftmul_f32_kernel(const float* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int i = i0 + wr * 64 + a * 32 + mfma32_row(r, half);
-                if (i < Ro && c < C) Ob[(long)i * ld + c] = acc[a][t][r];
+                if (i < Ro && c < C) Ob[(long)i * ldo + c] = acc[a][t][r];
             }
         }
 }
@@ -475,8 +530,8 @@ template <int NQ>                                       // columns handled per t
 __global__ __launch_bounds__(256) void leftmul_narrow_f32_kernel(const float* __restrict__ H, int Ro, int Ri,
                                                                  const float* __restrict__ M, long m_batch_stride,
                                                                  float* __restrict__ OUT, long o_batch_stride, long C,
-                                                                 long ld, long c_begin, const int2* __restrict__ ranges,
-                                                                 int nseg, int segw) {
+                                                                 long ld, long ldo, long c_begin,
+                                                                 const int2* __restrict__ ranges, int nseg, int segw) {
     __shared__ float Hs[LM_BM][LM_BK + 1];
     __shared__ float Ms[LM_BK][2 * NQ];
     const int tid = threadIdx.x;
@@ -523,7 +578,7 @@ __global__ __launch_bounds__(256) void leftmul_narrow_f32_kernel(const float* __
     const int i = i0 + row;
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
-        if (i < Ro && 2 * q + par < live) Ob[(long)i * ld + c_begin + 2 * q + par] = acc[q];
+        if (i < Ro && 2 * q + par < live) Ob[(long)i * ldo + c_begin + 2 * q + par] = acc[q];
 }
 
 // ---- the count column's own transform ---------------------------------------------------------------

@@ -143,10 +143,11 @@ class XPySom:
             raise ValueError("precision must be 'f32', 'bf16' or 'bf16x3'")
         # what som_create would refuse is refused here, at construction, as the reference raises at
         # construction (the engine itself is created lazily, on the first train() / winner())
-        if neighborhood_function == 'mexican_hat' and compact_support:
-            raise NotImplementedError('mexican_hat with compact_support is not supported: the reference masks px '
-                                      'twice and py never (neighborhoods.py:69-71, :91-93), which is neither the '
-                                      'documented neighbourhood nor defined on non-square maps')
+        if neighborhood_function == 'mexican_hat' and compact_support and topology == 'rectangular' and x != y:
+            # the reference masks px twice and py never (neighborhoods.py:69-71); its second mask is an (n, y) array
+            # against px's (n, x), so NumPy refuses to broadcast it at the first _update.  Reproduced on square maps.
+            raise ValueError('mexican_hat with compact_support needs a square map on the rectangular topology: '
+                             'operands could not be broadcast together with shapes (n,%d) (n,%d)' % (x, y))
         if precision != 'f32' and activation_distance not in ('euclidean', 'cosine'):
             raise ValueError("precision '%s' implements the GEMM-form distances 'euclidean' and 'cosine'; "
                              "'%s' needs precision='f32'" % (precision, activation_distance))
