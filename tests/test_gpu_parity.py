@@ -271,6 +271,8 @@ def test_reference_unit_test_known_answers():
     assert resp[2, 3] == 1 and resp[1, 1] == 1
     wm = som.win_map([[5.0], [2.0]])
     assert wm[(2, 3)][0] == [5.0] and wm[(1, 1)][0] == [2.0]
+    lm = som.labels_map([[5.0], [2.0], [5.1]], ['a', 'b', 'a'])
+    assert lm[(2, 3)]['a'] == 2 and lm[(1, 1)]['b'] == 1 and list(lm) == [(2, 3), (1, 1)]
     # determinism + "train lowers QE"
     rs = np.random.RandomState(1234)
     data = rs.rand(100, 2)

@@ -173,3 +173,27 @@ def test_constructor_refuses_what_the_engine_would_refuse():
             XPySom(5, 5, 3, activation_distance="norm_p", activation_distance_kwargs={"p": p})
     XPySom(5, 5, 3, activation_distance="norm_p", activation_distance_kwargs={"p": 3.0})
     XPySom(5, 5, 3, activation_distance="norm_p_no_opt")
+
+
+def test_win_map_labels_map_activation_response_equal_the_per_sample_definition(oracle_engine):
+    """The batched grouping (one BMU call + a stable sort) against the reference's per-sample definition
+    (xpysom.py:819-865: winner(x) for every x, appended in data order)."""
+    from collections import Counter, defaultdict
+    from xpysom_dask_amd import XPySom
+    data = O.gaussian_blobs(400, 4, seed=8)
+    labels = [int(v) % 3 for v in np.arange(400) * 7]
+    som = XPySom(5, 6, 4, random_seed=2)
+    wins = som.winner(data)
+    want_w, want_l = defaultdict(list), defaultdict(list)
+    for x, w_, lab in zip(data, wins, labels):
+        want_w[w_].append(x)
+        want_l[w_].append(lab)
+    wm, lm = som.win_map(data), som.labels_map(data, labels)
+    assert list(wm) == list(want_w) == list(lm)                   # units in order of first win
+    for k in want_w:
+        assert all(np.array_equal(a, b) for a, b in zip(wm[k], want_w[k])) and len(wm[k]) == len(want_w[k])
+        assert lm[k] == Counter(want_l[k])
+    resp = som.activation_response(data)
+    assert resp.shape == (5, 6) and resp.sum() == 400 and all(resp[k] == len(v) for k, v in want_w.items())
+    with pytest.raises(ValueError, match="same length"):
+        som.labels_map(data, labels[:-1])

@@ -420,21 +420,33 @@ class XPySom:
         data = _host_rows(data, self._engine)
         return self._winner_ids(data).astype(np.int64)
 
+    def _rows_by_unit(self, data):
+        """BMU ids of `data` grouped: yields ((i, j), row indices in data order), units in order of first win --
+        one batched BMU call and one stable sort instead of a winner() call per sample."""
+        ids = self._winner_ids(_host_rows(data, self._engine)).astype(np.int64)
+        if not len(ids):
+            return
+        order = np.argsort(ids, kind='stable')
+        cuts = np.flatnonzero(np.diff(ids[order])) + 1
+        groups = np.split(order, cuts)
+        Y = self._weights.shape[1]
+        for rows in sorted(groups, key=lambda r: r[0]):
+            i, j = np.divmod(ids[rows[0]], Y)
+            yield (i, j), rows
+
     def activation_response(self, data):
         """Matrix where element i,j is the number of times neuron i,j won (xpysom.py:819-829)."""
         data = _host_rows(data, self._engine)
         self._check_input_len(data)
-        a = np.zeros(self._weights.shape[:2])
-        ids = self._winner_ids(data)
-        np.add.at(a.reshape(-1), ids, 1)
-        return a
+        X, Y = self._weights.shape[:2]
+        return np.bincount(self._winner_ids(data), minlength=X * Y).astype(float).reshape(X, Y)
 
     def win_map(self, data):
         """Dictionary wm where wm[(i,j)] lists the patterns mapped to i,j (xpysom.py:831-840)."""
         self._check_input_len(data)
         winmap = defaultdict(list)
-        for x, win in zip(data, self.winner(data)):
-            winmap[win].append(x)
+        for unit, rows in self._rows_by_unit(data):
+            winmap[unit] = [data[n] for n in rows]
         return winmap
 
     def labels_map(self, data, labels):
@@ -443,10 +455,8 @@ class XPySom:
         if not len(data) == len(labels):
             raise ValueError('data and labels must have the same length.')
         winmap = defaultdict(list)
-        for win, lab in zip(self.winner(data), labels):
-            winmap[win].append(lab)
-        for position in winmap:
-            winmap[position] = Counter(winmap[position])
+        for unit, rows in self._rows_by_unit(data):
+            winmap[unit] = Counter(labels[n] for n in rows)
         return winmap
 
     # ------------------------------------------------------------------ host-side initialisers
