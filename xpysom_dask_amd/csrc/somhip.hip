@@ -878,7 +878,7 @@ int run_transform_stage1(som_handle* h, double sigma, double eta, int neigh_f64)
     // U_t[a][j] = sum_b C[a][b] Py_t[j][b] from the dense counts; stage 2 reads it densely (Ud) when it batches over
     // the map columns, or finds it where stage 1 would have put it, T_t[a][j][D], when it runs over whole rows
     const bool per_column = h->D % LM_BN == 0;
-    strided_gemm_f32_kernel<<<dim3((unsigned)cdiv(h->Y, 32), (unsigned)cdiv(h->X, 32), (unsigned)h->nt), dim3(256), 0, h->stream>>>(
+    strided_gemm_f32_kernel<<<dim3((unsigned)cdiv(h->Y, SG_T), (unsigned)cdiv(h->X, SG_T), (unsigned)h->nt), dim3(256), 0, h->stream>>>(
         h->SC + (size_t)h->K * h->D1p, h->Y, 1, h->P1, 1, h->Y, per_column ? h->Ud : h->T + h->D, per_column ? h->Y : slab,
         per_column ? 1 : h->D1p, h->X, h->Y, h->Y, 0, (long)h->Y * h->Y, per_column ? (long)h->K : (long)h->X * slab);
     HIPCHK(h, hipGetLastError());
@@ -909,7 +909,7 @@ int run_transform_stage2(som_handle* h, int b0, int b1) {
         launch_leftmul(h, H, rows, h->nt * h->X, h->T, h->D1p, h->ACC + i0 * slab, h->D1p, h->D, slab, b1 - b0, h->Y, ranges,
                        h->nt, h->X);
         // den[i][j] = sum_k [Px_0 | Px_1 ...][i][k] U[k][j], U = [U_0; U_1; ...] dense (stage 1)
-        strided_gemm_f32_kernel<<<dim3((unsigned)cdiv(h->Y, 32), (unsigned)cdiv(rows, 32), 1), dim3(256), 0, h->stream>>>(
+        strided_gemm_f32_kernel<<<dim3((unsigned)cdiv(h->Y, SG_T), (unsigned)cdiv(rows, SG_T), 1), dim3(256), 0, h->stream>>>(
             H, (long)h->nt * h->X, 1, h->Ud, h->Y, 1, h->ACC + i0 * slab + h->D, slab, h->D1p, rows, h->Y, h->nt * h->X, 0, 0, 0);
     } else {
         launch_leftmul(h, H, rows, h->nt * h->X, h->T, 0, h->ACC + i0 * slab, 0, slab, slab, b1 - b0, 1, ranges, h->nt, h->X);

@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void leftmul_f32_kernel(const float* __restric
                                                           long ld, long ldo, const int2* __restrict__ ranges, int nseg,
                                                           int segw) {
     __shared__ float Hs[LM_BM][LM_BK + 1];
-    __shared__ float Ms[LM_BK][LM_BN + 4];
+    __shared__ __attribute__((aligned(16))) float Ms[LM_BK][LM_BN + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
     const int wr = wave >> 1, wc = wave & 1;
@@ -450,23 +450,44 @@ __global__ __launch_bounds__(256) void leftmul_f32_kernel(const float* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.0f;
 
-    float hreg[16], mreg[16];                          // this thread's share of the staged chunk
+    // this thread's share of the staged chunk: four 4-float pieces of each operand tile -- piece q of the H tile
+    // (128 x 32) is row (tid + 256 q) >> 3, columns 4 ((tid + 256 q) & 7) .. + 3; of the M tile (32 x 128) row
+    // (tid + 256 q) >> 5, columns 4 ((tid + 256 q) & 31) .. + 3.  A piece that lies inside the operand and is
+    // 16-byte aligned is ONE global_load_dwordx4 (the common case: 8 loads per thread and chunk where the scalar
+    // form needed 32 loads with their 64-bit address arithmetic); otherwise its four floats are loaded one by one.
+    f32x4 hreg[4], mreg[4];
+    const bool h_vec = (Ri & 3) == 0 && ((uintptr_t)H & 15) == 0;
+    const bool m_vec = (ld & 3) == 0 && ((uintptr_t)Mb & 15) == 0;
     auto fetch = [&](int r0, int kend) {               // chunk [r0, r0 + 32) clipped to columns < kend
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            int idx = tid + q * 256;
-            int i = idx >> 5, k = idx & 31;            // H tile: 128 x 32
-            hreg[q] = (i0 + i < Ro && r0 + k < kend) ? H[(long)(i0 + i) * Ri + r0 + k] : 0.0f;
-            int kk = idx >> 7, c = idx & 127;          // M tile: 32 x 128
-            mreg[q] = (r0 + kk < kend && c0 + c < C) ? Mb[(long)(r0 + kk) * ld + c0 + c] : 0.0f;
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + q * 256;
+            {
+                const int i = idx >> 3, k = (idx & 7) * 4;
+                const float* src = H + (long)(i0 + i) * Ri + r0 + k;
+                if (h_vec && i0 + i < Ro && r0 + k + 3 < kend) hreg[q] = *(const f32x4*)src;
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hreg[q][e] = (i0 + i < Ro && r0 + k + e < kend) ? src[e] : 0.0f;
+            }
+            {
+                const int kk = idx >> 5, c = (idx & 31) * 4;
+                const float* src = Mb + (long)(r0 + kk) * ld + c0 + c;
+                if (m_vec && r0 + kk < kend && c0 + c + 3 < C) mreg[q] = *(const f32x4*)src;
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mreg[q][e] = (r0 + kk < kend && c0 + c + e < C) ? src[e] : 0.0f;
+            }
         }
     };
     auto stash = [&]() {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            int idx = tid + q * 256;
-            Hs[idx >> 5][idx & 31] = hreg[q];
-            Ms[idx >> 7][idx & 127] = mreg[q];
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + q * 256;
+            const int i = idx >> 3, k = (idx & 7) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Hs[i][k + e] = hreg[q][e];          // (33-float rows: conflict-free reads, scalar writes)
+            *(f32x4*)&Ms[idx >> 5][(idx & 31) * 4] = mreg[q];               // 132-float rows: 16-byte aligned
         }
     };
 
@@ -587,54 +608,49 @@ __global__ __launch_bounds__(256) void leftmul_narrow_f32_kernel(const float* __
 // give the count a second, empty tile.  OUT[i*oi + j*oj] = sum_k A[i*ai + k*ak] * B[k*bk + j*bj], k ascending,
 // one fmaf chain per output: exactly the chain the MFMA tiles computed for this column (skipped zero bands
 // add exact zeros), so the denominator is bit for bit what it was.  The operands are columns of wide arrays
-// (one float per 528-byte row), so the kernel is latency-bound: a workgroup (32 x 32 outputs) issues the loads of
-// SG_KC = 256 k-steps of both operands at once -- one round trip per 256 k-steps -- before it multiplies.
-constexpr int SG_KC = 256;
+// (one float per 528-byte row) or small dense matrices, so the kernel is latency-bound: a workgroup (16 x 16 outputs,
+// one per thread: 256 workgroups at 256 x 256) issues the loads of SG_KC = 256 k-steps of both operands at once --
+// one round trip per 256 k-steps -- before it multiplies.
+constexpr int SG_KC = 256, SG_T = 16;   // k-steps staged at once; output tile side (one output per thread)
 __global__ __launch_bounds__(256) void strided_gemm_f32_kernel(const float* __restrict__ A, long ai, long ak,
                                                                const float* __restrict__ B, long bk, long bj,
                                                                float* __restrict__ OUT, long oi, long oj, int M, int N,
                                                                int Kd, long a_batch, long b_batch, long o_batch) {
-    __shared__ float As[32][SG_KC + 1];
-    __shared__ float Bs[SG_KC][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
-    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    __shared__ float As[SG_T][SG_KC + 1];
+    __shared__ float Bs[SG_KC][SG_T + 1];
+    const int tx = threadIdx.x & (SG_T - 1), ty = threadIdx.x / SG_T;   // 16 x 16
+    const int i0 = blockIdx.y * SG_T, j0 = blockIdx.x * SG_T;
     A += (long)blockIdx.z * a_batch; B += (long)blockIdx.z * b_batch; OUT += (long)blockIdx.z * o_batch;
-    // the unit-stride axis of each operand goes along tx (either k or the row / column index)
+    // the unit-stride axis of each operand goes along consecutive threads (either k or the row / column index)
     const bool a_k_fast = ak <= ai, b_j_fast = bj <= bk;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc = 0.f;
     for (int k0 = 0; k0 < Kd; k0 += SG_KC) {
         __syncthreads();
-        float ra[SG_KC / 8], rb[SG_KC / 8];
+        constexpr int PER = SG_T * SG_KC / 256;                  // elements of each operand per thread
+        float ra[PER], rb[PER];
 #pragma unroll
-        for (int q = 0; q < SG_KC / 8; ++q) {                    // 32 * SG_KC elements of each operand, 256 threads
+        for (int q = 0; q < PER; ++q) {
             const int e = q * 256 + threadIdx.x;
-            const int ar = a_k_fast ? e / SG_KC : e & 31, akk = a_k_fast ? e % SG_KC : e >> 5;
+            const int ar = a_k_fast ? e / SG_KC : e % SG_T, akk = a_k_fast ? e % SG_KC : e / SG_T;
             ra[q] = (i0 + ar < M && k0 + akk < Kd) ? A[(long)(i0 + ar) * ai + (long)(k0 + akk) * ak] : 0.0f;
-            const int bc = b_j_fast ? e & 31 : e / SG_KC, bkk = b_j_fast ? e >> 5 : e % SG_KC;
+            const int bc = b_j_fast ? e % SG_T : e / SG_KC, bkk = b_j_fast ? e / SG_T : e % SG_KC;
             rb[q] = (k0 + bkk < Kd && j0 + bc < N) ? B[(long)(k0 + bkk) * bk + (long)(j0 + bc) * bj] : 0.0f;
         }
 #pragma unroll
-        for (int q = 0; q < SG_KC / 8; ++q) {
+        for (int q = 0; q < PER; ++q) {
             const int e = q * 256 + threadIdx.x;
-            const int ar = a_k_fast ? e / SG_KC : e & 31, akk = a_k_fast ? e % SG_KC : e >> 5;
+            const int ar = a_k_fast ? e / SG_KC : e % SG_T, akk = a_k_fast ? e % SG_KC : e / SG_T;
             As[ar][akk] = ra[q];
-            const int bc = b_j_fast ? e & 31 : e / SG_KC, bkk = b_j_fast ? e >> 5 : e % SG_KC;
+            const int bc = b_j_fast ? e % SG_T : e / SG_KC, bkk = b_j_fast ? e / SG_T : e % SG_KC;
             Bs[bkk][bc] = rb[q];
         }
         __syncthreads();
         const int kn = Kd - k0 < SG_KC ? Kd - k0 : SG_KC;
 #pragma unroll 8
-        for (int k = 0; k < kn; ++k) {
-            const float b = Bs[k][tx];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(As[ty + 8 * r][k], b, acc[r]);
-        }
+        for (int k = 0; k < kn; ++k) acc = __builtin_fmaf(As[ty][k], Bs[k][tx], acc);
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = i0 + ty + 8 * r, j = j0 + tx;
-        if (i < M && j < N) OUT[(long)i * oi + (long)j * oj] = acc[r];
-    }
+    const int i = i0 + ty, j = j0 + tx;
+    if (i < M && j < N) OUT[(long)i * oi + (long)j * oj] = acc;
 }
 
 // ---- merge: W = where(den != 0, num/den, W)  (xpysom.py:446-455) ---------------------------------
