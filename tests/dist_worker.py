@@ -55,6 +55,11 @@ def main():
         som = XPySom(X, Y, Dm, random_seed=3, decay_function="linear", device=dev, precision=prec, sharded_input=sharded)
         feed(som, data, T, iter_beg=2, iter_end=3)
         np.save(os.path.join(out_dir, "w_%s_%d.npy" % (mode, rank)), som._weights)
+        # (c) fewer rows than ranks: the last rank's shard is EMPTY and still takes part in every collective
+        one = O.gaussian_blobs(1, 5, seed=5)
+        som1 = XPySom(4, 3, 5, random_seed=3, decay_function="linear", device=dev, precision=prec)
+        som1.train(one, 2)
+        np.save(os.path.join(out_dir, "w1_%s_%d.npy" % (mode, rank)), som1._weights)
         lo, hi = D.shard_bounds(n, rank, world)
         # the collective really summed over the ranks: one more accumulate + all-reduce, fetched raw
         eng = som._engine()

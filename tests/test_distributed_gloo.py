@@ -38,6 +38,11 @@ def _worker(rank, world, port, sharded_input, out_dir, overlap="0"):
             mine = data[lo:hi]
         som.train(mine, 6)
         np.save(os.path.join(out_dir, "w%d.npy" % rank), som._weights)
+        if not sharded_input:                              # one row, two ranks: rank 1's shard is empty
+            one = O.gaussian_blobs(1, 5, seed=5)
+            som1 = XPySom(4, 3, 5, random_seed=3, decay_function="linear")
+            som1.train(one, 2)
+            np.save(os.path.join(out_dir, "one%d.npy" % rank), som1._weights)
     finally:
         dist.destroy_process_group()
 
@@ -52,6 +57,11 @@ def test_two_rank_training_equals_single_process(tmp_path, sharded_input):
     data = O.gaussian_blobs(601, 5, seed=11)
     ref = O.train(data, O.default_codebook(7, 6, 5, 3), 6, sigma0=3.0, decay="linear", n_parallel=4000)
     np.testing.assert_allclose(w0, ref, rtol=2e-5, atol=2e-6)   # sum order differs with the shard count
+    if not sharded_input:
+        o0, o1 = np.load(tmp_path / "one0.npy"), np.load(tmp_path / "one1.npy")
+        ref1 = O.train(O.gaussian_blobs(1, 5, seed=5), O.default_codebook(4, 3, 5, 3), 2, sigma0=1.5, decay="linear", n_parallel=4000)
+        assert np.array_equal(o0, o1)
+        np.testing.assert_allclose(o0, ref1, rtol=2e-5, atol=2e-6)
 
 
 def test_blockwise_allreduce_host_logic(tmp_path):

@@ -42,7 +42,7 @@ def _launch(backend, out_dir, mode, world=2, **extra_env):
 def _check(out_dir, mode, world=2):
     """Every rank holds the same results, bit for bit; returns rank 0's (small-run codebook, epoch codebook, den)."""
     got = []
-    for stem in ("ws", "w", "den"):
+    for stem in ("ws", "w", "den", "w1"):
         a = [np.load(os.path.join(out_dir, "%s_%s_%d.npy" % (stem, mode, r))) for r in range(world)]
         for b in a[1:]:
             assert np.array_equal(a[0], b)
@@ -63,9 +63,12 @@ def _references():
 @pytest.mark.parametrize("mode", ["full", "sharded", "stream"])
 def test_two_ranks_of_the_hip_engine_under_gloo(tmp_path, mode):
     _launch("gloo", tmp_path, mode)
-    ws, w, den = _check(tmp_path, mode)
+    ws, w, den, w1 = _check(tmp_path, mode)
     data, ref_small, ref_epoch = _references()
     np.testing.assert_allclose(ws, ref_small, rtol=2e-5, atol=2e-6)    # float32 sum order differs with the shard count
+    one = O.gaussian_blobs(1, 5, seed=5)                               # one row, two ranks: rank 1's shard is empty
+    ref1 = O.train(one, O.default_codebook(4, 3, 5, 3), 2, sigma0=1.5, decay="linear", n_parallel=4000)
+    np.testing.assert_allclose(w1, ref1, rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(w, ref_epoch, rtol=2e-5, atol=2e-6)
     # the all-reduced denominator covers ALL rows, not one shard's
     _, _, den_all = O.update(data, w.astype(np.float32), 0.3, 2.0, wide=False)
@@ -74,7 +77,7 @@ def test_two_ranks_of_the_hip_engine_under_gloo(tmp_path, mode):
 
 def test_two_ranks_bf16_precision_under_gloo(tmp_path):
     _launch("gloo", tmp_path, "bf16")
-    ws, w, _ = _check(tmp_path, "bf16")
+    ws, w, _, _ = _check(tmp_path, "bf16")
     _, ref_small, ref_epoch = _references()
     # bf16 BMUs: near-tie picks may differ from float32, the epoch's result barely moves
     scale = np.abs(ref_epoch).max()
@@ -100,7 +103,7 @@ def test_two_ranks_under_rccl(tmp_path):
         pytest.skip("needs two GPUs (the driver's multi-GPU node)")
     for mode in ("full", "stream", "wide"):
         _launch("nccl", tmp_path, mode)
-        ws, w, _ = _check(tmp_path, mode)
+        ws, w, _, _ = _check(tmp_path, mode)
         _, ref_small, ref_epoch = _references()
         np.testing.assert_allclose(ws, ref_small, rtol=2e-5, atol=2e-6)
         if mode != "wide":                                     # (wide: another map; rank-to-rank equality above)
