@@ -127,10 +127,10 @@ def pmc_traffic(workload, rows, precision, kernel, build_hash):
         try:
             with open(path) as f:
                 pm = json.load(f)
-            k = pm[kernel]
             if pm.get("rows_per_launch") != rows or pm.get("workload", "c3") != workload \
-                    or pm.get("precision", "bf16") != precision:
-                continue
+                    or pm.get("precision", "bf16") != precision or pm.get("library", "libsomhip.so") != "libsomhip.so":
+                continue                                   # (another workload, or a timing-experiment build)
+            k = next(v for name, v in pm.items() if name.startswith(kernel) and isinstance(v, dict))   # "<kernel><4>" too
             cand = {"bytes": k["fabric_bytes_corrected"], "file": os.path.basename(path), "build": pm.get("build")}
         except Exception:
             continue
