@@ -68,64 +68,94 @@ __global__ __launch_bounds__(256) void prep_w_bf16_k16_kernel(const float* __res
 // _merge_updates (xpysom.py:446-455) fused with the NEXT epoch's operand preparation: one pass over the fused
 // accumulator writes the merged float32 codebook, the bf16 stage image of -w~ and |w~_k|^2 (+ its maximum),
 // i.e. merge_kernel + prep_w_bf16_k16_kernel + prep_wnorm_kernel (euclidean) in one launch and one read of
-// the codebook.  Workgroup = one 16-unit tile = KS32 waves; thread = (unit, 8 features), exactly one 16-byte
-// fragment chunk of the image.  W = where(den != 0, num / den, W) as merge_kernel computes it.
+// the codebook.  Workgroup = MP_TILES 16-unit tiles, KS32 waves; thread = (unit, 8 features) of each tile, exactly one
+// 16-byte fragment chunk of the image.  W = where(den != 0, num / den, W) as merge_kernel computes it.
+constexpr int MP_TILES = 4;           // 16-unit tiles per workgroup: their loads are all issued before the first is used
 template <int KS32>
 __global__ __launch_bounds__(64 * KS32) void merge_prep_k16_kernel(float* __restrict__ W, const float* __restrict__ ACC,
                                                                  int K, int D, int D1p, char* __restrict__ Wst,
-                                                                 float* __restrict__ wn, float* __restrict__ wmax2) {
-    __shared__ float red[KS32][16];
+                                                                 float* __restrict__ wn, float* __restrict__ wmax2,
+                                                                 long n_tiles) {
+    __shared__ float red[MP_TILES][KS32][16];
     const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
-    const long tile = blockIdx.x;                     // (stage, t16)
-    const long stage = tile / K16_T;
-    const int t16 = (int)(tile - stage * K16_T);
-    const long u = stage * K16_STAGE_UNITS + t16 * 16 + (lane & 15);
     const int k0 = ks * 32 + (lane >> 4) * 8;
-    float w[8];
+    const bool full = k0 + 8 <= D && (D & 3) == 0;         // 16-byte aligned rows on both sides (D1p is a multiple of 4)
+    float w[MP_TILES][8], den[MP_TILES];
+    long unit[MP_TILES];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) w[j] = 0.0f;
-    if (u < K) {
-        const float den = ACC[u * D1p + D];
-        const bool full = k0 + 8 <= D && (D1p & 3) == 0 && (D & 3) == 0;   // 16-byte aligned rows on both sides
-        if (den != 0.0f) {
+    for (int i = 0; i < MP_TILES; ++i) {                   // phase 1: every load of the workgroup's tiles
+        const long tile = (long)blockIdx.x * MP_TILES + i;
+        const long stage = tile / K16_T;
+        const long u = stage * K16_STAGE_UNITS + (tile - stage * K16_T) * 16 + (lane & 15);
+        unit[i] = (tile < n_tiles && u < K) ? u : -1;
+        den[i] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[i][j] = 0.0f;
+        if (unit[i] >= 0) {
+            den[i] = ACC[u * D1p + D];
             if (full) {
-                const f32x4 a = *(const f32x4*)(ACC + u * D1p + k0), b = *(const f32x4*)(ACC + u * D1p + k0 + 4);
-                f32x4 q0, q1;
+                const f32x4 a = *(const f32x4*)(ACC + u * D1p + k0), c = *(const f32x4*)(ACC + u * D1p + k0 + 4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { q0[j] = a[j] / den; q1[j] = b[j] / den; w[j] = q0[j]; w[4 + j] = q1[j]; }
-                *(f32x4*)(W + u * D + k0) = q0;
-                *(f32x4*)(W + u * D + k0 + 4) = q1;
+                for (int j = 0; j < 4; ++j) { w[i][j] = a[j]; w[i][4 + j] = c[j]; }
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (k0 + j < D) { w[j] = ACC[u * D1p + k0 + j] / den; W[u * D + k0 + j] = w[j]; }
+                    if (k0 + j < D) w[i][j] = ACC[u * D1p + k0 + j];
             }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (k0 + j < D) w[j] = W[u * D + k0 + j];
         }
     }
-    bf16x8 v;
-    float s = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 b = (__bf16)w[j];
-        v[j] = (__bf16)(-w[j]);                       // (rounding is sign-symmetric: -bf16(w) == bf16(-w))
-        const float f = (float)b;
-        s = __builtin_fmaf(f, f, s);
+    for (int i = 0; i < MP_TILES; ++i) {                   // phase 2: merge, codebook row, stage image, norm partials
+        const long tile = (long)blockIdx.x * MP_TILES + i;
+        const long stage = tile / K16_T;
+        const int t16 = (int)(tile - stage * K16_T);
+        const long u = unit[i];
+        if (u >= 0) {
+            if (den[i] != 0.0f) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[i][j] = w[i][j] / den[i];
+                if (full) {
+                    f32x4 q0, q1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { q0[j] = w[i][j]; q1[j] = w[i][4 + j]; }
+                    *(f32x4*)(W + u * D + k0) = q0;
+                    *(f32x4*)(W + u * D + k0 + 4) = q1;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (k0 + j < D) W[u * D + k0 + j] = w[i][j];
+                }
+            } else {                                       // no row in reach of this unit: the old weights stay
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[i][j] = (k0 + j < D) ? W[u * D + k0 + j] : 0.0f;
+            }
+        }
+        if (tile < n_tiles) {
+            bf16x8 v;
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const __bf16 b = (__bf16)w[i][j];
+                v[j] = (__bf16)(-w[i][j]);                 // (rounding is sign-symmetric: -bf16(w) == bf16(-w))
+                const float f = (float)b;
+                s = __builtin_fmaf(f, f, s);
+            }
+            *(bf16x8*)(Wst + stage * k16_stage_bytes(KS32) + ((long)(t16 * KS32 + ks) * 64 + lane) * 16) = v;
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (lane < 16) red[i][ks][lane] = s;
+        }
     }
-    *(bf16x8*)(Wst + stage * k16_stage_bytes(KS32) + ((long)(t16 * KS32 + ks) * 64 + lane) * 16) = v;
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    if (lane < 16) red[ks][lane] = s;
     __syncthreads();
     if (ks == 0 && lane < 16) {
-        float t = 0.0f;
+        float m = 0.0f;
 #pragma unroll
-        for (int q = 0; q < KS32; ++q) t += red[q][lane];
-        if (u < K) wn[u] = t;
-        float m = u < K ? t : 0.0f;
+        for (int i = 0; i < MP_TILES; ++i) {
+            float t = 0.0f;
+#pragma unroll
+            for (int q = 0; q < KS32; ++q) t += red[i][q][lane];
+            if (unit[i] >= 0) { wn[unit[i]] = t; m = fmaxf(m, t); }
+        }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
         if (lane == 0) atomic_max_pos_f32(wmax2, m);

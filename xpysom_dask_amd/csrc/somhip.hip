@@ -1421,12 +1421,13 @@ int som_epoch_merge(som_handle* h) {
     if (h->cfg.precision == SOM_PREC_BF16 && !h->tiled && h->shape16 && h->cfg.distance == SOM_DIST_EUCLIDEAN &&
         h->fuse_merge_prep) {
         HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
-        const dim3 grid((unsigned)((long)h->n_stages * K16_T));
+        const long n_tiles = (long)h->n_stages * K16_T;
+        const dim3 grid((unsigned)cdiv(n_tiles, MP_TILES));
         switch (h->ks32) {
-        case 1: merge_prep_k16_kernel<1><<<grid, dim3(64), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2); break;
-        case 2: merge_prep_k16_kernel<2><<<grid, dim3(128), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2); break;
-        case 3: merge_prep_k16_kernel<3><<<grid, dim3(192), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2); break;
-        case 4: merge_prep_k16_kernel<4><<<grid, dim3(256), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2); break;
+        case 1: merge_prep_k16_kernel<1><<<grid, dim3(64), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2, n_tiles); break;
+        case 2: merge_prep_k16_kernel<2><<<grid, dim3(128), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2, n_tiles); break;
+        case 3: merge_prep_k16_kernel<3><<<grid, dim3(192), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2, n_tiles); break;
+        case 4: merge_prep_k16_kernel<4><<<grid, dim3(256), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2, n_tiles); break;
         default: return fail(h, "bf16 precision supports input_len <= 128");
         }
         HIPCHK(h, hipGetLastError());
