@@ -305,7 +305,8 @@ def main():
                        "map": [MAP_X, MAP_Y], "features": FEATURES, "rows_per_gpu": my_rows, "rows_total": total_rows,
                        "precision": args.precision, "distance": wl["distance"], "neighborhood": wl["neighborhood"],
                        "update": "bucketed (segment sum by BMU + separable neighbourhood transform; exact algebra of "
-                                 "the reference's g^T.x GEMM, xpysom.py:434-438)",
+                                 "the reference's g^T.x GEMM, xpysom.py:434-438; the faithful K x N x D GEMM form is "
+                                 "som_epoch_accumulate_faithful: 274 ms per Mi rows at this shape, tools/bench_faithful.py)",
                        "parallelism": "dp%d (sample shards, 1 all-reduce/epoch)" % world,
                        "epochs_per_sec": args.steps / dt, "build": build_hash},
             "roofline": {"bound": "mfma", "kernel": kernel_name + " (fused distance GEMM + argmin)",

@@ -109,6 +109,10 @@ int som_copy_to_host(som_handle* h, const void* x_dev, uint64_t bytes, void* dst
  * the neighbourhood in float64 (what NumPy >= 2 does when the schedule returns
  * numpy.float64, i.e. 'exponential'); 0 mimics the float32 evaluation. */
 int som_epoch_accumulate(som_handle* h, double sigma, double eta, int neigh_f64);
+/* the same accumulator computed the way the reference states it, xpysom.py:434-441: g = h * eta per (sample, unit)
+ * generated from the neighbourhood tables inside a K x N x D float32 MFMA GEMM (num = g^T x, den = sum_n g), 2*N*K*D
+ * flop where som_epoch_accumulate's bucketed algebra needs 2*K*(X+Y)*(D+1).  For cross-checks and the record. */
+int som_epoch_accumulate_faithful(som_handle* h, double sigma, double eta, int neigh_f64);
 int som_epoch_merge(som_handle* h);
 int som_epoch(som_handle* h, double sigma, double eta, int neigh_f64);
 

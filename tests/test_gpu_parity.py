@@ -1245,3 +1245,37 @@ def test_g15_mexican_hat_with_compact_support_as_the_reference_computes_it(topo,
     _, onum, oden = O.update(data, w0, np.float64(0.4), np.float64(3.0), wide=True, compact=True, forced_bmu=bmu,
                              neighbourhood="mexican_hat" + ("_hex" if topo == "hexagonal" else ""))
     assert rel_err(num, onum.reshape(-1, 5)) < 1e-5 and rel_err(den, oden.reshape(-1)) < 1e-5
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(X=20, Y=30, D=12, n=3000, neighborhood="gaussian"),
+    dict(X=9, Y=8, D=4, n=400, neighborhood="mexican_hat", topology="hexagonal"),
+    dict(X=13, Y=11, D=130, n=700, neighborhood="triangle", compact_support=True),
+    dict(X=150, Y=5, D=7, n=1000, neighborhood="bubble"),
+    dict(X=7, Y=7, D=3, n=300, neighborhood="mexican_hat", topology="hexagonal", compact_support=True),
+])
+def test_faithful_update_form_equals_the_bucketed_one(cfg):
+    """The update as the reference states it -- g[n, k] generated per (sample, unit) inside a K x N x D MFMA GEMM,
+    num = g^T x, den = sum_n g (xpysom.py:434-441; som_epoch_accumulate_faithful) -- against the bucketed algebra
+    the engine trains with (segment sums + separable transform): same accumulator to float32 summation order."""
+    cfg = dict(cfg)
+    X, Y, D, n = (cfg.pop(k) for k in ("X", "Y", "D", "n"))
+    data = O.gaussian_blobs(n, D, seed=X + D)
+    w = O.default_codebook(X, Y, D, 2).astype(F32)
+    e = engine(X, Y, D, **cfg)
+    e.set_weights(w)
+    e.set_data(data)
+    for sig, eta, wide in ((3.0, 0.4, True), (1.2, 0.1, False)):
+        e.epoch_accumulate(sig, eta, wide)
+        num0, den0, bmu0 = e.epoch_fetch()
+        e.epoch_accumulate_faithful(sig, eta, wide)
+        num1, den1, bmu1 = e.epoch_fetch()
+        assert np.array_equal(bmu0, bmu1)
+        assert rel_err(num1, num0) < 1e-5 and rel_err(den1, den0) < 1e-5
+    from xpysom_dask_amd.engine import SomHipError
+    if cfg.get("neighborhood") == "gaussian":
+        sq = engine(5, 5, 3, neighborhood="mexican_hat", compact_support=True)
+        sq.set_weights(O.default_codebook(5, 5, 3, 1).astype(F32))
+        sq.set_data(O.gaussian_blobs(50, 3, seed=1))
+        with pytest.raises(SomHipError, match="not a sum of row factor"):
+            sq.epoch_accumulate_faithful(1.0, 0.1, True)

@@ -42,6 +42,7 @@ SIGNATURES = {
     "som_sync_producer": (C.c_int, [_H, C.c_uint64, C.c_int32]),
     "som_copy_to_host": (C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p]),
     "som_epoch_accumulate": (C.c_int, [_H, C.c_double, C.c_double, C.c_int]),
+    "som_epoch_accumulate_faithful": (C.c_int, [_H, C.c_double, C.c_double, C.c_int]),
     "som_epoch_merge": (C.c_int, [_H]),
     "som_epoch": (C.c_int, [_H, C.c_double, C.c_double, C.c_int]),
     "som_epoch_accumulate_begin": (C.c_int, [_H, C.c_double, C.c_double, C.c_int]),

@@ -1301,6 +1301,24 @@ int som_epoch_accumulate(som_handle* h, double sigma, double eta, int neigh_f64)
     return epoch_accumulate_eager(h, sigma, eta, neigh_f64);
 }
 
+// the same accumulator through the update as the reference states it (update.hpp, faithful_update_f32_kernel)
+int som_epoch_accumulate_faithful(som_handle* h, double sigma, double eta, int neigh_f64) {
+    DeviceGuard dev_guard(h);
+    if (!h) return 1;
+    if (!h->Xd && h->N > 0) return fail(h, "som_epoch_accumulate_faithful: no resident data (call som_set_data)");
+    if (h->swapped) return fail(h, "som_epoch_accumulate_faithful: mexican_hat with compact_support on the rectangular "
+                                   "topology is not a sum of row factor x column factor terms");
+    if (int rc = run_activation_bmu(h, h->Xd, h->N, h->xsq, h->Xb, h->xmax2, h->bmu)) return rc;
+    Timed t(h, SOM_K_KRON);
+    if (int rc = build_tables(h, sigma, eta, neigh_f64, h->stream)) return rc;
+    HIPCHK(h, hipMemsetAsync(h->ACC, 0, (size_t)h->K * h->D1p * sizeof(float), h->stream));
+    const dim3 grid((unsigned)cdiv(h->D, LM_BN), (unsigned)cdiv(h->K, LM_BM));
+    faithful_update_f32_kernel<<<grid, dim3(256), 0, h->stream>>>(h->Xd, h->bmu, h->N, h->D, h->D1p, h->X, h->Y, h->nt, h->P1,
+                                                              h->P2, h->ACC);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 int som_epoch_accumulate_forced(som_handle* h, const int32_t* bmu_host, double sigma, double eta, int neigh_f64) {
     DeviceGuard dev_guard(h);
     if (!h || (!bmu_host && h->N > 0)) return fail(h, "som_epoch_accumulate_forced: bad argument");

@@ -602,6 +602,115 @@ __global__ __launch_bounds__(256) void leftmul_narrow_f32_kernel(const float* __
         if (i < Ro && 2 * q + par < live) Ob[(long)i * ldo + c_begin + 2 * q + par] = acc[q];
 }
 
+// ---- the update as the reference states it: num = g^T x, den = sum_n g  (xpysom.py:434-441) -----------------------
+// The FAITHFUL form, kept beside the bucketed one for cross-checking and for the record: a K x N x D
+// float32 MFMA GEMM whose A operand g[n, k] = sum_t Px_t[i_k, ci_n] Py_t[j_k, cj_n] is generated from the
+// neighbourhood tables on the way into LDS and never exists in memory.  Same tiling as leftmul_f32_kernel (128 units
+// x 128 features per workgroup, 32-row chunks of the samples as the k axis).  2 N K D flop: 17.6 TFLOP per epoch at
+// 256 x 256 x 128 with 1 Mi rows, where the bucketed form needs 8.7 GFLOP.
+__global__ __launch_bounds__(256) void faithful_update_f32_kernel(const float* __restrict__ X, const int* __restrict__ bmu,
+                                                                  long N, int D, int D1p, int Xm, int Ym, int nt,
+                                                                  const float* __restrict__ P1, const float* __restrict__ P2,
+                                                                  float* __restrict__ ACC) {
+    __shared__ float Gs[LM_BM][LM_BK + 1];               // g[unit][row of the chunk]
+    __shared__ __attribute__((aligned(16))) float Xs[LM_BK][LM_BN + 4];
+    __shared__ int ci_s[LM_BK], cj_s[LM_BK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int wr = wave >> 1, wc = wave & 1;
+    const long c0 = (long)blockIdx.x * LM_BN;            // first feature column of the tile
+    const int u0 = blockIdx.y * LM_BM;                   // first unit of the tile
+    const int K = Xm * Ym;
+    // this thread generates g for the 16 units (tid >> 5) + 8 q and the chunk row tid & 31
+    int iu[16], ju[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int u = u0 + (tid >> 5) + 8 * q;
+        iu[q] = u < K ? u / Ym : -1;
+        ju[q] = u < K ? u % Ym : 0;
+    }
+    float den[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) den[q] = 0.0f;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.0f;
+
+    for (long r0 = 0; r0 < N; r0 += LM_BK) {
+        __syncthreads();                                 // everyone is done with the previous chunk
+        if (tid < LM_BK) {
+            const long n = r0 + tid;
+            const int b = n < N ? bmu[n] : -1;
+            ci_s[tid] = b >= 0 ? b / Ym : -1;
+            cj_s[tid] = b >= 0 ? b % Ym : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                    // the rows of the chunk: 32 x 128 features (16-byte pieces)
+            const int idx = tid + q * 256;
+            const int kk = idx >> 5, c = (idx & 31) * 4;
+            const long n = r0 + kk;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n < N && c0 + c + e < D) v[e] = X[n * D + c0 + c + e];
+            *(f32x4*)&Xs[kk][c] = v;
+        }
+        __syncthreads();
+        {
+            const int k = tid & 31;
+            const int ci = ci_s[k], cj = cj_s[k];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float g = 0.0f;
+                if (ci >= 0 && iu[q] >= 0)
+                    for (int t = 0; t < nt; ++t)
+                        g = __builtin_fmaf(P2[(long)iu[q] * nt * Xm + t * Xm + ci], P1[((long)t * Ym + ju[q]) * Ym + cj], g);
+                Gs[(tid >> 5) + 8 * q][k] = g;
+                den[q] += g;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LM_BK; k += 2) {
+            float av[2], bv[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) av[a] = Gs[wr * 64 + a * 32 + col][k + half];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) bv[t] = Xs[k + half][wc * 64 + t * 32 + col];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[t], acc[a][t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const long c = c0 + wc * 64 + t * 32 + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int u = u0 + wr * 64 + a * 32 + mfma32_row(r, half);
+                if (u < K && c < D) ACC[(long)u * D1p + c] = acc[a][t][r];
+            }
+        }
+    if (blockIdx.x == 0) {                               // den: the 32 threads of a half-wave hold one unit's partial sums
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            float s = den[q];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            const int u = u0 + (tid >> 5) + 8 * q;
+            if ((tid & 31) == 0 && u < K) ACC[(long)u * D1p + D] = s;
+        }
+    }
+}
+
 // ---- the count column's own transform ---------------------------------------------------------------
 // den = sum_t Px_t C Py_t^T with C[a][b] = the count of unit (a, b): two X x Y x {Y, nt X} products, 33 MFLOP each
 // at 256 x 256.  Kept out of the batched MFMA transform, whose column tiles are 128 wide: input_len = 128 would

@@ -104,6 +104,10 @@ class HipEngine:
     def epoch_accumulate(self, sigma, eta, neigh_f64):
         self._check(self._lib.som_epoch_accumulate(self._h, float(sigma), float(eta), int(bool(neigh_f64))))
 
+    def epoch_accumulate_faithful(self, sigma, eta, neigh_f64):
+        """epoch_accumulate through the reference's own formulation (g^T x as one big MFMA GEMM): cross-checks."""
+        self._check(self._lib.som_epoch_accumulate_faithful(self._h, float(sigma), float(eta), int(bool(neigh_f64))))
+
     def epoch_accumulate_forced(self, bmu, sigma, eta, neigh_f64):
         bmu = np.ascontiguousarray(bmu, dtype=np.int32)
         if bmu.shape != (self.n_rows,):
