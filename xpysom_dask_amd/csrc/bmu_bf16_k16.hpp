@@ -1,9 +1,9 @@
 // Fused distance + BMU argmin, bf16, on v_mfma_f32_16x16x32_bf16.
 //
-// Same arithmetic and the same stage-image idea as bmu_bf16.hpp; only the MFMA shape (and so the
-// fragment geometry) differs.  On random data MI355X holds a higher clock on the 16x16x32 shape
-// than on 32x32x16 at equal cycles per flop (MI355X_MICROARCH.md, DVFS give-back item 7), and
-// this kernel is power/clock-limited, so the shape is a throughput lever by itself.
+// The arithmetic of bmu_bf16.hpp (d' = B + |w~|^2/2 - x~.w~, the norm term as the MFMA's initial accumulator) on a
+// stage image in MFMA fragment order.  On random data MI355X holds a higher clock on the 16x16x32 shape than on
+// 32x32x16 at equal cycles per flop (MI355X_MICROARCH.md, DVFS give-back item 7), and this kernel is
+// power/clock-limited, so the shape is a throughput lever by itself (round 1's 32x32x16 form: 11.9 -> 13.99 ms).
 //
 // Geometry: A = 16 units x 32 features (lane l: unit l&15, features 8*(l>>4)+j), B = 32 features x
 // 16 samples (lane l: sample l&15), C/D: lane holds sample l&15, units 4*(l>>4)+reg, reg 0..3.

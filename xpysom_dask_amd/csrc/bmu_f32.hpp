@@ -74,110 +74,6 @@ __device__ __forceinline__ void f32_tile_argmin(const f32x16& acc, const f32x4 (
 
 __device__ __forceinline__ int f32_key_unit(int key, int half) { return (key >> 4) * 32 + mfma32_row(key & 15, half); }
 
-// X: [N][D] row-major f32.  W: [K][D] row-major f32.  wsq: [K].  xsq: [N] (unused for MODE 0).
-// x_resident != 0: the workgroup's whole sample block stays in LDS (needs SB*(Dp+1)*4 bytes).
-template <int MODE, bool TOP2 = false>
-__global__ __launch_bounds__(256) void bmu_f32_kernel(const float* __restrict__ X, long N, int D, int Dp,
-                                                      const float* __restrict__ W, const float* __restrict__ wsq,
-                                                      int K, const float* __restrict__ xsq, int x_resident,
-                                                      int* __restrict__ out, int* __restrict__ out2) {
-    extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    float* Ws = smem_f;                                // [UB][KC+1]
-    float* wq = Ws + F32_UB * (F32_KC + 1);            // [UB]
-    float* Xs = wq + F32_UB;                           // [SB][xw+1]
-    const int xstride = (x_resident ? Dp : F32_KC) + 1;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int half = lane >> 5, col = lane & 31;
-    const long s0 = (long)blockIdx.x * F32_SB;
-    const long my_sample = s0 + wave * 32 + col;
-
-    float best = __builtin_inff(), sec = __builtin_inff();
-    int bidx = 0, sidx = 0;
-    float xs = 0.0f;
-    if (MODE != SCORE_EUCLID_PART) xs = (my_sample < N) ? xsq[my_sample] : 0.0f;
-
-    if (x_resident) {
-        for (int idx = tid; idx < F32_SB * Dp; idx += 256) {
-            int r = idx / Dp, k = idx - r * Dp;
-            float v = 0.0f;
-            if (s0 + r < N && k < D) v = X[(s0 + r) * (long)D + k];
-            Xs[r * xstride + k] = v;
-        }
-    }
-
-    for (int u0 = 0; u0 < K; u0 += F32_UB) {
-        f32x16 acc[4];
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
-
-        for (int kc = 0; kc < Dp; kc += F32_KC) {
-            __syncthreads();
-            for (int idx = tid; idx < F32_UB * F32_KC; idx += 256) {
-                int r = idx >> 5, k = idx & 31;
-                float v = 0.0f;
-                if (u0 + r < K && kc + k < D) v = W[(long)(u0 + r) * D + kc + k];
-                Ws[r * (F32_KC + 1) + k] = v;
-            }
-            if (kc == 0 && tid < F32_UB) wq[tid] = (u0 + tid < K) ? wsq[u0 + tid] : __builtin_inff();
-            if (!x_resident) {
-                for (int idx = tid; idx < F32_SB * F32_KC; idx += 256) {
-                    int r = idx >> 5, k = idx & 31;
-                    float v = 0.0f;
-                    if (s0 + r < N && kc + k < D) v = X[(s0 + r) * (long)D + kc + k];
-                    Xs[r * xstride + k] = v;
-                }
-            }
-            __syncthreads();
-            const float* xrow = Xs + (wave * 32 + col) * xstride + (x_resident ? kc : 0) + half;
-            const float* wrow = Ws + col * (F32_KC + 1) + half;
-#pragma unroll
-            for (int k = 0; k < F32_KC; k += 2) {
-                float b = xrow[k];
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb) {
-                    float a = wrow[rb * 32 * (F32_KC + 1) + k];
-                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[rb], 0, 0, 0);
-                }
-            }
-        }
-        // epilogue: units ascend with (rb, r) for a fixed lane half, '<' keeps the first minimum
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = rb * 32 + mfma32_row(r, half);
-                int u = u0 + row;
-                float v = score_f32<MODE>(acc[rb][r], wq[row], xs);
-                if (TOP2) {
-                    if (u < K && v < sec) {
-                        if (v < best) { sec = best; sidx = bidx; best = v; bidx = u; }
-                        else { sec = v; sidx = u; }
-                    }
-                } else if (u < K && v < best) { best = v; bidx = u; }
-            }
-        }
-    }
-    // join the two lane halves (same sample, disjoint units): smaller value, then smaller id
-    float ob = __shfl_xor(best, 32, 64);
-    int oi = __shfl_xor(bidx, 32, 64);
-    if (TOP2) {
-        float os = __shfl_xor(sec, 32, 64);
-        int osi = __shfl_xor(sidx, 32, 64);
-        const bool other_first = ob < best || (ob == best && oi < bidx);
-        int i1 = other_first ? oi : bidx;
-        float c1 = other_first ? best : ob;  int j1 = other_first ? bidx : oi;
-        float c2 = other_first ? os : sec;   int j2 = other_first ? osi : sidx;
-        const bool take_c1 = c1 < c2 || (c1 == c2 && j1 < j2);
-        if (half == 0 && my_sample < N) { out[my_sample] = i1; out2[my_sample] = take_c1 ? j1 : j2; }
-    } else {
-        if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-        if (half == 0 && my_sample < N) out[my_sample] = bidx;
-    }
-}
-
 // The (n, K) distance matrix itself, for the analysis calls that return it: XPySom.activate
 // (xpysom.py:323-354, configured distance) and distance_from_weights (:647-671, sqrt'd Euclidean).
 // Same tiling and the same bit-exact arithmetic as bmu_f32_kernel; the epilogue stores instead of

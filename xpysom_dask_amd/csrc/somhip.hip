@@ -19,7 +19,6 @@
 #include <vector>
 
 #include "../../include/somhip.h"
-#include "bmu_bf16.hpp"
 #include "bmu_bf16_k16.hpp"
 #include "bmu_bf16_tiled.hpp"
 #include "bmu_f32.hpp"
@@ -59,9 +58,7 @@ struct som_handle {
     hipStream_t comm_stream = nullptr;   // the blockwise all-reduce runs here, under the transform of the next block
     hipEvent_t ev_block = nullptr, ev_comm = nullptr;
     int X = 0, Y = 0, K = 0, D = 0, D1p = 0;
-    int ksteps = 0;          // bf16, 32x32x16 shape: ceil(D/16)
     int ks32 = 0;            // bf16, 16x16x32 shape: ceil(D/32)
-    bool shape16 = true;     // which MFMA shape the bf16 kernel uses
     bool tiled = false;      // bf16, input_len > 128 (and bf16x3 always): two-sided tiling (bmu_bf16_tiled.hpp)
     int x3 = 0;              // precision bf16x3: hi/lo split operands, tripled feature axis
     int n_kchunks = 0;       // tiled: 64-feature chunks
@@ -288,13 +285,6 @@ void launch_prep_w_k16(som_handle* h) {
         h->W, h->K, h->D, h->Wst, h->n_stages, h->cfg.distance == SOM_DIST_COSINE ? h->wsq : nullptr);
 }
 
-template <int KS>
-void launch_prep_w(som_handle* h) {
-    long total = (long)h->n_stages * BF_UT * KS * 64;
-    prep_w_bf16_kernel<KS><<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->Wst,
-                                                                                        h->n_stages);
-}
-
 void mark_codebook_changed(som_handle* h) { h->w_dirty = h->wsq_dirty = h->wf_dirty = true; }
 
 // need_f32: the caller is about to run a float32 kernel (parity-mode BMU, top-2, distance matrix).
@@ -338,24 +328,12 @@ int refresh_codebook_operands(som_handle* h, bool need_f32) {
         h->w_dirty = false;
         return 0;
     }
-    if (h->cfg.precision != SOM_PREC_F32 && h->shape16) {
+    if (h->cfg.precision != SOM_PREC_F32) {
         switch (h->ks32) {
         case 1: launch_prep_w_k16<1>(h); break;
         case 2: launch_prep_w_k16<2>(h); break;
         case 3: launch_prep_w_k16<3>(h); break;
         case 4: launch_prep_w_k16<4>(h); break;
-        default: return fail(h, "bf16 precision supports input_len <= 128");
-        }
-    } else if (h->cfg.precision != SOM_PREC_F32) {
-        switch (h->ksteps) {
-        case 1: launch_prep_w<1>(h); break;
-        case 2: launch_prep_w<2>(h); break;
-        case 3: launch_prep_w<3>(h); break;
-        case 4: launch_prep_w<4>(h); break;
-        case 5: launch_prep_w<5>(h); break;
-        case 6: launch_prep_w<6>(h); break;
-        case 7: launch_prep_w<7>(h); break;
-        case 8: launch_prep_w<8>(h); break;
         default: return fail(h, "bf16 precision supports input_len <= 128");
         }
     }
@@ -370,23 +348,6 @@ int refresh_codebook_operands(som_handle* h, bool need_f32) {
 }
 
 // ---- BMU launches ----------------------------------------------------------------------------
-template <int MODE, bool TOP2 = false>
-int launch_bmu_f32(som_handle* h, const float* X, long N, const float* xsq, int* out, int* out2 = nullptr) {
-    const int Dp = (int)round_up(h->D, F32_KC);
-    size_t base = (size_t)(F32_UB * (F32_KC + 1) + F32_UB) * sizeof(float);
-    size_t res = base + (size_t)F32_SB * (Dp + 1) * sizeof(float);
-    size_t chunked = base + (size_t)F32_SB * (F32_KC + 1) * sizeof(float);
-    int x_resident = res <= 150 * 1024;
-    size_t lds = x_resident ? res : chunked;
-    { int pc; if (int rc = kernel_per_cu(h, (const void*)bmu_f32_kernel<MODE, TOP2>, 256, lds, &pc)) return rc; }
-    long grid = cdiv(N, F32_SB);
-    if (grid <= 0 || grid > 0x7fffffffL) return fail(h, "bmu_f32: row count out of range");
-    bmu_f32_kernel<MODE, TOP2><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, N, h->D, Dp, h->W, h->wsq, h->K,
-                                                                                   xsq, x_resident, out, out2);
-    HIPCHK(h, hipGetLastError());
-    return 0;
-}
-
 int choose_parts(som_handle* h, long blocks, long slots, int max_parts_hint);
 
 template <int MODE, int KG, bool TOP2 = false>
@@ -450,7 +411,6 @@ int launch_bmu_f32_tiled(som_handle* h, const float* X, long N, const float* xsq
 template <int MODE>
 int launch_bmu_f32_any(som_handle* h, const float* X, long N, const float* xsq, int* out) {
     if (h->Wfimg) return launch_bmu_f32_tiled<MODE, false>(h, X, N, xsq, out, nullptr);   // input_len > 128
-    if (!h->Wfst) return launch_bmu_f32<MODE>(h, X, N, xsq, out);     // (SOM_F32_GENERIC) LDS-chunked kernel
     switch (h->fr_kg) {
     case 1: return launch_bmu_f32_res_kg<MODE, 1>(h, X, N, xsq, out);
     case 2: return launch_bmu_f32_res_kg<MODE, 2>(h, X, N, xsq, out);
@@ -465,7 +425,6 @@ int launch_bmu_f32_any(som_handle* h, const float* X, long N, const float* xsq, 
 int launch_bmu_top2(som_handle* h, const float* X, long N, const float* xsq, int* out, int* out2) {
     constexpr int M = SCORE_EUCLID_SQRT;
     if (h->Wfimg) return launch_bmu_f32_tiled<M, true>(h, X, N, xsq, out, out2);
-    if (!h->Wfst) return launch_bmu_f32<M, true>(h, X, N, xsq, out, out2);
     switch (h->fr_kg) {
     case 1: return launch_bmu_f32_res_kg<M, 1, true>(h, X, N, xsq, out, out2);
     case 2: return launch_bmu_f32_res_kg<M, 2, true>(h, X, N, xsq, out, out2);
@@ -474,17 +433,6 @@ int launch_bmu_top2(som_handle* h, const float* X, long N, const float* xsq, int
     case 16: return launch_bmu_f32_res_kg<M, 16, true>(h, X, N, xsq, out, out2);
     }
     return fail(h, "bmu_f32: bad k-group count");
-}
-
-template <int KS>
-int launch_bmu_bf16_ks(som_handle* h, const __bf16* Xb, long N, int* out) {
-    size_t lds = 2 * (size_t)bf_stage_bytes(KS);
-    { int pc; if (int rc = kernel_per_cu(h, (const void*)bmu_bf16_kernel<KS>, 256, lds, &pc)) return rc; }
-    long grid = cdiv(N, BF_WG_SAMPLES);
-    if (grid <= 0 || grid > 0x7fffffffL) return fail(h, "bmu_bf16: row count out of range");
-    bmu_bf16_kernel<KS><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(Xb, N, h->Wst, h->n_stages, h->K, out);
-    HIPCHK(h, hipGetLastError());
-    return 0;
 }
 
 // Number of codebook parts the scan is split into: fill whole rounds of the resident workgroup
@@ -577,36 +525,19 @@ int launch_bmu_bf16(som_handle* h, const __bf16* Xb, const float* xmax2, long N,
     // the stage image's initial accumulators depend on the row set through B = xmax * wmax; the same launch
     // resets the per-row merge keys of the 16x16x32 kernel
     long units = (long)h->n_stages * h->stage_units;
-    unsigned long long* init64 = nullptr;
-    if (h->shape16) {
-        if (N > h->best64_cap) {
-            (void)hipFree(h->best64);
-            h->best64 = nullptr; h->best64_cap = 0;
-            if (int rc = dev_alloc(h, &h->best64, (size_t)round_up(N, 1024))) return rc;
-            h->best64_cap = round_up(N, 1024);
-        }
-        init64 = h->best64;
+    if (N > h->best64_cap) {
+        (void)hipFree(h->best64);
+        h->best64 = nullptr; h->best64_cap = 0;
+        if (int rc = dev_alloc(h, &h->best64, (size_t)round_up(N, 1024))) return rc;
+        h->best64_cap = round_up(N, 1024);
     }
-    prep_wsqh_kernel<<<dim3((unsigned)cdiv(init64 ? std::max(units, N) : units, 256)), dim3(256), 0, h->stream>>>(
-        h->wn, h->K, h->wmax2, xmax2, h->Wst, h->n_stages, h->stage_bytes, h->stage_units, init64, N);
-    if (h->shape16) {
-        switch (h->ks32) {
-        case 1: return launch_bmu_bf16_k16<1>(h, Xb, N, out);
-        case 2: return launch_bmu_bf16_k16<2>(h, Xb, N, out);
-        case 3: return launch_bmu_bf16_k16<3>(h, Xb, N, out);
-        case 4: return launch_bmu_bf16_k16<4>(h, Xb, N, out);
-        }
-        return fail(h, "bf16 precision supports input_len <= 128");
-    }
-    switch (h->ksteps) {
-    case 1: return launch_bmu_bf16_ks<1>(h, Xb, N, out);
-    case 2: return launch_bmu_bf16_ks<2>(h, Xb, N, out);
-    case 3: return launch_bmu_bf16_ks<3>(h, Xb, N, out);
-    case 4: return launch_bmu_bf16_ks<4>(h, Xb, N, out);
-    case 5: return launch_bmu_bf16_ks<5>(h, Xb, N, out);
-    case 6: return launch_bmu_bf16_ks<6>(h, Xb, N, out);
-    case 7: return launch_bmu_bf16_ks<7>(h, Xb, N, out);
-    case 8: return launch_bmu_bf16_ks<8>(h, Xb, N, out);
+    prep_wsqh_kernel<<<dim3((unsigned)cdiv(std::max(units, N), 256)), dim3(256), 0, h->stream>>>(
+        h->wn, h->K, h->wmax2, xmax2, h->Wst, h->n_stages, h->stage_bytes, h->stage_units, h->best64, N);
+    switch (h->ks32) {
+    case 1: return launch_bmu_bf16_k16<1>(h, Xb, N, out);
+    case 2: return launch_bmu_bf16_k16<2>(h, Xb, N, out);
+    case 3: return launch_bmu_bf16_k16<3>(h, Xb, N, out);
+    case 4: return launch_bmu_bf16_k16<4>(h, Xb, N, out);
     }
     return fail(h, "bf16 precision supports input_len <= 128");
 }
@@ -996,8 +927,6 @@ int som_create(const som_config* cfg, som_handle** out) {
         if (cfg->distance == SOM_DIST_EUCLIDEAN_NO_OPT)
             return fail(nullptr, "som_create: bf16 precision implements 'euclidean' and 'cosine' "
                                  "('euclidean_no_opt' has the same argmin as 'euclidean')");
-        if (cfg->distance == SOM_DIST_COSINE && std::getenv("SOM_BF16_SHAPE") && std::atoi(std::getenv("SOM_BF16_SHAPE")) == 32)
-            return fail(nullptr, "som_create: cosine in bf16 needs the default 16x16x32 kernel");
     }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -1009,12 +938,7 @@ int som_create(const som_config* cfg, som_handle** out) {
     h->X = cfg->x; h->Y = cfg->y; h->K = cfg->x * cfg->y; h->D = cfg->input_len;
     h->D1p = (int)round_up(h->D + 1, 4);
     h->norm_p = cfg->norm_p > 0 ? cfg->norm_p : 2;
-    h->ksteps = (int)cdiv(h->D, 16);
     h->ks32 = (int)cdiv(h->D, 32);
-    {   // SOM_BF16_SHAPE=32 selects the 32x32x16 kernel (A/B against the default 16x16x32)
-        const char* e = std::getenv("SOM_BF16_SHAPE");
-        h->shape16 = !(e && std::atoi(e) == 32);
-    }
     h->x3 = cfg->precision == SOM_PREC_BF16X3;
     h->tiled = (cfg->precision == SOM_PREC_BF16 && h->D > 128) || h->x3;
     if (h->tiled) {
@@ -1031,9 +955,9 @@ int som_create(const som_config* cfg, som_handle** out) {
         h->n_kchunks = (int)cdiv(h->x3 ? 3L * h->D : (long)h->D, TL_BK);
         h->n_ublocks = (int)cdiv(h->K, h->tl_bn);
     }
-    h->dp = h->tiled ? TL_BK * h->n_kchunks : h->shape16 ? 32 * h->ks32 : 16 * h->ksteps;
-    h->stage_bytes = h->shape16 ? k16_stage_bytes(h->ks32) : bf_stage_bytes(h->ksteps);
-    h->stage_units = h->shape16 ? K16_STAGE_UNITS : BF_STAGE_UNITS;
+    h->dp = h->tiled ? TL_BK * h->n_kchunks : 32 * h->ks32;
+    h->stage_bytes = k16_stage_bytes(h->ks32);
+    h->stage_units = K16_STAGE_UNITS;
     h->nt = cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT ? (cfg->compact_support ? 4 : 2) : 1;
     h->swapped = cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT && cfg->compact_support && cfg->topology == SOM_TOPO_RECTANGULAR;
     if (cfg->topology == SOM_TOPO_HEXAGONAL && cfg->neighborhood != SOM_NEIGH_BUBBLE) h->nt *= 3;
@@ -1084,12 +1008,12 @@ int som_create(const som_config* cfg, som_handle** out) {
     if (hipMemsetAsync(h->W, 0, (size_t)h->K * h->D * sizeof(float), h->stream) != hipSuccess ||
         hipMemsetAsync(h->ACC, 0, KD1 * sizeof(float), h->stream) != hipSuccess)
         return bail(fail(h, "hipMemsetAsync failed"));
-    if (h->D > 128 && !std::getenv("SOM_F32_GENERIC")) {
+    if (h->D > 128) {
         h->ft_kchunks = (int)cdiv(h->D, FT_BK);
         h->ft_ublocks = (int)cdiv(h->K, FT_BN);
         if ((rc = dev_alloc(h, &h->Wfimg, (size_t)h->ft_ublocks * h->ft_kchunks * FT_WTILE))) return bail(rc);
     }
-    if (h->D <= 128 && !std::getenv("SOM_F32_GENERIC")) {
+    if (h->D <= 128) {
         int kg = 1;
         while (kg * 8 < h->D) kg *= 2;                      // 8, 16, 32, 64 or 128 features per row image
         h->fr_kg = kg;
@@ -1436,7 +1360,7 @@ int som_epoch_merge(som_handle* h) {
     if (!h) return 1;
     Timed t(h, SOM_K_MERGE);
     // the headline path (bf16, input_len <= 128, euclidean): the merge also writes the next epoch's bf16 operands
-    if (h->cfg.precision == SOM_PREC_BF16 && !h->tiled && h->shape16 && h->cfg.distance == SOM_DIST_EUCLIDEAN &&
+    if (h->cfg.precision == SOM_PREC_BF16 && !h->tiled && h->cfg.distance == SOM_DIST_EUCLIDEAN &&
         h->fuse_merge_prep) {
         HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
         const long n_tiles = (long)h->n_stages * K16_T;
