@@ -3,12 +3,13 @@
 // The arithmetic of bmu_bf16.hpp (d' = B + |w~|^2/2 - x~.w~, the norm term as the MFMA's initial accumulator) on a
 // stage image in MFMA fragment order.  On random data MI355X holds a higher clock on the 16x16x32 shape than on
 // 32x32x16 at equal cycles per flop (MI355X_MICROARCH.md, DVFS give-back item 7), and this kernel is
-// power/clock-limited, so the shape is a throughput lever by itself (round 1's 32x32x16 form: 11.9 -> 13.99 ms).
+// power/clock-limited, so the shape is a throughput lever by itself (round 1's 32x32x16 form took 13.99 ms where this one took 11.88).
 //
 // Geometry: A = 16 units x 32 features (lane l: unit l&15, features 8*(l>>4)+j), B = 32 features x
 // 16 samples (lane l: sample l&15), C/D: lane holds sample l&15, units 4*(l>>4)+reg, reg 0..3.
 // A wave keeps 4 x 16 samples' B fragments in registers; one A fragment read from LDS feeds 4 MFMAs.
-// Stage image (128 units): [t16 0..7][kstep32][lane 0..63][8 bf16 of -w~] + [128 x f32 B+|w~|^2/2].
+// Stage image (K16_STAGE_UNITS = 64 units): [t16 0..3][kstep32][lane 0..63][8 bf16 of -w~] + [64 x f32 B+|w~|^2/2]
+// (+ pad to 1 KiB).
 // Key = (bits & ~mask) | (t16<<2 | reg).
 //
 // Grid = (sample blocks) x (codebook parts): a workgroup scans only its part of the stages and
