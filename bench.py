@@ -285,6 +285,32 @@ def main():
                  "frac": b_ach / peak, "epoch_ms": 1e3 * tb / reps,
                  "ms_per_epoch_by_kernel": {k: eng.profile_get(k)[0] / reps for k in ("prep", "bmu", "segsum", "kron", "merge")}}
 
+    # the other precision modes on the same batch, so that the parity mode has a number from this very run
+    modes = None
+    if batch is not None and args.precision == "bf16" and FEATURES <= 128:
+        modes = {}
+        for prec, flop_peak in (("f32", MFMA_F32_PEAK_TFLOPS), ("bf16x3", MFMA_BF16_PEAK_TFLOPS)):
+            e2 = HipEngine(MAP_X, MAP_Y, FEATURES, precision=prec, device=dev, distance=wl["distance"],
+                           neighborhood=wl["neighborhood"])
+            e2.set_weights(w)
+            e2.set_data(rows_host[:NORTH_STAR_BATCH])
+            D.epoch(e2, sched[0][0], sched[0][1], True)
+            e2.sync()
+            e2.profile_reset()
+            e2.profile_enable(True)
+            t2 = time.perf_counter()
+            for t in range(3):
+                D.epoch(e2, sched[t % total][0], sched[t % total][1], True)
+            e2.sync()
+            t2 = (time.perf_counter() - t2) / 3
+            e2.profile_enable(False)
+            m_ms, m_n = e2.profile_get("bmu")
+            ach = KD2 * NORTH_STAR_BATCH / (m_ms / max(1, m_n) * 1e-3) / 1e12
+            modes[prec] = {"rows": NORTH_STAR_BATCH, "epoch_ms": 1e3 * t2, "bmu_launch_ms": m_ms / max(1, m_n),
+                           "achieved_tflops_algorithmic": ach, "frac_of_its_pipe_peak": ach / flop_peak,
+                           "kernel": kernel_name_for(prec, FEATURES)}
+            e2.close()
+
     if rank == 0:
         ms_step = 1e3 * dt / args.steps
         flops_launch = KD2 * my_rows
@@ -320,6 +346,8 @@ def main():
         }
         if batch is not None:
             out["roofline"]["batch65536"] = batch
+        if modes is not None:
+            out["precision_modes_at_batch65536"] = modes   # 'f32' = the parity mode (bit-exact float32 chain), 'bf16x3' = hi/lo split
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
