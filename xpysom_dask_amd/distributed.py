@@ -119,8 +119,10 @@ def _native_comm(engine, rank, world):
         return
     ids = [engine.comm_unique_id() if rank == 0 else None]
     if world > 1:
+        import torch
         import torch.distributed as dist
-        dist.broadcast_object_list(ids, src=0)
+        dev = torch.device("cuda", engine.device) if dist.get_backend() == "nccl" else None   # this rank's GPU, not cuda:0
+        dist.broadcast_object_list(ids, src=0, device=dev)
     engine.comm_init(world, rank, ids[0])
 
 
