@@ -20,6 +20,7 @@
 
 #include "../../include/somhip.h"
 #include "bmu_bf16_k16.hpp"
+#include "bmu_bf16_k16x3.hpp"
 #include "bmu_bf16_tiled.hpp"
 #include "bmu_f32.hpp"
 #include "bmu_f32_res.hpp"
@@ -61,6 +62,7 @@ struct som_handle {
     int ks32 = 0;            // bf16, 16x16x32 shape: ceil(D/32)
     bool tiled = false;      // bf16, input_len > 128 (and bf16x3 always): two-sided tiling (bmu_bf16_tiled.hpp)
     int x3 = 0;              // precision bf16x3: hi/lo split operands, tripled feature axis
+    bool x3res = false;      // bf16x3 with input_len <= 128: the register-resident split kernel (bmu_bf16_k16x3.hpp)
     int n_kchunks = 0;       // tiled: 64-feature chunks
     int n_ublocks = 0;       // tiled: unit blocks of tl_bn
     bool tl_big = false;     // tiled: 256 x 256 workgroup tiles (8 waves) instead of 128 x 128
@@ -328,6 +330,24 @@ int refresh_codebook_operands(som_handle* h, bool need_f32) {
         h->w_dirty = false;
         return 0;
     }
+    if (h->x3res) {
+        const float* unit = h->cfg.distance == SOM_DIST_COSINE ? h->wsq : nullptr;
+        const long total = (long)h->n_stages * 2 * K3_T * h->ks32 * 64;
+        const dim3 grid((unsigned)cdiv(total, 256)), block(256);
+        switch (h->ks32) {
+        case 1: prep_w_bf16_k16x3_kernel<1><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
+        case 2: prep_w_bf16_k16x3_kernel<2><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
+        case 3: prep_w_bf16_k16x3_kernel<3><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
+        case 4: prep_w_bf16_k16x3_kernel<4><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
+        default: return fail(h, "bf16x3 resident kernel supports input_len <= 128");
+        }
+        HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
+        rownorm_bf16_kernel<<<dim3((unsigned)cdiv(h->K, 4)), dim3(256), 0, h->stream>>>(   // exact float32 |w|^2
+            h->W, h->K, h->D, unit, unit != nullptr, h->wn, h->wmax2, 1);
+        HIPCHK(h, hipGetLastError());
+        h->w_dirty = false;
+        return 0;
+    }
     if (h->cfg.precision != SOM_PREC_F32) {
         switch (h->ks32) {
         case 1: launch_prep_w_k16<1>(h); break;
@@ -481,6 +501,27 @@ int launch_bmu_bf16_k16(som_handle* h, const __bf16* Xb, long N, int* out) {
     return 0;
 }
 
+template <int KS32>
+int launch_bmu_bf16_k16x3(som_handle* h, const __bf16* Xb, long N, int* out) {
+    size_t lds = 2 * (size_t)k3_stage_bytes(KS32);
+    int per_cu = 1;
+    if (int rc = kernel_per_cu(h, (const void*)bmu_bf16_k16x3_kernel<KS32>, 64 * K3_NW, lds, &per_cu)) return rc;
+    long blocks = cdiv(N, K3_WG_SAMPLES);
+    if (blocks <= 0 || blocks > 0x7fffffffL) return fail(h, "bmu_bf16x3: row count out of range");
+    const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
+    int parts = choose_parts(h, blocks, slots, h->n_stages);
+    if (h->env_bf16_parts > 0) parts = std::min(h->env_bf16_parts, h->n_stages);
+    if (h->debug)
+        std::fprintf(stderr, "[somhip] bmu_bf16_k16x3: blocks=%ld per_cu=%d slots=%ld parts=%d stages=%d\n", blocks, per_cu, slots,
+                     parts, h->n_stages);
+    // (best64[0..N) was reset by prep_wsqh_kernel, launch_bmu_bf16)
+    bmu_bf16_k16x3_kernel<KS32><<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * K3_NW), lds, h->stream>>>(
+        Xb, N, h->Wst, h->n_stages, h->K, h->best64);
+    bmu_finalize_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(h->best64, N, h->K, out);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 template <int WS, int NWR, int NWC>
 int launch_bmu_bf16_tiled_cfg(som_handle* h, const __bf16* Ximg, long N, int* out) {
     using C = TileCfg<WS, NWR, NWC>;
@@ -533,6 +574,15 @@ int launch_bmu_bf16(som_handle* h, const __bf16* Xb, const float* xmax2, long N,
     }
     prep_wsqh_kernel<<<dim3((unsigned)cdiv(std::max(units, N), 256)), dim3(256), 0, h->stream>>>(
         h->wn, h->K, h->wmax2, xmax2, h->Wst, h->n_stages, h->stage_bytes, h->stage_units, h->best64, N);
+    if (h->x3res) {
+        switch (h->ks32) {
+        case 1: return launch_bmu_bf16_k16x3<1>(h, Xb, N, out);
+        case 2: return launch_bmu_bf16_k16x3<2>(h, Xb, N, out);
+        case 3: return launch_bmu_bf16_k16x3<3>(h, Xb, N, out);
+        case 4: return launch_bmu_bf16_k16x3<4>(h, Xb, N, out);
+        }
+        return fail(h, "bf16x3 resident kernel supports input_len <= 128");
+    }
     switch (h->ks32) {
     case 1: return launch_bmu_bf16_k16<1>(h, Xb, N, out);
     case 2: return launch_bmu_bf16_k16<2>(h, Xb, N, out);
@@ -566,7 +616,11 @@ int prep_rows_bf16(som_handle* h, const float* X, long N, long Np, __bf16* Xb, f
         HIPCHK(h, hipGetLastError());
         return 0;
     }
-    prep_x_bf16_kernel<<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, Dp, Np, Xb, xmax2, unit ? 1 : 0);
+    if (h->x3res)
+        prep_x_bf16x3_kernel<<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, 32 * h->ks32, Np, Xb, xmax2,
+                                                                                       unit ? 1 : 0);
+    else
+        prep_x_bf16_kernel<<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, Dp, Np, Xb, xmax2, unit ? 1 : 0);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -940,7 +994,9 @@ int som_create(const som_config* cfg, som_handle** out) {
     h->norm_p = cfg->norm_p > 0 ? cfg->norm_p : 2;
     h->ks32 = (int)cdiv(h->D, 32);
     h->x3 = cfg->precision == SOM_PREC_BF16X3;
-    h->tiled = (cfg->precision == SOM_PREC_BF16 && h->D > 128) || h->x3;
+    h->x3res = h->x3 && h->D <= 128;
+    if (const char* e = std::getenv("SOM_X3_TILED")) if (std::atoi(e) != 0) h->x3res = false;   // A/B: the tiled split kernel
+    h->tiled = (cfg->precision == SOM_PREC_BF16 && h->D > 128) || (h->x3 && !h->x3res);
     if (h->tiled) {
         // 256 x 256 tiles need enough units to amortise them; SOM_BF16_TILE=128|256 overrides
         h->tl_big = h->K >= 4096;
@@ -955,9 +1011,9 @@ int som_create(const som_config* cfg, som_handle** out) {
         h->n_kchunks = (int)cdiv(h->x3 ? 3L * h->D : (long)h->D, TL_BK);
         h->n_ublocks = (int)cdiv(h->K, h->tl_bn);
     }
-    h->dp = h->tiled ? TL_BK * h->n_kchunks : 32 * h->ks32;
-    h->stage_bytes = k16_stage_bytes(h->ks32);
-    h->stage_units = K16_STAGE_UNITS;
+    h->dp = h->tiled ? TL_BK * h->n_kchunks : h->x3res ? 2 * 32 * h->ks32 : 32 * h->ks32;
+    h->stage_bytes = h->x3res ? k3_stage_bytes(h->ks32) : k16_stage_bytes(h->ks32);
+    h->stage_units = h->x3res ? K3_STAGE_UNITS : K16_STAGE_UNITS;
     h->nt = cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT ? (cfg->compact_support ? 4 : 2) : 1;
     h->swapped = cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT && cfg->compact_support && cfg->topology == SOM_TOPO_RECTANGULAR;
     if (cfg->topology == SOM_TOPO_HEXAGONAL && cfg->neighborhood != SOM_NEIGH_BUBBLE) h->nt *= 3;
