@@ -18,9 +18,15 @@
 
 namespace somhip {
 
-constexpr int K3_T = 2;               // 16-unit tiles per stage
+#ifndef SOM_K3_T
+#define SOM_K3_T 2
+#endif
+#ifndef SOM_K3_SB
+#define SOM_K3_SB 2
+#endif
+constexpr int K3_T = SOM_K3_T;        // 16-unit tiles per stage
 constexpr int K3_STAGE_UNITS = 16 * K3_T;
-constexpr int K3_SB = 2;              // 16-sample blocks per wave (hi + lo fragments: 64 VGPRs at 128 features)
+constexpr int K3_SB = SOM_K3_SB;      // 16-sample blocks per wave (hi + lo fragments: 64 VGPRs at 128 features)
 constexpr int K3_NW = 4;              // waves per workgroup
 constexpr int K3_WG_SAMPLES = K3_NW * 16 * K3_SB;
 
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(64 * K3_NW, 2) void bmu_bf16_k16x3_kernel(const __b
     constexpr int STAGE = k3_stage_bytes(KS32);
     constexpr int PIECES = 2 * K3_T * KS32 + 1;
     constexpr int LO = K3_T * KS32 * 1024;               // byte offset of the lo fragments inside a stage
-    constexpr uint32_t IDX_MASK = 4 * K3_T - 1;
+    constexpr uint32_t IDX_MASK = K3_T <= 2 ? 7u : 15u;   // (tile16 << 2 | reg) in the low mantissa bits
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
