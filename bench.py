@@ -69,11 +69,15 @@ def workload_rows(name, n, seed):
     return out
 
 
-def kernel_name_for(precision, features):
+def kernel_name_for(precision, features, units=1 << 16):
+    """The BMU kernel som_create selects (csrc/somhip.hip)."""
     if precision == "f32":
         return "bmu_f32_tiled_kernel" if features > 128 else "bmu_f32_res_kernel"
-    if precision == "bf16x3" or features > 128:
-        return "bmu_bf16_tiled_kernel"
+    if precision == "bf16x3":
+        return "bmu_bf16_tiled_kernel" if features > 128 else "bmu_bf16_k16x3_kernel"
+    if features > 128:
+        wide = units >= 4096 and features <= 800 and os.environ.get("SOM_BF16_WIDE", "1") != "0"
+        return "bmu_bf16_wide_kernel" if wide else "bmu_bf16_tiled_kernel"
     return "bmu_bf16_k16_kernel"
 
 
@@ -257,7 +261,7 @@ def main():
     w_end = eng.get_weights()
     assert np.isfinite(w_end).all()
 
-    kernel_name = kernel_name_for(args.precision, FEATURES)
+    kernel_name = kernel_name_for(args.precision, FEATURES, MAP_X * MAP_Y)
     peak = MFMA_F32_PEAK_TFLOPS if args.precision == "f32" else MFMA_BF16_PEAK_TFLOPS
     KD2 = 2.0 * (MAP_X * MAP_Y) * FEATURES            # 2*K*D flop per sample
 
@@ -308,7 +312,7 @@ def main():
             ach = KD2 * NORTH_STAR_BATCH / (m_ms / max(1, m_n) * 1e-3) / 1e12
             modes[prec] = {"rows": NORTH_STAR_BATCH, "epoch_ms": 1e3 * t2, "bmu_launch_ms": m_ms / max(1, m_n),
                            "achieved_tflops_algorithmic": ach, "frac_of_its_pipe_peak": ach / flop_peak,
-                           "kernel": kernel_name_for(prec, FEATURES)}
+                           "kernel": kernel_name_for(prec, FEATURES, MAP_X * MAP_Y)}
             e2.close()
 
     if rank == 0:

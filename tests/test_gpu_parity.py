@@ -913,12 +913,15 @@ def test_epoch_graph_replay_matches_eager_launches(monkeypatch):
 # ----------------------------------------------------------------------------- tiled kernel: schedule races
 @pytest.mark.parametrize("X,Y,D,n,precision", [(64, 64, 784, 5000, "bf16"), (100, 90, 257, 7000, "bf16"),
                                                (256, 256, 128, 20000, "bf16x3"), (2, 2, 129, 257, "bf16"),
-                                               (256, 16, 640, 3333, "bf16")])
+                                               (256, 16, 640, 3333, "bf16"), (64, 64, 900, 3000, "bf16"),
+                                               (64, 70, 150, 2500, "bf16x3"), (30, 30, 300, 1000, "bf16")])
 def test_tiled_kernel_is_repeatable_and_near_best(X, Y, D, n, precision):
     """bmu_bf16_tiled_kernel runs two wave groups one barrier apart over a 4-slot LDS-DMA ring with
-    counted vmcnt waits.  A mis-ordered read or refill would show up as run-to-run differences or as
-    picks outside the operand-rounding bound, so: six launches agree bit for bit, the resident-row
-    path (different padding and grid) agrees with the query path, and every pick is near-best."""
+    counted vmcnt waits; bmu_bf16_wide_kernel (bf16, 128 < input_len <= 800, maps of >= 4096 units: the
+    first, second and fifth case) refills a 3-slot ring behind one barrier per stage.  A mis-ordered read
+    or refill would show up as run-to-run differences or as picks outside the operand-rounding bound, so:
+    six launches agree bit for bit, the resident-row path (different padding and grid) agrees with the
+    query path, and every pick is near-best."""
     rs = np.random.RandomState(n)
     data = O.gaussian_blobs(n, D, seed=n % 97)
     w = (rs.rand(X, Y, D) * 2 - 1).astype(F32) * 2
@@ -935,6 +938,45 @@ def test_tiled_kernel_is_repeatable_and_near_best(X, Y, D, n, precision):
     dd = np.sqrt(np.maximum((x64 ** 2).sum(1)[:, None] - 2 * x64 @ w64.T + (w64 ** 2).sum(1)[None, :], 0))
     slack = (2.0 ** -8 if precision == "bf16" else 2.0 ** -15) * (np.linalg.norm(x64, axis=1) + np.linalg.norm(w64, axis=1).max())
     assert (dd[np.arange(len(idx)), outs[0][idx]] <= dd.min(1) + slack).all()
+
+
+@pytest.mark.parametrize("X,Y,D,n,dist,parts", [(64, 64, 129, 1000, "euclidean", None), (64, 70, 200, 777, "cosine", None),
+                                                (70, 70, 257, 2049, "euclidean", "3"), (64, 64, 400, 1, "euclidean", None),
+                                                (80, 80, 784, 5001, "cosine", None), (64, 64, 800, 257, "euclidean", "7"),
+                                                (72, 64, 540, 256, "euclidean", None)])
+def test_wide_kernel_matches_tiled_kernel(monkeypatch, X, Y, D, n, dist, parts):
+    """The two bf16 kernels for input_len > 128 compute the same accumulation chain (same operand images, same
+    offset B, features in the same order): bmu_bf16_wide_kernel (samples resident in registers, the default on
+    maps of >= 4096 units up to 800 features) must pick what bmu_bf16_tiled_kernel (SOM_BF16_WIDE=0) picks,
+    except where two units tie inside the index bits the keys give up (3 of the wide kernel's mantissa
+    bits, 4 of the tiled kernel's), and every pick must be near-best.  Row counts off the 256-row block,
+    unit counts off the 32-unit stage, forced part counts."""
+    data = np.abs(O.gaussian_blobs(n, D, seed=D))
+    w = np.abs(O.default_codebook(X, Y, D, 4).astype(F32)) * 3
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SOM_BF16_WIDE", mode)
+        if parts and mode == "1":
+            monkeypatch.setenv("SOM_BF16_PARTS", parts)
+        else:
+            monkeypatch.delenv("SOM_BF16_PARTS", raising=False)
+        e = engine(X, Y, D, precision="bf16", distance=dist)
+        e.set_weights(w)
+        e.set_data(data)
+        e.epoch_accumulate(2.0, 0.3, True)
+        got[mode] = (e.epoch_fetch()[2].copy(), e.bmu(data[: min(n, 300)]).copy())
+        e.close()
+    assert np.array_equal(got["1"][0][: len(got["1"][1])], got["1"][1])
+    differ = np.flatnonzero(got["1"][0] != got["0"][0])
+    assert len(differ) <= max(1, n // 1000)
+    x64, w64 = data.astype(np.float64), w.reshape(-1, D).astype(np.float64)
+    if dist == "cosine":
+        x64 = x64 / np.linalg.norm(x64, axis=1, keepdims=True)
+        w64 = w64 / np.linalg.norm(w64, axis=1, keepdims=True)
+    idx = np.arange(n) if n <= 1500 else np.random.RandomState(0).choice(n, 1500, replace=False)
+    dd = np.sqrt(np.maximum((x64[idx] ** 2).sum(1)[:, None] - 2 * x64[idx] @ w64.T + (w64 ** 2).sum(1)[None, :], 0))
+    slack = 2.0 ** -8 * (np.linalg.norm(x64[idx], axis=1) + np.linalg.norm(w64, axis=1).max())
+    assert (dd[np.arange(len(idx)), got["1"][0][idx]] <= dd.min(1) + slack).all()
 
 
 # ----------------------------------------------------------------------------- banded transform

@@ -1,0 +1,170 @@
+// Fused distance + BMU argmin, bf16, 128 < input_len <= 800 with the SAMPLES resident in registers.
+//
+// The two-sided tiling of bmu_bf16_tiled.hpp stages both operands for every (unit block, feature chunk) and its
+// sample tiles miss the L2 once per pass (18 % of 845 GB staged per launch at 512x512x784: 12 % of the launch,
+// DESIGN.md 3.1a).  Here a workgroup keeps its 256 samples' B fragments in registers for the whole codebook scan, as
+// bmu_bf16_k16.hpp does up to 128 features, and only the codebook streams:
+//   * 8 waves (two per SIMD, 256 registers each); a wave holds 2 x 16 samples x KS32 feature chunks = 8 KS32 VGPRs of
+//     B fragments (200 at 784 features) and 2 unit tiles x 2 sample blocks of accumulators;
+//   * stage = 32 units in fragment order, [tile 0..1][chunk 0..KS32-1][lane][8 bf16 of -w~] + 32 initial accumulators
+//     (B + |w~|^2/2) in the stage's last KiB: (2 KS32 + 1) KiB, 51 KiB at 784 features; three ring slots;
+//   * one A fragment read from LDS feeds two MFMAs (128 B/clk/CU of LDS reads at full rate);
+//   * stage s+2 is issued (LDS-DMA) right after the barrier of stage s, into the slot stage s-1 was read from, and
+//     awaited (vmcnt(0)) before the barrier of stage s+1: a whole stage of MFMAs (3 200 cycles per SIMD) covers it;
+//   * every workgroup resident on the chip scans the same codebook part from the same stage at the same pace, so a
+//     stage misses the L2 once per XCD and the other 31 workgroups hit; the sample image is read once per part.
+// Arithmetic, offset B, key packing ((bits & ~mask) | (tile << 2 | reg)), part split and the 64-bit atomicMin merge
+// are those of bmu_bf16_k16.hpp; the sample operand is the tile image of bmu_bf16_tiled.hpp (256-row blocks).
+#pragma once
+#include "bmu_bf16.hpp"
+#include "bmu_bf16_tiled.hpp"
+
+namespace somhip {
+
+constexpr int WD_T = 2;                          // 16-unit tiles per stage
+constexpr int WD_STAGE_UNITS = 16 * WD_T;
+constexpr int WD_SB = 2;                         // 16-sample blocks per wave
+constexpr int WD_NW = 8;                         // waves per workgroup
+constexpr int WD_WG_SAMPLES = WD_NW * WD_SB * 16;
+constexpr int WD_SLOTS = 3;
+constexpr int WD_XTILE = (WD_WG_SAMPLES / 16) * 1024;   // bytes of one (256-row block, 32-feature chunk) sample tile
+static_assert(WD_WG_SAMPLES == TileCfg<8, 2, 4>::BM && WD_XTILE == TileCfg<8, 2, 4>::XTILE,
+              "the sample operand is the 256-row tile image of the tiled kernel");
+
+__host__ __device__ constexpr int wd_stage_bytes(int ks32) { return (WD_T * ks32 + 1) * 1024; }
+
+// codebook -> stage image (the initial accumulators are written by prep_wsqh_kernel: they depend on the row set)
+__global__ __launch_bounds__(256) void prep_w_bf16_wide_kernel(const float* __restrict__ W, int K, int D, int ks32,
+                                                               char* __restrict__ Wst, int n_stages,
+                                                               const float* __restrict__ unit_wsq) {
+    long id = (long)blockIdx.x * 256 + threadIdx.x;
+    long total = (long)n_stages * WD_T * ks32 * 64;
+    if (id >= total) return;
+    int lane = id & 63;
+    long t = id >> 6;
+    int ks = t % ks32; t /= ks32;
+    int t16 = t % WD_T;
+    long stage = t / WD_T;
+    long u = stage * WD_STAGE_UNITS + t16 * 16 + (lane & 15);
+    int k0 = ks * 32 + (lane >> 4) * 8;
+    float scale = 1.0f;                          // cosine: unit-length rows (prep_w_bf16_k16_kernel)
+    if (unit_wsq != nullptr && u < K) { float q = unit_wsq[u]; scale = q > 0.0f ? 1.0f / __builtin_sqrtf(q) : 0.0f; }
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float f = (u < K && k0 + j < D) ? W[u * D + k0 + j] * scale : 0.0f;
+        v[j] = (__bf16)(-f);
+    }
+    *(bf16x8*)(Wst + stage * wd_stage_bytes(ks32) + ((long)(t16 * ks32 + ks) * 64 + lane) * 16) = v;
+}
+
+template <int KS32>
+__global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* __restrict__ Ximg, long N,
+                                                                   const char* __restrict__ Wst, int n_stages,
+                                                                   unsigned long long* __restrict__ out64) {
+    constexpr int STAGE = wd_stage_bytes(KS32);
+    constexpr int PIECES = WD_T * KS32;                      // whole 1 KiB pieces; the C-in row follows them
+    constexpr int CIN_LANES = WD_STAGE_UNITS * 4 / 16;
+    constexpr uint32_t IDX_MASK = 4 * WD_T - 1;              // (tile << 2 | register) in the low mantissa bits
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int quad = lane >> 4, col = lane & 15;
+
+    // this workgroup's share of the codebook stages
+    const int s_begin = (int)((long)n_stages * blockIdx.y / gridDim.y);
+    const int s_end = (int)((long)n_stages * (blockIdx.y + 1) / gridDim.y);
+    if (s_begin >= s_end) return;                            // (whole workgroup: no barrier is left behind)
+
+    auto issue = [&](int s, int slot) {
+#if defined(SOM_WD_EXPERIMENT) && SOM_WD_EXPERIMENT == 1
+        s = s_begin + (s & 1);                               // TIMING EXPERIMENT ONLY (wrong results): every fetch an L2 hit
+#endif
+        const char* src = Wst + (long)s * STAGE + lane * 16;
+        char* dst = smem + slot * STAGE;
+        for (int p = wave; p < PIECES; p += WD_NW) lds_dma_16(src + p * 1024, dst + p * 1024);
+        if (wave == PIECES % WD_NW && lane < CIN_LANES) lds_dma_16(src + PIECES * 1024, dst + PIECES * 1024);
+    };
+    issue(s_begin, 0);
+    if (s_begin + 1 < s_end) issue(s_begin + 1, 1);
+
+    // the wave's samples: B fragments of 2 x 16 rows, every feature chunk
+    bf16x8 xf[WD_SB][KS32];
+    {
+        const char* xb = Ximg + (long)blockIdx.x * KS32 * WD_XTILE + ((wave * WD_SB) * 64 + lane) * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS32; ++ks)
+#pragma unroll
+            for (int sb = 0; sb < WD_SB; ++sb) xf[sb][ks] = *(const bf16x8*)(xb + (long)ks * WD_XTILE + sb * 1024);
+    }
+
+    uint32_t gbest[WD_SB];                                   // unsigned keys: a NaN of either sign never beats a finite d'
+    int gstage[WD_SB];
+#pragma unroll
+    for (int sb = 0; sb < WD_SB; ++sb) { gbest[sb] = 0xFFFFFFFFu; gstage[sb] = 0; }
+
+    int cslot = 0, islot = 2;
+    for (int s = s_begin; s < s_end; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of stage s+1 (first: of s, and its samples)
+        __builtin_amdgcn_s_barrier();                         // ... everybody's; and nobody reads stage s-1 any more
+        asm volatile("" ::: "memory");
+        if (s + 2 < s_end) issue(s + 2, islot);               // -> the slot stage s-1 was read from
+        const char* st = smem + cslot * STAGE;
+        const float* wq = (const float*)(st + PIECES * 1024);
+
+        f32x4 acc[WD_T][WD_SB];
+#pragma unroll
+        for (int t = 0; t < WD_T; ++t) {
+            const f32x4 c = *(const f32x4*)(wq + t * 16 + 4 * quad);
+#pragma unroll
+            for (int sb = 0; sb < WD_SB; ++sb) acc[t][sb] = c;
+        }
+        // (measured against this plain form, DESIGN.md 3.1a: fragment reads pinned five k-steps ahead of their MFMAs
+        //  across tile, stage and barrier boundaries with a deferred reduction -- 3 % slower: the kernel sits at the
+        //  chip's power limit, not on LDS latency)
+#pragma unroll
+        for (int ks = 0; ks < KS32; ++ks) {
+            bf16x8 a[WD_T];
+#pragma unroll
+            for (int t = 0; t < WD_T; ++t) a[t] = *(const bf16x8*)(st + ((t * KS32 + ks) * 64 + lane) * 16);
+#pragma unroll
+            for (int t = 0; t < WD_T; ++t)
+#pragma unroll
+                for (int sb = 0; sb < WD_SB; ++sb)
+                    acc[t][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], xf[sb][ks], acc[t][sb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int sb = 0; sb < WD_SB; ++sb) {
+            uint32_t c0 = 0xFFFFFFFFu, c1 = 0xFFFFFFFFu;
+#pragma unroll
+            for (int t = 0; t < WD_T; ++t) {
+                const uint32_t k0 = (__float_as_uint(acc[t][sb][0]) & ~IDX_MASK) | (uint32_t)(t * 4 + 0);
+                const uint32_t k1 = (__float_as_uint(acc[t][sb][1]) & ~IDX_MASK) | (uint32_t)(t * 4 + 1);
+                const uint32_t k2 = (__float_as_uint(acc[t][sb][2]) & ~IDX_MASK) | (uint32_t)(t * 4 + 2);
+                const uint32_t k3 = (__float_as_uint(acc[t][sb][3]) & ~IDX_MASK) | (uint32_t)(t * 4 + 3);
+                c0 = min(min(c0, k0), k1);
+                c1 = min(min(c1, k2), k3);
+            }
+            const uint32_t c = min(c0, c1);
+            if (c < gbest[sb]) { gbest[sb] = c; gstage[sb] = s; }
+        }
+        cslot = cslot == WD_SLOTS - 1 ? 0 : cslot + 1;
+        islot = islot == WD_SLOTS - 1 ? 0 : islot + 1;
+    }
+
+#pragma unroll
+    for (int sb = 0; sb < WD_SB; ++sb) {
+        const uint32_t code = gbest[sb] & IDX_MASK;
+        const uint32_t unit = (uint32_t)gstage[sb] * WD_STAGE_UNITS + (code >> 2) * 16 + quad * 4 + (code & 3);
+        unsigned long long comp = ((unsigned long long)(gbest[sb] & ~IDX_MASK) << 32) | unit;
+        unsigned long long o = __shfl_xor(comp, 16, 64);
+        if (o < comp) comp = o;
+        o = __shfl_xor(comp, 32, 64);
+        if (o < comp) comp = o;
+        const long row = (long)blockIdx.x * WD_WG_SAMPLES + (wave * WD_SB + sb) * 16 + col;
+        if (quad == 0 && row < N) atomicMin(out64 + row, comp);
+    }
+}
+
+}  // namespace somhip

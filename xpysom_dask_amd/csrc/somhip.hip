@@ -22,6 +22,7 @@
 #include "bmu_bf16_k16.hpp"
 #include "bmu_bf16_k16x3.hpp"
 #include "bmu_bf16_tiled.hpp"
+#include "bmu_bf16_wide.hpp"
 #include "bmu_f32.hpp"
 #include "bmu_f32_res.hpp"
 #include "bmu_f32_tiled.hpp"
@@ -66,6 +67,7 @@ struct som_handle {
     int n_kchunks = 0;       // tiled: 64-feature chunks
     int n_ublocks = 0;       // tiled: unit blocks of tl_bn
     bool tl_big = false;     // tiled: 256 x 256 workgroup tiles (8 waves) instead of 128 x 128
+    bool wide = false;       // bf16, 128 < input_len <= 800, big maps: samples resident in registers (bmu_bf16_wide.hpp)
     int tl_bm = 128, tl_bn = 128, tl_xtile = 0, tl_wfrag = 0, tl_wtile = 0;
     int dp = 0;              // feature stride of the bf16 row image
     int stage_bytes = 0;     // bytes of one codebook stage image
@@ -320,9 +322,15 @@ int refresh_codebook_operands(som_handle* h, bool need_f32) {
     }
     if (h->cfg.precision != SOM_PREC_F32 && h->tiled) {
         const float* unit = h->cfg.distance == SOM_DIST_COSINE ? h->wsq : nullptr;
-        long total = (long)h->n_ublocks * h->n_kchunks * (h->tl_bn / 16) * TL_KS * 64;
-        prep_tiles_bf16_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
-            h->W, h->K, h->D, h->n_kchunks, h->n_ublocks, h->tl_bn, h->tl_wtile, -1.0f, unit, h->Wst, h->x3 ? 2 : 0);
+        if (h->wide) {
+            long total = (long)h->n_stages * WD_T * h->n_kchunks * 64;
+            prep_w_bf16_wide_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
+                h->W, h->K, h->D, h->n_kchunks, h->Wst, h->n_stages, unit);
+        } else {
+            long total = (long)h->n_ublocks * h->n_kchunks * (h->tl_bn / 16) * TL_KS * 64;
+            prep_tiles_bf16_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
+                h->W, h->K, h->D, h->n_kchunks, h->n_ublocks, h->tl_bn, h->tl_wtile, -1.0f, unit, h->Wst, h->x3 ? 2 : 0);
+        }
         HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
         rownorm_bf16_kernel<<<dim3((unsigned)cdiv(h->K, 4)), dim3(256), 0, h->stream>>>(
             h->W, h->K, h->D, unit, unit != nullptr, h->wn, h->wmax2, h->x3);
@@ -553,7 +561,60 @@ int launch_bmu_bf16_tiled_cfg(som_handle* h, const __bf16* Ximg, long N, int* ou
     return 0;
 }
 
+template <int KS32>
+int launch_bmu_bf16_wide(som_handle* h, const __bf16* Ximg, const float* xmax2, long N, int* out) {
+    auto kern = bmu_bf16_wide_kernel<KS32>;
+    const size_t lds = (size_t)WD_SLOTS * wd_stage_bytes(KS32);
+    int per_cu = 1;
+    if (int rc = kernel_per_cu(h, (const void*)kern, 64 * WD_NW, lds, &per_cu)) return rc;
+    const long blocks = cdiv(N, WD_WG_SAMPLES);
+    if (blocks <= 0 || blocks > 0x7fffffffL) return fail(h, "bmu_bf16: row count out of range");
+    const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
+    // parts: whole rounds of the resident slots (every round scans one part in step: one L2 miss per XCD and stage)
+    int parts = 1;
+    if (blocks < slots) {
+        parts = (int)std::min<long>(cdiv(slots, blocks), 64);
+    } else {
+        double best_eff = 0.0;
+        for (int p = 1; p <= 8; ++p) {
+            const long wgs = blocks * p;
+            const double eff = (double)wgs / (double)(cdiv(wgs, slots) * slots);
+            if (eff > best_eff + 0.01) { best_eff = eff; parts = p; }
+        }
+    }
+    if (h->env_bf16_parts > 0) parts = h->env_bf16_parts;
+    if (parts > h->n_stages) parts = h->n_stages;
+    if (N > h->best64_cap) {
+        (void)hipFree(h->best64);
+        h->best64 = nullptr; h->best64_cap = 0;
+        if (int rc = dev_alloc(h, &h->best64, (size_t)round_up(N, 1024))) return rc;
+        h->best64_cap = round_up(N, 1024);
+    }
+    const long units = (long)h->n_stages * h->stage_units;
+    prep_wsqh_kernel<<<dim3((unsigned)cdiv(std::max(units, N), 256)), dim3(256), 0, h->stream>>>(
+        h->wn, h->K, h->wmax2, xmax2, h->Wst, h->n_stages, h->stage_bytes, h->stage_units, h->best64, N);
+    if (h->debug)
+        std::fprintf(stderr, "[somhip] bmu_bf16_wide: blocks=%ld per_cu=%d slots=%ld parts=%d stages=%d\n", blocks, per_cu, slots,
+                     parts, h->n_stages);
+    kern<<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * WD_NW), lds, h->stream>>>((const char*)Ximg, N, h->Wst,
+                                                                                       h->n_stages, h->best64);
+    bmu_finalize_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(h->best64, N, h->K, out);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 int launch_bmu_bf16_tiled(som_handle* h, const __bf16* Ximg, const float* xmax2, long N, int* out) {
+    if (h->wide) {
+        switch (h->n_kchunks) {
+#define SOM_WIDE_CASE(n) case n: return launch_bmu_bf16_wide<n>(h, Ximg, xmax2, N, out);
+        SOM_WIDE_CASE(5) SOM_WIDE_CASE(6) SOM_WIDE_CASE(7) SOM_WIDE_CASE(8) SOM_WIDE_CASE(9) SOM_WIDE_CASE(10)
+        SOM_WIDE_CASE(11) SOM_WIDE_CASE(12) SOM_WIDE_CASE(13) SOM_WIDE_CASE(14) SOM_WIDE_CASE(15) SOM_WIDE_CASE(16)
+        SOM_WIDE_CASE(17) SOM_WIDE_CASE(18) SOM_WIDE_CASE(19) SOM_WIDE_CASE(20) SOM_WIDE_CASE(21) SOM_WIDE_CASE(22)
+        SOM_WIDE_CASE(23) SOM_WIDE_CASE(24) SOM_WIDE_CASE(25)
+#undef SOM_WIDE_CASE
+        }
+        return fail(h, "bmu_bf16_wide: no instance for this input_len");
+    }
     long cin = (long)h->n_ublocks * h->n_kchunks * h->tl_bn;
     prep_tiles_cin_kernel<<<dim3((unsigned)cdiv(cin, 256)), dim3(256), 0, h->stream>>>(
         h->wn, h->K, h->wmax2, xmax2, h->n_kchunks, h->n_ublocks, h->tl_bn, h->tl_wfrag, h->tl_wtile, h->Wst);
@@ -1011,9 +1072,11 @@ int som_create(const som_config* cfg, som_handle** out) {
         h->n_kchunks = (int)cdiv(h->x3 ? 3L * h->D : (long)h->D, TL_BK);
         h->n_ublocks = (int)cdiv(h->K, h->tl_bn);
     }
+    h->wide = cfg->precision == SOM_PREC_BF16 && h->tiled && h->tl_big && h->n_kchunks <= 25;
+    if (const char* e = std::getenv("SOM_BF16_WIDE")) if (std::atoi(e) == 0) h->wide = false;   // A/B: the two-sided tiling
     h->dp = h->tiled ? TL_BK * h->n_kchunks : h->x3res ? 2 * 32 * h->ks32 : 32 * h->ks32;
-    h->stage_bytes = h->x3res ? k3_stage_bytes(h->ks32) : k16_stage_bytes(h->ks32);
-    h->stage_units = h->x3res ? K3_STAGE_UNITS : K16_STAGE_UNITS;
+    h->stage_bytes = h->wide ? wd_stage_bytes(h->n_kchunks) : h->x3res ? k3_stage_bytes(h->ks32) : k16_stage_bytes(h->ks32);
+    h->stage_units = h->wide ? WD_STAGE_UNITS : h->x3res ? K3_STAGE_UNITS : K16_STAGE_UNITS;
     h->nt = cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT ? (cfg->compact_support ? 4 : 2) : 1;
     h->swapped = cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT && cfg->compact_support && cfg->topology == SOM_TOPO_RECTANGULAR;
     if (cfg->topology == SOM_TOPO_HEXAGONAL && cfg->neighborhood != SOM_NEIGH_BUBBLE) h->nt *= 3;
@@ -1079,7 +1142,7 @@ int som_create(const som_config* cfg, som_handle** out) {
     if (cfg->precision != SOM_PREC_F32) {
         h->n_stages = (int)cdiv(h->K, h->stage_units);
         size_t bytes = (size_t)h->n_stages * h->stage_bytes;
-        if (h->tiled) bytes = (size_t)h->n_ublocks * h->n_kchunks * h->tl_wtile;
+        if (h->tiled && !h->wide) bytes = (size_t)h->n_ublocks * h->n_kchunks * h->tl_wtile;
         if ((rc = dev_alloc(h, &h->Wst, bytes))) return bail(rc);
         if ((rc = dev_alloc(h, &h->xmax2, 2))) return bail(rc);
         if ((rc = dev_alloc(h, &h->wn, (size_t)h->K))) return bail(rc);
