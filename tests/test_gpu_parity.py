@@ -1188,6 +1188,50 @@ def test_fused_merge_and_operand_preparation(D, monkeypatch):
     assert len(diff) <= n // 100 and bf16_misses_are_near_best(data, outs[1][0][1], bmu_fused, diff)
 
 
+@pytest.mark.parametrize("D,dist", [(784, "cosine"), (200, "euclidean"), (130, "cosine"), (133, "euclidean")])
+def test_fused_merge_and_operand_preparation_wide_path(D, dist, monkeypatch):
+    """The same fusion on the wide path (bf16, 128 < input_len <= 800, >= 4096 units; merge_prep_wide_kernel), for
+    both GEMM-form distances, aligned and unaligned rows: the first epoch and its merge are bitwise equal to the
+    separate launches; afterwards the row norms are summed in another order, so a few bf16 near-ties may differ."""
+    X, Y, n = 64, 66, 3000
+    data = np.abs(O.gaussian_blobs(n, D, seed=3))
+    w = np.abs(O.default_codebook(X, Y, D, 9).astype(F32))
+    outs = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("SOM_FUSE_MERGE", fuse)
+        e = engine(X, Y, D, precision="bf16", distance=dist)
+        e.set_weights(w)
+        e.set_data(data)
+        trace = []
+        for t, (sig, eta) in enumerate([(8.0, 0.5), (2.0, 0.3), (0.4, 0.05)]):     # 0.4: den == 0 for most units
+            e.epoch_accumulate(sig, eta, t % 2 == 0)
+            num, den, bmu = e.epoch_fetch()
+            e.epoch_merge()
+            trace.append((bmu, e.get_weights(), num, den))
+        outs.append(trace)
+        e.close()
+    (b0, w0, n0, d0), (b1, w1, n1, d1) = outs[0][0], outs[1][0]
+    assert np.array_equal(b0, b1) and np.array_equal(n0, n1) and np.array_equal(d0, d1) and np.array_equal(w0, w1)
+    assert (outs[1][2][3] == 0).any()                         # the old-weights branch of the fused merge was taken
+    for (b0, w0, _, _), (b1, w1, _, _) in zip(outs[0][1:], outs[1][1:]):
+        assert (b0 != b1).mean() < 0.01
+        assert np.abs(w0 - w1).mean() < 2e-3 * np.abs(w0).max()
+    # the fused operands alone against freshly prepared ones on the same merged codebook
+    monkeypatch.setenv("SOM_FUSE_MERGE", "1")
+    e = engine(X, Y, D, precision="bf16", distance=dist)
+    e.set_weights(w)
+    e.set_data(data)
+    e.epoch(8.0, 0.5, True)
+    e.epoch_accumulate(2.0, 0.3, True)
+    _, _, bmu_fused = e.epoch_fetch()
+    e2 = engine(X, Y, D, precision="bf16", distance=dist)
+    e2.set_weights(outs[1][0][1])
+    e2.set_data(data)
+    e2.epoch_accumulate(2.0, 0.3, True)
+    _, _, bmu_plain = e2.epoch_fetch()
+    assert (bmu_fused != bmu_plain).sum() <= n // 100
+
+
 def test_staged_epoch_equals_the_monolithic_one():
     """som_epoch_accumulate_begin + one som_epoch_accumulate_block per 128-row map block (the form the overlapped
     all-reduce uses) leaves the accumulator of som_epoch_accumulate, bit for bit, and reports disjoint slices that

@@ -58,6 +58,106 @@ __global__ __launch_bounds__(256) void prep_w_bf16_wide_kernel(const float* __re
     *(bf16x8*)(Wst + stage * wd_stage_bytes(ks32) + ((long)(t16 * ks32 + ks) * 64 + lane) * 16) = v;
 }
 
+// _merge_updates (xpysom.py:446-455) fused with the NEXT epoch's operand preparation on the wide path, as
+// merge_prep_k16_kernel is on the 128-feature path: one pass over the fused accumulator writes the merged float32
+// codebook, the bf16 stage image and |w~_k|^2 (+ its maximum) -- merge_kernel + row_sq_f32_kernel (cosine) +
+// prep_w_bf16_wide_kernel + rownorm_bf16_kernel in one launch that reads the accumulator once and the old codebook
+// only where no row was in reach.  Workgroup = one 16-unit tile, 4 waves; wave w takes the feature chunks w, w+4, ...;
+// thread = (unit, 8 features) of each of its chunks = one 16-byte fragment chunk of the image.  cosine != 0: the
+// image holds the unit-length rows (scale 1/|w|, a zero row stays zero) and |w~|^2 is reported as 0 (rownorm_bf16_kernel).
+constexpr int WD_MP_ITERS = 7;                   // chunks per wave: up to 28 feature chunks (the wide kernel stops at 25)
+__global__ __launch_bounds__(256) void merge_prep_wide_kernel(float* __restrict__ W, const float* __restrict__ ACC, int K,
+                                                              int D, int D1p, int ks32, char* __restrict__ Wst,
+                                                              float* __restrict__ wn, float* __restrict__ wmax2,
+                                                              int cosine) {
+    __shared__ float red[2][4][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, quad = lane >> 4;
+    const long tile = blockIdx.x;
+    const long stage = tile / WD_T;
+    const int t16 = (int)(tile - stage * WD_T);
+    const long u = tile * 16 + col;
+    const bool live = u < K;
+    const bool aligned = (D & 3) == 0;                      // 16-byte aligned rows on both sides (D1p is a multiple of 4)
+    const float den = live ? ACC[u * D1p + D] : 0.0f;
+    float w[WD_MP_ITERS][8];
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < WD_MP_ITERS; ++i) {
+        const int ks = wave + 4 * i;
+        const int k0 = ks * 32 + quad * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[i][j] = 0.0f;
+        if (ks >= ks32 || !live || k0 >= D) continue;
+        const bool full = aligned && k0 + 8 <= D;
+        const float* src = den != 0.0f ? ACC + u * D1p + k0 : W + u * D + k0;   // no row in reach: the old weights stay
+        if (full) {
+            const f32x4 a = *(const f32x4*)src, c = *(const f32x4*)(src + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { w[i][j] = a[j]; w[i][4 + j] = c[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (k0 + j < D) w[i][j] = src[j];
+        }
+        if (den != 0.0f) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[i][j] = w[i][j] / den;
+            if (full) {
+                f32x4 q0, q1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { q0[j] = w[i][j]; q1[j] = w[i][4 + j]; }
+                *(f32x4*)(W + u * D + k0) = q0;
+                *(f32x4*)(W + u * D + k0 + 4) = q1;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (k0 + j < D) W[u * D + k0 + j] = w[i][j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q = __builtin_fmaf(w[i][j], w[i][j], q);
+    }
+    float scale = 1.0f;
+    if (cosine) {                                            // |w|^2 of the merged row: over the quads, then over the waves
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (lane < 16) red[0][wave][lane] = q;
+        __syncthreads();
+        const float qq = (red[0][0][col] + red[0][1][col]) + (red[0][2][col] + red[0][3][col]);
+        scale = qq > 0.0f ? 1.0f / __builtin_sqrtf(qq) : 0.0f;
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < WD_MP_ITERS; ++i) {
+        const int ks = wave + 4 * i;
+        if (ks >= ks32) continue;
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = w[i][j] * scale;
+            const __bf16 b = (__bf16)f;
+            v[j] = (__bf16)(-f);                             // (rounding is sign-symmetric: -bf16(f) == bf16(-f))
+            const float r = (float)b;
+            s = __builtin_fmaf(r, r, s);
+        }
+        *(bf16x8*)(Wst + stage * wd_stage_bytes(ks32) + ((long)(t16 * ks32 + ks) * 64 + lane) * 16) = v;
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (lane < 16) red[1][wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && lane < 16) {
+        float t = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+        if (!live) t = 0.0f;
+        if (live) wn[u] = cosine ? 0.0f : t;
+        float m = t;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) atomic_max_pos_f32(wmax2, m);
+    }
+}
+
 template <int KS32>
 __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* __restrict__ Ximg, long N,
                                                                    const char* __restrict__ Wst, int n_stages,

@@ -295,8 +295,9 @@ void mark_codebook_changed(som_handle* h) { h->w_dirty = h->wsq_dirty = h->wf_di
 int refresh_codebook_operands(som_handle* h, bool need_f32) {
     const bool bf = h->cfg.precision != SOM_PREC_F32;
     const bool do_f32 = (need_f32 || !bf) && h->wf_dirty;
-    const bool do_wsq = h->wsq_dirty && (need_f32 || !bf || h->cfg.distance == SOM_DIST_COSINE);
     const bool do_bf = bf && h->w_dirty;
+    // (cosine scales the bf16 images by 1/|w|: |w|^2 is wanted whenever they are rebuilt)
+    const bool do_wsq = h->wsq_dirty && (need_f32 || !bf || (do_bf && h->cfg.distance == SOM_DIST_COSINE));
     if (!do_f32 && !do_wsq && !do_bf) return 0;
     Timed t(h, SOM_K_PREP);
     if (do_wsq) {
@@ -1494,6 +1495,16 @@ int som_epoch_merge(som_handle* h) {
         HIPCHK(h, hipGetLastError());
         mark_codebook_changed(h);
         h->w_dirty = false;                              // the bf16 stage image and |w~|^2 are already the new codebook's
+        return 0;
+    }
+    // the wide path (bf16, 128 < input_len <= 800, big maps; euclidean and cosine) likewise
+    if (h->wide && h->fuse_merge_prep && h->n_kchunks <= 4 * WD_MP_ITERS) {
+        HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
+        merge_prep_wide_kernel<<<dim3((unsigned)(h->n_stages * WD_T)), dim3(256), 0, h->stream>>>(
+            h->W, h->ACC, h->K, h->D, h->D1p, h->n_kchunks, h->Wst, h->wn, h->wmax2, h->cfg.distance == SOM_DIST_COSINE);
+        HIPCHK(h, hipGetLastError());
+        mark_codebook_changed(h);
+        h->w_dirty = false;
         return 0;
     }
     long total = (long)h->K * h->D;
