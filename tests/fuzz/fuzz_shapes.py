@@ -15,6 +15,8 @@ for case in range(n_cases):
     side = int(os.environ.get("FUZZ_MAXSIDE", "40"))      # > 64 reaches the 256 x 256 tiles of the tiled kernel (K >= 4096)
     X, Y = int(rs.randint(1, side + 1)), int(rs.randint(1, side + 1))
     D = int(rs.choice([1, 2, 3, 7, 16, 31, 32, 33, 64, 100, 128, 129, 130, 200, 257, 300]))
+    if os.environ.get("FUZZ_BIGD") and rs.rand() < 0.6:       # with FUZZ_MAXSIDE > 64: the wide kernel's instances (<= 800) and past them
+        D = int(rs.choice([160, 224, 333, 416, 512, 640, 784, 800, 801, 900]))
     n = int(rs.choice([1, 2, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1000, 3000]))
     prec = str(rs.choice(["f32", "bf16", "bf16x3"]))
     dist = str(rs.choice(["euclidean", "cosine"]))
