@@ -242,8 +242,11 @@ def main():
     for t in range(args.warmup):
         D.epoch(eng, sched[t][0], sched[t][1], True)
     fence()
+    # The timed region carries HIP events around the dominant (BMU) kernel only -- two event records per epoch.
+    # Event pairs around every kernel family put a ~10 us bubble on the stream at each of the four phase
+    # boundaries of an epoch (kernel trace): that breakdown is taken in a separate pass below.
     eng.profile_reset()
-    eng.profile_enable(True)
+    eng.profile_enable("bmu")
     t0 = time.perf_counter()
     for t in range(args.warmup, total):
         D.epoch(eng, sched[t][0], sched[t][1], True)
@@ -257,7 +260,15 @@ def main():
         dt = float(tt.item())
 
     bmu_ms, bmu_n = eng.profile_get("bmu")
-    parts = {k: eng.profile_get(k)[0] / max(1, args.steps) for k in ("prep", "bmu", "segsum", "kron", "merge")}
+    # per-kernel-family breakdown: the same epochs once more (at most 5), untimed, every family under events
+    nb = max(1, min(args.steps, 5))
+    eng.profile_reset()
+    eng.profile_enable(True)
+    for t in range(args.warmup, args.warmup + nb):
+        D.epoch(eng, sched[t][0], sched[t][1], True)
+    fence()
+    eng.profile_enable(False)
+    parts = {k: eng.profile_get(k)[0] / nb for k in ("prep", "bmu", "segsum", "kron", "merge")}
     w_end = eng.get_weights()
     assert np.isfinite(w_end).all()
 
@@ -275,7 +286,7 @@ def main():
             D.epoch(eng, sched[0][0], sched[0][1], True)
         eng.sync()
         eng.profile_reset()
-        eng.profile_enable(True)
+        eng.profile_enable("bmu")
         tb = time.perf_counter()
         for t in range(reps):
             D.epoch(eng, sched[t % total][0], sched[t % total][1], True)
@@ -285,9 +296,15 @@ def main():
         b_ms, b_n = eng.profile_get("bmu")
         b_avg = b_ms / max(1, b_n)
         b_ach = KD2 * NORTH_STAR_BATCH / (b_avg * 1e-3) / 1e12
+        eng.profile_reset()
+        eng.profile_enable(True)                               # breakdown pass (see above)
+        for t in range(10):
+            D.epoch(eng, sched[t % total][0], sched[t % total][1], True)
+        eng.sync()
+        eng.profile_enable(False)
         batch = {"rows": NORTH_STAR_BATCH, "avg_launch_ms": b_avg, "launches": b_n, "achieved": b_ach,
                  "frac": b_ach / peak, "epoch_ms": 1e3 * tb / reps,
-                 "ms_per_epoch_by_kernel": {k: eng.profile_get(k)[0] / reps for k in ("prep", "bmu", "segsum", "kron", "merge")}}
+                 "ms_per_epoch_by_kernel": {k: eng.profile_get(k)[0] / 10 for k in ("prep", "bmu", "segsum", "kron", "merge")}}
 
     # the other precision modes on the same batch, so that the parity mode has a number from this very run
     modes = None
@@ -301,7 +318,7 @@ def main():
             D.epoch(e2, sched[0][0], sched[0][1], True)
             e2.sync()
             e2.profile_reset()
-            e2.profile_enable(True)
+            e2.profile_enable("bmu")
             t2 = time.perf_counter()
             for t in range(3):
                 D.epoch(e2, sched[t % total][0], sched[t % total][1], True)
@@ -347,6 +364,7 @@ def main():
                          "avg_launch_ms": bmu_ms / max(1, bmu_n), "launches": bmu_n,
                          "flops_per_launch": flops_launch},
             "ms_per_step_by_kernel": parts,
+            "ms_per_step_by_kernel_pass": "separate untimed pass of %d epochs after the timed region (events around every kernel family)" % nb,
         }
         if batch is not None:
             out["roofline"]["batch65536"] = batch

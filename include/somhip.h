@@ -194,7 +194,8 @@ int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, d
 
 /* stream / timing plumbing */
 int som_sync(som_handle* h);
-int som_profile_enable(som_handle* h, int32_t on);          /* hipEvent pairs around each kernel family */
+int som_profile_enable(som_handle* h, int32_t on);          /* hipEvent pairs around each kernel family (1), or around the
+                                                               BMU kernels only (2: two event records per epoch); 0 = off */
 int som_profile_get(som_handle* h, int32_t kernel, double* total_ms, int64_t* launches);
 int som_profile_reset(som_handle* h);
 

@@ -157,7 +157,7 @@ struct som_handle {
     std::vector<KernelSlots> kernel_slots;
     int staged_blocks_done = -1; // som_epoch_accumulate_begin / _block: next block expected, -1 = none pending
     bool async_copies = false;   // SOM_ASYNC_COPIES=1: round 1's original copy path (fresh_process_stress.py)
-    bool prof = false;
+    int prof = 0;            // som_profile_enable: 0 off, 1 every kernel family, 2 the BMU family only
     std::vector<EventPair> pending, pool;
     double ms[SOM_K_COUNT] = {0};
     int64_t launches[SOM_K_COUNT] = {0};
@@ -253,7 +253,7 @@ constexpr long ROW_PAD = 3072;   // bf16 row images are padded to a multiple of 
 // ---- profiling: event pairs recorded around kernel families, resolved lazily ---------------
 struct Timed {
     som_handle* h; int kernel; EventPair ep{}; bool on;
-    Timed(som_handle* h_, int k) : h(h_), kernel(k), on(h_->prof) {
+    Timed(som_handle* h_, int k) : h(h_), kernel(k), on(h_->prof == 1 || (h_->prof == 2 && k == SOM_K_BMU)) {
         if (!on) return;
         if (!h->pool.empty()) { ep = h->pool.back(); h->pool.pop_back(); }
         else { (void)hipEventCreate(&ep.a); (void)hipEventCreate(&ep.b); }
@@ -1804,7 +1804,7 @@ int som_profile_enable(som_handle* h, int32_t on) {
     DeviceGuard dev_guard(h);
     if (!h) return 1;
     if (!on) if (int rc = resolve_profile(h)) return rc;
-    h->prof = on != 0;
+    h->prof = on == 2 ? 2 : on != 0;
     return 0;
 }
 

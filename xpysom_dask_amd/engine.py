@@ -263,7 +263,7 @@ class HipEngine:
         self._check(self._lib.som_sync(self._h))
 
     def profile_enable(self, on=True):
-        self._check(self._lib.som_profile_enable(self._h, int(bool(on))))
+        self._check(self._lib.som_profile_enable(self._h, 2 if on == "bmu" else int(bool(on))))
 
     def profile_reset(self):
         self._check(self._lib.som_profile_reset(self._h))
