@@ -260,8 +260,9 @@ def main():
         dt = float(tt.item())
 
     bmu_ms, bmu_n = eng.profile_get("bmu")
-    # per-kernel-family breakdown: the same epochs once more (at most 5), untimed, every family under events
-    nb = max(1, min(args.steps, 5))
+    # per-kernel-family breakdown: the same epochs once more (the same schedule entries, at most 20), untimed, every
+    # family under events
+    nb = max(1, min(args.steps, 20))
     eng.profile_reset()
     eng.profile_enable(True)
     for t in range(args.warmup, args.warmup + nb):
