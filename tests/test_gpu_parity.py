@@ -914,11 +914,12 @@ def test_epoch_graph_replay_matches_eager_launches(monkeypatch):
 @pytest.mark.parametrize("X,Y,D,n,precision", [(64, 64, 784, 5000, "bf16"), (100, 90, 257, 7000, "bf16"),
                                                (256, 256, 128, 20000, "bf16x3"), (2, 2, 129, 257, "bf16"),
                                                (256, 16, 640, 3333, "bf16"), (64, 64, 900, 3000, "bf16"),
-                                               (64, 70, 150, 2500, "bf16x3"), (30, 30, 300, 1000, "bf16")])
+                                               (64, 70, 150, 2500, "bf16x3"), (30, 30, 300, 1000, "bf16"),
+                                               (64, 64, 300, 1500, "bf16x3")])
 def test_tiled_kernel_is_repeatable_and_near_best(X, Y, D, n, precision):
     """bmu_bf16_tiled_kernel runs two wave groups one barrier apart over a 4-slot LDS-DMA ring with
     counted vmcnt waits; bmu_bf16_wide_kernel (bf16, 128 < input_len <= 800, maps of >= 4096 units: the
-    first, second and fifth case) refills a 3-slot ring behind one barrier per stage.  A mis-ordered read
+    first, second, fifth and seventh case) refills a 3-slot ring behind one barrier per stage.  A mis-ordered read
     or refill would show up as run-to-run differences or as picks outside the operand-rounding bound, so:
     six launches agree bit for bit, the resident-row path (different padding and grid) agrees with the
     query path, and every pick is near-best."""
@@ -940,11 +941,13 @@ def test_tiled_kernel_is_repeatable_and_near_best(X, Y, D, n, precision):
     assert (dd[np.arange(len(idx)), outs[0][idx]] <= dd.min(1) + slack).all()
 
 
-@pytest.mark.parametrize("X,Y,D,n,dist,parts", [(64, 64, 129, 1000, "euclidean", None), (64, 70, 200, 777, "cosine", None),
-                                                (70, 70, 257, 2049, "euclidean", "3"), (64, 64, 400, 1, "euclidean", None),
-                                                (80, 80, 784, 5001, "cosine", None), (64, 64, 800, 257, "euclidean", "7"),
-                                                (72, 64, 540, 256, "euclidean", None)])
-def test_wide_kernel_matches_tiled_kernel(monkeypatch, X, Y, D, n, dist, parts):
+@pytest.mark.parametrize("X,Y,D,n,dist,parts,prec", [
+    (64, 64, 129, 1000, "euclidean", None, "bf16"), (64, 70, 200, 777, "cosine", None, "bf16"),
+    (70, 70, 257, 2049, "euclidean", "3", "bf16"), (64, 64, 400, 1, "euclidean", None, "bf16"),
+    (80, 80, 784, 5001, "cosine", None, "bf16"), (64, 64, 800, 257, "euclidean", "7", "bf16"),
+    (72, 64, 540, 256, "euclidean", None, "bf16"),
+    (64, 70, 150, 2500, "euclidean", None, "bf16x3"), (64, 64, 266, 700, "cosine", "5", "bf16x3")])   # 3 D <= 800
+def test_wide_kernel_matches_tiled_kernel(monkeypatch, X, Y, D, n, dist, parts, prec):
     """The two bf16 kernels for input_len > 128 compute the same accumulation chain (same operand images, same
     offset B, features in the same order): bmu_bf16_wide_kernel (samples resident in registers, the default on
     maps of >= 4096 units up to 800 features) must pick what bmu_bf16_tiled_kernel (SOM_BF16_WIDE=0) picks,
@@ -960,7 +963,7 @@ def test_wide_kernel_matches_tiled_kernel(monkeypatch, X, Y, D, n, dist, parts):
             monkeypatch.setenv("SOM_BF16_PARTS", parts)
         else:
             monkeypatch.delenv("SOM_BF16_PARTS", raising=False)
-        e = engine(X, Y, D, precision="bf16", distance=dist)
+        e = engine(X, Y, D, precision=prec, distance=dist)
         e.set_weights(w)
         e.set_data(data)
         e.epoch_accumulate(2.0, 0.3, True)
@@ -975,7 +978,7 @@ def test_wide_kernel_matches_tiled_kernel(monkeypatch, X, Y, D, n, dist, parts):
         w64 = w64 / np.linalg.norm(w64, axis=1, keepdims=True)
     idx = np.arange(n) if n <= 1500 else np.random.RandomState(0).choice(n, 1500, replace=False)
     dd = np.sqrt(np.maximum((x64[idx] ** 2).sum(1)[:, None] - 2 * x64[idx] @ w64.T + (w64 ** 2).sum(1)[None, :], 0))
-    slack = 2.0 ** -8 * (np.linalg.norm(x64[idx], axis=1) + np.linalg.norm(w64, axis=1).max())
+    slack = (2.0 ** -8 if prec == "bf16" else 2.0 ** -15) * (np.linalg.norm(x64[idx], axis=1) + np.linalg.norm(w64, axis=1).max())
     assert (dd[np.arange(len(idx)), got["1"][0][idx]] <= dd.min(1) + slack).all()
 
 

@@ -33,10 +33,11 @@ static_assert(WD_WG_SAMPLES == TileCfg<8, 2, 4>::BM && WD_XTILE == TileCfg<8, 2,
 
 __host__ __device__ constexpr int wd_stage_bytes(int ks32) { return (WD_T * ks32 + 1) * 1024; }
 
-// codebook -> stage image (the initial accumulators are written by prep_wsqh_kernel: they depend on the row set)
+// codebook -> stage image (the initial accumulators are written by prep_wsqh_kernel: they depend on the row set).
+// split != 0 (precision 'bf16x3', prep_tiles_bf16_kernel): the feature axis is tripled, units carry [hi | lo | hi].
 __global__ __launch_bounds__(256) void prep_w_bf16_wide_kernel(const float* __restrict__ W, int K, int D, int ks32,
                                                                char* __restrict__ Wst, int n_stages,
-                                                               const float* __restrict__ unit_wsq) {
+                                                               const float* __restrict__ unit_wsq, int split) {
     long id = (long)blockIdx.x * 256 + threadIdx.x;
     long total = (long)n_stages * WD_T * ks32 * 64;
     if (id >= total) return;
@@ -52,8 +53,15 @@ __global__ __launch_bounds__(256) void prep_w_bf16_wide_kernel(const float* __re
     bf16x8 v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        float f = (u < K && k0 + j < D) ? W[u * D + k0 + j] * scale : 0.0f;
-        v[j] = (__bf16)(-f);
+        if (split == 0) {
+            float f = (u < K && k0 + j < D) ? W[u * D + k0 + j] * scale : 0.0f;
+            v[j] = (__bf16)(-f);
+        } else {
+            const int kv = k0 + j, seg = kv / D, k = kv - seg * D;
+            float f = (u < K && seg < 3) ? -W[u * D + k] * scale : 0.0f;
+            const __bf16 hi = (__bf16)f;
+            v[j] = seg == 1 ? (__bf16)(f - (float)hi) : hi;
+        }
     }
     *(bf16x8*)(Wst + stage * wd_stage_bytes(ks32) + ((long)(t16 * ks32 + ks) * 64 + lane) * 16) = v;
 }

@@ -326,7 +326,7 @@ int refresh_codebook_operands(som_handle* h, bool need_f32) {
         if (h->wide) {
             long total = (long)h->n_stages * WD_T * h->n_kchunks * 64;
             prep_w_bf16_wide_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
-                h->W, h->K, h->D, h->n_kchunks, h->Wst, h->n_stages, unit);
+                h->W, h->K, h->D, h->n_kchunks, h->Wst, h->n_stages, unit, h->x3 ? 1 : 0);
         } else {
             long total = (long)h->n_ublocks * h->n_kchunks * (h->tl_bn / 16) * TL_KS * 64;
             prep_tiles_bf16_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
@@ -1073,7 +1073,7 @@ int som_create(const som_config* cfg, som_handle** out) {
         h->n_kchunks = (int)cdiv(h->x3 ? 3L * h->D : (long)h->D, TL_BK);
         h->n_ublocks = (int)cdiv(h->K, h->tl_bn);
     }
-    h->wide = cfg->precision == SOM_PREC_BF16 && h->tiled && h->tl_big && h->n_kchunks <= 25;
+    h->wide = h->tiled && h->tl_big && h->n_kchunks <= 25;     // (bf16x3: the tripled feature axis, input_len <= 266)
     if (const char* e = std::getenv("SOM_BF16_WIDE")) if (std::atoi(e) == 0) h->wide = false;   // A/B: the two-sided tiling
     h->dp = h->tiled ? TL_BK * h->n_kchunks : h->x3res ? 2 * 32 * h->ks32 : 32 * h->ks32;
     h->stage_bytes = h->wide ? wd_stage_bytes(h->n_kchunks) : h->x3res ? k3_stage_bytes(h->ks32) : k16_stage_bytes(h->ks32);
@@ -1498,7 +1498,7 @@ int som_epoch_merge(som_handle* h) {
         return 0;
     }
     // the wide path (bf16, 128 < input_len <= 800, big maps; euclidean and cosine) likewise
-    if (h->wide && h->fuse_merge_prep && h->n_kchunks <= 4 * WD_MP_ITERS) {
+    if (h->wide && !h->x3 && h->fuse_merge_prep && h->n_kchunks <= 4 * WD_MP_ITERS) {
         HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
         merge_prep_wide_kernel<<<dim3((unsigned)(h->n_stages * WD_T)), dim3(256), 0, h->stream>>>(
             h->W, h->ACC, h->K, h->D, h->D1p, h->n_kchunks, h->Wst, h->wn, h->wmax2, h->cfg.distance == SOM_DIST_COSINE);
