@@ -1264,12 +1264,14 @@ def test_staged_epoch_equals_the_monolithic_one():
             e.epoch_accumulate_block(0)                        # no epoch in progress
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16"])
-def test_nan_semantics_documented_in_design(precision):
+@pytest.mark.parametrize("precision,shape", [("f32", (4, 5, 6)), ("bf16", (4, 5, 6)), ("bf16", (64, 65, 200)),
+                                             ("bf16", (5, 5, 200)), ("bf16x3", (4, 5, 6)), ("f32", (6, 6, 150))])
+def test_nan_semantics_documented_in_design(precision, shape):
     """DESIGN.md 4, known difference: a unit whose distance is NaN never wins (`<` semantics), where numpy.argmin
     returns the FIRST NaN unit; a row whose distances are ALL NaN returns unit 0, as numpy.argmin does.  Only a
-    codebook (or a row) that already holds NaN can get there; this pins what the engine does."""
-    X, Y, D = 4, 5, 6
+    codebook (or a row) that already holds NaN can get there; this pins what the engine does -- in every BMU kernel
+    (resident, wide and tiled bf16 forms, the split kernel, both float32 forms)."""
+    X, Y, D = shape
     rs = np.random.RandomState(2)
     w = rs.randn(X * Y, D).astype(F32)
     x = rs.randn(50, D).astype(F32)
