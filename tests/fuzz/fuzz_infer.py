@@ -1,6 +1,6 @@
 """Inference fuzz: winner / quantization / quantization_error / topographic_error / activate / distance_map of
 XPySom (all three precisions) against the oracle on random maps, data and distances."""
-import sys, time, warnings, numpy as np
+import os, sys, time, warnings, numpy as np
 sys.path.insert(0, '.')
 from oracle import som_oracle as O
 from xpysom_dask_amd import XPySom
@@ -12,7 +12,8 @@ n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 bad = 0
 t0 = time.time()
 for case in range(n_cases):
-    X, Y = int(rs.randint(2, 30)), int(rs.randint(2, 30))
+    side = int(os.environ.get("FUZZ_MAXSIDE", "30"))        # > 64 reaches the wide bf16 kernel (>= 4096 units, 130 / 300 features)
+    X, Y = int(rs.randint(2, side)), int(rs.randint(2, side))
     D = int(rs.choice([1, 2, 5, 16, 33, 64, 128, 130, 300]))
     n = int(rs.choice([1, 2, 17, 256, 1000, 3001]))
     prec = str(rs.choice(["f32", "f32", "bf16x3", "bf16"]))
