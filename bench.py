@@ -73,8 +73,10 @@ def kernel_name_for(precision, features, units=1 << 16):
     """The BMU kernel som_create selects (csrc/somhip.hip)."""
     if precision == "f32":
         return "bmu_f32_tiled_kernel" if features > 128 else "bmu_f32_res_kernel"
-    if precision == "bf16x3":
-        return "bmu_bf16_tiled_kernel" if features > 128 else "bmu_bf16_k16x3_kernel"
+    if precision in ("bf16x3", "f16x3"):                    # ('f16' / 'f16x3': the bf16 kernels' _Float16 instances)
+        if features > 128:
+            return "bmu_bf16_wide_kernel" if units >= 4096 and 3 * features <= 800 else "bmu_bf16_tiled_kernel"
+        return "bmu_bf16_k16x3_kernel"
     if features > 128:
         wide = units >= 4096 and features <= 800 and os.environ.get("SOM_BF16_WIDE", "1") != "0"
         return "bmu_bf16_wide_kernel" if wide else "bmu_bf16_tiled_kernel"
@@ -168,7 +170,7 @@ def main():
                     help="weak: --rows per GPU (default); strong: --total-rows split over the ranks")
     ap.add_argument("--rows", type=int, default=None, help="weak scaling: rows per GPU (default: the workload's)")
     ap.add_argument("--total-rows", type=int, default=STRONG_TOTAL_ROWS, help="strong scaling: rows of the whole job")
-    ap.add_argument("--precision", default=None, choices=["bf16", "f32", "bf16x3"])
+    ap.add_argument("--precision", default=None, choices=["bf16", "f32", "bf16x3", "f16", "f16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch65536", action="store_true")
     args = ap.parse_args()
@@ -311,11 +313,16 @@ def main():
     modes = None
     if batch is not None and args.precision == "bf16" and FEATURES <= 128:
         modes = {}
-        for prec, flop_peak in (("f32", MFMA_F32_PEAK_TFLOPS), ("bf16x3", MFMA_BF16_PEAK_TFLOPS)):
+        ref_bmu = None
+        for prec, flop_peak in (("f32", MFMA_F32_PEAK_TFLOPS), ("bf16x3", MFMA_BF16_PEAK_TFLOPS), ("f16x3", MFMA_BF16_PEAK_TFLOPS),
+                                ("f16", MFMA_BF16_PEAK_TFLOPS), ("bf16", MFMA_BF16_PEAK_TFLOPS)):
             e2 = HipEngine(MAP_X, MAP_Y, FEATURES, precision=prec, device=dev, distance=wl["distance"],
                            neighborhood=wl["neighborhood"])
             e2.set_weights(w)
             e2.set_data(rows_host[:NORTH_STAR_BATCH])
+            first_bmu = e2.bmu(rows_host[:NORTH_STAR_BATCH])   # on the seeded codebook, before any update
+            if ref_bmu is None:
+                ref_bmu = first_bmu
             D.epoch(e2, sched[0][0], sched[0][1], True)
             e2.sync()
             e2.profile_reset()
@@ -330,6 +337,7 @@ def main():
             ach = KD2 * NORTH_STAR_BATCH / (m_ms / max(1, m_n) * 1e-3) / 1e12
             modes[prec] = {"rows": NORTH_STAR_BATCH, "epoch_ms": 1e3 * t2, "bmu_launch_ms": m_ms / max(1, m_n),
                            "achieved_tflops_algorithmic": ach, "frac_of_its_pipe_peak": ach / flop_peak,
+                           "bmus_equal_to_float32": float(np.mean(first_bmu == ref_bmu)),
                            "kernel": kernel_name_for(prec, FEATURES, MAP_X * MAP_Y)}
             e2.close()
 
@@ -344,7 +352,7 @@ def main():
             "metric": "samples/sec/epoch", "value": total_rows / (dt / args.steps), "unit": "samples/sec/epoch",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "bf16", "data": "synthetic",
+            "dtype": {"f32": "f32", "f16": "f16", "f16x3": "f16"}.get(args.precision, "bf16"), "data": "synthetic",
             "config": {"workload": "batch-SOM epoch, %dx%d map, %d features, %d Gaussian-blob rows %s resident "
                                    "in HBM (%s), one launch over all resident rows"
                                    % (MAP_X, MAP_Y, FEATURES, my_rows if args.scaling == "weak" else total_rows,
@@ -370,7 +378,7 @@ def main():
         if batch is not None:
             out["roofline"]["batch65536"] = batch
         if modes is not None:
-            out["precision_modes_at_batch65536"] = modes   # 'f32' = the parity mode (bit-exact float32 chain), 'bf16x3' = hi/lo split
+            out["precision_modes_at_batch65536"] = modes   # 'f32' = the parity mode (bit-exact float32 chain), '*x3' = hi/lo split, 'f16*' = IEEE half operands
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)

@@ -49,8 +49,13 @@ enum { SOM_TOPO_RECTANGULAR = 0, SOM_TOPO_HEXAGONAL = 1 };
  *   F32  : v_mfma_f32_32x32x2_f32, exact float32 fma chain -- the parity mode
  *   BF16 : v_mfma_f32_16x16x32_bf16 on bf16-rounded x and w, f32 accumulate -- the throughput mode
  *   BF16X3: the same MFMA on hi/lo-split operands (x_hi.w_hi + x_hi.w_lo + x_lo.w_hi, exact float32
- *           |w|^2): ~2^-16 relative error in x.w at 3x the bf16 work -- near-f32 BMUs, faster than F32 */
-enum { SOM_PREC_F32 = 0, SOM_PREC_BF16 = 1, SOM_PREC_BF16X3 = 2 };
+ *           |w|^2): ~2^-16 relative error in x.w at 3x the bf16 work -- near-f32 BMUs, faster than F32
+ *   F16 / F16X3: the BF16 / BF16X3 kernels instantiated on IEEE half (v_mfma_f32_16x16x32_f16): 11 significant
+ *           bits per operand instead of 8 at the same MFMA rate (97 % of the bf16 throughput under the chip's power
+ *           limit); rows and units must fit float16 -- som_set_data / som_set_weights refuse norms above 65504 */
+enum { SOM_PREC_F32 = 0, SOM_PREC_BF16 = 1, SOM_PREC_BF16X3 = 2,
+       SOM_PREC_F16 = 3,      /* the bf16 path on IEEE half operands: 11 significant bits instead of 8, |value| <= 65504 */
+       SOM_PREC_F16X3 = 4 };  /* the bf16x3 path on IEEE half hi/lo pairs */
 
 /* which BMU rule som_bmu applies */
 enum { SOM_BMU_ACTIVATION = 0,   /* configured activation distance: XPySom._winner, xpysom.py:410-417 */

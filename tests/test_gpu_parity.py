@@ -915,7 +915,8 @@ def test_epoch_graph_replay_matches_eager_launches(monkeypatch):
                                                (256, 256, 128, 20000, "bf16x3"), (2, 2, 129, 257, "bf16"),
                                                (256, 16, 640, 3333, "bf16"), (64, 64, 900, 3000, "bf16"),
                                                (64, 70, 150, 2500, "bf16x3"), (30, 30, 300, 1000, "bf16"),
-                                               (64, 64, 300, 1500, "bf16x3")])
+                                               (64, 64, 300, 1500, "bf16x3"), (64, 64, 784, 4000, "f16"),
+                                               (40, 40, 400, 2000, "f16"), (64, 64, 128, 9000, "f16x3")])
 def test_tiled_kernel_is_repeatable_and_near_best(X, Y, D, n, precision):
     """bmu_bf16_tiled_kernel runs two wave groups one barrier apart over a 4-slot LDS-DMA ring with
     counted vmcnt waits; bmu_bf16_wide_kernel (bf16, 128 < input_len <= 800, maps of >= 4096 units: the
@@ -937,7 +938,7 @@ def test_tiled_kernel_is_repeatable_and_near_best(X, Y, D, n, precision):
     idx = rs.choice(n, size=min(n, 1500), replace=False)
     x64, w64 = data[idx].astype(np.float64), w.reshape(-1, D).astype(np.float64)
     dd = np.sqrt(np.maximum((x64 ** 2).sum(1)[:, None] - 2 * x64 @ w64.T + (w64 ** 2).sum(1)[None, :], 0))
-    slack = (2.0 ** -8 if precision == "bf16" else 2.0 ** -15) * (np.linalg.norm(x64, axis=1) + np.linalg.norm(w64, axis=1).max())
+    slack = {"bf16": 2.0 ** -8, "f16": 2.0 ** -11}.get(precision, 2.0 ** -15) * (np.linalg.norm(x64, axis=1) + np.linalg.norm(w64, axis=1).max())
     assert (dd[np.arange(len(idx)), outs[0][idx]] <= dd.min(1) + slack).all()
 
 
@@ -1265,7 +1266,8 @@ def test_staged_epoch_equals_the_monolithic_one():
 
 
 @pytest.mark.parametrize("precision,shape", [("f32", (4, 5, 6)), ("bf16", (4, 5, 6)), ("bf16", (64, 65, 200)),
-                                             ("bf16", (5, 5, 200)), ("bf16x3", (4, 5, 6)), ("f32", (6, 6, 150))])
+                                             ("bf16", (5, 5, 200)), ("bf16x3", (4, 5, 6)), ("f32", (6, 6, 150)),
+                                             ("f16", (4, 5, 6)), ("f16", (64, 65, 200))])
 def test_nan_semantics_documented_in_design(precision, shape):
     """DESIGN.md 4, known difference: a unit whose distance is NaN never wins (`<` semantics), where numpy.argmin
     returns the FIRST NaN unit; a row whose distances are ALL NaN returns unit 0, as numpy.argmin does.  Only a

@@ -1,4 +1,4 @@
-"""precision='bf16x3' against 'f32' and 'bf16' on the configs[2] shard shape (256 x 256 x 128) and on
+"""precision='bf16x3' / 'f16x3' / 'f16' against 'f32' and 'bf16' on the configs[2] shard shape (256 x 256 x 128) and on
 configs[1] (64 x 64 x 32): epoch time, BMU kernel time and agreement with the float32 BMUs."""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
@@ -9,7 +9,7 @@ def run(X, Y, D, N, epochs=3):
     rs = np.random.RandomState(1234); w = rs.rand(X, Y, D) * 2 - 1; w /= np.linalg.norm(w, axis=-1, keepdims=True)
     data = gaussian_blobs(N, D)
     ref = None
-    for prec in ("f32", "bf16x3", "bf16"):
+    for prec in ("f32", "f16x3", "bf16x3", "f16", "bf16"):
         e = HipEngine(X, Y, D, precision=prec)
         e.set_weights(w.astype(np.float32)); e.set_data(data)
         e.epoch_accumulate(min(X, Y) / 2, 0.5, True); e.sync()

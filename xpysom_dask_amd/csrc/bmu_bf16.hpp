@@ -31,6 +31,7 @@ __device__ __forceinline__ void atomic_max_pos_f32(float* addr, float v) {
 }
 
 // |w~|^2 of every unit (bf16-rounded values) and its maximum over the codebook
+template <class E = __bf16>
 __global__ __launch_bounds__(256) void prep_wnorm_kernel(const float* __restrict__ W, int K, int D,
                                                          float* __restrict__ wn, float* __restrict__ wmax2,
                                                          const float* __restrict__ unit_wsq) {
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void prep_wnorm_kernel(const float* __restrict
     if (u < K) {
         float scale = 1.0f;       // cosine: the stage image holds unit-length rows and no norm term
         if (unit_wsq != nullptr) { float q = unit_wsq[u]; scale = q > 0.0f ? 1.0f / __builtin_sqrtf(q) : 0.0f; }
-        for (int k = 0; k < D; ++k) { float f = (float)(__bf16)(W[u * D + k] * scale); s = __builtin_fmaf(f, f, s); }
+        for (int k = 0; k < D; ++k) { float f = (float)(E)(W[u * D + k] * scale); s = __builtin_fmaf(f, f, s); }
         wn[u] = unit_wsq != nullptr ? 0.0f : s;
     }
     float m = s;
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(256) void prep_wsqh_kernel(const float* __restrict_
 
 // samples -> bf16 rows [Np][Dp] (zero padded) and max_n |x~_n|^2.  One wave per row.
 // unit != 0 (cosine): the row is scaled to unit length first (a zero row stays zero).
+template <class E = __bf16>
 __global__ __launch_bounds__(256) void prep_x_bf16_kernel(const float* __restrict__ X, long N, int D, int Dp,
                                                           long Np, __bf16* __restrict__ Xb,
                                                           float* __restrict__ xmax2, int unit) {
@@ -84,8 +86,8 @@ __global__ __launch_bounds__(256) void prep_x_bf16_kernel(const float* __restric
     float s = 0.0f;
     for (int k = lane; k < Dp; k += 64) {
         float f = (row < N && k < D) ? X[row * D + k] * scale : 0.0f;
-        __bf16 b = (__bf16)f;
-        Xb[row * Dp + k] = b;
+        E b = (E)f;
+        ((E*)Xb)[row * Dp + k] = b;
         float fb = (float)b;
         s = __builtin_fmaf(fb, fb, s);
     }

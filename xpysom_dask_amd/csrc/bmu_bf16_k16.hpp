@@ -38,10 +38,11 @@ constexpr int K16_WG_SAMPLES = K16_NW * 16 * K16_SB;
 
 __host__ __device__ constexpr int k16_stage_bytes(int ks32) { return (K16_T * ks32 + 1) * 1024; }
 
-template <int KS32>
+template <int KS32, class E = __bf16>
 __global__ __launch_bounds__(256) void prep_w_bf16_k16_kernel(const float* __restrict__ W, int K, int D,
                                                               char* __restrict__ Wst, int n_stages,
                                                               const float* __restrict__ unit_wsq) {
+    using bf16x8 = typename V8<E>::t;
     long id = (long)blockIdx.x * 256 + threadIdx.x;
     long total = (long)n_stages * K16_T * KS32 * 64;
     if (id >= total) return;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void prep_w_bf16_k16_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float f = (u < K && k0 + j < D) ? W[u * D + k0 + j] * scale : 0.0f;
-        v[j] = (__bf16)(-f);
+        v[j] = (E)(-f);
     }
     *(bf16x8*)(Wst + stage * k16_stage_bytes(KS32) + ((long)(t16 * KS32 + ks) * 64 + lane) * 16) = v;
 }
@@ -72,11 +73,12 @@ __global__ __launch_bounds__(256) void prep_w_bf16_k16_kernel(const float* __res
 // the codebook.  Workgroup = MP_TILES 16-unit tiles, KS32 waves; thread = (unit, 8 features) of each tile, exactly one
 // 16-byte fragment chunk of the image.  W = where(den != 0, num / den, W) as merge_kernel computes it.
 constexpr int MP_TILES = 4;           // 16-unit tiles per workgroup: their loads are all issued before the first is used
-template <int KS32>
+template <int KS32, class E = __bf16>
 __global__ __launch_bounds__(64 * KS32) void merge_prep_k16_kernel(float* __restrict__ W, const float* __restrict__ ACC,
                                                                  int K, int D, int D1p, char* __restrict__ Wst,
                                                                  float* __restrict__ wn, float* __restrict__ wmax2,
                                                                  long n_tiles) {
+    using bf16x8 = typename V8<E>::t;
     __shared__ float red[MP_TILES][KS32][16];
     const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
     const int k0 = ks * 32 + (lane >> 4) * 8;
@@ -136,8 +138,8 @@ __global__ __launch_bounds__(64 * KS32) void merge_prep_k16_kernel(float* __rest
             float s = 0.0f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const __bf16 b = (__bf16)w[i][j];
-                v[j] = (__bf16)(-w[i][j]);                 // (rounding is sign-symmetric: -bf16(w) == bf16(-w))
+                const E b = (E)w[i][j];
+                v[j] = (E)(-w[i][j]);                 // (rounding is sign-symmetric: -bf16(w) == bf16(-w))
                 const float f = (float)b;
                 s = __builtin_fmaf(f, f, s);
             }
@@ -166,10 +168,11 @@ __global__ __launch_bounds__(64 * KS32) void merge_prep_k16_kernel(float* __rest
 #ifndef SOM_K16_MINWAVES
 #define SOM_K16_MINWAVES 2
 #endif
-template <int KS32>
+template <int KS32, class E = __bf16>
 __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
                                                               const char* __restrict__ Wst, int n_stages, int K,
                                                               unsigned long long* __restrict__ out64) {
+    using bf16x8 = typename V8<E>::t;
     constexpr int DP = 32 * KS32;
     constexpr int STAGE = k16_stage_bytes(KS32);
     constexpr int PIECES = K16_T * KS32 + 1;
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
             for (int ks = 0; ks < KS32; ++ks)
 #pragma unroll
                 for (int sb = 0; sb < K16_SB; ++sb)
-                    accT[sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], xf[sb][ks], accT[sb], 0, 0, 0);
+                    accT[sb] = mfma16(a[ks], xf[sb][ks], accT[sb]);
             reduce_tile(accP, (t16 + K16_T - 1) % K16_T);
             if (t16 == 0) fold_stage(s - 1);
 #pragma unroll

@@ -34,10 +34,11 @@ __host__ __device__ constexpr int k3_stage_bytes(int ks32) { return (2 * K3_T * 
 
 // float32 codebook -> hi / lo stage image.  One thread per 16-byte fragment chunk; unit_wsq != nullptr (cosine): rows
 // scaled to unit length first.
-template <int KS32>
+template <int KS32, class E = __bf16>
 __global__ __launch_bounds__(256) void prep_w_bf16_k16x3_kernel(const float* __restrict__ W, int K, int D,
                                                                 char* __restrict__ Wst, int n_stages,
                                                                 const float* __restrict__ unit_wsq) {
+    using bf16x8 = typename V8<E>::t;
     long id = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)n_stages * 2 * K3_T * KS32 * 64;
     if (id >= total) return;
@@ -55,14 +56,15 @@ __global__ __launch_bounds__(256) void prep_w_bf16_k16x3_kernel(const float* __r
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float f = (u < K && k0 + j < D) ? -(W[u * D + k0 + j] * scale) : 0.0f;
-        const __bf16 hi = (__bf16)f;
-        v[j] = part == 0 ? hi : (__bf16)(f - (float)hi);
+        const E hi = (E)f;
+        v[j] = part == 0 ? hi : (E)(f - (float)hi);
     }
     *(bf16x8*)(Wst + stage * k3_stage_bytes(KS32) + ((long)((part * K3_T + t16) * KS32 + ks) * 64 + lane) * 16) = v;
 }
 
 // rows -> [hi | lo] bf16 images (zero padded to Np rows of 2 * Dp) and the maximum of the EXACT float32 |x|^2.
 // One wave per row; unit != 0 (cosine): the row is scaled to unit length first (a zero row stays zero).
+template <class E = __bf16>
 __global__ __launch_bounds__(256) void prep_x_bf16x3_kernel(const float* __restrict__ X, long N, int D, int Dp, long Np,
                                                             __bf16* __restrict__ Xb, float* __restrict__ xmax2, int unit) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -78,19 +80,20 @@ __global__ __launch_bounds__(256) void prep_x_bf16x3_kernel(const float* __restr
     float s = 0.0f;
     for (int k = lane; k < Dp; k += 64) {
         const float f = (row < N && k < D) ? X[row * D + k] * scale : 0.0f;
-        const __bf16 hi = (__bf16)f;
-        Xb[row * 2 * Dp + k] = hi;
-        Xb[row * 2 * Dp + Dp + k] = (__bf16)(f - (float)hi);
+        const E hi = (E)f;
+        ((E*)Xb)[row * 2 * Dp + k] = hi;
+        ((E*)Xb)[row * 2 * Dp + Dp + k] = (E)(f - (float)hi);
         s = __builtin_fmaf(f, f, s);
     }
     s = wave_sum(s);
     if (lane == 0) atomic_max_pos_f32(xmax2, s);
 }
 
-template <int KS32>
+template <int KS32, class E = __bf16>
 __global__ __launch_bounds__(64 * K3_NW, 2) void bmu_bf16_k16x3_kernel(const __bf16* __restrict__ Xb, long N,
                                                                        const char* __restrict__ Wst, int n_stages, int K,
                                                                        unsigned long long* __restrict__ out64) {
+    using bf16x8 = typename V8<E>::t;
     constexpr int DP = 32 * KS32;
     constexpr int STAGE = k3_stage_bytes(KS32);
     constexpr int PIECES = 2 * K3_T * KS32 + 1;
@@ -176,14 +179,14 @@ __global__ __launch_bounds__(64 * K3_NW, 2) void bmu_bf16_k16x3_kernel(const __b
             for (int ks = 0; ks < KS32; ++ks)
 #pragma unroll
                 for (int sb = 0; sb < K3_SB; ++sb) {
-                    accT[sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], xh[sb][ks], accT[sb], 0, 0, 0);
-                    accT[sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], xl[sb][ks], accT[sb], 0, 0, 0);
+                    accT[sb] = mfma16(al[ks], xh[sb][ks], accT[sb]);
+                    accT[sb] = mfma16(ah[ks], xl[sb][ks], accT[sb]);
                 }
 #pragma unroll
             for (int ks = 0; ks < KS32; ++ks)
 #pragma unroll
                 for (int sb = 0; sb < K3_SB; ++sb)
-                    accT[sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], xh[sb][ks], accT[sb], 0, 0, 0);
+                    accT[sb] = mfma16(ah[ks], xh[sb][ks], accT[sb]);
             reduce_tile(accP, (t16 + K3_T - 1) % K3_T);  // the previous tile's keys, under this tile's MFMAs
             if (t16 == 0) fold_stage(s - 1);
 #pragma unroll

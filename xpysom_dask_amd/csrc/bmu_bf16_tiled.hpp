@@ -48,10 +48,12 @@ struct TileCfg {
 // feature axis is tripled -- samples carry [hi | hi | lo], units [hi | lo | hi] -- so the same MFMA
 // contraction yields x_hi.w_hi + x_hi.w_lo + x_lo.w_hi, i.e. x.w to ~2^-16 relative (only lo.lo is
 // dropped) at three times the bf16 work.  split: 0 = plain bf16, 1 = sample pattern, 2 = unit pattern.
+template <class E = __bf16>
 __global__ __launch_bounds__(256) void prep_tiles_bf16_kernel(const float* __restrict__ A, long rows, int D,
                                                               int n_kchunks, long n_blocks, int brows, int tile_bytes,
                                                               float sign, const float* __restrict__ unit_sq,
                                                               char* __restrict__ img, int split) {
+    using bf16x8 = typename V8<E>::t;
     long id = (long)blockIdx.x * 256 + threadIdx.x;
     const int nt16 = brows / 16;
     const long per_block = (long)n_kchunks * nt16 * TL_KS * 64;
@@ -72,13 +74,13 @@ __global__ __launch_bounds__(256) void prep_tiles_bf16_kernel(const float* __res
     for (int j = 0; j < 8; ++j) {
         if (split == 0) {
             float f = (row < rows && k0 + j < D) ? A[row * D + k0 + j] * scale : 0.0f;
-            v[j] = (__bf16)f;
+            v[j] = (E)f;
         } else {
             const int kv = k0 + j, seg = kv / D, k = kv - seg * D;
             float f = (row < rows && seg < 3) ? A[row * D + k] * scale : 0.0f;
-            const __bf16 hi = (__bf16)f;
+            const E hi = (E)f;
             const bool want_lo = split == 1 ? seg == 2 : seg == 1;
-            v[j] = want_lo ? (__bf16)(f - (float)hi) : hi;
+            v[j] = want_lo ? (E)(f - (float)hi) : hi;
         }
     }
     *(bf16x8*)(img + (blk * n_kchunks + kc) * (long)tile_bytes + ((long)(t16 * TL_KS + ks) * 64 + lane) * 16) = v;
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(256) void prep_tiles_bf16_kernel(const float* __res
 
 // |a~_row|^2 of bf16-rounded (optionally unit-scaled) rows and their maximum.  One wave per row.
 // exact != 0 ('bf16x3'): the float32 rows themselves, not their bf16 roundings.
+template <class E = __bf16>
 __global__ __launch_bounds__(256) void rownorm_bf16_kernel(const float* __restrict__ A, long rows, int D,
                                                            const float* __restrict__ unit_sq, int zero_norm,
                                                            float* __restrict__ norm2, float* __restrict__ max2,
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void rownorm_bf16_kernel(const float* __restri
     float s = 0.0f;
     for (int k = lane; k < D; k += 64) {
         float f = A[row * D + k] * scale;
-        if (!exact) f = (float)(__bf16)f;
+        if (!exact) f = (float)(E)f;
         s = __builtin_fmaf(f, f, s);
     }
     s = wave_sum(s);
@@ -123,13 +126,14 @@ __global__ __launch_bounds__(256) void prep_tiles_cin_kernel(const float* __rest
     ((float*)(Wimg + tile * (long)wtile + wfrag))[within] = u < K ? __builtin_fmaf(0.5f, wn[u], big) : BF_PAD_NORM;
 }
 
-template <int WS, int NWR, int NWC>
+template <int WS, int NWR, int NWC, class E = __bf16>
 __global__ __launch_bounds__(64 * NWR * NWC, 2) void bmu_bf16_tiled_kernel(const char* __restrict__ Ximg, long N,
                                                                            const char* __restrict__ Wimg,
                                                                            int n_ublocks, int n_kchunks, int K,
                                                                            unsigned long long* __restrict__ out64,
                                                                            int n_sblocks, int n_parts) {
     using C = TileCfg<WS, NWR, NWC>;
+    using bf16x8 = typename V8<E>::t;
     static_assert(NWR == 2 && TL_KS == 1, "two wave groups (sample halves), one MFMA k-step per stage");
     constexpr int TL_BM = C::BM, TL_BN = C::BN, TL_TILE = C::XTILE, TL_WFRAG = C::WFRAG, TL_WTILE = C::WTILE;
     constexpr int NG = NWC;                                                // waves per group
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, 2) void bmu_bf16_tiled_kernel(const
             for (int tu = 0; tu < 4; ++tu)
 #pragma unroll
                 for (int sb = 0; sb < WS; ++sb)
-                    acc[tu][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tu], fb[sb], acc[tu][sb], 0, 0, 0);
+                    acc[tu][sb] = mfma16(fa[tu], fb[sb], acc[tu][sb]);
             __builtin_amdgcn_s_setprio(0);
             if (kc == n_kchunks - 1) done_ub = ub;
             if (!G1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS_X) : "memory");

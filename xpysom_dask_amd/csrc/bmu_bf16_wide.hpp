@@ -35,9 +35,11 @@ __host__ __device__ constexpr int wd_stage_bytes(int ks32) { return (WD_T * ks32
 
 // codebook -> stage image (the initial accumulators are written by prep_wsqh_kernel: they depend on the row set).
 // split != 0 (precision 'bf16x3', prep_tiles_bf16_kernel): the feature axis is tripled, units carry [hi | lo | hi].
+template <class E = __bf16>
 __global__ __launch_bounds__(256) void prep_w_bf16_wide_kernel(const float* __restrict__ W, int K, int D, int ks32,
                                                                char* __restrict__ Wst, int n_stages,
                                                                const float* __restrict__ unit_wsq, int split) {
+    using bf16x8 = typename V8<E>::t;
     long id = (long)blockIdx.x * 256 + threadIdx.x;
     long total = (long)n_stages * WD_T * ks32 * 64;
     if (id >= total) return;
@@ -55,12 +57,12 @@ __global__ __launch_bounds__(256) void prep_w_bf16_wide_kernel(const float* __re
     for (int j = 0; j < 8; ++j) {
         if (split == 0) {
             float f = (u < K && k0 + j < D) ? W[u * D + k0 + j] * scale : 0.0f;
-            v[j] = (__bf16)(-f);
+            v[j] = (E)(-f);
         } else {
             const int kv = k0 + j, seg = kv / D, k = kv - seg * D;
             float f = (u < K && seg < 3) ? -W[u * D + k] * scale : 0.0f;
-            const __bf16 hi = (__bf16)f;
-            v[j] = seg == 1 ? (__bf16)(f - (float)hi) : hi;
+            const E hi = (E)f;
+            v[j] = seg == 1 ? (E)(f - (float)hi) : hi;
         }
     }
     *(bf16x8*)(Wst + stage * wd_stage_bytes(ks32) + ((long)(t16 * ks32 + ks) * 64 + lane) * 16) = v;
@@ -74,10 +76,12 @@ __global__ __launch_bounds__(256) void prep_w_bf16_wide_kernel(const float* __re
 // thread = (unit, 8 features) of each of its chunks = one 16-byte fragment chunk of the image.  cosine != 0: the
 // image holds the unit-length rows (scale 1/|w|, a zero row stays zero) and |w~|^2 is reported as 0 (rownorm_bf16_kernel).
 constexpr int WD_MP_ITERS = 7;                   // chunks per wave: up to 28 feature chunks (the wide kernel stops at 25)
+template <class E = __bf16>
 __global__ __launch_bounds__(256) void merge_prep_wide_kernel(float* __restrict__ W, const float* __restrict__ ACC, int K,
                                                               int D, int D1p, int ks32, char* __restrict__ Wst,
                                                               float* __restrict__ wn, float* __restrict__ wmax2,
                                                               int cosine) {
+    using bf16x8 = typename V8<E>::t;
     __shared__ float red[2][4][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, quad = lane >> 4;
@@ -144,8 +148,8 @@ __global__ __launch_bounds__(256) void merge_prep_wide_kernel(float* __restrict_
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float f = w[i][j] * scale;
-            const __bf16 b = (__bf16)f;
-            v[j] = (__bf16)(-f);                             // (rounding is sign-symmetric: -bf16(f) == bf16(-f))
+            const E b = (E)f;
+            v[j] = (E)(-f);                             // (rounding is sign-symmetric: -bf16(f) == bf16(-f))
             const float r = (float)b;
             s = __builtin_fmaf(r, r, s);
         }
@@ -166,10 +170,11 @@ __global__ __launch_bounds__(256) void merge_prep_wide_kernel(float* __restrict_
     }
 }
 
-template <int KS32>
+template <int KS32, class E = __bf16>
 __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* __restrict__ Ximg, long N,
                                                                    const char* __restrict__ Wst, int n_stages,
                                                                    unsigned long long* __restrict__ out64) {
+    using bf16x8 = typename V8<E>::t;
     constexpr int STAGE = wd_stage_bytes(KS32);
     constexpr int PIECES = WD_T * KS32;                      // whole 1 KiB pieces; the C-in row follows them
     constexpr int CIN_LANES = WD_STAGE_UNITS * 4 / 16;
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
             for (int t = 0; t < WD_T; ++t)
 #pragma unroll
                 for (int sb = 0; sb < WD_SB; ++sb)
-                    acc[t][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], xf[sb][ks], acc[t][sb], 0, 0, 0);
+                    acc[t][sb] = mfma16(a[t], xf[sb][ks], acc[t][sb]);
         }
 #pragma unroll
         for (int sb = 0; sb < WD_SB; ++sb) {

@@ -4,11 +4,21 @@
 #include <stdint.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 #define SOM_WAVE 64
+
+// The 16-bit operand type of the half-precision BMU kernels: __bf16 (precision 'bf16' / 'bf16x3') or _Float16
+// ('f16' / 'f16x3': three more mantissa bits at the same MFMA rate, range 6e-8 .. 65504).  The kernels are templates on
+// it; their operand images are the same bytes either way.
+template <class E> struct V8;
+template <> struct V8<__bf16> { typedef bf16x8 t; };
+template <> struct V8<_Float16> { typedef f16x8 t; };
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 // C/D register -> row of a 32x32 MFMA accumulator tile (dtype independent on gfx950):
 // lane l holds column l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15.

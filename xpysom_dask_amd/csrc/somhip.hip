@@ -62,7 +62,8 @@ struct som_handle {
     int X = 0, Y = 0, K = 0, D = 0, D1p = 0;
     int ks32 = 0;            // bf16, 16x16x32 shape: ceil(D/32)
     bool tiled = false;      // bf16, input_len > 128 (and bf16x3 always): two-sided tiling (bmu_bf16_tiled.hpp)
-    int x3 = 0;              // precision bf16x3: hi/lo split operands, tripled feature axis
+    int x3 = 0;              // precision bf16x3 / f16x3: hi/lo split operands, tripled feature axis
+    bool f16 = false;        // precision f16 / f16x3: _Float16 operands instead of __bf16 (the same kernels, som_common.hpp)
     bool x3res = false;      // bf16x3 with input_len <= 128: the register-resident split kernel (bmu_bf16_k16x3.hpp)
     int n_kchunks = 0;       // tiled: 64-feature chunks
     int n_ublocks = 0;       // tiled: unit blocks of tl_bn
@@ -248,6 +249,7 @@ int kernel_per_cu(som_handle* h, const void* fn, int threads, size_t lds, int* p
 
 inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 inline long round_up(long a, long b) { return cdiv(a, b) * b; }
+constexpr float HALF_MAX = 65504.0f;   // largest finite _Float16
 constexpr long ROW_PAD = 3072;   // bf16 row images are padded to a multiple of every kernel's workgroup tile
 
 // ---- profiling: event pairs recorded around kernel families, resolved lazily ---------------
@@ -281,22 +283,68 @@ int resolve_profile(som_handle* h) {
     return 0;
 }
 
-// ---- codebook-derived operands (w_sq cache, xpysom.py:529-537; bf16 stage image) ------------
-template <int KS32>
-void launch_prep_w_k16(som_handle* h) {
-    long total = (long)h->n_stages * K16_T * KS32 * 64;
-    prep_w_bf16_k16_kernel<KS32><<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
-        h->W, h->K, h->D, h->Wst, h->n_stages, h->cfg.distance == SOM_DIST_COSINE ? h->wsq : nullptr);
-}
+// ---- codebook-derived operands (w_sq cache, xpysom.py:529-537; bf16 / f16 stage image) -----
+// The half-precision paths are templates on the operand type E (__bf16 or _Float16, som_common.hpp); SOM_HALF picks
+// the instance from the handle.
+#define SOM_HALF(h, fn, ...) ((h)->f16 ? fn<_Float16>(__VA_ARGS__) : fn<__bf16>(__VA_ARGS__))
 
 void mark_codebook_changed(som_handle* h) { h->w_dirty = h->wsq_dirty = h->wf_dirty = true; }
+
+// the 16-bit operand images of the codebook: stage / tile image, |w~|^2 per unit and its maximum
+template <class E>
+int prep_codebook_half(som_handle* h) {
+    const float* unit = h->cfg.distance == SOM_DIST_COSINE ? h->wsq : nullptr;
+    const dim3 block(256);
+    if (h->tiled) {
+        if (h->wide) {
+            long total = (long)h->n_stages * WD_T * h->n_kchunks * 64;
+            prep_w_bf16_wide_kernel<E><<<dim3((unsigned)cdiv(total, 256)), block, 0, h->stream>>>(
+                h->W, h->K, h->D, h->n_kchunks, h->Wst, h->n_stages, unit, h->x3 ? 1 : 0);
+        } else {
+            long total = (long)h->n_ublocks * h->n_kchunks * (h->tl_bn / 16) * TL_KS * 64;
+            prep_tiles_bf16_kernel<E><<<dim3((unsigned)cdiv(total, 256)), block, 0, h->stream>>>(
+                h->W, h->K, h->D, h->n_kchunks, h->n_ublocks, h->tl_bn, h->tl_wtile, -1.0f, unit, h->Wst, h->x3 ? 2 : 0);
+        }
+        HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
+        rownorm_bf16_kernel<E><<<dim3((unsigned)cdiv(h->K, 4)), block, 0, h->stream>>>(
+            h->W, h->K, h->D, unit, unit != nullptr, h->wn, h->wmax2, h->x3);
+        return 0;
+    }
+    if (h->x3res) {
+        const long total = (long)h->n_stages * 2 * K3_T * h->ks32 * 64;
+        const dim3 grid((unsigned)cdiv(total, 256));
+        switch (h->ks32) {
+        case 1: prep_w_bf16_k16x3_kernel<1, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
+        case 2: prep_w_bf16_k16x3_kernel<2, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
+        case 3: prep_w_bf16_k16x3_kernel<3, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
+        case 4: prep_w_bf16_k16x3_kernel<4, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
+        default: return fail(h, "the split resident kernel supports input_len <= 128");
+        }
+        HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
+        rownorm_bf16_kernel<E><<<dim3((unsigned)cdiv(h->K, 4)), block, 0, h->stream>>>(   // exact float32 |w|^2
+            h->W, h->K, h->D, unit, unit != nullptr, h->wn, h->wmax2, 1);
+        return 0;
+    }
+    const long total = (long)h->n_stages * K16_T * h->ks32 * 64;
+    const dim3 grid((unsigned)cdiv(total, 256));
+    switch (h->ks32) {
+    case 1: prep_w_bf16_k16_kernel<1, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
+    case 2: prep_w_bf16_k16_kernel<2, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
+    case 3: prep_w_bf16_k16_kernel<3, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
+    case 4: prep_w_bf16_k16_kernel<4, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
+    default: return fail(h, "the resident half-precision kernel supports input_len <= 128");
+    }
+    HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
+    prep_wnorm_kernel<E><<<dim3((unsigned)cdiv(h->K, 256)), block, 0, h->stream>>>(h->W, h->K, h->D, h->wn, h->wmax2, unit);
+    return 0;
+}
 
 // need_f32: the caller is about to run a float32 kernel (parity-mode BMU, top-2, distance matrix).
 int refresh_codebook_operands(som_handle* h, bool need_f32) {
     const bool bf = h->cfg.precision != SOM_PREC_F32;
     const bool do_f32 = (need_f32 || !bf) && h->wf_dirty;
     const bool do_bf = bf && h->w_dirty;
-    // (cosine scales the bf16 images by 1/|w|: |w|^2 is wanted whenever they are rebuilt)
+    // (cosine scales the 16-bit images by 1/|w|: |w|^2 is wanted whenever they are rebuilt)
     const bool do_wsq = h->wsq_dirty && (need_f32 || !bf || (do_bf && h->cfg.distance == SOM_DIST_COSINE));
     if (!do_f32 && !do_wsq && !do_bf) return 0;
     Timed t(h, SOM_K_PREP);
@@ -317,62 +365,11 @@ int refresh_codebook_operands(som_handle* h, bool need_f32) {
         }
         h->wf_dirty = false;
     }
-    if (!do_bf) {
-        HIPCHK(h, hipGetLastError());
-        return 0;
-    }
-    if (h->cfg.precision != SOM_PREC_F32 && h->tiled) {
-        const float* unit = h->cfg.distance == SOM_DIST_COSINE ? h->wsq : nullptr;
-        if (h->wide) {
-            long total = (long)h->n_stages * WD_T * h->n_kchunks * 64;
-            prep_w_bf16_wide_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
-                h->W, h->K, h->D, h->n_kchunks, h->Wst, h->n_stages, unit, h->x3 ? 1 : 0);
-        } else {
-            long total = (long)h->n_ublocks * h->n_kchunks * (h->tl_bn / 16) * TL_KS * 64;
-            prep_tiles_bf16_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
-                h->W, h->K, h->D, h->n_kchunks, h->n_ublocks, h->tl_bn, h->tl_wtile, -1.0f, unit, h->Wst, h->x3 ? 2 : 0);
-        }
-        HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
-        rownorm_bf16_kernel<<<dim3((unsigned)cdiv(h->K, 4)), dim3(256), 0, h->stream>>>(
-            h->W, h->K, h->D, unit, unit != nullptr, h->wn, h->wmax2, h->x3);
-        HIPCHK(h, hipGetLastError());
+    if (do_bf) {
+        if (int rc = SOM_HALF(h, prep_codebook_half, h)) return rc;
         h->w_dirty = false;
-        return 0;
-    }
-    if (h->x3res) {
-        const float* unit = h->cfg.distance == SOM_DIST_COSINE ? h->wsq : nullptr;
-        const long total = (long)h->n_stages * 2 * K3_T * h->ks32 * 64;
-        const dim3 grid((unsigned)cdiv(total, 256)), block(256);
-        switch (h->ks32) {
-        case 1: prep_w_bf16_k16x3_kernel<1><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
-        case 2: prep_w_bf16_k16x3_kernel<2><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
-        case 3: prep_w_bf16_k16x3_kernel<3><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
-        case 4: prep_w_bf16_k16x3_kernel<4><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
-        default: return fail(h, "bf16x3 resident kernel supports input_len <= 128");
-        }
-        HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
-        rownorm_bf16_kernel<<<dim3((unsigned)cdiv(h->K, 4)), dim3(256), 0, h->stream>>>(   // exact float32 |w|^2
-            h->W, h->K, h->D, unit, unit != nullptr, h->wn, h->wmax2, 1);
-        HIPCHK(h, hipGetLastError());
-        h->w_dirty = false;
-        return 0;
-    }
-    if (h->cfg.precision != SOM_PREC_F32) {
-        switch (h->ks32) {
-        case 1: launch_prep_w_k16<1>(h); break;
-        case 2: launch_prep_w_k16<2>(h); break;
-        case 3: launch_prep_w_k16<3>(h); break;
-        case 4: launch_prep_w_k16<4>(h); break;
-        default: return fail(h, "bf16 precision supports input_len <= 128");
-        }
-    }
-    if (h->cfg.precision != SOM_PREC_F32) {
-        HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
-        prep_wnorm_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(
-            h->W, h->K, h->D, h->wn, h->wmax2, h->cfg.distance == SOM_DIST_COSINE ? h->wsq : nullptr);
     }
     HIPCHK(h, hipGetLastError());
-    h->w_dirty = false;
     return 0;
 }
 
@@ -488,11 +485,11 @@ int choose_parts(som_handle* h, long blocks, long slots, int max_parts_hint) {
     return parts;
 }
 
-template <int KS32>
+template <int KS32, class E>
 int launch_bmu_bf16_k16(som_handle* h, const __bf16* Xb, long N, int* out) {
     size_t lds = 2 * (size_t)k16_stage_bytes(KS32);
     int per_cu = 1;
-    if (int rc = kernel_per_cu(h, (const void*)bmu_bf16_k16_kernel<KS32>, 64 * K16_NW, lds, &per_cu)) return rc;
+    if (int rc = kernel_per_cu(h, (const void*)bmu_bf16_k16_kernel<KS32, E>, 64 * K16_NW, lds, &per_cu)) return rc;
     long blocks = cdiv(N, K16_WG_SAMPLES);
     if (blocks <= 0 || blocks > 0x7fffffffL) return fail(h, "bmu_bf16: row count out of range");
     // split the codebook scan into `parts` so the grid fills whole rounds of resident workgroups
@@ -503,18 +500,18 @@ int launch_bmu_bf16_k16(som_handle* h, const __bf16* Xb, long N, int* out) {
         std::fprintf(stderr, "[somhip] bmu_bf16_k16: blocks=%ld per_cu=%d cus=%d slots=%ld parts=%d stages=%d\n", blocks,
                      per_cu, h->n_cus, slots, parts, h->n_stages);
     // (best64[0..N) was reset by prep_wsqh_kernel, launch_bmu_bf16)
-    bmu_bf16_k16_kernel<KS32><<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * K16_NW), lds, h->stream>>>(
+    bmu_bf16_k16_kernel<KS32, E><<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * K16_NW), lds, h->stream>>>(
         Xb, N, h->Wst, h->n_stages, h->K, h->best64);
     bmu_finalize_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(h->best64, N, h->K, out);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
 
-template <int KS32>
+template <int KS32, class E>
 int launch_bmu_bf16_k16x3(som_handle* h, const __bf16* Xb, long N, int* out) {
     size_t lds = 2 * (size_t)k3_stage_bytes(KS32);
     int per_cu = 1;
-    if (int rc = kernel_per_cu(h, (const void*)bmu_bf16_k16x3_kernel<KS32>, 64 * K3_NW, lds, &per_cu)) return rc;
+    if (int rc = kernel_per_cu(h, (const void*)bmu_bf16_k16x3_kernel<KS32, E>, 64 * K3_NW, lds, &per_cu)) return rc;
     long blocks = cdiv(N, K3_WG_SAMPLES);
     if (blocks <= 0 || blocks > 0x7fffffffL) return fail(h, "bmu_bf16x3: row count out of range");
     const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
@@ -524,17 +521,17 @@ int launch_bmu_bf16_k16x3(som_handle* h, const __bf16* Xb, long N, int* out) {
         std::fprintf(stderr, "[somhip] bmu_bf16_k16x3: blocks=%ld per_cu=%d slots=%ld parts=%d stages=%d\n", blocks, per_cu, slots,
                      parts, h->n_stages);
     // (best64[0..N) was reset by prep_wsqh_kernel, launch_bmu_bf16)
-    bmu_bf16_k16x3_kernel<KS32><<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * K3_NW), lds, h->stream>>>(
+    bmu_bf16_k16x3_kernel<KS32, E><<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * K3_NW), lds, h->stream>>>(
         Xb, N, h->Wst, h->n_stages, h->K, h->best64);
     bmu_finalize_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(h->best64, N, h->K, out);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
 
-template <int WS, int NWR, int NWC>
+template <int WS, int NWR, int NWC, class E>
 int launch_bmu_bf16_tiled_cfg(som_handle* h, const __bf16* Ximg, long N, int* out) {
     using C = TileCfg<WS, NWR, NWC>;
-    auto kern = bmu_bf16_tiled_kernel<WS, NWR, NWC>;
+    auto kern = bmu_bf16_tiled_kernel<WS, NWR, NWC, E>;
     size_t lds = (size_t)C::LDS_BYTES;
     int per_cu = 1;
     if (int rc = kernel_per_cu(h, (const void*)kern, 64 * C::WAVES, lds, &per_cu)) return rc;
@@ -562,9 +559,9 @@ int launch_bmu_bf16_tiled_cfg(som_handle* h, const __bf16* Ximg, long N, int* ou
     return 0;
 }
 
-template <int KS32>
+template <int KS32, class E>
 int launch_bmu_bf16_wide(som_handle* h, const __bf16* Ximg, const float* xmax2, long N, int* out) {
-    auto kern = bmu_bf16_wide_kernel<KS32>;
+    auto kern = bmu_bf16_wide_kernel<KS32, E>;
     const size_t lds = (size_t)WD_SLOTS * wd_stage_bytes(KS32);
     int per_cu = 1;
     if (int rc = kernel_per_cu(h, (const void*)kern, 64 * WD_NW, lds, &per_cu)) return rc;
@@ -604,10 +601,11 @@ int launch_bmu_bf16_wide(som_handle* h, const __bf16* Ximg, const float* xmax2, 
     return 0;
 }
 
+template <class E>
 int launch_bmu_bf16_tiled(som_handle* h, const __bf16* Ximg, const float* xmax2, long N, int* out) {
     if (h->wide) {
         switch (h->n_kchunks) {
-#define SOM_WIDE_CASE(n) case n: return launch_bmu_bf16_wide<n>(h, Ximg, xmax2, N, out);
+#define SOM_WIDE_CASE(n) case n: return launch_bmu_bf16_wide<n, E>(h, Ximg, xmax2, N, out);
         SOM_WIDE_CASE(5) SOM_WIDE_CASE(6) SOM_WIDE_CASE(7) SOM_WIDE_CASE(8) SOM_WIDE_CASE(9) SOM_WIDE_CASE(10)
         SOM_WIDE_CASE(11) SOM_WIDE_CASE(12) SOM_WIDE_CASE(13) SOM_WIDE_CASE(14) SOM_WIDE_CASE(15) SOM_WIDE_CASE(16)
         SOM_WIDE_CASE(17) SOM_WIDE_CASE(18) SOM_WIDE_CASE(19) SOM_WIDE_CASE(20) SOM_WIDE_CASE(21) SOM_WIDE_CASE(22)
@@ -619,12 +617,13 @@ int launch_bmu_bf16_tiled(som_handle* h, const __bf16* Ximg, const float* xmax2,
     long cin = (long)h->n_ublocks * h->n_kchunks * h->tl_bn;
     prep_tiles_cin_kernel<<<dim3((unsigned)cdiv(cin, 256)), dim3(256), 0, h->stream>>>(
         h->wn, h->K, h->wmax2, xmax2, h->n_kchunks, h->n_ublocks, h->tl_bn, h->tl_wfrag, h->tl_wtile, h->Wst);
-    if (h->tl_big) return launch_bmu_bf16_tiled_cfg<8, 2, 4>(h, Ximg, N, out);
-    return launch_bmu_bf16_tiled_cfg<4, 2, 2>(h, Ximg, N, out);
+    if (h->tl_big) return launch_bmu_bf16_tiled_cfg<8, 2, 4, E>(h, Ximg, N, out);
+    return launch_bmu_bf16_tiled_cfg<4, 2, 2, E>(h, Ximg, N, out);
 }
 
-int launch_bmu_bf16(som_handle* h, const __bf16* Xb, const float* xmax2, long N, int* out) {
-    if (h->tiled) return launch_bmu_bf16_tiled(h, Xb, xmax2, N, out);
+template <class E>
+int launch_bmu_half(som_handle* h, const __bf16* Xb, const float* xmax2, long N, int* out) {
+    if (h->tiled) return launch_bmu_bf16_tiled<E>(h, Xb, xmax2, N, out);
     // the stage image's initial accumulators depend on the row set through B = xmax * wmax; the same launch
     // resets the per-row merge keys of the 16x16x32 kernel
     long units = (long)h->n_stages * h->stage_units;
@@ -638,26 +637,31 @@ int launch_bmu_bf16(som_handle* h, const __bf16* Xb, const float* xmax2, long N,
         h->wn, h->K, h->wmax2, xmax2, h->Wst, h->n_stages, h->stage_bytes, h->stage_units, h->best64, N);
     if (h->x3res) {
         switch (h->ks32) {
-        case 1: return launch_bmu_bf16_k16x3<1>(h, Xb, N, out);
-        case 2: return launch_bmu_bf16_k16x3<2>(h, Xb, N, out);
-        case 3: return launch_bmu_bf16_k16x3<3>(h, Xb, N, out);
-        case 4: return launch_bmu_bf16_k16x3<4>(h, Xb, N, out);
+        case 1: return launch_bmu_bf16_k16x3<1, E>(h, Xb, N, out);
+        case 2: return launch_bmu_bf16_k16x3<2, E>(h, Xb, N, out);
+        case 3: return launch_bmu_bf16_k16x3<3, E>(h, Xb, N, out);
+        case 4: return launch_bmu_bf16_k16x3<4, E>(h, Xb, N, out);
         }
         return fail(h, "bf16x3 resident kernel supports input_len <= 128");
     }
     switch (h->ks32) {
-    case 1: return launch_bmu_bf16_k16<1>(h, Xb, N, out);
-    case 2: return launch_bmu_bf16_k16<2>(h, Xb, N, out);
-    case 3: return launch_bmu_bf16_k16<3>(h, Xb, N, out);
-    case 4: return launch_bmu_bf16_k16<4>(h, Xb, N, out);
+    case 1: return launch_bmu_bf16_k16<1, E>(h, Xb, N, out);
+    case 2: return launch_bmu_bf16_k16<2, E>(h, Xb, N, out);
+    case 3: return launch_bmu_bf16_k16<3, E>(h, Xb, N, out);
+    case 4: return launch_bmu_bf16_k16<4, E>(h, Xb, N, out);
     }
     return fail(h, "bf16 precision supports input_len <= 128");
+}
+
+int launch_bmu_bf16(som_handle* h, const __bf16* Xb, const float* xmax2, long N, int* out) {
+    return SOM_HALF(h, launch_bmu_half, h, Xb, xmax2, N, out);
 }
 
 // rows -> bf16 operand image (+ max |x~|^2 for the offset B).  Cosine: the rows go in at unit length -- the
 // argmin does not depend on |x|, and B = max|x~| max|w~| then resolves every row alike (a short row next to
 // long ones would otherwise be compared at B's absolute precision).  xsq_scratch: N floats, cosine + tiled only.
-int prep_rows_bf16(som_handle* h, const float* X, long N, long Np, __bf16* Xb, float* xmax2, float* xsq_scratch) {
+template <class E>
+int prep_rows_half(som_handle* h, const float* X, long N, long Np, __bf16* Xb, float* xmax2, float* xsq_scratch) {
     const int Dp = h->dp;
     const bool unit = h->cfg.distance == SOM_DIST_COSINE;
     HIPCHK(h, hipMemsetAsync(xmax2, 0, sizeof(float), h->stream));
@@ -670,20 +674,47 @@ int prep_rows_bf16(som_handle* h, const float* X, long N, long Np, __bf16* Xb, f
         }
         long n_blocks = Np / h->tl_bm;
         long total = n_blocks * h->n_kchunks * (h->tl_bm / 16) * TL_KS * 64;
-        prep_tiles_bf16_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
+        prep_tiles_bf16_kernel<E><<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
             X, N, h->D, h->n_kchunks, n_blocks, h->tl_bm, h->tl_xtile, 1.0f, usq, (char*)Xb, h->x3 ? 1 : 0);
         if (N > 0)
-            rownorm_bf16_kernel<<<dim3((unsigned)cdiv(N, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, usq, 0, nullptr, xmax2,
+            rownorm_bf16_kernel<E><<<dim3((unsigned)cdiv(N, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, usq, 0, nullptr, xmax2,
                                                                                         h->x3);
         HIPCHK(h, hipGetLastError());
         return 0;
     }
     if (h->x3res)
-        prep_x_bf16x3_kernel<<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, 32 * h->ks32, Np, Xb, xmax2,
+        prep_x_bf16x3_kernel<E><<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, 32 * h->ks32, Np, Xb, xmax2,
                                                                                        unit ? 1 : 0);
     else
-        prep_x_bf16_kernel<<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, Dp, Np, Xb, xmax2, unit ? 1 : 0);
+        prep_x_bf16_kernel<E><<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, Dp, Np, Xb, xmax2, unit ? 1 : 0);
     HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int prep_rows_bf16(som_handle* h, const float* X, long N, long Np, __bf16* Xb, float* xmax2, float* xsq_scratch) {
+    return SOM_HALF(h, prep_rows_half, h, X, N, Np, Xb, xmax2, xsq_scratch);
+}
+
+// single-pass half precision ('bf16' or 'f16'), as opposed to the hi/lo split modes
+inline bool is_half1(const som_handle* h) { return h->cfg.precision == SOM_PREC_BF16 || h->cfg.precision == SOM_PREC_F16; }
+
+template <class E>
+int merge_prep_half(som_handle* h) {
+    HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
+    if (h->wide) {
+        merge_prep_wide_kernel<E><<<dim3((unsigned)(h->n_stages * WD_T)), dim3(256), 0, h->stream>>>(
+            h->W, h->ACC, h->K, h->D, h->D1p, h->n_kchunks, h->Wst, h->wn, h->wmax2, h->cfg.distance == SOM_DIST_COSINE);
+        return 0;
+    }
+    const long n_tiles = (long)h->n_stages * K16_T;
+    const dim3 grid((unsigned)cdiv(n_tiles, MP_TILES));
+    switch (h->ks32) {
+    case 1: merge_prep_k16_kernel<1, E><<<grid, dim3(64), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2, n_tiles); break;
+    case 2: merge_prep_k16_kernel<2, E><<<grid, dim3(128), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2, n_tiles); break;
+    case 3: merge_prep_k16_kernel<3, E><<<grid, dim3(192), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2, n_tiles); break;
+    case 4: merge_prep_k16_kernel<4, E><<<grid, dim3(256), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2, n_tiles); break;
+    default: return fail(h, "the resident half-precision kernel supports input_len <= 128");
+    }
     return 0;
 }
 
@@ -1037,7 +1068,7 @@ int som_create(const som_config* cfg, som_handle** out) {
         return fail(nullptr, "som_create: unknown topology id");
     if (cfg->topology == SOM_TOPO_HEXAGONAL && cfg->neighborhood == SOM_NEIGH_TRIANGLE)
         return fail(nullptr, "som_create: the hexagonal topology has no triangle neighbourhood (xpysom.py:271-279)");
-    if (cfg->precision != SOM_PREC_F32 && cfg->precision != SOM_PREC_BF16 && cfg->precision != SOM_PREC_BF16X3)
+    if (cfg->precision < SOM_PREC_F32 || cfg->precision > SOM_PREC_F16X3)
         return fail(nullptr, "som_create: unknown precision id");
     if (cfg->precision != SOM_PREC_F32) {
         if (cfg->distance == SOM_DIST_EUCLIDEAN_NO_OPT)
@@ -1055,10 +1086,11 @@ int som_create(const som_config* cfg, som_handle** out) {
     h->D1p = (int)round_up(h->D + 1, 4);
     h->norm_p = cfg->norm_p > 0 ? cfg->norm_p : 2;
     h->ks32 = (int)cdiv(h->D, 32);
-    h->x3 = cfg->precision == SOM_PREC_BF16X3;
+    h->x3 = cfg->precision == SOM_PREC_BF16X3 || cfg->precision == SOM_PREC_F16X3;
+    h->f16 = cfg->precision == SOM_PREC_F16 || cfg->precision == SOM_PREC_F16X3;
     h->x3res = h->x3 && h->D <= 128;
     if (const char* e = std::getenv("SOM_X3_TILED")) if (std::atoi(e) != 0) h->x3res = false;   // A/B: the tiled split kernel
-    h->tiled = (cfg->precision == SOM_PREC_BF16 && h->D > 128) || (h->x3 && !h->x3res);
+    h->tiled = ((cfg->precision == SOM_PREC_BF16 || cfg->precision == SOM_PREC_F16) && h->D > 128) || (h->x3 && !h->x3res);
     if (h->tiled) {
         // 256 x 256 tiles need enough units to amortise them; SOM_BF16_TILE=128|256 overrides
         h->tl_big = h->K >= 4096;
@@ -1188,6 +1220,13 @@ void som_destroy(som_handle* h) {
 int som_set_weights(som_handle* h, const float* w_host) {
     DeviceGuard dev_guard(h);
     if (!h || !w_host) return fail(h, "som_set_weights: NULL argument");
+    if (h->f16 && h->cfg.distance != SOM_DIST_COSINE) {   // (cosine rounds unit-length rows)
+        const size_t n = (size_t)h->K * h->D;
+        float m = 0.0f;
+        for (size_t i = 0; i < n; ++i) { const float a = std::fabs(w_host[i]); if (a > m && a <= 3.0e38f) m = a; }   // finite values only
+        if (!(m * std::sqrt((float)h->D) <= HALF_MAX))
+            return fail(h, "som_set_weights: precision 'f16' needs units of norm <= 65504 (float16 range): scale the data, or use 'bf16' / 'f32'");
+    }
     if (int rc = h2d_blocking(h, h->W, w_host, (size_t)h->K * h->D * sizeof(float))) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     mark_codebook_changed(h);
@@ -1220,6 +1259,12 @@ static int adopt_rows(som_handle* h, int64_t n_rows) {
         if (int rc = prep_rows_bf16(h, h->Xd, n_rows, h->Np, h->Xb, h->xmax2, h->xsq)) return rc;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->f16 && n_rows > 0) {                          // IEEE half tops out at 65504: refuse rows that do not fit
+        float m2 = 0.0f;
+        if (int rc = d2h_blocking(h, &m2, h->xmax2, sizeof(float))) return rc;
+        if (!(m2 <= HALF_MAX * HALF_MAX))
+            return fail(h, "som_set_data: precision 'f16' needs rows of norm <= 65504 (float16 range): scale the data, or use 'bf16' / 'f32'");
+    }
     return 0;
 }
 
@@ -1479,32 +1524,14 @@ int som_epoch_merge(som_handle* h) {
     DeviceGuard dev_guard(h);
     if (!h) return 1;
     Timed t(h, SOM_K_MERGE);
-    // the headline path (bf16, input_len <= 128, euclidean): the merge also writes the next epoch's bf16 operands
-    if (h->cfg.precision == SOM_PREC_BF16 && !h->tiled && h->cfg.distance == SOM_DIST_EUCLIDEAN &&
-        h->fuse_merge_prep) {
-        HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
-        const long n_tiles = (long)h->n_stages * K16_T;
-        const dim3 grid((unsigned)cdiv(n_tiles, MP_TILES));
-        switch (h->ks32) {
-        case 1: merge_prep_k16_kernel<1><<<grid, dim3(64), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2, n_tiles); break;
-        case 2: merge_prep_k16_kernel<2><<<grid, dim3(128), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2, n_tiles); break;
-        case 3: merge_prep_k16_kernel<3><<<grid, dim3(192), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2, n_tiles); break;
-        case 4: merge_prep_k16_kernel<4><<<grid, dim3(256), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p, h->Wst, h->wn, h->wmax2, n_tiles); break;
-        default: return fail(h, "bf16 precision supports input_len <= 128");
-        }
+    // the half-precision paths whose operand image is a stage image (resident kernel, euclidean; wide kernel,
+    // euclidean and cosine): the merge also writes the next epoch's 16-bit operands
+    if (h->fuse_merge_prep && ((is_half1(h) && !h->tiled && h->cfg.distance == SOM_DIST_EUCLIDEAN) ||
+                               (h->wide && !h->x3 && h->n_kchunks <= 4 * WD_MP_ITERS))) {
+        if (int rc = SOM_HALF(h, merge_prep_half, h)) return rc;
         HIPCHK(h, hipGetLastError());
         mark_codebook_changed(h);
-        h->w_dirty = false;                              // the bf16 stage image and |w~|^2 are already the new codebook's
-        return 0;
-    }
-    // the wide path (bf16, 128 < input_len <= 800, big maps; euclidean and cosine) likewise
-    if (h->wide && !h->x3 && h->fuse_merge_prep && h->n_kchunks <= 4 * WD_MP_ITERS) {
-        HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
-        merge_prep_wide_kernel<<<dim3((unsigned)(h->n_stages * WD_T)), dim3(256), 0, h->stream>>>(
-            h->W, h->ACC, h->K, h->D, h->D1p, h->n_kchunks, h->Wst, h->wn, h->wmax2, h->cfg.distance == SOM_DIST_COSINE);
-        HIPCHK(h, hipGetLastError());
-        mark_codebook_changed(h);
-        h->w_dirty = false;
+        h->w_dirty = false;                              // the stage image and |w~|^2 are already the new codebook's
         return 0;
     }
     long total = (long)h->K * h->D;

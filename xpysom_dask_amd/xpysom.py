@@ -85,8 +85,10 @@ class XPySom:
         ``xp``, ``use_dask`` and ``dask_chunks`` are accepted for source compatibility and
         ignored: there is one backend (HIP) and multi-GPU runs use torch.distributed, not Dask.
         Extra keyword-only arguments:
-          precision      'f32' (exact-float32 MFMA, parity mode), 'bf16' (bf16 MFMA distance GEMM) or
-                         'bf16x3' (hi/lo-split bf16 MFMA: near-float32 BMUs at a third of the bf16 rate)
+          precision      'f32' (exact-float32 MFMA, parity mode), 'bf16' (bf16 MFMA distance GEMM),
+                         'bf16x3' (hi/lo-split bf16 MFMA: near-float32 BMUs at a third of the bf16 rate), or the
+                         same two paths on IEEE half operands, 'f16' / 'f16x3' (three more mantissa bits at the
+                         same MFMA rate; rows and units must fit float16: norms <= 65504)
           device         HIP device ordinal (default: LOCAL_RANK or 0)
           sharded_input  under an initialised process group: ``train(data)`` receives only this
                          rank's rows (default: every rank passes the full array and takes its slice)
@@ -139,8 +141,8 @@ class XPySom:
         if not DISTANCES[activation_distance]:
             raise NotImplementedError("activation_distance '%s' is not in the HIP engine yet "
                                       "(SURVEY 8(f) rank 3)" % activation_distance)
-        if precision not in ('f32', 'bf16', 'bf16x3'):
-            raise ValueError("precision must be 'f32', 'bf16' or 'bf16x3'")
+        if precision not in ('f32', 'bf16', 'bf16x3', 'f16', 'f16x3'):
+            raise ValueError("precision must be 'f32', 'bf16', 'bf16x3', 'f16' or 'f16x3'")
         # what som_create would refuse is refused here, at construction, as the reference raises at
         # construction (the engine itself is created lazily, on the first train() / winner())
         if neighborhood_function == 'mexican_hat' and compact_support and topology == 'rectangular' and x != y:
