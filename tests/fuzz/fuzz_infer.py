@@ -16,7 +16,7 @@ for case in range(n_cases):
     X, Y = int(rs.randint(2, side)), int(rs.randint(2, side))
     D = int(rs.choice([1, 2, 5, 16, 33, 64, 128, 130, 300]))
     n = int(rs.choice([1, 2, 17, 256, 1000, 3001]))
-    prec = str(rs.choice(["f32", "f32", "bf16x3", "bf16"]))
+    prec = str(rs.choice(["f32", "f32", "bf16x3", "bf16", "f16", "f16x3"]))
     dist = str(rs.choice(["euclidean", "cosine"])) if prec != "f32" else str(rs.choice(["euclidean", "cosine", "euclidean_no_opt", "manhattan"]))
     data = O.gaussian_blobs(n, D, seed=case + 5)
     if dist == "cosine":
@@ -28,7 +28,7 @@ for case in range(n_cases):
         som._weights = w
         wf = w.reshape(-1, D)
         x64, w64 = data.astype(np.float64), wf.astype(np.float64)
-        tol = {"f32": 2.0 ** -18, "bf16x3": 2.0 ** -14, "bf16": 2.0 ** -6}[prec]
+        tol = {"f32": 2.0 ** -18, "bf16x3": 2.0 ** -14, "bf16": 2.0 ** -6, "f16": 2.0 ** -9, "f16x3": 2.0 ** -14}[prec]
         # winner: configured distance
         ids = np.array([i * Y + j for i, j in som.winner(data)])
         if dist == "cosine":
@@ -50,7 +50,7 @@ for case in range(n_cases):
         qe, oqe = som.quantization_error(data), O.quantization_error(data, w)
         # bf16 modes: the pick is near-best in d^2 to eps |x||w|; a dense codebook (1 feature, hundreds of units) turns
         # that into a visible relative change of the tiny distances themselves
-        qtol = 1e-5 if prec == "f32" else (2e-3 if prec == "bf16x3" else 5e-2)
+        qtol = 1e-5 if prec == "f32" else (2e-3 if prec.endswith("x3") else 5e-2)
         if (prec == "f32" or n >= 17) and abs(qe - oqe) > qtol * max(oqe, 1e-6): msgs.append("QE %.7f vs %.7f" % (qe, oqe))
         q = som.quantization(data)
         if q.shape != data.shape or not np.isfinite(q).all(): msgs.append("quantization shape/finite")
