@@ -22,7 +22,7 @@ for case in range(n_cases):
     dist = str(rs.choice(["euclidean", "euclidean", "cosine", "euclidean_no_opt"]))
     sigma = float(rs.choice([0, 1.5, 3.0])) or min(X, Y) / 2
     lr = float(rs.choice([0.5, 0.1, 1.0]))
-    compact = bool(neigh in ("gaussian", "triangle") and topo == "rectangular" and rs.rand() < 0.4)
+    compact = bool(neigh in ("gaussian", "triangle") and rs.rand() < 0.4)      # (hexagonal gaussian: the four-class mask)
     if neigh == "mexican_hat" and rs.rand() < 0.4:            # the reference's double mask on px: hexagonal, or square maps
         compact = True
         if topo == "rectangular":
@@ -30,13 +30,6 @@ for case in range(n_cases):
     std_coeff = float(rs.choice([0.5, 0.5, 0.25, 1.0]))
     T = int(rs.choice([1, 3, 10]))                 # schedule length; ONE epoch of it is run and compared
     t_at = int(rs.randint(0, T))
-    # hexagonal + compact_support: the engine masks on the coordinate difference, the reference on rounded absolute
-    # coordinates; they differ only when this epoch's sigma is within an ulp of a lattice distance -- a
-    # schedule that lands there is drawn again with a sigma off the lattice
-    if topo == "hexagonal" and compact:
-        s_t = float(O.DECAYS[decay](sigma, 1, t_at, T))
-        if min(abs(s_t / 0.5 - round(s_t / 0.5)), abs(s_t / (np.sqrt(3) / 2) - round(s_t / (np.sqrt(3) / 2)))) < 1e-9:
-            sigma = sigma * 1.013
     data = O.gaussian_blobs(n, D, seed=case + 1000)
     if dist == "cosine":
         data = np.abs(data)

@@ -1297,6 +1297,32 @@ def test_nan_semantics_documented_in_design(precision, shape):
     assert got[7] == 0 and np.array_equal(np.delete(got, 7), np.delete(clean, 7))
 
 
+@pytest.mark.parametrize("neigh", ["mexican_hat", "gaussian"])
+def test_hexagonal_compact_support_mask_at_a_sigma_one_ulp_off_the_lattice(neigh):
+    """asymptotic_decay(5, ., 1, 3) = 5 / (1 + 2/3) = 3.0000000000000004: the reference's mask `nx < cx + sigma`
+    rounds cx + sigma first, so whether the unit exactly 3.0 away in x is inside depends on cx -- on the BMU's absolute
+    coordinate, half-unit row offset included (neighborhoods.py:50-54, :91-93).  The hexagonal factor tables therefore
+    keep four parity classes under compact_support (update.hpp); a mask on the coordinate difference alone gets the
+    boundary units of this epoch wrong (found by tests/fuzz/fuzz_train.py, seed 9 case 131)."""
+    from xpysom_dask_amd import XPySom
+    X, Y, D, n, T, t_at = 10, 12, 16, 200, 3, 1
+    data = O.gaussian_blobs(n, D, seed=1131)
+    som = XPySom(X, Y, D, sigma=5.0, learning_rate=0.5, decay_function="asymptotic", neighborhood_function=neigh,
+                 topology="hexagonal", random_seed=131, compact_support=True, std_coeff=1.0)
+    w0 = som._weights.copy()
+    ids = som._upload_weights().bmu(data)
+    som.train(data, T, iter_beg=t_at, iter_end=t_at + 1)
+    f = O.DECAYS["asymptotic"]
+    sig_t, eta_t = f(5.0, 1, t_at, T), f(0.5, 0.01, t_at, T)
+    assert sig_t != 3.0 and abs(sig_t - 3.0) < 1e-15
+    _, _, den, want = O.epoch(data, w0.astype(F32), eta_t, sig_t, wide=O.decay_is_wide("asymptotic"), n_parallel=n,
+                              forced_bmu=ids, compact=True, std_coeff=1.0, neighbourhood=neigh + "_hex")
+    live = np.abs(den[..., 0]) > 1e-3 * np.abs(den).max()
+    assert live.sum() > X * Y // 4
+    err = np.abs(som._weights[live] - want[live]).max() / np.abs(want[live]).max()
+    assert err < 5e-5
+
+
 @pytest.mark.parametrize("topo,shape", [("rectangular", (9, 9, 4, 400)), ("hexagonal", (9, 8, 4, 400)), ("hexagonal", (7, 7, 3, 300))])
 def test_g15_mexican_hat_with_compact_support_as_the_reference_computes_it(topo, shape):
     """neighborhoods.py:69-71 / :91-93: px masked twice (on the rectangular topology the second mask compares the

@@ -875,7 +875,8 @@ NeighParams make_neigh_params(const som_handle* h, double sigma, double eta, int
     if (p.kind == SOM_NEIGH_TRIANGLE) p.wide = 1;
     p.X = h->X; p.Y = h->Y; p.nt = h->nt;
     p.hex = h->cfg.topology == SOM_TOPO_HEXAGONAL && h->cfg.neighborhood != SOM_NEIGH_BUBBLE;
-    p.base_nt = p.hex ? h->nt / 3 : h->nt;
+    p.ncls = !p.hex ? 1 : h->cfg.compact_support ? 4 : 3;
+    p.base_nt = h->nt / p.ncls;
     p.swapped = h->swapped ? 1 : 0;
     return p;
 }
@@ -1112,7 +1113,9 @@ int som_create(const som_config* cfg, som_handle** out) {
     h->stage_units = h->wide ? WD_STAGE_UNITS : h->x3res ? K3_STAGE_UNITS : K16_STAGE_UNITS;
     h->nt = cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT ? (cfg->compact_support ? 4 : 2) : 1;
     h->swapped = cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT && cfg->compact_support && cfg->topology == SOM_TOPO_RECTANGULAR;
-    if (cfg->topology == SOM_TOPO_HEXAGONAL && cfg->neighborhood != SOM_NEIGH_BUBBLE) h->nt *= 3;
+    // hexagonal: one copy of the terms per parity class of (unit row, BMU row) -- three classes by the x offset
+    // difference (0, +0.5, -0.5); four with compact_support, whose mask compares ABSOLUTE x coordinates (update.hpp)
+    if (cfg->topology == SOM_TOPO_HEXAGONAL && cfg->neighborhood != SOM_NEIGH_BUBBLE) h->nt *= cfg->compact_support ? 4 : 3;
     int rc = 0;
     auto bail = [&](int code) { g_create_error = h->err; som_destroy(h); return code; };
     DeviceGuard dev_guard(h);

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64 * SEG_MAX_WAVES) void runsum_kernel(const float*
 struct NeighParams {
     double sigma, eta, d;   // d = 2*std_coeff^2*sigma^2 (host, double)
     int kind, compact, wide, X, Y, nt;
-    int hex, base_nt;       // hexagonal topology: nt = 3 * base_nt
+    int hex, base_nt, ncls; // hexagonal topology: nt = ncls * base_nt, one copy of the terms per parity class
     int swapped;            // mexican_hat + compact_support on the rectangular topology: row stage first (see below)
 };
 
@@ -251,25 +251,24 @@ __device__ __forceinline__ double neigh_exp(double delta2, const NeighParams& p)
     return (double)(float)exp((double)a);
 }
 // the reference's support mask, literally: n > c - sigma  and  n < c + sigma  in float64 (neighborhoods.py:29-31,
-// 105-110).  c -/+ sigma is rounded before the compare, so a sigma within an ulp of an integer (asymptotic decay
-// produces them: 5 / (1 + 2/3) = 3.0000000000000004) decides the boundary unit differently than |n - c| < sigma.
-// (The hexagonal classes carry only the coordinate DIFFERENCE, half-unit shift included, so their mask compares
-// that: the generic functions' mask, neighborhoods.py:50-54, up to the rounding of c -/+ sigma.)
-__device__ __forceinline__ double neigh_box(double n, double c, double dl, const NeighParams& p) {
-    if (p.hex) return (dl > -p.sigma && dl < p.sigma) ? 1.0 : 0.0;
+// 50-54, 105-110) on the units' coordinates.  c -/+ sigma is rounded before the compare, so a sigma within an ulp of
+// a lattice distance (asymptotic decay produces them: 5 / (1 + 2/3) = 3.0000000000000004) decides the boundary unit
+// differently than |n - c| < sigma would, and differently for different c.  n, c: absolute coordinates (hexagonal x:
+// half-unit row offsets included -- which is why compact_support needs the fourth parity class).
+__device__ __forceinline__ double neigh_box(double n, double c, const NeighParams& p) {
     return (n > c - p.sigma && n < c + p.sigma) ? 1.0 : 0.0;
 }
 __device__ __forceinline__ double neigh_round(double v, const NeighParams& p) { return p.wide ? v : (double)(float)v; }
 
 // value of factor `which` (0 = row factor Px, 1 = column factor Py) of base term t for unit coordinate n and
-// BMU coordinate c (`shift`: the hexagonal classes' half-unit offset, added to n - c)
-__device__ double neigh_factor(int which, int t, double n, double c, double shift, const NeighParams& p) {
-    const double dl = (n - c) + shift;
+// BMU coordinate c (absolute: on the hexagonal topology the x coordinates carry their rows' half-unit offsets)
+__device__ double neigh_factor(int which, int t, double n, double c, const NeighParams& p) {
+    const double dl = n - c;
     const double d2 = dl * dl;
     switch (p.kind) {
     case 0: {   // gaussian
         double e = neigh_exp(d2, p);
-        if (p.compact) e *= neigh_box(n, c, dl, p);
+        if (p.compact) e *= neigh_box(n, c, p);
         return e;
     }
     case 1: {   // mexican hat: (ex(1-2px/d)) * ey  -  ex * ((2py/d) ey)
@@ -286,7 +285,7 @@ __device__ double neigh_factor(int which, int t, double n, double c, double shif
         //     [mx A][my ey]  +  [-mx ex][my Q]  +  [-mx][my (ey - Q)]  +  [1][ey - Q].
         // Rectangular: M = m1(i; ci) m2(i; cj) -- the second mask compares the ROW index with the BMU's COLUMN --:
         // the same four terms with my = 1; m2 is applied between the row stage and the column stage (`swapped`).
-        const double m = neigh_box(n, c, dl, p);
+        const double m = neigh_box(n, c, p);
         if (which == 0) {
             if (t == 0) return neigh_round(m * e * (1.0 - q), p);
             return t == 1 ? -m * e : t == 2 ? -m : 1.0;
@@ -298,11 +297,11 @@ __device__ double neigh_factor(int which, int t, double n, double c, double shif
         return (t == 2 ? my : 1.0) * neigh_round(e - qe, p);
     }
     case 2:     // bubble
-        return neigh_box(n, c, dl, p);
+        return neigh_box(n, c, p);
     default: {  // triangle
         double v = p.sigma - fabs(dl);
         if (v < 0.0) v = 0.0;
-        if (p.compact) v *= neigh_box(n, c, dl, p);
+        if (p.compact) v *= neigh_box(n, c, p);
         return neigh_round(v, p);
     }
     }
@@ -328,14 +327,14 @@ __global__ __launch_bounds__(256) void neigh_tables_kernel(NeighParams p_val, co
             long r = id / p.X;
             int i = r % p.X;
             int t = r / p.X;
-            double v = neigh_factor(0, t, (double)i, (double)a, 0.0, p);
+            double v = neigh_factor(0, t, (double)i, (double)a, p);
             P1[id] = p.wide ? (float)(v * p.eta) : (float)v * (float)p.eta;
         } else if (id < n1 + n2) {
             long q = id - n1;
             int col = q % ((long)p.nt * p.Y);
             int j = q / ((long)p.nt * p.Y);
             int t = col / p.Y, b = col % p.Y;
-            P2[q] = (float)neigh_factor(1, t, (double)j, (double)b, 0.0, p);
+            P2[q] = (float)neigh_factor(1, t, (double)j, (double)b, p);
         }
         return;
     }
@@ -344,11 +343,14 @@ __global__ __launch_bounds__(256) void neigh_tables_kernel(NeighParams p_val, co
         long r = id / p.Y;
         int j = r % p.Y;
         int t = r / p.Y;
-        double v = neigh_factor(1, t % p.base_nt, (double)j, (double)b, 0.0, p);
-        if (p.hex) {                                   // class indicator on (s(j), s(cj))
+        double v = neigh_factor(1, t % p.base_nt, (double)j, (double)b, p);
+        if (p.hex) {                                   // class indicator on (s(j), s(cj)): s = the row is shifted by -0.5
             const int cls = t / p.base_nt;
             const int sj = ((p.Y - 1 - j) & 1) == 0, sb = ((p.Y - 1 - b) & 1) == 0;
-            const bool in = cls == 0 ? sj == sb : cls == 1 ? (sj == 0 && sb == 1) : (sj == 1 && sb == 0);
+            bool in;
+            if (p.ncls == 3) in = cls == 0 ? sj == sb : cls == 1 ? (sj == 0 && sb == 1) : (sj == 1 && sb == 0);
+            else in = cls == 0 ? (sj == 0 && sb == 0) : cls == 1 ? (sj == 0 && sb == 1) : cls == 2 ? (sj == 1 && sb == 0)
+                                                                                                  : (sj == 1 && sb == 1);
             if (!in) v = 0.0;
         }
         P1[id] = (float)v;
@@ -358,8 +360,11 @@ __global__ __launch_bounds__(256) void neigh_tables_kernel(NeighParams p_val, co
         int i = q / ((long)p.nt * p.X);
         int t = col / p.X, a = col % p.X;
         const int cls = t / p.base_nt;
-        const double shift = !p.hex ? 0.0 : cls == 1 ? 0.5 : cls == 2 ? -0.5 : 0.0;
-        double v = neigh_factor(0, t % p.base_nt, (double)i, (double)a, shift, p);
+        // x coordinates of the class: unit rows of classes 2, 3 and BMU rows of classes 1, 3 are shifted by -0.5
+        // (three classes: only the difference matters, the both-shifted rows share class 0 with the unshifted ones)
+        const double off_n = p.hex && (cls == 2 || cls == 3) ? -0.5 : 0.0;
+        const double off_c = p.hex && (cls == 1 || cls == 3) ? -0.5 : 0.0;
+        double v = neigh_factor(0, t % p.base_nt, (double)i + off_n, (double)a + off_c, p);
         P2[q] = p.wide ? (float)(v * p.eta) : (float)v * (float)p.eta;
     }
 }
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(256) void mask_rows_kernel(NeighParams p_val, const
     const long r = id - (long)i * per_i;
     const int t = (int)(r / ((long)p.Y * D1p));
     const int b = (int)((r / D1p) % p.Y);
-    if (t < nt_masked && neigh_box((double)i, (double)b, (double)(i - b), p) == 0.0) V[id] = 0.0f;
+    if (t < nt_masked && neigh_box((double)i, (double)b, p) == 0.0) V[id] = 0.0f;
 }
 
 // ---- OUT[b] = H (Ro x Ri) * M[b] (Ri x C), exact float32 on v_mfma_f32_32x32x2_f32 ---------------
