@@ -82,3 +82,15 @@ class OracleEngine:
 
     def quantization_error(self, x):
         return O.quantization_error(x, self.W.reshape(self.x, self.y, self.D))
+
+    def bmu_top2(self, x):
+        b = O.top2_ids(np.asarray(x, np.float32), self.W.reshape(self.x, self.y, self.D))
+        return b[:, 0].astype(np.int32), b[:, 1].astype(np.int32)
+
+    def distance_matrix(self, x, quantization=False):
+        """activate (the configured GEMM-form distance) / distance_from_weights (the full Euclidean distance)."""
+        x = np.asarray(x, np.float32)
+        if quantization:
+            return O.dist_euclid(x, self.W)
+        return O.DISTANCES[self.kw["distance"]](x, self.W)
+
