@@ -24,6 +24,12 @@ for case in range(n_cases):
     topo = str(rs.choice(["rectangular", "rectangular", "hexagonal"]))
     if neigh == "triangle":
         topo = "rectangular"                                  # (the hexagonal registry has no triangle, xpysom.py:271-279)
+    compact = bool(neigh in ("gaussian", "triangle") and rs.rand() < 0.3)
+    if neigh == "mexican_hat" and rs.rand() < 0.3:            # the reference's double mask on px: hexagonal, or square maps
+        compact = True
+        if topo == "rectangular":
+            Y = X
+    std_coeff = float(rs.choice([0.5, 0.5, 0.25, 1.0]))
     p_norm = 2
     if prec == "f32" and rs.rand() < 0.3:                     # the VALU distances exist in f32 only
         dist = str(rs.choice(["manhattan", "norm_p", "norm_p_no_opt", "euclidean_no_opt"]))
@@ -43,9 +49,12 @@ for case in range(n_cases):
     if dist == "cosine":
         data, w = np.abs(data), np.abs(w)
     try:
-        e = HipEngine(X, Y, D, precision=prec, distance=dist, neighborhood=neigh, topology=topo, norm_p=p_norm)
+        e = HipEngine(X, Y, D, precision=prec, distance=dist, neighborhood=neigh, topology=topo, norm_p=p_norm,
+                      compact_support=compact, std_coeff=std_coeff)
         e.set_weights(w); e.set_data(data)
-        sig, eta = max(min(X, Y) / 2, 1.0), 0.5
+        # sigma: half the map, or a value on / one ulp off the unit lattice (the support masks' boundary cases)
+        sig = float(rs.choice([max(min(X, Y) / 2, 1.0), 1.0, 2.5, 3.0, 5 / (1 + 2 / 3), 1.7320508]))
+        eta = 0.5
         e.epoch_accumulate(sig, eta, True)
         num, den, bmu = e.epoch_fetch()
         q = e.bmu(data)
@@ -67,8 +76,8 @@ for case in range(n_cases):
         #  bf16 -- up to 2^-6.4 of the scale when |w| >> |x|; seed 32 case 377 sits at 1.11 x 2^-7)
         tol = {"f32": 2.0 ** -18, "bf16x3": 2.0 ** -14, "bf16": 2.0 ** -6, "f16": 2.0 ** -9, "f16x3": 2.0 ** -14}[prec]
         ok_bmu = (dd[np.arange(n), bmu] <= dd.min(1) + tol * scale).all() and (dd[np.arange(n), q] <= dd.min(1) + tol * scale).all()
-        _, onum, oden = O.update(data, w, np.float64(eta), np.float64(sig), wide=True, forced_bmu=bmu,
-                                 neighbourhood=neigh + ("_hex" if topo == "hexagonal" else ""))
+        _, onum, oden = O.update(data, w, np.float64(eta), np.float64(sig), wide=True, forced_bmu=bmu, compact=compact,
+                                 std_coeff=std_coeff, neighbourhood=neigh + ("_hex" if topo == "hexagonal" else ""))
         en = np.abs(num - onum.reshape(-1, D)).max() / max(np.abs(onum).max(), 1e-30)
         ed = np.abs(den - oden.reshape(-1)).max() / max(np.abs(oden).max(), 1e-30)
         ok = ok_bmu and en < 1e-5 and ed < 1e-5 and (q != bmu).mean() <= 0.02
@@ -77,7 +86,7 @@ for case in range(n_cases):
         print("EXC", repr(ex)[:200])
     if not ok:
         bad += 1
-        print(f"FAIL case {case}: {X}x{Y}x{D} n={n} {prec} {dist}(p={p_norm}) {neigh} {topo} num {en:.2e} den {ed:.2e} bmu_ok {ok_bmu if en >= 0 else None}", flush=True)
+        print(f"FAIL case {case}: {X}x{Y}x{D} n={n} {prec} {dist}(p={p_norm}) {neigh} {topo} compact={compact} std={std_coeff} sigma={sig!r} num {en:.2e} den {ed:.2e} bmu_ok {ok_bmu if en >= 0 else None}", flush=True)
         if en >= 0 and not ok_bmu:                            # how far outside the bound, in units of the bound
             ex = (dd[np.arange(n), bmu] - dd.min(1)) / (tol * scale)
             exq = (dd[np.arange(n), q] - dd.min(1)) / (tol * scale)
