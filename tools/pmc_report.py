@@ -21,7 +21,32 @@ out_dir, tag, rows = sys.argv[1], sys.argv[2], int(sys.argv[3])
 extra = sys.argv[4:]
 
 
+def demangle_somhip(name):
+    """rocprofv3 leaves a kernel name mangled when its template arguments hold a 16-bit float type (DF16b = __bf16,
+    DF16_ = _Float16): _ZN6somhip<len><name>I<args>E... -> name<ints, type>."""
+    m = re.match(r"^_ZN6somhip(\d+)", name)
+    if not m:
+        return name
+    n = int(m.group(1))
+    ident, rest = name[m.end():m.end() + n], name[m.end() + n:]
+    args = []
+    if rest.startswith("I"):
+        t = rest[1:]
+        while t and not t.startswith("E"):
+            mi = re.match(r"^L[ib](\d+)E", t)
+            if mi:
+                args.append(mi.group(1)); t = t[mi.end():]
+            elif t.startswith("DF16b"):
+                args.append("bf16"); t = t[5:]
+            elif t.startswith("DF16_"):
+                args.append("f16"); t = t[5:]
+            else:
+                break
+    return ident + ("<" + ", ".join(args) + ">" if args else "")
+
+
 def short(name):
+    name = demangle_somhip(name)
     name = re.sub(r"^void ", "", name)
     name = name.split("(")[0]
     name = re.sub(r"^somhip::", "", name)

@@ -31,10 +31,11 @@ __device__ __forceinline__ void atomic_max_pos_f32(float* addr, float v) {
 }
 
 // |w~|^2 of every unit (bf16-rounded values) and its maximum over the codebook
-template <class E = __bf16>
+template <class EL = Bf16>
 __global__ __launch_bounds__(256) void prep_wnorm_kernel(const float* __restrict__ W, int K, int D,
                                                          float* __restrict__ wn, float* __restrict__ wmax2,
                                                          const float* __restrict__ unit_wsq) {
+    using E = typename EL::T;
     long u = (long)blockIdx.x * 256 + threadIdx.x;
     float s = 0.0f;
     if (u < K) {
@@ -69,10 +70,11 @@ __global__ __launch_bounds__(256) void prep_wsqh_kernel(const float* __restrict_
 
 // samples -> bf16 rows [Np][Dp] (zero padded) and max_n |x~_n|^2.  One wave per row.
 // unit != 0 (cosine): the row is scaled to unit length first (a zero row stays zero).
-template <class E = __bf16>
+template <class EL = Bf16>
 __global__ __launch_bounds__(256) void prep_x_bf16_kernel(const float* __restrict__ X, long N, int D, int Dp,
                                                           long Np, __bf16* __restrict__ Xb,
                                                           float* __restrict__ xmax2, int unit) {
+    using E = typename EL::T;
     long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (row >= Np) return;

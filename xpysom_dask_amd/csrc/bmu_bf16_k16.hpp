@@ -38,10 +38,11 @@ constexpr int K16_WG_SAMPLES = K16_NW * 16 * K16_SB;
 
 __host__ __device__ constexpr int k16_stage_bytes(int ks32) { return (K16_T * ks32 + 1) * 1024; }
 
-template <int KS32, class E = __bf16>
+template <int KS32, class EL = Bf16>
 __global__ __launch_bounds__(256) void prep_w_bf16_k16_kernel(const float* __restrict__ W, int K, int D,
                                                               char* __restrict__ Wst, int n_stages,
                                                               const float* __restrict__ unit_wsq) {
+    using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     long id = (long)blockIdx.x * 256 + threadIdx.x;
     long total = (long)n_stages * K16_T * KS32 * 64;
@@ -73,11 +74,12 @@ __global__ __launch_bounds__(256) void prep_w_bf16_k16_kernel(const float* __res
 // the codebook.  Workgroup = MP_TILES 16-unit tiles, KS32 waves; thread = (unit, 8 features) of each tile, exactly one
 // 16-byte fragment chunk of the image.  W = where(den != 0, num / den, W) as merge_kernel computes it.
 constexpr int MP_TILES = 4;           // 16-unit tiles per workgroup: their loads are all issued before the first is used
-template <int KS32, class E = __bf16>
+template <int KS32, class EL = Bf16>
 __global__ __launch_bounds__(64 * KS32) void merge_prep_k16_kernel(float* __restrict__ W, const float* __restrict__ ACC,
                                                                  int K, int D, int D1p, char* __restrict__ Wst,
                                                                  float* __restrict__ wn, float* __restrict__ wmax2,
                                                                  long n_tiles) {
+    using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     __shared__ float red[MP_TILES][KS32][16];
     const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
@@ -168,10 +170,11 @@ __global__ __launch_bounds__(64 * KS32) void merge_prep_k16_kernel(float* __rest
 #ifndef SOM_K16_MINWAVES
 #define SOM_K16_MINWAVES 2
 #endif
-template <int KS32, class E = __bf16>
+template <int KS32, class EL = Bf16>
 __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
                                                               const char* __restrict__ Wst, int n_stages, int K,
                                                               unsigned long long* __restrict__ out64) {
+    using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     constexpr int DP = 32 * KS32;
     constexpr int STAGE = k16_stage_bytes(KS32);

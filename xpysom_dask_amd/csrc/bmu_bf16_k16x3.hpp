@@ -34,10 +34,11 @@ __host__ __device__ constexpr int k3_stage_bytes(int ks32) { return (2 * K3_T * 
 
 // float32 codebook -> hi / lo stage image.  One thread per 16-byte fragment chunk; unit_wsq != nullptr (cosine): rows
 // scaled to unit length first.
-template <int KS32, class E = __bf16>
+template <int KS32, class EL = Bf16>
 __global__ __launch_bounds__(256) void prep_w_bf16_k16x3_kernel(const float* __restrict__ W, int K, int D,
                                                                 char* __restrict__ Wst, int n_stages,
                                                                 const float* __restrict__ unit_wsq) {
+    using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     long id = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)n_stages * 2 * K3_T * KS32 * 64;
@@ -64,9 +65,10 @@ __global__ __launch_bounds__(256) void prep_w_bf16_k16x3_kernel(const float* __r
 
 // rows -> [hi | lo] bf16 images (zero padded to Np rows of 2 * Dp) and the maximum of the EXACT float32 |x|^2.
 // One wave per row; unit != 0 (cosine): the row is scaled to unit length first (a zero row stays zero).
-template <class E = __bf16>
+template <class EL = Bf16>
 __global__ __launch_bounds__(256) void prep_x_bf16x3_kernel(const float* __restrict__ X, long N, int D, int Dp, long Np,
                                                             __bf16* __restrict__ Xb, float* __restrict__ xmax2, int unit) {
+    using E = typename EL::T;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= Np) return;
@@ -89,10 +91,11 @@ __global__ __launch_bounds__(256) void prep_x_bf16x3_kernel(const float* __restr
     if (lane == 0) atomic_max_pos_f32(xmax2, s);
 }
 
-template <int KS32, class E = __bf16>
+template <int KS32, class EL = Bf16>
 __global__ __launch_bounds__(64 * K3_NW, 2) void bmu_bf16_k16x3_kernel(const __bf16* __restrict__ Xb, long N,
                                                                        const char* __restrict__ Wst, int n_stages, int K,
                                                                        unsigned long long* __restrict__ out64) {
+    using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     constexpr int DP = 32 * KS32;
     constexpr int STAGE = k3_stage_bytes(KS32);

@@ -48,11 +48,12 @@ struct TileCfg {
 // feature axis is tripled -- samples carry [hi | hi | lo], units [hi | lo | hi] -- so the same MFMA
 // contraction yields x_hi.w_hi + x_hi.w_lo + x_lo.w_hi, i.e. x.w to ~2^-16 relative (only lo.lo is
 // dropped) at three times the bf16 work.  split: 0 = plain bf16, 1 = sample pattern, 2 = unit pattern.
-template <class E = __bf16>
+template <class EL = Bf16>
 __global__ __launch_bounds__(256) void prep_tiles_bf16_kernel(const float* __restrict__ A, long rows, int D,
                                                               int n_kchunks, long n_blocks, int brows, int tile_bytes,
                                                               float sign, const float* __restrict__ unit_sq,
                                                               char* __restrict__ img, int split) {
+    using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     long id = (long)blockIdx.x * 256 + threadIdx.x;
     const int nt16 = brows / 16;
@@ -88,11 +89,12 @@ __global__ __launch_bounds__(256) void prep_tiles_bf16_kernel(const float* __res
 
 // |a~_row|^2 of bf16-rounded (optionally unit-scaled) rows and their maximum.  One wave per row.
 // exact != 0 ('bf16x3'): the float32 rows themselves, not their bf16 roundings.
-template <class E = __bf16>
+template <class EL = Bf16>
 __global__ __launch_bounds__(256) void rownorm_bf16_kernel(const float* __restrict__ A, long rows, int D,
                                                            const float* __restrict__ unit_sq, int zero_norm,
                                                            float* __restrict__ norm2, float* __restrict__ max2,
                                                            int exact) {
+    using E = typename EL::T;
     long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -126,12 +128,13 @@ __global__ __launch_bounds__(256) void prep_tiles_cin_kernel(const float* __rest
     ((float*)(Wimg + tile * (long)wtile + wfrag))[within] = u < K ? __builtin_fmaf(0.5f, wn[u], big) : BF_PAD_NORM;
 }
 
-template <int WS, int NWR, int NWC, class E = __bf16>
+template <int WS, int NWR, int NWC, class EL = Bf16>
 __global__ __launch_bounds__(64 * NWR * NWC, 2) void bmu_bf16_tiled_kernel(const char* __restrict__ Ximg, long N,
                                                                            const char* __restrict__ Wimg,
                                                                            int n_ublocks, int n_kchunks, int K,
                                                                            unsigned long long* __restrict__ out64,
                                                                            int n_sblocks, int n_parts) {
+    using E = typename EL::T;
     using C = TileCfg<WS, NWR, NWC>;
     using bf16x8 = typename V8<E>::t;
     static_assert(NWR == 2 && TL_KS == 1, "two wave groups (sample halves), one MFMA k-step per stage");

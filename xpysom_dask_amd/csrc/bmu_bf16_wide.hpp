@@ -35,10 +35,11 @@ __host__ __device__ constexpr int wd_stage_bytes(int ks32) { return (WD_T * ks32
 
 // codebook -> stage image (the initial accumulators are written by prep_wsqh_kernel: they depend on the row set).
 // split != 0 (precision 'bf16x3', prep_tiles_bf16_kernel): the feature axis is tripled, units carry [hi | lo | hi].
-template <class E = __bf16>
+template <class EL = Bf16>
 __global__ __launch_bounds__(256) void prep_w_bf16_wide_kernel(const float* __restrict__ W, int K, int D, int ks32,
                                                                char* __restrict__ Wst, int n_stages,
                                                                const float* __restrict__ unit_wsq, int split) {
+    using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     long id = (long)blockIdx.x * 256 + threadIdx.x;
     long total = (long)n_stages * WD_T * ks32 * 64;
@@ -76,11 +77,12 @@ __global__ __launch_bounds__(256) void prep_w_bf16_wide_kernel(const float* __re
 // thread = (unit, 8 features) of each of its chunks = one 16-byte fragment chunk of the image.  cosine != 0: the
 // image holds the unit-length rows (scale 1/|w|, a zero row stays zero) and |w~|^2 is reported as 0 (rownorm_bf16_kernel).
 constexpr int WD_MP_ITERS = 7;                   // chunks per wave: up to 28 feature chunks (the wide kernel stops at 25)
-template <class E = __bf16>
+template <class EL = Bf16>
 __global__ __launch_bounds__(256) void merge_prep_wide_kernel(float* __restrict__ W, const float* __restrict__ ACC, int K,
                                                               int D, int D1p, int ks32, char* __restrict__ Wst,
                                                               float* __restrict__ wn, float* __restrict__ wmax2,
                                                               int cosine) {
+    using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     __shared__ float red[2][4][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -170,10 +172,11 @@ __global__ __launch_bounds__(256) void merge_prep_wide_kernel(float* __restrict_
     }
 }
 
-template <int KS32, class E = __bf16>
+template <int KS32, class EL = Bf16>
 __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* __restrict__ Ximg, long N,
                                                                    const char* __restrict__ Wst, int n_stages,
                                                                    unsigned long long* __restrict__ out64) {
+    using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     constexpr int STAGE = wd_stage_bytes(KS32);
     constexpr int PIECES = WD_T * KS32;                      // whole 1 KiB pieces; the C-in row follows them

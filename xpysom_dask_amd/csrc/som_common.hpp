@@ -13,7 +13,10 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 // The 16-bit operand type of the half-precision BMU kernels: __bf16 (precision 'bf16' / 'bf16x3') or _Float16
 // ('f16' / 'f16x3': three more mantissa bits at the same MFMA rate, range 6e-8 .. 65504).  The kernels are templates on
-// it; their operand images are the same bytes either way.
+// its tag (`class EL`, `using E = typename EL::T`); their operand images are the same bytes either way.
+// (kernels take the TAG, not the type: rocprofv3 cannot demangle a 16-bit float type in a kernel's template arguments)
+struct Bf16 { typedef __bf16 T; };
+struct F16 { typedef _Float16 T; };
 template <class E> struct V8;
 template <> struct V8<__bf16> { typedef bf16x8 t; };
 template <> struct V8<_Float16> { typedef f16x8 t; };

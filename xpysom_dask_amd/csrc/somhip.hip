@@ -284,9 +284,9 @@ int resolve_profile(som_handle* h) {
 }
 
 // ---- codebook-derived operands (w_sq cache, xpysom.py:529-537; bf16 / f16 stage image) -----
-// The half-precision paths are templates on the operand type E (__bf16 or _Float16, som_common.hpp); SOM_HALF picks
+// The half-precision paths are templates on the operand type's tag E (Bf16 or F16, som_common.hpp); SOM_HALF picks
 // the instance from the handle.
-#define SOM_HALF(h, fn, ...) ((h)->f16 ? fn<_Float16>(__VA_ARGS__) : fn<__bf16>(__VA_ARGS__))
+#define SOM_HALF(h, fn, ...) ((h)->f16 ? fn<F16>(__VA_ARGS__) : fn<Bf16>(__VA_ARGS__))
 
 void mark_codebook_changed(som_handle* h) { h->w_dirty = h->wsq_dirty = h->wf_dirty = true; }
 
