@@ -99,6 +99,28 @@ def test_f16_refuses_rows_and_units_outside_the_float16_range():
     assert ec.bmu(np.abs(big)).shape == (10,)
 
 
+def test_f16_saturates_instead_of_overflowing():
+    """Query rows are not range-checked (no host round trip on that path): a component beyond 65504 saturates in the
+    float16 image instead of becoming infinite -- an infinite row norm would make the launch's offset B, and with it
+    every other row's distances, infinite."""
+    X, Y, D, n = 12, 12, 16, 600
+    data = O.gaussian_blobs(n, D, seed=4)
+    w = (np.random.RandomState(1).rand(X, Y, D) * 2 - 1).astype(F32)
+    ref = O.bmu_ids(data, w.reshape(-1, D))
+    e = engine(X, Y, D, precision="f16")
+    e.set_weights(w)
+    q = data.copy()
+    q[5, 3] = 1.0e6                                                    # float16(1e6) = inf without the saturation
+    got = e.bmu(q)
+    assert ((got >= 0) & (got < X * Y)).all()
+    keep = np.arange(n) != 5
+    # (the saturated row raises B to ~65504 |w|max, so the others are compared at a coarser absolute resolution)
+    assert (got[keep] == ref[keep]).mean() > 0.5
+    clamped = q.copy()
+    clamped[5, 3] = 65504.0
+    assert got[5] == O.bmu_ids(clamped[5:6], w.reshape(-1, D))[0]
+
+
 def test_f16_class_surface_trains_and_scores_like_float32():
     from xpysom_dask_amd import XPySom
     data = O.gaussian_blobs(20000, 24, seed=2)

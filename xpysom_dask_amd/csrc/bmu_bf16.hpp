@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void prep_wnorm_kernel(const float* __restrict
     if (u < K) {
         float scale = 1.0f;       // cosine: the stage image holds unit-length rows and no norm term
         if (unit_wsq != nullptr) { float q = unit_wsq[u]; scale = q > 0.0f ? 1.0f / __builtin_sqrtf(q) : 0.0f; }
-        for (int k = 0; k < D; ++k) { float f = (float)(E)(W[u * D + k] * scale); s = __builtin_fmaf(f, f, s); }
+        for (int k = 0; k < D; ++k) { float f = (float)cvt<E>(W[u * D + k] * scale); s = __builtin_fmaf(f, f, s); }
         wn[u] = unit_wsq != nullptr ? 0.0f : s;
     }
     float m = s;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void prep_x_bf16_kernel(const float* __restric
     float s = 0.0f;
     for (int k = lane; k < Dp; k += 64) {
         float f = (row < N && k < D) ? X[row * D + k] * scale : 0.0f;
-        E b = (E)f;
+        E b = cvt<E>(f);
         ((E*)Xb)[row * Dp + k] = b;
         float fb = (float)b;
         s = __builtin_fmaf(fb, fb, s);

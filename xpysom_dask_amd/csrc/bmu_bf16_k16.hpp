@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void prep_w_bf16_k16_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float f = (u < K && k0 + j < D) ? W[u * D + k0 + j] * scale : 0.0f;
-        v[j] = (E)(-f);
+        v[j] = cvt<E>(-f);
     }
     *(bf16x8*)(Wst + stage * k16_stage_bytes(KS32) + ((long)(t16 * KS32 + ks) * 64 + lane) * 16) = v;
 }
@@ -140,8 +140,8 @@ __global__ __launch_bounds__(64 * KS32) void merge_prep_k16_kernel(float* __rest
             float s = 0.0f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const E b = (E)w[i][j];
-                v[j] = (E)(-w[i][j]);                 // (rounding is sign-symmetric: -bf16(w) == bf16(-w))
+                const E b = cvt<E>(w[i][j]);
+                v[j] = cvt<E>(-w[i][j]);                 // (rounding is sign-symmetric: -bf16(w) == bf16(-w))
                 const float f = (float)b;
                 s = __builtin_fmaf(f, f, s);
             }

@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void prep_w_bf16_k16x3_kernel(const float* __r
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float f = (u < K && k0 + j < D) ? -(W[u * D + k0 + j] * scale) : 0.0f;
-        const E hi = (E)f;
-        v[j] = part == 0 ? hi : (E)(f - (float)hi);
+        const E hi = cvt<E>(f);
+        v[j] = part == 0 ? hi : cvt<E>(f - (float)hi);
     }
     *(bf16x8*)(Wst + stage * k3_stage_bytes(KS32) + ((long)((part * K3_T + t16) * KS32 + ks) * 64 + lane) * 16) = v;
 }
@@ -82,9 +82,9 @@ __global__ __launch_bounds__(256) void prep_x_bf16x3_kernel(const float* __restr
     float s = 0.0f;
     for (int k = lane; k < Dp; k += 64) {
         const float f = (row < N && k < D) ? X[row * D + k] * scale : 0.0f;
-        const E hi = (E)f;
+        const E hi = cvt<E>(f);
         ((E*)Xb)[row * 2 * Dp + k] = hi;
-        ((E*)Xb)[row * 2 * Dp + Dp + k] = (E)(f - (float)hi);
+        ((E*)Xb)[row * 2 * Dp + Dp + k] = cvt<E>(f - (float)hi);
         s = __builtin_fmaf(f, f, s);
     }
     s = wave_sum(s);

@@ -75,13 +75,13 @@ __global__ __launch_bounds__(256) void prep_tiles_bf16_kernel(const float* __res
     for (int j = 0; j < 8; ++j) {
         if (split == 0) {
             float f = (row < rows && k0 + j < D) ? A[row * D + k0 + j] * scale : 0.0f;
-            v[j] = (E)f;
+            v[j] = cvt<E>(f);
         } else {
             const int kv = k0 + j, seg = kv / D, k = kv - seg * D;
             float f = (row < rows && seg < 3) ? A[row * D + k] * scale : 0.0f;
-            const E hi = (E)f;
+            const E hi = cvt<E>(f);
             const bool want_lo = split == 1 ? seg == 2 : seg == 1;
-            v[j] = want_lo ? (E)(f - (float)hi) : hi;
+            v[j] = want_lo ? cvt<E>(f - (float)hi) : hi;
         }
     }
     *(bf16x8*)(img + (blk * n_kchunks + kc) * (long)tile_bytes + ((long)(t16 * TL_KS + ks) * 64 + lane) * 16) = v;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void rownorm_bf16_kernel(const float* __restri
     float s = 0.0f;
     for (int k = lane; k < D; k += 64) {
         float f = A[row * D + k] * scale;
-        if (!exact) f = (float)(E)f;
+        if (!exact) f = (float)cvt<E>(f);
         s = __builtin_fmaf(f, f, s);
     }
     s = wave_sum(s);

@@ -58,12 +58,12 @@ __global__ __launch_bounds__(256) void prep_w_bf16_wide_kernel(const float* __re
     for (int j = 0; j < 8; ++j) {
         if (split == 0) {
             float f = (u < K && k0 + j < D) ? W[u * D + k0 + j] * scale : 0.0f;
-            v[j] = (E)(-f);
+            v[j] = cvt<E>(-f);
         } else {
             const int kv = k0 + j, seg = kv / D, k = kv - seg * D;
             float f = (u < K && seg < 3) ? -W[u * D + k] * scale : 0.0f;
-            const E hi = (E)f;
-            v[j] = seg == 1 ? (E)(f - (float)hi) : hi;
+            const E hi = cvt<E>(f);
+            v[j] = seg == 1 ? cvt<E>(f - (float)hi) : hi;
         }
     }
     *(bf16x8*)(Wst + stage * wd_stage_bytes(ks32) + ((long)(t16 * ks32 + ks) * 64 + lane) * 16) = v;
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256) void merge_prep_wide_kernel(float* __restrict_
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float f = w[i][j] * scale;
-            const E b = (E)f;
-            v[j] = (E)(-f);                             // (rounding is sign-symmetric: -bf16(f) == bf16(-f))
+            const E b = cvt<E>(f);
+            v[j] = cvt<E>(-f);                             // (rounding is sign-symmetric: -bf16(f) == bf16(-f))
             const float r = (float)b;
             s = __builtin_fmaf(r, r, s);
         }

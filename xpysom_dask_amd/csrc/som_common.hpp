@@ -20,6 +20,13 @@ struct F16 { typedef _Float16 T; };
 template <class E> struct V8;
 template <> struct V8<__bf16> { typedef bf16x8 t; };
 template <> struct V8<_Float16> { typedef f16x8 t; };
+// float -> operand type.  IEEE half saturates at +-65504 instead of overflowing to infinity (som_set_data / som_set_weights
+// refuse rows and units beyond the range, but a mexican-hat update can overshoot its data: one infinite unit norm would
+// make the offset B, and with it every distance of the launch, infinite); NaN stays NaN.
+template <class E> __device__ __forceinline__ E cvt(float f) { return (E)f; }
+template <> __device__ __forceinline__ _Float16 cvt<_Float16>(float f) {
+    return (_Float16)(f != f ? f : __builtin_fminf(__builtin_fmaxf(f, -65504.0f), 65504.0f));
+}
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
