@@ -278,6 +278,16 @@ def main():
     parts = {k: eng.profile_get(k)[0] / nb for k in ("prep", "bmu", "segsum", "kron", "merge")}
     w_end = eng.get_weights()
     assert np.isfinite(w_end).all()
+    # N > 1: every rank merged the same all-reduced sums, so the codebooks must be the same bits on every rank
+    ranks_agree = None
+    if dist is not None:
+        import zlib
+        crc = float(zlib.crc32(np.ascontiguousarray(w_end).tobytes()))
+        lo = torch.tensor([crc], dtype=torch.float64, device="cuda")
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ranks_agree = bool(lo.item() == hi.item())
 
     kernel_name = kernel_name_for(args.precision, FEATURES, MAP_X * MAP_Y)
     peak = MFMA_F32_PEAK_TFLOPS if args.precision == "f32" else MFMA_BF16_PEAK_TFLOPS
@@ -355,6 +365,7 @@ def main():
         out = {
             "metric": "samples/sec/epoch", "value": total_rows / (dt / args.steps), "unit": "samples/sec/epoch",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "codebooks_identical_on_all_ranks": ranks_agree,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": {"f32": "f32", "f16": "f16", "f16x3": "f16"}.get(args.precision, "bf16"), "data": "synthetic",
             "config": {"workload": "batch-SOM epoch, %dx%d map, %d features, %d Gaussian-blob rows %s resident "

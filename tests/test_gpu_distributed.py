@@ -126,3 +126,4 @@ def test_bench_launches_its_own_ranks(scaling):
     assert out["n_gpus"] == 2 and out["scaling"] == scaling
     assert out["config"]["rows_total"] == (131072 if scaling == "weak" else 131073)
     assert out["value"] > 0 and 0 < out["roofline"]["frac"] < 1
+    assert out["codebooks_identical_on_all_ranks"] is True      # every rank merged the same all-reduced sums
