@@ -90,7 +90,7 @@ for case in range(n_cases):
         if dist in ("manhattan", "norm_p"):
             ow = O.bmu_ids_pairwise(np.asarray(q), want.reshape(-1, D), dist, p_norm) if len(q) else []
         else:
-            ow = O.winner_ids(q, want, dist)
+            ow = O.winner_ids(q, want, dist, n_parallel=npar)    # (the same chunks: a GEMM's rounding depends on its shape)
         if [tuple(map(int, t)) for t in rw] != [(int(k) // Y, int(k) % Y) for k in ow]:
             msgs.append("winner")
         rq, oq = ref.quantization_error(q), O.quantization_error(q, want)
