@@ -481,8 +481,45 @@ def g15():
     save("g15_mexican_compact", **out)
 
 
+def g16():
+    """Hexagonal topology + compact_support at a sigma ONE ULP off the unit lattice: asymptotic_decay(5, ., 1, 3) =
+    5 / (1 + 2/3) = 3.0000000000000004.  The generic masks compare `xx > cx - sigma` / `xx < cx + sigma` after rounding
+    cx -/+ sigma (neighborhoods.py:50-54, :91-93), so whether the unit exactly 3.0 away in x is inside depends on the
+    BMU's absolute coordinate, half-unit row offset included.  Raw tensors for every centre, and one _update."""
+    out = {}
+    sig = 5.0 / (1 + 2 * 1 / 3)
+    assert sig != 3.0 and abs(sig - 3.0) < 1e-15
+    for (X, Y) in ((10, 12), (9, 7)):
+        ci, cj = np.divmod(np.arange(X * Y), Y)
+        c = (ci.astype(np.int64), cj.astype(np.int64))
+        som = RefSom(X, Y, 3, topology="hexagonal", xp=np)
+        for wide in (False, True):
+            s = np.float64(sig) if wide else float(sig)
+            tag = f"{X}x{Y}_{'f64' if wide else 'f32'}"
+            out["gauss_" + tag] = rneigh.gaussian_generic(som._xx, som._yy, 1.0, True, c, s, xp=np)
+            out["mex_" + tag] = rneigh.mexican_hat_generic(som._xx, som._yy, 1.0, True, c, s, xp=np)
+    X, Y, D, n = 10, 12, 16, 200
+    data = gaussian_blobs(n, D, seed=1131)
+    for neigh in ("gaussian", "mexican_hat"):
+        som = RefSom(X, Y, D, sigma=5.0, learning_rate=0.5, random_seed=131, decay_function="asymptotic", n_parallel=n,
+                     topology="hexagonal", neighborhood_function=neigh, compact_support=True, std_coeff=1.0, xp=np)
+        w0 = som._weights.astype(F32)
+        t, T = 1, 3
+        eta = som._decay_function(som._learning_rate, som._learning_rateN, t, T)
+        s_t = som._decay_function(som._sigma, som._sigmaN, t, T)
+        assert s_t == sig
+        wins = som._winner(data, w0)
+        num, den = som._update(data, w0, eta, s_t)
+        out[neigh + "_bmu"] = (wins[0] * Y + wins[1]).astype(np.int32)
+        out[neigh + "_num"] = num.astype(F32)
+        out[neigh + "_den"] = den.astype(F32)
+        out[neigh + "_eta"] = np.float64(eta)
+    out["sigma"] = np.float64(sig)
+    save("g16_hex_compact_lattice_sigma", **out)
+
+
 FAMILIES = {"g1": g1, "g2": g2, "g3": g3, "g4": g4_g5_g7, "g6": g6, "g8": g8, "g9": g9, "g10": g10, "g11": g11,
-            "g12": g12, "g13": g13, "g14": g14, "g15": g15}
+            "g12": g12, "g13": g13, "g14": g14, "g15": g15, "g16": g16}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

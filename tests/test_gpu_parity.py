@@ -1297,6 +1297,28 @@ def test_nan_semantics_documented_in_design(precision, shape):
     assert got[7] == 0 and np.array_equal(np.delete(got, 7), np.delete(clean, 7))
 
 
+@pytest.mark.parametrize("neigh", ["gaussian", "mexican_hat"])
+def test_g16_hexagonal_compact_support_at_a_lattice_sigma_against_the_reference(neigh):
+    """G16: the reference's own `_update` at sigma = 3.0000000000000004 on the hexagonal topology with
+    compact_support (the four-parity-class tables, update.hpp)."""
+    g = load_golden("g16_hex_compact_lattice_sigma")
+    X, Y, D, n = 10, 12, 16, 200
+    data = O.gaussian_blobs(n, D, seed=1131)
+    w0 = O.default_codebook(X, Y, D, 131).astype(F32)
+    e = engine(X, Y, D, neighborhood=neigh, compact_support=True, topology="hexagonal", std_coeff=1.0)
+    e.set_weights(w0)
+    e.set_data(data)
+    e.epoch_accumulate(float(g["sigma"]), float(g[neigh + "_eta"]), O.decay_is_wide("asymptotic"))
+    num, den, bmu = e.epoch_fetch()
+    assert np.array_equal(bmu, g[neigh + "_bmu"])
+    assert rel_err(num, g[neigh + "_num"].reshape(-1, D)) < 1e-5
+    assert rel_err(den, g[neigh + "_den"].reshape(-1)) < 1e-5
+    # the faithful K x N x D form agrees (it generates g from the same tables)
+    e.epoch_accumulate_faithful(float(g["sigma"]), float(g[neigh + "_eta"]), O.decay_is_wide("asymptotic"))
+    num2, den2, _ = e.epoch_fetch(want_bmu=False)
+    assert rel_err(num2, g[neigh + "_num"].reshape(-1, D)) < 1e-5 and rel_err(den2, g[neigh + "_den"].reshape(-1)) < 1e-5
+
+
 @pytest.mark.parametrize("neigh", ["mexican_hat", "gaussian"])
 def test_hexagonal_compact_support_mask_at_a_sigma_one_ulp_off_the_lattice(neigh):
     """asymptotic_decay(5, ., 1, 3) = 5 / (1 + 2/3) = 3.0000000000000004: the reference's mask `nx < cx + sigma`

@@ -388,3 +388,45 @@ def test_g15_update(topo, shape):
         assert np.array_equal(bmu, g[key + "_bmu"])
         np.testing.assert_allclose(num, g[key + "_num"], rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(den, g[key + "_den"], rtol=1e-5, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- G16 hexagonal compact_support, lattice sigma
+@pytest.mark.parametrize("XY", [(10, 12), (9, 7)])
+def test_g16_hexagonal_compact_support_tensors_at_a_sigma_one_ulp_off_the_lattice(XY):
+    """sigma = 5 / (1 + 2/3) = 3.0000000000000004: the generic masks round cx -/+ sigma before comparing
+    (neighborhoods.py:50-54, :91-93), so the boundary units depend on the BMU's absolute coordinate.  Bit-exact."""
+    g = load_golden("g16_hex_compact_lattice_sigma")
+    X, Y = XY
+    sig = float(g["sigma"])
+    assert sig != 3.0 and abs(sig - 3.0) < 1e-15
+    ci, cj = np.divmod(np.arange(X * Y), Y)
+    for wide in (False, True):
+        tag = f"{X}x{Y}_{'f64' if wide else 'f32'}"
+        for name, f in (("gauss_", O.neigh_gaussian_hex), ("mex_", O.neigh_mexican_hat_hex)):
+            got = f(X, Y, 1.0, True, ci, cj, sig, wide)
+            assert got.dtype == g[name + tag].dtype
+            np.testing.assert_array_equal(got, g[name + tag])
+    # the mask IS position dependent at this sigma: the same (dx = 3.0) pair is inside for one BMU and outside for another
+    m = g[f"gauss_{X}x{Y}_f64"] != 0
+    inside = []
+    for b in range(X * Y):
+        i0, j0 = divmod(b, Y)
+        if i0 + 3 < X:
+            inside.append(bool(m[b, i0 + 3, j0]))            # same row: dx = 3.0 exactly
+    assert any(inside) and not all(inside)
+
+
+@pytest.mark.parametrize("neigh", ["gaussian", "mexican_hat"])
+def test_g16_update(neigh):
+    g = load_golden("g16_hex_compact_lattice_sigma")
+    X, Y, D, n = 10, 12, 16, 200
+    data = O.gaussian_blobs(n, D, seed=1131)
+    w0 = O.default_codebook(X, Y, D, 131).astype(F32)
+    eta, sig = O.asymptotic_decay(0.5, 0.01, 1, 3), O.asymptotic_decay(5.0, 1, 1, 3)
+    assert float(eta) == float(g[neigh + "_eta"]) and float(sig) == float(g["sigma"])
+    bmu, num, den = O.update(data, w0, eta, sig, wide=O.decay_is_wide("asymptotic"), compact=True, std_coeff=1.0,
+                             neighbourhood=neigh + "_hex")
+    assert np.array_equal(bmu, g[neigh + "_bmu"])
+    np.testing.assert_allclose(num, g[neigh + "_num"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(den, g[neigh + "_den"], rtol=1e-5, atol=1e-5)
+
