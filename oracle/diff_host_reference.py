@@ -65,7 +65,9 @@ for case in range(n_cases):
         data = np.abs(data) + 0.01
     labels = [int(v) for v in rs.randint(0, 4, size=n)]
     kw = dict(sigma=sigma, learning_rate=lr, decay_function=decay, neighborhood_function=neigh, topology=topo,
-              activation_distance=dist, random_seed=case, n_parallel=4000)
+              activation_distance=dist, random_seed=case, n_parallel=4000, sigmaN=float(rs.choice([1, 1, 0.5, 0])),
+              learning_rateN=float(rs.choice([0.01, 0.01, 0])), std_coeff=float(rs.choice([0.5, 0.25, 1.0])),
+              compact_support=bool(neigh in ("gaussian", "triangle") and rs.rand() < 0.3))
     msgs = []
     try:
         with contextlib.redirect_stdout(io.StringIO()):
@@ -78,8 +80,21 @@ for case in range(n_cases):
             ref.pca_weights_init(data); som.pca_weights_init(data)
         if not same(ref._weights, som._weights, 1e-12): msgs.append(init + " init")
         som._weights = ref._weights.copy()                    # (pca: LAPACK sign noise aside, continue from one state)
-        with contextlib.redirect_stdout(io.StringIO()):
-            ref.train(data, T); som.train(data, T)
+        exc = []
+        for m in (ref, som):                                   # an exception must be the same exception on both sides
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    m.train(data, T)
+                exc.append(None)
+            except Exception as ex:                            # noqa: BLE001
+                exc.append((type(ex).__name__, str(ex)))
+        if exc[0] != exc[1]:
+            msgs.append("train raises %r vs %r" % (exc[0], exc[1]))
+        if exc[0] is not None or exc[1] is not None:
+            if msgs:
+                bad += 1
+                print(f"FAIL case {case}: {X}x{Y}x{D} {decay} {neigh} {topo} {dist}: " + "; ".join(msgs), flush=True)
+            continue
         if not same(ref._weights, som._weights, 2e-6): msgs.append("train %.2e" % np.abs(ref._weights - som._weights).max())
         if ref._weights.dtype != som._weights.dtype: msgs.append("weights dtype")
         som._weights = ref._weights.copy()

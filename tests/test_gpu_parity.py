@@ -1420,3 +1420,17 @@ def test_faithful_update_form_equals_the_bucketed_one(cfg):
         sq.set_data(O.gaussian_blobs(50, 3, seed=1))
         with pytest.raises(SomHipError, match="not a sum of row factor"):
             sq.epoch_accumulate_faithful(1.0, 0.1, True)
+
+
+def test_linear_schedule_ending_at_sigma_zero_with_mexican_hat_raises_like_the_reference():
+    """The reference's last epoch evaluates 2/d with d = 0.0 (a Python float) and raises; the engine would happily
+    compute infinities -- the host raises the same error before the launch."""
+    from xpysom_dask_amd import XPySom
+    data = O.gaussian_blobs(50, 3, seed=1)
+    som = XPySom(5, 5, 3, sigma=1.0, sigmaN=0, decay_function="linear", neighborhood_function="mexican_hat", random_seed=1)
+    with pytest.raises(ZeroDivisionError, match="float division by zero"):
+        som.train(data, 2)
+    som = XPySom(5, 5, 3, sigma=1.0, sigmaN=0, decay_function="linear", neighborhood_function="bubble", random_seed=1)
+    som.train(data, 2)                                             # bubble at sigma 0: nobody inside, weights unchanged
+    assert np.isfinite(som._weights).all()
+

@@ -197,3 +197,18 @@ def test_win_map_labels_map_activation_response_equal_the_per_sample_definition(
     assert resp.shape == (5, 6) and resp.sum() == 400 and all(resp[k] == len(v) for k, v in want_w.items())
     with pytest.raises(ValueError, match="same length"):
         som.labels_map(data, labels[:-1])
+
+
+def test_mexican_hat_with_a_python_float_sigma_of_zero_raises_as_the_reference_does():
+    """neighborhoods.py:72 / :94: `1 - 2/d*p` with d = 2 std_coeff^2 sigma^2 -- a linear schedule that ends at sigmaN=0
+    hands the last epoch a Python float 0.0 and the reference raises ZeroDivisionError there (oracle/diff_host_reference.py
+    found it); a numpy.float64 zero (exponential decay cannot produce one) divides to inf instead."""
+    import numpy as np
+    from xpysom_dask_amd import XPySom
+    som = XPySom(4, 4, 2, neighborhood_function="mexican_hat", decay_function="linear", sigma=1.0, sigmaN=0)
+    with pytest.raises(ZeroDivisionError, match="float division by zero"):
+        som._check_sigma(0.0)
+    som._check_sigma(np.float64(0.0))
+    som._check_sigma(0.5)
+    XPySom(4, 4, 2, neighborhood_function="gaussian")._check_sigma(0.0)      # gaussian: 0/0 -> NaN, no exception
+

@@ -303,6 +303,7 @@ class XPySom:
             sig = self._decay_function(self._sigma, self._sigmaN, iteration, num_epochs)
             # NumPy >= 2: a numpy scalar sigma makes the reference's neighbourhood float64
             neigh_f64 = isinstance(sig, np.generic)
+            self._check_sigma(sig)
             _dist.epoch(eng, sig, eta, neigh_f64)
             if verbose:
                 print('\r [ %d / %d ] %3.0f%%' % (iteration + 1, num_epochs, 100 * (iteration + 1) / num_epochs),
@@ -313,6 +314,14 @@ class XPySom:
         if verbose:
             print('\n quantization error:', self.quantization_error(data))
         return self
+
+    def _check_sigma(self, sig):
+        """mexican_hat evaluates ``1 - 2/d*p`` with ``d = 2*std_coeff**2*sigma**2`` (neighborhoods.py:72, :94): a
+        Python-float sigma of exactly 0 -- a linear schedule ending at sigmaN=0 -- raises there, in the reference, and
+        so here (a numpy.float64 sigma divides to inf with a warning; the gaussian's 0/0 gives NaN in both)."""
+        if self.neighborhood_func_name == 'mexican_hat' and not isinstance(sig, np.generic) \
+                and 2 * self._std_coeff * self._std_coeff * sig * sig == 0:
+            raise ZeroDivisionError('float division by zero')
 
     def train_streaming(self, chunks, num_epochs, iter_beg=0, iter_end=None):
         """``train`` for data that does not stay resident in HBM (or in host memory as one array).
@@ -328,6 +337,7 @@ class XPySom:
         for iteration in range(iter_beg, iter_end):
             eta = self._decay_function(self._learning_rate, self._learning_rateN, iteration, num_epochs)
             sig = self._decay_function(self._sigma, self._sigmaN, iteration, num_epochs)
+            self._check_sigma(sig)
             _dist.epoch(eng, sig, eta, isinstance(sig, np.generic), chunks=chunks())
         self._weights = eng.get_weights().reshape(self._weights.shape)
         return self
