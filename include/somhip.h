@@ -52,10 +52,19 @@ enum { SOM_TOPO_RECTANGULAR = 0, SOM_TOPO_HEXAGONAL = 1 };
  *           |w|^2): ~2^-16 relative error in x.w at 3x the bf16 work -- near-f32 BMUs, faster than F32
  *   F16 / F16X3: the BF16 / BF16X3 kernels instantiated on IEEE half (v_mfma_f32_16x16x32_f16): 11 significant
  *           bits per operand instead of 8 at the same MFMA rate (97 % of the bf16 throughput under the chip's power
- *           limit); rows and units must fit float16 -- som_set_data / som_set_weights refuse norms above 65504 */
+ *           limit); rows and units must fit float16 -- som_set_data / som_set_weights refuse rows and units whose
+ *           norm exceeds 65504; streamed chunks and query rows (som_stream_rows, som_bmu) are not checked: values
+ *           beyond the range saturate at +-65504
+ *   EXACT: the BMUs of F32, row for row and bit for bit (near-ties and exact ties included), at BF16X3 speed: the
+ *           split-bf16 MFMA pass screens every unit, records the minimum of every 64-unit group per row, and the
+ *           float32 fma chain itself re-scores the groups the screen's rigorous error bound cannot rule out; rows it
+ *           cannot vouch for (NaN / infinite values, more than 32 candidate groups) go to the F32 kernel.  Euclidean
+ *           distance, input_len <= 128; other configurations run the F32 kernels under this id (which are the exact
+ *           mode by definition).  Everything but the BMU search (update, merge, quantization) is as in F32. */
 enum { SOM_PREC_F32 = 0, SOM_PREC_BF16 = 1, SOM_PREC_BF16X3 = 2,
        SOM_PREC_F16 = 3,      /* the bf16 path on IEEE half operands: 11 significant bits instead of 8, |value| <= 65504 */
-       SOM_PREC_F16X3 = 4 };  /* the bf16x3 path on IEEE half hi/lo pairs */
+       SOM_PREC_F16X3 = 4,    /* the bf16x3 path on IEEE half hi/lo pairs */
+       SOM_PREC_EXACT = 5 };  /* F32's BMUs through the split-bf16 screen + float32 re-score (bmu_exact.hpp) */
 
 /* which BMU rule som_bmu applies */
 enum { SOM_BMU_ACTIVATION = 0,   /* configured activation distance: XPySom._winner, xpysom.py:410-417 */
@@ -196,6 +205,11 @@ int som_distance_matrix(som_handle* h, const float* x_host, int64_t n_rows, int3
  * runs through the configured MFMA path (same argmin up to the operand rounding), as does som_bmu's
  * QUANTIZATION mode. */
 int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, double* qe_out);
+
+/* precision EXACT bookkeeping: rows screened so far, rows that went to the float32 fallback kernel, screen passes */
+int som_exact_stats(som_handle* h, int64_t* rows, int64_t* rows_fallback, int64_t* passes);
+/* candidate groups per row of the LAST screen pass (its first n rows): how many 64-unit groups the re-score visited */
+int som_exact_last_counts(som_handle* h, int32_t* counts_out, int64_t n);
 
 /* stream / timing plumbing */
 int som_sync(som_handle* h);

@@ -1,0 +1,193 @@
+"""precision='exact' (csrc/bmu_exact.hpp): the BMUs of the float32 parity kernel, bit for bit, through the split-bf16
+screen + float32 re-score.  The checker here is the float32 kernel itself (whose own parity with the reference is
+pinned by tests/test_gpu_parity.py): every test demands IDENTICAL ids, never "near".  GPU only (`-m gpu`)."""
+import numpy as np
+import pytest
+
+from oracle import som_oracle as O
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def engine(X, Y, D, **kw):
+    from xpysom_dask_amd.engine import HipEngine
+    return HipEngine(X, Y, D, **kw)
+
+
+def both(X, Y, D, w, data, sigma=3.0, eta=0.4):
+    """(ids from the epoch path, ids from the query path) of 'f32' and of 'exact' + the exact engine's stats."""
+    out = {}
+    for p in ("f32", "exact"):
+        e = engine(X, Y, D, precision=p)
+        e.set_weights(w)
+        e.set_data(data)
+        e.epoch_accumulate(sigma, eta, True)
+        num, den, bmu = e.epoch_fetch()
+        q = e.bmu(data[:777])
+        out[p] = (bmu, q, num, den, e.exact_stats() if p == "exact" else None)
+        e.close()
+    return out
+
+
+SHAPES = [(6, 6, 4, 150), (20, 24, 128, 5000), (30, 30, 17, 3001), (64, 64, 32, 20000), (40, 50, 100, 4000),
+          (128, 128, 64, 9000), (3, 5, 1, 200), (37, 1, 9, 500), (1, 1, 5, 64), (25, 25, 127, 1000), (10, 7, 33, 129)]
+
+
+@pytest.mark.parametrize("X,Y,D,n", SHAPES)
+def test_exact_bmus_are_the_float32_bmus_on_a_seeded_codebook(X, Y, D, n):
+    data = O.gaussian_blobs(n, D, seed=D + n)
+    w = O.default_codebook(X, Y, D, 11).astype(F32)
+    r = both(X, Y, D, w, data)
+    assert np.array_equal(r["exact"][0], r["f32"][0])
+    assert np.array_equal(r["exact"][1], r["f32"][1])
+    # the update path is the shared float32 one: identical BMUs give identical accumulators
+    assert np.array_equal(r["exact"][2], r["f32"][2]) and np.array_equal(r["exact"][3], r["f32"][3])
+    rows, fb, _ = r["exact"][4]
+    assert rows >= n and fb <= max(2, n // 100)          # the float32 fallback kernel is the exception, not the path
+
+
+@pytest.mark.parametrize("X,Y,D,n,T", [(24, 24, 16, 6000, 8), (64, 64, 32, 20000, 6), (48, 40, 128, 8000, 5)])
+def test_exact_training_is_bitwise_the_float32_training(X, Y, D, n, T):
+    """Smooth maps (large sigma: neighbouring units nearly identical, hundreds of near-ties per row) are where a
+    screen is most often unsure.  Identical BMUs in every epoch <=> identical codebooks after T epochs."""
+    from xpysom_dask_amd import XPySom
+    data = O.gaussian_blobs(n, D, seed=5)
+    ws = {}
+    for p in ("f32", "exact"):
+        som = XPySom(X, Y, D, random_seed=3, precision=p)
+        som.train(data, T)
+        ws[p] = som._weights.copy()
+        if p == "exact":
+            rows, fb, _ = som._engine().exact_stats()
+            assert rows == n * T and fb <= rows // 50
+    assert np.array_equal(ws["exact"], ws["f32"])
+
+
+def test_exact_on_a_trained_smooth_map_state_by_state():
+    """Epoch by epoch from the float32 trajectory's own codebooks: the ids of every state agree."""
+    X, Y, D, n, T = 64, 64, 32, 16384, 6
+    data = O.gaussian_blobs(n, D, seed=9)
+    w = O.default_codebook(X, Y, D, 2).astype(F32)
+    f = engine(X, Y, D, precision="f32")
+    x = engine(X, Y, D, precision="exact")
+    f.set_data(data)
+    x.set_data(data)
+    f.set_weights(w)
+    for t in range(T):
+        sig, eta = O.exponential_decay(32.0, 1.0, t, T), O.exponential_decay(0.5, 0.01, t, T)
+        x.set_weights(f.get_weights())
+        f.epoch_accumulate(sig, eta, True)
+        x.epoch_accumulate(sig, eta, True)
+        bf, bx = f.epoch_fetch()[2], x.epoch_fetch()[2]
+        assert np.array_equal(bf, bx), "epoch %d: %d rows differ" % (t, (bf != bx).sum())
+        f.epoch_merge()
+    rows, fb, _ = x.exact_stats()
+    assert fb <= rows // 50
+    f.close()
+    x.close()
+
+
+def test_exact_ties_and_degenerate_rows():
+    """Exact ties (duplicated units, an all-zero codebook, zero rows) resolve to the lowest raveled id as numpy.argmin
+    does; small-integer data makes every product exact, so the answer is known without any kernel."""
+    rng = np.random.RandomState(0)
+    X, Y, D = 9, 8, 8
+    w = rng.randint(-3, 4, size=(X * Y, D)).astype(F32)
+    w[40] = w[7]
+    w[55] = w[7]
+    w[3] = 0
+    data = rng.randint(-3, 4, size=(500, D)).astype(F32)
+    data[10] = 0
+    data[11] = w[7]
+    want = (-2 * data.astype(np.float64) @ w.T.astype(np.float64) + (w.astype(np.float64) ** 2).sum(1)[None]).argmin(1)
+    r = both(X, Y, D, w.reshape(X, Y, D), data)
+    assert np.array_equal(r["f32"][0], want)
+    assert np.array_equal(r["exact"][0], want)
+    zero = both(X, Y, D, np.zeros((X, Y, D), F32), data)
+    assert (zero["exact"][0] == 0).all() and (zero["f32"][0] == 0).all()
+
+
+def test_exact_near_ties_below_the_screen_resolution():
+    """Units that differ from each other by a few float32 ulps: far below what the split-bf16 screen resolves, so the
+    re-score decides every row, and it must decide as the float32 kernel does."""
+    rng = np.random.RandomState(4)
+    X, Y, D, n = 16, 16, 64, 3000
+    base = rng.randn(1, D).astype(F32)
+    w = np.repeat(base, X * Y, axis=0)
+    w *= (1.0 + rng.randint(-4, 5, size=(X * Y, 1)) * 2.0 ** -22).astype(F32)      # clusters of near-identical units
+    data = (base + 0.05 * rng.randn(n, D)).astype(F32)
+    r = both(X, Y, D, w.reshape(X, Y, D), data)
+    assert np.array_equal(r["exact"][0], r["f32"][0])
+    assert np.array_equal(r["exact"][1], r["f32"][1])
+
+
+def test_exact_rows_with_nan_and_inf_take_the_float32_fallback():
+    X, Y, D, n = 12, 12, 24, 900
+    data = O.gaussian_blobs(n, D, seed=1)
+    data[5, 3] = np.nan
+    data[77] = np.inf
+    data[200, 0] = -np.inf
+    data[300] = 1e30                                      # finite, but its products overflow float32
+    w = O.default_codebook(X, Y, D, 5).astype(F32)
+    r = both(X, Y, D, w, data)
+    assert np.array_equal(r["exact"][0], r["f32"][0])
+    rows, fb, _ = r["exact"][4]
+    assert fb >= 3
+
+
+def test_exact_many_candidate_groups_overflow_to_the_fallback():
+    """A codebook of identical units: every group is a candidate of every row (more than the list holds)."""
+    X, Y, D, n = 64, 64, 16, 700
+    w = np.ones((X, Y, D), F32)
+    data = O.gaussian_blobs(n, D, seed=8)
+    r = both(X, Y, D, w, data)
+    assert (r["f32"][0] == 0).all() and np.array_equal(r["exact"][0], r["f32"][0])
+    rows, fb, _ = r["exact"][4]
+    assert fb >= n                                        # 64 groups > 32 list entries: all rows through the float32 kernel
+
+
+def test_exact_magnitudes_and_streamed_chunks():
+    X, Y, D, n = 20, 20, 48, 4096
+    for scale in (1e-3, 1.0, 1e3):
+        data = (O.gaussian_blobs(n, D, seed=2) * scale).astype(F32)
+        w = (O.default_codebook(X, Y, D, 6) * scale).astype(F32)
+        r = both(X, Y, D, w, data)
+        assert np.array_equal(r["exact"][0], r["f32"][0]), scale
+    # streamed chunks (pageable): same sums as the resident epoch of the float32 engine
+    data = O.gaussian_blobs(n, D, seed=2)
+    w = O.default_codebook(X, Y, D, 6).astype(F32)
+    outs = {}
+    for p in ("f32", "exact"):
+        e = engine(X, Y, D, precision=p)
+        e.set_weights(w)
+        e.stream_epoch_accumulate([data[:1000], data[1000:1001], data[1001:]], 2.0, 0.3, True)
+        outs[p] = e.epoch_fetch(want_bmu=False)[:2]
+        e.close()
+    assert np.array_equal(outs["exact"][0], outs["f32"][0]) and np.array_equal(outs["exact"][1], outs["f32"][1])
+
+
+def test_exact_falls_back_to_float32_kernels_where_the_screen_does_not_apply():
+    """input_len > 128 and the non-euclidean distances: 'exact' is served by the float32 kernels themselves."""
+    X, Y, n = 12, 12, 600
+    for D, dist in ((200, "euclidean"), (32, "cosine"), (16, "manhattan")):
+        data = np.abs(O.gaussian_blobs(n, D, seed=3))
+        w = np.abs(O.default_codebook(X, Y, D, 4)).astype(F32)
+        ids = {}
+        for p in ("f32", "exact"):
+            e = engine(X, Y, D, precision=p, distance=dist)
+            e.set_weights(w)
+            ids[p] = e.bmu(data)
+            e.close()
+        assert np.array_equal(ids["exact"], ids["f32"])
+
+
+def test_exact_class_surface():
+    from xpysom_dask_amd import XPySom
+    data = O.gaussian_blobs(500, 6, seed=1)
+    a = XPySom(7, 7, 6, random_seed=1, precision="exact").train(data, 3)
+    b = XPySom(7, 7, 6, random_seed=1, precision="f32").train(data, 3)
+    assert np.array_equal(a._weights, b._weights)
+    assert a.winner(data) == b.winner(data)
+    assert a.quantization_error(data) == b.quantization_error(data)
+    assert a.topographic_error(data) == b.topographic_error(data)

@@ -23,6 +23,7 @@
 #include "bmu_bf16_k16x3.hpp"
 #include "bmu_bf16_tiled.hpp"
 #include "bmu_bf16_wide.hpp"
+#include "bmu_exact.hpp"
 #include "bmu_f32.hpp"
 #include "bmu_f32_res.hpp"
 #include "bmu_f32_tiled.hpp"
@@ -65,6 +66,16 @@ struct som_handle {
     int x3 = 0;              // precision bf16x3 / f16x3: hi/lo split operands, tripled feature axis
     bool f16 = false;        // precision f16 / f16x3: _Float16 operands instead of __bf16 (the same kernels, som_common.hpp)
     bool x3res = false;      // bf16x3 with input_len <= 128: the register-resident split kernel (bmu_bf16_k16x3.hpp)
+    bool exact = false;      // precision 'exact': split-bf16 screen + float32 re-score of the candidates (bmu_exact.hpp)
+    struct ExactScratch {
+        uint32_t* gmin = nullptr;            // [n_groups][stride] group minima of the chunk being screened
+        long stride = 0;                     //   rows per group line (a chunk of the row set, padded)
+        int *cand = nullptr, *count = nullptr, *fb_list = nullptr, *fb_count = nullptr, *fb_ids = nullptr;
+        float* fbX = nullptr;                // fallback rows, dense, for the float32 kernel
+        long fb_cap = 0;
+        int* fb_count_host = nullptr;        // pinned
+        int64_t rows_total = 0, rows_fallback = 0, chunks = 0;   // som_exact_stats
+    } ex;
     int n_kchunks = 0;       // tiled: 64-feature chunks
     int n_ublocks = 0;       // tiled: unit blocks of tl_bn
     bool tl_big = false;     // tiled: 256 x 256 workgroup tiles (8 waves) instead of 128 x 128
@@ -321,8 +332,11 @@ int prep_codebook_half(som_handle* h) {
         default: return fail(h, "the split resident kernel supports input_len <= 128");
         }
         HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
-        rownorm_bf16_kernel<E><<<dim3((unsigned)cdiv(h->K, 4)), block, 0, h->stream>>>(   // exact float32 |w|^2
-            h->W, h->K, h->D, unit, unit != nullptr, h->wn, h->wmax2, 1);
+        if (h->exact)                                     // the float32 kernel's own |w|^2 (refreshed just before)
+            exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(h->K, 256)), block, 0, h->stream>>>(h->wsq, h->K, h->wn, h->wmax2);
+        else
+            rownorm_bf16_kernel<E><<<dim3((unsigned)cdiv(h->K, 4)), block, 0, h->stream>>>(   // exact float32 |w|^2
+                h->W, h->K, h->D, unit, unit != nullptr, h->wn, h->wmax2, 1);
         return 0;
     }
     const long total = (long)h->n_stages * K16_T * h->ks32 * 64;
@@ -341,6 +355,7 @@ int prep_codebook_half(som_handle* h) {
 
 // need_f32: the caller is about to run a float32 kernel (parity-mode BMU, top-2, distance matrix).
 int refresh_codebook_operands(som_handle* h, bool need_f32) {
+    if (h->exact) need_f32 = true;                       // the re-score reads the float32 stage image and |w|^2
     const bool bf = h->cfg.precision != SOM_PREC_F32;
     const bool do_f32 = (need_f32 || !bf) && h->wf_dirty;
     const bool do_bf = bf && h->w_dirty;
@@ -737,12 +752,153 @@ int launch_bmu_pairwise(som_handle* h, const float* X, long N, int p, bool even,
     return 0;
 }
 
+// ---- precision 'exact' (bmu_exact.hpp): screen -> candidate groups -> float32 re-score -> float32 fallback ----------
+// E(n) = cA |x_n| wmax + cW wmax^2 + cB Bm in d' units; derivation in bmu_exact.hpp.  KAPPA ulps are charged per MFMA.
+constexpr double EX_KAPPA = 4.0;
+ExactBound exact_bound(const som_handle* h) {
+    const double u = std::ldexp(1.0, -24), ub = h->f16 ? std::ldexp(1.0, -11) : std::ldexp(1.0, -8);
+    const double Dl = 8.0 * h->fr_kg;                    // chain length of the float32 kernel (zero padded)
+    const double gamma = Dl * u / (1.0 - Dl * u);
+    const double n_mfma = 3.0 * h->ks32;
+    const double slop = 1.01;                             // the kernel evaluates E in float32
+    ExactBound eb;
+    eb.cA = (float)(slop * ((2.0 * gamma + 2.0 * u) * (1.0 + u) + 2.0 * ub * ub * (3.0 + 5.0 * ub)));
+    eb.cW = (float)(slop * u);
+    eb.cB = (float)(slop * 2.0 * (EX_KAPPA * n_mfma + 9.0) * std::ldexp(1.0, -23));
+    return eb;
+}
+
+// rows of one screen pass: the group-minimum matrix of a pass stays within ~1 GiB
+long exact_chunk_rows(const som_handle* h) {
+    const long n_groups = cdiv(h->K, EX_GROUP);
+    long rows = (1L << 30) / (4 * n_groups);
+    rows = rows / ROW_PAD * ROW_PAD;
+    return rows < ROW_PAD ? ROW_PAD : rows;
+}
+
+int exact_reserve(som_handle* h, long rows) {
+    auto& ex = h->ex;
+    const long stride = round_up(std::min(rows, exact_chunk_rows(h)), 256);
+    if (stride <= ex.stride) return 0;
+    void* old[] = {ex.gmin, ex.cand, ex.count, ex.fb_list};
+    for (void* p : old) if (p) (void)hipFree(p);
+    ex.gmin = nullptr; ex.cand = nullptr; ex.count = nullptr; ex.fb_list = nullptr; ex.stride = 0;
+    const long n_groups = cdiv(h->K, EX_GROUP);
+    if (int rc = dev_alloc(h, &ex.gmin, (size_t)n_groups * stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.cand, (size_t)stride * EX_CAND)) return rc;
+    if (int rc = dev_alloc(h, &ex.count, (size_t)stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.fb_list, (size_t)stride)) return rc;
+    if (!ex.fb_count) {
+        if (int rc = dev_alloc(h, &ex.fb_count, 1)) return rc;
+        HIPCHK(h, hipHostMalloc((void**)&ex.fb_count_host, sizeof(int), hipHostMallocDefault));
+    }
+    ex.stride = stride;
+    return 0;
+}
+
+template <int KS32, class E>
+int exact_screen(som_handle* h, const __bf16* Xb, long n, unsigned long long* best64) {
+    auto kern = bmu_bf16_k16x3_kernel<KS32, E, true>;
+    size_t lds = 2 * (size_t)k3_stage_bytes(KS32);
+    int per_cu = 1;
+    if (int rc = kernel_per_cu(h, (const void*)kern, 64 * K3_NW, lds, &per_cu)) return rc;
+    const long blocks = cdiv(n, K3_WG_SAMPLES);
+    const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
+    const int n_groups = (int)cdiv(h->n_stages, 2);
+    int parts = choose_parts(h, blocks, slots, n_groups);
+    if (h->env_bf16_parts > 0) parts = std::min(h->env_bf16_parts, n_groups);
+    if (h->debug)
+        std::fprintf(stderr, "[somhip] exact screen: blocks=%ld per_cu=%d slots=%ld parts=%d groups=%d\n", blocks, per_cu, slots,
+                     parts, n_groups);
+    kern<<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * K3_NW), lds, h->stream>>>(Xb, n, h->Wst, h->n_stages, h->K, best64,
+                                                                                      h->ex.gmin, h->ex.stride);
+    return 0;
+}
+
+template <class E>
+int exact_screen_ks(som_handle* h, const __bf16* Xb, long n, unsigned long long* best64) {
+    switch (h->ks32) {
+    case 1: return exact_screen<1, E>(h, Xb, n, best64);
+    case 2: return exact_screen<2, E>(h, Xb, n, best64);
+    case 3: return exact_screen<3, E>(h, Xb, n, best64);
+    case 4: return exact_screen<4, E>(h, Xb, n, best64);
+    }
+    return fail(h, "exact: the screen kernel supports input_len <= 128");
+}
+
+int exact_rescore(som_handle* h, const float* X, long n, int* out) {
+    const dim3 grid((unsigned)cdiv(n, 4)), block(256);
+    auto& ex = h->ex;
+    switch (h->fr_kg) {
+#define SOM_EX_CASE(kg) case kg: exact_rescore_kernel<kg><<<grid, block, 0, h->stream>>>(X, n, h->D, h->Wfst, h->K, ex.cand, ex.count, out, ex.fb_list, ex.fb_count); break;
+    SOM_EX_CASE(1) SOM_EX_CASE(2) SOM_EX_CASE(4) SOM_EX_CASE(8) SOM_EX_CASE(16)
+#undef SOM_EX_CASE
+    default: return fail(h, "exact: bad k-group count");
+    }
+    return 0;
+}
+
+// X, xsq, Xb, out: the row set's float32 rows, their |x|^2, their hi / lo operand image, the ids to write.
+int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, const __bf16* Xb, const float* xmax2, int* out) {
+    if (h->capturing) return fail(h, "precision 'exact' reads a counter back per pass: not capturable");
+    if (!xsq) return fail(h, "exact: no row norms");
+    auto& ex = h->ex;
+    if (int rc = exact_reserve(h, N)) return rc;
+    if (N > h->best64_cap) {
+        (void)hipFree(h->best64);
+        h->best64 = nullptr; h->best64_cap = 0;
+        if (int rc = dev_alloc(h, &h->best64, (size_t)round_up(N, 1024))) return rc;
+        h->best64_cap = round_up(N, 1024);
+    }
+    const long units = (long)h->n_stages * h->stage_units;
+    prep_wsqh_kernel<<<dim3((unsigned)cdiv(std::max(units, N), 256)), dim3(256), 0, h->stream>>>(
+        h->wn, h->K, h->wmax2, xmax2, h->Wst, h->n_stages, h->stage_bytes, h->stage_units, h->best64, N);
+    const ExactBound eb = exact_bound(h);
+    const int n_groups = (int)cdiv(h->K, EX_GROUP);
+    const long chunk = std::min(exact_chunk_rows(h), ex.stride);
+    for (long r0 = 0; r0 < N; r0 += chunk) {
+        const long n = std::min(chunk, N - r0);
+        HIPCHK(h, hipMemsetAsync(ex.count, 0, (size_t)n * sizeof(int), h->stream));
+        HIPCHK(h, hipMemsetAsync(ex.fb_count, 0, sizeof(int), h->stream));
+        if (int rc = SOM_HALF(h, exact_screen_ks, h, Xb + r0 * h->dp, n, h->best64 + r0)) return rc;
+        exact_scan_kernel<<<dim3((unsigned)cdiv(n, 64)), dim3(64 * EX_SCAN_SPLIT), 0, h->stream>>>(
+            ex.gmin, ex.stride, n_groups, n, h->best64 + r0, xsq + r0, h->wmax2, xmax2, eb, ex.cand, ex.count);
+        if (int rc = exact_rescore(h, X + r0 * h->D, n, out + r0)) return rc;
+        HIPCHK(h, hipGetLastError());
+        // rows the scheme could not settle (normally none): the float32 kernel itself
+        HIPCHK(h, hipMemcpyAsync(ex.fb_count_host, ex.fb_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const int n_fb = *ex.fb_count_host;
+        ex.rows_total += n; ex.rows_fallback += n_fb; ex.chunks += 1;
+        if (n_fb < 0 || n_fb > n) return fail(h, "exact: fallback counter out of range");
+        if (n_fb > 0) {
+            if (n_fb > ex.fb_cap) {
+                (void)hipFree(ex.fbX); (void)hipFree(ex.fb_ids);
+                ex.fbX = nullptr; ex.fb_ids = nullptr; ex.fb_cap = 0;
+                const long cap = round_up(n_fb, 1024);
+                if (int rc = dev_alloc(h, &ex.fbX, (size_t)cap * h->D)) return rc;
+                if (int rc = dev_alloc(h, &ex.fb_ids, (size_t)cap)) return rc;
+                ex.fb_cap = cap;
+            }
+            exact_gather_rows_kernel<<<dim3((unsigned)cdiv((long)n_fb * h->D, 256)), dim3(256), 0, h->stream>>>(
+                X + r0 * h->D, ex.fb_list, n_fb, h->D, ex.fbX);
+            // (its part merge may reuse best64[0 .. n_fb): rows this pass has already settled)
+            if (int rc = launch_bmu_f32_any<SCORE_EUCLID_PART>(h, ex.fbX, n_fb, nullptr, ex.fb_ids)) return rc;
+            exact_scatter_ids_kernel<<<dim3((unsigned)cdiv(n_fb, 256)), dim3(256), 0, h->stream>>>(ex.fb_ids, ex.fb_list, n_fb,
+                                                                                                out + r0);
+            HIPCHK(h, hipGetLastError());
+        }
+    }
+    return 0;
+}
+
 // BMU of `N` device rows with the configured activation distance (xpysom.py:410-417)
 int run_activation_bmu(som_handle* h, const float* X, long N, const float* xsq, const __bf16* Xb, const float* xmax2,
                        int* out) {
     if (N == 0) return 0;
     if (int rc = refresh_codebook_operands(h, h->cfg.precision == SOM_PREC_F32)) return rc;
     Timed t(h, SOM_K_BMU);
+    if (h->exact) return launch_bmu_exact(h, X, N, xsq, Xb, xmax2, out);
     if (h->cfg.precision != SOM_PREC_F32) return launch_bmu_bf16(h, Xb, xmax2, N, out);
     switch (h->cfg.distance) {
     case SOM_DIST_EUCLIDEAN: return launch_bmu_f32_any<SCORE_EUCLID_PART>(h, X, N, xsq, out);
@@ -756,6 +912,7 @@ int run_activation_bmu(som_handle* h, const float* X, long N, const float* xsq, 
 }
 
 bool needs_xsq(const som_handle* h) {
+    if (h->exact) return true;                          // |x_n| scales the row's error bound (bmu_exact.hpp)
     return h->cfg.precision == SOM_PREC_F32 &&
            (h->cfg.distance == SOM_DIST_EUCLIDEAN_NO_OPT || h->cfg.distance == SOM_DIST_COSINE);
 }
@@ -1057,7 +1214,7 @@ int som_create(const som_config* cfg, som_handle** out) {
     if ((long)cfg->x * cfg->y > (1L << 30)) return fail(nullptr, "som_create: map too large");
     if (cfg->distance < 0 || cfg->distance > SOM_DIST_NORM_P_NO_OPT) return fail(nullptr, "som_create: unknown distance id");
     if (cfg->norm_p < 0 || cfg->norm_p > PW_MAX_P) return fail(nullptr, "som_create: norm_p out of range (1..16)");
-    if (cfg->distance >= SOM_DIST_MANHATTAN && cfg->precision != SOM_PREC_F32)
+    if (cfg->distance >= SOM_DIST_MANHATTAN && cfg->precision != SOM_PREC_F32 && cfg->precision != SOM_PREC_EXACT)
         return fail(nullptr, "som_create: manhattan / norm_p distances are float32 VALU kernels (precision f32)");
     if (cfg->neighborhood < 0 || cfg->neighborhood > SOM_NEIGH_TRIANGLE)
         return fail(nullptr, "som_create: unknown neighbourhood id");
@@ -1069,9 +1226,9 @@ int som_create(const som_config* cfg, som_handle** out) {
         return fail(nullptr, "som_create: unknown topology id");
     if (cfg->topology == SOM_TOPO_HEXAGONAL && cfg->neighborhood == SOM_NEIGH_TRIANGLE)
         return fail(nullptr, "som_create: the hexagonal topology has no triangle neighbourhood (xpysom.py:271-279)");
-    if (cfg->precision < SOM_PREC_F32 || cfg->precision > SOM_PREC_F16X3)
+    if (cfg->precision < SOM_PREC_F32 || cfg->precision > SOM_PREC_EXACT)
         return fail(nullptr, "som_create: unknown precision id");
-    if (cfg->precision != SOM_PREC_F32) {
+    if (cfg->precision != SOM_PREC_F32 && cfg->precision != SOM_PREC_EXACT) {
         if (cfg->distance == SOM_DIST_EUCLIDEAN_NO_OPT)
             return fail(nullptr, "som_create: bf16 precision implements 'euclidean' and 'cosine' "
                                  "('euclidean_no_opt' has the same argmin as 'euclidean')");
@@ -1083,14 +1240,21 @@ int som_create(const som_config* cfg, som_handle** out) {
 
     som_handle* h = new som_handle();
     h->cfg = *cfg;
+    if (cfg->precision == SOM_PREC_EXACT) {
+        // the screen + re-score scheme covers the euclidean distance up to 128 features; everywhere else the
+        // float32 kernels ARE the exact mode
+        if (cfg->distance == SOM_DIST_EUCLIDEAN && cfg->input_len <= 128) h->exact = true;
+        else h->cfg.precision = SOM_PREC_F32;
+    }
+    cfg = &h->cfg;
     h->X = cfg->x; h->Y = cfg->y; h->K = cfg->x * cfg->y; h->D = cfg->input_len;
     h->D1p = (int)round_up(h->D + 1, 4);
     h->norm_p = cfg->norm_p > 0 ? cfg->norm_p : 2;
     h->ks32 = (int)cdiv(h->D, 32);
-    h->x3 = cfg->precision == SOM_PREC_BF16X3 || cfg->precision == SOM_PREC_F16X3;
+    h->x3 = cfg->precision == SOM_PREC_BF16X3 || cfg->precision == SOM_PREC_F16X3 || h->exact;
     h->f16 = cfg->precision == SOM_PREC_F16 || cfg->precision == SOM_PREC_F16X3;
     h->x3res = h->x3 && h->D <= 128;
-    if (const char* e = std::getenv("SOM_X3_TILED")) if (std::atoi(e) != 0) h->x3res = false;   // A/B: the tiled split kernel
+    if (const char* e = std::getenv("SOM_X3_TILED")) if (std::atoi(e) != 0 && !h->exact) h->x3res = false;   // A/B: the tiled split kernel
     h->tiled = ((cfg->precision == SOM_PREC_BF16 || cfg->precision == SOM_PREC_F16) && h->D > 128) || (h->x3 && !h->x3res);
     if (h->tiled) {
         // 256 x 256 tiles need enough units to amortise them; SOM_BF16_TILE=128|256 overrides
@@ -1160,7 +1324,10 @@ int som_create(const som_config* cfg, som_handle** out) {
         const size_t nb = (size_t)h->nt * (cdiv(h->Y, LM_BM) + cdiv(h->X, LM_BM));
         if ((rc = dev_alloc(h, &h->bands, nb))) return bail(rc);
     }
+    // (T: stage 1 of the transform writes the feature columns and the count column only; the padding columns behind
+    //  them are read by a whole-row stage 2 and end up in ACC's padding, which is all-reduced: keep them defined)
     if (hipMemsetAsync(h->W, 0, (size_t)h->K * h->D * sizeof(float), h->stream) != hipSuccess ||
+        hipMemsetAsync(h->T, 0, KD1 * h->nt * sizeof(float), h->stream) != hipSuccess ||
         hipMemsetAsync(h->ACC, 0, KD1 * sizeof(float), h->stream) != hipSuccess)
         return bail(fail(h, "hipMemsetAsync failed"));
     if (h->D > 128) {
@@ -1209,6 +1376,11 @@ void som_destroy(som_handle* h) {
     for (void* b : bufs) if (b) (void)hipFree(b);
     seg_free(h->seg);
     seg_free(h->st_seg);
+    {
+        void* eb[] = {h->ex.gmin, h->ex.cand, h->ex.count, h->ex.fb_list, h->ex.fb_count, h->ex.fb_ids, h->ex.fbX};
+        for (void* b : eb) if (b) (void)hipFree(b);
+        if (h->ex.fb_count_host) (void)hipHostFree(h->ex.fb_count_host);
+    }
     for (auto& sl : h->slot) {
         void* sb[] = {sl.dX, sl.dXb, sl.dxsq, sl.dbmu};
         for (void* b : sb) if (b) (void)hipFree(b);
@@ -1224,11 +1396,13 @@ int som_set_weights(som_handle* h, const float* w_host) {
     DeviceGuard dev_guard(h);
     if (!h || !w_host) return fail(h, "som_set_weights: NULL argument");
     if (h->f16 && h->cfg.distance != SOM_DIST_COSINE) {   // (cosine rounds unit-length rows)
-        const size_t n = (size_t)h->K * h->D;
-        float m = 0.0f;
-        for (size_t i = 0; i < n; ++i) { const float a = std::fabs(w_host[i]); if (a > m && a <= 3.0e38f) m = a; }   // finite values only
-        if (!(m * std::sqrt((float)h->D) <= HALF_MAX))
-            return fail(h, "som_set_weights: precision 'f16' needs units of norm <= 65504 (float16 range): scale the data, or use 'bf16' / 'f32'");
+        // every unit's own norm must fit IEEE half (NaN / infinite units are left to the kernels' NaN rules)
+        for (long k = 0; k < h->K; ++k) {
+            double q = 0.0;
+            for (int d = 0; d < h->D; ++d) { const double v = w_host[k * h->D + d]; q += v * v; }
+            if (q > (double)HALF_MAX * HALF_MAX && q <= 1.0e300)
+                return fail(h, "som_set_weights: precision 'f16' needs units of norm <= 65504 (float16 range): scale the data, or use 'bf16' / 'f32'");
+        }
     }
     if (int rc = h2d_blocking(h, h->W, w_host, (size_t)h->K * h->D * sizeof(float))) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1367,7 +1541,7 @@ int som_epoch_accumulate(som_handle* h, double sigma, double eta, int neigh_f64)
     if (!h->Xd && h->N > 0) return fail(h, "som_epoch_accumulate: no resident data (call som_set_data)");
     // launch-bound maps (many short kernels per epoch) replay a captured graph; profiling needs the
     // per-kernel events of the eager path
-    if (h->use_graph && !h->prof && h->N > 0) {
+    if (h->use_graph && !h->prof && h->N > 0 && !h->exact) {
         const bool same = h->gexec && h->gexec_gen == h->alloc_gen && h->gexec_rows == h->Xd && h->gexec_n == h->N;
         if (!same) {
             if (h->graph_warm == 0 || h->gexec_rows != h->Xd || h->gexec_n != h->N) {
@@ -1551,18 +1725,20 @@ int som_epoch_accumulate_block(som_handle* h, int32_t block, int64_t* offset, in
 namespace {
 int rccl_load(const char* path) {
     if (g_rccl.lib) return 0;
-    const char* cands[] = {path, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    // an explicit path means that library and no other; NULL: a copy some other component of the process already
+    // loaded (torch's), else the system's
+    const char* search[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    const char* only[] = {path};
+    const char* const* cands = path ? only : search;
+    const int n_cands = path ? 1 : 3;
     void* lib = nullptr;
-    for (const char* c : cands) {                       // a copy some other component of the process already loaded, first
-        if (!c) continue;
-        lib = dlopen(c, RTLD_NOW | RTLD_NOLOAD);
-        if (lib) break;
+    for (int i = 0; i < n_cands && !lib; ++i) lib = dlopen(cands[i], RTLD_NOW | RTLD_NOLOAD);
+    std::string why;
+    for (int i = 0; i < n_cands && !lib; ++i) {
+        lib = dlopen(cands[i], RTLD_NOW | RTLD_LOCAL);
+        if (!lib) { const char* e = dlerror(); why = e ? e : ""; }   // dlerror() clears the message: read it once
     }
-    for (const char* c : cands) {
-        if (lib) break;
-        if (c) lib = dlopen(c, RTLD_NOW | RTLD_LOCAL);
-    }
-    if (!lib) { g_rccl_error = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return 1; }
+    if (!lib) { g_rccl_error = std::string("librccl not found: ") + why; return 1; }
     RcclApi a;
     a.lib = lib;
     a.GetUniqueId = (int (*)(som_nccl_id*))dlsym(lib, "ncclGetUniqueId");
@@ -1735,7 +1911,7 @@ namespace {
 // bf16 / bf16x3 precision with the 'euclidean' activation distance: the same argmin through the configured
 // MFMA path (the squared distance is monotone in it); the caller evaluates the distance itself exactly.
 int run_quantization_bmu(som_handle* h, long n_rows) {
-    if (h->cfg.precision != SOM_PREC_F32 && h->cfg.distance == SOM_DIST_EUCLIDEAN) {
+    if (h->cfg.precision != SOM_PREC_F32 && !h->exact && h->cfg.distance == SOM_DIST_EUCLIDEAN) {
         if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1, h->qxsq)) return rc;
         return run_activation_bmu(h, h->qX, n_rows, h->qxsq, h->qXb, h->xmax2 + 1, h->qbmu);
     }
@@ -1821,6 +1997,21 @@ int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, d
     if (int rc = d2h_blocking(h, &s, h->dsum, sizeof(double))) return rc;
     *qe_out = s / (double)n_rows;
     return 0;
+}
+
+int som_exact_stats(som_handle* h, int64_t* rows, int64_t* rows_fallback, int64_t* passes) {
+    if (!h) return 1;
+    if (rows) *rows = h->ex.rows_total;
+    if (rows_fallback) *rows_fallback = h->ex.rows_fallback;
+    if (passes) *passes = h->ex.chunks;
+    return 0;
+}
+
+int som_exact_last_counts(som_handle* h, int32_t* counts_out, int64_t n) {
+    DeviceGuard dev_guard(h);
+    if (!h || !counts_out || n < 0) return fail(h, "som_exact_last_counts: bad argument");
+    if (!h->exact || n > h->ex.stride) return fail(h, "som_exact_last_counts: no screen pass of that many rows");
+    return d2h_blocking(h, counts_out, h->ex.count, (size_t)n * sizeof(int));
 }
 
 int som_sync(som_handle* h) {

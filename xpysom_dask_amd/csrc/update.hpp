@@ -461,8 +461,6 @@ __global__ __launch_bounds__(256) void leftmul_f32_kernel(const float* __restric
     // 16-byte aligned is ONE global_load_dwordx4 (the common case: 8 loads per thread and chunk where the scalar
     // form needed 32 loads with their 64-bit address arithmetic); otherwise its four floats are loaded one by one.
     f32x4 hreg[4], mreg[4];
-    const bool h_vec = (Ri & 3) == 0 && ((uintptr_t)H & 15) == 0;
-    const bool m_vec = (ld & 3) == 0 && ((uintptr_t)Mb & 15) == 0;
     auto fetch = [&](int r0, int kend) {               // chunk [r0, r0 + 32) clipped to columns < kend
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -470,7 +468,8 @@ __global__ __launch_bounds__(256) void leftmul_f32_kernel(const float* __restric
             {
                 const int i = idx >> 3, k = (idx & 7) * 4;
                 const float* src = H + (long)(i0 + i) * Ri + r0 + k;
-                if (h_vec && i0 + i < Ro && r0 + k + 3 < kend) hreg[q] = *(const f32x4*)src;
+                // (the piece's own address decides: a banded chunk starts at sg * segw + lo, any float offset)
+                if (((uintptr_t)src & 15) == 0 && i0 + i < Ro && r0 + k + 3 < kend) hreg[q] = *(const f32x4*)src;
                 else
 #pragma unroll
                     for (int e = 0; e < 4; ++e) hreg[q][e] = (i0 + i < Ro && r0 + k + e < kend) ? src[e] : 0.0f;
@@ -478,7 +477,7 @@ __global__ __launch_bounds__(256) void leftmul_f32_kernel(const float* __restric
             {
                 const int kk = idx >> 5, c = (idx & 31) * 4;
                 const float* src = Mb + (long)(r0 + kk) * ld + c0 + c;
-                if (m_vec && r0 + kk < kend && c0 + c + 3 < C) mreg[q] = *(const f32x4*)src;
+                if (((uintptr_t)src & 15) == 0 && r0 + kk < kend && c0 + c + 3 < C) mreg[q] = *(const f32x4*)src;
                 else
 #pragma unroll
                     for (int e = 0; e < 4; ++e) mreg[q][e] = (r0 + kk < kend && c0 + c + e < C) ? src[e] : 0.0f;

@@ -258,6 +258,18 @@ class HipEngine:
         self._check(self._lib.som_quantization_error(self._h, self._fp(x), x.shape[0], C.byref(out)))
         return out.value
 
+    def exact_stats(self):
+        """precision 'exact': (rows screened, rows sent to the float32 fallback kernel, screen passes) so far."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._lib.som_exact_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def exact_last_counts(self, n):
+        """precision 'exact': candidate groups per row in the last screen pass (first n rows)."""
+        out = np.empty((int(n),), dtype=np.int32)
+        self._check(self._lib.som_exact_last_counts(self._h, self._ip(out), int(n)))
+        return out
+
     # -- timing -----------------------------------------------------------------------------
     def sync(self):
         self._check(self._lib.som_sync(self._h))

@@ -85,7 +85,9 @@ class XPySom:
         ``xp``, ``use_dask`` and ``dask_chunks`` are accepted for source compatibility and
         ignored: there is one backend (HIP) and multi-GPU runs use torch.distributed, not Dask.
         Extra keyword-only arguments:
-          precision      'f32' (exact-float32 MFMA, parity mode), 'bf16' (bf16 MFMA distance GEMM),
+          precision      'f32' (exact-float32 MFMA, parity mode), 'exact' (the BMUs of 'f32' bit for bit, found by a
+                         split-bf16 MFMA screen and a float32 re-score of the units its error bound cannot rule out:
+                         the parity contract at about three times the float32 kernel's speed), 'bf16' (bf16 MFMA distance GEMM),
                          'bf16x3' (hi/lo-split bf16 MFMA: near-float32 BMUs at a third of the bf16 rate), or the
                          same two paths on IEEE half operands, 'f16' / 'f16x3' (three more mantissa bits at the
                          same MFMA rate; rows and units must fit float16: norms <= 65504)
@@ -141,8 +143,8 @@ class XPySom:
         if not DISTANCES[activation_distance]:
             raise NotImplementedError("activation_distance '%s' is not in the HIP engine yet "
                                       "(SURVEY 8(f) rank 3)" % activation_distance)
-        if precision not in ('f32', 'bf16', 'bf16x3', 'f16', 'f16x3'):
-            raise ValueError("precision must be 'f32', 'bf16', 'bf16x3', 'f16' or 'f16x3'")
+        if precision not in ('f32', 'exact', 'bf16', 'bf16x3', 'f16', 'f16x3'):
+            raise ValueError("precision must be 'f32', 'exact', 'bf16', 'bf16x3', 'f16' or 'f16x3'")
         # what som_create would refuse is refused here, at construction, as the reference raises at
         # construction (the engine itself is created lazily, on the first train() / winner())
         if neighborhood_function == 'mexican_hat' and compact_support and topology == 'rectangular' and x != y:
@@ -150,7 +152,7 @@ class XPySom:
             # against px's (n, x), so NumPy refuses to broadcast it at the first _update.  Reproduced on square maps.
             raise ValueError('mexican_hat with compact_support needs a square map on the rectangular topology: '
                              'operands could not be broadcast together with shapes (n,%d) (n,%d)' % (x, y))
-        if precision != 'f32' and activation_distance not in ('euclidean', 'cosine'):
+        if precision not in ('f32', 'exact') and activation_distance not in ('euclidean', 'cosine'):
             raise ValueError("precision '%s' implements the GEMM-form distances 'euclidean' and 'cosine'; "
                              "'%s' needs precision='f32'" % (precision, activation_distance))
         if activation_distance.startswith('norm_p'):
@@ -297,19 +299,22 @@ class XPySom:
             eng = self._upload_weights()
             eng.set_data(data)
 
-        for iteration in range(iter_beg, iter_end):
-            eta = self._decay_function(self._learning_rate, self._learning_rateN, iteration, num_epochs)
-            # sigma and learning rate decrease with the same rule
-            sig = self._decay_function(self._sigma, self._sigmaN, iteration, num_epochs)
-            # NumPy >= 2: a numpy scalar sigma makes the reference's neighbourhood float64
-            neigh_f64 = isinstance(sig, np.generic)
-            self._check_sigma(sig)
-            _dist.epoch(eng, sig, eta, neigh_f64)
-            if verbose:
-                print('\r [ %d / %d ] %3.0f%%' % (iteration + 1, num_epochs, 100 * (iteration + 1) / num_epochs),
-                      end='')
-
-        self._weights = eng.get_weights().reshape(self._weights.shape)
+        try:
+            for iteration in range(iter_beg, iter_end):
+                eta = self._decay_function(self._learning_rate, self._learning_rateN, iteration, num_epochs)
+                # sigma and learning rate decrease with the same rule
+                sig = self._decay_function(self._sigma, self._sigmaN, iteration, num_epochs)
+                # NumPy >= 2: a numpy scalar sigma makes the reference's neighbourhood float64
+                neigh_f64 = isinstance(sig, np.generic)
+                self._check_sigma(sig)
+                _dist.epoch(eng, sig, eta, neigh_f64)
+                if verbose:
+                    print('\r [ %d / %d ] %3.0f%%' % (iteration + 1, num_epochs, 100 * (iteration + 1) / num_epochs),
+                          end='')
+        finally:
+            # also on the way out of an exception (mexican_hat's ZeroDivisionError at sigma 0): the object holds
+            # the codebook of the epochs that completed, as the reference's does
+            self._weights = eng.get_weights().reshape(self._weights.shape)
 
         if verbose:
             print('\n quantization error:', self.quantization_error(data))
@@ -320,7 +325,7 @@ class XPySom:
         Python-float sigma of exactly 0 -- a linear schedule ending at sigmaN=0 -- raises there, in the reference, and
         so here (a numpy.float64 sigma divides to inf with a warning; the gaussian's 0/0 gives NaN in both)."""
         if self.neighborhood_func_name == 'mexican_hat' and not isinstance(sig, np.generic) \
-                and 2 * self._std_coeff * self._std_coeff * sig * sig == 0:
+                and 2 * self._std_coeff ** 2 * sig ** 2 == 0:    # d, associated as neighborhoods.py:59 writes it
             raise ZeroDivisionError('float division by zero')
 
     def train_streaming(self, chunks, num_epochs, iter_beg=0, iter_end=None):
@@ -334,12 +339,14 @@ class XPySom:
         if iter_end is None:
             iter_end = num_epochs
         eng = self._upload_weights()
-        for iteration in range(iter_beg, iter_end):
-            eta = self._decay_function(self._learning_rate, self._learning_rateN, iteration, num_epochs)
-            sig = self._decay_function(self._sigma, self._sigmaN, iteration, num_epochs)
-            self._check_sigma(sig)
-            _dist.epoch(eng, sig, eta, isinstance(sig, np.generic), chunks=chunks())
-        self._weights = eng.get_weights().reshape(self._weights.shape)
+        try:
+            for iteration in range(iter_beg, iter_end):
+                eta = self._decay_function(self._learning_rate, self._learning_rateN, iteration, num_epochs)
+                sig = self._decay_function(self._sigma, self._sigmaN, iteration, num_epochs)
+                self._check_sigma(sig)
+                _dist.epoch(eng, sig, eta, isinstance(sig, np.generic), chunks=chunks())
+        finally:
+            self._weights = eng.get_weights().reshape(self._weights.shape)
         return self
 
     def train_batch(self, data, num_iteration, verbose=False):
@@ -457,8 +464,9 @@ class XPySom:
         """Dictionary wm where wm[(i,j)] lists the patterns mapped to i,j (xpysom.py:831-840)."""
         self._check_input_len(data)
         winmap = defaultdict(list)
-        for unit, rows in self._rows_by_unit(data):
-            winmap[unit] = [data[n] for n in rows]
+        host = data if hasattr(data, '__getitem__') and _device_rows(data) is None else _host_rows(data, self._engine)
+        for unit, rows in self._rows_by_unit(host):
+            winmap[unit] = [host[n] for n in rows]
         return winmap
 
     def labels_map(self, data, labels):
