@@ -138,13 +138,13 @@ def test_exact_rows_with_nan_and_inf_take_the_float32_fallback():
 
 def test_exact_many_candidate_groups_overflow_to_the_fallback():
     """A codebook of identical units: every group is a candidate of every row (more than the list holds)."""
-    X, Y, D, n = 64, 64, 16, 700
+    X, Y, D, n = 128, 64, 16, 700
     w = np.ones((X, Y, D), F32)
     data = O.gaussian_blobs(n, D, seed=8)
     r = both(X, Y, D, w, data)
     assert (r["f32"][0] == 0).all() and np.array_equal(r["exact"][0], r["f32"][0])
     rows, fb, _ = r["exact"][4]
-    assert fb >= n                                        # 64 groups > 32 list entries: all rows through the float32 kernel
+    assert fb >= n                                        # 128 groups > 64 list entries: all rows through the float32 kernel
 
 
 def test_exact_magnitudes_and_streamed_chunks():

@@ -14,13 +14,15 @@
 //                (float32 kernel's own rounding) + (screen's error), both relative to tau = |w|^2 - 2 x.w in real
 //                arithmetic -- derivation below.  The float32 winner k* has s(k*) <= s(k) for every k, so its screen
 //                value cannot exceed the screen's minimum by more than E: its group is a candidate.
-//   3. re-score  exact_rescore_kernel: one wave per row; for every candidate group the 64 units' float32 scores by the
-//                SAME arithmetic as the parity kernel (v_mfma_f32_32x32x2_f32 is bit for bit a k-ordered fmaf chain;
-//                here the chain runs on the vector ALU, one lane per unit, reading the parity kernel's own stage
-//                image), then the first minimum in unit order.  Because k* is among the re-scored units and is the
-//                global first minimum, it is the re-scored first minimum.
+//   3. re-score  the (row, group) pairs are bucketed by group (exact_offsets_kernel, exact_fill_kernel) and
+//                exact_rescore_mfma_kernel forms, tile by tile (up to 128 rows of a group's list x its 64 units), the
+//                float32 scores by the SAME instruction stream as the parity kernel (v_mfma_f32_32x32x2_f32 on the
+//                parity kernel's own stage image, same k order, same epilogue) and keeps the first minimum in unit
+//                order per row.  Because k* is among the re-scored units and is the global first minimum, it is the
+//                re-scored first minimum.  A group's stage is fetched once per tile, not once per row.
 //   4. fallback  rows the scheme cannot vouch for -- more candidate groups than the list holds, no candidate at all
-//                (NaN / infinite rows or norms), a minimum that is not finite -- go to the float32 kernel itself.
+//                (NaN / infinite rows or norms), a minimum that is not finite -- go to the float32 kernel itself
+//                (exact_finalize_kernel lists them).
 //
 // Error bound (euclidean, input_len <= 128).  u = 2^-24, ub = 2^-8 (bf16) or 2^-11 (f16), A(n,k) = sum_d |x_d w_kd|
 // <= |x_n| max_k|w_k|.
@@ -42,26 +44,35 @@
 namespace somhip {
 
 constexpr int EX_GROUP = 64;          // units per group = one stage of the float32 stage image = two screen stages
-constexpr int EX_CAND = 32;           // candidate groups kept per row; more -> the row goes to the float32 kernel
+constexpr int EX_CAND = 64;           // candidate groups kept per row; more -> the row goes to the float32 kernel
 constexpr int EX_SCAN_SPLIT = 4;      // waves that share a row's groups in the scan
+constexpr int EX_TR = 128;            // rows per re-score tile (4 waves x 32 rows against one 64-unit group)
 
 struct ExactBound {                   // E(n) = cA * |x_n| * wmax + cW * wmax^2 + cB * Bm   (d' units)
     float cA, cW, cB;
 };
 
-// gmin [n_groups][gm_stride] -> cand [N][EX_CAND], count [N].  Block = 64 rows x EX_SCAN_SPLIT group ranges.
+// Small per-pass counters, one allocation, zeroed by one memset before the scan:
+//   [0, n_groups)             gcount: (row, group) pairs per group
+//   [n_groups, 2 n_groups)    gfill:  fill cursor of the group's row list
+//   [2 n_groups]              fb_count: rows for the float32 fallback kernel
+//   [2 n_groups + 1]          n_tiles:  re-score tiles
+// goff (exclusive prefix of gcount) lives behind them and is written, not accumulated.
+
+// gmin [n_groups][gm_stride] -> cand [N][EX_CAND], count [N], gcount [n_groups].
+// Block = 64 rows x EX_SCAN_SPLIT group ranges.
 __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_scan_kernel(const uint32_t* __restrict__ gmin, long gm_stride,
                                                                        int n_groups, long N,
                                                                        const unsigned long long* __restrict__ best64,
                                                                        const float* __restrict__ xsq,
                                                                        const float* __restrict__ wmax2,
                                                                        const float* __restrict__ xmax2, ExactBound eb,
-                                                                       int* __restrict__ cand, int* __restrict__ count) {
+                                                                       int* __restrict__ cand, int* __restrict__ count,
+                                                                       int* __restrict__ gcount) {
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const long row = (long)blockIdx.x * 64 + lane;
     const bool live = row < N;
     const long r = live ? row : 0;
-    // thr: unsigned compare on the bit patterns (all d' are positive floats; a NaN pattern is above every threshold)
     const float wm = __builtin_sqrtf(*wmax2) * (1.0f + 1.0f / 1024.0f);
     const float big = __builtin_sqrtf(*wmax2) * __builtin_sqrtf(*xmax2) * (1.0f + 1.0f / 1024.0f);   // prep_wsqh_kernel's B
     const float bm = 2.01f * big + 0.5f * wm * wm;
@@ -69,8 +80,10 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_scan_kernel(const ui
     const float m = __uint_as_float((uint32_t)(best64[r] >> 32));
     const float e = eb.cA * xn * wm + eb.cW * wm * wm + eb.cB * bm;
     const float thr_f = m + e;
-    // a threshold that is not a finite positive number (NaN / infinite row or norms) selects nothing: fallback
-    const bool ok = live && thr_f > 0.0f && thr_f < 3.0e38f;
+    // A threshold that is not a finite positive number (NaN / infinite row or norms) selects nothing, and neither
+    // does a row or codebook so small that float32 products may underflow (the bound assumes none do): fallback.
+    const bool ok = live && thr_f > 0.0f && thr_f < 3.0e38f && xn * wm > 1.0e-20f && wm * wm > 1.0e-20f;
+    // unsigned compare on the bit patterns: every d' is a positive float, a NaN pattern is above every threshold
     const uint32_t thr = ok ? __float_as_uint(thr_f) : 0u;
     const int g0 = (int)((long)n_groups * part / EX_SCAN_SPLIT), g1 = (int)((long)n_groups * (part + 1) / EX_SCAN_SPLIT);
     const uint32_t* src = gmin + r;
@@ -82,66 +95,162 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_scan_kernel(const ui
         for (int q = 0; q < 8; ++q)
             if (v[q] <= thr && ok) {
                 const int slot = atomicAdd(count + r, 1);
-                if (slot < EX_CAND) cand[r * EX_CAND + slot] = g + q;
+                if (slot < EX_CAND) {
+                    cand[r * EX_CAND + slot] = g + q;
+                    atomicAdd(gcount + g + q, 1);
+                }
             }
     }
 }
 
-// One wave per row.  Scores of the 64 units of each candidate group exactly as bmu_f32_res_kernel<SCORE_EUCLID_PART>
-// forms them, first minimum in unit order over all candidates.  Rows it cannot settle are appended to fb_list.
-template <int KG>
-__global__ __launch_bounds__(256) void exact_rescore_kernel(const float* __restrict__ X, long N, int D,
-                                                            const char* __restrict__ Wfst, int K,
-                                                            const int* __restrict__ cand, const int* __restrict__ count,
-                                                            int* __restrict__ out, int* __restrict__ fb_list,
-                                                            int* __restrict__ fb_count) {
-    constexpr int STAGE = fr_stage_bytes(KG);
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// gcount -> goff (exclusive prefix), the tile table (group, first entry of the group's list) and n_tiles.  One block.
+__global__ __launch_bounds__(1024) void exact_offsets_kernel(const int* __restrict__ gcount, int n_groups,
+                                                             int* __restrict__ goff, int2* __restrict__ tile_tab,
+                                                             int* __restrict__ n_tiles_out) {
+    __shared__ int sums[1024], tsums[1024];
+    const int tid = threadIdx.x;
+    const int per = (n_groups + 1023) / 1024;
+    const int b = tid * per, e = min(b + per, n_groups);
+    int s = 0, ts = 0;
+    for (int g = b; g < e; ++g) { const int c = gcount[g]; s += c; ts += (c + EX_TR - 1) / EX_TR; }
+    sums[tid] = s; tsums[tid] = ts;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                  // inclusive Hillis-Steele scan of both
+        const int a = tid >= o ? sums[tid - o] : 0, c = tid >= o ? tsums[tid - o] : 0;
+        __syncthreads();
+        sums[tid] += a; tsums[tid] += c;
+        __syncthreads();
+    }
+    int off = sums[tid] - s, toff = tsums[tid] - ts;
+    for (int g = b; g < e; ++g) {
+        const int c = gcount[g];
+        goff[g] = off;
+        for (int i = 0; i * EX_TR < c; ++i) tile_tab[toff++] = make_int2(g, i * EX_TR);
+        off += c;
+    }
+    if (tid == 1023) *n_tiles_out = tsums[1023];
+}
+
+// rows into their groups' lists; the per-row merge keys of the re-score start from all ones
+__global__ __launch_bounds__(256) void exact_fill_kernel(const int* __restrict__ cand, const int* __restrict__ count, long N,
+                                                         const int* __restrict__ goff, int* __restrict__ gfill,
+                                                         int* __restrict__ plist, unsigned long long* __restrict__ best64) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
     if (row >= N) return;
-    const int cnt = count[row];
-    bool fallback = cnt <= 0 || cnt > EX_CAND;
-    float best = __builtin_inff();
-    int bunit = 0x7fffffff;
-    if (!fallback) {
-        const float* xrow = X + row * D;
-        const int ut = lane >> 5, col = lane & 31;
-        for (int ci = 0; ci < cnt; ++ci) {
-            const int g = cand[row * EX_CAND + ci];
-            const char* st = Wfst + (long)g * STAGE;
-            float c = 0.0f;
+    best64[row] = ~0ull;
+    const int c = min(count[row], EX_CAND);
+    for (int i = 0; i < c; ++i) {
+        const int g = cand[row * EX_CAND + i];
+        plist[goff[g] + atomicAdd(gfill + g, 1)] = (int)row;
+    }
+}
+
+// The float32 scores of one tile -- up to EX_TR rows of a group's list against the group's 64 units -- on
+// v_mfma_f32_32x32x2_f32, exactly as bmu_f32_res_kernel<SCORE_EUCLID_PART> forms them (same stage image, same k order,
+// same epilogue, same first-minimum rule); a row's best (value, unit) over its groups merges through the same
+// order-preserving 64-bit atomicMin the parity kernel's codebook parts use.  Persistent: a workgroup walks the tile
+// table from blockIdx.x in steps of gridDim.x, the next tile's stage in flight (LDS-DMA) under this tile's MFMAs.
+template <int KG>
+__global__ __launch_bounds__(256, 2) void exact_rescore_mfma_kernel(const float* __restrict__ X, int D,
+                                                                    const char* __restrict__ Wfst, int K,
+                                                                    const int2* __restrict__ tile_tab,
+                                                                    const int* __restrict__ n_tiles_dev,
+                                                                    const int* __restrict__ gcount,
+                                                                    const int* __restrict__ goff,
+                                                                    const int* __restrict__ plist,
+                                                                    unsigned long long* __restrict__ best64) {
+    constexpr int STAGE = fr_stage_bytes(KG);
+    constexpr int PIECES = FR_UT * KG + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, col = lane & 31;
+    const int n_tiles = *n_tiles_dev;
+    int slot = 0;
+    if ((int)blockIdx.x < n_tiles) {
+        const int g = tile_tab[blockIdx.x].x;
+        for (int p = wave; p < PIECES; p += 4) lds_dma_16(Wfst + (long)g * STAGE + (long)p * 1024 + lane * 16, smem + p * 1024);
+    }
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x, slot ^= 1) {
+        const int2 tt = tile_tab[t];
+        const int g = tt.x;
+        const int first = tt.y + wave * 32;               // this wave's first entry of the group's list
+        const int cnt = gcount[g];
+        const bool wave_live = first < cnt;                // (wave-uniform)
+        const int row = first + col < cnt ? plist[goff[g] + first + col] : -1;
+        float xf[4 * KG];
+        if ((D & 3) == 0) {
+#pragma unroll
+            for (int c = 0; c < 2 * KG; ++c) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row >= 0 && 4 * c < D) v = *(const f32x4*)(X + (long)row * D + 4 * c);
+                xf[2 * c] = half ? v[1] : v[0];
+                xf[2 * c + 1] = half ? v[3] : v[2];
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4 * KG; ++s) {
+                const int k = 2 * s + half;
+                xf[s] = (row >= 0 && k < D) ? X[(long)row * D + k] : 0.0f;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's stage (issued one tile ago) and the rows
+        __builtin_amdgcn_s_barrier();                      // ... of every wave; everyone is done with the other slot
+        asm volatile("" ::: "memory");
+        if (t + (int)gridDim.x < n_tiles) {
+            const int g2 = tile_tab[t + gridDim.x].x;
+            char* dst = smem + (slot ^ 1) * STAGE;
+            for (int p = wave; p < PIECES; p += 4) lds_dma_16(Wfst + (long)g2 * STAGE + (long)p * 1024 + lane * 16, dst + p * 1024);
+        }
+        if (!wave_live) continue;
+        const char* st = smem + slot * STAGE;
+        const float* wq = (const float*)(st + FR_UT * KG * 1024);
+        float best = __builtin_inff();
+        int bkey = 0;
+#pragma unroll
+        for (int ut = 0; ut < FR_UT; ++ut) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
             for (int kg = 0; kg < KG; ++kg) {
-                // lane col of the MFMA image holds the even features 8 kg + 2 j, lane col + 32 the odd ones
-                const f32x4 a0 = *(const f32x4*)(st + ((long)(ut * KG + kg) * 64 + col) * 16);
-                const f32x4 a1 = *(const f32x4*)(st + ((long)(ut * KG + kg) * 64 + col + 32) * 16);
+                const f32x4 a4 = *(const f32x4*)(st + ((ut * KG + kg) * 64 + lane) * 16);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = 8 * kg + 2 * j;
-                    const float x0 = k < D ? xrow[k] : 0.0f, x1 = k + 1 < D ? xrow[k + 1] : 0.0f;
-                    c = __builtin_fmaf(a0[j], x0, c);
-                    c = __builtin_fmaf(a1[j], x1, c);
-                }
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], xf[4 * kg + j], acc, 0, 0, 0);
             }
-            const float wsq = ((const float*)(st + (long)FR_UT * KG * 1024))[lane];   // +inf behind the last unit
-            float v = score_f32<SCORE_EUCLID_PART>(c, wsq, 0.0f);
-            int u = g * EX_GROUP + lane;
-            if (!(v == v) || u >= K) v = __builtin_inff();                          // a NaN never wins ('<' semantics)
-            if (v < best || (v == best && u < bunit)) { best = v; bunit = u; }
-        }
+            f32x4 wv[4];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o, 64);
-            const int ou = __shfl_xor(bunit, o, 64);
-            if (ov < best || (ov == best && ou < bunit)) { best = ov; bunit = ou; }
+            for (int q = 0; q < 4; ++q) wv[q] = *(const f32x4*)(wq + ut * 32 + 8 * q + 4 * half);
+            const int tile = g * FR_UT + ut;
+            if ((tile + 1) * 32 > K) f32_tile_argmin<SCORE_EUCLID_PART, true>(acc, wv, 0.0f, tile, half, K, best, bkey);
+            else f32_tile_argmin<SCORE_EUCLID_PART, false>(acc, wv, 0.0f, tile, half, K, best, bkey);
         }
-        // +inf: no unit with a finite score among the candidates; -inf: leave such rows to the parity kernel too
-        fallback = !(best > -3.0e38f && best < 3.0e38f);
+        int bidx = f32_key_unit(bkey, half);
+        const float ob = __shfl_xor(best, 32, 64);
+        const int oi = __shfl_xor(bidx, 32, 64);
+        if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+        if (half == 0 && row >= 0) {                      // (best == +inf: no unit of this group scored below it)
+            const uint32_t bits = __float_as_uint(best);
+            const uint32_t key = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+            atomicMin(best64 + row, ((unsigned long long)key << 32) | (uint32_t)bidx);
+        }
     }
-    if (lane == 0) {
-        if (fallback) fb_list[atomicAdd(fb_count, 1)] = (int)row;
-        else out[row] = bunit;
-    }
+}
+
+// merge key -> id; rows the scheme cannot vouch for -> the fallback list
+__global__ __launch_bounds__(256) void exact_finalize_kernel(const unsigned long long* __restrict__ best64,
+                                                             const int* __restrict__ count, long N, int K,
+                                                             int* __restrict__ out, int* __restrict__ fb_list,
+                                                             int* __restrict__ fb_count) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= N) return;
+    const int c = count[row];
+    const unsigned long long k64 = best64[row];
+    const uint32_t key = (uint32_t)(k64 >> 32), unit = (uint32_t)k64;
+    const uint32_t bits = (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key;
+    const bool finite = (bits & 0x7F800000u) != 0x7F800000u;
+    if (c <= 0 || c > EX_CAND || !finite || unit >= (uint32_t)K) fb_list[atomicAdd(fb_count, 1)] = (int)row;
+    else out[row] = (int)unit;
 }
 
 // fallback rows -> a dense block for the float32 kernel, and its ids back

@@ -70,7 +70,11 @@ struct som_handle {
     struct ExactScratch {
         uint32_t* gmin = nullptr;            // [n_groups][stride] group minima of the chunk being screened
         long stride = 0;                     //   rows per group line (a chunk of the row set, padded)
-        int *cand = nullptr, *count = nullptr, *fb_list = nullptr, *fb_count = nullptr, *fb_ids = nullptr;
+        int *cand = nullptr, *count = nullptr, *fb_list = nullptr, *fb_ids = nullptr;
+        int* ctr = nullptr;                  // gcount | gfill | fb_count | n_tiles (zeroed per pass), then goff
+        int* plist = nullptr;                // rows bucketed by candidate group
+        int2* tile_tab = nullptr;            // re-score tiles: (group, first list entry)
+        long max_tiles = 0;
         float* fbX = nullptr;                // fallback rows, dense, for the float32 kernel
         long fb_cap = 0;
         int* fb_count_host = nullptr;        // pinned
@@ -780,16 +784,21 @@ int exact_reserve(som_handle* h, long rows) {
     auto& ex = h->ex;
     const long stride = round_up(std::min(rows, exact_chunk_rows(h)), 256);
     if (stride <= ex.stride) return 0;
-    void* old[] = {ex.gmin, ex.cand, ex.count, ex.fb_list};
+    void* old[] = {ex.gmin, ex.cand, ex.count, ex.fb_list, ex.plist, ex.tile_tab};
     for (void* p : old) if (p) (void)hipFree(p);
-    ex.gmin = nullptr; ex.cand = nullptr; ex.count = nullptr; ex.fb_list = nullptr; ex.stride = 0;
+    ex.gmin = nullptr; ex.cand = nullptr; ex.count = nullptr; ex.fb_list = nullptr; ex.plist = nullptr; ex.tile_tab = nullptr;
+    ex.stride = 0;
     const long n_groups = cdiv(h->K, EX_GROUP);
+    if (stride * EX_CAND > 0x7fffffffL) return fail(h, "exact: pass too large");
     if (int rc = dev_alloc(h, &ex.gmin, (size_t)n_groups * stride)) return rc;
     if (int rc = dev_alloc(h, &ex.cand, (size_t)stride * EX_CAND)) return rc;
+    if (int rc = dev_alloc(h, &ex.plist, (size_t)stride * EX_CAND)) return rc;
     if (int rc = dev_alloc(h, &ex.count, (size_t)stride)) return rc;
     if (int rc = dev_alloc(h, &ex.fb_list, (size_t)stride)) return rc;
-    if (!ex.fb_count) {
-        if (int rc = dev_alloc(h, &ex.fb_count, 1)) return rc;
+    ex.max_tiles = cdiv(stride * EX_CAND, EX_TR) + n_groups;
+    if (int rc = dev_alloc(h, &ex.tile_tab, (size_t)ex.max_tiles)) return rc;
+    if (!ex.ctr) {
+        if (int rc = dev_alloc(h, &ex.ctr, (size_t)3 * n_groups + 2)) return rc;
         HIPCHK(h, hipHostMalloc((void**)&ex.fb_count_host, sizeof(int), hipHostMallocDefault));
     }
     ex.stride = stride;
@@ -826,15 +835,43 @@ int exact_screen_ks(som_handle* h, const __bf16* Xb, long n, unsigned long long*
     return fail(h, "exact: the screen kernel supports input_len <= 128");
 }
 
-int exact_rescore(som_handle* h, const float* X, long n, int* out) {
-    const dim3 grid((unsigned)cdiv(n, 4)), block(256);
+template <int KG>
+int exact_rescore_kg(som_handle* h, const float* X, int n_groups) {
     auto& ex = h->ex;
+    auto kern = exact_rescore_mfma_kernel<KG>;
+    const size_t lds = 2 * (size_t)fr_stage_bytes(KG);
+    int per_cu = 1;
+    if (int rc = kernel_per_cu(h, (const void*)kern, 256, lds, &per_cu)) return rc;
+    const long grid = std::min<long>(ex.max_tiles, (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256));
+    kern<<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, h->D, h->Wfst, h->K, ex.tile_tab, ex.ctr + 2 * n_groups + 1, ex.ctr,
+                                                             ex.ctr + 2 * n_groups + 2, ex.plist, h->best64);
+    return 0;
+}
+
+// the re-score of one pass: bucket the (row, group) pairs by group, score tile by tile, settle the rows.  best64 is the
+// pass's slice of the merge keys (the scan has read the screen's minima from it; the fill resets it).
+int exact_rescore(som_handle* h, const float* X, long n, unsigned long long* best64, int* out) {
+    auto& ex = h->ex;
+    const int n_groups = (int)cdiv(h->K, EX_GROUP);
+    int* gcount = ex.ctr; int* gfill = ex.ctr + n_groups; int* fb_count = ex.ctr + 2 * n_groups;
+    int* n_tiles = fb_count + 1; int* goff = fb_count + 2;
+    exact_offsets_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(gcount, n_groups, goff, ex.tile_tab, n_tiles);
+    exact_fill_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(ex.cand, ex.count, n, goff, gfill, ex.plist, best64);
+    unsigned long long* saved = h->best64;
+    h->best64 = best64;                                   // (exact_rescore_kg reads it from the handle)
+    int rc = 0;
     switch (h->fr_kg) {
-#define SOM_EX_CASE(kg) case kg: exact_rescore_kernel<kg><<<grid, block, 0, h->stream>>>(X, n, h->D, h->Wfst, h->K, ex.cand, ex.count, out, ex.fb_list, ex.fb_count); break;
-    SOM_EX_CASE(1) SOM_EX_CASE(2) SOM_EX_CASE(4) SOM_EX_CASE(8) SOM_EX_CASE(16)
-#undef SOM_EX_CASE
-    default: return fail(h, "exact: bad k-group count");
+    case 1: rc = exact_rescore_kg<1>(h, X, n_groups); break;
+    case 2: rc = exact_rescore_kg<2>(h, X, n_groups); break;
+    case 4: rc = exact_rescore_kg<4>(h, X, n_groups); break;
+    case 8: rc = exact_rescore_kg<8>(h, X, n_groups); break;
+    case 16: rc = exact_rescore_kg<16>(h, X, n_groups); break;
+    default: rc = fail(h, "exact: bad k-group count");
     }
+    h->best64 = saved;
+    if (rc) return rc;
+    exact_finalize_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(best64, ex.count, n, h->K, out, ex.fb_list,
+                                                                                 fb_count);
     return 0;
 }
 
@@ -859,14 +896,14 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     for (long r0 = 0; r0 < N; r0 += chunk) {
         const long n = std::min(chunk, N - r0);
         HIPCHK(h, hipMemsetAsync(ex.count, 0, (size_t)n * sizeof(int), h->stream));
-        HIPCHK(h, hipMemsetAsync(ex.fb_count, 0, sizeof(int), h->stream));
+        HIPCHK(h, hipMemsetAsync(ex.ctr, 0, (size_t)(2 * n_groups + 2) * sizeof(int), h->stream));
         if (int rc = SOM_HALF(h, exact_screen_ks, h, Xb + r0 * h->dp, n, h->best64 + r0)) return rc;
         exact_scan_kernel<<<dim3((unsigned)cdiv(n, 64)), dim3(64 * EX_SCAN_SPLIT), 0, h->stream>>>(
-            ex.gmin, ex.stride, n_groups, n, h->best64 + r0, xsq + r0, h->wmax2, xmax2, eb, ex.cand, ex.count);
-        if (int rc = exact_rescore(h, X + r0 * h->D, n, out + r0)) return rc;
+            ex.gmin, ex.stride, n_groups, n, h->best64 + r0, xsq + r0, h->wmax2, xmax2, eb, ex.cand, ex.count, ex.ctr);
+        if (int rc = exact_rescore(h, X + r0 * h->D, n, h->best64 + r0, out + r0)) return rc;
         HIPCHK(h, hipGetLastError());
         // rows the scheme could not settle (normally none): the float32 kernel itself
-        HIPCHK(h, hipMemcpyAsync(ex.fb_count_host, ex.fb_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(ex.fb_count_host, ex.ctr + 2 * n_groups, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         const int n_fb = *ex.fb_count_host;
         ex.rows_total += n; ex.rows_fallback += n_fb; ex.chunks += 1;
@@ -1377,7 +1414,8 @@ void som_destroy(som_handle* h) {
     seg_free(h->seg);
     seg_free(h->st_seg);
     {
-        void* eb[] = {h->ex.gmin, h->ex.cand, h->ex.count, h->ex.fb_list, h->ex.fb_count, h->ex.fb_ids, h->ex.fbX};
+        void* eb[] = {h->ex.gmin, h->ex.cand, h->ex.count, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist,
+                      h->ex.tile_tab};
         for (void* b : eb) if (b) (void)hipFree(b);
         if (h->ex.fb_count_host) (void)hipHostFree(h->ex.fb_count_host);
     }
