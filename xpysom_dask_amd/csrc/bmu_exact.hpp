@@ -20,9 +20,9 @@
 //                parity kernel's own stage image, same k order, same epilogue) and keeps the first minimum in unit
 //                order per row.  Because k* is among the re-scored units and is the global first minimum, it is the
 //                re-scored first minimum.  A group's stage is fetched once per tile, not once per row.
-//   4. fallback  rows the scheme cannot vouch for -- more candidate groups than the list holds, no candidate at all
-//                (NaN / infinite rows or norms), a minimum that is not finite -- go to the float32 kernel itself
-//                (exact_finalize_kernel lists them).
+//   4. fallback  rows the scheme cannot vouch for -- no candidate at all (NaN / infinite rows or norms), a minimum that
+//                is not finite, a pass with more pairs than its lists hold (64 per row on average: a degenerate
+//                codebook) -- go to the float32 kernel itself (exact_finalize_kernel lists them).
 //
 // Error bound (euclidean, input_len <= 128).  u = 2^-24, ub = 2^-8 (bf16) or 2^-11 (f16), A(n,k) = sum_d |x_d w_kd|
 // <= |x_n| max_k|w_k|.
@@ -44,7 +44,7 @@
 namespace somhip {
 
 constexpr int EX_GROUP = 64;          // units per group = one stage of the float32 stage image = two screen stages
-constexpr int EX_CAND = 64;           // candidate groups kept per row; more -> the row goes to the float32 kernel
+constexpr int EX_PAIRS = 64;          // capacity of a pass: this many (row, group) pairs per row ON AVERAGE
 constexpr int EX_SCAN_SPLIT = 4;      // waves that share a row's groups in the scan
 constexpr int EX_TR = 128;            // rows per re-score tile (4 waves x 32 rows against one 64-unit group)
 
@@ -57,71 +57,106 @@ struct ExactBound {                   // E(n) = cA * |x_n| * wmax + cW * wmax^2 
 //   [n_groups, 2 n_groups)    gfill:  fill cursor of the group's row list
 //   [2 n_groups]              fb_count: rows for the float32 fallback kernel
 //   [2 n_groups + 1]          n_tiles:  re-score tiles
+//   [2 n_groups + 2]          overflow: the pass has more pairs than the lists hold (a degenerate codebook: identical
+//                             units everywhere) -- every row goes to the float32 kernel
 // goff (exclusive prefix of gcount) lives behind them and is written, not accumulated.
 
-// gmin [n_groups][gm_stride] -> cand [N][EX_CAND], count [N], gcount [n_groups].
-// Block = 64 rows x EX_SCAN_SPLIT group ranges.
+// per-bit population of a word of hit bits over the wave: lane b < 32 returns the number of lanes whose bit b is set
+__device__ __forceinline__ int ex_bit_counts(uint32_t bits, int lane) {
+    int c = 0;
+    for (int b = 0; b < 32; ++b) {
+        const unsigned long long m = __ballot((bits >> b) & 1u);
+        if (lane == b) c = (int)__builtin_popcountll(m);
+    }
+    return c;
+}
+
+// gmin [n_groups][gm_stride] -> hit bits bm [n_words][gm_stride] (bit b of word w of a row: group 32 w + b is a
+// candidate) and gcount [n_groups].  Block = 64 consecutive rows x EX_SCAN_SPLIT word ranges.  The 64 lanes of a wave
+// test the SAME group at the same time, so a group's hits are counted with one atomic per wave and word (smooth maps
+// send most rows to the same few groups: one address would otherwise take an add per row).
 __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_scan_kernel(const uint32_t* __restrict__ gmin, long gm_stride,
                                                                        int n_groups, long N,
                                                                        const unsigned long long* __restrict__ best64,
                                                                        const float* __restrict__ xsq,
                                                                        const float* __restrict__ wmax2,
                                                                        const float* __restrict__ xmax2, ExactBound eb,
-                                                                       int* __restrict__ cand, int* __restrict__ count,
-                                                                       int* __restrict__ gcount) {
+                                                                       uint32_t* __restrict__ bm, int* __restrict__ gcount) {
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const long row = (long)blockIdx.x * 64 + lane;
     const bool live = row < N;
     const long r = live ? row : 0;
     const float wm = __builtin_sqrtf(*wmax2) * (1.0f + 1.0f / 1024.0f);
     const float big = __builtin_sqrtf(*wmax2) * __builtin_sqrtf(*xmax2) * (1.0f + 1.0f / 1024.0f);   // prep_wsqh_kernel's B
-    const float bm = 2.01f * big + 0.5f * wm * wm;
+    const float bmag = 2.01f * big + 0.5f * wm * wm;
     const float xn = __builtin_sqrtf(xsq[r]) * (1.0f + 1.0f / 1024.0f);
     const float m = __uint_as_float((uint32_t)(best64[r] >> 32));
-    const float e = eb.cA * xn * wm + eb.cW * wm * wm + eb.cB * bm;
+    const float e = eb.cA * xn * wm + eb.cW * wm * wm + eb.cB * bmag;
     const float thr_f = m + e;
     // A threshold that is not a finite positive number (NaN / infinite row or norms) selects nothing, and neither
     // does a row or codebook so small that float32 products may underflow (the bound assumes none do): fallback.
     const bool ok = live && thr_f > 0.0f && thr_f < 3.0e38f && xn * wm > 1.0e-20f && wm * wm > 1.0e-20f;
     // unsigned compare on the bit patterns: every d' is a positive float, a NaN pattern is above every threshold
     const uint32_t thr = ok ? __float_as_uint(thr_f) : 0u;
-    const int g0 = (int)((long)n_groups * part / EX_SCAN_SPLIT), g1 = (int)((long)n_groups * (part + 1) / EX_SCAN_SPLIT);
+    const int n_words = (n_groups + 31) / 32;
+    const int w0 = (int)((long)n_words * part / EX_SCAN_SPLIT), w1 = (int)((long)n_words * (part + 1) / EX_SCAN_SPLIT);
     const uint32_t* src = gmin + r;
-    for (int g = g0; g < g1; g += 8) {
-        uint32_t v[8];
+    for (int wc = w0; wc < w1; wc += 8) {                 // 8 words = 256 groups at a time
+        uint32_t bits[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = g + q < g1 ? src[(long)(g + q) * gm_stride] : 0xFFFFFFFFu;
+        for (int w = 0; w < 8; ++w) {                     // streaming half: loads and compares only
+            bits[w] = 0;
+            if (wc + w >= w1) continue;                   // (uniform)
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (v[q] <= thr && ok) {
-                const int slot = atomicAdd(count + r, 1);
-                if (slot < EX_CAND) {
-                    cand[r * EX_CAND + slot] = g + q;
-                    atomicAdd(gcount + g + q, 1);
+            for (int b8 = 0; b8 < 32; b8 += 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int g = 32 * (wc + w) + b8 + q;
+                    v[q] = g < n_groups ? src[(long)g * gm_stride] : 0xFFFFFFFFu;
                 }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) bits[w] |= (uint32_t)(v[q] <= thr) << (b8 + q);
             }
+            if (!ok) bits[w] = 0;
+            if (live) bm[(long)(wc + w) * gm_stride + row] = bits[w];
+        }
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {                     // the groups' populations: one add per wave, word and group
+            if (__ballot(bits[w] != 0) == 0) continue;
+            const int c = ex_bit_counts(bits[w], lane);
+            if (lane < 32 && c > 0) atomicAdd(gcount + 32 * (wc + w) + lane, c);
+        }
     }
 }
 
-// gcount -> goff (exclusive prefix), the tile table (group, first entry of the group's list) and n_tiles.  One block.
-__global__ __launch_bounds__(1024) void exact_offsets_kernel(const int* __restrict__ gcount, int n_groups,
+// gcount -> goff (exclusive prefix), the tile table (group, first entry of the group's list) and n_tiles; more pairs
+// than `capacity` -> overflow flag, no tiles.  One block.
+__global__ __launch_bounds__(1024) void exact_offsets_kernel(const int* __restrict__ gcount, int n_groups, long capacity,
                                                              int* __restrict__ goff, int2* __restrict__ tile_tab,
-                                                             int* __restrict__ n_tiles_out) {
-    __shared__ int sums[1024], tsums[1024];
+                                                             int* __restrict__ n_tiles_out, int* __restrict__ overflow) {
+    __shared__ long sums[1024];
+    __shared__ int tsums[1024];
     const int tid = threadIdx.x;
     const int per = (n_groups + 1023) / 1024;
     const int b = tid * per, e = min(b + per, n_groups);
-    int s = 0, ts = 0;
+    long s = 0;
+    int ts = 0;
     for (int g = b; g < e; ++g) { const int c = gcount[g]; s += c; ts += (c + EX_TR - 1) / EX_TR; }
     sums[tid] = s; tsums[tid] = ts;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {                  // inclusive Hillis-Steele scan of both
-        const int a = tid >= o ? sums[tid - o] : 0, c = tid >= o ? tsums[tid - o] : 0;
+        const long a = tid >= o ? sums[tid - o] : 0;
+        const int c = tid >= o ? tsums[tid - o] : 0;
         __syncthreads();
         sums[tid] += a; tsums[tid] += c;
         __syncthreads();
     }
-    int off = sums[tid] - s, toff = tsums[tid] - ts;
+    if (sums[1023] > capacity) {
+        if (tid == 0) { *overflow = 1; *n_tiles_out = 0; }
+        return;
+    }
+    int off = (int)(sums[tid] - s), toff = tsums[tid] - ts;
     for (int g = b; g < e; ++g) {
         const int c = gcount[g];
         goff[g] = off;
@@ -131,17 +166,34 @@ __global__ __launch_bounds__(1024) void exact_offsets_kernel(const int* __restri
     if (tid == 1023) *n_tiles_out = tsums[1023];
 }
 
-// rows into their groups' lists; the per-row merge keys of the re-score start from all ones
-__global__ __launch_bounds__(256) void exact_fill_kernel(const int* __restrict__ cand, const int* __restrict__ count, long N,
-                                                         const int* __restrict__ goff, int* __restrict__ gfill,
-                                                         int* __restrict__ plist, unsigned long long* __restrict__ best64) {
-    const long row = (long)blockIdx.x * 256 + threadIdx.x;
-    if (row >= N) return;
-    best64[row] = ~0ull;
-    const int c = min(count[row], EX_CAND);
-    for (int i = 0; i < c; ++i) {
-        const int g = cand[row * EX_CAND + i];
-        plist[goff[g] + atomicAdd(gfill + g, 1)] = (int)row;
+// hit bits -> the groups' row lists; the per-row merge keys of the re-score start from all ones.  Same geometry as the
+// scan: lanes that set the same bit take consecutive list positions from ONE returning atomic per wave, word and group
+// (lane b < 32 adds group b's population and hands out the base).
+__global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_fill_kernel(const uint32_t* __restrict__ bm, long gm_stride,
+                                                                       int n_groups, long N, const int* __restrict__ goff,
+                                                                       int* __restrict__ gfill, const int* __restrict__ overflow,
+                                                                       int* __restrict__ plist,
+                                                                       unsigned long long* __restrict__ best64) {
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 64 + lane;
+    const bool live = row < N;
+    if (part == 0 && live) best64[row] = ~0ull;
+    if (*overflow) return;
+    const int n_words = (n_groups + 31) / 32;
+    const int w0 = (int)((long)n_words * part / EX_SCAN_SPLIT), w1 = (int)((long)n_words * (part + 1) / EX_SCAN_SPLIT);
+    const unsigned long long below = (1ull << lane) - 1;
+    for (int w = w0; w < w1; ++w) {
+        const uint32_t bits = live ? bm[(long)w * gm_stride + row] : 0u;
+        if (__ballot(bits != 0) == 0) continue;
+        const int c = ex_bit_counts(bits, lane);
+        int off = 0;
+        if (lane < 32 && c > 0) off = goff[32 * w + lane] + atomicAdd(gfill + 32 * w + lane, c);
+        for (int b = 0; b < 32; ++b) {
+            const unsigned long long mk = __ballot((bits >> b) & 1u);
+            if (mk == 0) continue;
+            const int o = __builtin_amdgcn_readlane(off, b);
+            if ((bits >> b) & 1u) plist[o + (int)__builtin_popcountll(mk & below)] = (int)row;
+        }
     }
 }
 
@@ -237,19 +289,18 @@ __global__ __launch_bounds__(256, 2) void exact_rescore_mfma_kernel(const float*
     }
 }
 
-// merge key -> id; rows the scheme cannot vouch for -> the fallback list
-__global__ __launch_bounds__(256) void exact_finalize_kernel(const unsigned long long* __restrict__ best64,
-                                                             const int* __restrict__ count, long N, int K,
-                                                             int* __restrict__ out, int* __restrict__ fb_list,
-                                                             int* __restrict__ fb_count) {
+// merge key -> id; rows the scheme cannot vouch for (no candidate was scored: the key is still all ones; a best score
+// that is not finite; an overflowed pass) -> the fallback list
+__global__ __launch_bounds__(256) void exact_finalize_kernel(const unsigned long long* __restrict__ best64, long N, int K,
+                                                             const int* __restrict__ overflow, int* __restrict__ out,
+                                                             int* __restrict__ fb_list, int* __restrict__ fb_count) {
     const long row = (long)blockIdx.x * 256 + threadIdx.x;
     if (row >= N) return;
-    const int c = count[row];
     const unsigned long long k64 = best64[row];
     const uint32_t key = (uint32_t)(k64 >> 32), unit = (uint32_t)k64;
     const uint32_t bits = (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key;
     const bool finite = (bits & 0x7F800000u) != 0x7F800000u;
-    if (c <= 0 || c > EX_CAND || !finite || unit >= (uint32_t)K) fb_list[atomicAdd(fb_count, 1)] = (int)row;
+    if (*overflow || k64 == ~0ull || !finite || unit >= (uint32_t)K) fb_list[atomicAdd(fb_count, 1)] = (int)row;
     else out[row] = (int)unit;
 }
 

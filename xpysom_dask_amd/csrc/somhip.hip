@@ -70,7 +70,8 @@ struct som_handle {
     struct ExactScratch {
         uint32_t* gmin = nullptr;            // [n_groups][stride] group minima of the chunk being screened
         long stride = 0;                     //   rows per group line (a chunk of the row set, padded)
-        int *cand = nullptr, *count = nullptr, *fb_list = nullptr, *fb_ids = nullptr;
+        uint32_t* bm = nullptr;              // [n_words][stride] hit bits: group 32 w + b is a candidate of the row
+        int *fb_list = nullptr, *fb_ids = nullptr;
         int* ctr = nullptr;                  // gcount | gfill | fb_count | n_tiles (zeroed per pass), then goff
         int* plist = nullptr;                // rows bucketed by candidate group
         int2* tile_tab = nullptr;            // re-score tiles: (group, first list entry)
@@ -490,7 +491,10 @@ int choose_parts(som_handle* h, long blocks, long slots, int max_parts_hint) {
         // exist -- co-resident workgroups share a CU's MFMA pipe, so finer pieces balance the CUs
         // (measured: batch 65 536 at 256x256x128 bf16 +5 %, configs[1] f32 +15 % over one exact round)
         parts = (int)cdiv(2 * slots, blocks);
-        if (parts > 32) parts = 32;                      // a handful of query rows: spread the scan itself
+        // a handful of query rows: spread the scan itself (one or two workgroups' worth of rows -- winner() of a few
+        // samples, the exact mode's fallback rows -- over up to 256 pieces: every CU streams a slice of the codebook)
+        const int cap = blocks <= 2 ? 256 : 32;
+        if (parts > cap) parts = cap;
     } else {
         double best_eff = 0.0;
         for (int p = 1; p <= 4; ++p) {
@@ -784,21 +788,20 @@ int exact_reserve(som_handle* h, long rows) {
     auto& ex = h->ex;
     const long stride = round_up(std::min(rows, exact_chunk_rows(h)), 256);
     if (stride <= ex.stride) return 0;
-    void* old[] = {ex.gmin, ex.cand, ex.count, ex.fb_list, ex.plist, ex.tile_tab};
+    void* old[] = {ex.gmin, ex.bm, ex.fb_list, ex.plist, ex.tile_tab};
     for (void* p : old) if (p) (void)hipFree(p);
-    ex.gmin = nullptr; ex.cand = nullptr; ex.count = nullptr; ex.fb_list = nullptr; ex.plist = nullptr; ex.tile_tab = nullptr;
+    ex.gmin = nullptr; ex.bm = nullptr; ex.fb_list = nullptr; ex.plist = nullptr; ex.tile_tab = nullptr;
     ex.stride = 0;
     const long n_groups = cdiv(h->K, EX_GROUP);
-    if (stride * EX_CAND > 0x7fffffffL) return fail(h, "exact: pass too large");
+    if (stride * EX_PAIRS > 0x7fffffffL) return fail(h, "exact: pass too large");
     if (int rc = dev_alloc(h, &ex.gmin, (size_t)n_groups * stride)) return rc;
-    if (int rc = dev_alloc(h, &ex.cand, (size_t)stride * EX_CAND)) return rc;
-    if (int rc = dev_alloc(h, &ex.plist, (size_t)stride * EX_CAND)) return rc;
-    if (int rc = dev_alloc(h, &ex.count, (size_t)stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.bm, (size_t)cdiv(n_groups, 32) * stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.plist, (size_t)stride * EX_PAIRS)) return rc;
     if (int rc = dev_alloc(h, &ex.fb_list, (size_t)stride)) return rc;
-    ex.max_tiles = cdiv(stride * EX_CAND, EX_TR) + n_groups;
+    ex.max_tiles = cdiv(stride * EX_PAIRS, EX_TR) + n_groups;
     if (int rc = dev_alloc(h, &ex.tile_tab, (size_t)ex.max_tiles)) return rc;
     if (!ex.ctr) {
-        if (int rc = dev_alloc(h, &ex.ctr, (size_t)3 * n_groups + 2)) return rc;
+        if (int rc = dev_alloc(h, &ex.ctr, (size_t)3 * n_groups + 3)) return rc;
         HIPCHK(h, hipHostMalloc((void**)&ex.fb_count_host, sizeof(int), hipHostMallocDefault));
     }
     ex.stride = stride;
@@ -844,7 +847,7 @@ int exact_rescore_kg(som_handle* h, const float* X, int n_groups) {
     if (int rc = kernel_per_cu(h, (const void*)kern, 256, lds, &per_cu)) return rc;
     const long grid = std::min<long>(ex.max_tiles, (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256));
     kern<<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, h->D, h->Wfst, h->K, ex.tile_tab, ex.ctr + 2 * n_groups + 1, ex.ctr,
-                                                             ex.ctr + 2 * n_groups + 2, ex.plist, h->best64);
+                                                             ex.ctr + 2 * n_groups + 3, ex.plist, h->best64);
     return 0;
 }
 
@@ -854,9 +857,11 @@ int exact_rescore(som_handle* h, const float* X, long n, unsigned long long* bes
     auto& ex = h->ex;
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
     int* gcount = ex.ctr; int* gfill = ex.ctr + n_groups; int* fb_count = ex.ctr + 2 * n_groups;
-    int* n_tiles = fb_count + 1; int* goff = fb_count + 2;
-    exact_offsets_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(gcount, n_groups, goff, ex.tile_tab, n_tiles);
-    exact_fill_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(ex.cand, ex.count, n, goff, gfill, ex.plist, best64);
+    int* n_tiles = fb_count + 1; int* overflow = fb_count + 2; int* goff = fb_count + 3;
+    exact_offsets_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(gcount, n_groups, ex.stride * EX_PAIRS, goff, ex.tile_tab, n_tiles,
+                                                               overflow);
+    exact_fill_kernel<<<dim3((unsigned)cdiv(n, 64)), dim3(64 * EX_SCAN_SPLIT), 0, h->stream>>>(ex.bm, ex.stride, n_groups, n, goff,
+                                                                                          gfill, overflow, ex.plist, best64);
     unsigned long long* saved = h->best64;
     h->best64 = best64;                                   // (exact_rescore_kg reads it from the handle)
     int rc = 0;
@@ -870,7 +875,7 @@ int exact_rescore(som_handle* h, const float* X, long n, unsigned long long* bes
     }
     h->best64 = saved;
     if (rc) return rc;
-    exact_finalize_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(best64, ex.count, n, h->K, out, ex.fb_list,
+    exact_finalize_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(best64, n, h->K, overflow, out, ex.fb_list,
                                                                                  fb_count);
     return 0;
 }
@@ -895,11 +900,10 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     const long chunk = std::min(exact_chunk_rows(h), ex.stride);
     for (long r0 = 0; r0 < N; r0 += chunk) {
         const long n = std::min(chunk, N - r0);
-        HIPCHK(h, hipMemsetAsync(ex.count, 0, (size_t)n * sizeof(int), h->stream));
-        HIPCHK(h, hipMemsetAsync(ex.ctr, 0, (size_t)(2 * n_groups + 2) * sizeof(int), h->stream));
+        HIPCHK(h, hipMemsetAsync(ex.ctr, 0, (size_t)(2 * n_groups + 3) * sizeof(int), h->stream));
         if (int rc = SOM_HALF(h, exact_screen_ks, h, Xb + r0 * h->dp, n, h->best64 + r0)) return rc;
         exact_scan_kernel<<<dim3((unsigned)cdiv(n, 64)), dim3(64 * EX_SCAN_SPLIT), 0, h->stream>>>(
-            ex.gmin, ex.stride, n_groups, n, h->best64 + r0, xsq + r0, h->wmax2, xmax2, eb, ex.cand, ex.count, ex.ctr);
+            ex.gmin, ex.stride, n_groups, n, h->best64 + r0, xsq + r0, h->wmax2, xmax2, eb, ex.bm, ex.ctr);
         if (int rc = exact_rescore(h, X + r0 * h->D, n, h->best64 + r0, out + r0)) return rc;
         HIPCHK(h, hipGetLastError());
         // rows the scheme could not settle (normally none): the float32 kernel itself
@@ -1414,8 +1418,7 @@ void som_destroy(som_handle* h) {
     seg_free(h->seg);
     seg_free(h->st_seg);
     {
-        void* eb[] = {h->ex.gmin, h->ex.cand, h->ex.count, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist,
-                      h->ex.tile_tab};
+        void* eb[] = {h->ex.gmin, h->ex.bm, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab};
         for (void* b : eb) if (b) (void)hipFree(b);
         if (h->ex.fb_count_host) (void)hipHostFree(h->ex.fb_count_host);
     }
@@ -2049,7 +2052,15 @@ int som_exact_last_counts(som_handle* h, int32_t* counts_out, int64_t n) {
     DeviceGuard dev_guard(h);
     if (!h || !counts_out || n < 0) return fail(h, "som_exact_last_counts: bad argument");
     if (!h->exact || n > h->ex.stride) return fail(h, "som_exact_last_counts: no screen pass of that many rows");
-    return d2h_blocking(h, counts_out, h->ex.count, (size_t)n * sizeof(int));
+    const long n_words = cdiv(cdiv(h->K, EX_GROUP), 32);
+    std::vector<uint32_t> bm((size_t)n_words * h->ex.stride);
+    if (int rc = d2h_blocking(h, bm.data(), h->ex.bm, bm.size() * sizeof(uint32_t))) return rc;
+    for (int64_t r = 0; r < n; ++r) {
+        int c = 0;
+        for (long w = 0; w < n_words; ++w) c += __builtin_popcount(bm[(size_t)w * h->ex.stride + r]);
+        counts_out[r] = c;
+    }
+    return 0;
 }
 
 int som_sync(som_handle* h) {
