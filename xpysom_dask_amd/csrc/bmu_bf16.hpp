@@ -30,6 +30,19 @@ __device__ __forceinline__ void atomic_max_pos_f32(float* addr, float v) {
         atomicMax((unsigned int*)addr, __float_as_uint(v));
 }
 
+// precision 'exact' on IEEE half operands (bmu_exact.hpp): rows and units are scaled by powers of two so that the
+// longest one has a norm in [2^13, 2^14) -- every element then fits float16 with room to spare, and only elements
+// 2^-27 of the longest norm and smaller reach the subnormal range.  max2 = the largest squared norm of the set.
+__device__ __forceinline__ float ex_scale(float max2) {
+    const float m = __builtin_sqrtf(max2) * (1.0f + 1.0f / 1024.0f);
+    if (!(m > 0.0f) || !(m < 3.0e38f)) return 1.0f;
+    int e;
+    (void)frexpf(m, &e);                                   // m = f * 2^e, f in [0.5, 1)
+    e = 14 - e;
+    e = e > 100 ? 100 : e < -100 ? -100 : e;
+    return ldexpf(1.0f, e);
+}
+
 // |w~|^2 of every unit (bf16-rounded values) and its maximum over the codebook
 template <class EL = Bf16>
 __global__ __launch_bounds__(256) void prep_wnorm_kernel(const float* __restrict__ W, int K, int D,
@@ -56,12 +69,15 @@ __global__ __launch_bounds__(256) void prep_wsqh_kernel(const float* __restrict_
                                                         const float* __restrict__ wmax2,
                                                         const float* __restrict__ xmax2, char* __restrict__ Wst,
                                                         int n_stages, int stage_bytes, int stage_units,
-                                                        unsigned long long* __restrict__ best64, long n_rows) {
+                                                        unsigned long long* __restrict__ best64, long n_rows,
+                                                        int scaled = 0) {
     long u = (long)blockIdx.x * 256 + threadIdx.x;
     if (best64 != nullptr && u < n_rows) best64[u] = ~0ull;
     if (u >= (long)n_stages * stage_units) return;
     const float big = __builtin_sqrtf(*wmax2) * __builtin_sqrtf(*xmax2) * (1.0f + 1.0f / 1024.0f);
-    float s = (u < K) ? __builtin_fmaf(0.5f, wn[u], big) : BF_PAD_NORM;
+    // scaled (exact mode on half operands): the operands carry ex_scale factors, so does the accumulator (exactly)
+    const float S = scaled ? ex_scale(*xmax2) * ex_scale(*wmax2) : 1.0f;
+    float s = (u < K) ? __builtin_fmaf(0.5f * S, wn[u], S * big) : BF_PAD_NORM;
     long stage = u / stage_units;
     int within = u % stage_units;
     float* dst = (float*)(Wst + (stage + 1) * (long)stage_bytes - 1024);   // the stage's last KiB
@@ -73,12 +89,14 @@ __global__ __launch_bounds__(256) void prep_wsqh_kernel(const float* __restrict_
 template <class EL = Bf16>
 __global__ __launch_bounds__(256) void prep_x_bf16_kernel(const float* __restrict__ X, long N, int D, int Dp,
                                                           long Np, __bf16* __restrict__ Xb,
-                                                          float* __restrict__ xmax2, int unit) {
+                                                          float* __restrict__ xmax2, int unit,
+                                                          const float* __restrict__ scale_max2 = nullptr) {
     using E = typename EL::T;
     long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (row >= Np) return;
-    float scale = 1.0f;
+    // scale_max2 (exact mode): rows times ex_scale(*scale_max2); the caller keeps max |x|^2 itself (xmax2 == nullptr)
+    float scale = scale_max2 != nullptr ? ex_scale(*scale_max2) : 1.0f;
     if (unit) {
         float q = 0.0f;
         for (int k = lane; k < D; k += 64) { float f = row < N ? X[row * D + k] : 0.0f; q = __builtin_fmaf(f, f, q); }
@@ -94,7 +112,7 @@ __global__ __launch_bounds__(256) void prep_x_bf16_kernel(const float* __restric
         s = __builtin_fmaf(fb, fb, s);
     }
     s = wave_sum(s);
-    if (lane == 0) atomic_max_pos_f32(xmax2, s);
+    if (lane == 0 && xmax2 != nullptr) atomic_max_pos_f32(xmax2, s);
 }
 
 }  // namespace somhip

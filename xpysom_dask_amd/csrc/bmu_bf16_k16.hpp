@@ -41,7 +41,8 @@ __host__ __device__ constexpr int k16_stage_bytes(int ks32) { return (K16_T * ks
 template <int KS32, class EL = Bf16>
 __global__ __launch_bounds__(256) void prep_w_bf16_k16_kernel(const float* __restrict__ W, int K, int D,
                                                               char* __restrict__ Wst, int n_stages,
-                                                              const float* __restrict__ unit_wsq) {
+                                                              const float* __restrict__ unit_wsq,
+                                                              const float* __restrict__ scale_max2 = nullptr) {
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     long id = (long)blockIdx.x * 256 + threadIdx.x;
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(256) void prep_w_bf16_k16_kernel(const float* __res
     // (its similarity is nan_to_num(0/0) = 0 in the reference, and x~ . 0 = 0 here).
     float scale = 1.0f;
     if (unit_wsq != nullptr && u < K) { float q = unit_wsq[u]; scale = q > 0.0f ? 1.0f / __builtin_sqrtf(q) : 0.0f; }
+    if (scale_max2 != nullptr) scale = ex_scale(*scale_max2);   // exact mode on half operands: a power of two
     bf16x8 v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -170,10 +172,16 @@ __global__ __launch_bounds__(64 * KS32) void merge_prep_k16_kernel(float* __rest
 #ifndef SOM_K16_MINWAVES
 #define SOM_K16_MINWAVES 2
 #endif
-template <int KS32, class EL = Bf16>
+// GM (precision 'exact', bmu_exact.hpp): besides the row's best key the kernel writes, per stage (= one GROUP of 64
+// units) and row, the smallest value it saw there: gmin[stage * gm_stride + row] (value bits, index bits cleared).  A
+// lane holds its quad's minimum for each of the wave's 4 sample blocks; three v_permlane*_swap + v_min steps transpose
+// and reduce so that quad q ends with the full minimum of sample block q -- lane l then owns row wave_s0 + l, and the
+// wave stores 256 contiguous bytes per stage.
+template <int KS32, class EL = Bf16, bool GM = false>
 __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
                                                               const char* __restrict__ Wst, int n_stages, int K,
-                                                              unsigned long long* __restrict__ out64) {
+                                                              unsigned long long* __restrict__ out64,
+                                                              uint32_t* __restrict__ gmin = nullptr, long gm_stride = 0) {
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     constexpr int DP = 32 * KS32;
@@ -237,6 +245,17 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
         }
     };
     auto fold_stage = [&](int stage) {
+        if (GM && stage >= s_begin) {
+            static_assert(!GM || K16_SB == 4, "the group-minimum transpose pairs four 16-sample blocks with four lane quads");
+            // rows of 16 lanes (quads) q0..q3 each hold (v0, v1, v2, v3): after the three steps quad q holds min over quads of v_q
+            auto a = __builtin_amdgcn_permlane16_swap(cbest[0], cbest[K16_SB > 1 ? 1 : 0], false, false);
+            const uint32_t t01 = min(a[0], a[1]);         // quads: (v0 q01, v1 q01, v0 q23, v1 q23)
+            auto b = __builtin_amdgcn_permlane16_swap(cbest[K16_SB > 2 ? 2 : 0], cbest[K16_SB > 3 ? 3 : 0], false, false);
+            const uint32_t t23 = min(b[0], b[1]);         // quads: (v2 q01, v3 q01, v2 q23, v3 q23)
+            auto c = __builtin_amdgcn_permlane32_swap(t01, t23, false, false);
+            const uint32_t full = min(c[0], c[1]) & ~IDX_MASK;   // quads: (v0, v1, v2, v3), each over all four quads
+            gmin[(long)stage * gm_stride + wave_s0 + lane] = full;
+        }
 #pragma unroll
         for (int sb = 0; sb < K16_SB; ++sb) {
             if (cbest[sb] < gbest[sb]) { gbest[sb] = cbest[sb]; gstage[sb] = stage; }

@@ -34,7 +34,12 @@
 //                    ulps of the largest magnitude the accumulator can take, Bm = 2.01 B + max wsq / 2 (the hardware's
 //                    internal summation is not documented; tests/test_gpu_exact.py measures it at <= 1 ulp), plus the
 //                    8 ulps the index bits packed into the key's low mantissa bits hide.
-//   E (in units of d' = tau / 2 + B):  E32 / 2 ... spelled out in exact_bound() (host side, somhip.hip).
+//   screen on IEEE half operands in ONE pass (the default; the split-bf16 screen is kept for A/B): rows and units are
+//                    first scaled by powers of two (ex_scale: the longest norm lands in [2^13, 2^14), exact), then
+//                    rounded to float16: |v~ - v^| <= max(2^-11 |v^|, delta), delta = 2^-14 covering even a
+//                    flush of subnormal operands to zero.  Products: (2 ub + ub^2) A relative, plus
+//                    delta sqrt(D) (|w^|max + |x^_n|) + D delta^2 absolute.  One MFMA chain of ceil(D/32).
+//   E (in units of d' = tau / 2 + B):  spelled out in exact_bound() (host side, somhip.hip).
 // The bound is deliberately loose (worst-case rounding everywhere): widening E only adds candidate groups, and a
 // candidate group costs one 64-unit re-score.
 #pragma once
@@ -48,8 +53,11 @@ constexpr int EX_PAIRS = 64;          // capacity of a pass: this many (row, gro
 constexpr int EX_SCAN_SPLIT = 4;      // waves that share a row's groups in the scan
 constexpr int EX_TR = 128;            // rows per re-score tile (4 waves x 32 rows against one 64-unit group)
 
-struct ExactBound {                   // E(n) = cA * |x_n| * wmax + cW * wmax^2 + cB * Bm   (d' units)
-    float cA, cW, cB;
+// E(n) = S (cA |x_n| wmax + cW wmax^2 + cB Bm) + cD (sw wmax + sx |x_n|) + cD2   in (scaled) d' units;
+// S = sx sw = the power-of-two operand scales of the half-precision screen (1 for the split-bf16 screen: scaled == 0)
+struct ExactBound {
+    float cA, cW, cB, cD, cD2;
+    int scaled;
 };
 
 // Small per-pass counters, one allocation, zeroed by one memset before the scan:
@@ -91,7 +99,8 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_scan_kernel(const ui
     const float bmag = 2.01f * big + 0.5f * wm * wm;
     const float xn = __builtin_sqrtf(xsq[r]) * (1.0f + 1.0f / 1024.0f);
     const float m = __uint_as_float((uint32_t)(best64[r] >> 32));
-    const float e = eb.cA * xn * wm + eb.cW * wm * wm + eb.cB * bmag;
+    const float sx = eb.scaled ? ex_scale(*xmax2) : 1.0f, sw = eb.scaled ? ex_scale(*wmax2) : 1.0f;
+    const float e = sx * sw * (eb.cA * xn * wm + eb.cW * wm * wm + eb.cB * bmag) + eb.cD * (sw * wm + sx * xn) + eb.cD2;
     const float thr_f = m + e;
     // A threshold that is not a finite positive number (NaN / infinite row or norms) selects nothing, and neither
     // does a row or codebook so small that float32 products may underflow (the bound assumes none do): fallback.
@@ -316,6 +325,16 @@ __global__ __launch_bounds__(256) void exact_scatter_ids_kernel(const int* __res
                                                                 int n, int* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[list[i]] = ids[i];
+}
+
+// max_n v[n] (positive floats; NaN left out) into *out, which the caller zeroed
+__global__ __launch_bounds__(256) void exact_max_kernel(const float* __restrict__ v, long n, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float m = 0.0f;
+    if (i < n) { const float s = v[i]; if (s == s) m = s; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomic_max_pos_f32(out, m);
 }
 
 // wn = wsq (the float32 kernel's own |w|^2) and its maximum: the screen's initial accumulator then carries the same

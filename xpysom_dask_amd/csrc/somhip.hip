@@ -66,7 +66,8 @@ struct som_handle {
     int x3 = 0;              // precision bf16x3 / f16x3: hi/lo split operands, tripled feature axis
     bool f16 = false;        // precision f16 / f16x3: _Float16 operands instead of __bf16 (the same kernels, som_common.hpp)
     bool x3res = false;      // bf16x3 with input_len <= 128: the register-resident split kernel (bmu_bf16_k16x3.hpp)
-    bool exact = false;      // precision 'exact': split-bf16 screen + float32 re-score of the candidates (bmu_exact.hpp)
+    bool exact = false;      // precision 'exact': MFMA screen + float32 re-score of the candidates (bmu_exact.hpp)
+    bool ex_x3 = false;      //   its screen: the split-bf16 kernel (SOM_EXACT_SCREEN=x3) instead of one pass on scaled IEEE half operands
     struct ExactScratch {
         uint32_t* gmin = nullptr;            // [n_groups][stride] group minima of the chunk being screened
         long stride = 0;                     //   rows per group line (a chunk of the row set, padded)
@@ -346,13 +347,22 @@ int prep_codebook_half(som_handle* h) {
     }
     const long total = (long)h->n_stages * K16_T * h->ks32 * 64;
     const dim3 grid((unsigned)cdiv(total, 256));
+    const float* sc = nullptr;
+    if (h->exact) {
+        // the float32 kernel's own |w|^2 (refreshed just before) and its maximum first: the units go in scaled by
+        // ex_scale(max |w|^2)
+        HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
+        exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(h->K, 256)), block, 0, h->stream>>>(h->wsq, h->K, h->wn, h->wmax2);
+        sc = h->wmax2;
+    }
     switch (h->ks32) {
-    case 1: prep_w_bf16_k16_kernel<1, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
-    case 2: prep_w_bf16_k16_kernel<2, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
-    case 3: prep_w_bf16_k16_kernel<3, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
-    case 4: prep_w_bf16_k16_kernel<4, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
+    case 1: prep_w_bf16_k16_kernel<1, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit, sc); break;
+    case 2: prep_w_bf16_k16_kernel<2, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit, sc); break;
+    case 3: prep_w_bf16_k16_kernel<3, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit, sc); break;
+    case 4: prep_w_bf16_k16_kernel<4, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit, sc); break;
     default: return fail(h, "the resident half-precision kernel supports input_len <= 128");
     }
+    if (h->exact) return 0;
     HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
     prep_wnorm_kernel<E><<<dim3((unsigned)cdiv(h->K, 256)), block, 0, h->stream>>>(h->W, h->K, h->D, h->wn, h->wmax2, unit);
     return 0;
@@ -708,7 +718,12 @@ int prep_rows_half(som_handle* h, const float* X, long N, long Np, __bf16* Xb, f
     if (h->x3res)
         prep_x_bf16x3_kernel<E><<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, 32 * h->ks32, Np, Xb, xmax2,
                                                                                        unit ? 1 : 0);
-    else
+    else if (h->exact) {
+        // max |x|^2 from the rows' float32 norms (xsq_scratch: computed by the caller), then the rows scaled by ex_scale of it
+        if (!xsq_scratch && N > 0) return fail(h, "exact: no row norms");
+        if (N > 0) exact_max_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(xsq_scratch, N, xmax2);
+        prep_x_bf16_kernel<E><<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, Dp, Np, Xb, nullptr, 0, xmax2);
+    } else
         prep_x_bf16_kernel<E><<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, Dp, Np, Xb, xmax2, unit ? 1 : 0);
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -767,12 +782,26 @@ ExactBound exact_bound(const som_handle* h) {
     const double u = std::ldexp(1.0, -24), ub = h->f16 ? std::ldexp(1.0, -11) : std::ldexp(1.0, -8);
     const double Dl = 8.0 * h->fr_kg;                    // chain length of the float32 kernel (zero padded)
     const double gamma = Dl * u / (1.0 - Dl * u);
-    const double n_mfma = 3.0 * h->ks32;
     const double slop = 1.01;                             // the kernel evaluates E in float32
-    ExactBound eb;
-    eb.cA = (float)(slop * ((2.0 * gamma + 2.0 * u) * (1.0 + u) + 2.0 * ub * ub * (3.0 + 5.0 * ub)));
+    const double e32 = (2.0 * gamma + 2.0 * u) * (1.0 + u);   // float32 kernel, relative to A (tau units)
+    ExactBound eb{};
     eb.cW = (float)(slop * u);
-    eb.cB = (float)(slop * 2.0 * (EX_KAPPA * n_mfma + 9.0) * std::ldexp(1.0, -23));
+    if (h->ex_x3) {                                       // split screen: hi.hi + lo.hi + hi.lo, three MFMA chains
+        eb.cA = (float)(slop * (e32 + 2.0 * ub * ub * (3.0 + 5.0 * ub)));
+        eb.cB = (float)(slop * 2.0 * (EX_KAPPA * 3.0 * h->ks32 + 9.0) * std::ldexp(1.0, -23));
+    } else {                                              // one pass on scaled half operands
+        const double delta = std::ldexp(1.0, -14);        // absolute rounding of an operand in the subnormal range (FTZ-safe)
+        const double Dp = 32.0 * h->ks32;
+        eb.cA = (float)(slop * (e32 + 2.0 * (2.0 * ub + ub * ub)));
+        eb.cB = (float)(slop * 2.0 * (EX_KAPPA * h->ks32 + 9.0) * std::ldexp(1.0, -23));
+        eb.cD = (float)(slop * 2.0 * delta * std::sqrt(Dp) * (1.0 + ub));
+        eb.cD2 = (float)(slop * 2.0 * Dp * delta * delta);
+        eb.scaled = 1;
+    }
+    if (const char* e = std::getenv("SOM_EXACT_BOUND_SCALE")) {   // experiments: how the candidate load grows with the band
+        const float f = (float)std::atof(e);
+        if (f > 1.0f) { eb.cA *= f; eb.cW *= f; eb.cB *= f; eb.cD *= f; eb.cD2 *= f; }
+    }
     return eb;
 }
 
@@ -810,18 +839,34 @@ int exact_reserve(som_handle* h, long rows) {
 
 template <int KS32, class E>
 int exact_screen(som_handle* h, const __bf16* Xb, long n, unsigned long long* best64) {
+    const int n_groups = (int)cdiv(h->K, EX_GROUP);
+    if (!h->ex_x3) {                                      // one pass on scaled half operands: a stage IS a group
+        auto kern = bmu_bf16_k16_kernel<KS32, E, true>;
+        size_t lds = 2 * (size_t)k16_stage_bytes(KS32);
+        int per_cu = 1;
+        if (int rc = kernel_per_cu(h, (const void*)kern, 64 * K16_NW, lds, &per_cu)) return rc;
+        const long blocks = cdiv(n, K16_WG_SAMPLES);
+        const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
+        int parts = choose_parts(h, blocks, slots, h->n_stages);
+        if (h->env_bf16_parts > 0) parts = std::min(h->env_bf16_parts, h->n_stages);
+        if (h->debug)
+            std::fprintf(stderr, "[somhip] exact screen (half): blocks=%ld per_cu=%d slots=%ld parts=%d groups=%d\n", blocks, per_cu,
+                         slots, parts, n_groups);
+        kern<<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * K16_NW), lds, h->stream>>>(Xb, n, h->Wst, h->n_stages, h->K, best64,
+                                                                                           h->ex.gmin, h->ex.stride);
+        return 0;
+    }
     auto kern = bmu_bf16_k16x3_kernel<KS32, E, true>;
     size_t lds = 2 * (size_t)k3_stage_bytes(KS32);
     int per_cu = 1;
     if (int rc = kernel_per_cu(h, (const void*)kern, 64 * K3_NW, lds, &per_cu)) return rc;
     const long blocks = cdiv(n, K3_WG_SAMPLES);
     const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
-    const int n_groups = (int)cdiv(h->n_stages, 2);
     int parts = choose_parts(h, blocks, slots, n_groups);
     if (h->env_bf16_parts > 0) parts = std::min(h->env_bf16_parts, n_groups);
     if (h->debug)
-        std::fprintf(stderr, "[somhip] exact screen: blocks=%ld per_cu=%d slots=%ld parts=%d groups=%d\n", blocks, per_cu, slots,
-                     parts, n_groups);
+        std::fprintf(stderr, "[somhip] exact screen (split): blocks=%ld per_cu=%d slots=%ld parts=%d groups=%d\n", blocks, per_cu,
+                     slots, parts, n_groups);
     kern<<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * K3_NW), lds, h->stream>>>(Xb, n, h->Wst, h->n_stages, h->K, best64,
                                                                                       h->ex.gmin, h->ex.stride);
     return 0;
@@ -894,7 +939,7 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     }
     const long units = (long)h->n_stages * h->stage_units;
     prep_wsqh_kernel<<<dim3((unsigned)cdiv(std::max(units, N), 256)), dim3(256), 0, h->stream>>>(
-        h->wn, h->K, h->wmax2, xmax2, h->Wst, h->n_stages, h->stage_bytes, h->stage_units, h->best64, N);
+        h->wn, h->K, h->wmax2, xmax2, h->Wst, h->n_stages, h->stage_bytes, h->stage_units, h->best64, N, h->ex_x3 ? 0 : 1);
     const ExactBound eb = exact_bound(h);
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
     const long chunk = std::min(exact_chunk_rows(h), ex.stride);
@@ -1292,8 +1337,9 @@ int som_create(const som_config* cfg, som_handle** out) {
     h->D1p = (int)round_up(h->D + 1, 4);
     h->norm_p = cfg->norm_p > 0 ? cfg->norm_p : 2;
     h->ks32 = (int)cdiv(h->D, 32);
-    h->x3 = cfg->precision == SOM_PREC_BF16X3 || cfg->precision == SOM_PREC_F16X3 || h->exact;
-    h->f16 = cfg->precision == SOM_PREC_F16 || cfg->precision == SOM_PREC_F16X3;
+    if (h->exact) if (const char* e = std::getenv("SOM_EXACT_SCREEN")) h->ex_x3 = std::string(e) == "x3";   // A/B: the split-bf16 screen
+    h->x3 = cfg->precision == SOM_PREC_BF16X3 || cfg->precision == SOM_PREC_F16X3 || (h->exact && h->ex_x3);
+    h->f16 = cfg->precision == SOM_PREC_F16 || cfg->precision == SOM_PREC_F16X3 || (h->exact && !h->ex_x3);
     h->x3res = h->x3 && h->D <= 128;
     if (const char* e = std::getenv("SOM_X3_TILED")) if (std::atoi(e) != 0 && !h->exact) h->x3res = false;   // A/B: the tiled split kernel
     h->tiled = ((cfg->precision == SOM_PREC_BF16 || cfg->precision == SOM_PREC_F16) && h->D > 128) || (h->x3 && !h->x3res);
@@ -1436,7 +1482,7 @@ void som_destroy(som_handle* h) {
 int som_set_weights(som_handle* h, const float* w_host) {
     DeviceGuard dev_guard(h);
     if (!h || !w_host) return fail(h, "som_set_weights: NULL argument");
-    if (h->f16 && h->cfg.distance != SOM_DIST_COSINE) {   // (cosine rounds unit-length rows)
+    if (h->f16 && !h->exact && h->cfg.distance != SOM_DIST_COSINE) {   // (cosine rounds unit-length rows; exact scales)
         // every unit's own norm must fit IEEE half (NaN / infinite units are left to the kernels' NaN rules)
         for (long k = 0; k < h->K; ++k) {
             double q = 0.0;
@@ -1477,7 +1523,7 @@ static int adopt_rows(som_handle* h, int64_t n_rows) {
         if (int rc = prep_rows_bf16(h, h->Xd, n_rows, h->Np, h->Xb, h->xmax2, h->xsq)) return rc;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->f16 && n_rows > 0) {                          // IEEE half tops out at 65504: refuse rows that do not fit
+    if (h->f16 && !h->exact && n_rows > 0) {             // IEEE half tops out at 65504: refuse rows that do not fit
         float m2 = 0.0f;
         if (int rc = d2h_blocking(h, &m2, h->xmax2, sizeof(float))) return rc;
         if (!(m2 <= HALF_MAX * HALF_MAX))
