@@ -43,6 +43,14 @@ __device__ __forceinline__ float ex_scale(float max2) {
     return ldexpf(1.0f, e);
 }
 
+// what the MFMA may see instead of the (scaled) float32 value f once it went through the 16-bit type as fb: the rounding
+// error |f - fb|, or all of |f| when fb is a subnormal IEEE half (an MFMA that flushes subnormal inputs reads 0 there;
+// one that does not errs by less: the larger of the two covers both)
+__device__ __forceinline__ float half_operand_error(float f, float fb) {
+    const float a = __builtin_fabsf(fb);
+    return (a > 0.0f && a < 6.103515625e-05f) ? __builtin_fabsf(f) : __builtin_fabsf(f - fb);
+}
+
 // |w~|^2 of every unit (bf16-rounded values) and its maximum over the codebook
 template <class EL = Bf16>
 __global__ __launch_bounds__(256) void prep_wnorm_kernel(const float* __restrict__ W, int K, int D,
@@ -90,7 +98,8 @@ template <class EL = Bf16>
 __global__ __launch_bounds__(256) void prep_x_bf16_kernel(const float* __restrict__ X, long N, int D, int Dp,
                                                           long Np, __bf16* __restrict__ Xb,
                                                           float* __restrict__ xmax2, int unit,
-                                                          const float* __restrict__ scale_max2 = nullptr) {
+                                                          const float* __restrict__ scale_max2 = nullptr,
+                                                          float* __restrict__ xerr = nullptr) {
     using E = typename EL::T;
     long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
@@ -103,16 +112,21 @@ __global__ __launch_bounds__(256) void prep_x_bf16_kernel(const float* __restric
         q = wave_sum(q);
         scale = q > 0.0f ? 1.0f / __builtin_sqrtf(q) : 0.0f;
     }
-    float s = 0.0f;
+    float s = 0.0f, er = 0.0f;
     for (int k = lane; k < Dp; k += 64) {
         float f = (row < N && k < D) ? X[row * D + k] * scale : 0.0f;
         E b = cvt<E>(f);
         ((E*)Xb)[row * Dp + k] = b;
         float fb = (float)b;
         s = __builtin_fmaf(fb, fb, s);
+        er = __builtin_fmaf(half_operand_error(f, fb), half_operand_error(f, fb), er);
     }
     s = wave_sum(s);
     if (lane == 0 && xmax2 != nullptr) atomic_max_pos_f32(xmax2, s);
+    if (xerr != nullptr) {                                 // |x^ - x~| of the row, rounded up (exact mode's measured bound)
+        er = wave_sum(er);
+        if (lane == 0 && row < N) xerr[row] = __builtin_sqrtf(er) * (1.0f + 1.0f / 1024.0f);
+    }
 }
 
 }  // namespace somhip

@@ -36,9 +36,12 @@
 //                    8 ulps the index bits packed into the key's low mantissa bits hide.
 //   screen on IEEE half operands in ONE pass (the default; the split-bf16 screen is kept for A/B): rows and units are
 //                    first scaled by powers of two (ex_scale: the longest norm lands in [2^13, 2^14), exact), then
-//                    rounded to float16: |v~ - v^| <= max(2^-11 |v^|, delta), delta = 2^-14 covering even a
-//                    flush of subnormal operands to zero.  Products: (2 ub + ub^2) A relative, plus
-//                    delta sqrt(D) (|w^|max + |x^_n|) + D delta^2 absolute.  One MFMA chain of ceil(D/32).
+//                    rounded to float16.  The operand error is MEASURED, not assumed: the preparation kernels know
+//                    both x^ (scaled float32) and x~ (what the MFMA reads), so |x^_n - x~_n| per row and
+//                    max_k |w^_k - w~_k| are numbers (a subnormal half counts with its whole value: covers an MFMA
+//                    that flushes it), and  |x~.w~ - x^.w^| = |dx.w^ + x~.dw| <= |dx| |w^| + (|x^| + |dx|) |dw|
+//                    by Cauchy-Schwarz -- about 0.4 of the worst-case 2^-11 relative rounding on Gaussian-like rows.
+//                    One MFMA chain of ceil(D/32).
 //   E (in units of d' = tau / 2 + B):  spelled out in exact_bound() (host side, somhip.hip).
 // The bound is deliberately loose (worst-case rounding everywhere): widening E only adds candidate groups, and a
 // candidate group costs one 64-unit re-score.
@@ -53,10 +56,11 @@ constexpr int EX_PAIRS = 64;          // capacity of a pass: this many (row, gro
 constexpr int EX_SCAN_SPLIT = 4;      // waves that share a row's groups in the scan
 constexpr int EX_TR = 128;            // rows per re-score tile (4 waves x 32 rows against one 64-unit group)
 
-// E(n) = S (cA |x_n| wmax + cW wmax^2 + cB Bm) + cD (sw wmax + sx |x_n|) + cD2   in (scaled) d' units;
-// S = sx sw = the power-of-two operand scales of the half-precision screen (1 for the split-bf16 screen: scaled == 0)
+// E(n) = S (cA |x_n| wmax + cW wmax^2 + cB Bm) [+ cM (xerr_n w^max + (x^_n + xerr_n) werr)]   in (scaled) d' units;
+// S = sx sw = the power-of-two operand scales of the half-precision screen (1 for the split-bf16 screen: scaled == 0,
+// whose operand error is inside cA); xerr_n, werr: the MEASURED rounding errors |x^_n - x~_n|, max_k |w^_k - w~_k|
 struct ExactBound {
-    float cA, cW, cB, cD, cD2;
+    float cA, cW, cB, cM;
     int scaled;
 };
 
@@ -89,6 +93,8 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_scan_kernel(const ui
                                                                        const float* __restrict__ xsq,
                                                                        const float* __restrict__ wmax2,
                                                                        const float* __restrict__ xmax2, ExactBound eb,
+                                                                       const float* __restrict__ xerr,
+                                                                       const float* __restrict__ werr2,
                                                                        uint32_t* __restrict__ bm, int* __restrict__ gcount) {
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const long row = (long)blockIdx.x * 64 + lane;
@@ -100,7 +106,11 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_scan_kernel(const ui
     const float xn = __builtin_sqrtf(xsq[r]) * (1.0f + 1.0f / 1024.0f);
     const float m = __uint_as_float((uint32_t)(best64[r] >> 32));
     const float sx = eb.scaled ? ex_scale(*xmax2) : 1.0f, sw = eb.scaled ? ex_scale(*wmax2) : 1.0f;
-    const float e = sx * sw * (eb.cA * xn * wm + eb.cW * wm * wm + eb.cB * bmag) + eb.cD * (sw * wm + sx * xn) + eb.cD2;
+    float e = sx * sw * (eb.cA * xn * wm + eb.cW * wm * wm + eb.cB * bmag);
+    if (eb.scaled) {                                       // one-pass screen: its operands' measured rounding errors
+        const float xe = xerr[r], we = __builtin_sqrtf(*werr2) * (1.0f + 1.0f / 1024.0f);
+        e += eb.cM * (xe * sw * wm + (sx * xn + xe) * we);
+    }
     const float thr_f = m + e;
     // A threshold that is not a finite positive number (NaN / infinite row or norms) selects nothing, and neither
     // does a row or codebook so small that float32 products may underflow (the bound assumes none do): fallback.
@@ -332,6 +342,27 @@ __global__ __launch_bounds__(256) void exact_max_kernel(const float* __restrict_
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     float m = 0.0f;
     if (i < n) { const float s = v[i]; if (s == s) m = s; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomic_max_pos_f32(out, m);
+}
+
+// max_k |w^_k - w~_k|^2 over the units (w^ = sw w in float32, w~ = what the MFMA reads: half_operand_error) into *out
+template <class EL>
+__global__ __launch_bounds__(256) void exact_werr_kernel(const float* __restrict__ W, int K, int D,
+                                                         const float* __restrict__ wmax2, float* __restrict__ out) {
+    using E = typename EL::T;
+    const long u = (long)blockIdx.x * 256 + threadIdx.x;
+    float er = 0.0f;
+    if (u < K) {
+        const float scale = ex_scale(*wmax2);
+        for (int k = 0; k < D; ++k) {
+            const float f = W[u * D + k] * scale;
+            const float e = half_operand_error(f, (float)cvt<E>(f));
+            er = __builtin_fmaf(e, e, er);
+        }
+    }
+    float m = (er == er) ? er : 0.0f;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) atomic_max_pos_f32(out, m);

@@ -354,6 +354,8 @@ int prep_codebook_half(som_handle* h) {
         HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
         exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(h->K, 256)), block, 0, h->stream>>>(h->wsq, h->K, h->wn, h->wmax2);
         sc = h->wmax2;
+        HIPCHK(h, hipMemsetAsync(h->wmax2 + 1, 0, sizeof(float), h->stream));     // [1]: max_k |w^_k - w~_k|^2
+        exact_werr_kernel<E><<<dim3((unsigned)cdiv(h->K, 256)), block, 0, h->stream>>>(h->W, h->K, h->D, h->wmax2, h->wmax2 + 1);
     }
     switch (h->ks32) {
     case 1: prep_w_bf16_k16_kernel<1, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit, sc); break;
@@ -690,6 +692,16 @@ int launch_bmu_bf16(som_handle* h, const __bf16* Xb, const float* xmax2, long N,
     return SOM_HALF(h, launch_bmu_half, h, Xb, xmax2, N, out);
 }
 
+// precision 'exact': every |x|^2 buffer is allocated with twice its row capacity; the second half holds the rows'
+// measured operand rounding errors (bmu_exact.hpp).  Which half-way point belongs to this buffer:
+float* exact_err_of(som_handle* h, const float* xsq) {
+    if (!xsq) return nullptr;
+    if (xsq == h->xsq) return h->xsq + h->N;
+    if (xsq == h->qxsq) return h->qxsq + h->qcap;
+    for (auto& sl : h->slot) if (xsq == sl.dxsq) return sl.dxsq + sl.cap;
+    return nullptr;
+}
+
 // rows -> bf16 operand image (+ max |x~|^2 for the offset B).  Cosine: the rows go in at unit length -- the
 // argmin does not depend on |x|, and B = max|x~| max|w~| then resolves every row alike (a short row next to
 // long ones would otherwise be compared at B's absolute precision).  xsq_scratch: N floats, cosine + tiled only.
@@ -721,8 +733,10 @@ int prep_rows_half(som_handle* h, const float* X, long N, long Np, __bf16* Xb, f
     else if (h->exact) {
         // max |x|^2 from the rows' float32 norms (xsq_scratch: computed by the caller), then the rows scaled by ex_scale of it
         if (!xsq_scratch && N > 0) return fail(h, "exact: no row norms");
+        float* xerr = exact_err_of(h, xsq_scratch);
+        if (!xerr && N > 0) return fail(h, "exact: unknown row-norm buffer");
         if (N > 0) exact_max_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(xsq_scratch, N, xmax2);
-        prep_x_bf16_kernel<E><<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, Dp, Np, Xb, nullptr, 0, xmax2);
+        prep_x_bf16_kernel<E><<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, Dp, Np, Xb, nullptr, 0, xmax2, xerr);
     } else
         prep_x_bf16_kernel<E><<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, Dp, Np, Xb, xmax2, unit ? 1 : 0);
     HIPCHK(h, hipGetLastError());
@@ -789,18 +803,15 @@ ExactBound exact_bound(const som_handle* h) {
     if (h->ex_x3) {                                       // split screen: hi.hi + lo.hi + hi.lo, three MFMA chains
         eb.cA = (float)(slop * (e32 + 2.0 * ub * ub * (3.0 + 5.0 * ub)));
         eb.cB = (float)(slop * 2.0 * (EX_KAPPA * 3.0 * h->ks32 + 9.0) * std::ldexp(1.0, -23));
-    } else {                                              // one pass on scaled half operands
-        const double delta = std::ldexp(1.0, -14);        // absolute rounding of an operand in the subnormal range (FTZ-safe)
-        const double Dp = 32.0 * h->ks32;
-        eb.cA = (float)(slop * (e32 + 2.0 * (2.0 * ub + ub * ub)));
+    } else {                                              // one pass on scaled half operands: measured operand errors
+        eb.cA = (float)(slop * e32);
         eb.cB = (float)(slop * 2.0 * (EX_KAPPA * h->ks32 + 9.0) * std::ldexp(1.0, -23));
-        eb.cD = (float)(slop * 2.0 * delta * std::sqrt(Dp) * (1.0 + ub));
-        eb.cD2 = (float)(slop * 2.0 * Dp * delta * delta);
+        eb.cM = (float)(slop * 2.0);
         eb.scaled = 1;
     }
     if (const char* e = std::getenv("SOM_EXACT_BOUND_SCALE")) {   // experiments: how the candidate load grows with the band
         const float f = (float)std::atof(e);
-        if (f > 1.0f) { eb.cA *= f; eb.cW *= f; eb.cB *= f; eb.cD *= f; eb.cD2 *= f; }
+        if (f > 1.0f) { eb.cA *= f; eb.cW *= f; eb.cB *= f; eb.cM *= f; }
     }
     return eb;
 }
@@ -809,8 +820,8 @@ ExactBound exact_bound(const som_handle* h) {
 long exact_chunk_rows(const som_handle* h) {
     const long n_groups = cdiv(h->K, EX_GROUP);
     long rows = (1L << 30) / (4 * n_groups);
-    rows = rows / ROW_PAD * ROW_PAD;
-    return rows < ROW_PAD ? ROW_PAD : rows;
+    rows = rows / 1024 * 1024;                           // (a multiple of every screen kernel's workgroup tile)
+    return rows < 1024 ? 1024 : rows;
 }
 
 int exact_reserve(som_handle* h, long rows) {
@@ -929,6 +940,8 @@ int exact_rescore(som_handle* h, const float* X, long n, unsigned long long* bes
 int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, const __bf16* Xb, const float* xmax2, int* out) {
     if (h->capturing) return fail(h, "precision 'exact' reads a counter back per pass: not capturable");
     if (!xsq) return fail(h, "exact: no row norms");
+    const float* xerr = h->ex_x3 ? nullptr : exact_err_of(h, xsq);
+    if (!h->ex_x3 && !xerr) return fail(h, "exact: unknown row-norm buffer");
     auto& ex = h->ex;
     if (int rc = exact_reserve(h, N)) return rc;
     if (N > h->best64_cap) {
@@ -948,7 +961,8 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         HIPCHK(h, hipMemsetAsync(ex.ctr, 0, (size_t)(2 * n_groups + 3) * sizeof(int), h->stream));
         if (int rc = SOM_HALF(h, exact_screen_ks, h, Xb + r0 * h->dp, n, h->best64 + r0)) return rc;
         exact_scan_kernel<<<dim3((unsigned)cdiv(n, 64)), dim3(64 * EX_SCAN_SPLIT), 0, h->stream>>>(
-            ex.gmin, ex.stride, n_groups, n, h->best64 + r0, xsq + r0, h->wmax2, xmax2, eb, ex.bm, ex.ctr);
+            ex.gmin, ex.stride, n_groups, n, h->best64 + r0, xsq + r0, h->wmax2, xmax2, eb, xerr ? xerr + r0 : nullptr, h->wmax2 + 1,
+            ex.bm, ex.ctr);
         if (int rc = exact_rescore(h, X + r0 * h->D, n, h->best64 + r0, out + r0)) return rc;
         HIPCHK(h, hipGetLastError());
         // rows the scheme could not settle (normally none): the float32 kernel itself
@@ -1254,7 +1268,7 @@ int ensure_query_scratch(som_handle* h, long n) {
     if (int rc = dev_alloc(h, &h->qX, (size_t)cap * h->D)) return rc;
     if (int rc = dev_alloc(h, &h->qbmu, (size_t)cap)) return rc;
     if (int rc = dev_alloc(h, &h->qbmu2, (size_t)cap)) return rc;
-    if (int rc = dev_alloc(h, &h->qxsq, (size_t)cap)) return rc;
+    if (int rc = dev_alloc(h, &h->qxsq, (size_t)cap * (h->exact ? 2 : 1))) return rc;
     if (h->cfg.precision != SOM_PREC_F32) {
         long capp = round_up(cap, ROW_PAD);
         if (int rc = dev_alloc(h, &h->qXb, (size_t)capp * h->dp)) return rc;
@@ -1436,7 +1450,7 @@ int som_create(const som_config* cfg, som_handle** out) {
         if ((rc = dev_alloc(h, &h->Wst, bytes))) return bail(rc);
         if ((rc = dev_alloc(h, &h->xmax2, 2))) return bail(rc);
         if ((rc = dev_alloc(h, &h->wn, (size_t)h->K))) return bail(rc);
-        if ((rc = dev_alloc(h, &h->wmax2, 1))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->wmax2, 2))) return bail(rc);
         if (hipMemsetAsync(h->Wst, 0, bytes, h->stream) != hipSuccess) return bail(fail(h, "hipMemsetAsync failed"));
     }
     if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(fail(h, "hipStreamSynchronize failed"));
@@ -1515,7 +1529,7 @@ static int adopt_rows(som_handle* h, int64_t n_rows) {
         if (int rc = seg_reserve(h, h->seg, n_rows)) return rc;
     const bool bf_cos_tiled = h->cfg.precision != SOM_PREC_F32 && h->cfg.distance == SOM_DIST_COSINE && h->tiled;
     if (needs_xsq(h) || bf_cos_tiled) {
-        if (int rc = dev_alloc(h, &h->xsq, (size_t)n_rows)) return rc;
+        if (int rc = dev_alloc(h, &h->xsq, (size_t)n_rows * (h->exact ? 2 : 1))) return rc;
         if (needs_xsq(h)) if (int rc = row_sq(h, h->Xd, n_rows, h->xsq)) return rc;
     }
     if (h->cfg.precision != SOM_PREC_F32 && n_rows > 0) {
@@ -1704,7 +1718,7 @@ static int ensure_slot(som_handle* h, som_handle::Slot& sl, long n) {
     long cap = round_up(n, ROW_PAD);
     if (int rc = dev_alloc(h, &sl.dX, (size_t)cap * h->D)) return rc;
     if (int rc = dev_alloc(h, &sl.dbmu, (size_t)cap)) return rc;
-    if (int rc = dev_alloc(h, &sl.dxsq, (size_t)cap)) return rc;
+    if (int rc = dev_alloc(h, &sl.dxsq, (size_t)cap * (h->exact ? 2 : 1))) return rc;
     if (h->cfg.precision != SOM_PREC_F32)
         if (int rc = dev_alloc(h, &sl.dXb, (size_t)cap * h->dp)) return rc;
     sl.cap = cap;
