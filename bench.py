@@ -9,9 +9,14 @@ exits with their code.  Under an external launcher (the driver's `torch.distribu
 it is a rank and reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
 
 Workload (BASELINE.json configs[2]/[3]): 256x256 map, 128 features, synthetic Gaussian-blob rows resident in HBM,
-bf16 MFMA distance GEMM, default schedule.  A step = one full epoch over the resident rows: codebook prep, fused
+16-bit MFMA distance GEMM, default schedule.  A step = one full epoch over the resident rows: codebook prep, fused
 distance+BMU, segment sum, separable neighbourhood transform, (N > 1: one RCCL all-reduce of the fused
 numerator|denominator buffer), merge.
+The headline mode is precision='exact': the BMUs -- hence every epoch's accumulators and the trained codebook -- are bit
+for bit those of the float32 parity mode (the reference's own arithmetic), found by an IEEE-half MFMA screen over all
+units and a float32 re-score of the candidates its error bound leaves (csrc/bmu_exact.hpp).  `throughput_mode` in the
+same line is the plain bf16 kernel (round 1-2's headline: faster, but its BMUs differ from float32's on up to 70 % of
+the rows of a smooth mid-schedule map); `precision_modes_at_batch65536` quantifies every mode's agreement.
   --scaling weak   (default) 1,048,576 rows PER GPU: N = 1 is configs[2], N = 8 is configs[3] (8 Mi rows on 8 GPUs)
   --scaling strong configs[3]'s 8,388,608 rows IN TOTAL split over the N ranks (N = 1 holds all of them)
 
@@ -42,7 +47,7 @@ NORTH_STAR_BATCH = 65536
 # `c3` is the configuration BASELINE.json's metric is quoted on and the default; the other two put the
 # remaining GPU configs through the same harness (python bench.py --workload c5).
 WORKLOADS = {
-    "c3": dict(map=(256, 256), features=128, rows=1 << 20, precision="bf16", distance="euclidean",
+    "c3": dict(map=(256, 256), features=128, rows=1 << 20, precision="exact", distance="euclidean",
                neighborhood="gaussian", cpu_rows=8192, label="BASELINE configs[2]/[3]"),
     "c2": dict(map=(64, 64), features=32, rows=100000, precision="f32", distance="euclidean",
                neighborhood="gaussian", cpu_rows=100000, label="BASELINE configs[1]"),
@@ -71,6 +76,8 @@ def workload_rows(name, n, seed):
 
 def kernel_name_for(precision, features, units=1 << 16):
     """The BMU kernel som_create selects (csrc/somhip.hip)."""
+    if precision == "exact":                               # (input_len > 128: served by the float32 kernels)
+        return "bmu_f32_tiled_kernel" if features > 128 else "bmu_bf16_k16_kernel"
     if precision == "f32":
         return "bmu_f32_tiled_kernel" if features > 128 else "bmu_f32_res_kernel"
     if precision in ("bf16x3", "f16x3"):                    # ('f16' / 'f16x3': the bf16 kernels' _Float16 instances)
@@ -174,7 +181,8 @@ def main():
                     help="weak: --rows per GPU (default); strong: --total-rows split over the ranks")
     ap.add_argument("--rows", type=int, default=None, help="weak scaling: rows per GPU (default: the workload's)")
     ap.add_argument("--total-rows", type=int, default=STRONG_TOTAL_ROWS, help="strong scaling: rows of the whole job")
-    ap.add_argument("--precision", default=None, choices=["bf16", "f32", "bf16x3", "f16", "f16x3"])
+    ap.add_argument("--precision", default=None, choices=["exact", "bf16", "f32", "bf16x3", "f16", "f16x3"])
+    ap.add_argument("--no-modes", action="store_true", help="skip the per-precision-mode block at batch 65 536")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch65536", action="store_true")
     args = ap.parse_args()
@@ -215,6 +223,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    lo = hi = 0
     if args.scaling == "strong":
         lo, hi = D.shard_bounds(args.total_rows, rank, world)
         my_rows, total_rows = hi - lo, args.total_rows
@@ -222,50 +231,58 @@ def main():
         my_rows = args.rows if args.rows is not None else wl["rows"]
         total_rows = my_rows * world
 
-    eng = HipEngine(MAP_X, MAP_Y, FEATURES, precision=args.precision, device=dev, distance=wl["distance"],
-                    neighborhood=wl["neighborhood"])
     rs = np.random.RandomState(1234)                  # default codebook init, xpysom.py:189-190
     w = rs.rand(MAP_X, MAP_Y, FEATURES) * 2 - 1
     w /= np.linalg.norm(w, axis=-1, keepdims=True)
     if args.workload == "c5":
         w = np.abs(w)
     w = w.astype(np.float32)
-    eng.set_weights(w)
-    rows_host = workload_rows(args.workload, my_rows, 1234 + rank)
-    eng.set_data(rows_host)
+    # strong scaling: ONE data set, every rank holds its contiguous slice of it (an N = 1 and an N = 8 run train on
+    # the same rows, so their codebooks can be compared); weak scaling: each rank draws its own rows
+    rows_host = (workload_rows(args.workload, args.total_rows, 1234)[lo:hi] if args.scaling == "strong"
+                 else workload_rows(args.workload, my_rows, 1234 + rank))
 
     total = args.warmup + args.steps
     sched = [(exponential_decay(min(MAP_X, MAP_Y) / 2, 1, t, total), exponential_decay(0.5, 0.01, t, total))
              for t in range(total)]
 
-    def fence():
+    def fence(eng):
         eng.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for t in range(args.warmup):
-        D.epoch(eng, sched[t][0], sched[t][1], True)
-    fence()
-    # The timed region carries HIP events around the dominant (BMU) kernel only -- two event records per epoch.
-    # Event pairs around every kernel family put a ~10 us bubble on the stream at each of the four phase
-    # boundaries of an epoch (kernel trace): that breakdown is taken in a separate pass below.
-    eng.profile_reset()
-    eng.profile_enable("bmu")
-    t0 = time.perf_counter()
-    for t in range(args.warmup, total):
-        D.epoch(eng, sched[t][0], sched[t][1], True)
-    fence()
-    dt = time.perf_counter() - t0
-    eng.profile_enable(False)
+    def timed_run(precision):
+        """W warm-up epochs, then exactly K timed epochs between fences; max over ranks.  Returns the engine too."""
+        eng = HipEngine(MAP_X, MAP_Y, FEATURES, precision=precision, device=dev, distance=wl["distance"],
+                        neighborhood=wl["neighborhood"])
+        eng.set_weights(w)
+        eng.set_data(rows_host)
+        for t in range(args.warmup):
+            D.epoch(eng, sched[t][0], sched[t][1], True)
+        fence(eng)
+        # The timed region carries HIP events around the dominant (BMU) kernels only -- two event records per epoch
+        # (precision 'exact': two more per screen pass).  Event pairs around every kernel family put a ~10 us bubble
+        # on the stream at each of the four phase boundaries of an epoch (kernel trace, DESIGN.md 5): that breakdown
+        # is taken in a separate pass below.
+        eng.profile_reset()
+        eng.profile_enable("bmu")
+        t0 = time.perf_counter()
+        for t in range(args.warmup, total):
+            D.epoch(eng, sched[t][0], sched[t][1], True)
+        fence(eng)
+        dt = time.perf_counter() - t0
+        eng.profile_enable(False)
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return eng, dt
 
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
+    eng, dt = timed_run(args.precision)
     bmu_ms, bmu_n = eng.profile_get("bmu")
+    scr_ms, scr_n = eng.profile_get("screen")
     # per-kernel-family breakdown: the same epochs once more (the same schedule entries, at most 20), untimed, every
     # family under events
     nb = max(1, min(args.steps, 20))
@@ -273,29 +290,55 @@ def main():
     eng.profile_enable(True)
     for t in range(args.warmup, args.warmup + nb):
         D.epoch(eng, sched[t][0], sched[t][1], True)
-    fence()
+    fence(eng)
     eng.profile_enable(False)
     parts = {k: eng.profile_get(k)[0] / nb for k in ("prep", "bmu", "segsum", "kron", "merge")}
+    if args.precision == "exact":
+        parts["bmu_of_which_screen"] = eng.profile_get("screen")[0] / nb
     w_end = eng.get_weights()
     assert np.isfinite(w_end).all()
+    exact_stats = eng.exact_stats() if args.precision == "exact" else None
     # N > 1: every rank merged the same all-reduced sums, so the codebooks must be the same bits on every rank
     ranks_agree = None
+    import zlib
+    w_crc = zlib.crc32(np.ascontiguousarray(w_end).tobytes())
     if dist is not None:
-        import zlib
-        crc = float(zlib.crc32(np.ascontiguousarray(w_end).tobytes()))
-        lo = torch.tensor([crc], dtype=torch.float64, device="cuda")
-        hi = lo.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        ranks_agree = bool(lo.item() == hi.item())
+        lo_t = torch.tensor([float(w_crc)], dtype=torch.float64, device="cuda")
+        hi_t = lo_t.clone()
+        dist.all_reduce(lo_t, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_t, op=dist.ReduceOp.MAX)
+        ranks_agree = bool(lo_t.item() == hi_t.item())
+
+    # the throughput mode beside the parity-grade headline: the same K epochs through the plain bf16 kernel
+    thr = None
+    if args.precision == "exact" and FEATURES <= 128:
+        eng.close()
+        e_t, dt_t = timed_run("bf16")
+        t_ms, t_n = e_t.profile_get("bmu")
+        thr = {"precision": "bf16", "value": total_rows / (dt_t / args.steps), "unit": "samples/sec/epoch",
+               "ms_per_step": 1e3 * dt_t / args.steps, "kernel": kernel_name_for("bf16", FEATURES, MAP_X * MAP_Y),
+               "avg_launch_ms": t_ms / max(1, t_n),
+               "roofline_frac": 2.0 * (MAP_X * MAP_Y) * FEATURES * my_rows / (t_ms / max(1, t_n) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+               "note": "BMUs NOT those of float32 (see precision_modes_at_batch65536): the parity contract holds in the headline mode"}
+        e_t.close()
+        eng = HipEngine(MAP_X, MAP_Y, FEATURES, precision=args.precision, device=dev, distance=wl["distance"],
+                        neighborhood=wl["neighborhood"])
 
     kernel_name = kernel_name_for(args.precision, FEATURES, MAP_X * MAP_Y)
     peak = MFMA_F32_PEAK_TFLOPS if args.precision == "f32" else MFMA_BF16_PEAK_TFLOPS
     KD2 = 2.0 * (MAP_X * MAP_Y) * FEATURES            # 2*K*D flop per sample
 
-    # the north-star's launch: the same kernel over a batch of 65 536 resident rows, same process, same engine
+    def kernel_ms(e):
+        """(average launch, launches) of the MFMA distance kernel of the epochs just timed: the screen kernel of the
+        exact mode, the fused distance+BMU kernel otherwise."""
+        fam = "screen" if e.precision == "exact" and FEATURES <= 128 and wl["distance"] == "euclidean" else "bmu"
+        ms, n = e.profile_get(fam)
+        return ms / max(1, n), n
+
+    # the north-star's launch: the same kernel over a batch of 65 536 resident rows, same process
     batch = None
-    if rank == 0 and world == 1 and not args.no_batch65536 and my_rows >= NORTH_STAR_BATCH:
+    do_batch = rank == 0 and world == 1 and not args.no_batch65536 and my_rows >= NORTH_STAR_BATCH
+    if do_batch:
         eng.set_weights(w)
         eng.set_data(rows_host[:NORTH_STAR_BATCH])
         reps = 30
@@ -310,8 +353,7 @@ def main():
         eng.sync()
         tb = time.perf_counter() - tb
         eng.profile_enable(False)
-        b_ms, b_n = eng.profile_get("bmu")
-        b_avg = b_ms / max(1, b_n)
+        b_avg, b_n = kernel_ms(eng)
         b_ach = KD2 * NORTH_STAR_BATCH / (b_avg * 1e-3) / 1e12
         eng.profile_reset()
         eng.profile_enable(True)                               # breakdown pass (see above)
@@ -319,46 +361,114 @@ def main():
             D.epoch(eng, sched[t % total][0], sched[t % total][1], True)
         eng.sync()
         eng.profile_enable(False)
+        by_k = {k: eng.profile_get(k)[0] / 10 for k in ("prep", "bmu", "segsum", "kron", "merge")}
+        if args.precision == "exact":
+            by_k["bmu_of_which_screen"] = eng.profile_get("screen")[0] / 10
         batch = {"rows": NORTH_STAR_BATCH, "avg_launch_ms": b_avg, "launches": b_n, "achieved": b_ach,
-                 "frac": b_ach / peak, "epoch_ms": 1e3 * tb / reps,
-                 "ms_per_epoch_by_kernel": {k: eng.profile_get(k)[0] / 10 for k in ("prep", "bmu", "segsum", "kron", "merge")}}
+                 "frac": b_ach / peak, "epoch_ms": 1e3 * tb / reps, "ms_per_epoch_by_kernel": by_k}
 
-    # the other precision modes on the same batch, so that the parity mode has a number from this very run
-    modes = None
-    if batch is not None and args.precision == "bf16" and FEATURES <= 128:
+    # Every precision mode on the same batch: speed AND how far its BMUs / its trained codebook are from float32's --
+    # on the seeded codebook (the easiest state a SOM is ever in), on the smooth maps of the early schedule (where a
+    # screen is least sure) and at the end of the schedule.  The codebook states come from the float32 arithmetic
+    # (trained through 'exact', which is bit for bit the float32 training: checked below against 'f32' itself).
+    modes, update_forms = None, None
+    if do_batch and not args.no_modes and FEATURES <= 128 and wl["distance"] == "euclidean":
+        xb = rows_host[:NORTH_STAR_BATCH]
+        T = 10
+        sch = [(exponential_decay(min(MAP_X, MAP_Y) / 2, 1, t, T), exponential_decay(0.5, 0.01, t, T)) for t in range(T)]
+        mk = lambda prec: HipEngine(MAP_X, MAP_Y, FEATURES, precision=prec, device=dev, distance=wl["distance"],
+                                    neighborhood=wl["neighborhood"])
+        states = {}                                            # epochs done -> float32-trajectory codebook
+        tr_e = mk("exact")
+        tr_e.set_weights(w)
+        tr_e.set_data(xb)
+        for t in range(T):
+            if t in (0, 1, 5):
+                states[t] = tr_e.get_weights()
+            D.epoch(tr_e, sch[t][0], sch[t][1], True)
+        w_exact_end = tr_e.get_weights()
+        tr_e.close()
         modes = {}
-        ref_bmu = None
-        for prec, flop_peak in (("f32", MFMA_F32_PEAK_TFLOPS), ("bf16x3", MFMA_BF16_PEAK_TFLOPS), ("f16x3", MFMA_BF16_PEAK_TFLOPS),
-                                ("f16", MFMA_BF16_PEAK_TFLOPS), ("bf16", MFMA_BF16_PEAK_TFLOPS)):
-            e2 = HipEngine(MAP_X, MAP_Y, FEATURES, precision=prec, device=dev, distance=wl["distance"],
-                           neighborhood=wl["neighborhood"])
+        ref = {}
+        w_f32_end = None
+        for prec, flop_peak in (("f32", MFMA_F32_PEAK_TFLOPS), ("exact", MFMA_BF16_PEAK_TFLOPS), ("bf16x3", MFMA_BF16_PEAK_TFLOPS),
+                                ("f16x3", MFMA_BF16_PEAK_TFLOPS), ("f16", MFMA_BF16_PEAK_TFLOPS), ("bf16", MFMA_BF16_PEAK_TFLOPS)):
+            e2 = mk(prec)
+            e2.set_data(xb)
+            agree, ep_ms, k_ms = {}, {}, {}
+            for t, wt in states.items():
+                e2.set_weights(wt)
+                ids = e2.bmu(xb)
+                if prec == "f32":
+                    ref[t] = ids
+                agree["after_%d_epochs" % t] = float(np.mean(ids == ref[t]))
+                # this state's epoch, timed (the exact mode's re-score load depends on the map's smoothness)
+                e2.epoch_accumulate(sch[t][0], sch[t][1], True)
+                e2.sync()
+                e2.profile_reset()
+                e2.profile_enable("bmu")
+                e2.set_weights(wt)
+                t2 = time.perf_counter()
+                for _ in range(3):                             # (three epochs from this state at its sigma)
+                    D.epoch(e2, sch[t][0], sch[t][1], True)
+                e2.sync()
+                ep_ms["after_%d_epochs" % t] = 1e3 * (time.perf_counter() - t2) / 3
+                e2.profile_enable(False)
+                k_ms["after_%d_epochs" % t] = kernel_ms(e2)[0]
+            # the whole schedule from the seeded codebook in this mode: where does its codebook end up?
             e2.set_weights(w)
-            e2.set_data(rows_host[:NORTH_STAR_BATCH])
-            first_bmu = e2.bmu(rows_host[:NORTH_STAR_BATCH])   # on the seeded codebook, before any update
-            if ref_bmu is None:
-                ref_bmu = first_bmu
-            D.epoch(e2, sched[0][0], sched[0][1], True)
-            e2.sync()
-            e2.profile_reset()
-            e2.profile_enable("bmu")
-            t2 = time.perf_counter()
-            for t in range(3):
-                D.epoch(e2, sched[t % total][0], sched[t % total][1], True)
-            e2.sync()
-            t2 = (time.perf_counter() - t2) / 3
-            e2.profile_enable(False)
-            m_ms, m_n = e2.profile_get("bmu")
-            ach = KD2 * NORTH_STAR_BATCH / (m_ms / max(1, m_n) * 1e-3) / 1e12
-            modes[prec] = {"rows": NORTH_STAR_BATCH, "epoch_ms": 1e3 * t2, "bmu_launch_ms": m_ms / max(1, m_n),
+            for t in range(T):
+                D.epoch(e2, sch[t][0], sch[t][1], True)
+            w_end_m = e2.get_weights()
+            if prec == "f32":
+                w_f32_end = w_end_m
+                qe_f32 = e2.quantization_error(xb[:8192])
+            qe = e2.quantization_error(xb[:8192])
+            k0 = k_ms["after_0_epochs"]
+            ach = KD2 * NORTH_STAR_BATCH / (k0 * 1e-3) / 1e12
+            modes[prec] = {"rows": NORTH_STAR_BATCH, "epoch_ms": ep_ms, "distance_kernel_launch_ms": k_ms,
                            "achieved_tflops_algorithmic": ach, "frac_of_its_pipe_peak": ach / flop_peak,
-                           "bmus_equal_to_float32": float(np.mean(first_bmu == ref_bmu)),
+                           "bmus_equal_to_float32": agree,
+                           "trained_codebook_max_rel_dev_vs_float32": float(np.abs(w_end_m - w_f32_end).max() / np.abs(w_f32_end).max()),
+                           "trained_codebook_bitwise_equal_to_float32": bool(np.array_equal(w_end_m, w_f32_end)),
+                           "quantization_error_rel_dev_vs_float32": float(abs(qe - qe_f32) / qe_f32),
                            "kernel": kernel_name_for(prec, FEATURES, MAP_X * MAP_Y)}
+            if prec == "exact":
+                modes[prec]["fallback_rows"], modes[prec]["rows_screened"] = e2.exact_stats()[1], e2.exact_stats()[0]
             e2.close()
+        assert np.array_equal(w_exact_end, w_f32_end), "the exact mode's training left the float32 trajectory"
+
+        # both forms of the update on this batch: the bucketed one the product runs, and the reference's
+        # own K x N x D formulation g^T x as one float32 MFMA GEMM (som_epoch_accumulate_faithful)
+        e3 = mk("exact")
+        e3.set_weights(states[1])
+        e3.set_data(xb)
+        e3.epoch_accumulate_faithful(sch[1][0], sch[1][1], True)
+        e3.sync()
+        forms = {}
+        for name, fn in (("bucketed", e3.epoch_accumulate), ("faithful", e3.epoch_accumulate_faithful)):
+            e3.profile_reset()
+            e3.profile_enable(True)
+            for _ in range(3):
+                fn(sch[1][0], sch[1][1], True)
+            e3.sync()
+            e3.profile_enable(False)
+            forms[name] = (e3.profile_get("segsum")[0] + e3.profile_get("kron")[0]) / 3
+        fl = 2.0 * NORTH_STAR_BATCH * (MAP_X * MAP_Y) * (FEATURES + 1)
+        update_forms = {"rows": NORTH_STAR_BATCH, "bucketed_ms": forms["bucketed"], "faithful_ms": forms["faithful"],
+                        "faithful_tflops": fl / (forms["faithful"] * 1e-3) / 1e12,
+                        "faithful_frac": fl / (forms["faithful"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                        "note": "update only (segment sum + transform, or tables + g^T x GEMM), hipEvent-timed; float32 MFMA peak"}
+        e3.close()
 
     if rank == 0:
         ms_step = 1e3 * dt / args.steps
-        flops_launch = KD2 * my_rows
-        achieved = flops_launch / (bmu_ms / max(1, bmu_n) * 1e-3) / 1e12
+        is_exact = args.precision == "exact" and FEATURES <= 128 and wl["distance"] == "euclidean"
+        k_avg = (scr_ms / max(1, scr_n)) if is_exact else (bmu_ms / max(1, bmu_n))
+        k_n = scr_n if is_exact else bmu_n
+        rows_launch = my_rows * (bmu_n / max(1, k_n)) if is_exact else my_rows     # (the exact mode screens in passes)
+        flops_launch = KD2 * rows_launch
+        achieved = flops_launch / (k_avg * 1e-3) / 1e12
         # algorithmic flops against the peak of the pipe the kernel runs on; bf16x3 executes 3x them
         build_hash = B.built_hash()
         tr = pmc_traffic(args.workload, my_rows, args.precision, kernel_name, build_hash)
@@ -367,7 +477,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "codebooks_identical_on_all_ranks": ranks_agree,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": {"f32": "f32", "f16": "f16", "f16x3": "f16"}.get(args.precision, "bf16"), "data": "synthetic",
+            "dtype": {"f32": "f32", "f16": "f16", "f16x3": "f16", "exact": "f16"}.get(args.precision, "bf16"), "data": "synthetic",
             "config": {"workload": "batch-SOM epoch, %dx%d map, %d features, %d Gaussian-blob rows %s resident "
                                    "in HBM (%s), one launch over all resident rows"
                                    % (MAP_X, MAP_Y, FEATURES, my_rows if args.scaling == "weak" else total_rows,
@@ -375,25 +485,39 @@ def main():
                                       wl["label"] if args.scaling == "weak" else "BASELINE configs[3] rows, strong scaling"),
                        "map": [MAP_X, MAP_Y], "features": FEATURES, "rows_per_gpu": my_rows, "rows_total": total_rows,
                        "precision": args.precision, "distance": wl["distance"], "neighborhood": wl["neighborhood"],
+                       "parity": ("BMUs, accumulators and codebook bit for bit those of the float32 parity mode (IEEE-half "
+                                  "MFMA screen + float32 re-score of the candidate units, csrc/bmu_exact.hpp)" if is_exact else
+                                  "float32 parity mode itself" if args.precision in ("f32", "exact") else
+                                  "throughput mode: BMUs within the operand rounding of float32's, not equal to them"),
                        "update": "bucketed (segment sum by BMU + separable neighbourhood transform; exact algebra of "
-                                 "the reference's g^T.x GEMM, xpysom.py:434-438; the faithful K x N x D GEMM form is "
-                                 "som_epoch_accumulate_faithful: 274 ms per Mi rows at this shape, tools/bench_faithful.py)",
+                                 "the reference's g^T.x GEMM, xpysom.py:434-438; both forms timed: update_forms)",
                        "parallelism": "dp%d (sample shards, 1 all-reduce/epoch)" % world,
-                       "epochs_per_sec": args.steps / dt, "build": build_hash},
-            "roofline": {"bound": "mfma", "kernel": kernel_name + " (fused distance GEMM + argmin)",
+                       "epochs_per_sec": args.steps / dt, "build": build_hash,
+                       "codebook_crc32_after_run": w_crc},
+            "roofline": {"bound": "mfma", "kernel": kernel_name + (" (IEEE-half distance GEMM of the exact mode's screen, fused "
+                                                                   "argmin + per-group minima)" if is_exact else " (fused distance GEMM + argmin)"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": tr["bytes"] if tr else None,
                          "traffic_source": ({"file": "profiles/" + tr["file"], "build": tr["build"],
                                              "same_build": tr["build"] == build_hash} if tr else None),
-                         "avg_launch_ms": bmu_ms / max(1, bmu_n), "launches": bmu_n,
-                         "flops_per_launch": flops_launch},
+                         "avg_launch_ms": k_avg, "launches": k_n, "rows_per_launch": rows_launch,
+                         "flops_per_launch": flops_launch,
+                         "whole_bmu_search_ms_per_step": bmu_ms / max(1, bmu_n)},
             "ms_per_step_by_kernel": parts,
             "ms_per_step_by_kernel_pass": "separate untimed pass of %d epochs after the timed region (events around every kernel family)" % nb,
         }
+        if exact_stats is not None:
+            out["parity_mode"] = {"precision": "exact", "is_headline": True, "value": out["value"], "unit": out["unit"],
+                                  "roofline_frac": achieved / peak, "rows_screened": exact_stats[0],
+                                  "rows_through_float32_fallback_kernel": exact_stats[1], "screen_passes": exact_stats[2]}
+        if thr is not None:
+            out["throughput_mode"] = thr
         if batch is not None:
             out["roofline"]["batch65536"] = batch
         if modes is not None:
-            out["precision_modes_at_batch65536"] = modes   # 'f32' = the parity mode (bit-exact float32 chain), '*x3' = hi/lo split, 'f16*' = IEEE half operands
+            out["precision_modes_at_batch65536"] = modes   # 'f32' = the parity mode itself, 'exact' = its BMUs at MFMA-half speed, '*x3' = hi/lo split, 'f16*' = IEEE half operands
+        if update_forms is not None:
+            out["update_forms"] = update_forms
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)

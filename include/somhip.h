@@ -71,7 +71,9 @@ enum { SOM_BMU_ACTIVATION = 0,   /* configured activation distance: XPySom._winn
        SOM_BMU_QUANTIZATION = 1  /* full sqrt'd Euclidean + nan_to_num: _quantization, xpysom.py:640,670 */ };
 
 /* timed kernels for som_profile_get */
-enum { SOM_K_BMU = 0, SOM_K_SEGSUM = 1, SOM_K_KRON = 2, SOM_K_MERGE = 3, SOM_K_PREP = 4, SOM_K_COUNT = 5 };
+enum { SOM_K_BMU = 0, SOM_K_SEGSUM = 1, SOM_K_KRON = 2, SOM_K_MERGE = 3, SOM_K_PREP = 4,
+       SOM_K_SCREEN = 5,   /* precision EXACT: the MFMA screen kernel alone (a part of SOM_K_BMU's time) */
+       SOM_K_COUNT = 6 };
 
 typedef struct som_config {
     int32_t x, y, input_len;     /* map rows, cols, features: XPySom.__init__, xpysom.py:73 */

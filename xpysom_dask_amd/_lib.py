@@ -13,7 +13,7 @@ SOM_NEIGH = {"gaussian": 0, "mexican_hat": 1, "bubble": 2, "triangle": 3}
 SOM_PREC = {"f32": 0, "bf16": 1, "bf16x3": 2, "f16": 3, "f16x3": 4, "exact": 5}
 SOM_TOPO = {"rectangular": 0, "hexagonal": 1}
 SOM_BMU_ACTIVATION, SOM_BMU_QUANTIZATION = 0, 1
-SOM_KERNELS = {"bmu": 0, "segsum": 1, "kron": 2, "merge": 3, "prep": 4}
+SOM_KERNELS = {"bmu": 0, "segsum": 1, "kron": 2, "merge": 3, "prep": 4, "screen": 5}
 
 
 class SomConfig(C.Structure):

@@ -272,7 +272,7 @@ constexpr long ROW_PAD = 3072;   // bf16 row images are padded to a multiple of 
 // ---- profiling: event pairs recorded around kernel families, resolved lazily ---------------
 struct Timed {
     som_handle* h; int kernel; EventPair ep{}; bool on;
-    Timed(som_handle* h_, int k) : h(h_), kernel(k), on(h_->prof == 1 || (h_->prof == 2 && k == SOM_K_BMU)) {
+    Timed(som_handle* h_, int k) : h(h_), kernel(k), on(h_->prof == 1 || (h_->prof == 2 && (k == SOM_K_BMU || k == SOM_K_SCREEN))) {
         if (!on) return;
         if (!h->pool.empty()) { ep = h->pool.back(); h->pool.pop_back(); }
         else { (void)hipEventCreate(&ep.a); (void)hipEventCreate(&ep.b); }
@@ -959,7 +959,10 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     for (long r0 = 0; r0 < N; r0 += chunk) {
         const long n = std::min(chunk, N - r0);
         HIPCHK(h, hipMemsetAsync(ex.ctr, 0, (size_t)(2 * n_groups + 3) * sizeof(int), h->stream));
-        if (int rc = SOM_HALF(h, exact_screen_ks, h, Xb + r0 * h->dp, n, h->best64 + r0)) return rc;
+        {
+            Timed ts(h, SOM_K_SCREEN);
+            if (int rc = SOM_HALF(h, exact_screen_ks, h, Xb + r0 * h->dp, n, h->best64 + r0)) return rc;
+        }
         exact_scan_kernel<<<dim3((unsigned)cdiv(n, 64)), dim3(64 * EX_SCAN_SPLIT), 0, h->stream>>>(
             ex.gmin, ex.stride, n_groups, n, h->best64 + r0, xsq + r0, h->wmax2, xmax2, eb, xerr ? xerr + r0 : nullptr, h->wmax2 + 1,
             ex.bm, ex.ctr);
