@@ -149,10 +149,10 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_scan_kernel(const ui
     }
 }
 
-// gcount -> goff (exclusive prefix), the tile table (group, first entry of the group's list) and n_tiles; more pairs
-// than `capacity` -> overflow flag, no tiles.  One block.
+// gcount -> goff (exclusive prefix), the tile table (group, first list entry of the tile in plist, its rows) and n_tiles;
+// more pairs than `capacity` -> overflow flag, no tiles.  One block.
 __global__ __launch_bounds__(1024) void exact_offsets_kernel(const int* __restrict__ gcount, int n_groups, long capacity,
-                                                             int* __restrict__ goff, int2* __restrict__ tile_tab,
+                                                             int* __restrict__ goff, int4* __restrict__ tile_tab,
                                                              int* __restrict__ n_tiles_out, int* __restrict__ overflow) {
     __shared__ long sums[1024];
     __shared__ int tsums[1024];
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(1024) void exact_offsets_kernel(const int* __restri
     for (int g = b; g < e; ++g) {
         const int c = gcount[g];
         goff[g] = off;
-        for (int i = 0; i * EX_TR < c; ++i) tile_tab[toff++] = make_int2(g, i * EX_TR);
+        for (int i = 0; i * EX_TR < c; ++i) tile_tab[toff++] = make_int4(g, off + i * EX_TR, min(EX_TR, c - i * EX_TR), 0);
         off += c;
     }
     if (tid == 1023) *n_tiles_out = tsums[1023];
@@ -219,36 +219,44 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_fill_kernel(const ui
 // The float32 scores of one tile -- up to EX_TR rows of a group's list against the group's 64 units -- on
 // v_mfma_f32_32x32x2_f32, exactly as bmu_f32_res_kernel<SCORE_EUCLID_PART> forms them (same stage image, same k order,
 // same epilogue, same first-minimum rule); a row's best (value, unit) over its groups merges through the same
-// order-preserving 64-bit atomicMin the parity kernel's codebook parts use.  Persistent: a workgroup walks the tile
-// table from blockIdx.x in steps of gridDim.x, the next tile's stage in flight (LDS-DMA) under this tile's MFMAs.
+// order-preserving 64-bit atomicMin the parity kernel's codebook parts use.  Persistent: a workgroup takes a contiguous
+// run of the tile table -- consecutive tiles mostly belong to one group, whose stage is fetched once and stays in LDS
+// -- and between two stage changes its four waves run free of each other (no barrier per tile).
 template <int KG>
-__global__ __launch_bounds__(256, 2) void exact_rescore_mfma_kernel(const float* __restrict__ X, int D,
+__global__ __launch_bounds__(256, 3) void exact_rescore_mfma_kernel(const float* __restrict__ X, int D,
                                                                     const char* __restrict__ Wfst, int K,
-                                                                    const int2* __restrict__ tile_tab,
+                                                                    const int4* __restrict__ tile_tab,
                                                                     const int* __restrict__ n_tiles_dev,
-                                                                    const int* __restrict__ gcount,
-                                                                    const int* __restrict__ goff,
                                                                     const int* __restrict__ plist,
                                                                     unsigned long long* __restrict__ best64) {
     constexpr int STAGE = fr_stage_bytes(KG);
     constexpr int PIECES = FR_UT * KG + 1;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE stage: occupancy (three workgroups per CU), not a
+                                                                  // ring, hides a tile's load latency under other tiles' MFMAs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col = lane & 31;
     const int n_tiles = *n_tiles_dev;
-    int slot = 0;
-    if ((int)blockIdx.x < n_tiles) {
-        const int g = tile_tab[blockIdx.x].x;
-        for (int p = wave; p < PIECES; p += 4) lds_dma_16(Wfst + (long)g * STAGE + (long)p * 1024 + lane * 16, smem + p * 1024);
-    }
-    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x, slot ^= 1) {
-        const int2 tt = tile_tab[t];
-        const int g = tt.x;
-        const int first = tt.y + wave * 32;               // this wave's first entry of the group's list
-        const int cnt = gcount[g];
-        const bool wave_live = first < cnt;                // (wave-uniform)
-        const int row = first + col < cnt ? plist[goff[g] + first + col] : -1;
+    int g_have = -1;                                       // group whose stage the LDS holds
+    // a workgroup takes a contiguous run of tiles: consecutive tiles mostly belong to ONE group, whose stage stays put
+    const int per = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t_begin = blockIdx.x * per, t_end = min(t_begin + per, n_tiles);
+    // this lane's list entry (a row id, or -1) of tile t; read one tile ahead of its use
+    auto entry = [&](int t) -> int {
+        if (t >= t_end) return -1;
+        const int4 tt = tile_tab[t];
+        const int i = wave * 32 + col;
+        return i < tt.z ? plist[tt.y + i] : -1;
+    };
+    int row_next = entry(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        const int g = tile_tab[t].x;
+        const int row = row_next;
+        const bool wave_live = __ballot(row >= 0) != 0;    // (wave-uniform)
+        if (g != g_have) {                                 // (uniform over the workgroup)
+            __builtin_amdgcn_s_barrier();                  // everyone is done with the previous group's stage
+            for (int p = wave; p < PIECES; p += 4) lds_dma_16(Wfst + (long)g * STAGE + (long)p * 1024 + lane * 16, smem + p * 1024);
+        }
         float xf[4 * KG];
         if ((D & 3) == 0) {
 #pragma unroll
@@ -265,16 +273,15 @@ __global__ __launch_bounds__(256, 2) void exact_rescore_mfma_kernel(const float*
                 xf[s] = (row >= 0 && k < D) ? X[(long)row * D + k] : 0.0f;
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's stage (issued one tile ago) and the rows
-        __builtin_amdgcn_s_barrier();                      // ... of every wave; everyone is done with the other slot
-        asm volatile("" ::: "memory");
-        if (t + (int)gridDim.x < n_tiles) {
-            const int g2 = tile_tab[t + gridDim.x].x;
-            char* dst = smem + (slot ^ 1) * STAGE;
-            for (int p = wave; p < PIECES; p += 4) lds_dma_16(Wfst + (long)g2 * STAGE + (long)p * 1024 + lane * 16, dst + p * 1024);
+        row_next = entry(t + 1);                           // (in flight under this tile's MFMAs)
+        if (g != g_have) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the stage
+            __builtin_amdgcn_s_barrier();                      // ... and everybody else's
+            asm volatile("" ::: "memory");
+            g_have = g;
         }
         if (!wave_live) continue;
-        const char* st = smem + slot * STAGE;
+        const char* st = smem;
         const float* wq = (const float*)(st + FR_UT * KG * 1024);
         float best = __builtin_inff();
         int bkey = 0;

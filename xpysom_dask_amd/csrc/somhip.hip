@@ -75,7 +75,7 @@ struct som_handle {
         int *fb_list = nullptr, *fb_ids = nullptr;
         int* ctr = nullptr;                  // gcount | gfill | fb_count | n_tiles (zeroed per pass), then goff
         int* plist = nullptr;                // rows bucketed by candidate group
-        int2* tile_tab = nullptr;            // re-score tiles: (group, first list entry)
+        int4* tile_tab = nullptr;            // re-score tiles: (group, first list entry, rows)
         long max_tiles = 0;
         float* fbX = nullptr;                // fallback rows, dense, for the float32 kernel
         long fb_cap = 0;
@@ -898,12 +898,13 @@ template <int KG>
 int exact_rescore_kg(som_handle* h, const float* X, int n_groups) {
     auto& ex = h->ex;
     auto kern = exact_rescore_mfma_kernel<KG>;
-    const size_t lds = 2 * (size_t)fr_stage_bytes(KG);
+    const size_t lds = (size_t)fr_stage_bytes(KG);
     int per_cu = 1;
     if (int rc = kernel_per_cu(h, (const void*)kern, 256, lds, &per_cu)) return rc;
-    const long grid = std::min<long>(ex.max_tiles, (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256));
-    kern<<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, h->D, h->Wfst, h->K, ex.tile_tab, ex.ctr + 2 * n_groups + 1, ex.ctr,
-                                                             ex.ctr + 2 * n_groups + 3, ex.plist, h->best64);
+    // (twice the resident slots: the runs of tiles are uneven -- partial tiles, idle waves -- and finer runs balance them)
+    const long grid = std::min<long>(ex.max_tiles, 2L * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
+    kern<<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, h->D, h->Wfst, h->K, ex.tile_tab, ex.ctr + 2 * n_groups + 1, ex.plist,
+                                                             h->best64);
     return 0;
 }
 
