@@ -1,0 +1,67 @@
+"""precision='exact' against precision='f32' on random configurations: IDENTICAL ids, row for row, from the epoch path and
+from the query path -- never "near".  Maps 1..100 a side, 1..128 features (and past 128, where 'exact' is served by the
+float32 kernels), 1..5000 rows, magnitudes 1e-3..1e3, zero rows, duplicated units, and the three codebook shapes that
+decide how hard the screen's job is: random units (one candidate group per row), a smooth sheet (hundreds of
+near-ties per row: the early-schedule state) and clusters of units a few float32 ulps apart (every row re-scored)."""
+import os, sys, time, numpy as np
+sys.path.insert(0, '.')
+from oracle import som_oracle as O
+from xpysom_dask_amd.engine import HipEngine
+
+F32 = np.float32
+rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+bad = 0
+fb_total = rows_total = 0
+t0 = time.time()
+for case in range(n_cases):
+    side = int(os.environ.get("FUZZ_MAXSIDE", "100"))
+    X, Y = int(rs.randint(1, side + 1)), int(rs.randint(1, side + 1))
+    D = int(rs.choice([1, 2, 3, 7, 16, 31, 32, 33, 64, 96, 100, 127, 128, 128, 128, 130, 200]))
+    n = int(rs.choice([1, 2, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 3000, 5000]))
+    kind = str(rs.choice(["random", "random", "sheet", "sheet", "clusters"]))
+    data = O.gaussian_blobs(n, D, seed=case)
+    if kind == "random":
+        w = O.default_codebook(X, Y, D, case + 1).astype(F32) * 3
+    elif kind == "sheet":                                    # a smooth, nearly flat sheet through the data: many near-ties
+        a, b, c = rs.randn(D), rs.randn(D), rs.randn(D)
+        ii, jj = np.meshgrid(np.arange(X) / max(X, 1), np.arange(Y) / max(Y, 1), indexing="ij")
+        amp = float(rs.choice([1e-3, 1e-2, 0.3]))
+        w = (data.mean(0) + amp * (ii[..., None] * b + jj[..., None] * c) + 1e-6 * rs.randn(X, Y, D) + 0 * a).astype(F32)
+    else:                                                    # units a few ulps apart
+        base = data[rs.randint(0, n)]
+        w = np.repeat(base[None, None, :], X, 0).repeat(Y, 1).astype(F32)
+        w = (w * (1.0 + rs.randint(-6, 7, size=(X, Y, 1)) * 2.0 ** -22)).astype(F32)
+    sx, sw = F32(rs.choice([1e-3, 1.0, 1.0, 1e3])), F32(rs.choice([1e-2, 1.0, 1.0, 1e2]))
+    data, w = data * sx, w * sw
+    if n > 4 and rs.rand() < 0.3:
+        data[rs.randint(0, n, size=max(1, n // 50))] = 0
+    if X * Y > 3 and rs.rand() < 0.3:
+        wf0 = w.reshape(-1, D)
+        wf0[rs.randint(0, X * Y)] = wf0[rs.randint(0, X * Y)]
+    if rs.rand() < 0.1 and n > 2:
+        data[rs.randint(0, n)] = np.nan
+    sig = float(rs.choice([max(min(X, Y) / 2, 1.0), 1.0, 2.5]))
+    try:
+        out = {}
+        for p in ("f32", "exact"):
+            e = HipEngine(X, Y, D, precision=p)
+            e.set_weights(w); e.set_data(data)
+            e.epoch_accumulate(sig, 0.5, True)
+            num, den, bmu = e.epoch_fetch()
+            q = e.bmu(data[: min(n, 700)])
+            out[p] = (bmu, q, num, den)
+            if p == "exact":
+                r, fb, _ = e.exact_stats()
+                rows_total += r; fb_total += fb
+            e.close()
+        a, b = out["f32"], out["exact"]
+        ok = np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True) \
+            and np.array_equal(a[3], b[3], equal_nan=True)
+        detail = "%d epoch rows, %d query rows differ" % ((a[0] != b[0]).sum(), (a[1] != b[1]).sum())
+    except Exception as ex:                      # noqa: BLE001
+        ok, detail = False, "EXC " + repr(ex)[:200]
+    if not ok:
+        bad += 1
+        print(f"FAIL case {case}: {X}x{Y}x{D} n={n} {kind} scale {sx}/{sw}: {detail}", flush=True)
+print(f"{n_cases} cases, {bad} failures, {time.time()-t0:.1f} s; float32 fallback kernel: {fb_total} of {rows_total} rows")

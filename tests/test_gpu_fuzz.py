@@ -11,7 +11,8 @@ from tests.conftest import REPO
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("script,cases", [("fuzz_shapes.py", 250), ("fuzz_paths.py", 150), ("fuzz_train.py", 150), ("fuzz_infer.py", 150)])
+@pytest.mark.parametrize("script,cases", [("fuzz_shapes.py", 250), ("fuzz_paths.py", 150), ("fuzz_train.py", 150), ("fuzz_infer.py", 150),
+                                          ("fuzz_exact.py", 300)])
 def test_fuzz(script, cases):
     r = subprocess.run([sys.executable, os.path.join("tests", "fuzz", script), "12345", str(cases)], cwd=REPO,
                        capture_output=True, text=True, timeout=600)

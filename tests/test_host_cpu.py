@@ -212,3 +212,38 @@ def test_mexican_hat_with_a_python_float_sigma_of_zero_raises_as_the_reference_d
     som._check_sigma(0.5)
     XPySom(4, 4, 2, neighborhood_function="gaussian")._check_sigma(0.0)      # gaussian: 0/0 -> NaN, no exception
 
+
+
+def test_comm_load_of_a_missing_library_fails_with_a_message():
+    """som_comm_load(path) means that library and no other: a path that does not exist returns non-zero and leaves a
+    'librccl not found' message (round 2 read dlerror() twice there: a NULL string concatenation)."""
+    from xpysom_dask_amd import _lib
+    lib = _lib.load()
+    rc = lib.som_comm_load(b"/nonexistent/dir/librccl-not-here.so")
+    msg = lib.som_last_error(None).decode()
+    if rc == 0:
+        pytest.skip("a RCCL library was already bound in this process")
+    assert rc != 0 and "librccl not found" in msg and "nonexistent" in msg
+
+
+def test_train_keeps_the_completed_epochs_when_an_epoch_raises(oracle_engine):
+    """mexican_hat + a linear schedule ending at sigmaN=0: the last epoch raises ZeroDivisionError (as the reference's
+    does); the object must then hold the codebook of the epochs that completed, not its pre-train codebook."""
+    from xpysom_dask_amd import XPySom
+    data = O.gaussian_blobs(200, 3, seed=1)
+    som = XPySom(5, 5, 3, neighborhood_function="mexican_hat", decay_function="linear", sigma=2.0, sigmaN=0, random_seed=1)
+    w0 = som._weights.copy()
+    with pytest.raises(ZeroDivisionError):
+        som.train(data, 4)
+    ref = XPySom(5, 5, 3, neighborhood_function="mexican_hat", decay_function="linear", sigma=2.0, sigmaN=0, random_seed=1)
+    ref.train(data, 4, iter_beg=0, iter_end=3)          # the three epochs that run before sigma reaches 0
+    assert not np.array_equal(som._weights, w0.astype(np.float32))
+    np.testing.assert_array_equal(som._weights, ref._weights)
+
+
+def test_precision_exact_is_accepted_with_every_distance():
+    from xpysom_dask_amd import XPySom
+    for dist in ("euclidean", "cosine", "manhattan", "norm_p"):
+        XPySom(4, 4, 3, activation_distance=dist, precision="exact")
+    with pytest.raises(ValueError):
+        XPySom(4, 4, 3, activation_distance="manhattan", precision="bf16")
