@@ -36,9 +36,12 @@ n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 bad = 0
 worst = 0.0
 for case in range(n_cases):
-    X, Y = int(rs.randint(2, 13)), int(rs.randint(2, 13))
-    D = int(rs.choice([1, 2, 3, 5, 8, 17]))
-    n = int(rs.choice([1, 7, 40, 150, 400]))
+    # DIFF_BIG=1: maps up to 48 x 48, up to 300 features, up to 3000 rows -- where OpenBLAS threads the GEMMs and (past
+    # 448 features only) splits K; the default stays small and fast (thousands of cases per minute)
+    big = bool(os.environ.get("DIFF_BIG"))
+    X, Y = int(rs.randint(2, 49 if big else 13)), int(rs.randint(2, 49 if big else 13))
+    D = int(rs.choice([1, 2, 3, 5, 8, 17] + ([32, 64, 100, 128, 200, 300] if big else [])))
+    n = int(rs.choice([1, 7, 40, 150, 400] + ([1000, 3000] if big else [])))
     decay = str(rs.choice(["linear", "exponential", "asymptotic"]))
     neigh = str(rs.choice(["gaussian", "mexican_hat", "bubble", "triangle"]))
     topo = "rectangular" if neigh == "triangle" else str(rs.choice(["rectangular", "hexagonal"]))
@@ -88,16 +91,19 @@ for case in range(n_cases):
         q = data[: min(n, 50)]
         rw = ref.winner(q) if len(q) > 0 else []
         if dist in ("manhattan", "norm_p"):
-            ow = O.bmu_ids_pairwise(np.asarray(q), want.reshape(-1, D), dist, p_norm) if len(q) else []
+            # (mini-batches of n_parallel rows as the reference's winner() forms them: norm_p with an even p is a sum of
+            #  GEMMs, and a GEMM's float32 rounding depends on its shape)
+            ow = np.concatenate([O.bmu_ids_pairwise(np.asarray(q)[s:s + npar], want.reshape(-1, D), dist, p_norm)
+                                 for s in range(0, len(q), npar)]) if len(q) else []
         else:
             ow = O.winner_ids(q, want, dist, n_parallel=npar)    # (the same chunks: a GEMM's rounding depends on its shape)
         if [tuple(map(int, t)) for t in rw] != [(int(k) // Y, int(k) % Y) for k in ow]:
             msgs.append("winner")
-        rq, oq = ref.quantization_error(q), O.quantization_error(q, want)
+        rq, oq = ref.quantization_error(q), O.quantization_error(q, want, n_parallel=npar)
         if abs(rq - oq) > 1e-6 * max(abs(rq), 1e-30):
             msgs.append("QE %.8g vs %.8g" % (rq, oq))
         if X * Y > 1 and (topo == "rectangular" or X == Y):
-            rt, ot = ref.topographic_error(q), O.topographic_error(q, want, topo)
+            rt, ot = ref.topographic_error(q), O.topographic_error(q, want, topo, n_parallel=npar)
             if abs(rt - ot) > 1e-12:
                 msgs.append("TE %.6f vs %.6f" % (rt, ot))
     except Exception as ex:                               # noqa: BLE001

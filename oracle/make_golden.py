@@ -17,6 +17,7 @@ import io
 import itertools
 import os
 import sys
+import zlib
 
 import numpy as np
 
@@ -518,7 +519,73 @@ def g16():
     save("g16_hex_compact_lattice_sigma", **out)
 
 
-FAMILIES = {"g1": g1, "g2": g2, "g3": g3, "g4": g4_g5_g7, "g6": g6, "g8": g8, "g9": g9, "g10": g10, "g11": g11,
+# ---------------------------------------------------------------- G17 configs[4] semantics at a wide-kernel shape
+def g17():
+    """BASELINE configs[4] (cosine + mexican_hat, 784 features, non-negative unit rows) on a 64 x 64 map: the shape class
+    of the wide / tiled kernels (input_len > 128).  Inputs are seeds; outputs as G12 stores them (all BMUs, the whole
+    denominator, every 32nd unit's numerator and merged row).  Note for the reader of the tests: with 784 features the
+    reference's sgemm (OpenBLAS 0.3.29 of the numpy 2.2.6 wheel, this host) no longer runs ONE k-ordered fma chain per
+    output -- it splits K into blocks (<= 448 stay one chain; measured here) -- so a near-tie may fall the other way."""
+    X, Y, D, n, T = 64, 64, 784, 2048, 10
+    data = np.abs(gaussian_blobs(n, D, seed=417))
+    data /= np.linalg.norm(data, axis=1, keepdims=True)
+    data = data.astype(F32)
+    out = {"shape": np.array([X, Y, D, n]), "data_seed": np.array(417), "T": np.array(T), "stride": np.array(32)}
+    for decay in ("linear", "exponential"):
+        som = RefSom(X, Y, D, random_seed=1234, decay_function=decay, n_parallel=n,
+                     neighborhood_function="mexican_hat", activation_distance="cosine", xp=np)
+        w0 = np.abs(som._weights).astype(F32)
+        eta = som._decay_function(som._learning_rate, som._learning_rateN, 0, T)
+        sig = som._decay_function(som._sigma, som._sigmaN, 0, T)
+        som._sq_weights_gpu = np.power(w0.reshape(-1, D), 2).sum(axis=1, keepdims=True)
+        wins = som._winner(data, w0)
+        num, den = som._update(data, w0, eta, sig)
+        som._sq_weights_gpu = None
+        e = RefSom(X, Y, D, random_seed=1234, decay_function=decay, n_parallel=n,
+                   neighborhood_function="mexican_hat", activation_distance="cosine", xp=np)
+        e._weights = w0.copy()
+        with np.errstate(all="ignore"):
+            e.train(data, T, iter_beg=0, iter_end=1)
+        out[f"{decay}_bmu"] = (wins[0] * Y + wins[1]).astype(np.int32)
+        out[f"{decay}_den"] = den.astype(F32)
+        out[f"{decay}_num32"] = num.astype(F32).reshape(X * Y, D)[::32]
+        out[f"{decay}_wout32"] = e._weights.astype(F32).reshape(X * Y, D)[::32]
+        out[f"{decay}_eta"] = np.float64(eta)
+        out[f"{decay}_sig"] = np.float64(sig)
+    # the euclidean BMUs of the same rows on the same codebook (the float32 tiled kernel's other epilogue)
+    som = RefSom(X, Y, D, random_seed=1234, n_parallel=n, xp=np)
+    w0 = np.abs(som._weights).astype(F32)
+    wins = som._winner(data, w0)
+    out["euclidean_bmu"] = (wins[0] * Y + wins[1]).astype(np.int32)
+    save("g17_configs4_64x64x784", **out)
+
+
+# ---------------------------------------------------------------- G18 BMUs at the configs[2] shape
+def g18():
+    """256 x 256 x 128, 4 096 rows: the reference's `_winner` on the seeded default codebook and on a smooth sheet (the
+    early-schedule state: hundreds of near-best units per row).  Both codebooks are functions of seeds that every host
+    evaluates bit for bit (oracle.som_oracle.default_codebook / smooth_sheet_codebook), so the fixture holds ids only;
+    a codebook the reference itself trained at this shape is 33 MB and is not stored."""
+    from oracle.som_oracle import smooth_sheet_codebook
+    X, Y, D, n = 256, 256, 128, 4096
+    data = gaussian_blobs(n, D, seed=1234)
+    out = {"shape": np.array([X, Y, D, n]), "data_seed": np.array(1234), "codebook_seed": np.array(1234),
+           "sheet_seed": np.array(77), "sheet_amplitude": np.float64(0.5)}
+    som = RefSom(X, Y, D, random_seed=1234, n_parallel=1024, xp=np)
+    w_seeded = som._weights.astype(F32)
+    w_sheet = smooth_sheet_codebook(X, Y, D, 77, amplitude=0.5, centre=data.astype(np.float64).mean(0))
+    for tag, w in (("seeded", w_seeded), ("sheet", w_sheet)):
+        bmu = np.empty(n, dtype=np.int32)
+        for s in range(0, n, 1024):                       # (n, K) float32 temporaries of 268 MB per chunk
+            som._sq_weights_gpu = None
+            wins = som._winner(data[s:s + 1024], w)
+            bmu[s:s + 1024] = wins[0] * Y + wins[1]
+        out[tag + "_bmu"] = bmu
+        out[tag + "_w_crc"] = np.array(zlib.crc32(np.ascontiguousarray(w).tobytes()), dtype=np.int64)
+    save("g18_bmus_256x256x128", **out)
+
+
+FAMILIES = {"g17": g17, "g18": g18, "g1": g1, "g2": g2, "g3": g3, "g4": g4_g5_g7, "g6": g6, "g8": g8, "g9": g9, "g10": g10, "g11": g11,
             "g12": g12, "g13": g13, "g14": g14, "g15": g15, "g16": g16}
 
 if __name__ == "__main__":

@@ -383,19 +383,25 @@ def quantization_error(data, W3, n_parallel=4000):
     return np.linalg.norm(x, axis=1).mean().item()
 
 
-def top2_ids(x32, W3):
-    """Best and second-best unit under the full Euclidean distance (xpysom.py:727-734)."""
-    d = dist_euclid(np.asarray(x32, dtype=F32), W3.reshape(-1, W3.shape[2]))
+def top2_ids(x32, W3, n_parallel=4000):
+    """Best and second-best unit under the full Euclidean distance (xpysom.py:727-734).  The distances come in
+    mini-batches of `n_parallel` rows as the reference forms them (_distance_from_weights, xpysom.py:660-671): a
+    GEMM's float32 summation order depends on its shape once K is in the hundreds (oracle/diff_reference.py with
+    DIFF_BIG=1 found a 200-feature case where one chunk of 150 rows and chunks of 7 rows order a near-tie differently)."""
+    x32 = np.asarray(x32, dtype=F32)
+    w = W3.reshape(-1, W3.shape[2])
+    d = np.vstack([dist_euclid(x32[s:s + n_parallel], w) for s in range(0, len(x32), n_parallel)]) if len(x32) else \
+        np.zeros((0, len(w)), F32)
     return np.argsort(d, axis=1)[:, :2]
 
 
-def topographic_error(data, W3, topology="rectangular"):
+def topographic_error(data, W3, topology="rectangular", n_parallel=4000):
     """xpysom.py:709-746: share of samples whose two best units are not adjacent -- rectangular: |di| > 1 or
     |dj| > 1; hexagonal (:739-746): farther apart than 1.5 in the coordinates ``_xx[i, j], _yy[i, j]``.  The
     reference indexes its UNtransposed (Y, X) meshgrids with the map index (i, j), i.e. it reads
     ``x = j - s(i)/2, y = i`` (s: the shifted rows of xpysom.py:201-206); only square maps are well defined."""
     X, Y = W3.shape[:2]
-    b = top2_ids(np.array(data, dtype=F32), np.asarray(W3))
+    b = top2_ids(np.array(data, dtype=F32), np.asarray(W3), n_parallel)
     i, j = b // Y, b % Y
     if topology == "hexagonal":
         xx, yy = hex_coords(X, Y)
@@ -414,3 +420,32 @@ def gaussian_blobs(N, D, seed=1234, centres=64, spread=3.0):
     lab = rng.integers(0, centres, size=N)
     x = c[lab] + rng.normal(0.0, 1.0, size=(N, D))
     return x.astype(F32)
+
+
+def smooth_sheet_codebook(X, Y, D, seed, anchors=9, amplitude=0.5, centre=None):
+    """A smooth codebook that any host reproduces BIT FOR BIT from its arguments: bilinear interpolation between a coarse
+    grid of seeded anchor vectors, evaluated with elementwise float64 products and sums only (no BLAS, no fused
+    operations), then rounded to float32.  Neighbouring units differ by ~amplitude/side -- the state a SOM is in
+    early in its schedule, where every row has hundreds of near-best units -- without a 33 MB trained codebook having
+    to be stored next to the reference's answers for it (tests/golden/g18)."""
+    rs = np.random.RandomState(seed)
+    A = rs.randn(anchors, anchors, D) * amplitude
+    if centre is not None:
+        A = A + np.asarray(centre, dtype=F64)[None, None, :]
+    gi = np.arange(X, dtype=F64) * ((anchors - 1) / max(X - 1, 1))
+    gj = np.arange(Y, dtype=F64) * ((anchors - 1) / max(Y - 1, 1))
+    i0 = np.minimum(gi.astype(np.int64), anchors - 2)
+    j0 = np.minimum(gj.astype(np.int64), anchors - 2)
+    fi = (gi - i0)[:, None, None]
+    fj = (gj - j0)[None, :, None]
+    a00 = A[i0][:, j0]
+    a10 = A[i0 + 1][:, j0]
+    a01 = A[i0][:, j0 + 1]
+    a11 = A[i0 + 1][:, j0 + 1]
+    top = a00 * (1.0 - fi)
+    top = top + a10 * fi
+    bot = a01 * (1.0 - fi)
+    bot = bot + a11 * fi
+    w = top * (1.0 - fj)
+    w = w + bot * fj
+    return w.astype(F32)

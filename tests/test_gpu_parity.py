@@ -45,8 +45,23 @@ def rel_err(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
+def rel_elem(a, b, floor=1e-3):
+    """Largest ELEMENTWISE relative error over the elements that are not small next to the largest one
+    (|b| >= floor * max|b|): a unit far from the data has a numerator orders of magnitude below the map's largest,
+    and a normwise bound says nothing about it."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    big = np.abs(b) >= floor * max(np.abs(b).max(), 1e-300)
+    return float((np.abs(a - b)[big] / np.abs(b)[big]).max()) if big.any() else 0.0
+
+
+# golden comparisons a float32 near-tie took away (the reference's accumulators belong to ITS BMUs): counted, and
+# bounded by the last test of this module, instead of silently skipped
+LOST = []
+COMPARED = []
+
+
 # ----------------------------------------------------------------------------- G1 exact ties
-@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "exact", "bf16"])
 def test_g1_exact_ties_lowest_index(precision):
     g = load_golden("g1_ties")
     x, w = g["x"].astype(F32), g["w"].astype(F32)
@@ -110,11 +125,14 @@ def test_g4_g5_update_and_epoch(shape, decay):
         ok = oden > 1e-30
         np.testing.assert_allclose(den[ok], oden[ok], rtol=1e-5)
         assert rel_err(num, onum.reshape(-1, D)) < 1e-5
+        (LOST if len(diff) else COMPARED).append(("g4", shape, decay, tag))
+        assert rel_elem(num, onum.reshape(-1, D)) < 1e-5
         if not len(diff):                                     # same BMUs: the golden itself
             gden = g[f"{decay}_{tag}_den"].reshape(-1)
             np.testing.assert_allclose(den[ok], gden[ok], rtol=1e-5)
             if f"{decay}_{tag}_num" in g:
                 assert rel_err(num, g[f"{decay}_{tag}_num"].reshape(-1, D)) < 1e-5
+                assert rel_elem(num, g[f"{decay}_{tag}_num"].reshape(-1, D)) < 1e-5
         e.epoch_merge()
         wout = e.get_weights()
         if not len(diff):
@@ -188,7 +206,10 @@ def test_g6_iris_end_to_end(decay, init):
     assert abs(som.quantization_error(z) - float(g[f"{decay}_{init}_qe0"])) < 1e-5
     som.train(z, 100)
     assert som._weights.dtype == np.float32
-    np.testing.assert_allclose(som._weights, g[f"{decay}_{init}_w"], rtol=1e-4, atol=1e-5)
+    # 100 epochs end to end: the reference against ITSELF under another mini-batch split agrees to 7e-7;
+    # measured here 3e-7 .. 1.2e-6 normwise -- the bound is twice the worst
+    assert rel_err(som._weights, g[f"{decay}_{init}_w"]) < 2.5e-6
+    assert rel_elem(som._weights, g[f"{decay}_{init}_w"]) < 1e-5
     ids = np.array([i * 6 + j for i, j in som.winner(z)])
     assert np.array_equal(ids, g[f"{decay}_{init}_bmu"])
     assert abs(som.quantization_error(z) - float(g[f"{decay}_{init}_qe"])) < 1e-5
@@ -351,7 +372,7 @@ def test_g11_bubble_triangle_against_the_reference(shape, neigh, compact):
 
 
 @pytest.mark.parametrize("decay,tag", [("linear", "init"), ("exponential", "init"), ("exponential", "mid")])
-@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "exact", "bf16"])
 def test_g12_configs1_map_against_the_reference(decay, tag, precision):
     """64x64x32 (BASELINE configs[1]'s map), one _update of 4096 rows: BMUs, denominator, strided numerator and
     merged rows of the reference itself."""
@@ -367,7 +388,7 @@ def test_g12_configs1_map_against_the_reference(decay, tag, precision):
     e.epoch_accumulate(float(g[key + "_sig"]), float(g[key + "_eta"]), O.decay_is_wide(decay))
     num, den, bmu = e.epoch_fetch()
     diff = np.flatnonzero(bmu != g[key + "_bmu"])
-    if precision == "f32":
+    if precision in ("f32", "exact"):
         if len(diff):                                         # only float32 near-ties (1-2 ulp gaps) may differ
             assert len(diff) <= max(2, n // 500) and near_tie_mask(data[diff], w.reshape(-1, D)).all()
     else:
@@ -380,12 +401,16 @@ def test_g12_configs1_map_against_the_reference(decay, tag, precision):
     ok = oden > 1e-30
     np.testing.assert_allclose(den[ok], oden[ok], rtol=1e-5)
     assert rel_err(num, onum.reshape(-1, D)) < 1e-5
+    assert rel_elem(num, onum.reshape(-1, D)) < 1e-5
+    if precision == "f32":
+        (LOST if len(diff) else COMPARED).append(("g12", decay, tag))
     if len(diff):
         return
     gden = g[key + "_den"].reshape(-1)                        # same BMUs: the reference's own outputs
     ok = gden > 1e-30
     np.testing.assert_allclose(den[ok], gden[ok], rtol=1e-5)
     assert rel_err(num[::st], g[key + "_num16"]) < 1e-5
+    assert rel_elem(num[::st], g[key + "_num16"]) < 1e-5
     e.epoch_merge()
     gw = g[key + "_wout16"]
     np.testing.assert_allclose(e.get_weights()[::st][ok[::st]], gw[ok[::st]], rtol=1e-5, atol=1e-5 * np.abs(gw).max())
@@ -1434,3 +1459,107 @@ def test_linear_schedule_ending_at_sigma_zero_with_mexican_hat_raises_like_the_r
     som.train(data, 2)                                             # bubble at sigma 0: nobody inside, weights unchanged
     assert np.isfinite(som._weights).all()
 
+
+
+# ----------------------------------------------------------------------------- G17 / G18: wide shapes pinned by the reference
+@pytest.mark.parametrize("decay", ["linear", "exponential"])
+@pytest.mark.parametrize("precision", ["f32", "bf16", "bf16x3"])
+def test_g17_configs4_semantics_at_a_wide_kernel_shape(decay, precision):
+    """cosine + mexican_hat, 784 features, non-negative unit rows (BASELINE configs[4]) on a 64 x 64 map: the reference's
+    own BMUs, denominator, strided numerator and merged rows (distances.py:45-59, neighborhoods.py:57-74).  With 784
+    features the reference's sgemm splits K into blocks (one k-ordered chain only up to 448, measured on the generating
+    host), so float32 near-ties may fall the other way: counted, bounded, and each one checked to BE a near-tie."""
+    g = load_golden("g17_configs4_64x64x784")
+    X, Y, D, n = (int(v) for v in g["shape"])
+    st = int(g["stride"])
+    data = np.abs(O.gaussian_blobs(n, D, seed=int(g["data_seed"])))
+    data /= np.linalg.norm(data, axis=1, keepdims=True)
+    data = data.astype(F32)
+    w = np.abs(O.default_codebook(X, Y, D, 1234)).astype(F32)
+    wide = O.decay_is_wide(decay)
+    e = engine(X, Y, D, precision=precision, distance="cosine", neighborhood="mexican_hat")
+    e.set_weights(w)
+    e.set_data(data)
+    e.epoch_accumulate(float(g[decay + "_sig"]), float(g[decay + "_eta"]), wide)
+    num, den, bmu = e.epoch_fetch()
+    ref = g[decay + "_bmu"]
+    diff = np.flatnonzero(bmu != ref)
+    x64, w64 = data.astype(np.float64), w.reshape(-1, D).astype(np.float64)
+    cosd = 1.0 - (x64 @ w64.T) / np.sqrt((x64 ** 2).sum(1)[:, None] * (w64 ** 2).sum(1)[None, :])
+    gap = cosd[diff, bmu[diff]] - cosd[diff].min(1)         # how much worse than the best unit the engine's pick is
+    tol = {"f32": 2e-6, "bf16x3": 2.0 ** -13, "bf16": 2.0 ** -6}[precision]
+    assert (gap <= tol).all(), (precision, gap.max())
+    assert len(diff) <= {"f32": max(2, n // 500), "bf16x3": n // 100, "bf16": n // 4}[precision], len(diff)
+    # the update from the engine's own BMUs against the oracle, elementwise
+    sig = np.float64(g[decay + "_sig"]) if wide else float(g[decay + "_sig"])
+    eta = np.float64(g[decay + "_eta"]) if wide else float(g[decay + "_eta"])
+    _, onum, oden = O.update(data, w, eta, sig, wide=wide, forced_bmu=bmu, neighbourhood="mexican_hat", distance="cosine")
+    assert rel_err(num, onum.reshape(-1, D)) < 1e-5 and rel_err(den, oden.reshape(-1)) < 1e-5
+    if precision == "f32":
+        (LOST if len(diff) else COMPARED).append(("g17", decay))
+    if len(diff):
+        return
+    gden = g[decay + "_den"].reshape(-1)                     # same BMUs: the reference's own accumulators
+    assert rel_err(den, gden) < 1e-5
+    assert rel_err(num[::st], g[decay + "_num32"]) < 1e-5
+    e.epoch_merge()
+    gw = g[decay + "_wout32"]
+    ok = np.abs(gden[::st]) > 1e-3 * np.abs(gden).max()      # (mexican hat: a denominator near zero amplifies everything)
+    np.testing.assert_allclose(e.get_weights()[::st][ok], gw[ok], rtol=2e-4, atol=1e-5 * np.abs(gw).max())
+
+
+def test_g17_euclidean_bmus_at_784_features():
+    g = load_golden("g17_configs4_64x64x784")
+    X, Y, D, n = (int(v) for v in g["shape"])
+    data = np.abs(O.gaussian_blobs(n, D, seed=int(g["data_seed"])))
+    data /= np.linalg.norm(data, axis=1, keepdims=True)
+    data = data.astype(F32)
+    w = np.abs(O.default_codebook(X, Y, D, 1234)).astype(F32)
+    for precision in ("f32", "exact"):
+        e = engine(X, Y, D, precision=precision)
+        e.set_weights(w)
+        ids = e.bmu(data)
+        diff = np.flatnonzero(ids != g["euclidean_bmu"])
+        assert len(diff) <= max(2, n // 500) and near_tie_mask(data[diff], w.reshape(-1, D)).all(), (precision, len(diff))
+        e.close()
+
+
+@pytest.mark.parametrize("state", ["seeded", "sheet"])
+def test_g18_bmus_at_the_configs2_shape(state):
+    """256 x 256 x 128, 4 096 rows: the reference's `_winner` on the seeded codebook and on a smooth sheet (the state of
+    the early schedule: hundreds of near-best units per row).  Up to 448 features the reference's sgemm IS one
+    k-ordered fma chain per output, which is what the float32 MFMA kernel computes: ids must be IDENTICAL, in the
+    float32 mode and in the exact mode; the throughput modes are held to their bounds."""
+    import zlib
+    g = load_golden("g18_bmus_256x256x128")
+    X, Y, D, n = (int(v) for v in g["shape"])
+    data = O.gaussian_blobs(n, D, seed=int(g["data_seed"]))
+    if state == "seeded":
+        w = O.default_codebook(X, Y, D, int(g["codebook_seed"])).astype(F32)
+    else:
+        w = O.smooth_sheet_codebook(X, Y, D, int(g["sheet_seed"]), amplitude=float(g["sheet_amplitude"]),
+                                    centre=data.astype(np.float64).mean(0))
+    assert zlib.crc32(np.ascontiguousarray(w).tobytes()) == int(g[state + "_w_crc"]), "the codebook recipe left the fixture's"
+    ref = g[state + "_bmu"]
+    x64, w64 = data.astype(np.float64), w.reshape(-1, D).astype(np.float64)
+    for precision in ("f32", "exact", "bf16x3", "f16", "bf16"):
+        e = engine(X, Y, D, precision=precision)
+        e.set_weights(w)
+        ids = e.bmu(data)
+        e.close()
+        if precision in ("f32", "exact"):
+            assert np.array_equal(ids, ref), (precision, int((ids != ref).sum()))
+            continue
+        diff = np.flatnonzero(ids != ref)
+        got = ((x64[diff] - w64[ids[diff]]) ** 2).sum(1)
+        best = ((x64[diff] - w64[ref[diff]]) ** 2).sum(1)
+        slack = {"bf16x3": 2.0 ** -14, "f16": 2.0 ** -9, "bf16": 2.0 ** -6}[precision] * \
+            (np.linalg.norm(x64[diff], axis=1) + np.linalg.norm(w64, axis=1).max()) ** 2
+        assert (got <= best + slack).all(), precision
+
+
+def test_zz_few_golden_comparisons_were_lost_to_near_ties():
+    """The float32 mode's BMUs equal the reference's except on float32 near-ties (G12's one row; G17's K-split sgemm):
+    the comparisons of accumulators / merged rows that such a difference makes meaningless are counted here."""
+    assert len(COMPARED) >= 20, (len(COMPARED), LOST)
+    assert len(LOST) <= 3, LOST

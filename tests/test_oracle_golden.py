@@ -430,3 +430,43 @@ def test_g16_update(neigh):
     np.testing.assert_allclose(num, g[neigh + "_num"], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(den, g[neigh + "_den"], rtol=1e-5, atol=1e-5)
 
+
+
+@pytest.mark.parametrize("decay", ["linear", "exponential"])
+def test_g17_configs4_semantics_64x64x784(decay):
+    """cosine + mexican_hat at 784 features (BASELINE configs[4]'s semantics): BMUs, denominator, strided numerator.
+    The reference's sgemm splits K = 784 into blocks; NumPy here does the same on the same host, another host's BLAS
+    may order the sum differently: a few float32 near-ties are allowed to move."""
+    g = load_golden("g17_configs4_64x64x784")
+    X, Y, D, n = (int(v) for v in g["shape"])
+    st = int(g["stride"])
+    data = np.abs(O.gaussian_blobs(n, D, seed=int(g["data_seed"])))
+    data /= np.linalg.norm(data, axis=1, keepdims=True)
+    data = data.astype(F32)
+    w = np.abs(O.default_codebook(X, Y, D, 1234)).astype(F32)
+    wide = O.decay_is_wide(decay)
+    sig = np.float64(g[decay + "_sig"]) if wide else float(g[decay + "_sig"])
+    eta = np.float64(g[decay + "_eta"]) if wide else float(g[decay + "_eta"])
+    bmu, num, den = O.update(data, w, eta, sig, wide=wide, neighbourhood="mexican_hat", distance="cosine")
+    assert (bmu != g[decay + "_bmu"]).sum() <= max(2, n // 500)
+    if np.array_equal(bmu, g[decay + "_bmu"]):
+        np.testing.assert_allclose(den.reshape(-1).astype(F32), g[decay + "_den"].reshape(-1), rtol=1e-5, atol=1e-5 * np.abs(g[decay + "_den"]).max())
+        ref = g[decay + "_num32"]
+        assert np.abs(num.reshape(-1, D)[::st] - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("state", ["seeded", "sheet"])
+def test_g18_bmus_256x256x128(state):
+    """The oracle's winner ids at the configs[2] shape against the reference's, and the host-independent codebook recipe."""
+    import zlib
+    g = load_golden("g18_bmus_256x256x128")
+    X, Y, D, n = (int(v) for v in g["shape"])
+    data = O.gaussian_blobs(n, D, seed=int(g["data_seed"]))
+    if state == "seeded":
+        w = O.default_codebook(X, Y, D, int(g["codebook_seed"])).astype(F32)
+    else:
+        w = O.smooth_sheet_codebook(X, Y, D, int(g["sheet_seed"]), amplitude=float(g["sheet_amplitude"]),
+                                    centre=data.astype(np.float64).mean(0))
+    assert zlib.crc32(np.ascontiguousarray(w).tobytes()) == int(g[state + "_w_crc"])
+    ids = O.winner_ids(data[:1024], w, n_parallel=1024)          # (a quarter of the rows: 8.6 GFLOP on the CPU)
+    assert (ids != g[state + "_bmu"][:1024]).sum() <= 2
