@@ -253,6 +253,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    first_epoch = {}
+
     def timed_run(precision):
         """W warm-up epochs, then exactly K timed epochs between fences; max over ranks.  Returns the engine too."""
         eng = HipEngine(MAP_X, MAP_Y, FEATURES, precision=precision, device=dev, distance=wl["distance"],
@@ -261,6 +263,8 @@ def main():
         eng.set_data(rows_host)
         for t in range(args.warmup):
             D.epoch(eng, sched[t][0], sched[t][1], True)
+            if t == 0 and precision == args.precision:
+                first_epoch["w"] = eng.get_weights()      # the codebook one epoch from the seed (strong scaling: probe)
         fence(eng)
         # The timed region carries HIP events around the dominant (BMU) kernels only -- two event records per epoch
         # (precision 'exact': two more per screen pass).  Event pairs around every kernel family put a ~10 us bubble
@@ -461,6 +465,31 @@ def main():
                         "note": "update only (segment sum + transform, or tables + g^T x GEMM), hipEvent-timed; float32 MFMA peak"}
         e3.close()
 
+    # strong scaling: did this run train the SAME map as the one-GPU run of the same rows?  After ONE epoch from the
+    # seeded codebook the answer is a number (later epochs amplify float32 summation-order noise chaotically):
+    # 4096 fixed entries of the codebook against the probe a --gpus 1 --scaling strong run stored under profiles/.
+    probe = None
+    if rank == 0 and args.scaling == "strong" and "w" in first_epoch:
+        idx = np.random.RandomState(99).randint(0, first_epoch["w"].size, 4096)
+        mine = first_epoch["w"].reshape(-1)[idx].astype(np.float64)
+        key = {"workload": args.workload, "total_rows": total_rows, "precision": args.precision}
+        ref_path = os.path.join(REPO, "profiles", "strong_first_epoch_probe_%s.json" % args.workload)
+        probe = {"entries": 4096, "after_epochs": 1}
+        try:
+            with open(ref_path) as f:
+                ref_p = json.load(f)
+            if all(ref_p.get(k) == v for k, v in key.items()):
+                r = np.asarray(ref_p["probe"])
+                probe["codebook_max_rel_vs_n1"] = float(np.abs(mine - r).max() / np.abs(r).max())
+                probe["n1_probe"] = {"file": "profiles/" + os.path.basename(ref_path), "build": ref_p.get("build")}
+        except (OSError, ValueError, KeyError):
+            pass
+        if world == 1:                                         # this IS the one-GPU run: (re)write the probe
+            os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(REPO, "gpurun_out", os.path.basename(ref_path)), "w") as f:
+                json.dump(dict(key, build=B.built_hash(), probe=[float(v) for v in mine]), f)
+            probe["written"] = "gpurun_out/" + os.path.basename(ref_path)
+
     if rank == 0:
         ms_step = 1e3 * dt / args.steps
         is_exact = args.precision == "exact" and FEATURES <= 128 and wl["distance"] == "euclidean"
@@ -512,6 +541,8 @@ def main():
                                   "rows_through_float32_fallback_kernel": exact_stats[1], "screen_passes": exact_stats[2]}
         if thr is not None:
             out["throughput_mode"] = thr
+        if probe is not None:
+            out["strong_scaling_probe"] = probe
         if batch is not None:
             out["roofline"]["batch65536"] = batch
         if modes is not None:

@@ -1,8 +1,9 @@
 """One rank of the N > 1 GPU tests (tests/test_gpu_distributed.py): launched by torch.distributed.run,
 trains through the PRODUCT path (XPySom -> HipEngine -> libsomhip) and saves what the test compares.
 
-    dist_worker.py <backend> <out_dir> <mode>     mode: full | sharded | stream | bf16 | wide
-(wide: a 130-row map, i.e. two 128-row blocks of the accumulator, for the blockwise all-reduce: SOM_OVERLAP=0/1)
+    dist_worker.py <backend> <out_dir> <mode>     mode: full | sharded | stream | bf16 | exact | wide | wide4
+(wide: a 130-row map, i.e. two 128-row blocks of the accumulator, for the blockwise all-reduce: SOM_OVERLAP=0/1;
+ wide4: a 512-row map, four blocks -- the block count from which the overlapped epoch is the default under RCCL)
 """
 import os
 import sys
@@ -30,12 +31,12 @@ def main():
         dist.init_process_group(backend)
     try:
         assert D.dist_info() == (rank, world)
-        prec = "bf16" if mode == "bf16" else "f32"
+        prec = mode if mode in ("bf16", "exact") else "f32"
         sharded = mode in ("sharded", "stream")
 
         def feed(som, data, T, **kw):
             lo, hi = D.shard_bounds(len(data), rank, world)
-            if mode in ("full", "bf16", "wide"):
+            if mode in ("full", "bf16", "exact", "wide", "wide4"):
                 som.train(data, T, **kw)                      # every rank passes all rows and keeps its slice
             elif mode == "sharded":
                 som.train(data[lo:hi], T, **kw)
@@ -50,7 +51,7 @@ def main():
         feed(som, small, 6)
         np.save(os.path.join(out_dir, "ws_%s_%d.npy" % (mode, rank)), som._weights)
         # (b) one teacher-forced epoch (iteration 2 of 5) of a mid-size map from the seeded codebook
-        X, Y, Dm, n, T = (130, 6, 16, 6001, 5) if mode == "wide" else (24, 20, 16, 6001, 5)
+        X, Y, Dm, n, T = (130, 6, 16, 6001, 5) if mode == "wide" else (512, 4, 16, 6001, 5) if mode == "wide4" else (24, 20, 16, 6001, 5)
         data = O.gaussian_blobs(n, Dm, seed=11)
         som = XPySom(X, Y, Dm, random_seed=3, decay_function="linear", device=dev, precision=prec, sharded_input=sharded)
         feed(som, data, T, iter_beg=2, iter_end=3)

@@ -64,6 +64,21 @@ def test_two_rank_training_equals_single_process(tmp_path, sharded_input):
         np.testing.assert_allclose(o0, ref1, rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_eight_rank_training_equals_single_process(tmp_path, overlap):
+    """The real world size of BASELINE configs[3] / [4]: eight gloo ranks (75 rows each, one of them with 76), the
+    one-shot all-reduce and the blockwise one (three 3-row blocks of the 7-row test map)."""
+    import torch.multiprocessing as mp
+    world = 8
+    mp.spawn(_worker, args=(world, _free_port(), True, str(tmp_path), overlap), nprocs=world, join=True)
+    ws = [np.load(tmp_path / ("w%d.npy" % r)) for r in range(world)]
+    for w in ws[1:]:
+        assert np.array_equal(ws[0], w)                 # every rank holds the same codebook, bit for bit
+    data = O.gaussian_blobs(601, 5, seed=11)
+    ref = O.train(data, O.default_codebook(7, 6, 5, 3), 6, sigma0=3.0, decay="linear", n_parallel=4000)
+    np.testing.assert_allclose(ws[0], ref, rtol=2e-5, atol=2e-6)
+
+
 def test_blockwise_allreduce_host_logic(tmp_path):
     """distributed._epoch_overlapped (begin -> [block b, all-reduce of its slice] ... -> merge) against the one-shot
     all-reduce, two gloo ranks, the test-double engine with three-row blocks: same codebook bit for bit."""
