@@ -121,6 +121,18 @@ def test_five_ranks_of_the_hip_engine_on_one_gpu(tmp_path):
         np.testing.assert_allclose(x, y, rtol=2e-6, atol=2e-6 * np.abs(y).max())
 
 
+def test_native_collective_with_two_ranks_on_one_gpu_fails_loudly(tmp_path):
+    """SOM_COMM=native (RCCL inside libsomhip) needs one GPU per rank: two ranks on ONE card must end with an error from
+    ncclCommInitRank on every rank -- promptly, not in a hang -- so that a mis-launched job says what is wrong."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", SOM_COMM="native")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "tests", "dist_worker.py"), "gloo", str(tmp_path), "full"]
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=180)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0
+    assert "ncclCommInitRank" in out or "SomHipError" in out, out[-3000:]
+
+
 def test_two_ranks_under_rccl(tmp_path):
     import torch
     if torch.cuda.device_count() < 2:
