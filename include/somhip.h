@@ -208,6 +208,17 @@ int som_distance_matrix(som_handle* h, const float* x_host, int64_t n_rows, int3
  * QUANTIZATION mode. */
 int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, double* qe_out);
 
+/* The canary.  n_rows > 0: after every BMU launch (epochs, streamed chunks, som_bmu) n_rows strided rows are scored
+ * again by the float32 parity kernel and the launch's own picks must be the float32 picks (F32, EXACT) or within the
+ * precision mode's operand-rounding bound of them; otherwise the call fails with a message naming a row.  Costs one
+ * small float32 launch and one host synchronisation per BMU launch: for smoke tests and stress runs (also: the
+ * environment variable SOM_VERIFY=n at som_create).  som_verify_stats: launches / rows checked so far.
+ * som_debug_corrupt_operands is the canary's TEST HOOK: it zeroes the operand images the kernels read (bit 0: the
+ * 16-bit image, bit 1: the float32 image) without marking them stale, as a lost staging copy would. */
+int som_set_verify(som_handle* h, int32_t n_rows);
+int som_verify_stats(som_handle* h, int64_t* launches, int64_t* rows_checked);
+int som_debug_corrupt_operands(som_handle* h, int32_t which);
+
 /* precision EXACT bookkeeping: rows screened so far, rows that went to the float32 fallback kernel, screen passes */
 int som_exact_stats(som_handle* h, int64_t* rows, int64_t* rows_fallback, int64_t* passes);
 /* candidate groups per row of the LAST screen pass (its first n rows): how many 64-unit groups the re-score visited */

@@ -66,6 +66,9 @@ SIGNATURES = {
     "som_bmu_top2": (C.c_int, [_H, _F, C.c_int64, _I, _I]),
     "som_distance_matrix": (C.c_int, [_H, _F, C.c_int64, C.c_int32, _F]),
     "som_quantization_error": (C.c_int, [_H, _F, C.c_int64, C.POINTER(C.c_double)]),
+    "som_set_verify": (C.c_int, [_H, C.c_int32]),
+    "som_verify_stats": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "som_debug_corrupt_operands": (C.c_int, [_H, C.c_int32]),
     "som_exact_stats": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "som_exact_last_counts": (C.c_int, [_H, _I, C.c_int64]),
     "som_sync": (C.c_int, [_H]),

@@ -375,6 +375,87 @@ __global__ __launch_bounds__(256) void exact_werr_kernel(const float* __restrict
     if ((threadIdx.x & 63) == 0) atomic_max_pos_f32(out, m);
 }
 
+// ---- the canary (som_set_verify / SOM_VERIFY=n): n strided rows of every BMU launch are scored again by the float32
+// kernel, and the launch's own pick must be the float32 pick or within the precision mode's bound of it.
+// picks[i], best[i]: the launch's / the float32 kernel's unit for gathered row i.  tol_rel: the mode's bound on the
+// score gap relative to |x| max|w| (euclidean: scores |w|^2 - 2 x.w) or absolute (cosine: scores 1 - cos); 0 = the
+// ids must be equal.  bad[0] counts offenders, bad[1..3] = (row, pick, float32 pick) of one of them.
+__global__ __launch_bounds__(256) void verify_picks_kernel(const float* __restrict__ Xv, int n, int D,
+                                                           const float* __restrict__ W, const float* __restrict__ wsq,
+                                                           const float* __restrict__ wmax2, const int* __restrict__ rows,
+                                                           const int* __restrict__ picks, const int* __restrict__ best,
+                                                           int cosine, float tol_rel, int* __restrict__ bad) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int p = picks[i], b = best[i];
+    if (p == b) return;
+    bool ok = false;
+    if (tol_rel > 0.0f) {
+        const float* x = Xv + (long)i * D;
+        double cp = 0.0, cb = 0.0, xs = 0.0;
+        for (int k = 0; k < D; ++k) {
+            const double xv = x[k];
+            cp += xv * W[(long)p * D + k]; cb += xv * W[(long)b * D + k]; xs += xv * xv;
+        }
+        if (cosine) {
+            const double sp = 1.0 - cp / sqrt(xs * wsq[p]), sb = 1.0 - cb / sqrt(xs * wsq[b]);
+            ok = sp <= sb + tol_rel || !(xs > 0.0);
+        } else {
+            const double sp = wsq[p] - 2.0 * cp, sb = wsq[b] - 2.0 * cb;
+            ok = sp <= sb + (double)tol_rel * sqrt(xs) * sqrt((double)*wmax2);
+        }
+    }
+    if (!ok && atomicAdd(bad, 1) == 0) { bad[1] = rows[i]; bad[2] = p; bad[3] = b; }
+}
+
+// The float32 first-minimum of one gathered row over ALL units by the plainest possible route: one workgroup per row,
+// a thread per unit stride, the k-ordered fmaf chain on the vector ALU straight from the float32 codebook and |w|^2 --
+// no MFMA, no stage image, no LDS-DMA, no codebook parts.  Same arithmetic as the parity kernels (score_f32), so its
+// answer is theirs; sharing nothing with them is the point.
+template <int MODE>
+__global__ __launch_bounds__(256) void verify_best_kernel(const float* __restrict__ Xv, int D, const float* __restrict__ W,
+                                                          const float* __restrict__ wsq, int K, int* __restrict__ best_out) {
+    extern __shared__ float vsm[];                         // D floats of the row, then the reduction scratch
+    __shared__ float rv[256];
+    __shared__ int ru[256];
+    __shared__ float xsq_s;
+    const int tid = threadIdx.x;
+    const float* x = Xv + (long)blockIdx.x * D;
+    for (int k = tid; k < D; k += 256) vsm[k] = x[k];
+    if (tid == 0) xsq_s = np_pairwise_sq_sum(x, D);
+    __syncthreads();
+    const float xsq = xsq_s;
+    float best = __builtin_inff();
+    int bu = 0;
+    for (int u = tid; u < K; u += 256) {
+        const float* w = W + (long)u * D;
+        float c = 0.0f;
+        for (int k = 0; k < D; ++k) c = __builtin_fmaf(w[k], vsm[k], c);
+        const float v = score_f32<MODE>(c, wsq[u], xsq);
+        if (v < best) { best = v; bu = u; }               // (ascending u per thread: the first minimum of its stride)
+    }
+    rv[tid] = best; ru[tid] = bu;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            const float ov = rv[tid + o];
+            const int ou = ru[tid + o];
+            if (ov < rv[tid] || (ov == rv[tid] && ou < ru[tid])) { rv[tid] = ov; ru[tid] = ou; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) best_out[blockIdx.x] = rv[0] < __builtin_inff() ? ru[0] : 0;   // nothing below +inf: numpy.argmin's 0
+}
+
+__global__ __launch_bounds__(256) void verify_pick_rows_kernel(long N, int n, const int* __restrict__ ids, int* __restrict__ rows,
+                                                               int* __restrict__ picks) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long r = (long)i * (N / n) + (N / n) / 2;        // n strided rows, mid-stride
+    rows[i] = (int)r;
+    picks[i] = ids[r];
+}
+
 // wn = wsq (the float32 kernel's own |w|^2) and its maximum: the screen's initial accumulator then carries the same
 // norm the re-score adds
 __global__ __launch_bounds__(256) void exact_copy_wsq_kernel(const float* __restrict__ wsq, int K, float* __restrict__ wn,

@@ -166,6 +166,13 @@ struct som_handle {
     int2* bands = nullptr;   // nonzero column ranges of the neighbourhood tables per 128-row block (update.hpp)
     bool use_bands = true;
 
+    // canary (som_set_verify / SOM_VERIFY=n): n strided rows of every BMU launch re-scored by the float32 kernel
+    int verify_rows = 0;
+    bool verifying = false;
+    int *vf_rows = nullptr, *vf_picks = nullptr, *vf_best = nullptr, *vf_bad = nullptr;
+    float* vf_X = nullptr;
+    int vf_cap = 0;
+    int64_t verify_launches = 0, verify_rows_checked = 0;
     bool fuse_merge_prep = true; // SOM_FUSE_MERGE=0: separate merge and operand-preparation launches (A/B)
     // read once in som_create (experiments / A-B runs): forced part counts, launch-geometry printing
     int env_bf16_parts = 0, env_f32_parts = 0;
@@ -996,10 +1003,64 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     return 0;
 }
 
+// ---- canary: re-score a strided sample of a BMU launch's rows with the float32 kernel (bmu_exact.hpp) -------------
+int verify_bmu_launch(som_handle* h, const float* X, long N, const int* ids) {
+    const int n = (int)std::min<long>(h->verify_rows, N);
+    if (n <= 0 || h->cfg.distance > SOM_DIST_COSINE) return 0;     // (the VALU distances have one precision: nothing to cross-check)
+    if (h->capturing) return fail(h, "SOM_VERIFY reads a flag back per launch: not capturable");
+    if (n > h->vf_cap) {
+        void* old[] = {h->vf_rows, h->vf_picks, h->vf_best, h->vf_X};
+        for (void* p : old) if (p) (void)hipFree(p);
+        h->vf_rows = h->vf_picks = h->vf_best = nullptr; h->vf_X = nullptr; h->vf_cap = 0;
+        if (int rc = dev_alloc(h, &h->vf_rows, (size_t)n)) return rc;
+        if (int rc = dev_alloc(h, &h->vf_picks, (size_t)n)) return rc;
+        if (int rc = dev_alloc(h, &h->vf_best, (size_t)n)) return rc;
+        if (int rc = dev_alloc(h, &h->vf_X, (size_t)n * h->D)) return rc;
+        if (!h->vf_bad) if (int rc = dev_alloc(h, &h->vf_bad, 4)) return rc;
+        h->vf_cap = n;
+    }
+    verify_pick_rows_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(N, n, ids, h->vf_rows, h->vf_picks);
+    exact_gather_rows_kernel<<<dim3((unsigned)cdiv((long)n * h->D, 256)), dim3(256), 0, h->stream>>>(X, h->vf_rows, n, h->D, h->vf_X);
+    HIPCHK(h, hipMemsetAsync(h->vf_bad, 0, 4 * sizeof(int), h->stream));
+    if (h->wsq_dirty) {                                            // |w|^2 in NumPy's order (the parity kernels' own)
+        row_sq_f32_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->wsq);
+        h->wsq_dirty = false;
+    }
+    const dim3 grid((unsigned)n), block(256);
+    const size_t lds = (size_t)h->D * sizeof(float);
+    if (lds > 60 * 1024) return fail(h, "SOM_VERIFY: input_len too large for the canary's row buffer");
+    switch (h->cfg.distance) {
+    case SOM_DIST_EUCLIDEAN: verify_best_kernel<SCORE_EUCLID_PART><<<grid, block, lds, h->stream>>>(h->vf_X, h->D, h->W, h->wsq, h->K, h->vf_best); break;
+    case SOM_DIST_EUCLIDEAN_NO_OPT: verify_best_kernel<SCORE_EUCLID_SQ><<<grid, block, lds, h->stream>>>(h->vf_X, h->D, h->W, h->wsq, h->K, h->vf_best); break;
+    default: verify_best_kernel<SCORE_COSINE><<<grid, block, lds, h->stream>>>(h->vf_X, h->D, h->W, h->wsq, h->K, h->vf_best); break;
+    }
+    // the mode's bound on the score gap: 0 = the float32 pick itself (f32, exact); half operands: 4 ub |x||w| (two
+    // units, two operands each) with a margin; split operands: their dropped lo.lo terms
+    float tol = 0.0f;
+    const int prec = h->cfg.precision;
+    const bool cosine = h->cfg.distance == SOM_DIST_COSINE;
+    if (prec == SOM_PREC_BF16) tol = 8.0f / 256.0f;
+    else if (prec == SOM_PREC_F16) tol = 8.0f / 2048.0f;
+    else if (prec == SOM_PREC_BF16X3 || prec == SOM_PREC_F16X3) tol = 1.0f / 4096.0f;
+    if (cosine && tol > 0.0f) tol *= 0.5f;                         // (unit-length operands: |x||w| = 1)
+    verify_picks_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(
+        h->vf_X, n, h->D, h->W, h->wsq, h->wmax2 ? h->wmax2 : h->wsq, h->vf_rows, h->vf_picks, h->vf_best, cosine ? 1 : 0, tol, h->vf_bad);
+    HIPCHK(h, hipGetLastError());
+    int bad[4] = {0, 0, 0, 0};
+    if (int rc2 = d2h_blocking(h, bad, h->vf_bad, sizeof(bad))) return rc2;
+    h->verify_launches += 1; h->verify_rows_checked += n;
+    if (bad[0] > 0) {
+        char msg[256];
+        std::snprintf(msg, sizeof(msg), "SOM_VERIFY: %d of %d re-scored rows carry a pick outside the precision mode's bound "
+                      "(e.g. row %d: unit %d, the float32 kernel says %d)", bad[0], n, bad[1], bad[2], bad[3]);
+        return fail(h, msg);
+    }
+    return 0;
+}
+
 // BMU of `N` device rows with the configured activation distance (xpysom.py:410-417)
-int run_activation_bmu(som_handle* h, const float* X, long N, const float* xsq, const __bf16* Xb, const float* xmax2,
-                       int* out) {
-    if (N == 0) return 0;
+int run_activation_bmu_launch(som_handle* h, const float* X, long N, const float* xsq, const __bf16* Xb, const float* xmax2,
+                              int* out) {
     if (int rc = refresh_codebook_operands(h, h->cfg.precision == SOM_PREC_F32)) return rc;
     Timed t(h, SOM_K_BMU);
     if (h->exact) return launch_bmu_exact(h, X, N, xsq, Xb, xmax2, out);
@@ -1013,6 +1074,14 @@ int run_activation_bmu(som_handle* h, const float* X, long N, const float* xsq, 
     case SOM_DIST_NORM_P: return launch_bmu_pairwise(h, X, N, h->norm_p, h->norm_p % 2 == 0, out);
     }
     return fail(h, "unknown distance id");
+}
+
+int run_activation_bmu(som_handle* h, const float* X, long N, const float* xsq, const __bf16* Xb, const float* xmax2,
+                       int* out) {
+    if (N == 0) return 0;
+    if (int rc = run_activation_bmu_launch(h, X, N, xsq, Xb, xmax2, out)) return rc;
+    if (h->verify_rows > 0 && !h->verifying) return verify_bmu_launch(h, X, N, out);
+    return 0;
 }
 
 bool needs_xsq(const som_handle* h) {
@@ -1420,6 +1489,7 @@ int som_create(const som_config* cfg, som_handle** out) {
         if (const char* e = std::getenv("SOM_BF16_PARTS")) h->env_bf16_parts = std::atoi(e);
         if (const char* e = std::getenv("SOM_F32_PARTS")) h->env_f32_parts = std::atoi(e);
         h->debug = std::getenv("SOM_DEBUG") != nullptr;
+        if (const char* e = std::getenv("SOM_VERIFY")) h->verify_rows = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("SOM_ASYNC_COPIES")) h->async_copies = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_FUSE_MERGE")) h->fuse_merge_prep = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_SORT_ONESWEEP_ROWS")) SORT_ONESWEEP_ROWS = std::atol(e);
@@ -1481,6 +1551,10 @@ void som_destroy(som_handle* h) {
     for (void* b : bufs) if (b) (void)hipFree(b);
     seg_free(h->seg);
     seg_free(h->st_seg);
+    {
+        void* vb[] = {h->vf_rows, h->vf_picks, h->vf_best, h->vf_bad, h->vf_X};
+        for (void* b : vb) if (b) (void)hipFree(b);
+    }
     {
         void* eb[] = {h->ex.gmin, h->ex.bm, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab};
         for (void* b : eb) if (b) (void)hipFree(b);
@@ -2101,6 +2175,35 @@ int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, d
     double s = 0.0;
     if (int rc = d2h_blocking(h, &s, h->dsum, sizeof(double))) return rc;
     *qe_out = s / (double)n_rows;
+    return 0;
+}
+
+int som_set_verify(som_handle* h, int32_t n_rows) {
+    if (!h || n_rows < 0) return fail(h, "som_set_verify: bad argument");
+    h->verify_rows = n_rows;
+    return 0;
+}
+
+int som_verify_stats(som_handle* h, int64_t* launches, int64_t* rows_checked) {
+    if (!h) return 1;
+    if (launches) *launches = h->verify_launches;
+    if (rows_checked) *rows_checked = h->verify_rows_checked;
+    return 0;
+}
+
+// TEST HOOK of the canary: overwrite the operand images the BMU kernels read (the 16-bit stage / tile image and the
+// float32 stage image) with zeros WITHOUT marking them stale -- what a lost or torn staging copy would look like.
+int som_debug_corrupt_operands(som_handle* h, int32_t which) {
+    DeviceGuard dev_guard(h);
+    if (!h) return 1;
+    if (int rc = refresh_codebook_operands(h, true)) return rc;
+    if ((which & 1) && h->Wst) {
+        size_t bytes = (size_t)h->n_stages * h->stage_bytes;
+        if (h->tiled && !h->wide) bytes = (size_t)h->n_ublocks * h->n_kchunks * h->tl_wtile;
+        HIPCHK(h, hipMemsetAsync(h->Wst, 0, bytes, h->stream));
+    }
+    if ((which & 2) && h->Wfst) HIPCHK(h, hipMemsetAsync(h->Wfst, 0, (size_t)h->fr_stages * fr_stage_bytes(h->fr_kg), h->stream));
+    if ((which & 2) && h->Wfimg) HIPCHK(h, hipMemsetAsync(h->Wfimg, 0, (size_t)h->ft_ublocks * h->ft_kchunks * FT_WTILE, h->stream));
     return 0;
 }
 

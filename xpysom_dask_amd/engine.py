@@ -258,6 +258,19 @@ class HipEngine:
         self._check(self._lib.som_quantization_error(self._h, self._fp(x), x.shape[0], C.byref(out)))
         return out.value
 
+    def set_verify(self, n_rows):
+        """The canary: re-score `n_rows` strided rows of every BMU launch with the float32 kernel (0 = off)."""
+        self._check(self._lib.som_set_verify(self._h, int(n_rows)))
+
+    def verify_stats(self):
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self._lib.som_verify_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def debug_corrupt_operands(self, which=3):
+        """TEST HOOK of the canary: zero the operand images behind the library's back (1: 16-bit, 2: float32)."""
+        self._check(self._lib.som_debug_corrupt_operands(self._h, int(which)))
+
     def exact_stats(self):
         """precision 'exact': (rows screened, rows sent to the float32 fallback kernel, screen passes) so far."""
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
