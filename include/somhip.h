@@ -219,6 +219,12 @@ int som_set_verify(som_handle* h, int32_t n_rows);
 int som_verify_stats(som_handle* h, int64_t* launches, int64_t* rows_checked);
 int som_debug_corrupt_operands(som_handle* h, int32_t which);
 
+/* measurement hook: ONE v_mfma_f32_16x16x32 (_f16 when is_f16, else _bf16) on the caller's operands -- a [16][32] and
+ * b [32][16] as 16-bit patterns, c and d [16][16] float32, row-major.  tests/test_gpu_exact.py uses it to measure the
+ * rounding error the exact mode's bound charges per MFMA (the hardware's internal summation is not documented). */
+int som_debug_mfma16(som_handle* h, const uint16_t* a_host, const uint16_t* b_host, const float* c_host, float* d_host,
+                     int32_t is_f16);
+
 /* precision EXACT bookkeeping: rows screened so far, rows that went to the float32 fallback kernel, screen passes */
 int som_exact_stats(som_handle* h, int64_t* rows, int64_t* rows_fallback, int64_t* passes);
 /* candidate groups per row of the LAST screen pass (its first n rows): how many 64-unit groups the re-score visited */

@@ -191,3 +191,38 @@ def test_exact_class_surface():
     assert a.winner(data) == b.winner(data)
     assert a.quantization_error(data) == b.quantization_error(data)
     assert a.topographic_error(data) == b.topographic_error(data)
+
+
+def test_the_mfma_rounding_the_bound_charges_for_is_measured():
+    """exact_bound() charges KAPPA = 6 ulps (of the largest magnitude among accumulator, result and sum of |products|) per
+    v_mfma_f32_16x16x32: the hardware's internal summation order and width are not documented, so the number is
+    MEASURED here (som_debug_mfma16: one MFMA on given operands against float64) over operand scales, accumulators
+    from 0 to 2^37, cancelling and non-cancelling products, IEEE half and bfloat16.  Observed <= 2.4; fail above 3."""
+    e = engine(4, 4, 4, precision="f32")
+    rs = np.random.RandomState(0)
+    worst = 0.0
+    for trial in range(1500):
+        f16 = trial % 2 == 0
+        a = rs.randn(16, 32) * 2.0 ** rs.randint(-6, 12)
+        b = rs.randn(32, 16) * 2.0 ** rs.randint(-6, 12)
+        if trial % 5 == 1:
+            a[:, 2:] = 0
+        if trial % 5 == 2:
+            a, b = np.abs(a), np.abs(b)
+        if f16:
+            a16, b16 = a.astype(np.float16), b.astype(np.float16)
+            av, bv = a16.astype(np.float64), b16.astype(np.float64)
+        else:                                             # bfloat16: the upper half of the float32 pattern (truncated)
+            a16 = (a.astype(F32).view(np.uint32) >> 16).astype(np.uint16)
+            b16 = (b.astype(F32).view(np.uint32) >> 16).astype(np.uint16)
+            av = (a16.astype(np.uint32) << 16).view(F32).astype(np.float64)
+            bv = (b16.astype(np.uint32) << 16).view(F32).astype(np.float64)
+        cs = [0.0, 1.0, 2.0 ** 10, 2.0 ** 20, 2.0 ** 30, 2.0 ** 37][rs.randint(0, 6)]
+        c = ((rs.rand(16, 16) + 0.5) * cs * (1 if trial % 7 else -1)).astype(F32)
+        d = e.debug_mfma16(a16, b16, c, f16=f16)
+        ex = av @ bv + c.astype(np.float64)
+        mag = np.maximum(np.maximum(np.abs(c.astype(np.float64)), np.abs(ex)), np.abs(av) @ np.abs(bv))
+        ulp = 2.0 ** (np.floor(np.log2(np.maximum(mag, 1e-300))) - 23)
+        worst = max(worst, float((np.abs(d.astype(np.float64) - ex) / ulp).max()))
+    e.close()
+    assert worst <= 3.0, worst

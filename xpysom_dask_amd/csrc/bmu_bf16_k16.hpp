@@ -173,7 +173,8 @@ __global__ __launch_bounds__(64 * KS32) void merge_prep_k16_kernel(float* __rest
 #define SOM_K16_MINWAVES 2
 #endif
 // GM (precision 'exact', bmu_exact.hpp): besides the row's best key the kernel writes, per stage (= one GROUP of 64
-// units) and row, the smallest value it saw there: gmin[stage * gm_stride + row] (value bits, index bits cleared).  A
+// units) and row, the smallest value it saw there: gmin[stage * gm_stride + row] (plain value bits: this instance
+// keeps no unit indices at all -- out64's lower half is meaningless, the float32 re-score names the unit).  A
 // lane holds its quad's minimum for each of the wave's 4 sample blocks; three v_permlane*_swap + v_min steps transpose
 // and reduce so that quad q ends with the full minimum of sample block q -- lane l then owns row wave_s0 + l, and the
 // wave stores 256 contiguous bytes per stage.
@@ -229,6 +230,16 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
         }
         return;
 #endif
+        if (GM) {
+            // the exact mode's screen needs VALUES only (the row minimum and the groups' minima): which unit holds
+            // them is decided by the float32 re-score.  Two v_min3 per tile and sample block, no key packing.
+#pragma unroll
+            for (int sb = 0; sb < K16_SB; ++sb) {
+                cbest[sb] = min(min(cbest[sb], __float_as_uint(acc[sb][0])), __float_as_uint(acc[sb][1]));
+                cbest[sb] = min(min(cbest[sb], __float_as_uint(acc[sb][2])), __float_as_uint(acc[sb][3]));
+            }
+            return;
+        }
 #pragma unroll
         for (int sb = 0; sb < K16_SB; ++sb) {
 #if defined(SOM_K16_EXPERIMENT) && SOM_K16_EXPERIMENT == 2
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
             auto b = __builtin_amdgcn_permlane16_swap(cbest[K16_SB > 2 ? 2 : 0], cbest[K16_SB > 3 ? 3 : 0], false, false);
             const uint32_t t23 = min(b[0], b[1]);         // quads: (v2 q01, v3 q01, v2 q23, v3 q23)
             auto c = __builtin_amdgcn_permlane32_swap(t01, t23, false, false);
-            const uint32_t full = min(c[0], c[1]) & ~IDX_MASK;   // quads: (v0, v1, v2, v3), each over all four quads
+            const uint32_t full = min(c[0], c[1]);         // quads: (v0, v1, v2, v3), each over all four quads
             gmin[(long)stage * gm_stride + wave_s0 + lane] = full;
         }
 #pragma unroll
@@ -323,6 +334,7 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
         uint32_t unit = (uint32_t)gstage[sb] * K16_STAGE_UNITS + (code >> 2) * 16 + quad * 4 + (code & 3);
         // all distances are positive floats: (value bits, unit) orders as one unsigned 64-bit key
         unsigned long long comp = ((unsigned long long)(gbest[sb] & ~IDX_MASK) << 32) | unit;
+        if (GM) comp = (unsigned long long)gbest[sb] << 32;   // the plain minimum, every bit of it (no indices kept)
         unsigned long long o = __shfl_xor(comp, 16, 64);
         if (o < comp) comp = o;
         o = __shfl_xor(comp, 32, 64);

@@ -32,8 +32,9 @@
 //                    is bounded by ub^2 (3 + 5 ub) A.
 //   screen, accumulation: the initial accumulator fl(B + wsq/2) and 3 * ceil(D/32) chained MFMAs, each charged KAPPA
 //                    ulps of the largest magnitude the accumulator can take, Bm = 2.01 B + max wsq / 2 (the hardware's
-//                    internal summation is not documented; tests/test_gpu_exact.py measures it at <= 1 ulp), plus the
-//                    8 ulps the index bits packed into the key's low mantissa bits hide.
+//                    internal summation is not documented; tests/test_gpu_exact.py measures it through
+//                    som_debug_mfma16 at <= 2.4 ulps and fails above 3; KAPPA = 6), plus, in the split-bf16 screen, the
+//                    8 ulps its index bits packed into the key's low mantissa bits hide (the half screen keeps values only).
 //   screen on IEEE half operands in ONE pass (the default; the split-bf16 screen is kept for A/B): rows and units are
 //                    first scaled by powers of two (ex_scale: the longest norm lands in [2^13, 2^14), exact), then
 //                    rounded to float16.  The operand error is MEASURED, not assumed: the preparation kernels know
@@ -454,6 +455,31 @@ __global__ __launch_bounds__(256) void verify_pick_rows_kernel(long N, int n, co
     const long r = (long)i * (N / n) + (N / n) / 2;        // n strided rows, mid-stride
     rows[i] = (int)r;
     picks[i] = ids[r];
+}
+
+// ---- measurement hook (som_debug_mfma16): ONE v_mfma_f32_16x16x32 on caller-supplied operands, so that a test can
+// put a number on what exact_bound() charges per MFMA (KAPPA ulps of the accumulator's magnitude): the hardware's
+// internal summation of the 32 products and the accumulator is not documented.
+// A [16][32] (row = output row), B [32][16] (column = output column), C / D [16][16], all row-major; one wave.
+template <class EL>
+__global__ __launch_bounds__(64) void debug_mfma16_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+                                                          const float* __restrict__ Cin, float* __restrict__ Dout) {
+    using E = typename EL::T;
+    using v8 = typename V8<E>::t;
+    const int lane = threadIdx.x, col = lane & 15, quad = lane >> 4;
+    v8 a, b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint16_t ua = A[col * 32 + quad * 8 + j], ub = B[(quad * 8 + j) * 16 + col];
+        a[j] = __builtin_bit_cast(E, ua);
+        b[j] = __builtin_bit_cast(E, ub);
+    }
+    f32x4 c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = Cin[(quad * 4 + r) * 16 + col];
+    const f32x4 d = mfma16(a, b, c);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Dout[(quad * 4 + r) * 16 + col] = d[r];
 }
 
 // wn = wsq (the float32 kernel's own |w|^2) and its maximum: the screen's initial accumulator then carries the same

@@ -271,6 +271,17 @@ class HipEngine:
         """TEST HOOK of the canary: zero the operand images behind the library's back (1: 16-bit, 2: float32)."""
         self._check(self._lib.som_debug_corrupt_operands(self._h, int(which)))
 
+    def debug_mfma16(self, a, b, c, f16=True):
+        """Measurement hook: d = a (16x32) . b (32x16) + c (16x16) by ONE 16x16x32 MFMA; a, b float16 (or bfloat16 bit
+        patterns as uint16 when f16=False), c float32."""
+        a = np.ascontiguousarray(a).view(np.uint16).reshape(16, 32)
+        b = np.ascontiguousarray(b).view(np.uint16).reshape(32, 16)
+        c = np.ascontiguousarray(c, dtype=np.float32).reshape(16, 16)
+        d = np.empty((16, 16), dtype=np.float32)
+        self._check(self._lib.som_debug_mfma16(self._h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
+                                               self._fp(c), self._fp(d), int(bool(f16))))
+        return d
+
     def exact_stats(self):
         """precision 'exact': (rows screened, rows sent to the float32 fallback kernel, screen passes) so far."""
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
