@@ -51,6 +51,36 @@ __device__ __forceinline__ float half_operand_error(float f, float fb) {
     return (a > 0.0f && a < 6.103515625e-05f) ? __builtin_fabsf(f) : __builtin_fabsf(f - fb);
 }
 
+// The exact mode's per-row error bound E(n) (derivation: bmu_exact.hpp), in scaled d' units:
+//   E(n) = S (cA |x_n| wmax + cW wmax^2 + cB Bm) + cM (xerr_n w^max + (x^_n + xerr_n) werr),   S = sx sw.
+// The screen (which group minima can still matter) and the scan (which do) evaluate it through this one function.
+struct ExactBound {
+    float cA, cW, cB, cM;
+};
+struct ExactScales {                  // per launch: from max|x|^2, max|w|^2, max_k |w^_k - w~_k|^2
+    float sx, sw, wm, bmag, we;
+};
+__device__ __forceinline__ ExactScales ex_scales(const float* __restrict__ xmax2, const float* __restrict__ wmax2,
+                                                 const float* __restrict__ werr2) {
+    ExactScales s;
+    s.sx = ex_scale(*xmax2);
+    s.sw = ex_scale(*wmax2);
+    s.wm = __builtin_sqrtf(*wmax2) * (1.0f + 1.0f / 1024.0f);
+    const float big = __builtin_sqrtf(*wmax2) * __builtin_sqrtf(*xmax2) * (1.0f + 1.0f / 1024.0f);   // prep_wsqh_kernel's B
+    s.bmag = 2.01f * big + 0.5f * s.wm * s.wm;
+    s.we = __builtin_sqrtf(*werr2) * (1.0f + 1.0f / 1024.0f);
+    return s;
+}
+// E(n), or a NaN for a row / codebook the bound does not cover (NaN or infinite norms; norms so small that float32
+// products may underflow): such a row selects nothing and goes to the float32 kernel
+__device__ __forceinline__ float ex_row_bound(const ExactBound& eb, const ExactScales& s, float xsq, float xerr) {
+    const float xn = __builtin_sqrtf(xsq) * (1.0f + 1.0f / 1024.0f);
+    const float e = s.sx * s.sw * (eb.cA * xn * s.wm + eb.cW * s.wm * s.wm + eb.cB * s.bmag) +
+                    eb.cM * (xerr * s.sw * s.wm + (s.sx * xn + xerr) * s.we);
+    const bool ok = e > 0.0f && e < 3.0e38f && xn * s.wm > 1.0e-20f && s.wm * s.wm > 1.0e-20f;
+    return ok ? e : __builtin_nanf("");
+}
+
 // |w~|^2 of every unit (bf16-rounded values) and its maximum over the codebook
 template <class EL = Bf16>
 __global__ __launch_bounds__(256) void prep_wnorm_kernel(const float* __restrict__ W, int K, int D,

@@ -172,17 +172,26 @@ __global__ __launch_bounds__(64 * KS32) void merge_prep_k16_kernel(float* __rest
 #ifndef SOM_K16_MINWAVES
 #define SOM_K16_MINWAVES 2
 #endif
-// GM (precision 'exact', bmu_exact.hpp): besides the row's best key the kernel writes, per stage (= one GROUP of 64
-// units) and row, the smallest value it saw there: gmin[stage * gm_stride + row] (plain value bits: this instance
-// keeps no unit indices at all -- out64's lower half is meaningless, the float32 re-score names the unit).  A
-// lane holds its quad's minimum for each of the wave's 4 sample blocks; three v_permlane*_swap + v_min steps transpose
-// and reduce so that quad q ends with the full minimum of sample block q -- lane l then owns row wave_s0 + l, and the
-// wave stores 256 contiguous bytes per stage.
+// GM (precision 'exact', bmu_exact.hpp): the kernel keeps VALUES only -- the row minimum (out64's upper half; no unit
+// indices exist in this instance, the float32 re-score names the unit) and, per stage (= one GROUP of 64 units) and row,
+// the group's minimum.  A lane holds its quad's minimum for each of the wave's 4 sample blocks; three v_permlane*_swap +
+// v_min steps transpose and reduce so that quad q ends with the full minimum of sample block q -- lane l then owns row
+// wave_s0 + l.  A group minimum can only matter to the scan if it is within the row's bound E of the FINAL row minimum,
+// hence of the minimum so far: only those are stored (gmin[stage * gm_stride + row], exec-masked), and every wave and
+// stage leaves the 64-bit mask of the lanes it stored in gflags[stage * (gm_stride / 64) + row / 64] -- on a random
+// codebook ~2 % of the matrix is written and read, on the smoothest maps 10-25 %.
 template <int KS32, class EL = Bf16, bool GM = false>
 __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
                                                               const char* __restrict__ Wst, int n_stages, int K,
                                                               unsigned long long* __restrict__ out64,
-                                                              uint32_t* __restrict__ gmin = nullptr, long gm_stride = 0) {
+                                                              uint32_t* __restrict__ gmin = nullptr, long gm_stride = 0,
+                                                              unsigned long long* __restrict__ gflags = nullptr,
+                                                              const float* __restrict__ xsq = nullptr,
+                                                              const float* __restrict__ xerr = nullptr,
+                                                              const float* __restrict__ xmax2 = nullptr,
+                                                              const float* __restrict__ wmax2 = nullptr,
+                                                              const float* __restrict__ werr2 = nullptr,
+                                                              ExactBound eb = ExactBound()) {
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     constexpr int DP = 32 * KS32;
@@ -214,6 +223,12 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
         for (int r = 0; r < 4; ++r) accP[sb][r] = __builtin_inff();
     }
 
+    float run_min = __builtin_inff(), row_e = 0.0f;       // GM: lane l <-> row wave_s0 + l: its minimum so far, its bound E
+    if (GM) {
+        const long r = wave_s0 + lane;
+        row_e = r < N ? ex_row_bound(eb, ex_scales(xmax2, wmax2, werr2), xsq[r], xerr[r]) : __builtin_nanf("");
+        if (!(row_e == row_e)) row_e = __builtin_inff();   // a row the bound does not cover: keep everything (the scan drops it)
+    }
     // this workgroup's share of the codebook stages
     const int s_begin = (int)((long)n_stages * blockIdx.y / gridDim.y);
     const int s_end = (int)((long)n_stages * (blockIdx.y + 1) / gridDim.y);
@@ -265,7 +280,12 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
             const uint32_t t23 = min(b[0], b[1]);         // quads: (v2 q01, v3 q01, v2 q23, v3 q23)
             auto c = __builtin_amdgcn_permlane32_swap(t01, t23, false, false);
             const uint32_t full = min(c[0], c[1]);         // quads: (v0, v1, v2, v3), each over all four quads
-            gmin[(long)stage * gm_stride + wave_s0 + lane] = full;
+            const float f = __uint_as_float(full);         // (positive, or a NaN pattern: compares false, never kept)
+            const bool keep = f <= run_min + row_e;
+            run_min = __builtin_fminf(run_min, f);
+            if (keep) gmin[(long)stage * gm_stride + wave_s0 + lane] = full;
+            const unsigned long long mask = __ballot(keep);
+            if (lane == 0) gflags[(long)stage * (gm_stride >> 6) + (wave_s0 >> 6)] = mask;
         }
 #pragma unroll
         for (int sb = 0; sb < K16_SB; ++sb) {

@@ -91,16 +91,10 @@ __global__ __launch_bounds__(256) void prep_x_bf16x3_kernel(const float* __restr
     if (lane == 0) atomic_max_pos_f32(xmax2, s);
 }
 
-// GM (precision 'exact', bmu_exact.hpp): besides the row's best key the kernel writes, per GROUP of 64 units (two
-// stages) and row, the smallest value it saw in that group: gmin[group * gm_stride + row] (value bits with the index
-// bits cleared, as in out64's upper half).  The codebook parts then split on group boundaries.  Cost: two
-// v_permlane*_swap joins of the four lane quads and one 128-byte store per wave and group.
-template <int KS32, class EL = Bf16, bool GM = false>
+template <int KS32, class EL = Bf16>
 __global__ __launch_bounds__(64 * K3_NW, 2) void bmu_bf16_k16x3_kernel(const __bf16* __restrict__ Xb, long N,
                                                                        const char* __restrict__ Wst, int n_stages, int K,
-                                                                       unsigned long long* __restrict__ out64,
-                                                                       uint32_t* __restrict__ gmin = nullptr,
-                                                                       long gm_stride = 0) {
+                                                                       unsigned long long* __restrict__ out64) {
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     constexpr int DP = 32 * KS32;
@@ -136,18 +130,10 @@ __global__ __launch_bounds__(64 * K3_NW, 2) void bmu_bf16_k16x3_kernel(const __b
         for (int r = 0; r < 4; ++r) accP[sb][r] = __builtin_inff();
     }
 
-    int s_begin = (int)((long)n_stages * blockIdx.y / gridDim.y);
-    int s_end = (int)((long)n_stages * (blockIdx.y + 1) / gridDim.y);
-    if (GM) {                                            // parts of whole groups (pairs of stages)
-        const int n_groups = (n_stages + 1) / 2;
-        s_begin = 2 * (int)((long)n_groups * blockIdx.y / gridDim.y);
-        s_end = min(2 * (int)((long)n_groups * (blockIdx.y + 1) / gridDim.y), n_stages);
-    }
+    const int s_begin = (int)((long)n_stages * blockIdx.y / gridDim.y);
+    const int s_end = (int)((long)n_stages * (blockIdx.y + 1) / gridDim.y);
     for (int p = wave; p < PIECES; p += K3_NW)
         lds_dma_16(Wst + (long)s_begin * STAGE + (long)p * 1024 + lane * 16, smem + p * 1024);
-    uint32_t pmin[K3_SB];                                // GM: this lane's minimum over the group so far
-#pragma unroll
-    for (int sb = 0; sb < K3_SB; ++sb) pmin[sb] = 0xFFFFFFFFu;
 
     auto reduce_tile = [&](const f32x4 (&acc)[K3_SB], int t16) {
 #pragma unroll
@@ -160,25 +146,6 @@ __global__ __launch_bounds__(64 * K3_NW, 2) void bmu_bf16_k16x3_kernel(const __b
         }
     };
     auto fold_stage = [&](int stage) {
-        if (GM && stage >= s_begin) {
-#pragma unroll
-            for (int sb = 0; sb < K3_SB; ++sb) pmin[sb] = min(pmin[sb], cbest[sb]);
-            if ((stage & 1) || stage == s_end - 1) {      // the group is complete: join the four lane quads, store
-                static_assert(!GM || K3_SB == 2, "the group-minimum store pairs two 16-sample blocks per wave");
-                uint32_t v[K3_SB];
-#pragma unroll
-                for (int sb = 0; sb < K3_SB; ++sb) {
-                    const uint32_t m = pmin[sb] & ~IDX_MASK;
-                    const auto a = __builtin_amdgcn_permlane32_swap(m, m, false, false);
-                    const uint32_t m2 = min(a[0], a[1]);
-                    const auto b = __builtin_amdgcn_permlane16_swap(m2, m2, false, false);
-                    v[sb] = min(b[0], b[1]);
-                    pmin[sb] = 0xFFFFFFFFu;
-                }
-                // lanes 0..15: sample block 0, lanes 16..31: sample block 1 = 32 consecutive rows
-                if (lane < 32) gmin[(long)(stage >> 1) * gm_stride + wave_s0 + lane] = quad == 0 ? v[0] : v[K3_SB - 1];
-            }
-        }
 #pragma unroll
         for (int sb = 0; sb < K3_SB; ++sb) {
             if (cbest[sb] < gbest[sb]) { gbest[sb] = cbest[sb]; gstage[sb] = stage; }

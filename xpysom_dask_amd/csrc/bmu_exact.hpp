@@ -57,14 +57,6 @@ constexpr int EX_PAIRS = 64;          // capacity of a pass: this many (row, gro
 constexpr int EX_SCAN_SPLIT = 4;      // waves that share a row's groups in the scan
 constexpr int EX_TR = 128;            // rows per re-score tile (4 waves x 32 rows against one 64-unit group)
 
-// E(n) = S (cA |x_n| wmax + cW wmax^2 + cB Bm) [+ cM (xerr_n w^max + (x^_n + xerr_n) werr)]   in (scaled) d' units;
-// S = sx sw = the power-of-two operand scales of the half-precision screen (1 for the split-bf16 screen: scaled == 0,
-// whose operand error is inside cA); xerr_n, werr: the MEASURED rounding errors |x^_n - x~_n|, max_k |w^_k - w~_k|
-struct ExactBound {
-    float cA, cW, cB, cM;
-    int scaled;
-};
-
 // Small per-pass counters, one allocation, zeroed by one memset before the scan:
 //   [0, n_groups)             gcount: (row, group) pairs per group
 //   [n_groups, 2 n_groups)    gfill:  fill cursor of the group's row list
@@ -84,12 +76,16 @@ __device__ __forceinline__ int ex_bit_counts(uint32_t bits, int lane) {
     return c;
 }
 
-// gmin [n_groups][gm_stride] -> hit bits bm [n_words][gm_stride] (bit b of word w of a row: group 32 w + b is a
-// candidate) and gcount [n_groups].  Block = 64 consecutive rows x EX_SCAN_SPLIT word ranges.  The 64 lanes of a wave
-// test the SAME group at the same time, so a group's hits are counted with one atomic per wave and word (smooth maps
-// send most rows to the same few groups: one address would otherwise take an add per row).
-__global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_scan_kernel(const uint32_t* __restrict__ gmin, long gm_stride,
-                                                                       int n_groups, long N,
+// (gmin [n_groups][gm_stride], gflags [n_groups][gm_stride / 64]) -> hit bits bm [n_words][gm_stride] (bit b of word w of a
+// row: group 32 w + b is a candidate) and gcount [n_groups].  Block = 64 consecutive rows x EX_SCAN_SPLIT word ranges.
+// The screen stored only the group minima within E of the row minimum SO FAR and left, per stage and 64 rows, the mask
+// of the rows it stored (one 8-byte word a wave reads with a scalar load): the scan looks at a group only where some
+// row of its 64 has the bit, loads only those rows' values, and keeps the ones within E of the FINAL row minimum.  The
+// 64 lanes of a wave test the SAME group at the same time, so a group's hits are counted with one atomic per wave, word
+// and group (smooth maps send most rows to the same few groups: one address would otherwise take an add per row).
+__global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_scan_kernel(const uint32_t* __restrict__ gmin,
+                                                                       const unsigned long long* __restrict__ gflags,
+                                                                       long gm_stride, int n_groups, long N,
                                                                        const unsigned long long* __restrict__ best64,
                                                                        const float* __restrict__ xsq,
                                                                        const float* __restrict__ wmax2,
@@ -98,55 +94,47 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_scan_kernel(const ui
                                                                        const float* __restrict__ werr2,
                                                                        uint32_t* __restrict__ bm, int* __restrict__ gcount) {
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const long row = (long)blockIdx.x * 64 + lane;
+    const long row0 = (long)blockIdx.x * 64;
+    const long row = row0 + lane;
     const bool live = row < N;
     const long r = live ? row : 0;
-    const float wm = __builtin_sqrtf(*wmax2) * (1.0f + 1.0f / 1024.0f);
-    const float big = __builtin_sqrtf(*wmax2) * __builtin_sqrtf(*xmax2) * (1.0f + 1.0f / 1024.0f);   // prep_wsqh_kernel's B
-    const float bmag = 2.01f * big + 0.5f * wm * wm;
-    const float xn = __builtin_sqrtf(xsq[r]) * (1.0f + 1.0f / 1024.0f);
+    const float e = ex_row_bound(eb, ex_scales(xmax2, wmax2, werr2), xsq[r], xerr[r]);
     const float m = __uint_as_float((uint32_t)(best64[r] >> 32));
-    const float sx = eb.scaled ? ex_scale(*xmax2) : 1.0f, sw = eb.scaled ? ex_scale(*wmax2) : 1.0f;
-    float e = sx * sw * (eb.cA * xn * wm + eb.cW * wm * wm + eb.cB * bmag);
-    if (eb.scaled) {                                       // one-pass screen: its operands' measured rounding errors
-        const float xe = xerr[r], we = __builtin_sqrtf(*werr2) * (1.0f + 1.0f / 1024.0f);
-        e += eb.cM * (xe * sw * wm + (sx * xn + xe) * we);
-    }
     const float thr_f = m + e;
-    // A threshold that is not a finite positive number (NaN / infinite row or norms) selects nothing, and neither
-    // does a row or codebook so small that float32 products may underflow (the bound assumes none do): fallback.
-    const bool ok = live && thr_f > 0.0f && thr_f < 3.0e38f && xn * wm > 1.0e-20f && wm * wm > 1.0e-20f;
+    // a threshold that is not a finite positive number (a row the bound does not cover, a NaN minimum) selects nothing
+    const bool ok = live && thr_f > 0.0f && thr_f < 3.0e38f;
     // unsigned compare on the bit patterns: every d' is a positive float, a NaN pattern is above every threshold
     const uint32_t thr = ok ? __float_as_uint(thr_f) : 0u;
     const int n_words = (n_groups + 31) / 32;
     const int w0 = (int)((long)n_words * part / EX_SCAN_SPLIT), w1 = (int)((long)n_words * (part + 1) / EX_SCAN_SPLIT);
+    const unsigned long long* fl = gflags + (row0 >> 6);
+    const long fstride = gm_stride >> 6;
     const uint32_t* src = gmin + r;
-    for (int wc = w0; wc < w1; wc += 8) {                 // 8 words = 256 groups at a time
-        uint32_t bits[8];
+    for (int w = w0; w < w1; ++w) {
+        uint32_t bits = 0;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) {                     // streaming half: loads and compares only
-            bits[w] = 0;
-            if (wc + w >= w1) continue;                   // (uniform)
+        for (int b8 = 0; b8 < 32; b8 += 8) {               // eight groups at a time: their loads are in flight together
+            unsigned long long stored[8];
 #pragma unroll
-            for (int b8 = 0; b8 < 32; b8 += 8) {
-                uint32_t v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int g = 32 * (wc + w) + b8 + q;
-                    v[q] = g < n_groups ? src[(long)g * gm_stride] : 0xFFFFFFFFu;
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) bits[w] |= (uint32_t)(v[q] <= thr) << (b8 + q);
+            for (int q = 0; q < 8; ++q) {
+                const int g = 32 * w + b8 + q;
+                stored[q] = g < n_groups ? fl[(long)g * fstride] : 0ull;   // (wave-uniform: scalar loads)
             }
-            if (!ok) bits[w] = 0;
-            if (live) bm[(long)(wc + w) * gm_stride + row] = bits[w];
-        }
+            uint32_t v[8];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) {                     // the groups' populations: one add per wave, word and group
-            if (__ballot(bits[w] != 0) == 0) continue;
-            const int c = ex_bit_counts(bits[w], lane);
-            if (lane < 32 && c > 0) atomicAdd(gcount + 32 * (wc + w) + lane, c);
+            for (int q = 0; q < 8; ++q) {
+                const int g = 32 * w + b8 + q;
+                v[q] = 0xFFFFFFFFu;
+                if ((stored[q] >> lane) & 1ull) v[q] = src[(long)g * gm_stride];   // (only the rows the screen stored)
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bits |= (uint32_t)(v[q] <= thr) << (b8 + q);
         }
+        if (!ok) bits = 0;
+        if (live) bm[(long)w * gm_stride + row] = bits;
+        if (__ballot(bits != 0) == 0) continue;
+        const int c = ex_bit_counts(bits, lane);       // the groups' populations: one add per wave, word and group
+        if (lane < 32 && c > 0) atomicAdd(gcount + 32 * w + lane, c);
     }
 }
 

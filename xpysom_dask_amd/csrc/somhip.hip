@@ -67,9 +67,9 @@ struct som_handle {
     bool f16 = false;        // precision f16 / f16x3: _Float16 operands instead of __bf16 (the same kernels, som_common.hpp)
     bool x3res = false;      // bf16x3 with input_len <= 128: the register-resident split kernel (bmu_bf16_k16x3.hpp)
     bool exact = false;      // precision 'exact': MFMA screen + float32 re-score of the candidates (bmu_exact.hpp)
-    bool ex_x3 = false;      //   its screen: the split-bf16 kernel (SOM_EXACT_SCREEN=x3) instead of one pass on scaled IEEE half operands
     struct ExactScratch {
-        uint32_t* gmin = nullptr;            // [n_groups][stride] group minima of the chunk being screened
+        uint32_t* gmin = nullptr;            // [n_groups][stride] group minima of the chunk being screened (sparse: see gflags)
+        unsigned long long* gflags = nullptr;   // [n_groups][stride / 64] which rows' minima the screen stored
         long stride = 0;                     //   rows per group line (a chunk of the row set, padded)
         uint32_t* bm = nullptr;              // [n_words][stride] hit bits: group 32 w + b is a candidate of the row
         int *fb_list = nullptr, *fb_ids = nullptr;
@@ -345,11 +345,8 @@ int prep_codebook_half(som_handle* h) {
         default: return fail(h, "the split resident kernel supports input_len <= 128");
         }
         HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
-        if (h->exact)                                     // the float32 kernel's own |w|^2 (refreshed just before)
-            exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(h->K, 256)), block, 0, h->stream>>>(h->wsq, h->K, h->wn, h->wmax2);
-        else
-            rownorm_bf16_kernel<E><<<dim3((unsigned)cdiv(h->K, 4)), block, 0, h->stream>>>(   // exact float32 |w|^2
-                h->W, h->K, h->D, unit, unit != nullptr, h->wn, h->wmax2, 1);
+        rownorm_bf16_kernel<E><<<dim3((unsigned)cdiv(h->K, 4)), block, 0, h->stream>>>(   // exact float32 |w|^2
+            h->W, h->K, h->D, unit, unit != nullptr, h->wn, h->wmax2, 1);
         return 0;
     }
     const long total = (long)h->n_stages * K16_T * h->ks32 * 64;
@@ -800,22 +797,17 @@ int launch_bmu_pairwise(som_handle* h, const float* X, long N, int p, bool even,
 // E(n) = cA |x_n| wmax + cW wmax^2 + cB Bm in d' units; derivation in bmu_exact.hpp.  KAPPA ulps are charged per MFMA.
 constexpr double EX_KAPPA = 6.0;     // measured through som_debug_mfma16: <= 2.4 (tests/test_gpu_exact.py holds it below 3)
 ExactBound exact_bound(const som_handle* h) {
-    const double u = std::ldexp(1.0, -24), ub = h->f16 ? std::ldexp(1.0, -11) : std::ldexp(1.0, -8);
+    const double u = std::ldexp(1.0, -24);
     const double Dl = 8.0 * h->fr_kg;                    // chain length of the float32 kernel (zero padded)
     const double gamma = Dl * u / (1.0 - Dl * u);
     const double slop = 1.01;                             // the kernel evaluates E in float32
     const double e32 = (2.0 * gamma + 2.0 * u) * (1.0 + u);   // float32 kernel, relative to A (tau units)
     ExactBound eb{};
     eb.cW = (float)(slop * u);
-    if (h->ex_x3) {                                       // split screen: hi.hi + lo.hi + hi.lo, three MFMA chains
-        eb.cA = (float)(slop * (e32 + 2.0 * ub * ub * (3.0 + 5.0 * ub)));
-        eb.cB = (float)(slop * 2.0 * (EX_KAPPA * 3.0 * h->ks32 + 9.0) * std::ldexp(1.0, -23));
-    } else {                                              // one pass on scaled half operands: measured operand errors
-        eb.cA = (float)(slop * e32);
-        eb.cB = (float)(slop * 2.0 * (EX_KAPPA * h->ks32 + 1.0) * std::ldexp(1.0, -23));   // (+1: the initial accumulator's rounding; no index bits)
-        eb.cM = (float)(slop * 2.0);
-        eb.scaled = 1;
-    }
+    // one pass on scaled half operands, measured operand errors (bmu_exact.hpp); +1: the initial accumulator's rounding
+    eb.cA = (float)(slop * e32);
+    eb.cB = (float)(slop * 2.0 * (EX_KAPPA * h->ks32 + 1.0) * std::ldexp(1.0, -23));
+    eb.cM = (float)(slop * 2.0);
     if (const char* e = std::getenv("SOM_EXACT_BOUND_SCALE")) {   // experiments: how the candidate load grows with the band
         const float f = (float)std::atof(e);
         if (f > 1.0f) { eb.cA *= f; eb.cW *= f; eb.cB *= f; eb.cM *= f; }
@@ -835,13 +827,14 @@ int exact_reserve(som_handle* h, long rows) {
     auto& ex = h->ex;
     const long stride = round_up(std::min(rows, exact_chunk_rows(h)), 256);
     if (stride <= ex.stride) return 0;
-    void* old[] = {ex.gmin, ex.bm, ex.fb_list, ex.plist, ex.tile_tab};
+    void* old[] = {ex.gmin, ex.gflags, ex.bm, ex.fb_list, ex.plist, ex.tile_tab};
     for (void* p : old) if (p) (void)hipFree(p);
-    ex.gmin = nullptr; ex.bm = nullptr; ex.fb_list = nullptr; ex.plist = nullptr; ex.tile_tab = nullptr;
+    ex.gmin = nullptr; ex.gflags = nullptr; ex.bm = nullptr; ex.fb_list = nullptr; ex.plist = nullptr; ex.tile_tab = nullptr;
     ex.stride = 0;
     const long n_groups = cdiv(h->K, EX_GROUP);
     if (stride * EX_PAIRS > 0x7fffffffL) return fail(h, "exact: pass too large");
     if (int rc = dev_alloc(h, &ex.gmin, (size_t)n_groups * stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.gflags, (size_t)n_groups * (stride / 64))) return rc;
     if (int rc = dev_alloc(h, &ex.bm, (size_t)cdiv(n_groups, 32) * stride)) return rc;
     if (int rc = dev_alloc(h, &ex.plist, (size_t)stride * EX_PAIRS)) return rc;
     if (int rc = dev_alloc(h, &ex.fb_list, (size_t)stride)) return rc;
@@ -856,47 +849,34 @@ int exact_reserve(som_handle* h, long rows) {
 }
 
 template <int KS32, class E>
-int exact_screen(som_handle* h, const __bf16* Xb, long n, unsigned long long* best64) {
+int exact_screen(som_handle* h, const __bf16* Xb, long n, unsigned long long* best64, const float* xsq, const float* xerr,
+                 const float* xmax2, const ExactBound& eb) {
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
-    if (!h->ex_x3) {                                      // one pass on scaled half operands: a stage IS a group
-        auto kern = bmu_bf16_k16_kernel<KS32, E, true>;
-        size_t lds = 2 * (size_t)k16_stage_bytes(KS32);
-        int per_cu = 1;
-        if (int rc = kernel_per_cu(h, (const void*)kern, 64 * K16_NW, lds, &per_cu)) return rc;
-        const long blocks = cdiv(n, K16_WG_SAMPLES);
-        const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
-        int parts = choose_parts(h, blocks, slots, h->n_stages);
-        if (h->env_bf16_parts > 0) parts = std::min(h->env_bf16_parts, h->n_stages);
-        if (h->debug)
-            std::fprintf(stderr, "[somhip] exact screen (half): blocks=%ld per_cu=%d slots=%ld parts=%d groups=%d\n", blocks, per_cu,
-                         slots, parts, n_groups);
-        kern<<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * K16_NW), lds, h->stream>>>(Xb, n, h->Wst, h->n_stages, h->K, best64,
-                                                                                           h->ex.gmin, h->ex.stride);
-        return 0;
-    }
-    auto kern = bmu_bf16_k16x3_kernel<KS32, E, true>;
-    size_t lds = 2 * (size_t)k3_stage_bytes(KS32);
+    // one pass on scaled half operands: a stage IS a group
+    auto kern = bmu_bf16_k16_kernel<KS32, E, true>;
+    size_t lds = 2 * (size_t)k16_stage_bytes(KS32);
     int per_cu = 1;
-    if (int rc = kernel_per_cu(h, (const void*)kern, 64 * K3_NW, lds, &per_cu)) return rc;
-    const long blocks = cdiv(n, K3_WG_SAMPLES);
+    if (int rc = kernel_per_cu(h, (const void*)kern, 64 * K16_NW, lds, &per_cu)) return rc;
+    const long blocks = cdiv(n, K16_WG_SAMPLES);
     const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
-    int parts = choose_parts(h, blocks, slots, n_groups);
-    if (h->env_bf16_parts > 0) parts = std::min(h->env_bf16_parts, n_groups);
+    int parts = choose_parts(h, blocks, slots, h->n_stages);
+    if (h->env_bf16_parts > 0) parts = std::min(h->env_bf16_parts, h->n_stages);
     if (h->debug)
-        std::fprintf(stderr, "[somhip] exact screen (split): blocks=%ld per_cu=%d slots=%ld parts=%d groups=%d\n", blocks, per_cu,
+        std::fprintf(stderr, "[somhip] exact screen: blocks=%ld per_cu=%d slots=%ld parts=%d groups=%d\n", blocks, per_cu,
                      slots, parts, n_groups);
-    kern<<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * K3_NW), lds, h->stream>>>(Xb, n, h->Wst, h->n_stages, h->K, best64,
-                                                                                      h->ex.gmin, h->ex.stride);
+    kern<<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * K16_NW), lds, h->stream>>>(
+        Xb, n, h->Wst, h->n_stages, h->K, best64, h->ex.gmin, h->ex.stride, h->ex.gflags, xsq, xerr, xmax2, h->wmax2, h->wmax2 + 1, eb);
     return 0;
 }
 
 template <class E>
-int exact_screen_ks(som_handle* h, const __bf16* Xb, long n, unsigned long long* best64) {
+int exact_screen_ks(som_handle* h, const __bf16* Xb, long n, unsigned long long* best64, const float* xsq, const float* xerr,
+                    const float* xmax2, const ExactBound& eb) {
     switch (h->ks32) {
-    case 1: return exact_screen<1, E>(h, Xb, n, best64);
-    case 2: return exact_screen<2, E>(h, Xb, n, best64);
-    case 3: return exact_screen<3, E>(h, Xb, n, best64);
-    case 4: return exact_screen<4, E>(h, Xb, n, best64);
+    case 1: return exact_screen<1, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb);
+    case 2: return exact_screen<2, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb);
+    case 3: return exact_screen<3, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb);
+    case 4: return exact_screen<4, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb);
     }
     return fail(h, "exact: the screen kernel supports input_len <= 128");
 }
@@ -948,8 +928,8 @@ int exact_rescore(som_handle* h, const float* X, long n, unsigned long long* bes
 int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, const __bf16* Xb, const float* xmax2, int* out) {
     if (h->capturing) return fail(h, "precision 'exact' reads a counter back per pass: not capturable");
     if (!xsq) return fail(h, "exact: no row norms");
-    const float* xerr = h->ex_x3 ? nullptr : exact_err_of(h, xsq);
-    if (!h->ex_x3 && !xerr) return fail(h, "exact: unknown row-norm buffer");
+    const float* xerr = exact_err_of(h, xsq);
+    if (!xerr) return fail(h, "exact: unknown row-norm buffer");
     auto& ex = h->ex;
     if (int rc = exact_reserve(h, N)) return rc;
     if (N > h->best64_cap) {
@@ -960,7 +940,7 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     }
     const long units = (long)h->n_stages * h->stage_units;
     prep_wsqh_kernel<<<dim3((unsigned)cdiv(std::max(units, N), 256)), dim3(256), 0, h->stream>>>(
-        h->wn, h->K, h->wmax2, xmax2, h->Wst, h->n_stages, h->stage_bytes, h->stage_units, h->best64, N, h->ex_x3 ? 0 : 1);
+        h->wn, h->K, h->wmax2, xmax2, h->Wst, h->n_stages, h->stage_bytes, h->stage_units, h->best64, N, 1);
     const ExactBound eb = exact_bound(h);
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
     const long chunk = std::min(exact_chunk_rows(h), ex.stride);
@@ -969,11 +949,11 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         HIPCHK(h, hipMemsetAsync(ex.ctr, 0, (size_t)(2 * n_groups + 3) * sizeof(int), h->stream));
         {
             Timed ts(h, SOM_K_SCREEN);
-            if (int rc = SOM_HALF(h, exact_screen_ks, h, Xb + r0 * h->dp, n, h->best64 + r0)) return rc;
+            if (int rc = SOM_HALF(h, exact_screen_ks, h, Xb + r0 * h->dp, n, h->best64 + r0, xsq + r0, xerr + r0, xmax2, eb)) return rc;
         }
         exact_scan_kernel<<<dim3((unsigned)cdiv(n, 64)), dim3(64 * EX_SCAN_SPLIT), 0, h->stream>>>(
-            ex.gmin, ex.stride, n_groups, n, h->best64 + r0, xsq + r0, h->wmax2, xmax2, eb, xerr ? xerr + r0 : nullptr, h->wmax2 + 1,
-            ex.bm, ex.ctr);
+            ex.gmin, ex.gflags, ex.stride, n_groups, n, h->best64 + r0, xsq + r0, h->wmax2, xmax2, eb, xerr + r0, h->wmax2 + 1, ex.bm,
+            ex.ctr);
         if (int rc = exact_rescore(h, X + r0 * h->D, n, h->best64 + r0, out + r0)) return rc;
         HIPCHK(h, hipGetLastError());
         // rows the scheme could not settle (normally none): the float32 kernel itself
@@ -1424,11 +1404,10 @@ int som_create(const som_config* cfg, som_handle** out) {
     h->D1p = (int)round_up(h->D + 1, 4);
     h->norm_p = cfg->norm_p > 0 ? cfg->norm_p : 2;
     h->ks32 = (int)cdiv(h->D, 32);
-    if (h->exact) if (const char* e = std::getenv("SOM_EXACT_SCREEN")) h->ex_x3 = std::string(e) == "x3";   // A/B: the split-bf16 screen
-    h->x3 = cfg->precision == SOM_PREC_BF16X3 || cfg->precision == SOM_PREC_F16X3 || (h->exact && h->ex_x3);
-    h->f16 = cfg->precision == SOM_PREC_F16 || cfg->precision == SOM_PREC_F16X3 || (h->exact && !h->ex_x3);
+    h->x3 = cfg->precision == SOM_PREC_BF16X3 || cfg->precision == SOM_PREC_F16X3;
+    h->f16 = cfg->precision == SOM_PREC_F16 || cfg->precision == SOM_PREC_F16X3 || h->exact;   // (the exact mode's screen: IEEE half)
     h->x3res = h->x3 && h->D <= 128;
-    if (const char* e = std::getenv("SOM_X3_TILED")) if (std::atoi(e) != 0 && !h->exact) h->x3res = false;   // A/B: the tiled split kernel
+    if (const char* e = std::getenv("SOM_X3_TILED")) if (std::atoi(e) != 0) h->x3res = false;   // A/B: the tiled split kernel
     h->tiled = ((cfg->precision == SOM_PREC_BF16 || cfg->precision == SOM_PREC_F16) && h->D > 128) || (h->x3 && !h->x3res);
     if (h->tiled) {
         // 256 x 256 tiles need enough units to amortise them; SOM_BF16_TILE=128|256 overrides
@@ -1556,7 +1535,7 @@ void som_destroy(som_handle* h) {
         for (void* b : vb) if (b) (void)hipFree(b);
     }
     {
-        void* eb[] = {h->ex.gmin, h->ex.bm, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab};
+        void* eb[] = {h->ex.gmin, h->ex.gflags, h->ex.bm, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab};
         for (void* b : eb) if (b) (void)hipFree(b);
         if (h->ex.fb_count_host) (void)hipHostFree(h->ex.fb_count_host);
     }
