@@ -147,7 +147,8 @@ def pmc_traffic(workload, rows, precision, kernel, build_hash):
             if pm.get("rows_per_launch") != rows or pm.get("workload", "c3") != workload \
                     or pm.get("precision", "bf16") != precision or pm.get("library", "libsomhip.so") != "libsomhip.so":
                 continue                                   # (another workload, or a timing-experiment build)
-            k = next(v for name, v in pm.items() if name.startswith(kernel) and isinstance(v, dict))   # "<kernel><4>" too
+            k = next(v for name, v in pm.items() if name.startswith(kernel) and isinstance(v, dict) and
+                     (precision != "exact" or "F16" in name or "f16" in name))   # "<kernel><4>" too; exact: the IEEE-half screen instance
             cand = {"bytes": k["fabric_bytes_corrected"], "file": os.path.basename(path), "build": pm.get("build")}
         except Exception:
             continue
@@ -183,6 +184,7 @@ def main():
     ap.add_argument("--total-rows", type=int, default=STRONG_TOTAL_ROWS, help="strong scaling: rows of the whole job")
     ap.add_argument("--precision", default=None, choices=["exact", "bf16", "f32", "bf16x3", "f16", "f16x3"])
     ap.add_argument("--no-modes", action="store_true", help="skip the per-precision-mode block at batch 65 536")
+    ap.add_argument("--no-throughput-mode", action="store_true", help="skip the bf16 run beside the exact headline (profiling passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch65536", action="store_true")
     args = ap.parse_args()
@@ -315,7 +317,7 @@ def main():
 
     # the throughput mode beside the parity-grade headline: the same K epochs through the plain bf16 kernel
     thr = None
-    if args.precision == "exact" and FEATURES <= 128:
+    if args.precision == "exact" and FEATURES <= 128 and not args.no_throughput_mode:
         eng.close()
         e_t, dt_t = timed_run("bf16")
         t_ms, t_n = e_t.profile_get("bmu")

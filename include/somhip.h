@@ -225,6 +225,11 @@ int som_debug_corrupt_operands(som_handle* h, int32_t which);
 int som_debug_mfma16(som_handle* h, const uint16_t* a_host, const uint16_t* b_host, const float* c_host, float* d_host,
                      int32_t is_f16);
 
+/* diagnostic builds only (-DSOM_STAMPS, tools/stamps.py): out_host == NULL attaches a buffer of n_pairs (shader-clock
+ * ticks, 100 MHz ticks) pairs, one per workgroup of the next BMU launches (n_pairs == 0 detaches); out_host != NULL
+ * reads n_pairs pairs back.  The product build refuses both. */
+int som_debug_stamps(som_handle* h, int64_t n_pairs, uint64_t* out_host);
+
 /* precision EXACT bookkeeping: rows screened so far, rows that went to the float32 fallback kernel, screen passes */
 int som_exact_stats(som_handle* h, int64_t* rows, int64_t* rows_fallback, int64_t* passes);
 /* candidate groups per row of the LAST screen pass (its first n rows): how many 64-unit groups the re-score visited */

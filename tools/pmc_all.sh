@@ -5,7 +5,7 @@
 # tools/pmc_report.py folds them into gpurun_out/<tag>_pmc_rows<rows>.json (+ the kernel stats csv).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=$1; ROWS=$2; shift 2
-ARGS="--rows $ROWS --steps 3 --warmup 1 --no-cpu-baseline --no-batch65536 $@"
+ARGS="--rows $ROWS --steps 3 --warmup 1 --no-cpu-baseline --no-batch65536 --no-throughput-mode $@"
 OUT=gpurun_out/pmc_${TAG}_${ROWS}
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/trace.log 2>&1 &&

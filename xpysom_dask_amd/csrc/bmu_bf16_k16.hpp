@@ -294,6 +294,7 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
         }
     };
 
+    SOM_STAMP_BEGIN();
     for (int s = s_begin; s < s_end; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -347,6 +348,7 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
     }
     reduce_tile(accP, K16_T - 1);
     fold_stage(s_end - 1);
+    SOM_STAMP_END();
 
 #pragma unroll
     for (int sb = 0; sb < K16_SB; ++sb) {

@@ -221,6 +221,7 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
     for (int sb = 0; sb < WD_SB; ++sb) { gbest[sb] = 0xFFFFFFFFu; gstage[sb] = 0; }
 
     int cslot = 0, islot = 2;
+    SOM_STAMP_BEGIN();
     for (int s = s_begin; s < s_end; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of stage s+1 (first: of s, and its samples)
         __builtin_amdgcn_s_barrier();                         // ... everybody's; and nobody reads stage s-1 any more
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
         cslot = cslot == WD_SLOTS - 1 ? 0 : cslot + 1;
         islot = islot == WD_SLOTS - 1 ? 0 : islot + 1;
     }
+    SOM_STAMP_END();
 
 #pragma unroll
     for (int sb = 0; sb < WD_SB; ++sb) {

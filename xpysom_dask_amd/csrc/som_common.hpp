@@ -11,6 +11,30 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 #define SOM_WAVE 64
 
+// Diagnostic build only (-DSOM_STAMPS; tools/stamps.py): a workgroup's first wave stamps s_memtime (shader clock) and
+// s_memrealtime (100 MHz) on entry and on exit of the BMU kernels' scan and leaves the two differences in a buffer of
+// their own -- the clock the chip holds INSIDE the kernel is d(memtime) / d(memrealtime) * 100 MHz
+// (MI355X_MICROARCH.md, DVFS give-back item 6).  No product code path reads the buffer; without the macro nothing exists.
+#ifdef SOM_STAMPS
+__device__ unsigned long long* g_som_stamps = nullptr;     // [2 * workgroups] or nullptr
+struct SomStamp {
+    unsigned long long t0, r0;
+    __device__ __forceinline__ SomStamp() : t0(__builtin_amdgcn_s_memtime()), r0(__builtin_amdgcn_s_memrealtime()) {}
+    __device__ __forceinline__ void done() const {
+        if (g_som_stamps != nullptr && threadIdx.x == 0) {
+            const unsigned long long wg = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
+            g_som_stamps[2 * wg] = __builtin_amdgcn_s_memtime() - t0;
+            g_som_stamps[2 * wg + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+        }
+    }
+};
+#define SOM_STAMP_BEGIN() const SomStamp som_stamp_
+#define SOM_STAMP_END() som_stamp_.done()
+#else
+#define SOM_STAMP_BEGIN() do {} while (0)
+#define SOM_STAMP_END() do {} while (0)
+#endif
+
 // The 16-bit operand type of the half-precision BMU kernels: __bf16 (precision 'bf16' / 'bf16x3') or _Float16
 // ('f16' / 'f16x3': three more mantissa bits at the same MFMA rate, range 6e-8 .. 65504).  The kernels are templates on
 // its tag (`class EL`, `using E = typename EL::T`); their operand images are the same bytes either way.

@@ -2209,6 +2209,34 @@ int som_debug_mfma16(som_handle* h, const uint16_t* a_host, const uint16_t* b_ho
     return rc;
 }
 
+// Diagnostic builds only (-DSOM_STAMPS): hand the BMU kernels a buffer for their in-kernel clock stamps (n_pairs
+// workgroups' worth; NULL detaches it), or read it back.  In the product build both calls fail with a message.
+int som_debug_stamps(som_handle* h, int64_t n_pairs, uint64_t* out_host) {
+    DeviceGuard dev_guard(h);
+    if (!h) return 1;
+#ifdef SOM_STAMPS
+    static unsigned long long* buf = nullptr;
+    static int64_t cap = 0;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (out_host) {
+        if (n_pairs > cap) return fail(h, "som_debug_stamps: more pairs than the buffer holds");
+        HIPCHK(h, hipMemcpy(out_host, buf, (size_t)n_pairs * 16, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    if (buf) { (void)hipFree(buf); buf = nullptr; cap = 0; }
+    if (n_pairs > 0) {
+        HIPCHK(h, hipMalloc((void**)&buf, (size_t)n_pairs * 16));
+        HIPCHK(h, hipMemset(buf, 0, (size_t)n_pairs * 16));
+        cap = n_pairs;
+    }
+    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(g_som_stamps), &buf, sizeof(buf)));
+    return 0;
+#else
+    (void)n_pairs; (void)out_host;
+    return fail(h, "som_debug_stamps: this library was built without -DSOM_STAMPS (tools/stamps.py builds the diagnostic one)");
+#endif
+}
+
 int som_exact_stats(som_handle* h, int64_t* rows, int64_t* rows_fallback, int64_t* passes) {
     if (!h) return 1;
     if (rows) *rows = h->ex.rows_total;
