@@ -97,14 +97,14 @@ def test_blockwise_allreduce_equals_the_monolithic_one(tmp_path):
         assert np.array_equal(x, y)
 
 
-def test_five_ranks_of_the_hip_engine_on_one_gpu(tmp_path):
-    """The widest rehearsal one GPU allows (the box admits six processes on its card, the test runner being one of them;
-    the real run has eight ranks -- eight run under gloo on the CPU double, tests/test_distributed_gloo.py): five
-    real-engine ranks under gloo, precision 'exact', rows split 5 ways -- rank-to-rank bit equality and the oracle's
+def test_four_ranks_of_the_hip_engine_on_one_gpu(tmp_path):
+    """The widest rehearsal one GPU allows (the box admits six processes on its card, the test runner and the launcher
+    among them; the real run has eight ranks -- eight run under gloo on the CPU double, tests/test_distributed_gloo.py):
+    four real-engine ranks under gloo, precision 'exact', rows split 4 ways -- rank-to-rank bit equality and the oracle's
     training; then the 512-row map, whose four 128-row blocks take the blockwise all-reduce (SOM_OVERLAP=1: the path
     that is the default under RCCL from three blocks on), against the one-shot all-reduce."""
-    _launch("gloo", tmp_path, "exact", world=5)
-    ws, w, den, w1 = _check(tmp_path, "exact", world=5)
+    _launch("gloo", tmp_path, "exact", world=4)
+    ws, w, den, w1 = _check(tmp_path, "exact", world=4)
     data, ref_small, ref_epoch = _references()
     np.testing.assert_allclose(ws, ref_small, rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(w, ref_epoch, rtol=2e-5, atol=2e-6)
@@ -112,12 +112,12 @@ def test_five_ranks_of_the_hip_engine_on_one_gpu(tmp_path):
     np.testing.assert_allclose(den.reshape(-1), den_all.reshape(-1), rtol=2e-5, atol=1e-6)
     a, b = tmp_path / "mono", tmp_path / "blocks"
     a.mkdir(); b.mkdir()
-    _launch("gloo", a, "wide4", world=5, SOM_OVERLAP="0")
-    _launch("gloo", b, "wide4", world=5, SOM_OVERLAP="1")
+    _launch("gloo", a, "wide4", world=4, SOM_OVERLAP="0")
+    _launch("gloo", b, "wide4", world=4, SOM_OVERLAP="1")
     # (each run's ranks agree bit for bit: _check.  Between the two runs only the ORDER in which a collective adds the
-    #  five ranks' partial sums may differ -- it depends on where an element sits in the buffer being reduced -- so with
+    #  ranks' partial sums may differ -- it depends on where an element sits in the buffer being reduced -- so with
     #  more than two ranks the blockwise and the one-shot result are equal to float32 summation order, not bitwise)
-    for x, y in zip(_check(a, "wide4", world=5), _check(b, "wide4", world=5)):
+    for x, y in zip(_check(a, "wide4", world=4), _check(b, "wide4", world=4)):
         np.testing.assert_allclose(x, y, rtol=2e-6, atol=2e-6 * np.abs(y).max())
 
 
