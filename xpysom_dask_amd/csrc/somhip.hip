@@ -68,27 +68,18 @@ struct som_handle {
     bool x3res = false;      // bf16x3 with input_len <= 128: the register-resident split kernel (bmu_bf16_k16x3.hpp)
     bool exact = false;      // precision 'exact': MFMA screen + float32 re-score of the candidates (bmu_exact.hpp)
     struct ExactScratch {
-        // Two sets of per-pass scratch: while the screen of pass p+1 runs on the handle's stream, the candidate scan,
-        // bucketing, re-score and finalize of pass p run on `side` (they are latency-bound and fill the screen's idle
-        // issue slots and its tail)
-        struct Set {
-            uint32_t* gmin = nullptr;            // [n_groups][stride] group minima of the pass (sparse: see gflags)
-            unsigned long long* gflags = nullptr;   // [n_groups][stride / 64] which rows' minima the screen stored
-            uint32_t* bm = nullptr;              // [n_words][stride] hit bits: group 32 w + b is a candidate of the row
-            int* fb_list = nullptr;
-            int* ctr = nullptr;                  // gcount | gfill | fb_count | n_tiles | overflow (zeroed per pass), then goff
-            int* plist = nullptr;                // rows bucketed by candidate group
-            int4* tile_tab = nullptr;            // re-score tiles: (group, first list entry, rows)
-            hipEvent_t screened = nullptr, done = nullptr;
-        } set[2];
-        hipStream_t side = nullptr;
-        int last_set = 0, n_sets = 0;
-        long stride = 0;                     //   rows per group line (a pass of the row set, padded)
+        uint32_t* gmin = nullptr;            // [n_groups][stride] group minima of the chunk being screened (sparse: see gflags)
+        unsigned long long* gflags = nullptr;   // [n_groups][stride / 64] which rows' minima the screen stored
+        long stride = 0;                     //   rows per group line (a chunk of the row set, padded)
+        uint32_t* bm = nullptr;              // [n_words][stride] hit bits: group 32 w + b is a candidate of the row
+        int *fb_list = nullptr, *fb_ids = nullptr;
+        int* ctr = nullptr;                  // gcount | gfill | fb_count | n_tiles (zeroed per pass), then goff
+        int* plist = nullptr;                // rows bucketed by candidate group
+        int4* tile_tab = nullptr;            // re-score tiles: (group, first list entry, rows)
         long max_tiles = 0;
-        int* fb_ids = nullptr;
         float* fbX = nullptr;                // fallback rows, dense, for the float32 kernel
         long fb_cap = 0;
-        int* fb_count_host = nullptr;        // pinned, one per set
+        int* fb_count_host = nullptr;        // pinned
         int64_t rows_total = 0, rows_fallback = 0, chunks = 0;   // som_exact_stats
     } ex;
     int n_kchunks = 0;       // tiled: 64-feature chunks
@@ -834,47 +825,32 @@ long exact_chunk_rows(const som_handle* h) {
 
 int exact_reserve(som_handle* h, long rows) {
     auto& ex = h->ex;
-    long stride = round_up(std::min(rows, exact_chunk_rows(h)), 256);
-    const int want_sets = rows > stride ? 2 : 1;             // (one pass: nothing to overlap, one set)
-    if (stride <= ex.stride && want_sets <= ex.n_sets) return 0;
-    stride = std::max(stride, ex.stride);
+    const long stride = round_up(std::min(rows, exact_chunk_rows(h)), 256);
+    if (stride <= ex.stride) return 0;
+    void* old[] = {ex.gmin, ex.gflags, ex.bm, ex.fb_list, ex.plist, ex.tile_tab};
+    for (void* p : old) if (p) (void)hipFree(p);
+    ex.gmin = nullptr; ex.gflags = nullptr; ex.bm = nullptr; ex.fb_list = nullptr; ex.plist = nullptr; ex.tile_tab = nullptr;
+    ex.stride = 0;
     const long n_groups = cdiv(h->K, EX_GROUP);
     if (stride * EX_PAIRS > 0x7fffffffL) return fail(h, "exact: pass too large");
-    if (!ex.side) {
-        HIPCHK(h, hipStreamCreateWithFlags(&ex.side, hipStreamNonBlocking));
-        HIPCHK(h, hipHostMalloc((void**)&ex.fb_count_host, 2 * sizeof(int), hipHostMallocDefault));
-    }
-    HIPCHK(h, hipStreamSynchronize(ex.side));
-    ex.stride = 0;
+    if (int rc = dev_alloc(h, &ex.gmin, (size_t)n_groups * stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.gflags, (size_t)n_groups * (stride / 64))) return rc;
+    if (int rc = dev_alloc(h, &ex.bm, (size_t)cdiv(n_groups, 32) * stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.plist, (size_t)stride * EX_PAIRS)) return rc;
+    if (int rc = dev_alloc(h, &ex.fb_list, (size_t)stride)) return rc;
     ex.max_tiles = cdiv(stride * EX_PAIRS, EX_TR) + n_groups;
-    const int n_sets = std::max(want_sets, ex.n_sets);
-    ex.n_sets = 0;
-    for (int i = 0; i < 2; ++i) {
-        auto& st = ex.set[i];
-        void* old[] = {st.gmin, st.gflags, st.bm, st.fb_list, st.plist, st.tile_tab};
-        for (void* p : old) if (p) (void)hipFree(p);
-        st.gmin = nullptr; st.gflags = nullptr; st.bm = nullptr; st.fb_list = nullptr; st.plist = nullptr; st.tile_tab = nullptr;
-        if (!st.screened) {
-            HIPCHK(h, hipEventCreateWithFlags(&st.screened, hipEventDisableTiming));
-            HIPCHK(h, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
-        }
-        if (!st.ctr) if (int rc = dev_alloc(h, &st.ctr, (size_t)3 * n_groups + 3)) return rc;
-        if (i >= n_sets) continue;
-        if (int rc = dev_alloc(h, &st.gmin, (size_t)n_groups * stride)) return rc;
-        if (int rc = dev_alloc(h, &st.gflags, (size_t)n_groups * (stride / 64))) return rc;
-        if (int rc = dev_alloc(h, &st.bm, (size_t)cdiv(n_groups, 32) * stride)) return rc;
-        if (int rc = dev_alloc(h, &st.plist, (size_t)stride * EX_PAIRS)) return rc;
-        if (int rc = dev_alloc(h, &st.fb_list, (size_t)stride)) return rc;
-        if (int rc = dev_alloc(h, &st.tile_tab, (size_t)ex.max_tiles)) return rc;
+    if (int rc = dev_alloc(h, &ex.tile_tab, (size_t)ex.max_tiles)) return rc;
+    if (!ex.ctr) {
+        if (int rc = dev_alloc(h, &ex.ctr, (size_t)3 * n_groups + 3)) return rc;
+        HIPCHK(h, hipHostMalloc((void**)&ex.fb_count_host, sizeof(int), hipHostMallocDefault));
     }
     ex.stride = stride;
-    ex.n_sets = n_sets;
     return 0;
 }
 
 template <int KS32, class E>
-int exact_screen(som_handle* h, som_handle::ExactScratch::Set& st, const __bf16* Xb, long n, unsigned long long* best64,
-                 const float* xsq, const float* xerr, const float* xmax2, const ExactBound& eb) {
+int exact_screen(som_handle* h, const __bf16* Xb, long n, unsigned long long* best64, const float* xsq, const float* xerr,
+                 const float* xmax2, const ExactBound& eb) {
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
     // one pass on scaled half operands: a stage IS a group
     auto kern = bmu_bf16_k16_kernel<KS32, E, true>;
@@ -889,25 +865,24 @@ int exact_screen(som_handle* h, som_handle::ExactScratch::Set& st, const __bf16*
         std::fprintf(stderr, "[somhip] exact screen: blocks=%ld per_cu=%d slots=%ld parts=%d groups=%d\n", blocks, per_cu,
                      slots, parts, n_groups);
     kern<<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * K16_NW), lds, h->stream>>>(
-        Xb, n, h->Wst, h->n_stages, h->K, best64, st.gmin, h->ex.stride, st.gflags, xsq, xerr, xmax2, h->wmax2, h->wmax2 + 1, eb);
+        Xb, n, h->Wst, h->n_stages, h->K, best64, h->ex.gmin, h->ex.stride, h->ex.gflags, xsq, xerr, xmax2, h->wmax2, h->wmax2 + 1, eb);
     return 0;
 }
 
 template <class E>
-int exact_screen_ks(som_handle* h, som_handle::ExactScratch::Set& st, const __bf16* Xb, long n, unsigned long long* best64,
-                    const float* xsq, const float* xerr, const float* xmax2, const ExactBound& eb) {
+int exact_screen_ks(som_handle* h, const __bf16* Xb, long n, unsigned long long* best64, const float* xsq, const float* xerr,
+                    const float* xmax2, const ExactBound& eb) {
     switch (h->ks32) {
-    case 1: return exact_screen<1, E>(h, st, Xb, n, best64, xsq, xerr, xmax2, eb);
-    case 2: return exact_screen<2, E>(h, st, Xb, n, best64, xsq, xerr, xmax2, eb);
-    case 3: return exact_screen<3, E>(h, st, Xb, n, best64, xsq, xerr, xmax2, eb);
-    case 4: return exact_screen<4, E>(h, st, Xb, n, best64, xsq, xerr, xmax2, eb);
+    case 1: return exact_screen<1, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb);
+    case 2: return exact_screen<2, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb);
+    case 3: return exact_screen<3, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb);
+    case 4: return exact_screen<4, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb);
     }
     return fail(h, "exact: the screen kernel supports input_len <= 128");
 }
 
 template <int KG>
-int exact_rescore_kg(som_handle* h, som_handle::ExactScratch::Set& st, const float* X, int n_groups, unsigned long long* best64,
-                     hipStream_t stream) {
+int exact_rescore_kg(som_handle* h, const float* X, int n_groups) {
     auto& ex = h->ex;
     auto kern = exact_rescore_mfma_kernel<KG>;
     const size_t lds = (size_t)fr_stage_bytes(KG);
@@ -915,60 +890,37 @@ int exact_rescore_kg(som_handle* h, som_handle::ExactScratch::Set& st, const flo
     if (int rc = kernel_per_cu(h, (const void*)kern, 256, lds, &per_cu)) return rc;
     // (twice the resident slots: the runs of tiles are uneven -- partial tiles, idle waves -- and finer runs balance them)
     const long grid = std::min<long>(ex.max_tiles, 2L * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
-    kern<<<dim3((unsigned)grid), dim3(256), lds, stream>>>(X, h->D, h->Wfst, h->K, st.tile_tab, st.ctr + 2 * n_groups + 1, st.plist,
-                                                          best64);
+    kern<<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, h->D, h->Wfst, h->K, ex.tile_tab, ex.ctr + 2 * n_groups + 1, ex.plist,
+                                                             h->best64);
     return 0;
 }
 
-// everything of a pass behind its screen, on `stream`: candidates, bucketing by group, re-score tile by tile, settle the
-// rows.  best64 is the pass's slice of the merge keys (the scan reads the screen's minima from it; the fill resets it).
-int exact_after_screen(som_handle* h, som_handle::ExactScratch::Set& st, const float* X, long n, unsigned long long* best64,
-                       const float* xsq, const float* xerr, const float* xmax2, const ExactBound& eb, int* out, hipStream_t stream) {
+// the re-score of one pass: bucket the (row, group) pairs by group, score tile by tile, settle the rows.  best64 is the
+// pass's slice of the merge keys (the scan has read the screen's minima from it; the fill resets it).
+int exact_rescore(som_handle* h, const float* X, long n, unsigned long long* best64, int* out) {
     auto& ex = h->ex;
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
-    int* gcount = st.ctr; int* gfill = st.ctr + n_groups; int* fb_count = st.ctr + 2 * n_groups;
+    int* gcount = ex.ctr; int* gfill = ex.ctr + n_groups; int* fb_count = ex.ctr + 2 * n_groups;
     int* n_tiles = fb_count + 1; int* overflow = fb_count + 2; int* goff = fb_count + 3;
-    exact_scan_kernel<<<dim3((unsigned)cdiv(n, 64)), dim3(64 * EX_SCAN_SPLIT), 0, stream>>>(
-        st.gmin, st.gflags, ex.stride, n_groups, n, best64, xsq, h->wmax2, xmax2, eb, xerr, h->wmax2 + 1, st.bm, st.ctr);
-    exact_offsets_kernel<<<dim3(1), dim3(1024), 0, stream>>>(gcount, n_groups, ex.stride * EX_PAIRS, goff, st.tile_tab, n_tiles,
-                                                            overflow);
-    exact_fill_kernel<<<dim3((unsigned)cdiv(n, 64)), dim3(64 * EX_SCAN_SPLIT), 0, stream>>>(st.bm, ex.stride, n_groups, n, goff, gfill,
-                                                                                       overflow, st.plist, best64);
+    exact_offsets_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(gcount, n_groups, ex.stride * EX_PAIRS, goff, ex.tile_tab, n_tiles,
+                                                               overflow);
+    exact_fill_kernel<<<dim3((unsigned)cdiv(n, 64)), dim3(64 * EX_SCAN_SPLIT), 0, h->stream>>>(ex.bm, ex.stride, n_groups, n, goff,
+                                                                                          gfill, overflow, ex.plist, best64);
+    unsigned long long* saved = h->best64;
+    h->best64 = best64;                                   // (exact_rescore_kg reads it from the handle)
     int rc = 0;
     switch (h->fr_kg) {
-    case 1: rc = exact_rescore_kg<1>(h, st, X, n_groups, best64, stream); break;
-    case 2: rc = exact_rescore_kg<2>(h, st, X, n_groups, best64, stream); break;
-    case 4: rc = exact_rescore_kg<4>(h, st, X, n_groups, best64, stream); break;
-    case 8: rc = exact_rescore_kg<8>(h, st, X, n_groups, best64, stream); break;
-    case 16: rc = exact_rescore_kg<16>(h, st, X, n_groups, best64, stream); break;
+    case 1: rc = exact_rescore_kg<1>(h, X, n_groups); break;
+    case 2: rc = exact_rescore_kg<2>(h, X, n_groups); break;
+    case 4: rc = exact_rescore_kg<4>(h, X, n_groups); break;
+    case 8: rc = exact_rescore_kg<8>(h, X, n_groups); break;
+    case 16: rc = exact_rescore_kg<16>(h, X, n_groups); break;
     default: rc = fail(h, "exact: bad k-group count");
     }
+    h->best64 = saved;
     if (rc) return rc;
-    exact_finalize_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream>>>(best64, n, h->K, overflow, out, st.fb_list, fb_count);
-    HIPCHK(h, hipGetLastError());
-    return 0;
-}
-
-// rows of a finished pass the scheme could not settle (normally none): the float32 kernel itself, on the handle's stream
-int exact_fallback(som_handle* h, som_handle::ExactScratch::Set& st, const float* X, long n, int n_fb, int* out) {
-    auto& ex = h->ex;
-    ex.rows_total += n; ex.rows_fallback += n_fb; ex.chunks += 1;
-    if (n_fb < 0 || n_fb > n) return fail(h, "exact: fallback counter out of range");
-    if (n_fb == 0) return 0;
-    if (n_fb > ex.fb_cap) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        (void)hipFree(ex.fbX); (void)hipFree(ex.fb_ids);
-        ex.fbX = nullptr; ex.fb_ids = nullptr; ex.fb_cap = 0;
-        const long cap = round_up(n_fb, 1024);
-        if (int rc = dev_alloc(h, &ex.fbX, (size_t)cap * h->D)) return rc;
-        if (int rc = dev_alloc(h, &ex.fb_ids, (size_t)cap)) return rc;
-        ex.fb_cap = cap;
-    }
-    exact_gather_rows_kernel<<<dim3((unsigned)cdiv((long)n_fb * h->D, 256)), dim3(256), 0, h->stream>>>(X, st.fb_list, n_fb, h->D, ex.fbX);
-    // (its part merge reuses best64[0 .. n_fb): rows of the row set's FIRST pass, settled before any fallback runs)
-    if (int rc = launch_bmu_f32_any<SCORE_EUCLID_PART>(h, ex.fbX, n_fb, nullptr, ex.fb_ids)) return rc;
-    exact_scatter_ids_kernel<<<dim3((unsigned)cdiv(n_fb, 256)), dim3(256), 0, h->stream>>>(ex.fb_ids, st.fb_list, n_fb, out);
-    HIPCHK(h, hipGetLastError());
+    exact_finalize_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(best64, n, h->K, overflow, out, ex.fb_list,
+                                                                                 fb_count);
     return 0;
 }
 
@@ -992,41 +944,42 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     const ExactBound eb = exact_bound(h);
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
     const long chunk = std::min(exact_chunk_rows(h), ex.stride);
-    const long n_pass = cdiv(N, chunk);
-    // Pass p: its screen on the handle's stream, everything behind the screen on `side`, so that the screen of pass
-    // p + 1 runs beside the scan / bucketing / re-score of pass p.  One pass: all of it on the handle's stream.
-    const bool overlap = n_pass > 1;
-    HIPCHK(h, hipEventRecord(ex.set[0].done, h->stream));          // (the side stream starts behind what is queued here)
-    if (overlap) HIPCHK(h, hipStreamWaitEvent(ex.side, ex.set[0].done, 0));
-    auto settle = [&](long p) -> int {                             // pass p is finished: its fallback rows, if any
-        const int si = overlap ? (int)(p & 1) : 0;
-        auto& st = ex.set[si];
-        const long r0 = p * chunk, n = std::min(chunk, N - r0);
-        HIPCHK(h, hipEventSynchronize(st.done));
-        return exact_fallback(h, st, X + r0 * h->D, n, ex.fb_count_host[si], out + r0);
-    };
-    for (long p = 0; p < n_pass; ++p) {
-        auto& st = ex.set[overlap ? (p & 1) : 0];
-        const long r0 = p * chunk, n = std::min(chunk, N - r0);
-        hipStream_t post = overlap ? ex.side : h->stream;
-        if (overlap && p >= 2) HIPCHK(h, hipStreamWaitEvent(h->stream, st.done, 0));   // the set is free again (pass p - 2)
-        HIPCHK(h, hipMemsetAsync(st.ctr, 0, (size_t)(2 * n_groups + 3) * sizeof(int), h->stream));
+    for (long r0 = 0; r0 < N; r0 += chunk) {
+        const long n = std::min(chunk, N - r0);
+        HIPCHK(h, hipMemsetAsync(ex.ctr, 0, (size_t)(2 * n_groups + 3) * sizeof(int), h->stream));
         {
             Timed ts(h, SOM_K_SCREEN);
-            if (int rc = SOM_HALF(h, exact_screen_ks, h, st, Xb + r0 * h->dp, n, h->best64 + r0, xsq + r0, xerr + r0, xmax2, eb)) return rc;
+            if (int rc = SOM_HALF(h, exact_screen_ks, h, Xb + r0 * h->dp, n, h->best64 + r0, xsq + r0, xerr + r0, xmax2, eb)) return rc;
         }
-        if (overlap) {
-            HIPCHK(h, hipEventRecord(st.screened, h->stream));
-            HIPCHK(h, hipStreamWaitEvent(post, st.screened, 0));
+        exact_scan_kernel<<<dim3((unsigned)cdiv(n, 64)), dim3(64 * EX_SCAN_SPLIT), 0, h->stream>>>(
+            ex.gmin, ex.gflags, ex.stride, n_groups, n, h->best64 + r0, xsq + r0, h->wmax2, xmax2, eb, xerr + r0, h->wmax2 + 1, ex.bm,
+            ex.ctr);
+        if (int rc = exact_rescore(h, X + r0 * h->D, n, h->best64 + r0, out + r0)) return rc;
+        HIPCHK(h, hipGetLastError());
+        // rows the scheme could not settle (normally none): the float32 kernel itself
+        HIPCHK(h, hipMemcpyAsync(ex.fb_count_host, ex.ctr + 2 * n_groups, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const int n_fb = *ex.fb_count_host;
+        ex.rows_total += n; ex.rows_fallback += n_fb; ex.chunks += 1;
+        if (n_fb < 0 || n_fb > n) return fail(h, "exact: fallback counter out of range");
+        if (n_fb > 0) {
+            if (n_fb > ex.fb_cap) {
+                (void)hipFree(ex.fbX); (void)hipFree(ex.fb_ids);
+                ex.fbX = nullptr; ex.fb_ids = nullptr; ex.fb_cap = 0;
+                const long cap = round_up(n_fb, 1024);
+                if (int rc = dev_alloc(h, &ex.fbX, (size_t)cap * h->D)) return rc;
+                if (int rc = dev_alloc(h, &ex.fb_ids, (size_t)cap)) return rc;
+                ex.fb_cap = cap;
+            }
+            exact_gather_rows_kernel<<<dim3((unsigned)cdiv((long)n_fb * h->D, 256)), dim3(256), 0, h->stream>>>(
+                X + r0 * h->D, ex.fb_list, n_fb, h->D, ex.fbX);
+            // (its part merge may reuse best64[0 .. n_fb): rows this pass has already settled)
+            if (int rc = launch_bmu_f32_any<SCORE_EUCLID_PART>(h, ex.fbX, n_fb, nullptr, ex.fb_ids)) return rc;
+            exact_scatter_ids_kernel<<<dim3((unsigned)cdiv(n_fb, 256)), dim3(256), 0, h->stream>>>(ex.fb_ids, ex.fb_list, n_fb,
+                                                                                                out + r0);
+            HIPCHK(h, hipGetLastError());
         }
-        if (int rc = exact_after_screen(h, st, X + r0 * h->D, n, h->best64 + r0, xsq + r0, xerr + r0, xmax2, eb, out + r0, post)) return rc;
-        HIPCHK(h, hipMemcpyAsync(ex.fb_count_host + (overlap ? (p & 1) : 0), st.ctr + 2 * n_groups, sizeof(int), hipMemcpyDeviceToHost, post));
-        HIPCHK(h, hipEventRecord(st.done, post));
-        ex.last_set = overlap ? (int)(p & 1) : 0;
-        if (!overlap) { if (int rc = settle(p)) return rc; }
-        else if (p >= 1) { if (int rc = settle(p - 1)) return rc; }
     }
-    if (overlap) if (int rc = settle(n_pass - 1)) return rc;      // (host-synchronised: the side stream is drained)
     return 0;
 }
 
@@ -1582,16 +1535,8 @@ void som_destroy(som_handle* h) {
         for (void* b : vb) if (b) (void)hipFree(b);
     }
     {
-        if (h->ex.side) (void)hipStreamSynchronize(h->ex.side);
-        for (auto& st : h->ex.set) {
-            void* eb[] = {st.gmin, st.gflags, st.bm, st.fb_list, st.ctr, st.plist, st.tile_tab};
-            for (void* b : eb) if (b) (void)hipFree(b);
-            if (st.screened) (void)hipEventDestroy(st.screened);
-            if (st.done) (void)hipEventDestroy(st.done);
-        }
-        if (h->ex.fb_ids) (void)hipFree(h->ex.fb_ids);
-        if (h->ex.fbX) (void)hipFree(h->ex.fbX);
-        if (h->ex.side) (void)hipStreamDestroy(h->ex.side);
+        void* eb[] = {h->ex.gmin, h->ex.gflags, h->ex.bm, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab};
+        for (void* b : eb) if (b) (void)hipFree(b);
         if (h->ex.fb_count_host) (void)hipHostFree(h->ex.fb_count_host);
     }
     for (auto& sl : h->slot) {
@@ -2306,7 +2251,7 @@ int som_exact_last_counts(som_handle* h, int32_t* counts_out, int64_t n) {
     if (!h->exact || n > h->ex.stride) return fail(h, "som_exact_last_counts: no screen pass of that many rows");
     const long n_words = cdiv(cdiv(h->K, EX_GROUP), 32);
     std::vector<uint32_t> bm((size_t)n_words * h->ex.stride);
-    if (int rc = d2h_blocking(h, bm.data(), h->ex.set[h->ex.last_set].bm, bm.size() * sizeof(uint32_t))) return rc;
+    if (int rc = d2h_blocking(h, bm.data(), h->ex.bm, bm.size() * sizeof(uint32_t))) return rc;
     for (int64_t r = 0; r < n; ++r) {
         int c = 0;
         for (long w = 0; w < n_words; ++w) c += __builtin_popcount(bm[(size_t)w * h->ex.stride + r]);
