@@ -1,4 +1,4 @@
-// precision 'exact': float32-exact BMUs at split-bf16 MFMA speed.
+// precision 'exact': float32-exact BMUs at MFMA-half speed.
 //
 // What it returns is, row for row and bit for bit, what the float32 parity kernel returns (bmu_f32_res.hpp:
 // argmin_k fl(|w_k|^2 - 2 c_k), c_k the k-ordered float32 fma chain of x . w_k -- the reference's
@@ -6,53 +6,50 @@
 // How: a cheap SCREEN that may be wrong by a bounded amount, then the float32 chain itself on the few units the screen
 // cannot rule out.
 //
-//   1. screen    bmu_bf16_k16x3_kernel<.., GM = true> (hi/lo-split bf16 MFMA, bmu_bf16_k16x3.hpp) computes
-//                d'(n,k) = B + |w_k|^2/2 - x_n . w_k approximately, keeps the row minimum m(n) as always, and also
-//                writes, per GROUP of 64 units and row, the group's minimum: gmin[group][row] (4 bytes per row and
-//                64 units: 268 MB per 65 536 rows of a 256 x 256 map, written once, read once).
+//   1. screen    bmu_bf16_k16_kernel<.., F16, GM = true> (bmu_bf16_k16.hpp): one pass of the 16x16x32 MFMA kernel on
+//                IEEE-half operands computes d'(n,k) = S (B + |w_k|^2/2 - x_n . w_k) approximately and keeps VALUES
+//                only: the row minimum m(n) and, per GROUP of 64 units (one stage) and row, the group's minimum --
+//                stored (gmin[group][row]) only where it is within the row's bound E(n) of the minimum so far, with the
+//                64-bit mask of the rows stored per stage and wave (gflags).  No unit indices exist in that instance.
 //   2. candidates  exact_scan_kernel: every group with gmin <= m(n) + E(n) is a candidate of row n.  E(n) bounds
 //                (float32 kernel's own rounding) + (screen's error), both relative to tau = |w|^2 - 2 x.w in real
 //                arithmetic -- derivation below.  The float32 winner k* has s(k*) <= s(k) for every k, so its screen
-//                value cannot exceed the screen's minimum by more than E: its group is a candidate.
+//                value cannot exceed the screen's minimum by more than E: its group is a candidate (and was stored:
+//                the minimum so far is never below the final one).
 //   3. re-score  the (row, group) pairs are bucketed by group (exact_offsets_kernel, exact_fill_kernel) and
 //                exact_rescore_mfma_kernel forms, tile by tile (up to 128 rows of a group's list x its 64 units), the
 //                float32 scores by the SAME instruction stream as the parity kernel (v_mfma_f32_32x32x2_f32 on the
 //                parity kernel's own stage image, same k order, same epilogue) and keeps the first minimum in unit
 //                order per row.  Because k* is among the re-scored units and is the global first minimum, it is the
-//                re-scored first minimum.  A group's stage is fetched once per tile, not once per row.
+//                re-scored first minimum.
 //   4. fallback  rows the scheme cannot vouch for -- no candidate at all (NaN / infinite rows or norms), a minimum that
 //                is not finite, a pass with more pairs than its lists hold (64 per row on average: a degenerate
 //                codebook) -- go to the float32 kernel itself (exact_finalize_kernel lists them).
 //
-// Error bound (euclidean, input_len <= 128).  u = 2^-24, ub = 2^-8 (bf16) or 2^-11 (f16), A(n,k) = sum_d |x_d w_kd|
-// <= |x_n| max_k|w_k|.
+// Error bound (euclidean, input_len <= 128).  u = 2^-24, A(n,k) = sum_d |x_d w_kd| <= |x_n| max_k|w_k|.
 //   float32 kernel:  |c - x.w| <= gamma_D A (fma chain of D terms), s = fl(wsq - 2c):
 //                    |s - tau| <= (2 gamma_D + 2u)(1+u) A + u wsq.
-//   screen, operands: v = hi + lo + r with |r| <= ub^2 |v|; the kernel contracts hi.hi + lo.hi + hi.lo, what it drops
-//                    is bounded by ub^2 (3 + 5 ub) A.
-//   screen, accumulation: the initial accumulator fl(B + wsq/2) and 3 * ceil(D/32) chained MFMAs, each charged KAPPA
-//                    ulps of the largest magnitude the accumulator can take, Bm = 2.01 B + max wsq / 2 (the hardware's
-//                    internal summation is not documented; tests/test_gpu_exact.py measures it through
-//                    som_debug_mfma16 at <= 2.4 ulps and fails above 3; KAPPA = 6), plus, in the split-bf16 screen, the
-//                    8 ulps its index bits packed into the key's low mantissa bits hide (the half screen keeps values only).
-//   screen on IEEE half operands in ONE pass (the default; the split-bf16 screen is kept for A/B): rows and units are
-//                    first scaled by powers of two (ex_scale: the longest norm lands in [2^13, 2^14), exact), then
-//                    rounded to float16.  The operand error is MEASURED, not assumed: the preparation kernels know
-//                    both x^ (scaled float32) and x~ (what the MFMA reads), so |x^_n - x~_n| per row and
-//                    max_k |w^_k - w~_k| are numbers (a subnormal half counts with its whole value: covers an MFMA
-//                    that flushes it), and  |x~.w~ - x^.w^| = |dx.w^ + x~.dw| <= |dx| |w^| + (|x^| + |dx|) |dw|
+//   screen, operands: rows and units are first scaled by powers of two (ex_scale: the longest norm lands in
+//                    [2^13, 2^14), exact), then rounded to float16.  The operand error is MEASURED, not assumed: the
+//                    preparation kernels know both x^ (scaled float32) and x~ (what the MFMA reads), so |x^_n - x~_n|
+//                    per row and max_k |w^_k - w~_k| are numbers (a subnormal half counts with its whole value: covers
+//                    an MFMA that flushes it), and  |x~.w~ - x^.w^| = |dx.w^ + x~.dw| <= |dx| |w^| + (|x^| + |dx|) |dw|
 //                    by Cauchy-Schwarz -- about 0.4 of the worst-case 2^-11 relative rounding on Gaussian-like rows.
-//                    One MFMA chain of ceil(D/32).
-//   E (in units of d' = tau / 2 + B):  spelled out in exact_bound() (host side, somhip.hip).
-// The bound is deliberately loose (worst-case rounding everywhere): widening E only adds candidate groups, and a
-// candidate group costs one 64-unit re-score.
+//   screen, accumulation: the initial accumulator fl(S (B + wsq/2)) and ONE chain of ceil(D/32) MFMAs, each charged
+//                    KAPPA = 6 ulps of the largest magnitude the accumulator can take, Bm = 2.01 B + max wsq / 2 (the
+//                    hardware's internal summation is not documented; tests/test_gpu_exact.py measures it through
+//                    som_debug_mfma16 at <= 2.4 ulps and fails above 3).
+//   E(n) (in units of d' = S (tau / 2 + B)):  ex_row_bound() in bmu_bf16.hpp, constants in exact_bound() (somhip.hip):
+//                    E32_tau + 2 (operand term + accumulation term).
+// The bound is deliberately loose (worst-case rounding everywhere it is not measured): widening E only adds candidate
+// groups, and a candidate group costs one 64-unit re-score.
 #pragma once
-#include "bmu_bf16_k16x3.hpp"
+#include "bmu_bf16_k16.hpp"
 #include "bmu_f32_res.hpp"
 
 namespace somhip {
 
-constexpr int EX_GROUP = 64;          // units per group = one stage of the float32 stage image = two screen stages
+constexpr int EX_GROUP = 64;          // units per group = one stage of the float32 stage image = one stage of the screen
 constexpr int EX_PAIRS = 64;          // capacity of a pass: this many (row, group) pairs per row ON AVERAGE
 constexpr int EX_SCAN_SPLIT = 4;      // waves that share a row's groups in the scan
 constexpr int EX_TR = 128;            // rows per re-score tile (4 waves x 32 rows against one 64-unit group)
