@@ -226,3 +226,26 @@ def test_the_mfma_rounding_the_bound_charges_for_is_measured():
         worst = max(worst, float((np.abs(d.astype(np.float64) - ex) / ulp).max()))
     e.close()
     assert worst <= 3.0, worst
+
+
+def test_exact_in_several_screen_passes(monkeypatch):
+    """Large row sets are screened in passes (the group-minimum matrix of a pass stays within 1 GiB: 262 144 rows at
+    256 x 256); SOM_EXACT_PASS_ROWS forces passes of 1 024 / 2 048 rows so that the pass loop -- slices of the rows, of the
+    merge keys, of the norms; a last short pass; fallback rows in a later pass -- runs on test-sized data."""
+    X, Y, D, n = 40, 40, 64, 7001
+    data = O.gaussian_blobs(n, D, seed=12)
+    data[5000] = np.nan                                   # a fallback row in the fifth / third pass
+    w = O.smooth_sheet_codebook(X, Y, D, 5, amplitude=0.3, centre=np.nanmean(data.astype(np.float64), axis=0))
+    want = both(X, Y, D, w, data)["f32"][0]
+    for rows in ("1024", "2048"):
+        monkeypatch.setenv("SOM_EXACT_PASS_ROWS", rows)
+        e = engine(X, Y, D, precision="exact")
+        e.set_weights(w)
+        e.set_data(data)
+        e.epoch_accumulate(3.0, 0.4, True)
+        got = e.epoch_fetch()[2]
+        r, fb, passes = e.exact_stats()
+        assert passes == -(-n // int(rows)) and r == n and fb >= 1
+        assert np.array_equal(got, want), (rows, int((got != want).sum()))
+        assert np.array_equal(e.bmu(data[:3000]), want[:3000])
+        e.close()

@@ -81,6 +81,7 @@ struct som_handle {
         long fb_cap = 0;
         int* fb_count_host = nullptr;        // pinned
         int64_t rows_total = 0, rows_fallback = 0, chunks = 0;   // som_exact_stats
+        long pass_rows_override = 0;
     } ex;
     int n_kchunks = 0;       // tiled: 64-feature chunks
     int n_ublocks = 0;       // tiled: unit blocks of tl_bn
@@ -819,6 +820,7 @@ ExactBound exact_bound(const som_handle* h) {
 long exact_chunk_rows(const som_handle* h) {
     const long n_groups = cdiv(h->K, EX_GROUP);
     long rows = (1L << 30) / (4 * n_groups);
+    if (h->ex.pass_rows_override > 0) rows = h->ex.pass_rows_override;   // SOM_EXACT_PASS_ROWS: tests walk several passes on small data
     rows = rows / 1024 * 1024;                           // (a multiple of every screen kernel's workgroup tile)
     return rows < 1024 ? 1024 : rows;
 }
@@ -1469,6 +1471,7 @@ int som_create(const som_config* cfg, som_handle** out) {
         if (const char* e = std::getenv("SOM_F32_PARTS")) h->env_f32_parts = std::atoi(e);
         h->debug = std::getenv("SOM_DEBUG") != nullptr;
         if (const char* e = std::getenv("SOM_VERIFY")) h->verify_rows = std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("SOM_EXACT_PASS_ROWS")) h->ex.pass_rows_override = std::atol(e);
         if (const char* e = std::getenv("SOM_ASYNC_COPIES")) h->async_copies = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_FUSE_MERGE")) h->fuse_merge_prep = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_SORT_ONESWEEP_ROWS")) SORT_ONESWEEP_ROWS = std::atol(e);
