@@ -51,7 +51,7 @@ WORKLOADS = {
                neighborhood="gaussian", cpu_rows=8192, label="BASELINE configs[2]/[3]"),
     "c2": dict(map=(64, 64), features=32, rows=100000, precision="f32", distance="euclidean",
                neighborhood="gaussian", cpu_rows=100000, label="BASELINE configs[1]"),
-    "c5": dict(map=(512, 512), features=784, rows=250000, precision="bf16", distance="cosine",
+    "c5": dict(map=(512, 512), features=784, rows=250000, precision="exact", distance="cosine",
                neighborhood="mexican_hat", cpu_rows=256, label="BASELINE configs[4], one GPU's shard of 2M rows"),
 }
 
@@ -74,10 +74,20 @@ def workload_rows(name, n, seed):
     return out
 
 
+def exact_has_screen(features, units, distance):
+    """precision='exact' screens on half operands (<= 128 features: euclidean; 129..800 features on maps of >= 4096
+    units: euclidean and cosine -- som_create); elsewhere the float32 kernels serve it."""
+    if features <= 128:
+        return distance == "euclidean"
+    return features <= 800 and units >= 4096 and distance in ("euclidean", "cosine") and os.environ.get("SOM_BF16_WIDE", "1") != "0"
+
+
 def kernel_name_for(precision, features, units=1 << 16):
     """The BMU kernel som_create selects (csrc/somhip.hip)."""
-    if precision == "exact":                               # (input_len > 128: served by the float32 kernels)
-        return "bmu_f32_tiled_kernel" if features > 128 else "bmu_bf16_k16_kernel"
+    if precision == "exact":                               # (its screen kernel; no screen: served by the float32 kernels)
+        if features > 128:
+            return "bmu_bf16_wide_kernel" if exact_has_screen(features, units, "euclidean") else "bmu_f32_tiled_kernel"
+        return "bmu_bf16_k16_kernel"
     if precision == "f32":
         return "bmu_f32_tiled_kernel" if features > 128 else "bmu_f32_res_kernel"
     if precision in ("bf16x3", "f16x3"):                    # ('f16' / 'f16x3': the bf16 kernels' _Float16 instances)
@@ -317,7 +327,7 @@ def main():
 
     # the throughput mode beside the parity-grade headline: the same K epochs through the plain bf16 kernel
     thr = None
-    if args.precision == "exact" and FEATURES <= 128 and not args.no_throughput_mode:
+    if args.precision == "exact" and exact_has_screen(FEATURES, MAP_X * MAP_Y, wl["distance"]) and not args.no_throughput_mode:
         eng.close()
         e_t, dt_t = timed_run("bf16")
         t_ms, t_n = e_t.profile_get("bmu")
@@ -337,7 +347,7 @@ def main():
     def kernel_ms(e):
         """(average launch, launches) of the MFMA distance kernel of the epochs just timed: the screen kernel of the
         exact mode, the fused distance+BMU kernel otherwise."""
-        fam = "screen" if e.precision == "exact" and FEATURES <= 128 and wl["distance"] == "euclidean" else "bmu"
+        fam = "screen" if e.precision == "exact" and exact_has_screen(FEATURES, MAP_X * MAP_Y, wl["distance"]) else "bmu"
         ms, n = e.profile_get(fam)
         return ms / max(1, n), n
 
@@ -494,7 +504,7 @@ def main():
 
     if rank == 0:
         ms_step = 1e3 * dt / args.steps
-        is_exact = args.precision == "exact" and FEATURES <= 128 and wl["distance"] == "euclidean"
+        is_exact = args.precision == "exact" and exact_has_screen(FEATURES, MAP_X * MAP_Y, wl["distance"])
         k_avg = (scr_ms / max(1, scr_n)) if is_exact else (bmu_ms / max(1, bmu_n))
         k_n = scr_n if is_exact else bmu_n
         rows_launch = my_rows * (bmu_n / max(1, k_n)) if is_exact else my_rows     # (the exact mode screens in passes)

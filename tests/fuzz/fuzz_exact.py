@@ -1,5 +1,6 @@
 """precision='exact' against precision='f32' on random configurations: IDENTICAL ids, row for row, from the epoch path and
-from the query path -- never "near".  Maps 1..100 a side, 1..128 features (and past 128, where 'exact' is served by the
+from the query path -- never "near".  FUZZ_WIDE=1: maps of 64..110 a side, 129..800 features, euclidean and cosine (the
+wide screen); otherwise maps 1..100 a side, 1..128 features (and past 128, where 'exact' is served by the
 float32 kernels), 1..5000 rows, magnitudes 1e-3..1e3, zero rows, duplicated units, and the three codebook shapes that
 decide how hard the screen's job is: random units (one candidate group per row), a smooth sheet (hundreds of
 near-ties per row: the early-schedule state) and clusters of units a few float32 ulps apart (every row re-scored)."""
@@ -11,6 +12,7 @@ from xpysom_dask_amd.engine import HipEngine
 F32 = np.float32
 rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+WIDE = os.environ.get("FUZZ_WIDE", "0") == "1"
 bad = 0
 fb_total = rows_total = 0
 t0 = time.time()
@@ -19,6 +21,12 @@ for case in range(n_cases):
     X, Y = int(rs.randint(1, side + 1)), int(rs.randint(1, side + 1))
     D = int(rs.choice([1, 2, 3, 7, 16, 31, 32, 33, 64, 96, 100, 127, 128, 128, 128, 130, 200]))
     n = int(rs.choice([1, 2, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 3000, 5000]))
+    dist = "euclidean"
+    if WIDE:                                                 # the wide screen: >= 4096 units, 129..800 features
+        X, Y = int(rs.randint(64, 111)), int(rs.randint(64, 111))
+        D = int(rs.choice([129, 130, 160, 161, 200, 256, 257, 300, 512, 600, 784, 800]))
+        n = int(rs.choice([1, 2, 31, 32, 33, 255, 256, 257, 1000, 2500]))
+        dist = str(rs.choice(["euclidean", "cosine"]))
     kind = str(rs.choice(["random", "random", "sheet", "sheet", "clusters"]))
     data = O.gaussian_blobs(n, D, seed=case)
     if kind == "random":
@@ -45,7 +53,7 @@ for case in range(n_cases):
     try:
         out = {}
         for p in ("f32", "exact"):
-            e = HipEngine(X, Y, D, precision=p)
+            e = HipEngine(X, Y, D, precision=p, distance=dist)
             e.set_weights(w); e.set_data(data)
             e.epoch_accumulate(sig, 0.5, True)
             num, den, bmu = e.epoch_fetch()
@@ -63,5 +71,5 @@ for case in range(n_cases):
         ok, detail = False, "EXC " + repr(ex)[:200]
     if not ok:
         bad += 1
-        print(f"FAIL case {case}: {X}x{Y}x{D} n={n} {kind} scale {sx}/{sw}: {detail}", flush=True)
+        print(f"FAIL case {case}: {X}x{Y}x{D} {dist} n={n} {kind} scale {sx}/{sw}: {detail}", flush=True)
 print(f"{n_cases} cases, {bad} failures, {time.time()-t0:.1f} s; float32 fallback kernel: {fb_total} of {rows_total} rows")

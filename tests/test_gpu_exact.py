@@ -170,7 +170,7 @@ def test_exact_magnitudes_and_streamed_chunks():
 def test_exact_falls_back_to_float32_kernels_where_the_screen_does_not_apply():
     """input_len > 128 and the non-euclidean distances: 'exact' is served by the float32 kernels themselves."""
     X, Y, n = 12, 12, 600
-    for D, dist in ((200, "euclidean"), (32, "cosine"), (16, "manhattan")):
+    for D, dist in ((200, "euclidean"), (900, "euclidean"), (32, "cosine"), (16, "manhattan")):
         data = np.abs(O.gaussian_blobs(n, D, seed=3))
         w = np.abs(O.default_codebook(X, Y, D, 4)).astype(F32)
         ids = {}
@@ -249,3 +249,97 @@ def test_exact_in_several_screen_passes(monkeypatch):
         assert np.array_equal(got, want), (rows, int((got != want).sum()))
         assert np.array_equal(e.bmu(data[:3000]), want[:3000])
         e.close()
+
+
+# ---- beyond 128 features: the wide screen (maps of >= 4096 units, euclidean and cosine) -------------------------------
+
+def both_dist(X, Y, D, w, data, dist, sigma=3.0, eta=0.4):
+    out = {}
+    for p in ("f32", "exact"):
+        e = engine(X, Y, D, precision=p, distance=dist)
+        e.set_weights(w)
+        e.set_data(data)
+        e.epoch_accumulate(sigma, eta, True)
+        num, den, bmu = e.epoch_fetch()
+        q = e.bmu(data[:777])
+        out[p] = (bmu, q, num, den, e.exact_stats() if p == "exact" else None)
+        e.close()
+    return out
+
+
+WIDE_SHAPES = [(64, 64, 200, 3000), (64, 64, 784, 2500), (80, 60, 129, 1111), (64, 70, 300, 4097), (100, 100, 517, 2000),
+               (64, 64, 800, 700), (128, 64, 160, 5000)]
+
+
+@pytest.mark.parametrize("dist", ["euclidean", "cosine"])
+@pytest.mark.parametrize("X,Y,D,n", WIDE_SHAPES)
+def test_exact_wide_bmus_are_the_float32_bmus(X, Y, D, n, dist):
+    data = O.gaussian_blobs(n, D, seed=D + n)
+    w = O.default_codebook(X, Y, D, 11).astype(F32)
+    r = both_dist(X, Y, D, w, data, dist)
+    assert np.array_equal(r["exact"][0], r["f32"][0])
+    assert np.array_equal(r["exact"][1], r["f32"][1])
+    assert np.array_equal(r["exact"][2], r["f32"][2]) and np.array_equal(r["exact"][3], r["f32"][3])
+    rows, fb, _ = r["exact"][4]
+    assert rows >= n and fb <= max(2, n // 100)          # the screen serves: the float32 fallback is the exception
+
+
+@pytest.mark.parametrize("dist", ["euclidean", "cosine"])
+def test_exact_wide_training_is_bitwise_the_float32_training(dist):
+    from xpysom_dask_amd import XPySom
+    X, Y, D, n, T = 64, 64, 200, 6000, 5
+    data = np.abs(O.gaussian_blobs(n, D, seed=5)) + F32(0.05)
+    ws = {}
+    for p in ("f32", "exact"):
+        som = XPySom(X, Y, D, random_seed=3, precision=p, activation_distance=dist)
+        som.train(data, T)
+        ws[p] = som._weights.copy()
+        if p == "exact":
+            rows, fb, _ = som._engine().exact_stats()
+            assert rows == n * T and fb <= rows // 50
+    assert np.array_equal(ws["exact"], ws["f32"])
+
+
+@pytest.mark.parametrize("dist", ["euclidean", "cosine"])
+def test_exact_wide_ties_degenerate_rows_and_magnitudes(dist):
+    X, Y, D, n = 64, 64, 256, 2048
+    rng = np.random.default_rng(7)
+    w = rng.standard_normal((X * Y, D)).astype(F32)
+    w[100] = w[7]; w[4000] = w[7]; w[3000:3010] = w[2999]              # duplicate units: the first one wins
+    data = rng.standard_normal((n, D)).astype(F32)
+    data[0] = w[7]; data[1] = w[4000] * F32(1.0000001); data[2] = 0.0   # on a unit; next to it; a zero row
+    data[3] = data[4]                                                   # equal rows
+    data[5] = np.nan; data[6, 3] = np.inf; data[7] = 1e-30; data[8] = 1e18
+    data[100:200] *= F32(1e-3); data[200:300] *= F32(1e3)               # a wide spread of row norms
+    data[300:400] = w[rng.integers(0, X * Y, 100)] + F32(1e-4) * rng.standard_normal((100, D)).astype(F32)
+    r = both_dist(X, Y, D, w.reshape(X, Y, D), data, dist)
+    assert np.array_equal(r["exact"][0], r["f32"][0])
+    assert np.array_equal(r["exact"][1], r["f32"][1])
+    for scale in (1e-12, 1e9):                                          # the whole problem far from 1
+        r = both_dist(X, Y, D, (w * F32(scale)).reshape(X, Y, D), data * F32(scale), dist)
+        assert np.array_equal(r["exact"][0], r["f32"][0])
+
+
+def test_exact_wide_cosine_with_unusable_units_falls_back_whole():
+    """a zero unit (the float32 kernel's 0/0 -> nan_to_num rule) and units outside the window in which |x|^2 |w|^2 stays a
+    normal float32: the bound does not model them, every row goes to the float32 kernel."""
+    X, Y, D, n = 64, 64, 130, 900
+    rng = np.random.default_rng(3)
+    for bad in (0.0, 1e-25, 1e25):
+        w = rng.standard_normal((X * Y, D)).astype(F32)
+        w[17] = w[17] * F32(bad)
+        data = rng.standard_normal((n, D)).astype(F32)
+        r = both_dist(X, Y, D, w.reshape(X, Y, D), data, "cosine")
+        assert np.array_equal(r["exact"][0], r["f32"][0])
+        rows, fb, _ = r["exact"][4]
+        assert fb == rows
+
+
+def test_exact_wide_on_a_smooth_sheet():
+    """neighbouring units nearly identical: hundreds of near-ties per row."""
+    X, Y, D, n = 64, 64, 784, 3000
+    w = O.smooth_sheet_codebook(X, Y, D, seed=2).astype(F32)
+    data = O.gaussian_blobs(n, D, seed=9)
+    for dist in ("euclidean", "cosine"):
+        r = both_dist(X, Y, D, w, data, dist)
+        assert np.array_equal(r["exact"][0], r["f32"][0])

@@ -19,3 +19,13 @@ def test_fuzz(script, cases):
     tail = r.stdout[-3000:] + r.stderr[-2000:]
     assert r.returncode == 0, tail
     assert "%d cases, 0 failures" % cases in r.stdout, tail
+
+
+def test_fuzz_exact_wide():
+    """the exact mode's wide screen (129..800 features, >= 4096 units, euclidean and cosine)"""
+    env = dict(os.environ, FUZZ_WIDE="1")
+    r = subprocess.run([sys.executable, os.path.join("tests", "fuzz", "fuzz_exact.py"), "777", "120"], cwd=REPO, env=env,
+                       capture_output=True, text=True, timeout=600)
+    tail = r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.returncode == 0, tail
+    assert "120 cases, 0 failures" in r.stdout, tail

@@ -12,6 +12,8 @@ D = int(os.environ.get("EX_D", "128"))
 N = int(os.environ.get("EX_ROWS", "65536"))
 T = int(os.environ.get("EX_EPOCHS", "10"))
 MODES = os.environ.get("EX_MODES", "f32,exact,bf16x3,bf16").split(",")
+DIST = os.environ.get("EX_DIST", "euclidean")
+NEIGH = os.environ.get("EX_NEIGH", "gaussian")
 
 
 def main():
@@ -20,7 +22,7 @@ def main():
     w /= np.linalg.norm(w, axis=-1, keepdims=True)
     w = w.astype(np.float32)
     data = gaussian_blobs(N, D)
-    eng = {m: HipEngine(X, Y, D, precision=m) for m in MODES}
+    eng = {m: HipEngine(X, Y, D, precision=m, distance=DIST, neighborhood=NEIGH) for m in MODES}
     for e in eng.values():
         e.set_data(data)
     trainer = eng["f32"]

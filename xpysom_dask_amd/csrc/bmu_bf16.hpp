@@ -56,6 +56,7 @@ __device__ __forceinline__ float half_operand_error(float f, float fb) {
 // The screen (which group minima can still matter) and the scan (which do) evaluate it through this one function.
 struct ExactBound {
     float cA, cW, cB, cM;
+    int unit;                         // cosine: the operands are unit-length rows (|x_n| = wmax = 1 in the formula)
 };
 struct ExactScales {                  // per launch: from max|x|^2, max|w|^2, max_k |w^_k - w~_k|^2
     float sx, sw, wm, bmag, we;
@@ -74,7 +75,9 @@ __device__ __forceinline__ ExactScales ex_scales(const float* __restrict__ xmax2
 // E(n), or a NaN for a row / codebook the bound does not cover (NaN or infinite norms; norms so small that float32
 // products may underflow): such a row selects nothing and goes to the float32 kernel
 __device__ __forceinline__ float ex_row_bound(const ExactBound& eb, const ExactScales& s, float xsq, float xerr) {
-    const float xn = __builtin_sqrtf(xsq) * (1.0f + 1.0f / 1024.0f);
+    float xn = __builtin_sqrtf(xsq) * (1.0f + 1.0f / 1024.0f);
+    // cosine: unit-length operands; |x|^2 in the window that keeps |x|^2 |w|^2 a normal float32 (exact_werr_kernel)
+    if (eb.unit) xn = (xsq > 0x1p-60f && xsq < 0x1p60f) ? 1.0f + 1.0f / 1024.0f : __builtin_nanf("");
     const float e = s.sx * s.sw * (eb.cA * xn * s.wm + eb.cW * s.wm * s.wm + eb.cB * s.bmag) +
                     eb.cM * (xerr * s.sw * s.wm + (s.sx * xn + xerr) * s.we);
     const bool ok = e > 0.0f && e < 3.0e38f && xn * s.wm > 1.0e-20f && s.wm * s.wm > 1.0e-20f;

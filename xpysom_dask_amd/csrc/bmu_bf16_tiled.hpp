@@ -52,7 +52,8 @@ template <class EL = Bf16>
 __global__ __launch_bounds__(256) void prep_tiles_bf16_kernel(const float* __restrict__ A, long rows, int D,
                                                               int n_kchunks, long n_blocks, int brows, int tile_bytes,
                                                               float sign, const float* __restrict__ unit_sq,
-                                                              char* __restrict__ img, int split) {
+                                                              char* __restrict__ img, int split,
+                                                              const float* __restrict__ scale_max2 = nullptr) {
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     long id = (long)blockIdx.x * 256 + threadIdx.x;
@@ -70,11 +71,12 @@ __global__ __launch_bounds__(256) void prep_tiles_bf16_kernel(const float* __res
     int k0 = kc * TL_BK + ks * 32 + (lane >> 4) * 8;
     float scale = sign;
     if (unit_sq != nullptr && row < rows) { float q = unit_sq[row]; scale = q > 0.0f ? sign / __builtin_sqrtf(q) : 0.0f; }
+    const float pow2 = scale_max2 != nullptr ? ex_scale(*scale_max2) : 1.0f;   // exact mode: a power of two on top (exact)
     bf16x8 v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         if (split == 0) {
-            float f = (row < rows && k0 + j < D) ? A[row * D + k0 + j] * scale : 0.0f;
+            float f = (row < rows && k0 + j < D) ? A[row * D + k0 + j] * scale * pow2 : 0.0f;
             v[j] = cvt<E>(f);
         } else {
             const int kv = k0 + j, seg = kv / D, k = kv - seg * D;

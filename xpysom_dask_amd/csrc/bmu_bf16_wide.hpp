@@ -38,7 +38,8 @@ __host__ __device__ constexpr int wd_stage_bytes(int ks32) { return (WD_T * ks32
 template <class EL = Bf16>
 __global__ __launch_bounds__(256) void prep_w_bf16_wide_kernel(const float* __restrict__ W, int K, int D, int ks32,
                                                                char* __restrict__ Wst, int n_stages,
-                                                               const float* __restrict__ unit_wsq, int split) {
+                                                               const float* __restrict__ unit_wsq, int split,
+                                                               const float* __restrict__ scale_max2 = nullptr) {
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     long id = (long)blockIdx.x * 256 + threadIdx.x;
@@ -53,11 +54,12 @@ __global__ __launch_bounds__(256) void prep_w_bf16_wide_kernel(const float* __re
     int k0 = ks * 32 + (lane >> 4) * 8;
     float scale = 1.0f;                          // cosine: unit-length rows (prep_w_bf16_k16_kernel)
     if (unit_wsq != nullptr && u < K) { float q = unit_wsq[u]; scale = q > 0.0f ? 1.0f / __builtin_sqrtf(q) : 0.0f; }
+    const float pow2 = scale_max2 != nullptr ? ex_scale(*scale_max2) : 1.0f;   // exact mode: a power of two on top (exact)
     bf16x8 v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         if (split == 0) {
-            float f = (u < K && k0 + j < D) ? W[u * D + k0 + j] * scale : 0.0f;
+            float f = (u < K && k0 + j < D) ? W[u * D + k0 + j] * scale * pow2 : 0.0f;
             v[j] = cvt<E>(-f);
         } else {
             const int kv = k0 + j, seg = kv / D, k = kv - seg * D;
@@ -172,10 +174,21 @@ __global__ __launch_bounds__(256) void merge_prep_wide_kernel(float* __restrict_
     }
 }
 
-template <int KS32, class EL = Bf16>
+// GM (precision 'exact' beyond 128 features, bmu_exact.hpp): as in bmu_bf16_k16_kernel<.., GM = true> -- values only,
+// the minimum of every GROUP of 64 units (two stages) per row stored where it is within the row's bound of the
+// minimum so far, and the mask of the rows stored (32 per wave) per group; the parts split on group boundaries.
+template <int KS32, class EL = Bf16, bool GM = false>
 __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* __restrict__ Ximg, long N,
                                                                    const char* __restrict__ Wst, int n_stages,
-                                                                   unsigned long long* __restrict__ out64) {
+                                                                   unsigned long long* __restrict__ out64,
+                                                                   uint32_t* __restrict__ gmin = nullptr, long gm_stride = 0,
+                                                                   uint32_t* __restrict__ gflags32 = nullptr,
+                                                                   const float* __restrict__ xsq = nullptr,
+                                                                   const float* __restrict__ xerr = nullptr,
+                                                                   const float* __restrict__ xmax2 = nullptr,
+                                                                   const float* __restrict__ wmax2 = nullptr,
+                                                                   const float* __restrict__ werr2 = nullptr,
+                                                                   ExactBound eb = ExactBound()) {
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     constexpr int STAGE = wd_stage_bytes(KS32);
@@ -189,9 +202,25 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
     const int quad = lane >> 4, col = lane & 15;
 
     // this workgroup's share of the codebook stages
-    const int s_begin = (int)((long)n_stages * blockIdx.y / gridDim.y);
-    const int s_end = (int)((long)n_stages * (blockIdx.y + 1) / gridDim.y);
+    int s_begin = (int)((long)n_stages * blockIdx.y / gridDim.y);
+    int s_end = (int)((long)n_stages * (blockIdx.y + 1) / gridDim.y);
+    if (GM) {                                                // parts of whole groups (pairs of stages)
+        const int n_groups = (n_stages + 1) / 2;
+        s_begin = 2 * (int)((long)n_groups * blockIdx.y / gridDim.y);
+        s_end = min(2 * (int)((long)n_groups * (blockIdx.y + 1) / gridDim.y), n_stages);
+    }
     if (s_begin >= s_end) return;                            // (whole workgroup: no barrier is left behind)
+    // GM: lane l < 32 <-> row (block, wave, l): its minimum so far, its bound E; pmin: this lane's minimum over the group
+    const long wave_row0 = (long)blockIdx.x * WD_WG_SAMPLES + wave * (WD_SB * 16);
+    float run_min = __builtin_inff(), row_e = __builtin_inff();
+    uint32_t pmin[WD_SB];
+#pragma unroll
+    for (int sb = 0; sb < WD_SB; ++sb) pmin[sb] = 0xFFFFFFFFu;
+    if (GM) {
+        const long r = wave_row0 + (lane & 31);
+        const float e = r < N ? ex_row_bound(eb, ex_scales(xmax2, wmax2, werr2), xsq[r], xerr[r]) : __builtin_nanf("");
+        if (e == e) row_e = e;                               // (a row the bound does not cover keeps everything: the scan drops it)
+    }
 
     auto issue = [&](int s, int slot) {
 #if defined(SOM_WD_EXPERIMENT) && SOM_WD_EXPERIMENT == 1
@@ -251,6 +280,39 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
                 for (int sb = 0; sb < WD_SB; ++sb)
                     acc[t][sb] = mfma16(a[t], xf[sb][ks], acc[t][sb]);
         }
+        if (GM) {
+            static_assert(!GM || WD_SB == 2, "the group-minimum store pairs two 16-sample blocks per wave");
+#pragma unroll
+            for (int sb = 0; sb < WD_SB; ++sb) {
+                uint32_t c = 0xFFFFFFFFu;
+#pragma unroll
+                for (int t = 0; t < WD_T; ++t) {
+                    c = min(min(c, __float_as_uint(acc[t][sb][0])), __float_as_uint(acc[t][sb][1]));
+                    c = min(min(c, __float_as_uint(acc[t][sb][2])), __float_as_uint(acc[t][sb][3]));
+                }
+                pmin[sb] = min(pmin[sb], c);
+                gbest[sb] = min(gbest[sb], c);
+            }
+            if ((s & 1) || s == s_end - 1) {                 // the group is complete: join the four lane quads, store
+                uint32_t v[WD_SB];
+#pragma unroll
+                for (int sb = 0; sb < WD_SB; ++sb) {
+                    const auto a = __builtin_amdgcn_permlane32_swap(pmin[sb], pmin[sb], false, false);
+                    const uint32_t m2 = min(a[0], a[1]);
+                    const auto b = __builtin_amdgcn_permlane16_swap(m2, m2, false, false);
+                    v[sb] = min(b[0], b[1]);
+                    pmin[sb] = 0xFFFFFFFFu;
+                }
+                // lanes 0..15: sample block 0, lanes 16..31: sample block 1 = 32 consecutive rows
+                const uint32_t full = (lane & 16) ? v[WD_SB - 1] : v[0];
+                const float f = __uint_as_float(full);
+                const bool keep = lane < 32 && f <= run_min + row_e;
+                run_min = __builtin_fminf(run_min, f);
+                if (keep) gmin[(long)(s >> 1) * gm_stride + wave_row0 + lane] = full;
+                const unsigned long long mask = __ballot(keep);
+                if (lane == 0) gflags32[(long)(s >> 1) * (gm_stride >> 5) + (wave_row0 >> 5)] = (uint32_t)mask;
+            }
+        } else {
 #pragma unroll
         for (int sb = 0; sb < WD_SB; ++sb) {
             uint32_t c0 = 0xFFFFFFFFu, c1 = 0xFFFFFFFFu;
@@ -266,6 +328,7 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
             const uint32_t c = min(c0, c1);
             if (c < gbest[sb]) { gbest[sb] = c; gstage[sb] = s; }
         }
+        }
         cslot = cslot == WD_SLOTS - 1 ? 0 : cslot + 1;
         islot = islot == WD_SLOTS - 1 ? 0 : islot + 1;
     }
@@ -276,6 +339,7 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
         const uint32_t code = gbest[sb] & IDX_MASK;
         const uint32_t unit = (uint32_t)gstage[sb] * WD_STAGE_UNITS + (code >> 2) * 16 + quad * 4 + (code & 3);
         unsigned long long comp = ((unsigned long long)(gbest[sb] & ~IDX_MASK) << 32) | unit;
+        if (GM) comp = (unsigned long long)gbest[sb] << 32;  // the plain minimum, every bit of it (no indices kept)
         unsigned long long o = __shfl_xor(comp, 16, 64);
         if (o < comp) comp = o;
         o = __shfl_xor(comp, 32, 64);

@@ -45,12 +45,14 @@
 // groups, and a candidate group costs one 64-unit re-score.
 #pragma once
 #include "bmu_bf16_k16.hpp"
+#include "bmu_bf16_wide.hpp"
 #include "bmu_f32_res.hpp"
+#include "bmu_f32_tiled.hpp"
 
 namespace somhip {
 
 constexpr int EX_GROUP = 64;          // units per group = one stage of the float32 stage image = one stage of the screen
-constexpr int EX_PAIRS = 64;          // capacity of a pass: this many (row, group) pairs per row ON AVERAGE
+constexpr int EX_PAIRS = 64;          // least capacity of a pass in (row, group) pairs per row ON AVERAGE (exact_reserve sizes it)
 constexpr int EX_SCAN_SPLIT = 4;      // waves that share a row's groups in the scan
 constexpr int EX_TR = 128;            // rows per re-score tile (4 waves x 32 rows against one 64-unit group)
 
@@ -301,6 +303,121 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_mfma_kernel(const float*
     }
 }
 
+// The same re-score beyond 128 features, on the float32 TILE image (bmu_f32_tiled.hpp: [128-unit block][32-feature chunk]
+// of 16 KB fragments + the block's |w|^2): a tile is up to 128 rows of a group's list against the group's 64 units (one
+// half of a unit block), the features go by in chunks of 32 -- the group's 8 KB of fragments by LDS-DMA into a two-slot
+// ring, the rows' 128 bytes gathered into registers a chunk ahead -- and the accumulators live across the chunks: the
+// k-ordered chain of bmu_f32_tiled_kernel, its epilogues (score_f32<MODE>: euclidean or cosine), its first-minimum rule.
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void exact_rescore_tiled_kernel(const float* __restrict__ X, int D,
+                                                                     const float* __restrict__ xsq,
+                                                                     const char* __restrict__ Wfimg, int n_kchunks, int K,
+                                                                     const int4* __restrict__ tile_tab,
+                                                                     const int* __restrict__ n_tiles_dev,
+                                                                     const int* __restrict__ plist,
+                                                                     unsigned long long* __restrict__ best64) {
+    __shared__ __attribute__((aligned(16))) char ring[2][8192];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, col = lane & 31;
+    const int n_tiles = *n_tiles_dev;
+    const int per = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t_begin = blockIdx.x * per, t_end = min(t_begin + per, n_tiles);
+    const bool vec = (D & 3) == 0;
+    auto entry = [&](int t) -> int {
+        if (t >= t_end) return -1;
+        const int4 tt = tile_tab[t];
+        const int i = wave * 32 + col;
+        return i < tt.z ? plist[tt.y + i] : -1;
+    };
+    // this lane's 16 operands of feature chunk kc: features 32 kc + 8 g + 2 j + half, g, j = 0..3
+    auto gather = [&](int row, int kc, float (&b)[16]) {
+        const int k0 = 32 * kc;
+        if (vec) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row >= 0 && k0 + 4 * c < D) v = *(const f32x4*)(X + (long)row * D + k0 + 4 * c);
+                b[2 * c] = half ? v[1] : v[0];
+                b[2 * c + 1] = half ? v[3] : v[2];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k = k0 + 2 * i + half;
+                b[i] = (row >= 0 && k < D) ? X[(long)row * D + k] : 0.0f;
+            }
+        }
+    };
+    int row_next = entry(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        const int g = tile_tab[t].x;
+        const int ub = g >> 1, uh = g & 1;                 // 128-unit block of the tile image, which half of it
+        const int row = row_next;
+        const bool wave_live = __ballot(row >= 0) != 0;    // (wave-uniform)
+        const float xs = (MODE != SCORE_EUCLID_PART && row >= 0) ? xsq[row] : 0.0f;
+        const char* wtile = Wfimg + (long)ub * n_kchunks * FT_WTILE;
+        auto stage_dma = [&](int kc, int slot) {           // the half block's 8 KB of fragments of chunk kc
+            const char* src = wtile + (long)kc * FT_WTILE + uh * 8192;
+            for (int p = wave; p < 8; p += 4) lds_dma_16(src + p * 1024 + lane * 16, ring[slot] + p * 1024);
+        };
+        __builtin_amdgcn_s_barrier();                      // everyone is done with the previous tile's ring
+        stage_dma(0, 0);
+        float b[16], bn[16];
+        gather(row, 0, b);
+        row_next = entry(t + 1);
+        f32x16 acc[2];
+#pragma unroll
+        for (int tu = 0; tu < 2; ++tu)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tu][r] = 0.0f;
+        for (int kc = 0; kc < n_kchunks; ++kc) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk kc: this wave's ring pieces and row operands
+            __builtin_amdgcn_s_barrier();                      // ... everybody's pieces; the other slot is free
+            asm volatile("" ::: "memory");
+            if (kc + 1 < n_kchunks) { stage_dma(kc + 1, (kc + 1) & 1); gather(row, kc + 1, bn); }
+            if (wave_live) {
+                const char* st = ring[kc & 1];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f32x4 a[2];
+#pragma unroll
+                    for (int tu = 0; tu < 2; ++tu) a[tu] = *(const f32x4*)(st + ((tu * 4 + g4) * 64 + lane) * 16);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int tu = 0; tu < 2; ++tu)
+                            acc[tu] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tu][j], b[4 * g4 + j], acc[tu], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) b[i] = bn[i];
+        }
+        if (!wave_live) continue;
+        const float* wq = (const float*)(wtile + FT_TILE);     // the block's 128 |w|^2 (+inf behind the last unit)
+        float best = __builtin_inff();
+        int bkey = 0;
+#pragma unroll
+        for (int tu = 0; tu < 2; ++tu) {
+            f32x4 wv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wv[q] = *(const f32x4*)(wq + uh * 64 + tu * 32 + 8 * q + 4 * half);
+            const int tile = ub * (FT_BN / 32) + uh * 2 + tu;
+            if ((tile + 1) * 32 > K) f32_tile_argmin<MODE, true>(acc[tu], wv, xs, tile, half, K, best, bkey);
+            else f32_tile_argmin<MODE, false>(acc[tu], wv, xs, tile, half, K, best, bkey);
+        }
+        int bidx = f32_key_unit(bkey, half);
+        const float ob = __shfl_xor(best, 32, 64);
+        const int oi = __shfl_xor(bidx, 32, 64);
+        if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+        if (half == 0 && row >= 0) {
+            const uint32_t bits = __float_as_uint(best);
+            const uint32_t key = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+            atomicMin(best64 + row, ((unsigned long long)key << 32) | (uint32_t)bidx);
+        }
+    }
+}
+
 // merge key -> id; rows the scheme cannot vouch for (no candidate was scored: the key is still all ones; a best score
 // that is not finite; an overflowed pass) -> the fallback list
 __global__ __launch_bounds__(256) void exact_finalize_kernel(const unsigned long long* __restrict__ best64, long N, int K,
@@ -340,15 +457,49 @@ __global__ __launch_bounds__(256) void exact_max_kernel(const float* __restrict_
     if ((threadIdx.x & 63) == 0) atomic_max_pos_f32(out, m);
 }
 
-// max_k |w^_k - w~_k|^2 over the units (w^ = sw w in float32, w~ = what the MFMA reads: half_operand_error) into *out
+// |x^_n - x~_n| of every row for the tile-image screens (beyond 128 features): x^ = x * (1/|x| when unit_sq) * the power
+// of two of ex_scale(*scale_max2), exactly as prep_tiles_bf16_kernel forms it; one wave per row
+template <class EL>
+__global__ __launch_bounds__(256) void exact_rowerr_kernel(const float* __restrict__ X, long N, int D,
+                                                           const float* __restrict__ unit_sq,
+                                                           const float* __restrict__ scale_max2, float* __restrict__ xerr) {
+    using E = typename EL::T;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= N) return;
+    float scale = 1.0f;
+    if (unit_sq != nullptr) { const float q = unit_sq[row]; scale = q > 0.0f ? 1.0f / __builtin_sqrtf(q) : 0.0f; }
+    const float pow2 = ex_scale(*scale_max2);
+    float er = 0.0f;
+    for (int k = lane; k < D; k += 64) {
+        const float f = X[row * D + k] * scale * pow2;
+        const float e = half_operand_error(f, (float)cvt<E>(f));
+        er = __builtin_fmaf(e, e, er);
+    }
+    er = wave_sum(er);
+    if (lane == 0) xerr[row] = __builtin_sqrtf(er) * (1.0f + 1.0f / 1024.0f);
+}
+
+// max_k |w^_k - w~_k|^2 over the units (w^ = sw w in float32 -- of the unit-length w / |w| when unit_wsq --, w~ = what the
+// MFMA reads: half_operand_error) into *out
 template <class EL>
 __global__ __launch_bounds__(256) void exact_werr_kernel(const float* __restrict__ W, int K, int D,
-                                                         const float* __restrict__ wmax2, float* __restrict__ out) {
+                                                         const float* __restrict__ wmax2, float* __restrict__ out,
+                                                         const float* __restrict__ unit_wsq = nullptr) {
     using E = typename EL::T;
     const long u = (long)blockIdx.x * 256 + threadIdx.x;
     float er = 0.0f;
+    bool poison = false;
     if (u < K) {
-        const float scale = ex_scale(*wmax2);
+        float scale = 1.0f;
+        if (unit_wsq != nullptr) {
+            const float q = unit_wsq[u];
+            scale = q > 0.0f ? 1.0f / __builtin_sqrtf(q) : 0.0f;
+            // cosine: |x|^2 |w|^2 must stay a normal float32 for the float32 kernel's division to be what the bound models
+            // (ex_row_bound keeps |x|^2 in the same window); a zero, tiny, huge or NaN unit: no bound -> every row falls back
+            if (!(q > 0x1p-60f && q < 0x1p60f)) poison = true;
+        }
+        scale *= ex_scale(*wmax2);
         for (int k = 0; k < D; ++k) {
             const float f = W[u * D + k] * scale;
             const float e = half_operand_error(f, (float)cvt<E>(f));
@@ -356,6 +507,7 @@ __global__ __launch_bounds__(256) void exact_werr_kernel(const float* __restrict
         }
     }
     float m = (er == er) ? er : 0.0f;
+    if (poison) m = __builtin_inff();
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) atomic_max_pos_f32(out, m);

@@ -82,6 +82,7 @@ struct som_handle {
         int* fb_count_host = nullptr;        // pinned
         int64_t rows_total = 0, rows_fallback = 0, chunks = 0;   // som_exact_stats
         long pass_rows_override = 0;
+        long pairs = 64;                  // capacity of a pass: (row, group) pairs per row on average (exact_reserve)
     } ex;
     int n_kchunks = 0;       // tiled: 64-feature chunks
     int n_ublocks = 0;       // tiled: unit blocks of tl_bn
@@ -321,6 +322,23 @@ int prep_codebook_half(som_handle* h) {
     const float* unit = h->cfg.distance == SOM_DIST_COSINE ? h->wsq : nullptr;
     const dim3 block(256);
     if (h->tiled) {
+        if (h->wide && h->exact) {
+            // exact mode beyond 128 features: the float32 kernel's own |w|^2 as the norm term (euclidean) or none (cosine:
+            // unit-length units, max |w| = 1), the units scaled by a power of two, their rounding errors measured
+            if (unit) {
+                HIPCHK(h, hipMemsetAsync(h->wn, 0, (size_t)h->K * sizeof(float), h->stream));
+                HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)h->wmax2, 0x3F800000, 1, h->stream));
+            } else {
+                HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
+                exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(h->K, 256)), block, 0, h->stream>>>(h->wsq, h->K, h->wn, h->wmax2);
+            }
+            long total = (long)h->n_stages * WD_T * h->n_kchunks * 64;
+            prep_w_bf16_wide_kernel<E><<<dim3((unsigned)cdiv(total, 256)), block, 0, h->stream>>>(
+                h->W, h->K, h->D, h->n_kchunks, h->Wst, h->n_stages, unit, 0, h->wmax2);
+            HIPCHK(h, hipMemsetAsync(h->wmax2 + 1, 0, sizeof(float), h->stream));
+            exact_werr_kernel<E><<<dim3((unsigned)cdiv(h->K, 256)), block, 0, h->stream>>>(h->W, h->K, h->D, h->wmax2, h->wmax2 + 1, unit);
+            return 0;
+        }
         if (h->wide) {
             long total = (long)h->n_stages * WD_T * h->n_kchunks * 64;
             prep_w_bf16_wide_kernel<E><<<dim3((unsigned)cdiv(total, 256)), block, 0, h->stream>>>(
@@ -634,8 +652,8 @@ int launch_bmu_bf16_wide(som_handle* h, const __bf16* Ximg, const float* xmax2, 
     if (h->debug)
         std::fprintf(stderr, "[somhip] bmu_bf16_wide: blocks=%ld per_cu=%d slots=%ld parts=%d stages=%d\n", blocks, per_cu, slots,
                      parts, h->n_stages);
-    kern<<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * WD_NW), lds, h->stream>>>((const char*)Ximg, N, h->Wst,
-                                                                                       h->n_stages, h->best64);
+    bmu_bf16_wide_kernel<KS32, E><<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * WD_NW), lds, h->stream>>>(
+        (const char*)Ximg, N, h->Wst, h->n_stages, h->best64);
     bmu_finalize_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(h->best64, N, h->K, out);
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -715,6 +733,21 @@ int prep_rows_half(som_handle* h, const float* X, long N, long Np, __bf16* Xb, f
     const int Dp = h->dp;
     const bool unit = h->cfg.distance == SOM_DIST_COSINE;
     HIPCHK(h, hipMemsetAsync(xmax2, 0, sizeof(float), h->stream));
+    if (h->tiled && h->exact) {
+        // |x|^2 in NumPy's order is in xsq_scratch (the caller's row_sq); its second half takes the rounding errors
+        float* xerr = exact_err_of(h, xsq_scratch);
+        if ((!xsq_scratch || !xerr) && N > 0) return fail(h, "exact: no row-norm buffer");
+        const float* usq = unit ? xsq_scratch : nullptr;
+        if (unit) HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)xmax2, 0x3F800000, 1, h->stream));   // unit-length rows: max |x| = 1
+        else if (N > 0) exact_max_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(xsq_scratch, N, xmax2);
+        const long n_blocks = Np / h->tl_bm;
+        const long total = n_blocks * h->n_kchunks * (h->tl_bm / 16) * TL_KS * 64;
+        prep_tiles_bf16_kernel<E><<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
+            X, N, h->D, h->n_kchunks, n_blocks, h->tl_bm, h->tl_xtile, 1.0f, usq, (char*)Xb, 0, xmax2);
+        if (N > 0) exact_rowerr_kernel<E><<<dim3((unsigned)cdiv(N, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, usq, xmax2, xerr);
+        HIPCHK(h, hipGetLastError());
+        return 0;
+    }
     if (h->tiled) {
         const float* usq = nullptr;
         if (unit && N > 0) {
@@ -799,16 +832,25 @@ int launch_bmu_pairwise(som_handle* h, const float* X, long N, int p, bool even,
 constexpr double EX_KAPPA = 6.0;     // measured through som_debug_mfma16: <= 2.4 (tests/test_gpu_exact.py holds it below 3)
 ExactBound exact_bound(const som_handle* h) {
     const double u = std::ldexp(1.0, -24);
-    const double Dl = 8.0 * h->fr_kg;                    // chain length of the float32 kernel (zero padded)
+    // chain length of the float32 kernel (zero padded), MFMAs of the screen's one accumulator chain
+    const double Dl = h->wide ? 32.0 * h->ft_kchunks : 8.0 * h->fr_kg;
+    const double n_mfma = h->wide ? h->n_kchunks : h->ks32;
     const double gamma = Dl * u / (1.0 - Dl * u);
     const double slop = 1.01;                             // the kernel evaluates E in float32
-    const double e32 = (2.0 * gamma + 2.0 * u) * (1.0 + u);   // float32 kernel, relative to A (tau units)
     ExactBound eb{};
-    eb.cW = (float)(slop * u);
     // one pass on scaled half operands, measured operand errors (bmu_exact.hpp); +1: the initial accumulator's rounding
-    eb.cA = (float)(slop * e32);
-    eb.cB = (float)(slop * 2.0 * (EX_KAPPA * h->ks32 + 1.0) * std::ldexp(1.0, -23));
+    eb.cB = (float)(slop * 2.0 * (EX_KAPPA * n_mfma + 1.0) * std::ldexp(1.0, -23));
     eb.cM = (float)(slop * 2.0);
+    if (h->cfg.distance == SOM_DIST_COSINE) {
+        // scores 1 - cos: the float32 kernel's chain (gamma_D), its two pairwise |.|^2 sums, product, sqrt, division and
+        // subtraction (< 27 u together); the screen's two normalisations 1/sqrt(|.|^2) and their products (< 30 u)
+        eb.cA = (float)(slop * 2.0 * (gamma + 57.0 * u));
+        eb.cW = 0.0f;
+        eb.unit = 1;
+    } else {
+        eb.cA = (float)(slop * (2.0 * gamma + 2.0 * u) * (1.0 + u));   // float32 kernel, relative to A (tau units)
+        eb.cW = (float)(slop * u);
+    }
     if (const char* e = std::getenv("SOM_EXACT_BOUND_SCALE")) {   // experiments: how the candidate load grows with the band
         const float f = (float)std::atof(e);
         if (f > 1.0f) { eb.cA *= f; eb.cW *= f; eb.cB *= f; eb.cM *= f; }
@@ -834,13 +876,17 @@ int exact_reserve(som_handle* h, long rows) {
     ex.gmin = nullptr; ex.gflags = nullptr; ex.bm = nullptr; ex.fb_list = nullptr; ex.plist = nullptr; ex.tile_tab = nullptr;
     ex.stride = 0;
     const long n_groups = cdiv(h->K, EX_GROUP);
-    if (stride * EX_PAIRS > 0x7fffffffL) return fail(h, "exact: pass too large");
+    // capacity of a pass in (row, group) pairs per row on average: a quarter of the groups -- past that the float32
+    // kernel over all of them costs about what the re-score would
+    ex.pairs = std::max<long>(EX_PAIRS, std::min<long>(n_groups / 4, 512));
+    if (const char* e = std::getenv("SOM_EXACT_PAIRS")) ex.pairs = std::max(1L, std::atol(e));
+    if (stride * ex.pairs > 0x7fffffffL) return fail(h, "exact: pass too large");
     if (int rc = dev_alloc(h, &ex.gmin, (size_t)n_groups * stride)) return rc;
     if (int rc = dev_alloc(h, &ex.gflags, (size_t)n_groups * (stride / 64))) return rc;
     if (int rc = dev_alloc(h, &ex.bm, (size_t)cdiv(n_groups, 32) * stride)) return rc;
-    if (int rc = dev_alloc(h, &ex.plist, (size_t)stride * EX_PAIRS)) return rc;
+    if (int rc = dev_alloc(h, &ex.plist, (size_t)stride * ex.pairs)) return rc;
     if (int rc = dev_alloc(h, &ex.fb_list, (size_t)stride)) return rc;
-    ex.max_tiles = cdiv(stride * EX_PAIRS, EX_TR) + n_groups;
+    ex.max_tiles = cdiv(stride * ex.pairs, EX_TR) + n_groups;
     if (int rc = dev_alloc(h, &ex.tile_tab, (size_t)ex.max_tiles)) return rc;
     if (!ex.ctr) {
         if (int rc = dev_alloc(h, &ex.ctr, (size_t)3 * n_groups + 3)) return rc;
@@ -871,9 +917,52 @@ int exact_screen(som_handle* h, const __bf16* Xb, long n, unsigned long long* be
     return 0;
 }
 
+// beyond 128 features: the wide kernel's GM instance (groups = pairs of its 32-unit stages)
+template <int KS32, class E>
+int exact_screen_wide(som_handle* h, const __bf16* Ximg, long n, unsigned long long* best64, const float* xsq, const float* xerr,
+                      const float* xmax2, const ExactBound& eb) {
+    auto kern = bmu_bf16_wide_kernel<KS32, E, true>;
+    const size_t lds = (size_t)WD_SLOTS * wd_stage_bytes(KS32);
+    int per_cu = 1;
+    if (int rc = kernel_per_cu(h, (const void*)kern, 64 * WD_NW, lds, &per_cu)) return rc;
+    const long blocks = cdiv(n, WD_WG_SAMPLES);
+    const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
+    const int n_groups = (int)cdiv(h->n_stages, 2);
+    int parts = 1;
+    if (blocks < slots) parts = (int)std::min<long>(cdiv(slots, blocks), 64);
+    else {
+        double best_eff = 0.0;
+        for (int p = 1; p <= 8; ++p) {
+            const long wgs = blocks * p;
+            const double eff = (double)wgs / (double)(cdiv(wgs, slots) * slots);
+            if (eff > best_eff + 0.01) { best_eff = eff; parts = p; }
+        }
+    }
+    if (h->env_bf16_parts > 0) parts = h->env_bf16_parts;
+    parts = std::max(1, std::min(parts, n_groups));
+    if (h->debug)
+        std::fprintf(stderr, "[somhip] exact screen (wide): blocks=%ld per_cu=%d slots=%ld parts=%d groups=%d\n", blocks, per_cu, slots,
+                     parts, n_groups);
+    kern<<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * WD_NW), lds, h->stream>>>(
+        (const char*)Ximg, n, h->Wst, h->n_stages, best64, h->ex.gmin, h->ex.stride, (uint32_t*)h->ex.gflags, xsq, xerr, xmax2,
+        h->wmax2, h->wmax2 + 1, eb);
+    return 0;
+}
+
 template <class E>
 int exact_screen_ks(som_handle* h, const __bf16* Xb, long n, unsigned long long* best64, const float* xsq, const float* xerr,
                     const float* xmax2, const ExactBound& eb) {
+    if (h->wide) {
+        switch (h->n_kchunks) {
+#define SOM_WIDE_CASE(k) case k: return exact_screen_wide<k, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb);
+        SOM_WIDE_CASE(5) SOM_WIDE_CASE(6) SOM_WIDE_CASE(7) SOM_WIDE_CASE(8) SOM_WIDE_CASE(9) SOM_WIDE_CASE(10)
+        SOM_WIDE_CASE(11) SOM_WIDE_CASE(12) SOM_WIDE_CASE(13) SOM_WIDE_CASE(14) SOM_WIDE_CASE(15) SOM_WIDE_CASE(16)
+        SOM_WIDE_CASE(17) SOM_WIDE_CASE(18) SOM_WIDE_CASE(19) SOM_WIDE_CASE(20) SOM_WIDE_CASE(21) SOM_WIDE_CASE(22)
+        SOM_WIDE_CASE(23) SOM_WIDE_CASE(24) SOM_WIDE_CASE(25)
+#undef SOM_WIDE_CASE
+        }
+        return fail(h, "exact: no wide screen instance for this input_len");
+    }
     switch (h->ks32) {
     case 1: return exact_screen<1, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb);
     case 2: return exact_screen<2, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb);
@@ -899,18 +988,39 @@ int exact_rescore_kg(som_handle* h, const float* X, int n_groups) {
 
 // the re-score of one pass: bucket the (row, group) pairs by group, score tile by tile, settle the rows.  best64 is the
 // pass's slice of the merge keys (the scan has read the screen's minima from it; the fill resets it).
-int exact_rescore(som_handle* h, const float* X, long n, unsigned long long* best64, int* out) {
+int exact_rescore(som_handle* h, const float* X, const float* xsq, long n, unsigned long long* best64, int* out) {
     auto& ex = h->ex;
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
     int* gcount = ex.ctr; int* gfill = ex.ctr + n_groups; int* fb_count = ex.ctr + 2 * n_groups;
     int* n_tiles = fb_count + 1; int* overflow = fb_count + 2; int* goff = fb_count + 3;
-    exact_offsets_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(gcount, n_groups, ex.stride * EX_PAIRS, goff, ex.tile_tab, n_tiles,
+    exact_offsets_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(gcount, n_groups, ex.stride * ex.pairs, goff, ex.tile_tab, n_tiles,
                                                                overflow);
     exact_fill_kernel<<<dim3((unsigned)cdiv(n, 64)), dim3(64 * EX_SCAN_SPLIT), 0, h->stream>>>(ex.bm, ex.stride, n_groups, n, goff,
                                                                                           gfill, overflow, ex.plist, best64);
     unsigned long long* saved = h->best64;
     h->best64 = best64;                                   // (exact_rescore_kg reads it from the handle)
     int rc = 0;
+    if (h->wide) {
+        // beyond 128 features: the float32 tile image, chunk by chunk
+        if (!h->Wfimg) { h->best64 = saved; return fail(h, "exact: no float32 tile image"); }
+        const bool cosine = h->cfg.distance == SOM_DIST_COSINE;
+        const void* kern = cosine ? (const void*)exact_rescore_tiled_kernel<SCORE_COSINE>
+                                  : (const void*)exact_rescore_tiled_kernel<SCORE_EUCLID_PART>;
+        int per_cu = 1;
+        if (int rc2 = kernel_per_cu(h, kern, 256, 0, &per_cu)) { h->best64 = saved; return rc2; }
+        const long grid = std::min<long>(ex.max_tiles, 2L * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
+        int* n_tiles_dev = ex.ctr + 2 * n_groups + 1;
+        if (cosine)
+            exact_rescore_tiled_kernel<SCORE_COSINE><<<dim3((unsigned)grid), dim3(256), 0, h->stream>>>(
+                X, h->D, xsq, h->Wfimg, h->ft_kchunks, h->K, ex.tile_tab, n_tiles_dev, ex.plist, best64);
+        else
+            exact_rescore_tiled_kernel<SCORE_EUCLID_PART><<<dim3((unsigned)grid), dim3(256), 0, h->stream>>>(
+                X, h->D, xsq, h->Wfimg, h->ft_kchunks, h->K, ex.tile_tab, n_tiles_dev, ex.plist, best64);
+        h->best64 = saved;
+        exact_finalize_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(best64, n, h->K, overflow, out, ex.fb_list,
+                                                                                     fb_count);
+        return 0;
+    }
     switch (h->fr_kg) {
     case 1: rc = exact_rescore_kg<1>(h, X, n_groups); break;
     case 2: rc = exact_rescore_kg<2>(h, X, n_groups); break;
@@ -956,7 +1066,7 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         exact_scan_kernel<<<dim3((unsigned)cdiv(n, 64)), dim3(64 * EX_SCAN_SPLIT), 0, h->stream>>>(
             ex.gmin, ex.gflags, ex.stride, n_groups, n, h->best64 + r0, xsq + r0, h->wmax2, xmax2, eb, xerr + r0, h->wmax2 + 1, ex.bm,
             ex.ctr);
-        if (int rc = exact_rescore(h, X + r0 * h->D, n, h->best64 + r0, out + r0)) return rc;
+        if (int rc = exact_rescore(h, X + r0 * h->D, xsq + r0, n, h->best64 + r0, out + r0)) return rc;
         HIPCHK(h, hipGetLastError());
         // rows the scheme could not settle (normally none): the float32 kernel itself
         HIPCHK(h, hipMemcpyAsync(ex.fb_count_host, ex.ctr + 2 * n_groups, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -976,7 +1086,12 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
             exact_gather_rows_kernel<<<dim3((unsigned)cdiv((long)n_fb * h->D, 256)), dim3(256), 0, h->stream>>>(
                 X + r0 * h->D, ex.fb_list, n_fb, h->D, ex.fbX);
             // (its part merge may reuse best64[0 .. n_fb): rows this pass has already settled)
-            if (int rc = launch_bmu_f32_any<SCORE_EUCLID_PART>(h, ex.fbX, n_fb, nullptr, ex.fb_ids)) return rc;
+            if (h->cfg.distance == SOM_DIST_COSINE) {
+                // (|x|^2 of the gathered rows in NumPy's order, into the head of the pass's spent minima)
+                float* fsq = (float*)ex.gmin;
+                row_sq_f32_kernel<<<dim3((unsigned)cdiv(n_fb, 256)), dim3(256), 0, h->stream>>>(ex.fbX, n_fb, h->D, fsq);
+                if (int rc = launch_bmu_f32_any<SCORE_COSINE>(h, ex.fbX, n_fb, fsq, ex.fb_ids)) return rc;
+            } else if (int rc = launch_bmu_f32_any<SCORE_EUCLID_PART>(h, ex.fbX, n_fb, nullptr, ex.fb_ids)) return rc;
             exact_scatter_ids_kernel<<<dim3((unsigned)cdiv(n_fb, 256)), dim3(256), 0, h->stream>>>(ex.fb_ids, ex.fb_list, n_fb,
                                                                                                 out + r0);
             HIPCHK(h, hipGetLastError());
@@ -1398,7 +1513,10 @@ int som_create(const som_config* cfg, som_handle** out) {
     if (cfg->precision == SOM_PREC_EXACT) {
         // the screen + re-score scheme covers the euclidean distance up to 128 features; everywhere else the
         // float32 kernels ARE the exact mode
-        if (cfg->distance == SOM_DIST_EUCLIDEAN && cfg->input_len <= 128) h->exact = true;
+        // (<= 128 features: the resident screen, euclidean; 129 .. 800 features on maps of >= 4096 units: the wide
+        //  screen, euclidean and cosine -- decided below, once the tiling is known)
+        if ((cfg->distance == SOM_DIST_EUCLIDEAN && cfg->input_len <= 128) ||
+            ((cfg->distance == SOM_DIST_EUCLIDEAN || cfg->distance == SOM_DIST_COSINE) && cfg->input_len > 128)) h->exact = true;
         else h->cfg.precision = SOM_PREC_F32;
     }
     cfg = &h->cfg;
@@ -1410,7 +1528,7 @@ int som_create(const som_config* cfg, som_handle** out) {
     h->f16 = cfg->precision == SOM_PREC_F16 || cfg->precision == SOM_PREC_F16X3 || h->exact;   // (the exact mode's screen: IEEE half)
     h->x3res = h->x3 && h->D <= 128;
     if (const char* e = std::getenv("SOM_X3_TILED")) if (std::atoi(e) != 0) h->x3res = false;   // A/B: the tiled split kernel
-    h->tiled = ((cfg->precision == SOM_PREC_BF16 || cfg->precision == SOM_PREC_F16) && h->D > 128) || (h->x3 && !h->x3res);
+    h->tiled = ((cfg->precision == SOM_PREC_BF16 || cfg->precision == SOM_PREC_F16 || h->exact) && h->D > 128) || (h->x3 && !h->x3res);
     if (h->tiled) {
         // 256 x 256 tiles need enough units to amortise them; SOM_BF16_TILE=128|256 overrides
         h->tl_big = h->K >= 4096;
@@ -1427,6 +1545,10 @@ int som_create(const som_config* cfg, som_handle** out) {
     }
     h->wide = h->tiled && h->tl_big && h->n_kchunks <= 25;     // (bf16x3: the tripled feature axis, input_len <= 266)
     if (const char* e = std::getenv("SOM_BF16_WIDE")) if (std::atoi(e) == 0) h->wide = false;   // A/B: the two-sided tiling
+    if (h->exact && h->tiled && !h->wide) {              // no exact screen on the two-sided tiling: the float32 kernels serve
+        h->exact = false; h->f16 = false; h->tiled = false;
+        h->cfg.precision = SOM_PREC_F32;
+    }
     h->dp = h->tiled ? TL_BK * h->n_kchunks : h->x3res ? 2 * 32 * h->ks32 : 32 * h->ks32;
     h->stage_bytes = h->wide ? wd_stage_bytes(h->n_kchunks) : h->x3res ? k3_stage_bytes(h->ks32) : k16_stage_bytes(h->ks32);
     h->stage_units = h->wide ? WD_STAGE_UNITS : h->x3res ? K3_STAGE_UNITS : K16_STAGE_UNITS;
@@ -1499,7 +1621,7 @@ int som_create(const som_config* cfg, som_handle** out) {
         h->fr_stages = (int)cdiv(h->K, FR_STAGE_UNITS);
         if ((rc = dev_alloc(h, &h->Wfst, (size_t)h->fr_stages * fr_stage_bytes(kg)))) return bail(rc);
     }
-    if (cfg->precision != SOM_PREC_F32) {
+    if (h->cfg.precision != SOM_PREC_F32) {
         h->n_stages = (int)cdiv(h->K, h->stage_units);
         size_t bytes = (size_t)h->n_stages * h->stage_bytes;
         if (h->tiled && !h->wide) bytes = (size_t)h->n_ublocks * h->n_kchunks * h->tl_wtile;
@@ -1865,7 +1987,7 @@ int som_epoch_merge(som_handle* h) {
     // the half-precision paths whose operand image is a stage image (resident kernel, euclidean; wide kernel,
     // euclidean and cosine): the merge also writes the next epoch's 16-bit operands
     if (h->fuse_merge_prep && ((is_half1(h) && !h->tiled && h->cfg.distance == SOM_DIST_EUCLIDEAN) ||
-                               (h->wide && !h->x3 && h->n_kchunks <= 4 * WD_MP_ITERS))) {
+                               (h->wide && !h->x3 && !h->exact && h->n_kchunks <= 4 * WD_MP_ITERS))) {
         if (int rc = SOM_HALF(h, merge_prep_half, h)) return rc;
         HIPCHK(h, hipGetLastError());
         mark_codebook_changed(h);
