@@ -12,17 +12,19 @@ N = int(os.environ.get("EX_ROWS", "65536"))
 T = 10
 mode = os.environ.get("EX_MODE", "exact")
 state = int(os.environ.get("EX_STATE", "0"))
+DIST = os.environ.get("EX_DIST", "euclidean")
+NEIGH = os.environ.get("EX_NEIGH", "gaussian")
 rs = np.random.RandomState(1234)
 w = rs.rand(X, Y, D) * 2 - 1
 w /= np.linalg.norm(w, axis=-1, keepdims=True)
 data = gaussian_blobs(N, D)
 if state > 0:
-    tr = HipEngine(X, Y, D, precision="bf16x3")
+    tr = HipEngine(X, Y, D, precision="bf16x3" if D <= 128 else "exact", distance=DIST, neighborhood=NEIGH)
     tr.set_data(data); tr.set_weights(w.astype(np.float32))
     for t in range(state):
         tr.epoch(exponential_decay(min(X, Y) / 2, 1, t, T), exponential_decay(0.5, 0.01, t, T), True)
     w = tr.get_weights(); tr.close()
-e = HipEngine(X, Y, D, precision=mode)
+e = HipEngine(X, Y, D, precision=mode, distance=DIST, neighborhood=NEIGH)
 e.set_data(data); e.set_weights(w.astype(np.float32))
 sig, eta = exponential_decay(min(X, Y) / 2, 1, min(state, T - 1), T), exponential_decay(0.5, 0.01, min(state, T - 1), T)
 for _ in range(int(os.environ.get("EX_REPS", "8"))):

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64 * KS32) void merge_prep_k16_kernel(float* __rest
 // v_min steps transpose and reduce so that quad q ends with the full minimum of sample block q -- lane l then owns row
 // wave_s0 + l.  A group minimum can only matter to the scan if it is within the row's bound E of the FINAL row minimum,
 // hence of the minimum so far: only those are stored (gmin[stage * gm_stride + row], exec-masked), and every wave and
-// stage leaves the 64-bit mask of the lanes it stored in gflags[stage * (gm_stride / 64) + row / 64] -- on a random
+// stage leaves the 64-bit mask of the lanes it stored in gflags[(row / 64) * n_stages + stage] -- on a random
 // codebook ~2 % of the matrix is written and read, on the smoothest maps 10-25 %.
 template <int KS32, class EL = Bf16, bool GM = false>
 __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
             run_min = __builtin_fminf(run_min, f);
             if (keep) gmin[(long)stage * gm_stride + wave_s0 + lane] = full;
             const unsigned long long mask = __ballot(keep);
-            if (lane == 0) gflags[(long)stage * (gm_stride >> 6) + (wave_s0 >> 6)] = mask;
+            if (lane == 0) gflags[(long)(wave_s0 >> 6) * n_stages + stage] = mask;
         }
 #pragma unroll
         for (int sb = 0; sb < K16_SB; ++sb) {

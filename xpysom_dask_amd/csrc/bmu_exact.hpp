@@ -11,20 +11,20 @@
 //                only: the row minimum m(n) and, per GROUP of 64 units (one stage) and row, the group's minimum --
 //                stored (gmin[group][row]) only where it is within the row's bound E(n) of the minimum so far, with the
 //                64-bit mask of the rows stored per stage and wave (gflags).  No unit indices exist in that instance.
-//   2. candidates  exact_scan_kernel: every group with gmin <= m(n) + E(n) is a candidate of row n.  E(n) bounds
+//   2. candidates  exact_select_kernel: every group with gmin <= m(n) + E(n) is a candidate of row n.  E(n) bounds
 //                (float32 kernel's own rounding) + (screen's error), both relative to tau = |w|^2 - 2 x.w in real
 //                arithmetic -- derivation below.  The float32 winner k* has s(k*) <= s(k) for every k, so its screen
 //                value cannot exceed the screen's minimum by more than E: its group is a candidate (and was stored:
 //                the minimum so far is never below the final one).
-//   3. re-score  the (row, group) pairs are bucketed by group (exact_offsets_kernel, exact_fill_kernel) and
-//                exact_rescore_mfma_kernel forms, tile by tile (up to 128 rows of a group's list x its 64 units), the
+//   3. re-score  the (row, group) pairs are bucketed by group as they are found (every group owns a list with room for a
+//                whole pass; exact_tiles_kernel cuts the lists into tiles) and exact_rescore_mfma_kernel forms, tile by tile (up to 128 rows of a group's list x its 64 units), the
 //                float32 scores by the SAME instruction stream as the parity kernel (v_mfma_f32_32x32x2_f32 on the
 //                parity kernel's own stage image, same k order, same epilogue) and keeps the first minimum in unit
 //                order per row.  Because k* is among the re-scored units and is the global first minimum, it is the
 //                re-scored first minimum.
 //   4. fallback  rows the scheme cannot vouch for -- no candidate at all (NaN / infinite rows or norms), a minimum that
-//                is not finite, a pass with more pairs than its lists hold (64 per row on average: a degenerate
-//                codebook) -- go to the float32 kernel itself (exact_finalize_kernel lists them).
+//                is not finite, a pass with more pairs than re-scoring is worth (a quarter of the groups per row on average: a
+//                degenerate codebook) -- go to the float32 kernel itself (exact_finalize_kernel lists them).
 //
 // Error bound (euclidean, input_len <= 128).  u = 2^-24, A(n,k) = sum_d |x_d w_kd| <= |x_n| max_k|w_k|.
 //   float32 kernel:  |c - x.w| <= gamma_D A (fma chain of D terms), s = fl(wsq - 2c):
@@ -57,41 +57,36 @@ constexpr int EX_SCAN_SPLIT = 4;      // waves that share a row's groups in the 
 constexpr int EX_TR = 128;            // rows per re-score tile (4 waves x 32 rows against one 64-unit group)
 
 // Small per-pass counters, one allocation, zeroed by one memset before the scan:
-//   [0, n_groups)             gcount: (row, group) pairs per group
-//   [n_groups, 2 n_groups)    gfill:  fill cursor of the group's row list
+//   [0, n_groups)             gcount: (row, group) pairs per group = fill cursor of the group's row list
+//   [n_groups, 2 n_groups)    (unused)
 //   [2 n_groups]              fb_count: rows for the float32 fallback kernel
 //   [2 n_groups + 1]          n_tiles:  re-score tiles
 //   [2 n_groups + 2]          overflow: the pass has more pairs than the lists hold (a degenerate codebook: identical
 //                             units everywhere) -- every row goes to the float32 kernel
-// goff (exclusive prefix of gcount) lives behind them and is written, not accumulated.
 
-// per-bit population of a word of hit bits over the wave: lane b < 32 returns the number of lanes whose bit b is set
-__device__ __forceinline__ int ex_bit_counts(uint32_t bits, int lane) {
-    int c = 0;
-    for (int b = 0; b < 32; ++b) {
-        const unsigned long long m = __ballot((bits >> b) & 1u);
-        if (lane == b) c = (int)__builtin_popcountll(m);
-    }
-    return c;
-}
-
-// (gmin [n_groups][gm_stride], gflags [n_groups][gm_stride / 64]) -> hit bits bm [n_words][gm_stride] (bit b of word w of a
-// row: group 32 w + b is a candidate) and gcount [n_groups].  Block = 64 consecutive rows x EX_SCAN_SPLIT word ranges.
-// The screen stored only the group minima within E of the row minimum SO FAR and left, per stage and 64 rows, the mask
-// of the rows it stored (one 8-byte word a wave reads with a scalar load): the scan looks at a group only where some
-// row of its 64 has the bit, loads only those rows' values, and keeps the ones within E of the FINAL row minimum.  The
-// 64 lanes of a wave test the SAME group at the same time, so a group's hits are counted with one atomic per wave, word
-// and group (smooth maps send most rows to the same few groups: one address would otherwise take an add per row).
-__global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_scan_kernel(const uint32_t* __restrict__ gmin,
-                                                                       const unsigned long long* __restrict__ gflags,
-                                                                       long gm_stride, int n_groups, long N,
-                                                                       const unsigned long long* __restrict__ best64,
-                                                                       const float* __restrict__ xsq,
-                                                                       const float* __restrict__ wmax2,
-                                                                       const float* __restrict__ xmax2, ExactBound eb,
-                                                                       const float* __restrict__ xerr,
-                                                                       const float* __restrict__ werr2,
-                                                                       uint32_t* __restrict__ bm, int* __restrict__ gcount) {
+// (gmin [n_groups][gm_stride], gflags [gm_stride / 64][n_groups]) -> the groups' row lists plist [n_groups][gm_stride] (every
+// group owns room for a whole pass: nothing to size, nothing to prefix-sum), gcount [n_groups] and the rows' candidate
+// counts.  Block = 64 consecutive rows x EX_SCAN_SPLIT ranges of groups; lane = row.
+// The screen stored only the group minima within E of the row minimum SO FAR and left, per group and 64 rows, the mask
+// of the rows it stored.  A wave reads the masks of 64 groups with one coalesced load (lane = group), walks the groups
+// whose mask is not empty -- eight at a time, so that their value loads are in flight together --, loads only the stored
+// rows' values and keeps the ones within E of the FINAL row minimum.  The 64 lanes test the SAME group at the same time:
+// a group's hits take consecutive list positions from ONE returning atomic per wave and 64 groups (lane j adds group
+// j's population and hands out the base).  The order of a list depends on the order of the atomics; the re-score's
+// result does not (every (row, group) pair is scored on its own and merged by atomicMin).
+// The per-row merge keys of the re-score start from all ones: reset here, once every wave has read the screen's minimum.
+__global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_select_kernel(const uint32_t* __restrict__ gmin,
+                                                                         const unsigned long long* __restrict__ gflags,
+                                                                         long gm_stride, int n_groups, long N,
+                                                                         unsigned long long* __restrict__ best64,
+                                                                         const float* __restrict__ xsq,
+                                                                         const float* __restrict__ wmax2,
+                                                                         const float* __restrict__ xmax2, ExactBound eb,
+                                                                         const float* __restrict__ xerr,
+                                                                         const float* __restrict__ werr2,
+                                                                         int* __restrict__ plist, int* __restrict__ gcount,
+                                                                         int* __restrict__ rowcnt) {
+    __shared__ int cnt_s[EX_SCAN_SPLIT][64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const long row0 = (long)blockIdx.x * 64;
     const long row = row0 + lane;
@@ -104,44 +99,76 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_scan_kernel(const ui
     const bool ok = live && thr_f > 0.0f && thr_f < 3.0e38f;
     // unsigned compare on the bit patterns: every d' is a positive float, a NaN pattern is above every threshold
     const uint32_t thr = ok ? __float_as_uint(thr_f) : 0u;
-    const int n_words = (n_groups + 31) / 32;
-    const int w0 = (int)((long)n_words * part / EX_SCAN_SPLIT), w1 = (int)((long)n_words * (part + 1) / EX_SCAN_SPLIT);
-    const unsigned long long* fl = gflags + (row0 >> 6);
-    const long fstride = gm_stride >> 6;
+    __syncthreads();
+    if (part == 0 && live) best64[row] = ~0ull;
+    const int g_begin = (int)((long)n_groups * part / EX_SCAN_SPLIT), g_end = (int)((long)n_groups * (part + 1) / EX_SCAN_SPLIT);
+    const unsigned long long* fl = gflags + (long)blockIdx.x * n_groups;
     const uint32_t* src = gmin + r;
-    for (int w = w0; w < w1; ++w) {
-        uint32_t bits = 0;
-#pragma unroll
-        for (int b8 = 0; b8 < 32; b8 += 8) {               // eight groups at a time: their loads are in flight together
-            unsigned long long stored[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int g = 32 * w + b8 + q;
-                stored[q] = g < n_groups ? fl[(long)g * fstride] : 0ull;   // (wave-uniform: scalar loads)
-            }
+    const unsigned long long below = (1ull << lane) - 1;
+    int mine = 0;
+    for (int gb = g_begin; gb < g_end; gb += 64) {
+        const unsigned long long fw = gb + lane < g_end ? fl[gb + lane] : 0ull;
+        const unsigned long long any = __ballot(fw != 0ull);
+        if (any == 0) continue;
+        const uint32_t fw_lo = (uint32_t)fw, fw_hi = (uint32_t)(fw >> 32);
+        unsigned long long hits = 0;                       // bit j: group gb + j is a candidate of this lane's row
+        unsigned long long todo = any;
+        while (todo != 0) {
+            int j[8];
             uint32_t v[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int g = 32 * w + b8 + q;
-                v[q] = 0xFFFFFFFFu;
-                if ((stored[q] >> lane) & 1ull) v[q] = src[(long)g * gm_stride];   // (only the rows the screen stored)
+                j[q] = todo != 0 ? (int)__builtin_ctzll(todo) : -1;
+                if (todo != 0) todo &= todo - 1;
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) bits |= (uint32_t)(v[q] <= thr) << (b8 + q);
+            for (int q = 0; q < 8; ++q) {
+                v[q] = 0xFFFFFFFFu;
+                if (j[q] >= 0) {                           // (wave-uniform)
+                    const unsigned long long stored = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)fw_hi, j[q]) << 32) |
+                                                      (uint32_t)__builtin_amdgcn_readlane((int)fw_lo, j[q]);
+                    if ((stored >> lane) & 1ull) v[q] = src[(long)(gb + j[q]) * gm_stride];   // (only the rows the screen stored)
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (j[q] >= 0) hits |= (unsigned long long)(v[q] <= thr) << j[q];
         }
-        if (!ok) bits = 0;
-        if (live) bm[(long)w * gm_stride + row] = bits;
-        if (__ballot(bits != 0) == 0) continue;
-        const int c = ex_bit_counts(bits, lane);       // the groups' populations: one add per wave, word and group
-        if (lane < 32 && c > 0) atomicAdd(gcount + 32 * w + lane, c);
+        if (!ok) hits = 0;
+        if (__ballot(hits != 0ull) == 0) continue;
+        int c = 0;                                         // lane j: the wave's hits in group gb + j
+        for (todo = any; todo != 0; todo &= todo - 1) {
+            const int jj = (int)__builtin_ctzll(todo);
+            const unsigned long long mk = __ballot((hits >> jj) & 1ull);
+            if (lane == jj) c = (int)__builtin_popcountll(mk);
+        }
+        int base = 0;
+        if (c > 0) base = atomicAdd(gcount + gb + lane, c);
+        for (todo = any; todo != 0; todo &= todo - 1) {
+            const int jj = (int)__builtin_ctzll(todo);
+            const unsigned long long mk = __ballot((hits >> jj) & 1ull);
+            if (mk == 0) continue;
+            const int o = __builtin_amdgcn_readlane(base, jj);
+            if ((hits >> jj) & 1ull) plist[(long)(gb + jj) * gm_stride + o + (int)__builtin_popcountll(mk & below)] = (int)row;
+        }
+        mine += (int)__builtin_popcountll(hits);
+    }
+    cnt_s[part][lane] = mine;
+    __syncthreads();
+    if (part == 0 && live) {
+        int t = 0;
+#pragma unroll
+        for (int p = 0; p < EX_SCAN_SPLIT; ++p) t += cnt_s[p][lane];
+        rowcnt[row] = t;
     }
 }
 
-// gcount -> goff (exclusive prefix), the tile table (group, first list entry of the tile in plist, its rows) and n_tiles;
-// more pairs than `capacity` -> overflow flag, no tiles.  One block.
-__global__ __launch_bounds__(1024) void exact_offsets_kernel(const int* __restrict__ gcount, int n_groups, long capacity,
-                                                             int* __restrict__ goff, int4* __restrict__ tile_tab,
-                                                             int* __restrict__ n_tiles_out, int* __restrict__ overflow) {
+// gcount -> the tile table (group, first list entry of the tile in plist, its rows) and n_tiles; more pairs than
+// `capacity` (a degenerate codebook: the float32 kernel over all units costs less than re-scoring that many pairs) ->
+// overflow flag, no tiles.  One block.
+__global__ __launch_bounds__(1024) void exact_tiles_kernel(const int* __restrict__ gcount, int n_groups, long gm_stride,
+                                                           long capacity, int4* __restrict__ tile_tab,
+                                                           int* __restrict__ n_tiles_out, int* __restrict__ overflow) {
     __shared__ long sums[1024];
     __shared__ int tsums[1024];
     const int tid = threadIdx.x;
@@ -163,45 +190,13 @@ __global__ __launch_bounds__(1024) void exact_offsets_kernel(const int* __restri
         if (tid == 0) { *overflow = 1; *n_tiles_out = 0; }
         return;
     }
-    int off = (int)(sums[tid] - s), toff = tsums[tid] - ts;
+    int toff = tsums[tid] - ts;
     for (int g = b; g < e; ++g) {
         const int c = gcount[g];
-        goff[g] = off;
+        const int off = (int)((long)g * gm_stride);
         for (int i = 0; i * EX_TR < c; ++i) tile_tab[toff++] = make_int4(g, off + i * EX_TR, min(EX_TR, c - i * EX_TR), 0);
-        off += c;
     }
     if (tid == 1023) *n_tiles_out = tsums[1023];
-}
-
-// hit bits -> the groups' row lists; the per-row merge keys of the re-score start from all ones.  Same geometry as the
-// scan: lanes that set the same bit take consecutive list positions from ONE returning atomic per wave, word and group
-// (lane b < 32 adds group b's population and hands out the base).
-__global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_fill_kernel(const uint32_t* __restrict__ bm, long gm_stride,
-                                                                       int n_groups, long N, const int* __restrict__ goff,
-                                                                       int* __restrict__ gfill, const int* __restrict__ overflow,
-                                                                       int* __restrict__ plist,
-                                                                       unsigned long long* __restrict__ best64) {
-    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const long row = (long)blockIdx.x * 64 + lane;
-    const bool live = row < N;
-    if (part == 0 && live) best64[row] = ~0ull;
-    if (*overflow) return;
-    const int n_words = (n_groups + 31) / 32;
-    const int w0 = (int)((long)n_words * part / EX_SCAN_SPLIT), w1 = (int)((long)n_words * (part + 1) / EX_SCAN_SPLIT);
-    const unsigned long long below = (1ull << lane) - 1;
-    for (int w = w0; w < w1; ++w) {
-        const uint32_t bits = live ? bm[(long)w * gm_stride + row] : 0u;
-        if (__ballot(bits != 0) == 0) continue;
-        const int c = ex_bit_counts(bits, lane);
-        int off = 0;
-        if (lane < 32 && c > 0) off = goff[32 * w + lane] + atomicAdd(gfill + 32 * w + lane, c);
-        for (int b = 0; b < 32; ++b) {
-            const unsigned long long mk = __ballot((bits >> b) & 1u);
-            if (mk == 0) continue;
-            const int o = __builtin_amdgcn_readlane(off, b);
-            if ((bits >> b) & 1u) plist[o + (int)__builtin_popcountll(mk & below)] = (int)row;
-        }
-    }
 }
 
 // The float32 scores of one tile -- up to EX_TR rows of a group's list against the group's 64 units -- on
@@ -487,7 +482,8 @@ __global__ __launch_bounds__(256) void exact_werr_kernel(const float* __restrict
                                                          const float* __restrict__ wmax2, float* __restrict__ out,
                                                          const float* __restrict__ unit_wsq = nullptr) {
     using E = typename EL::T;
-    const long u = (long)blockIdx.x * 256 + threadIdx.x;
+    const long u = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // one wave per unit: coalesced reads of its row
+    const int lane = threadIdx.x & 63;
     float er = 0.0f;
     bool poison = false;
     if (u < K) {
@@ -500,17 +496,16 @@ __global__ __launch_bounds__(256) void exact_werr_kernel(const float* __restrict
             if (!(q > 0x1p-60f && q < 0x1p60f)) poison = true;
         }
         scale *= ex_scale(*wmax2);
-        for (int k = 0; k < D; ++k) {
+        for (int k = lane; k < D; k += 64) {
             const float f = W[u * D + k] * scale;
             const float e = half_operand_error(f, (float)cvt<E>(f));
             er = __builtin_fmaf(e, e, er);
         }
     }
+    er = wave_sum(er);
     float m = (er == er) ? er : 0.0f;
     if (poison) m = __builtin_inff();
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomic_max_pos_f32(out, m);
+    if (lane == 0 && u < K) atomic_max_pos_f32(out, m);
 }
 
 // ---- the canary (som_set_verify / SOM_VERIFY=n): n strided rows of every BMU launch are scored again by the float32

@@ -69,12 +69,12 @@ struct som_handle {
     bool exact = false;      // precision 'exact': MFMA screen + float32 re-score of the candidates (bmu_exact.hpp)
     struct ExactScratch {
         uint32_t* gmin = nullptr;            // [n_groups][stride] group minima of the chunk being screened (sparse: see gflags)
-        unsigned long long* gflags = nullptr;   // [n_groups][stride / 64] which rows' minima the screen stored
+        unsigned long long* gflags = nullptr;   // [stride / 64][n_groups] which rows' minima the screen stored
         long stride = 0;                     //   rows per group line (a chunk of the row set, padded)
-        uint32_t* bm = nullptr;              // [n_words][stride] hit bits: group 32 w + b is a candidate of the row
+        int* rowcnt = nullptr;               // [stride] candidate groups of every row of the last pass (som_exact_last_counts)
         int *fb_list = nullptr, *fb_ids = nullptr;
-        int* ctr = nullptr;                  // gcount | gfill | fb_count | n_tiles (zeroed per pass), then goff
-        int* plist = nullptr;                // rows bucketed by candidate group
+        int* ctr = nullptr;                  // gcount | (unused) | fb_count | n_tiles | overflow (zeroed per pass)
+        int* plist = nullptr;                // [n_groups][stride] rows bucketed by candidate group
         int4* tile_tab = nullptr;            // re-score tiles: (group, first list entry, rows)
         long max_tiles = 0;
         float* fbX = nullptr;                // fallback rows, dense, for the float32 kernel
@@ -336,7 +336,7 @@ int prep_codebook_half(som_handle* h) {
             prep_w_bf16_wide_kernel<E><<<dim3((unsigned)cdiv(total, 256)), block, 0, h->stream>>>(
                 h->W, h->K, h->D, h->n_kchunks, h->Wst, h->n_stages, unit, 0, h->wmax2);
             HIPCHK(h, hipMemsetAsync(h->wmax2 + 1, 0, sizeof(float), h->stream));
-            exact_werr_kernel<E><<<dim3((unsigned)cdiv(h->K, 256)), block, 0, h->stream>>>(h->W, h->K, h->D, h->wmax2, h->wmax2 + 1, unit);
+            exact_werr_kernel<E><<<dim3((unsigned)cdiv(h->K, 4)), block, 0, h->stream>>>(h->W, h->K, h->D, h->wmax2, h->wmax2 + 1, unit);
             return 0;
         }
         if (h->wide) {
@@ -378,7 +378,7 @@ int prep_codebook_half(som_handle* h) {
         exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(h->K, 256)), block, 0, h->stream>>>(h->wsq, h->K, h->wn, h->wmax2);
         sc = h->wmax2;
         HIPCHK(h, hipMemsetAsync(h->wmax2 + 1, 0, sizeof(float), h->stream));     // [1]: max_k |w^_k - w~_k|^2
-        exact_werr_kernel<E><<<dim3((unsigned)cdiv(h->K, 256)), block, 0, h->stream>>>(h->W, h->K, h->D, h->wmax2, h->wmax2 + 1);
+        exact_werr_kernel<E><<<dim3((unsigned)cdiv(h->K, 4)), block, 0, h->stream>>>(h->W, h->K, h->D, h->wmax2, h->wmax2 + 1);
     }
     switch (h->ks32) {
     case 1: prep_w_bf16_k16_kernel<1, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit, sc); break;
@@ -871,9 +871,9 @@ int exact_reserve(som_handle* h, long rows) {
     auto& ex = h->ex;
     const long stride = round_up(std::min(rows, exact_chunk_rows(h)), 256);
     if (stride <= ex.stride) return 0;
-    void* old[] = {ex.gmin, ex.gflags, ex.bm, ex.fb_list, ex.plist, ex.tile_tab};
+    void* old[] = {ex.gmin, ex.gflags, ex.rowcnt, ex.fb_list, ex.plist, ex.tile_tab};
     for (void* p : old) if (p) (void)hipFree(p);
-    ex.gmin = nullptr; ex.gflags = nullptr; ex.bm = nullptr; ex.fb_list = nullptr; ex.plist = nullptr; ex.tile_tab = nullptr;
+    ex.gmin = nullptr; ex.gflags = nullptr; ex.rowcnt = nullptr; ex.fb_list = nullptr; ex.plist = nullptr; ex.tile_tab = nullptr;
     ex.stride = 0;
     const long n_groups = cdiv(h->K, EX_GROUP);
     // capacity of a pass in (row, group) pairs per row on average: a quarter of the groups -- past that the float32
@@ -883,8 +883,8 @@ int exact_reserve(som_handle* h, long rows) {
     if (stride * ex.pairs > 0x7fffffffL) return fail(h, "exact: pass too large");
     if (int rc = dev_alloc(h, &ex.gmin, (size_t)n_groups * stride)) return rc;
     if (int rc = dev_alloc(h, &ex.gflags, (size_t)n_groups * (stride / 64))) return rc;
-    if (int rc = dev_alloc(h, &ex.bm, (size_t)cdiv(n_groups, 32) * stride)) return rc;
-    if (int rc = dev_alloc(h, &ex.plist, (size_t)stride * ex.pairs)) return rc;
+    if (int rc = dev_alloc(h, &ex.rowcnt, (size_t)stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.plist, (size_t)n_groups * stride)) return rc;   // every group: room for the whole pass
     if (int rc = dev_alloc(h, &ex.fb_list, (size_t)stride)) return rc;
     ex.max_tiles = cdiv(stride * ex.pairs, EX_TR) + n_groups;
     if (int rc = dev_alloc(h, &ex.tile_tab, (size_t)ex.max_tiles)) return rc;
@@ -991,12 +991,10 @@ int exact_rescore_kg(som_handle* h, const float* X, int n_groups) {
 int exact_rescore(som_handle* h, const float* X, const float* xsq, long n, unsigned long long* best64, int* out) {
     auto& ex = h->ex;
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
-    int* gcount = ex.ctr; int* gfill = ex.ctr + n_groups; int* fb_count = ex.ctr + 2 * n_groups;
-    int* n_tiles = fb_count + 1; int* overflow = fb_count + 2; int* goff = fb_count + 3;
-    exact_offsets_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(gcount, n_groups, ex.stride * ex.pairs, goff, ex.tile_tab, n_tiles,
-                                                               overflow);
-    exact_fill_kernel<<<dim3((unsigned)cdiv(n, 64)), dim3(64 * EX_SCAN_SPLIT), 0, h->stream>>>(ex.bm, ex.stride, n_groups, n, goff,
-                                                                                          gfill, overflow, ex.plist, best64);
+    int* gcount = ex.ctr; int* fb_count = ex.ctr + 2 * n_groups;
+    int* n_tiles = fb_count + 1; int* overflow = fb_count + 2;
+    exact_tiles_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(gcount, n_groups, ex.stride, ex.stride * ex.pairs, ex.tile_tab, n_tiles,
+                                                             overflow);
     unsigned long long* saved = h->best64;
     h->best64 = best64;                                   // (exact_rescore_kg reads it from the handle)
     int rc = 0;
@@ -1063,9 +1061,9 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
             Timed ts(h, SOM_K_SCREEN);
             if (int rc = SOM_HALF(h, exact_screen_ks, h, Xb + r0 * h->dp, n, h->best64 + r0, xsq + r0, xerr + r0, xmax2, eb)) return rc;
         }
-        exact_scan_kernel<<<dim3((unsigned)cdiv(n, 64)), dim3(64 * EX_SCAN_SPLIT), 0, h->stream>>>(
-            ex.gmin, ex.gflags, ex.stride, n_groups, n, h->best64 + r0, xsq + r0, h->wmax2, xmax2, eb, xerr + r0, h->wmax2 + 1, ex.bm,
-            ex.ctr);
+        exact_select_kernel<<<dim3((unsigned)cdiv(n, 64)), dim3(64 * EX_SCAN_SPLIT), 0, h->stream>>>(
+            ex.gmin, ex.gflags, ex.stride, n_groups, n, h->best64 + r0, xsq + r0, h->wmax2, xmax2, eb, xerr + r0, h->wmax2 + 1,
+            ex.plist, ex.ctr, ex.rowcnt);
         if (int rc = exact_rescore(h, X + r0 * h->D, xsq + r0, n, h->best64 + r0, out + r0)) return rc;
         HIPCHK(h, hipGetLastError());
         // rows the scheme could not settle (normally none): the float32 kernel itself
@@ -1660,7 +1658,7 @@ void som_destroy(som_handle* h) {
         for (void* b : vb) if (b) (void)hipFree(b);
     }
     {
-        void* eb[] = {h->ex.gmin, h->ex.gflags, h->ex.bm, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab};
+        void* eb[] = {h->ex.gmin, h->ex.gflags, h->ex.rowcnt, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab};
         for (void* b : eb) if (b) (void)hipFree(b);
         if (h->ex.fb_count_host) (void)hipHostFree(h->ex.fb_count_host);
     }
@@ -2374,14 +2372,7 @@ int som_exact_last_counts(som_handle* h, int32_t* counts_out, int64_t n) {
     DeviceGuard dev_guard(h);
     if (!h || !counts_out || n < 0) return fail(h, "som_exact_last_counts: bad argument");
     if (!h->exact || n > h->ex.stride) return fail(h, "som_exact_last_counts: no screen pass of that many rows");
-    const long n_words = cdiv(cdiv(h->K, EX_GROUP), 32);
-    std::vector<uint32_t> bm((size_t)n_words * h->ex.stride);
-    if (int rc = d2h_blocking(h, bm.data(), h->ex.bm, bm.size() * sizeof(uint32_t))) return rc;
-    for (int64_t r = 0; r < n; ++r) {
-        int c = 0;
-        for (long w = 0; w < n_words; ++w) c += __builtin_popcount(bm[(size_t)w * h->ex.stride + r]);
-        counts_out[r] = c;
-    }
+    if (int rc = d2h_blocking(h, counts_out, h->ex.rowcnt, (size_t)n * sizeof(int32_t))) return rc;
     return 0;
 }
 
