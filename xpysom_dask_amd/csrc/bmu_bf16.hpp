@@ -43,6 +43,13 @@ __device__ __forceinline__ float ex_scale(float max2) {
     return ldexpf(1.0f, e);
 }
 
+// where the exact mode's screens leave the mask of the rows whose minimum of group g they stored, for row block rb (64
+// rows): [row block][group] -- the select kernel reads 64 groups' masks in one load ([group][row block] measured the same
+// in the screen and no better in the select)
+__device__ __forceinline__ long ex_flag_index(long rb, int g, int n_groups, long /*gm_stride*/) {
+    return rb * n_groups + g;
+}
+
 // what the MFMA may see instead of the (scaled) float32 value f once it went through the 16-bit type as fb: the rounding
 // error |f - fb|, or all of |f| when fb is a subnormal IEEE half (an MFMA that flushes subnormal inputs reads 0 there;
 // one that does not errs by less: the larger of the two covers both)

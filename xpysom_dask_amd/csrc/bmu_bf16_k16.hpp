@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
             run_min = __builtin_fminf(run_min, f);
             if (keep) gmin[(long)stage * gm_stride + wave_s0 + lane] = full;
             const unsigned long long mask = __ballot(keep);
-            if (lane == 0) gflags[(long)(wave_s0 >> 6) * n_stages + stage] = mask;
+            if (lane == 0) gflags[ex_flag_index(wave_s0 >> 6, stage, n_stages, gm_stride)] = mask;
         }
 #pragma unroll
         for (int sb = 0; sb < K16_SB; ++sb) {

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
                 run_min = __builtin_fminf(run_min, f);
                 if (keep) gmin[(long)(s >> 1) * gm_stride + wave_row0 + lane] = full;
                 const unsigned long long mask = __ballot(keep);
-                if (lane == 0) gflags32[((long)(wave_row0 >> 6) * ((n_stages + 1) >> 1) + (s >> 1)) * 2 + ((wave_row0 >> 5) & 1)] = (uint32_t)mask;
+                if (lane == 0) gflags32[ex_flag_index(wave_row0 >> 6, s >> 1, (n_stages + 1) >> 1, gm_stride) * 2 + ((wave_row0 >> 5) & 1)] = (uint32_t)mask;
             }
         } else {
 #pragma unroll

@@ -54,6 +54,7 @@ namespace somhip {
 constexpr int EX_GROUP = 64;          // units per group = one stage of the float32 stage image = one stage of the screen
 constexpr int EX_PAIRS = 64;          // least capacity of a pass in (row, group) pairs per row ON AVERAGE (exact_reserve sizes it)
 constexpr int EX_SCAN_SPLIT = 4;      // waves that share a row's groups in the scan
+constexpr int EX_WERR_UNITS = 16;     // units per wave in exact_werr_kernel
 constexpr int EX_TR = 128;            // rows per re-score tile (4 waves x 32 rows against one 64-unit group)
 
 // Small per-pass counters, one allocation, zeroed by one memset before the scan:
@@ -102,12 +103,11 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_select_kernel(const 
     __syncthreads();
     if (part == 0 && live) best64[row] = ~0ull;
     const int g_begin = (int)((long)n_groups * part / EX_SCAN_SPLIT), g_end = (int)((long)n_groups * (part + 1) / EX_SCAN_SPLIT);
-    const unsigned long long* fl = gflags + (long)blockIdx.x * n_groups;
     const uint32_t* src = gmin + r;
     const unsigned long long below = (1ull << lane) - 1;
     int mine = 0;
     for (int gb = g_begin; gb < g_end; gb += 64) {
-        const unsigned long long fw = gb + lane < g_end ? fl[gb + lane] : 0ull;
+        const unsigned long long fw = gb + lane < g_end ? gflags[ex_flag_index(blockIdx.x, gb + lane, n_groups, gm_stride)] : 0ull;
         const unsigned long long any = __ballot(fw != 0ull);
         if (any == 0) continue;
         const uint32_t fw_lo = (uint32_t)fw, fw_hi = (uint32_t)(fw >> 32);
@@ -482,12 +482,14 @@ __global__ __launch_bounds__(256) void exact_werr_kernel(const float* __restrict
                                                          const float* __restrict__ wmax2, float* __restrict__ out,
                                                          const float* __restrict__ unit_wsq = nullptr) {
     using E = typename EL::T;
-    const long u = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // one wave per unit: coalesced reads of its row
+    // a wave takes EX_WERR_UNITS consecutive units, one at a time (coalesced reads of the unit's row), and hands in ONE maximum
     const int lane = threadIdx.x & 63;
-    float er = 0.0f;
-    bool poison = false;
-    if (u < K) {
+    const long u_begin = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * EX_WERR_UNITS;
+    const float pow2 = ex_scale(*wmax2);
+    float m = 0.0f;
+    for (long u = u_begin; u < u_begin + EX_WERR_UNITS && u < K; ++u) {
         float scale = 1.0f;
+        bool poison = false;
         if (unit_wsq != nullptr) {
             const float q = unit_wsq[u];
             scale = q > 0.0f ? 1.0f / __builtin_sqrtf(q) : 0.0f;
@@ -495,17 +497,18 @@ __global__ __launch_bounds__(256) void exact_werr_kernel(const float* __restrict
             // (ex_row_bound keeps |x|^2 in the same window); a zero, tiny, huge or NaN unit: no bound -> every row falls back
             if (!(q > 0x1p-60f && q < 0x1p60f)) poison = true;
         }
-        scale *= ex_scale(*wmax2);
+        scale *= pow2;
+        float er = 0.0f;
         for (int k = lane; k < D; k += 64) {
             const float f = W[u * D + k] * scale;
             const float e = half_operand_error(f, (float)cvt<E>(f));
             er = __builtin_fmaf(e, e, er);
         }
+        er = wave_sum(er);
+        if (poison) er = __builtin_inff();
+        if (er == er) m = fmaxf(m, er);
     }
-    er = wave_sum(er);
-    float m = (er == er) ? er : 0.0f;
-    if (poison) m = __builtin_inff();
-    if (lane == 0 && u < K) atomic_max_pos_f32(out, m);
+    if (lane == 0 && u_begin < K) atomic_max_pos_f32(out, m);
 }
 
 // ---- the canary (som_set_verify / SOM_VERIFY=n): n strided rows of every BMU launch are scored again by the float32

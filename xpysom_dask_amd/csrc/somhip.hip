@@ -336,7 +336,7 @@ int prep_codebook_half(som_handle* h) {
             prep_w_bf16_wide_kernel<E><<<dim3((unsigned)cdiv(total, 256)), block, 0, h->stream>>>(
                 h->W, h->K, h->D, h->n_kchunks, h->Wst, h->n_stages, unit, 0, h->wmax2);
             HIPCHK(h, hipMemsetAsync(h->wmax2 + 1, 0, sizeof(float), h->stream));
-            exact_werr_kernel<E><<<dim3((unsigned)cdiv(h->K, 4)), block, 0, h->stream>>>(h->W, h->K, h->D, h->wmax2, h->wmax2 + 1, unit);
+            exact_werr_kernel<E><<<dim3((unsigned)cdiv(h->K, 4 * EX_WERR_UNITS)), block, 0, h->stream>>>(h->W, h->K, h->D, h->wmax2, h->wmax2 + 1, unit);
             return 0;
         }
         if (h->wide) {
@@ -378,7 +378,7 @@ int prep_codebook_half(som_handle* h) {
         exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(h->K, 256)), block, 0, h->stream>>>(h->wsq, h->K, h->wn, h->wmax2);
         sc = h->wmax2;
         HIPCHK(h, hipMemsetAsync(h->wmax2 + 1, 0, sizeof(float), h->stream));     // [1]: max_k |w^_k - w~_k|^2
-        exact_werr_kernel<E><<<dim3((unsigned)cdiv(h->K, 4)), block, 0, h->stream>>>(h->W, h->K, h->D, h->wmax2, h->wmax2 + 1);
+        exact_werr_kernel<E><<<dim3((unsigned)cdiv(h->K, 4 * EX_WERR_UNITS)), block, 0, h->stream>>>(h->W, h->K, h->D, h->wmax2, h->wmax2 + 1);
     }
     switch (h->ks32) {
     case 1: prep_w_bf16_k16_kernel<1, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit, sc); break;
