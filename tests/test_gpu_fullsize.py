@@ -197,3 +197,34 @@ def test_full_size_c5_shard_properties():
     # the positivity offset B = max|x~| max|w~| belongs to the shard, so a near-tie may round the other way
     assert moved < 1e-3 * N
     assert rel_err(tot_den, den) < 2e-3 and rel_err(tot_num, num[:, cols]) < 2e-3
+
+
+def test_full_size_c5_shard_exact_mode_equals_float32():
+    """configs[4]'s whole one-GPU shard (250 000 rows, 512 x 512 x 784, cosine) through precision='exact' -- the wide
+    IEEE-half screen in four passes + the float32 re-score on the tile image -- and through the float32 kernel itself:
+    the same 250 000 BMUs, on the seeded codebook and on a smooth one (the early-schedule state: many candidates)."""
+    X = Y = 512
+    D, N = 784, 250000
+    data = np.abs(O.gaussian_blobs(N, D, seed=4321))
+    data /= np.linalg.norm(data, axis=1, keepdims=True)
+    data = data.astype(F32)
+    rs = np.random.RandomState(5)
+    for state in ("seeded", "smooth"):
+        if state == "seeded":
+            w = np.abs(rs.rand(X, Y, D).astype(F32))
+        else:
+            w = np.abs(O.smooth_sheet_codebook(X, Y, D, seed=3, amplitude=0.3, centre=data[:4096].astype(np.float64).mean(0))).astype(F32)
+        ids = {}
+        for p in ("exact", "f32"):
+            e = engine(X, Y, D, precision=p, distance="cosine", neighborhood="mexican_hat")
+            e.set_weights(w)
+            e.set_data(data)
+            e.epoch_accumulate(40.0, 0.3, True)
+            ids[p] = e.epoch_fetch()[2]
+            if p == "exact":
+                rows, fb, passes = e.exact_stats()
+                assert rows == N and passes >= 4
+                if state == "seeded":
+                    assert fb <= N // 100
+            e.close()
+        assert np.array_equal(ids["exact"], ids["f32"]), (state, int((ids["exact"] != ids["f32"]).sum()))

@@ -1470,7 +1470,7 @@ def test_linear_schedule_ending_at_sigma_zero_with_mexican_hat_raises_like_the_r
 
 # ----------------------------------------------------------------------------- G17 / G18: wide shapes pinned by the reference
 @pytest.mark.parametrize("decay", ["linear", "exponential"])
-@pytest.mark.parametrize("precision", ["f32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "exact", "bf16", "bf16x3"])
 def test_g17_configs4_semantics_at_a_wide_kernel_shape(decay, precision):
     """cosine + mexican_hat, 784 features, non-negative unit rows (BASELINE configs[4]) on a 64 x 64 map: the reference's
     own BMUs, denominator, strided numerator and merged rows (distances.py:45-59, neighborhoods.py:57-74).  With 784
@@ -1494,9 +1494,12 @@ def test_g17_configs4_semantics_at_a_wide_kernel_shape(decay, precision):
     x64, w64 = data.astype(np.float64), w.reshape(-1, D).astype(np.float64)
     cosd = 1.0 - (x64 @ w64.T) / np.sqrt((x64 ** 2).sum(1)[:, None] * (w64 ** 2).sum(1)[None, :])
     gap = cosd[diff, bmu[diff]] - cosd[diff].min(1)         # how much worse than the best unit the engine's pick is
-    tol = {"f32": 2e-6, "bf16x3": 2.0 ** -13, "bf16": 2.0 ** -6}[precision]
+    tol = {"f32": 2e-6, "exact": 2e-6, "bf16x3": 2.0 ** -13, "bf16": 2.0 ** -6}[precision]
     assert (gap <= tol).all(), (precision, gap.max())
-    assert len(diff) <= {"f32": max(2, n // 500), "bf16x3": n // 100, "bf16": n // 4}[precision], len(diff)
+    assert len(diff) <= {"f32": max(2, n // 500), "exact": max(2, n // 500), "bf16x3": n // 100, "bf16": n // 4}[precision], len(diff)
+    if precision == "exact":                                 # (the wide screen served, not the float32 fallback)
+        rows, fb, _ = e.exact_stats()
+        assert rows == n and fb <= n // 50
     # the update from the engine's own BMUs against the oracle, elementwise
     sig = np.float64(g[decay + "_sig"]) if wide else float(g[decay + "_sig"])
     eta = np.float64(g[decay + "_eta"]) if wide else float(g[decay + "_eta"])
