@@ -16,6 +16,7 @@
 // Arithmetic, offset B, key packing ((bits & ~mask) | (tile << 2 | reg)), part split and the 64-bit atomicMin merge
 // are those of bmu_bf16_k16.hpp; the sample operand is the tile image of bmu_bf16_tiled.hpp (256-row blocks).
 #pragma once
+#include <type_traits>
 #include "bmu_bf16.hpp"
 #include "bmu_bf16_tiled.hpp"
 
@@ -226,10 +227,12 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
 #if defined(SOM_WD_EXPERIMENT) && SOM_WD_EXPERIMENT == 1
         s = s_begin + (s & 1);                               // TIMING EXPERIMENT ONLY (wrong results): every fetch an L2 hit
 #endif
-        const char* src = Wst + (long)s * STAGE + lane * 16;
+        // (uniform base + a 32-bit lane offset: the scalar-base form of the load, no 64-bit address kept in registers)
+        const char* src = Wst + (long)s * STAGE;
+        const uint32_t lane16 = (uint32_t)lane * 16u;
         char* dst = smem + slot * STAGE;
-        for (int p = wave; p < PIECES; p += WD_NW) lds_dma_16(src + p * 1024, dst + p * 1024);
-        if (wave == PIECES % WD_NW && lane < CIN_LANES) lds_dma_16(src + PIECES * 1024, dst + PIECES * 1024);
+        for (int p = wave; p < PIECES; p += WD_NW) lds_dma_16(src + p * 1024 + lane16, dst + p * 1024);
+        if (wave == PIECES % WD_NW && lane < CIN_LANES) lds_dma_16(src + PIECES * 1024 + lane16, dst + PIECES * 1024);
     };
     issue(s_begin, 0);
     if (s_begin + 1 < s_end) issue(s_begin + 1, 1);
@@ -249,28 +252,22 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
 #pragma unroll
     for (int sb = 0; sb < WD_SB; ++sb) { gbest[sb] = 0xFFFFFFFFu; gstage[sb] = 0; }
 
-    int cslot = 0, islot = 2;
-    SOM_STAMP_BEGIN();
-    for (int s = s_begin; s < s_end; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of stage s+1 (first: of s, and its samples)
-        __builtin_amdgcn_s_barrier();                         // ... everybody's; and nobody reads stage s-1 any more
-        asm volatile("" ::: "memory");
-        if (s + 2 < s_end) issue(s + 2, islot);               // -> the slot stage s-1 was read from
-        const char* st = smem + cslot * STAGE;
+    f32x4 acc[WD_T][WD_SB];
+    auto slot_of = [&](int s) { return smem + ((s - s_begin) % WD_SLOTS) * STAGE; };
+    auto begin_stage = [&](const char* st) {
         const float* wq = (const float*)(st + PIECES * 1024);
-
-        f32x4 acc[WD_T][WD_SB];
 #pragma unroll
         for (int t = 0; t < WD_T; ++t) {
             const f32x4 c = *(const f32x4*)(wq + t * 16 + 4 * quad);
 #pragma unroll
             for (int sb = 0; sb < WD_SB; ++sb) acc[t][sb] = c;
         }
-        // (measured against this plain form, DESIGN.md 3.1a: fragment reads pinned five k-steps ahead of their MFMAs
-        //  across tile, stage and barrier boundaries with a deferred reduction -- 3 % slower: the kernel sits at the
-        //  chip's power limit, not on LDS latency)
+    };
+    // (measured against this plain form, DESIGN.md 3.1a: fragment reads pinned five k-steps ahead of their MFMAs
+    //  across tile, stage and barrier boundaries with a deferred reduction -- 3 % slower)
+    auto chunks = [&](const char* st, auto k0, auto k1) {
 #pragma unroll
-        for (int ks = 0; ks < KS32; ++ks) {
+        for (int ks = decltype(k0)::value; ks < decltype(k1)::value; ++ks) {
             bf16x8 a[WD_T];
 #pragma unroll
             for (int t = 0; t < WD_T; ++t) a[t] = *(const bf16x8*)(st + ((t * KS32 + ks) * 64 + lane) * 16);
@@ -280,66 +277,98 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
                 for (int sb = 0; sb < WD_SB; ++sb)
                     acc[t][sb] = mfma16(a[t], xf[sb][ks], acc[t][sb]);
         }
+    };
+    auto finish_stage = [&](int s) {
         if (GM) {
-            static_assert(!GM || WD_SB == 2, "the group-minimum store pairs two 16-sample blocks per wave");
-#pragma unroll
-            for (int sb = 0; sb < WD_SB; ++sb) {
-                uint32_t c = 0xFFFFFFFFu;
-#pragma unroll
-                for (int t = 0; t < WD_T; ++t) {
-                    c = min(min(c, __float_as_uint(acc[t][sb][0])), __float_as_uint(acc[t][sb][1]));
-                    c = min(min(c, __float_as_uint(acc[t][sb][2])), __float_as_uint(acc[t][sb][3]));
-                }
-                pmin[sb] = min(pmin[sb], c);
-                gbest[sb] = min(gbest[sb], c);
-            }
-            if ((s & 1) || s == s_end - 1) {                 // the group is complete: join the four lane quads, store
-                uint32_t v[WD_SB];
-#pragma unroll
-                for (int sb = 0; sb < WD_SB; ++sb) {
-                    const auto a = __builtin_amdgcn_permlane32_swap(pmin[sb], pmin[sb], false, false);
-                    const uint32_t m2 = min(a[0], a[1]);
-                    const auto b = __builtin_amdgcn_permlane16_swap(m2, m2, false, false);
-                    v[sb] = min(b[0], b[1]);
-                    pmin[sb] = 0xFFFFFFFFu;
-                }
-                // lanes 0..15: sample block 0, lanes 16..31: sample block 1 = 32 consecutive rows
-                const uint32_t full = (lane & 16) ? v[WD_SB - 1] : v[0];
-                const float f = __uint_as_float(full);
-                const bool keep = lane < 32 && f <= run_min + row_e;
-                run_min = __builtin_fminf(run_min, f);
-                if (keep) gmin[(long)(s >> 1) * gm_stride + wave_row0 + lane] = full;
-                const unsigned long long mask = __ballot(keep);
-                if (lane == 0) gflags32[ex_flag_index(wave_row0 >> 6, s >> 1, (n_stages + 1) >> 1, gm_stride) * 2 + ((wave_row0 >> 5) & 1)] = (uint32_t)mask;
-            }
-        } else {
+        static_assert(!GM || WD_SB == 2, "the group-minimum store pairs two 16-sample blocks per wave");
 #pragma unroll
         for (int sb = 0; sb < WD_SB; ++sb) {
-            uint32_t c0 = 0xFFFFFFFFu, c1 = 0xFFFFFFFFu;
+            uint32_t c = 0xFFFFFFFFu;
 #pragma unroll
             for (int t = 0; t < WD_T; ++t) {
-                const uint32_t k0 = (__float_as_uint(acc[t][sb][0]) & ~IDX_MASK) | (uint32_t)(t * 4 + 0);
-                const uint32_t k1 = (__float_as_uint(acc[t][sb][1]) & ~IDX_MASK) | (uint32_t)(t * 4 + 1);
-                const uint32_t k2 = (__float_as_uint(acc[t][sb][2]) & ~IDX_MASK) | (uint32_t)(t * 4 + 2);
-                const uint32_t k3 = (__float_as_uint(acc[t][sb][3]) & ~IDX_MASK) | (uint32_t)(t * 4 + 3);
-                c0 = min(min(c0, k0), k1);
-                c1 = min(min(c1, k2), k3);
+                c = min(min(c, __float_as_uint(acc[t][sb][0])), __float_as_uint(acc[t][sb][1]));
+                c = min(min(c, __float_as_uint(acc[t][sb][2])), __float_as_uint(acc[t][sb][3]));
             }
-            const uint32_t c = min(c0, c1);
-            if (c < gbest[sb]) { gbest[sb] = c; gstage[sb] = s; }
+            pmin[sb] = min(pmin[sb], c);
         }
+        if ((s & 1) || s == s_end - 1) {                 // the group is complete: join the four lane quads, store
+            uint32_t v[WD_SB];
+#pragma unroll
+            for (int sb = 0; sb < WD_SB; ++sb) {
+                const auto a = __builtin_amdgcn_permlane32_swap(pmin[sb], pmin[sb], false, false);
+                const uint32_t m2 = min(a[0], a[1]);
+                const auto b = __builtin_amdgcn_permlane16_swap(m2, m2, false, false);
+                v[sb] = min(b[0], b[1]);
+                pmin[sb] = 0xFFFFFFFFu;
+            }
+            // lanes 0..15: sample block 0, lanes 16..31: sample block 1 = 32 consecutive rows
+            const uint32_t full = (lane & 16) ? v[WD_SB - 1] : v[0];
+            const float f = __uint_as_float(full);
+            const bool keep = lane < 32 && f <= run_min + row_e;
+            run_min = __builtin_fminf(run_min, f);
+            // (uniform base + 32-bit lane offset: no 64-bit address kept in registers across the stages)
+            uint32_t* grow = gmin + ((long)(s >> 1) * gm_stride + wave_row0);
+            uint32_t off = (uint32_t)lane;
+            asm volatile("" : "+v"(off));                     // (opaque: the compiler would hoist gmin + row as a 64-bit VGPR pair and spill it)
+            if (keep) grow[off] = full;
+            const unsigned long long mask = __ballot(keep);
+            if (lane == 0) gflags32[ex_flag_index(wave_row0 >> 6, s >> 1, (n_stages + 1) >> 1, gm_stride) * 2 + ((wave_row0 >> 5) & 1)] = (uint32_t)mask;
         }
-        cslot = cslot == WD_SLOTS - 1 ? 0 : cslot + 1;
-        islot = islot == WD_SLOTS - 1 ? 0 : islot + 1;
+    } else {
+#pragma unroll
+    for (int sb = 0; sb < WD_SB; ++sb) {
+        uint32_t c0 = 0xFFFFFFFFu, c1 = 0xFFFFFFFFu;
+#pragma unroll
+        for (int t = 0; t < WD_T; ++t) {
+            const uint32_t k0 = (__float_as_uint(acc[t][sb][0]) & ~IDX_MASK) | (uint32_t)(t * 4 + 0);
+            const uint32_t k1 = (__float_as_uint(acc[t][sb][1]) & ~IDX_MASK) | (uint32_t)(t * 4 + 1);
+            const uint32_t k2 = (__float_as_uint(acc[t][sb][2]) & ~IDX_MASK) | (uint32_t)(t * 4 + 2);
+            const uint32_t k3 = (__float_as_uint(acc[t][sb][3]) & ~IDX_MASK) | (uint32_t)(t * 4 + 3);
+            c0 = min(min(c0, k0), k1);
+            c1 = min(min(c1, k2), k3);
+        }
+        const uint32_t c = min(c0, c1);
+        if (c < gbest[sb]) { gbest[sb] = c; gstage[sb] = s; }
+    }
+    }
+    };
+    // the samples are in their registers before the loop: an (empty) use of each here makes the compiler's wait-count pass
+    // place its vmcnt wait HERE -- with their first use inside a branch of the loop it would wait for vmcnt(0) there, behind
+    // the next stage's DMA
+#pragma unroll
+    for (int ks = 0; ks < KS32; ++ks)
+#pragma unroll
+        for (int sb = 0; sb < WD_SB; ++sb) asm volatile("" ::"v"(xf[sb][ks]) : "memory");
+    using KC0 = std::integral_constant<int, 0>;
+    using KCN = std::integral_constant<int, KS32>;
+    // (measured, DESIGN.md 3.4: a counted vmcnt that leaves stage s+2's pieces in flight across the barrier of s+1 -- two
+    //  stage times to land instead of one -- is 6 % SLOWER at 784 features: the workgroups of an XCD drift apart and stop
+    //  sharing their L2 misses; waves 4..7 run half a stage behind their SIMD partners (stagger): +1 % at 784, -5 % at 256)
+    SOM_STAMP_BEGIN();
+    for (int s = s_begin; s < s_end; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of stage s+1 (first: of s, and its samples)
+        __builtin_amdgcn_s_barrier();                         // ... everybody's; and nobody reads stage s-1 any more
+        asm volatile("" ::: "memory");
+        if (s + 2 < s_end) issue(s + 2, (s + 2 - s_begin) % WD_SLOTS);   // -> the slot stage s-1 was read from
+        const char* st = slot_of(s);
+        begin_stage(st);
+        chunks(st, KC0(), KCN());
+        finish_stage(s);
     }
     SOM_STAMP_END();
 
+    if (GM) {
+        // the row minimum IS the minimum so far after the last group (lanes 0..31 <-> rows wave_row0 + lane): the plain
+        // value, every bit of it (no indices kept)
+        const long row = wave_row0 + lane;
+        if (lane < 32 && row < N) atomicMin(out64 + row, (unsigned long long)__float_as_uint(run_min) << 32);
+        return;
+    }
 #pragma unroll
     for (int sb = 0; sb < WD_SB; ++sb) {
         const uint32_t code = gbest[sb] & IDX_MASK;
         const uint32_t unit = (uint32_t)gstage[sb] * WD_STAGE_UNITS + (code >> 2) * 16 + quad * 4 + (code & 3);
         unsigned long long comp = ((unsigned long long)(gbest[sb] & ~IDX_MASK) << 32) | unit;
-        if (GM) comp = (unsigned long long)gbest[sb] << 32;  // the plain minimum, every bit of it (no indices kept)
         unsigned long long o = __shfl_xor(comp, 16, 64);
         if (o < comp) comp = o;
         o = __shfl_xor(comp, 32, 64);
