@@ -78,7 +78,7 @@ res = {"note": "rocprofv3 --pmc passes (one counter group per pass) of `python3 
        "workload": "c3" if "--workload" not in extra else extra[extra.index("--workload") + 1],
        "rows_per_launch": rows,
        "precision": extra[extra.index("--precision") + 1] if "--precision" in extra else
-                    {"c3": "exact", "c2": "f32", "c5": "bf16"}["c3" if "--workload" not in extra else extra[extra.index("--workload") + 1]],
+                    {"c3": "exact", "c2": "f32", "c5": "exact"}["c3" if "--workload" not in extra else extra[extra.index("--workload") + 1]],
        "build": B.built_hash(lib) if lib else B.built_hash(), "library": os.path.basename(lib) if lib else "libsomhip.so"}
 for k, cs in sorted(counters.items()):
     d = {c: sum(v) / len(v) for c, v in cs.items()}

@@ -263,19 +263,43 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
             for (int sb = 0; sb < WD_SB; ++sb) acc[t][sb] = c;
         }
     };
-    // (measured against this plain form, DESIGN.md 3.1a: fragment reads pinned five k-steps ahead of their MFMAs
-    //  across tile, stage and barrier boundaries with a deferred reduction -- 3 % slower)
+    // The fragments of chunk ks + 1 are requested BEFORE the MFMAs of chunk ks, by hand: ds_read_b128 and the counted
+    // lgkmcnt wait are inline assembly.  Left to the compiler every read sinks to just before its use (register pressure:
+    // 200 of the 256 VGPRs hold samples) and, pinned with sched_barrier, its wait-count pass still answers with
+    // lgkmcnt(0) every second chunk; either way a wave waits out the LDS latency with only its partner's four MFMAs to
+    // cover it -- the matrix pipe idled 41 % of the launch (profiles/r03_c5_pmc_traffic: SQ_WAIT_INST_ANY 0.35 of the
+    // wave cycles, LDS array 31 % busy, no bank conflicts).  (Waits the compiler adds for its own LDS reads -- the initial
+    // accumulators -- see fewer reads in flight than there are: stricter than needed, never too weak.)
     auto chunks = [&](const char* st, auto k0, auto k1) {
+        constexpr int K0 = decltype(k0)::value, K1 = decltype(k1)::value;
+        const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)st + (uint32_t)lane * 16u;
+        auto read16 = [&](int piece) {
+            f32x4 v;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(base + (uint32_t)piece * 1024u));
+            return v;
+        };
+        f32x4 a[WD_T], an[WD_T];
 #pragma unroll
-        for (int ks = decltype(k0)::value; ks < decltype(k1)::value; ++ks) {
-            bf16x8 a[WD_T];
+        for (int t = 0; t < WD_T; ++t) a[t] = read16(t * KS32 + K0);
 #pragma unroll
-            for (int t = 0; t < WD_T; ++t) a[t] = *(const bf16x8*)(st + ((t * KS32 + ks) * 64 + lane) * 16);
+        for (int ks = K0; ks < K1; ++ks) {
+            static_assert(WD_T == 2, "the counted wait below leaves exactly the next chunk's two reads in flight");
+            if (ks + 1 < K1) {
+#pragma unroll
+                for (int t = 0; t < WD_T; ++t) an[t] = read16(t * KS32 + ks + 1);
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a[0]), "+v"(a[1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]));
+            }
 #pragma unroll
             for (int t = 0; t < WD_T; ++t)
 #pragma unroll
                 for (int sb = 0; sb < WD_SB; ++sb)
-                    acc[t][sb] = mfma16(a[t], xf[sb][ks], acc[t][sb]);
+                    acc[t][sb] = mfma16(__builtin_bit_cast(bf16x8, a[t]), xf[sb][ks], acc[t][sb]);
+            if (ks + 1 < K1) {
+#pragma unroll
+                for (int t = 0; t < WD_T; ++t) a[t] = an[t];
+            }
         }
     };
     auto finish_stage = [&](int s) {

@@ -867,6 +867,9 @@ long exact_chunk_rows(const som_handle* h) {
     return rows < 1024 ? 1024 : rows;
 }
 
+// (the screens write group minima and row masks for whole workgroup tiles: a pass's row stride must hold them)
+static_assert(256 % K16_WG_SAMPLES == 0 && 256 % WD_WG_SAMPLES == 0 && K16_WG_SAMPLES % 64 == 0 && WD_WG_SAMPLES % 64 == 0,
+              "exact: the pass stride (a multiple of 256 rows) must be a whole number of screen workgroup tiles");
 int exact_reserve(som_handle* h, long rows) {
     auto& ex = h->ex;
     const long stride = round_up(std::min(rows, exact_chunk_rows(h)), 256);
