@@ -55,16 +55,18 @@ enum { SOM_TOPO_RECTANGULAR = 0, SOM_TOPO_HEXAGONAL = 1 };
  *           limit); rows and units must fit float16 -- som_set_data / som_set_weights refuse rows and units whose
  *           norm exceeds 65504; streamed chunks and query rows (som_stream_rows, som_bmu) are not checked: values
  *           beyond the range saturate at +-65504
- *   EXACT: the BMUs of F32, row for row and bit for bit (near-ties and exact ties included), at BF16X3 speed: the
- *           split-bf16 MFMA pass screens every unit, records the minimum of every 64-unit group per row, and the
- *           float32 fma chain itself re-scores the groups the screen's rigorous error bound cannot rule out; rows it
- *           cannot vouch for (NaN / infinite values, more than 32 candidate groups) go to the F32 kernel.  Euclidean
- *           distance, input_len <= 128; other configurations run the F32 kernels under this id (which are the exact
- *           mode by definition).  Everything but the BMU search (update, merge, quantization) is as in F32. */
+ *   EXACT: the BMUs of F32, row for row and bit for bit (near-ties and exact ties included), at half-precision MFMA
+ *           speed: one pass of the MFMA kernel on power-of-two-scaled IEEE-half operands screens every unit and records
+ *           the minimum of every 64-unit group per row, and the float32 fma chain itself re-scores the groups the
+ *           screen's rigorous (partly measured) error bound cannot rule out; rows it cannot vouch for (NaN / infinite
+ *           values, a pass with more candidate pairs than re-scoring is worth) go to the F32 kernel.  Euclidean distance
+ *           with input_len <= 128; euclidean and cosine with 128 < input_len <= 800 on maps of >= 4096 units; other
+ *           configurations run the F32 kernels under this id (which are the exact mode by definition).  Everything but
+ *           the BMU search (update, merge, quantization) is as in F32. */
 enum { SOM_PREC_F32 = 0, SOM_PREC_BF16 = 1, SOM_PREC_BF16X3 = 2,
        SOM_PREC_F16 = 3,      /* the bf16 path on IEEE half operands: 11 significant bits instead of 8, |value| <= 65504 */
        SOM_PREC_F16X3 = 4,    /* the bf16x3 path on IEEE half hi/lo pairs */
-       SOM_PREC_EXACT = 5 };  /* F32's BMUs through the split-bf16 screen + float32 re-score (bmu_exact.hpp) */
+       SOM_PREC_EXACT = 5 };  /* F32's BMUs through an IEEE-half MFMA screen + float32 re-score (bmu_exact.hpp) */
 
 /* which BMU rule som_bmu applies */
 enum { SOM_BMU_ACTIVATION = 0,   /* configured activation distance: XPySom._winner, xpysom.py:410-417 */

@@ -85,9 +85,9 @@ class XPySom:
         ``xp``, ``use_dask`` and ``dask_chunks`` are accepted for source compatibility and
         ignored: there is one backend (HIP) and multi-GPU runs use torch.distributed, not Dask.
         Extra keyword-only arguments:
-          precision      'f32' (exact-float32 MFMA, parity mode), 'exact' (the BMUs of 'f32' bit for bit, found by a
-                         split-bf16 MFMA screen and a float32 re-score of the units its error bound cannot rule out:
-                         the parity contract at about three times the float32 kernel's speed), 'bf16' (bf16 MFMA distance GEMM),
+          precision      'f32' (exact-float32 MFMA, parity mode), 'exact' (the BMUs of 'f32' bit for bit, found by an
+                         IEEE-half MFMA screen and a float32 re-score of the units its error bound cannot rule out:
+                         the parity contract at six to nine times the float32 kernel's speed), 'bf16' (bf16 MFMA distance GEMM),
                          'bf16x3' (hi/lo-split bf16 MFMA: near-float32 BMUs at a third of the bf16 rate), or the
                          same two paths on IEEE half operands, 'f16' / 'f16x3' (three more mantissa bits at the
                          same MFMA rate; rows and units must fit float16: norms <= 65504)
