@@ -229,7 +229,7 @@ def test_the_mfma_rounding_the_bound_charges_for_is_measured():
 
 
 def test_exact_in_several_screen_passes(monkeypatch):
-    """Large row sets are screened in passes (the group-minimum matrix of a pass stays within 1 GiB: 262 144 rows at
+    """Large row sets are screened in passes (the group-minimum matrix of a pass stays within 4 GiB: 1 Mi rows at
     256 x 256); SOM_EXACT_PASS_ROWS forces passes of 1 024 / 2 048 rows so that the pass loop -- slices of the rows, of the
     merge keys, of the norms; a last short pass; fallback rows in a later pass -- runs on test-sized data."""
     X, Y, D, n = 40, 40, 64, 7001

@@ -199,10 +199,11 @@ def test_full_size_c5_shard_properties():
     assert rel_err(tot_den, den) < 2e-3 and rel_err(tot_num, num[:, cols]) < 2e-3
 
 
-def test_full_size_c5_shard_exact_mode_equals_float32():
+def test_full_size_c5_shard_exact_mode_equals_float32(monkeypatch):
     """configs[4]'s whole one-GPU shard (250 000 rows, 512 x 512 x 784, cosine) through precision='exact' -- the wide
-    IEEE-half screen in four passes + the float32 re-score on the tile image -- and through the float32 kernel itself:
-    the same 250 000 BMUs, on the seeded codebook and on a smooth one (the early-schedule state: many candidates)."""
+    IEEE-half screen (one pass on the seeded codebook, four passes of 65 536 rows on the smooth one) + the float32 re-score on
+    the tile image -- and through the float32 kernel itself: the same 250 000 BMUs, on the seeded codebook and on a smooth
+    one (the early-schedule state: many candidates)."""
     X = Y = 512
     D, N = 784, 250000
     data = np.abs(O.gaussian_blobs(N, D, seed=4321))
@@ -215,6 +216,8 @@ def test_full_size_c5_shard_exact_mode_equals_float32():
         else:
             w = np.abs(O.smooth_sheet_codebook(X, Y, D, seed=3, amplitude=0.3, centre=data[:4096].astype(np.float64).mean(0))).astype(F32)
         ids = {}
+        if state == "smooth":
+            monkeypatch.setenv("SOM_EXACT_PASS_ROWS", "65536")
         for p in ("exact", "f32"):
             e = engine(X, Y, D, precision=p, distance="cosine", neighborhood="mexican_hat")
             e.set_weights(w)
@@ -223,7 +226,7 @@ def test_full_size_c5_shard_exact_mode_equals_float32():
             ids[p] = e.epoch_fetch()[2]
             if p == "exact":
                 rows, fb, passes = e.exact_stats()
-                assert rows == N and passes >= 4
+                assert rows == N and passes == (1 if state == "seeded" else 4)
                 if state == "seeded":
                     assert fb <= N // 100
             e.close()

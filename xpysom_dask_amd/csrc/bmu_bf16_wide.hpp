@@ -302,6 +302,20 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
             }
         }
     };
+    uint32_t pend_full = 0;                                  // GM: the group minimum waiting to be stored, whether to, its group
+    bool pend_keep = false;
+    int pend_group = -1;
+    auto flush_group = [&]() {
+        if (!GM || pend_group < 0) return;                   // (wave-uniform)
+        // (uniform base + 32-bit lane offset: no 64-bit address kept in registers across the stages)
+        uint32_t* grow = gmin + ((long)pend_group * gm_stride + wave_row0);
+        uint32_t off = (uint32_t)lane;
+        asm volatile("" : "+v"(off));                         // (opaque: the compiler would hoist gmin + row as a 64-bit VGPR pair and spill it)
+        if (pend_keep) grow[off] = pend_full;
+        const unsigned long long mask = __ballot(pend_keep);
+        if (lane == 0) gflags32[ex_flag_index(wave_row0 >> 6, pend_group, (n_stages + 1) >> 1, gm_stride) * 2 + ((wave_row0 >> 5) & 1)] = (uint32_t)mask;
+        pend_group = -1;
+    };
     auto finish_stage = [&](int s) {
         if (GM) {
         static_assert(!GM || WD_SB == 2, "the group-minimum store pairs two 16-sample blocks per wave");
@@ -330,13 +344,9 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
             const float f = __uint_as_float(full);
             const bool keep = lane < 32 && f <= run_min + row_e;
             run_min = __builtin_fminf(run_min, f);
-            // (uniform base + 32-bit lane offset: no 64-bit address kept in registers across the stages)
-            uint32_t* grow = gmin + ((long)(s >> 1) * gm_stride + wave_row0);
-            uint32_t off = (uint32_t)lane;
-            asm volatile("" : "+v"(off));                     // (opaque: the compiler would hoist gmin + row as a 64-bit VGPR pair and spill it)
-            if (keep) grow[off] = full;
-            const unsigned long long mask = __ballot(keep);
-            if (lane == 0) gflags32[ex_flag_index(wave_row0 >> 6, s >> 1, (n_stages + 1) >> 1, gm_stride) * 2 + ((wave_row0 >> 5) & 1)] = (uint32_t)mask;
+            // the stores wait for the next stage (flush_group): issued here they would be the youngest vector-memory
+            // operations at the loop's vmcnt(0), and every wave would sit out a store's round trip before the barrier
+            pend_full = full; pend_keep = keep; pend_group = s >> 1;
         }
     } else {
 #pragma unroll
@@ -374,12 +384,14 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
         __builtin_amdgcn_s_barrier();                         // ... everybody's; and nobody reads stage s-1 any more
         asm volatile("" ::: "memory");
         if (s + 2 < s_end) issue(s + 2, (s + 2 - s_begin) % WD_SLOTS);   // -> the slot stage s-1 was read from
+        flush_group();                                        // the previous group's stores: a whole stage to complete
         const char* st = slot_of(s);
         begin_stage(st);
         chunks(st, KC0(), KCN());
         finish_stage(s);
     }
     SOM_STAMP_END();
+    flush_group();
 
     if (GM) {
         // the row minimum IS the minimum so far after the last group (lanes 0..31 <-> rows wave_row0 + lane): the plain

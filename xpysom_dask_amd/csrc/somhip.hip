@@ -858,10 +858,13 @@ ExactBound exact_bound(const som_handle* h) {
     return eb;
 }
 
-// rows of one screen pass: the group-minimum matrix of a pass stays within ~1 GiB
+// rows of one screen pass: the group-minimum matrix of a pass (and, as large again, the groups' row lists) stays within
+// 4 GiB -- address space rather than traffic: both are written and read only where a row is near its minimum.  1 Mi rows
+// of a 256 x 256 map, or configs[4]'s 250 000-row shard of a 512 x 512 one, are ONE pass (measured against passes of a
+// quarter of that: -2.3 % / -3.5 % per epoch: fewer, larger launches and one counter read-back instead of four).
 long exact_chunk_rows(const som_handle* h) {
     const long n_groups = cdiv(h->K, EX_GROUP);
-    long rows = (1L << 30) / (4 * n_groups);
+    long rows = (4L << 30) / (4 * n_groups);
     if (h->ex.pass_rows_override > 0) rows = h->ex.pass_rows_override;   // SOM_EXACT_PASS_ROWS: tests walk several passes on small data
     rows = rows / 1024 * 1024;                           // (a multiple of every screen kernel's workgroup tile)
     return rows < 1024 ? 1024 : rows;
