@@ -343,3 +343,19 @@ def test_exact_wide_on_a_smooth_sheet():
     for dist in ("euclidean", "cosine"):
         r = both_dist(X, Y, D, w, data, dist)
         assert np.array_equal(r["exact"][0], r["f32"][0])
+
+
+@pytest.mark.parametrize("two_round", ["0", "1"])
+@pytest.mark.parametrize("X,Y,D,dist", [(64, 64, 32, "euclidean"), (64, 64, 200, "cosine")])
+def test_exact_one_round_and_two_round_rescore_agree_with_float32(monkeypatch, two_round, X, Y, D, dist):
+    """SOM_EXACT_TWO_ROUND forces either re-score scheme on either tiling (the default is one round up to 128 features, two
+    beyond): both must return the float32 kernel's BMUs, on a random and on a smooth codebook."""
+    monkeypatch.setenv("SOM_EXACT_TWO_ROUND", two_round)
+    n = 3000
+    data = O.gaussian_blobs(n, D, seed=21)
+    for w in (O.default_codebook(X, Y, D, 5).astype(F32), O.smooth_sheet_codebook(X, Y, D, seed=4).astype(F32)):
+        r = both_dist(X, Y, D, w, data, dist)
+        assert np.array_equal(r["exact"][0], r["f32"][0])
+        assert np.array_equal(r["exact"][1], r["f32"][1])
+        rows, fb, _ = r["exact"][4]
+        assert rows >= n and fb <= n // 20

@@ -66,7 +66,7 @@ struct ExactBound {
     int unit;                         // cosine: the operands are unit-length rows (|x_n| = wmax = 1 in the formula)
 };
 struct ExactScales {                  // per launch: from max|x|^2, max|w|^2, max_k |w^_k - w~_k|^2
-    float sx, sw, wm, bmag, we;
+    float sx, sw, wm, bmag, we, big;
 };
 __device__ __forceinline__ ExactScales ex_scales(const float* __restrict__ xmax2, const float* __restrict__ wmax2,
                                                  const float* __restrict__ werr2) {
@@ -75,6 +75,7 @@ __device__ __forceinline__ ExactScales ex_scales(const float* __restrict__ xmax2
     s.sw = ex_scale(*wmax2);
     s.wm = __builtin_sqrtf(*wmax2) * (1.0f + 1.0f / 1024.0f);
     const float big = __builtin_sqrtf(*wmax2) * __builtin_sqrtf(*xmax2) * (1.0f + 1.0f / 1024.0f);   // prep_wsqh_kernel's B
+    s.big = big;
     s.bmag = 2.01f * big + 0.5f * s.wm * s.wm;
     s.we = __builtin_sqrtf(*werr2) * (1.0f + 1.0f / 1024.0f);
     return s;

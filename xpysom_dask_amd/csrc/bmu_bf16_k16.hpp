@@ -224,6 +224,7 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
     }
 
     float run_min = __builtin_inff(), row_e = 0.0f;       // GM: lane l <-> row wave_s0 + l: its minimum so far, its bound E
+    int run_arg = 0;                                      //     ... and the group (stage) that holds it
     if (GM) {
         const long r = wave_s0 + lane;
         row_e = r < N ? ex_row_bound(eb, ex_scales(xmax2, wmax2, werr2), xsq[r], xerr[r]) : __builtin_nanf("");
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
             const uint32_t full = min(c[0], c[1]);         // quads: (v0, v1, v2, v3), each over all four quads
             const float f = __uint_as_float(full);         // (positive, or a NaN pattern: compares false, never kept)
             const bool keep = f <= run_min + row_e;
+            if (f < run_min) run_arg = stage;              // (the group that holds the row minimum: the first re-score round)
             run_min = __builtin_fminf(run_min, f);
             if (keep) gmin[(long)stage * gm_stride + wave_s0 + lane] = full;
             const unsigned long long mask = __ballot(keep);
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
         }
 #pragma unroll
         for (int sb = 0; sb < K16_SB; ++sb) {
-            if (cbest[sb] < gbest[sb]) { gbest[sb] = cbest[sb]; gstage[sb] = stage; }
+            if (!GM && cbest[sb] < gbest[sb]) { gbest[sb] = cbest[sb]; gstage[sb] = stage; }   // (GM: run_min is the row minimum)
             cbest[sb] = 0xFFFFFFFFu;
         }
     };
@@ -350,13 +352,20 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
     fold_stage(s_end - 1);
     SOM_STAMP_END();
 
+    if (GM) {
+        // the row minimum IS the minimum so far after the last group (lane l <-> row wave_s0 + l): the plain value, every
+        // bit of it, and the group that holds it (no unit indices exist here); parts merge by value, then lower group
+        const long row = wave_s0 + lane;
+        if (row < N) atomicMin(out64 + row, ((unsigned long long)__float_as_uint(run_min) << 32) | (uint32_t)run_arg);
+        return;
+    }
+
 #pragma unroll
     for (int sb = 0; sb < K16_SB; ++sb) {
         uint32_t code = gbest[sb] & IDX_MASK;
         uint32_t unit = (uint32_t)gstage[sb] * K16_STAGE_UNITS + (code >> 2) * 16 + quad * 4 + (code & 3);
         // all distances are positive floats: (value bits, unit) orders as one unsigned 64-bit key
         unsigned long long comp = ((unsigned long long)(gbest[sb] & ~IDX_MASK) << 32) | unit;
-        if (GM) comp = (unsigned long long)gbest[sb] << 32;   // the plain minimum, every bit of it (no indices kept)
         unsigned long long o = __shfl_xor(comp, 16, 64);
         if (o < comp) comp = o;
         o = __shfl_xor(comp, 32, 64);

@@ -214,6 +214,7 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
     // GM: lane l < 32 <-> row (block, wave, l): its minimum so far, its bound E; pmin: this lane's minimum over the group
     const long wave_row0 = (long)blockIdx.x * WD_WG_SAMPLES + wave * (WD_SB * 16);
     float run_min = __builtin_inff(), row_e = __builtin_inff();
+    int run_arg = 0;
     uint32_t pmin[WD_SB];
 #pragma unroll
     for (int sb = 0; sb < WD_SB; ++sb) pmin[sb] = 0xFFFFFFFFu;
@@ -343,6 +344,7 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
             const uint32_t full = (lane & 16) ? v[WD_SB - 1] : v[0];
             const float f = __uint_as_float(full);
             const bool keep = lane < 32 && f <= run_min + row_e;
+            if (f < run_min) run_arg = s >> 1;               // (the group that holds the row minimum: the first re-score round)
             run_min = __builtin_fminf(run_min, f);
             // the stores wait for the next stage (flush_group): issued here they would be the youngest vector-memory
             // operations at the loop's vmcnt(0), and every wave would sit out a store's round trip before the barrier
@@ -395,9 +397,9 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
 
     if (GM) {
         // the row minimum IS the minimum so far after the last group (lanes 0..31 <-> rows wave_row0 + lane): the plain
-        // value, every bit of it (no indices kept)
+        // value, every bit of it, and the group that holds it (no unit indices kept)
         const long row = wave_row0 + lane;
-        if (lane < 32 && row < N) atomicMin(out64 + row, (unsigned long long)__float_as_uint(run_min) << 32);
+        if (lane < 32 && row < N) atomicMin(out64 + row, ((unsigned long long)__float_as_uint(run_min) << 32) | (uint32_t)run_arg);
         return;
     }
 #pragma unroll

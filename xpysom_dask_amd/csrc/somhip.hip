@@ -72,8 +72,10 @@ struct som_handle {
         unsigned long long* gflags = nullptr;   // [stride / 64][n_groups] which rows' minima the screen stored
         long stride = 0;                     //   rows per group line (a chunk of the row set, padded)
         int* rowcnt = nullptr;               // [stride] candidate groups of every row of the last pass (som_exact_last_counts)
+        int* rowarg = nullptr;               // [stride] the group round 1 scored for the row (-1: none)
+        int two_round = -1;                  // SOM_EXACT_TWO_ROUND=0|1 forces the one- / two-round re-score (default: two rounds beyond 128 features)
         int *fb_list = nullptr, *fb_ids = nullptr;
-        int* ctr = nullptr;                  // gcount | (unused) | fb_count | n_tiles | overflow (zeroed per pass)
+        int* ctr = nullptr;                  // gcount | gstart of round 2 | fb_count | n_tiles | overflow (zeroed per pass)
         int* plist = nullptr;                // [n_groups][stride] rows bucketed by candidate group
         int4* tile_tab = nullptr;            // re-score tiles: (group, first list entry, rows)
         long max_tiles = 0;
@@ -877,9 +879,9 @@ int exact_reserve(som_handle* h, long rows) {
     auto& ex = h->ex;
     const long stride = round_up(std::min(rows, exact_chunk_rows(h)), 256);
     if (stride <= ex.stride) return 0;
-    void* old[] = {ex.gmin, ex.gflags, ex.rowcnt, ex.fb_list, ex.plist, ex.tile_tab};
+    void* old[] = {ex.gmin, ex.gflags, ex.rowcnt, ex.rowarg, ex.fb_list, ex.plist, ex.tile_tab};
     for (void* p : old) if (p) (void)hipFree(p);
-    ex.gmin = nullptr; ex.gflags = nullptr; ex.rowcnt = nullptr; ex.fb_list = nullptr; ex.plist = nullptr; ex.tile_tab = nullptr;
+    ex.gmin = nullptr; ex.gflags = nullptr; ex.rowcnt = nullptr; ex.rowarg = nullptr; ex.fb_list = nullptr; ex.plist = nullptr; ex.tile_tab = nullptr;
     ex.stride = 0;
     const long n_groups = cdiv(h->K, EX_GROUP);
     // capacity of a pass in (row, group) pairs per row on average: a quarter of the groups -- past that the float32
@@ -890,6 +892,7 @@ int exact_reserve(som_handle* h, long rows) {
     if (int rc = dev_alloc(h, &ex.gmin, (size_t)n_groups * stride)) return rc;
     if (int rc = dev_alloc(h, &ex.gflags, (size_t)n_groups * (stride / 64))) return rc;
     if (int rc = dev_alloc(h, &ex.rowcnt, (size_t)stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.rowarg, (size_t)stride)) return rc;
     if (int rc = dev_alloc(h, &ex.plist, (size_t)n_groups * stride)) return rc;   // every group: room for the whole pass
     if (int rc = dev_alloc(h, &ex.fb_list, (size_t)stride)) return rc;
     ex.max_tiles = cdiv(stride * ex.pairs, EX_TR) + n_groups;
@@ -992,15 +995,15 @@ int exact_rescore_kg(som_handle* h, const float* X, int n_groups) {
     return 0;
 }
 
-// the re-score of one pass: bucket the (row, group) pairs by group, score tile by tile, settle the rows.  best64 is the
-// pass's slice of the merge keys (the scan has read the screen's minima from it; the fill resets it).
-int exact_rescore(som_handle* h, const float* X, const float* xsq, long n, unsigned long long* best64, int* out) {
+// the lists' entries from gstart on -> tiles -> float32 scores merged into best64 (the pass's slice of the merge keys)
+int exact_rescore_round(som_handle* h, const float* X, const float* xsq, unsigned long long* best64, const int* gstart,
+                        int* gstart_out) {
     auto& ex = h->ex;
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
     int* gcount = ex.ctr; int* fb_count = ex.ctr + 2 * n_groups;
     int* n_tiles = fb_count + 1; int* overflow = fb_count + 2;
     exact_tiles_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(gcount, n_groups, ex.stride, ex.stride * ex.pairs, ex.tile_tab, n_tiles,
-                                                             overflow);
+                                                             overflow, gstart, gstart_out);
     unsigned long long* saved = h->best64;
     h->best64 = best64;                                   // (exact_rescore_kg reads it from the handle)
     int rc = 0;
@@ -1013,16 +1016,13 @@ int exact_rescore(som_handle* h, const float* X, const float* xsq, long n, unsig
         int per_cu = 1;
         if (int rc2 = kernel_per_cu(h, kern, 256, 0, &per_cu)) { h->best64 = saved; return rc2; }
         const long grid = std::min<long>(ex.max_tiles, 2L * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
-        int* n_tiles_dev = ex.ctr + 2 * n_groups + 1;
         if (cosine)
             exact_rescore_tiled_kernel<SCORE_COSINE><<<dim3((unsigned)grid), dim3(256), 0, h->stream>>>(
-                X, h->D, xsq, h->Wfimg, h->ft_kchunks, h->K, ex.tile_tab, n_tiles_dev, ex.plist, best64);
+                X, h->D, xsq, h->Wfimg, h->ft_kchunks, h->K, ex.tile_tab, n_tiles, ex.plist, best64);
         else
             exact_rescore_tiled_kernel<SCORE_EUCLID_PART><<<dim3((unsigned)grid), dim3(256), 0, h->stream>>>(
-                X, h->D, xsq, h->Wfimg, h->ft_kchunks, h->K, ex.tile_tab, n_tiles_dev, ex.plist, best64);
+                X, h->D, xsq, h->Wfimg, h->ft_kchunks, h->K, ex.tile_tab, n_tiles, ex.plist, best64);
         h->best64 = saved;
-        exact_finalize_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(best64, n, h->K, overflow, out, ex.fb_list,
-                                                                                     fb_count);
         return 0;
     }
     switch (h->fr_kg) {
@@ -1034,10 +1034,7 @@ int exact_rescore(som_handle* h, const float* X, const float* xsq, long n, unsig
     default: rc = fail(h, "exact: bad k-group count");
     }
     h->best64 = saved;
-    if (rc) return rc;
-    exact_finalize_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(best64, n, h->K, overflow, out, ex.fb_list,
-                                                                                 fb_count);
-    return 0;
+    return rc;
 }
 
 // X, xsq, Xb, out: the row set's float32 rows, their |x|^2, their hi / lo operand image, the ids to write.
@@ -1067,10 +1064,31 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
             Timed ts(h, SOM_K_SCREEN);
             if (int rc = SOM_HALF(h, exact_screen_ks, h, Xb + r0 * h->dp, n, h->best64 + r0, xsq + r0, xerr + r0, xmax2, eb)) return rc;
         }
-        exact_select_kernel<<<dim3((unsigned)cdiv(n, 64)), dim3(64 * EX_SCAN_SPLIT), 0, h->stream>>>(
-            ex.gmin, ex.gflags, ex.stride, n_groups, n, h->best64 + r0, xsq + r0, h->wmax2, xmax2, eb, xerr + r0, h->wmax2 + 1,
-            ex.plist, ex.ctr, ex.rowcnt);
-        if (int rc = exact_rescore(h, X + r0 * h->D, xsq + r0, n, h->best64 + r0, out + r0)) return rc;
+        const dim3 sel_grid((unsigned)cdiv(n, 64)), sel_block(64 * EX_SCAN_SPLIT);
+        unsigned long long* best = h->best64 + r0;
+        // two rounds beyond 128 features, where a (row, group) pair costs 64 x D flop AND a gather of the row's D floats
+        // (configs[4]: 92.8 -> 87.8 ms per epoch); one round up to 128 features, where the three launches more cost more than
+        // the pairs they save (256 x 256 x 128, 1 Mi rows: 15.5 vs 15.8 ms; 65 536 rows: +3 % in every map state)
+        const bool two_round = ex.two_round >= 0 ? ex.two_round != 0 : h->wide;
+        if (two_round) {
+            // round 1: every row against the group that holds its screen minimum; round 2: the groups within the ONE-unit
+            // bound of that float32 score (exact_select_kernel<true>: 20-32 % fewer pairs than the one-round scheme on
+            // smooth maps, up to one pair per row more on random ones)
+            exact_first_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(
+                best, n, n_groups, ex.stride, xsq + r0, h->wmax2, xmax2, eb, xerr + r0, h->wmax2 + 1, ex.plist, ex.ctr, ex.rowarg);
+            if (int rc = exact_rescore_round(h, X + r0 * h->D, xsq + r0, best, nullptr, ex.ctr + n_groups)) return rc;
+            exact_select_kernel<true><<<sel_grid, sel_block, 0, h->stream>>>(
+                ex.gmin, ex.gflags, ex.stride, n_groups, n, best, xsq + r0, h->wmax2, xmax2, eb, xerr + r0, h->wmax2 + 1, ex.plist,
+                ex.ctr, ex.rowcnt, ex.rowarg);
+            if (int rc = exact_rescore_round(h, X + r0 * h->D, xsq + r0, best, ex.ctr + n_groups, nullptr)) return rc;
+        } else {
+            exact_select_kernel<false><<<sel_grid, sel_block, 0, h->stream>>>(
+                ex.gmin, ex.gflags, ex.stride, n_groups, n, best, xsq + r0, h->wmax2, xmax2, eb, xerr + r0, h->wmax2 + 1, ex.plist,
+                ex.ctr, ex.rowcnt);
+            if (int rc = exact_rescore_round(h, X + r0 * h->D, xsq + r0, best, nullptr, nullptr)) return rc;
+        }
+        exact_finalize_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(
+            best, n, h->K, ex.ctr + 2 * n_groups + 2, out + r0, ex.fb_list, ex.ctr + 2 * n_groups);
         HIPCHK(h, hipGetLastError());
         // rows the scheme could not settle (normally none): the float32 kernel itself
         HIPCHK(h, hipMemcpyAsync(ex.fb_count_host, ex.ctr + 2 * n_groups, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1598,6 +1616,7 @@ int som_create(const som_config* cfg, som_handle** out) {
         h->debug = std::getenv("SOM_DEBUG") != nullptr;
         if (const char* e = std::getenv("SOM_VERIFY")) h->verify_rows = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("SOM_EXACT_PASS_ROWS")) h->ex.pass_rows_override = std::atol(e);
+        if (const char* e = std::getenv("SOM_EXACT_TWO_ROUND")) h->ex.two_round = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("SOM_ASYNC_COPIES")) h->async_copies = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_FUSE_MERGE")) h->fuse_merge_prep = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_SORT_ONESWEEP_ROWS")) SORT_ONESWEEP_ROWS = std::atol(e);
@@ -1664,7 +1683,7 @@ void som_destroy(som_handle* h) {
         for (void* b : vb) if (b) (void)hipFree(b);
     }
     {
-        void* eb[] = {h->ex.gmin, h->ex.gflags, h->ex.rowcnt, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab};
+        void* eb[] = {h->ex.gmin, h->ex.gflags, h->ex.rowcnt, h->ex.rowarg, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab};
         for (void* b : eb) if (b) (void)hipFree(b);
         if (h->ex.fb_count_host) (void)hipHostFree(h->ex.fb_count_host);
     }
