@@ -432,26 +432,33 @@ __global__ __launch_bounds__(256) void band_ranges_kernel(const float* __restric
 }
 
 // ranges == nullptr: the whole of H (one segment [0, Ri)).  C columns are computed; rows of M are ld, rows of OUT ldo floats apart.
+// BM = rows of H per workgroup: 128 (waves 2 x 2, each 64 rows x 64 columns) or 64 (waves 1 x 4, each 64 rows x 32
+// columns) for maps of at most 64 rows, whose 128-row tiles would be half empty.
+template <int BM>
 __global__ __launch_bounds__(256) void leftmul_f32_kernel(const float* __restrict__ H, int Ro, int Ri,
                                                           const float* __restrict__ M, long m_batch_stride,
                                                           float* __restrict__ OUT, long o_batch_stride, long C,
                                                           long ld, long ldo, const int2* __restrict__ ranges, int nseg,
                                                           int segw) {
-    __shared__ float Hs[LM_BM][LM_BK + 1];
+    static_assert(BM == 128 || BM == 64, "leftmul: 128- or 64-row tiles");
+    constexpr int TC = BM / 64;                          // 32-column tiles per wave: 2 (64 columns) or 1 (32 columns)
+    constexpr int HQ = BM / 32;                          // 4-float pieces of the H tile per thread
+    __shared__ float Hs[BM][LM_BK + 1];
     __shared__ __attribute__((aligned(16))) float Ms[LM_BK][LM_BN + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = BM == 128 ? wave >> 1 : 0;            // this wave's 64 rows ...
+    const int wcol = BM == 128 ? (wave & 1) * 64 : wave * 32;   // ... and its first column inside the 128-column tile
     const long c0 = (long)blockIdx.x * LM_BN;
-    const int i0 = blockIdx.y * LM_BM;
+    const int i0 = blockIdx.y * BM;
     const float* Mb = M + (long)blockIdx.z * m_batch_stride;
     float* Ob = OUT + (long)blockIdx.z * o_batch_stride;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][TC];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < TC; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.0f;
 
@@ -460,12 +467,12 @@ __global__ __launch_bounds__(256) void leftmul_f32_kernel(const float* __restric
     // (tid + 256 q) >> 5, columns 4 ((tid + 256 q) & 31) .. + 3.  A piece that lies inside the operand and is
     // 16-byte aligned is ONE global_load_dwordx4 (the common case: 8 loads per thread and chunk where the scalar
     // form needed 32 loads with their 64-bit address arithmetic); otherwise its four floats are loaded one by one.
-    f32x4 hreg[4], mreg[4];
+    f32x4 hreg[HQ], mreg[4];
     auto fetch = [&](int r0, int kend) {               // chunk [r0, r0 + 32) clipped to columns < kend
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int idx = tid + q * 256;
-            {
+            if (q < HQ) {
                 const int i = idx >> 3, k = (idx & 7) * 4;
                 const float* src = H + (long)(i0 + i) * Ri + r0 + k;
                 // (the piece's own address decides: a banded chunk starts at sg * segw + lo, any float offset)
@@ -488,9 +495,11 @@ __global__ __launch_bounds__(256) void leftmul_f32_kernel(const float* __restric
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int idx = tid + q * 256;
-            const int i = idx >> 3, k = (idx & 7) * 4;
+            if (q < HQ) {
+                const int i = idx >> 3, k = (idx & 7) * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) Hs[i][k + e] = hreg[q][e];          // (33-float rows: conflict-free reads, scalar writes)
+                for (int e = 0; e < 4; ++e) Hs[i][k + e] = hreg[q][e];      // (33-float rows: conflict-free reads, scalar writes)
+            }
             *(f32x4*)&Ms[idx >> 5][(idx & 31) * 4] = mreg[q];               // 132-float rows: 16-byte aligned
         }
     };
@@ -501,7 +510,7 @@ __global__ __launch_bounds__(256) void leftmul_f32_kernel(const float* __restric
     if (ranges != nullptr) {
         ns = nseg; sw = segw; lo = segw; hi = 0;
         for (int sg = 0; sg < nseg; ++sg) {
-            const int2 v = ranges[blockIdx.y * nseg + sg];   // {segw - first nonzero, last nonzero + 1}
+            const int2 v = ranges[(blockIdx.y * BM / LM_BM) * nseg + sg];   // {segw - first nonzero, last nonzero + 1} of the 128-row block
             if (v.y > 0) { lo = min(lo, ((segw - v.x) / LM_BK) * LM_BK); hi = max(hi, min(v.y, segw)); }
         }
         if (hi <= lo) lo = hi = 0;
@@ -521,23 +530,23 @@ __global__ __launch_bounds__(256) void leftmul_f32_kernel(const float* __restric
         if (c + 1 < total) { int r0, kend; chunk_at(c + 1, r0, kend); fetch(r0, kend); }   // in flight under the MFMAs below
 #pragma unroll
         for (int k = 0; k < LM_BK; k += 2) {
-            float av[2], bv[2];
+            float av[2], bv[TC];
 #pragma unroll
             for (int a = 0; a < 2; ++a) av[a] = Hs[wr * 64 + a * 32 + col][k + half];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) bv[t] = Ms[k + half][wc * 64 + t * 32 + col];
+            for (int t = 0; t < TC; ++t) bv[t] = Ms[k + half][wcol + t * 32 + col];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < TC; ++t)
                     acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[t], acc[a][t], 0, 0, 0);
         }
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            long c = c0 + wc * 64 + t * 32 + col;
+        for (int t = 0; t < TC; ++t) {
+            long c = c0 + wcol + t * 32 + col;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int i = i0 + wr * 64 + a * 32 + mfma32_row(r, half);
