@@ -34,6 +34,7 @@ CASES = [
     (20, 20, 16, 2000, "bf16x3"),
     (64, 64, 200, 1500, "bf16"), (24, 20, 32, 2561, "f16"), (64, 66, 160, 1200, "f16"), (20, 20, 16, 2000, "f16x3"),   # wide kernel, IEEE half
     (24, 20, 32, 2561, "exact"), (64, 64, 128, 4096, "exact"),
+    (64, 64, 200, 1500, "exact"), (72, 64, 784, 900, "exact"),                     # the wide screen + two-round re-score
 ]
 
 
