@@ -70,6 +70,48 @@ __global__ __launch_bounds__(256) void prep_w_bf16_k16_kernel(const float* __res
     *(bf16x8*)(Wst + stage * k16_stage_bytes(KS32) + ((long)(t16 * KS32 + ks) * 64 + lane) * 16) = v;
 }
 
+// The exact mode's codebook preparation up to 128 features (bmu_exact.hpp): the stage image of the units scaled by the power
+// of two ex_scale(*scale_max2) AND max_k |w^_k - w~_k|^2, what the MFMA will read instead of the scaled float32 units
+// (half_operand_error), in one pass -- prep_w_bf16_k16_kernel + exact_werr_kernel.  One wave per 16-unit tile walks the
+// tile's KS32 feature chunks (lane = (unit, 8 features) of each: one 16-byte fragment chunk of the image per chunk), so a
+// unit's error is four lanes of one wave.
+template <int KS32, class EL = Bf16>
+__global__ __launch_bounds__(256) void prep_w_exact_k16_kernel(const float* __restrict__ W, int K, int D,
+                                                               char* __restrict__ Wst, int n_stages,
+                                                               const float* __restrict__ scale_max2,
+                                                               float* __restrict__ werr2) {
+    using E = typename EL::T;
+    using bf16x8 = typename V8<E>::t;
+    const int lane = threadIdx.x & 63;
+    const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // (stage, t16)
+    if (tile >= (long)n_stages * K16_T) return;
+    const long stage = tile / K16_T;
+    const int t16 = (int)(tile - stage * K16_T);
+    const long u = stage * K16_STAGE_UNITS + t16 * 16 + (lane & 15);
+    const float scale = ex_scale(*scale_max2);
+    float er = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS32; ++ks) {
+        const int k0 = ks * 32 + (lane >> 4) * 8;
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = (u < K && k0 + j < D) ? W[u * D + k0 + j] * scale : 0.0f;
+            const E hb = cvt<E>(-f);
+            v[j] = hb;
+            const float e = half_operand_error(-f, (float)hb);
+            er = __builtin_fmaf(e, e, er);
+        }
+        *(bf16x8*)(Wst + stage * k16_stage_bytes(KS32) + ((long)(t16 * KS32 + ks) * 64 + lane) * 16) = v;
+    }
+    er += __shfl_xor(er, 16, 64);                            // the unit's four feature quarters
+    er += __shfl_xor(er, 32, 64);
+    float m = (er == er) ? er : 0.0f;                        // (a NaN unit is left out, as in exact_werr_kernel)
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) atomic_max_pos_f32(werr2, m);
+}
+
 // _merge_updates (xpysom.py:446-455) fused with the NEXT epoch's operand preparation: one pass over the fused
 // accumulator writes the merged float32 codebook, the bf16 stage image of -w~ and |w~_k|^2 (+ its maximum),
 // i.e. merge_kernel + prep_w_bf16_k16_kernel + prep_wnorm_kernel (euclidean) in one launch and one read of

@@ -689,15 +689,25 @@ __global__ __launch_bounds__(64) void debug_mfma16_kernel(const uint16_t* __rest
 
 // wn = wsq (the float32 kernel's own |w|^2) and its maximum: the screen's initial accumulator then carries the same
 // norm the re-score adds
-__global__ __launch_bounds__(256) void exact_copy_wsq_kernel(const float* __restrict__ wsq, int K, float* __restrict__ wn,
-                                                             float* __restrict__ wmax2) {
-    const long u = (long)blockIdx.x * 256 + threadIdx.x;
+// (blocks of 1 024 units hand in ONE maximum each: a wave per atomic -- 1 024 of them polling one address at 256 x 256 units --
+//  took 17 us for a 256 KB copy)
+__global__ __launch_bounds__(1024) void exact_copy_wsq_kernel(const float* __restrict__ wsq, int K, float* __restrict__ wn,
+                                                              float* __restrict__ wmax2) {
+    __shared__ float wave_max[16];
+    const long u = (long)blockIdx.x * 1024 + threadIdx.x;
     float s = 0.0f;
     if (u < K) { s = wsq[u]; wn[u] = s; }
     float m = (s == s) ? s : 0.0f;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomic_max_pos_f32(wmax2, m);
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        m = wave_max[threadIdx.x];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (threadIdx.x == 0) atomic_max_pos_f32(wmax2, m);
+    }
 }
 
 }  // namespace somhip

@@ -332,7 +332,7 @@ int prep_codebook_half(som_handle* h) {
                 HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)h->wmax2, 0x3F800000, 1, h->stream));
             } else {
                 HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
-                exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(h->K, 256)), block, 0, h->stream>>>(h->wsq, h->K, h->wn, h->wmax2);
+                exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(h->K, 1024)), dim3(1024), 0, h->stream>>>(h->wsq, h->K, h->wn, h->wmax2);
             }
             long total = (long)h->n_stages * WD_T * h->n_kchunks * 64;
             prep_w_bf16_wide_kernel<E><<<dim3((unsigned)cdiv(total, 256)), block, 0, h->stream>>>(
@@ -372,16 +372,22 @@ int prep_codebook_half(som_handle* h) {
     }
     const long total = (long)h->n_stages * K16_T * h->ks32 * 64;
     const dim3 grid((unsigned)cdiv(total, 256));
-    const float* sc = nullptr;
     if (h->exact) {
         // the float32 kernel's own |w|^2 (refreshed just before) and its maximum first: the units go in scaled by
-        // ex_scale(max |w|^2)
-        HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
-        exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(h->K, 256)), block, 0, h->stream>>>(h->wsq, h->K, h->wn, h->wmax2);
-        sc = h->wmax2;
-        HIPCHK(h, hipMemsetAsync(h->wmax2 + 1, 0, sizeof(float), h->stream));     // [1]: max_k |w^_k - w~_k|^2
-        exact_werr_kernel<E><<<dim3((unsigned)cdiv(h->K, 4 * EX_WERR_UNITS)), block, 0, h->stream>>>(h->W, h->K, h->D, h->wmax2, h->wmax2 + 1);
+        // ex_scale(max |w|^2); then the scaled stage image and the units' rounding errors in one pass
+        HIPCHK(h, hipMemsetAsync(h->wmax2, 0, 2 * sizeof(float), h->stream));     // [0]: max |w|^2, [1]: max_k |w^_k - w~_k|^2
+        exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(h->K, 1024)), dim3(1024), 0, h->stream>>>(h->wsq, h->K, h->wn, h->wmax2);
+        const dim3 tgrid((unsigned)cdiv((long)h->n_stages * K16_T, 4));
+        switch (h->ks32) {
+        case 1: prep_w_exact_k16_kernel<1, E><<<tgrid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1); break;
+        case 2: prep_w_exact_k16_kernel<2, E><<<tgrid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1); break;
+        case 3: prep_w_exact_k16_kernel<3, E><<<tgrid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1); break;
+        case 4: prep_w_exact_k16_kernel<4, E><<<tgrid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1); break;
+        default: return fail(h, "the resident half-precision kernel supports input_len <= 128");
+        }
+        return 0;
     }
+    const float* sc = nullptr;
     switch (h->ks32) {
     case 1: prep_w_bf16_k16_kernel<1, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit, sc); break;
     case 2: prep_w_bf16_k16_kernel<2, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit, sc); break;
@@ -389,7 +395,6 @@ int prep_codebook_half(som_handle* h) {
     case 4: prep_w_bf16_k16_kernel<4, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit, sc); break;
     default: return fail(h, "the resident half-precision kernel supports input_len <= 128");
     }
-    if (h->exact) return 0;
     HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
     prep_wnorm_kernel<E><<<dim3((unsigned)cdiv(h->K, 256)), block, 0, h->stream>>>(h->W, h->K, h->D, h->wn, h->wmax2, unit);
     return 0;
