@@ -233,7 +233,8 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
                                                               const float* __restrict__ xmax2 = nullptr,
                                                               const float* __restrict__ wmax2 = nullptr,
                                                               const float* __restrict__ werr2 = nullptr,
-                                                              ExactBound eb = ExactBound()) {
+                                                              ExactBound eb = ExactBound(),
+                                                              const float* __restrict__ seed = nullptr) {
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     constexpr int DP = 32 * KS32;
@@ -267,10 +268,14 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
 
     float run_min = __builtin_inff(), row_e = 0.0f;       // GM: lane l <-> row wave_s0 + l: its minimum so far, its bound E
     int run_arg = 0;                                      //     ... and the group (stage) that holds it
+    float run_cap = __builtin_inff();                     //     ... and the seed's cap on the keep threshold
     if (GM) {
         const long r = wave_s0 + lane;
         row_e = r < N ? ex_row_bound(eb, ex_scales(xmax2, wmax2, werr2), xsq[r], xerr[r]) : __builtin_nanf("");
         if (!(row_e == row_e)) row_e = __builtin_inff();   // a row the bound does not cover: keep everything (the scan drops it)
+        // seed (exact_seed_kernel): an upper bound on what the screen will hold for ONE unit of the row's choice (last
+        // epoch's BMU), known before the scan: no group minimum above it + E can be selected, whatever the minimum so far
+        if (seed != nullptr && r < N) { const float sd = seed[r]; if (sd == sd) run_cap = sd; }
     }
     // this workgroup's share of the codebook stages
     const int s_begin = (int)((long)n_stages * blockIdx.y / gridDim.y);
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
             auto c = __builtin_amdgcn_permlane32_swap(t01, t23, false, false);
             const uint32_t full = min(c[0], c[1]);         // quads: (v0, v1, v2, v3), each over all four quads
             const float f = __uint_as_float(full);         // (positive, or a NaN pattern: compares false, never kept)
-            const bool keep = f <= run_min + row_e;
+            const bool keep = f <= __builtin_fminf(run_min, run_cap) + row_e;
             if (f < run_min) run_arg = stage;              // (the group that holds the row minimum: the first re-score round)
             run_min = __builtin_fminf(run_min, f);
             if (keep) gmin[(long)stage * gm_stride + wave_s0 + lane] = full;

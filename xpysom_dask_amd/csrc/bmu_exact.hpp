@@ -189,6 +189,38 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_select_kernel(const 
     }
 }
 
+// seed[n] = an upper bound on the screen value of unit u = prev[n] (any unit: last epoch's BMU is the useful choice) for row
+// n, from the float32 operands: t = |w_u|^2 - 2 x.w_u in float32 (a 16-lane fma tree: its error is within the float32
+// kernel's share of the bound), d'(t) + E/2 as in the second re-score round.  The screen keeps a group minimum only if it
+// is within E of min(minimum so far, seed): on a trained map the seed IS about the row minimum, and the groups passed on
+// the way down to it -- most of what a smooth map makes the screen store and the select kernel read -- are never written.
+// Euclidean, input_len <= 128; 16 lanes per row.
+__global__ __launch_bounds__(256) void exact_seed_kernel(const float* __restrict__ X, long N, int D,
+                                                         const float* __restrict__ W, const float* __restrict__ wsq, int K,
+                                                         const int* __restrict__ prev, const float* __restrict__ xsq,
+                                                         const float* __restrict__ xerr, const float* __restrict__ wmax2,
+                                                         const float* __restrict__ xmax2, const float* __restrict__ werr2,
+                                                         ExactBound eb, float* __restrict__ seed) {
+    const int sub = threadIdx.x & 15;
+    const long row = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const bool live = row < N;
+    const long r = live ? row : 0;
+    int u = prev[r];
+    u = u < 0 ? 0 : u >= K ? K - 1 : u;                      // (any unit gives a valid bound)
+    float c = 0.0f;
+    for (int k = sub; k < D; k += 16) c = __builtin_fmaf(X[r * D + k], W[(long)u * D + k], c);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (sub != 0 || !live) return;
+    const ExactScales sc = ex_scales(xmax2, wmax2, werr2);
+    const float e = ex_row_bound(eb, sc, xsq[r], xerr[r]);
+    const float t = __builtin_fmaf(-2.0f, c, wsq[u]);
+    const float S = sc.sx * sc.sw;
+    const float dp = __builtin_fmaf(0.5f * S, t, S * sc.big);
+    const float sd = dp + 0.5f * e * (1.0f + 1.0f / 1024.0f) + S * sc.bmag * 0x1p-21f;
+    seed[r] = (sd > 0.0f && sd < 3.0e38f) ? sd : __builtin_inff();
+}
+
 // Round 1 of the two-round scheme: every row goes to the list of the group that holds its screen minimum (the screen
 // leaves that group in the low half of the row's merge key).  rowarg[n] = that group, or -1 for a row the bound does not
 // cover (it selects nothing in round 2 either and ends in the fallback list).  One returning atomic per wave and distinct

@@ -73,6 +73,9 @@ struct som_handle {
         long stride = 0;                     //   rows per group line (a chunk of the row set, padded)
         int* rowcnt = nullptr;               // [stride] candidate groups of every row of the last pass (som_exact_last_counts)
         int* rowarg = nullptr;               // [stride] the group round 1 scored for the row (-1: none)
+        float* seed = nullptr;               // [stride] exact_seed_kernel: the cap on the screen's keep threshold
+        bool seed_on = true;                 // SOM_EXACT_SEED=0: no seed (A/B)
+        bool seed_live = false;              // this pass's screen reads the seed
         int two_round = -1;                  // SOM_EXACT_TWO_ROUND=0|1 forces the one- / two-round re-score (default: two rounds beyond 128 features)
         int *fb_list = nullptr, *fb_ids = nullptr;
         int* ctr = nullptr;                  // gcount | gstart of round 2 | fb_count | n_tiles | overflow (zeroed per pass)
@@ -119,6 +122,7 @@ struct som_handle {
     float* X_owned = nullptr;
     long N = 0, Np = 0;
     int* bmu = nullptr;
+    bool bmu_valid = false;  // bmu holds the ids of a completed BMU pass over the resident rows
     unsigned long long* best64 = nullptr;   // bf16 path: per-row (value bits | unit) merged across codebook parts
     long best64_cap = 0;
     int n_cus = 0;
@@ -884,9 +888,9 @@ int exact_reserve(som_handle* h, long rows) {
     auto& ex = h->ex;
     const long stride = round_up(std::min(rows, exact_chunk_rows(h)), 256);
     if (stride <= ex.stride) return 0;
-    void* old[] = {ex.gmin, ex.gflags, ex.rowcnt, ex.rowarg, ex.fb_list, ex.plist, ex.tile_tab};
+    void* old[] = {ex.gmin, ex.gflags, ex.rowcnt, ex.rowarg, ex.seed, ex.fb_list, ex.plist, ex.tile_tab};
     for (void* p : old) if (p) (void)hipFree(p);
-    ex.gmin = nullptr; ex.gflags = nullptr; ex.rowcnt = nullptr; ex.rowarg = nullptr; ex.fb_list = nullptr; ex.plist = nullptr; ex.tile_tab = nullptr;
+    ex.gmin = nullptr; ex.gflags = nullptr; ex.rowcnt = nullptr; ex.rowarg = nullptr; ex.seed = nullptr; ex.fb_list = nullptr; ex.plist = nullptr; ex.tile_tab = nullptr;
     ex.stride = 0;
     const long n_groups = cdiv(h->K, EX_GROUP);
     // capacity of a pass in (row, group) pairs per row on average: a quarter of the groups -- past that the float32
@@ -898,6 +902,7 @@ int exact_reserve(som_handle* h, long rows) {
     if (int rc = dev_alloc(h, &ex.gflags, (size_t)n_groups * (stride / 64))) return rc;
     if (int rc = dev_alloc(h, &ex.rowcnt, (size_t)stride)) return rc;
     if (int rc = dev_alloc(h, &ex.rowarg, (size_t)stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.seed, (size_t)stride)) return rc;
     if (int rc = dev_alloc(h, &ex.plist, (size_t)n_groups * stride)) return rc;   // every group: room for the whole pass
     if (int rc = dev_alloc(h, &ex.fb_list, (size_t)stride)) return rc;
     ex.max_tiles = cdiv(stride * ex.pairs, EX_TR) + n_groups;
@@ -927,7 +932,8 @@ int exact_screen(som_handle* h, const __bf16* Xb, long n, unsigned long long* be
         std::fprintf(stderr, "[somhip] exact screen: blocks=%ld per_cu=%d slots=%ld parts=%d groups=%d\n", blocks, per_cu,
                      slots, parts, n_groups);
     kern<<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * K16_NW), lds, h->stream>>>(
-        Xb, n, h->Wst, h->n_stages, h->K, best64, h->ex.gmin, h->ex.stride, h->ex.gflags, xsq, xerr, xmax2, h->wmax2, h->wmax2 + 1, eb);
+        Xb, n, h->Wst, h->n_stages, h->K, best64, h->ex.gmin, h->ex.stride, h->ex.gflags, xsq, xerr, xmax2, h->wmax2, h->wmax2 + 1, eb,
+        h->ex.seed_live ? h->ex.seed : nullptr);
     return 0;
 }
 
@@ -1065,6 +1071,11 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     for (long r0 = 0; r0 < N; r0 += chunk) {
         const long n = std::min(chunk, N - r0);
         HIPCHK(h, hipMemsetAsync(ex.ctr, 0, (size_t)(2 * n_groups + 3) * sizeof(int), h->stream));
+        // resident rows from their second epoch on: last epoch's BMU of every row caps the screen's keep threshold
+        ex.seed_live = ex.seed_on && !h->wide && out == h->bmu && h->bmu_valid;
+        if (ex.seed_live)
+            exact_seed_kernel<<<dim3((unsigned)cdiv(n * 16, 256)), dim3(256), 0, h->stream>>>(
+                X + r0 * h->D, n, h->D, h->W, h->wsq, h->K, out + r0, xsq + r0, xerr + r0, h->wmax2, xmax2, h->wmax2 + 1, eb, ex.seed);
         {
             Timed ts(h, SOM_K_SCREEN);
             if (int rc = SOM_HALF(h, exact_screen_ks, h, Xb + r0 * h->dp, n, h->best64 + r0, xsq + r0, xerr + r0, xmax2, eb)) return rc;
@@ -1204,6 +1215,7 @@ int run_activation_bmu(som_handle* h, const float* X, long N, const float* xsq, 
                        int* out) {
     if (N == 0) return 0;
     if (int rc = run_activation_bmu_launch(h, X, N, xsq, Xb, xmax2, out)) return rc;
+    if (out == h->bmu) h->bmu_valid = true;               // (the next epoch's exact screen seeds its thresholds from these ids)
     if (h->verify_rows > 0 && !h->verifying) return verify_bmu_launch(h, X, N, out);
     return 0;
 }
@@ -1628,6 +1640,7 @@ int som_create(const som_config* cfg, som_handle** out) {
         if (const char* e = std::getenv("SOM_VERIFY")) h->verify_rows = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("SOM_EXACT_PASS_ROWS")) h->ex.pass_rows_override = std::atol(e);
         if (const char* e = std::getenv("SOM_EXACT_TWO_ROUND")) h->ex.two_round = std::atoi(e) != 0 ? 1 : 0;
+        if (const char* e = std::getenv("SOM_EXACT_SEED")) h->ex.seed_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_ASYNC_COPIES")) h->async_copies = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_FUSE_MERGE")) h->fuse_merge_prep = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_SORT_ONESWEEP_ROWS")) SORT_ONESWEEP_ROWS = std::atol(e);
@@ -1694,7 +1707,7 @@ void som_destroy(som_handle* h) {
         for (void* b : vb) if (b) (void)hipFree(b);
     }
     {
-        void* eb[] = {h->ex.gmin, h->ex.gflags, h->ex.rowcnt, h->ex.rowarg, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab};
+        void* eb[] = {h->ex.gmin, h->ex.gflags, h->ex.rowcnt, h->ex.rowarg, h->ex.seed, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab};
         for (void* b : eb) if (b) (void)hipFree(b);
         if (h->ex.fb_count_host) (void)hipHostFree(h->ex.fb_count_host);
     }
@@ -1736,6 +1749,7 @@ int som_get_weights(som_handle* h, float* w_host) {
 static int adopt_rows(som_handle* h, int64_t n_rows) {
     (void)hipFree(h->bmu); (void)hipFree(h->xsq); (void)hipFree(h->Xb);
     h->bmu = nullptr; h->xsq = nullptr; h->Xb = nullptr;
+    h->bmu_valid = false;
     seg_free(h->seg);
     h->N = n_rows;
     h->Np = round_up(n_rows, ROW_PAD);
