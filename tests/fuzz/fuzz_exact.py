@@ -50,6 +50,7 @@ for case in range(n_cases):
     if rs.rand() < 0.1 and n > 2:
         data[rs.randint(0, n)] = np.nan
     sig = float(rs.choice([max(min(X, Y) / 2, 1.0), 1.0, 2.5]))
+    w2 = (w[::-1, ::-1] * F32(rs.choice([1.0, 0.5, 3.0]))).copy()   # (another codebook of the same kind: the units change places)
     try:
         out = {}
         for p in ("f32", "exact"):
@@ -58,15 +59,24 @@ for case in range(n_cases):
             e.epoch_accumulate(sig, 0.5, True)
             num, den, bmu = e.epoch_fetch()
             q = e.bmu(data[: min(n, 700)])
-            out[p] = (bmu, q, num, den)
+            # a second and third epoch on the same resident rows: the exact mode now seeds its thresholds from the previous
+            # epoch's BMUs -- after a merge (the usual case: most BMUs stay) and after a codebook the old BMUs say nothing about
+            e.epoch_merge()
+            e.epoch_accumulate(sig * 0.7, 0.4, True)
+            bmu2 = e.epoch_fetch()[2]
+            e.set_weights(w2)
+            e.epoch_accumulate(sig, 0.5, True)
+            bmu3 = e.epoch_fetch()[2]
+            out[p] = (bmu, q, num, den, bmu2, bmu3)
             if p == "exact":
                 r, fb, _ = e.exact_stats()
                 rows_total += r; fb_total += fb
             e.close()
         a, b = out["f32"], out["exact"]
         ok = np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True) \
-            and np.array_equal(a[3], b[3], equal_nan=True)
-        detail = "%d epoch rows, %d query rows differ" % ((a[0] != b[0]).sum(), (a[1] != b[1]).sum())
+            and np.array_equal(a[3], b[3], equal_nan=True) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+        detail = "%d epoch rows, %d query rows, %d / %d rows of the seeded epochs differ" % (
+            (a[0] != b[0]).sum(), (a[1] != b[1]).sum(), (a[4] != b[4]).sum(), (a[5] != b[5]).sum())
     except Exception as ex:                      # noqa: BLE001
         ok, detail = False, "EXC " + repr(ex)[:200]
     if not ok:

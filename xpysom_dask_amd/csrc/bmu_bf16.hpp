@@ -92,6 +92,13 @@ __device__ __forceinline__ float ex_row_bound(const ExactBound& eb, const ExactS
     return ok ? e : __builtin_nanf("");
 }
 
+// the float32 share of E(n): S (cA |x_n| wmax + cW wmax^2) -- twice what ONE float32 evaluation of a unit's score (the
+// kernel's k-ordered chain, or any other summation of the same D products) can be away from the real score, in d' units
+__device__ __forceinline__ float ex_f32_share(const ExactBound& eb, const ExactScales& s, float xsq) {
+    const float xn = __builtin_sqrtf(xsq) * (1.0f + 1.0f / 1024.0f);
+    return s.sx * s.sw * (eb.cA * xn * s.wm + eb.cW * s.wm * s.wm);
+}
+
 // |w~|^2 of every unit (bf16-rounded values) and its maximum over the codebook
 template <class EL = Bf16>
 __global__ __launch_bounds__(256) void prep_wnorm_kernel(const float* __restrict__ W, int K, int D,

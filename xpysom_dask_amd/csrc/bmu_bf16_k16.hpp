@@ -268,14 +268,18 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
 
     float run_min = __builtin_inff(), row_e = 0.0f;       // GM: lane l <-> row wave_s0 + l: its minimum so far, its bound E
     int run_arg = 0;                                      //     ... and the group (stage) that holds it
-    float run_cap = __builtin_inff();                     //     ... and the seed's cap on the keep threshold
+    float run_cap = __builtin_inff();                     //     ... and the seed's cap on what can be selected at all
     if (GM) {
         const long r = wave_s0 + lane;
         row_e = r < N ? ex_row_bound(eb, ex_scales(xmax2, wmax2, werr2), xsq[r], xerr[r]) : __builtin_nanf("");
         if (!(row_e == row_e)) row_e = __builtin_inff();   // a row the bound does not cover: keep everything (the scan drops it)
-        // seed (exact_seed_kernel): an upper bound on what the screen will hold for ONE unit of the row's choice (last
-        // epoch's BMU), known before the scan: no group minimum above it + E can be selected, whatever the minimum so far
-        if (seed != nullptr && r < N) { const float sd = seed[r]; if (sd == sd) run_cap = sd; }
+        // seed (exact_seed_kernel): d'(t) + E/2 for the float32 score t of ONE unit of the row's choice (last epoch's BMU),
+        // known before the scan.  A unit that beats that one in the float32 kernel has a screen value of at most seed +
+        // the float32 share of E (exact_select_kernel applies the same cap): no group minimum above it is ever selected
+        if (seed != nullptr && r < N) {
+            const float sd = seed[r] + ex_f32_share(eb, ex_scales(xmax2, wmax2, werr2), xsq[r]);
+            if (sd == sd) run_cap = sd;
+        }
     }
     // this workgroup's share of the codebook stages
     const int s_begin = (int)((long)n_stages * blockIdx.y / gridDim.y);
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
             auto c = __builtin_amdgcn_permlane32_swap(t01, t23, false, false);
             const uint32_t full = min(c[0], c[1]);         // quads: (v0, v1, v2, v3), each over all four quads
             const float f = __uint_as_float(full);         // (positive, or a NaN pattern: compares false, never kept)
-            const bool keep = f <= __builtin_fminf(run_min, run_cap) + row_e;
+            const bool keep = f <= __builtin_fminf(run_min + row_e, run_cap);
             if (f < run_min) run_arg = stage;              // (the group that holds the row minimum: the first re-score round)
             run_min = __builtin_fminf(run_min, f);
             if (keep) gmin[(long)stage * gm_stride + wave_s0 + lane] = full;

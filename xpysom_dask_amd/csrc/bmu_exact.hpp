@@ -93,7 +93,8 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_select_kernel(const 
                                                                          const float* __restrict__ werr2,
                                                                          int* __restrict__ plist, int* __restrict__ gcount,
                                                                          int* __restrict__ rowcnt,
-                                                                         const int* __restrict__ rowarg = nullptr) {
+                                                                         const int* __restrict__ rowarg = nullptr,
+                                                                         const float* __restrict__ seed = nullptr) {
     __shared__ int cnt_s[EX_SCAN_SPLIT][64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const long row0 = (long)blockIdx.x * 64;
@@ -118,6 +119,10 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_select_kernel(const 
         arg = rowarg[r];
     } else {
         thr_f = __uint_as_float((uint32_t)(best64[r] >> 32)) + e;
+        // seed (exact_seed_kernel): d'(t) + E/2 of one unit's float32 score t, computed outside the float32 kernel: whoever
+        // beats that unit THERE scores at most t + twice a float32 evaluation's error, so its screen value is at most
+        // seed + the float32 share of E -- often half the two-unit window m + E
+        if (seed != nullptr) thr_f = __builtin_fminf(thr_f, seed[r] + ex_f32_share(eb, sc, xsq[r]));
     }
     // a threshold that is not a finite positive number (a row the bound does not cover, a NaN minimum) selects nothing
     const bool ok = live && thr_f > 0.0f && thr_f < 3.0e38f;
@@ -191,9 +196,11 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_select_kernel(const 
 
 // seed[n] = an upper bound on the screen value of unit u = prev[n] (any unit: last epoch's BMU is the useful choice) for row
 // n, from the float32 operands: t = |w_u|^2 - 2 x.w_u in float32 (a 16-lane fma tree: its error is within the float32
-// kernel's share of the bound), d'(t) + E/2 as in the second re-score round.  The screen keeps a group minimum only if it
-// is within E of min(minimum so far, seed): on a trained map the seed IS about the row minimum, and the groups passed on
-// the way down to it -- most of what a smooth map makes the screen store and the select kernel read -- are never written.
+// kernel's share of the bound), d'(t) + E/2 as in the second re-score round.  Whatever beats unit u in the float32 kernel
+// has a screen value of at most seed + the float32 share of E: the screen stores no group minimum above that and the
+// select kernel selects none -- on a trained map the seed IS about the row minimum, and the groups passed on the way down
+// to it (most of what a smooth map makes the screen store and the select kernel read) are never written, and the
+// two-unit window m + E shrinks towards the one-unit E/2 around a float32 reference.
 // Euclidean, input_len <= 128; 16 lanes per row.
 __global__ __launch_bounds__(256) void exact_seed_kernel(const float* __restrict__ X, long N, int D,
                                                          const float* __restrict__ W, const float* __restrict__ wsq, int K,

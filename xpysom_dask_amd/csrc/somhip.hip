@@ -1100,7 +1100,7 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         } else {
             exact_select_kernel<false><<<sel_grid, sel_block, 0, h->stream>>>(
                 ex.gmin, ex.gflags, ex.stride, n_groups, n, best, xsq + r0, h->wmax2, xmax2, eb, xerr + r0, h->wmax2 + 1, ex.plist,
-                ex.ctr, ex.rowcnt);
+                ex.ctr, ex.rowcnt, nullptr, ex.seed_live ? ex.seed : nullptr);
             if (int rc = exact_rescore_round(h, X + r0 * h->D, xsq + r0, best, nullptr, nullptr)) return rc;
         }
         exact_finalize_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(
