@@ -1,4 +1,4 @@
-"""precision='exact' (csrc/bmu_exact.hpp): the BMUs of the float32 parity kernel, bit for bit, through the split-bf16
+"""precision='exact' (csrc/bmu_exact.hpp): the BMUs of the float32 parity kernel, bit for bit, through the IEEE-half MFMA
 screen + float32 re-score.  The checker here is the float32 kernel itself (whose own parity with the reference is
 pinned by tests/test_gpu_parity.py): every test demands IDENTICAL ids, never "near".  GPU only (`-m gpu`)."""
 import numpy as np
@@ -109,7 +109,7 @@ def test_exact_ties_and_degenerate_rows():
 
 
 def test_exact_near_ties_below_the_screen_resolution():
-    """Units that differ from each other by a few float32 ulps: far below what the split-bf16 screen resolves, so the
+    """Units that differ from each other by a few float32 ulps: far below what the half-precision screen resolves, so the
     re-score decides every row, and it must decide as the float32 kernel does."""
     rng = np.random.RandomState(4)
     X, Y, D, n = 16, 16, 64, 3000
