@@ -134,6 +134,8 @@ struct som_handle {
         int *kA = nullptr, *kB = nullptr;        // keys of the level-1 / level-2 lists (ping-pong from there on)
         float *vA = nullptr, *vB = nullptr;      // their vectors [entries][D1p]
         long cap = 0;                            // rows this scratch serves
+        int* cs_table = nullptr;                 // counting sort (small maps): [K][blocks of 1 024 rows] counts, then [K] totals
+        long cs_blocks = 0;
     };
     SegScratch seg;                              // resident rows
     float* xsq = nullptr;
@@ -182,6 +184,7 @@ struct som_handle {
     int vf_cap = 0;
     int64_t verify_launches = 0, verify_rows_checked = 0;
     bool fuse_merge_prep = true; // SOM_FUSE_MERGE=0: separate merge and operand-preparation launches (A/B)
+    bool counting_sort = true;   // SOM_COUNTING_SORT=0: rocPRIM's sort on small maps too (A/B)
     // read once in som_create (experiments / A-B runs): forced part counts, launch-geometry printing
     int env_bf16_parts = 0, env_f32_parts = 0;
     bool debug = false;
@@ -1258,7 +1261,7 @@ hipError_t sort_bmu_pairs_storage(size_t& bytes, K* kin, K* kout, V* vin, V* vou
 // ---- update path: segment sum + separable neighbourhood transform --------------------------
 // SC[b] += sum of the rows whose BMU is b (and their count): sort by BMU, chunked register sums
 void seg_free(som_handle::SegScratch& sg) {
-    void* b[] = {sg.iota, sg.skey, sg.srow, sg.tmp, sg.kA, sg.kB, sg.vA, sg.vB};
+    void* b[] = {sg.iota, sg.skey, sg.srow, sg.tmp, sg.kA, sg.kB, sg.vA, sg.vB, sg.cs_table};
     for (void* p : b) if (p) (void)hipFree(p);
     sg = som_handle::SegScratch();
 }
@@ -1284,6 +1287,12 @@ int seg_reserve(som_handle* h, som_handle::SegScratch& sg, long rows) {
     if (int rc = dev_alloc(h, &sg.vA, (size_t)n1 * h->D1p)) return rc;
     if (int rc = dev_alloc(h, &sg.kB, (size_t)n2)) return rc;
     if (int rc = dev_alloc(h, &sg.vB, (size_t)n2 * h->D1p)) return rc;
+    // small maps: the counting sort's table (update.hpp); SOM_COUNTING_SORT=0 keeps rocPRIM's sort (A/B)
+    const long csb = cdiv(rows, CS_BLOCK);
+    if (h->counting_sort && h->K <= CS_MAX_K && rows >= 2 * CS_BLOCK && csb * h->K <= (1L << 21)) {
+        if (int rc = dev_alloc(h, &sg.cs_table, (size_t)(csb + 1) * h->K)) return rc;
+        sg.cs_blocks = csb;
+    }
     sg.cap = rows;
     return 0;
 }
@@ -1314,8 +1323,20 @@ int segsum_rows(som_handle* h, const float* X, const int* bmu, long N, som_handl
         if (N > sg.cap) return fail(h, "segment sum: scratch smaller than the row set");
         int bits = 1;
         while ((1L << bits) < h->K) ++bits;
-        hipError_t e = sort_bmu_pairs(N, sg.tmp, sg.tmp_bytes, bmu, sg.skey, sg.iota, sg.srow, (size_t)N, 0u, (unsigned)bits, h->stream);
-        if (e != hipSuccess) return fail_hip(h, "rocprim::radix_sort_pairs", e);
+        const int B = (int)cdiv(N, CS_BLOCK);
+        if (sg.cs_table != nullptr && B <= sg.cs_blocks && N >= 2 * CS_BLOCK) {
+            // few units: a stable counting sort in three launches (same order as the radix sort: unit, then row)
+            int* tot = sg.cs_table + (long)B * h->K;
+            const size_t lds = (size_t)h->K * sizeof(int);
+            cs_hist_kernel<<<dim3((unsigned)B), dim3(256), lds, h->stream>>>(bmu, N, h->K, B, sg.cs_table);
+            cs_scan_kernel<<<dim3((unsigned)cdiv(h->K, 4)), dim3(256), 0, h->stream>>>(sg.cs_table, h->K, B, tot);
+            cs_scatter_kernel<<<dim3((unsigned)B), dim3(CS_BLOCK), lds, h->stream>>>(bmu, N, h->K, B, bits, sg.cs_table, tot, sg.skey,
+                                                                                    sg.srow);
+            HIPCHK(h, hipGetLastError());
+        } else {
+            hipError_t e = sort_bmu_pairs(N, sg.tmp, sg.tmp_bytes, bmu, sg.skey, sg.iota, sg.srow, (size_t)N, 0u, (unsigned)bits, h->stream);
+            if (e != hipSuccess) return fail_hip(h, "rocprim::radix_sort_pairs", e);
+        }
         const int acc = zero_first ? 0 : 1;
         long blocks = launch_runsum<true>(h, X, sg.skey, sg.srow, nullptr, N, acc, sg.kA, sg.vA);
         int *kin = sg.kA, *kout = sg.kB;
@@ -1643,6 +1664,7 @@ int som_create(const som_config* cfg, som_handle** out) {
         if (const char* e = std::getenv("SOM_EXACT_SEED")) h->ex.seed_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_ASYNC_COPIES")) h->async_copies = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_FUSE_MERGE")) h->fuse_merge_prep = std::atoi(e) != 0;
+        if (const char* e = std::getenv("SOM_COUNTING_SORT")) h->counting_sort = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_SORT_ONESWEEP_ROWS")) SORT_ONESWEEP_ROWS = std::atol(e);
         // a 128-row block of a table already spans most of a map side up to 256: nothing to skip there
         h->use_bands = h->X > 256 || h->Y > 256;

@@ -52,6 +52,97 @@ __global__ __launch_bounds__(256) void iota_kernel(int* __restrict__ v, long n) 
     if (i < n) v[i] = (int)i;
 }
 
+// ---- stable counting sort of the rows by BMU for maps of at most CS_MAX_K units ------------------------------------
+// (sorted by unit, rows ascending inside a unit: exactly what the stable radix sort returns, so the run sum adds in the same
+// fixed order.)  rocPRIM's merge sort takes six to seven launches at 100 000 rows (55 us of a 0.4 ms epoch at 64 x 64 x 32);
+// with few units a histogram per 1 024-row block is small: table[unit][block], three launches.
+//   cs_hist_kernel     block = 1 024 rows: LDS histogram of its units -> table[k * B + block]
+//   cs_scan_kernel     wave per unit: exclusive scan of its B block counts in place, the unit's total -> tot[k]
+//   cs_scatter_kernel  block = 1 024 rows: first destination of every (unit, block) = scan of tot over the units + the block's
+//                      prefix; the block's 16 waves take their turns in order, a wave ranks its rows among equal units by
+//                      ballots over the unit's bits (lower lane = lower row first)
+constexpr int CS_MAX_K = 8192;        // units (LDS: 4 bytes per unit)
+constexpr int CS_BLOCK = 1024;        // rows per block
+
+__global__ __launch_bounds__(256) void cs_hist_kernel(const int* __restrict__ bmu, long N, int K, int B, int* __restrict__ table) {
+    extern __shared__ int cs_lds[];
+    for (int k = threadIdx.x; k < K; k += 256) cs_lds[k] = 0;
+    __syncthreads();
+    const long r0 = (long)blockIdx.x * CS_BLOCK;
+#pragma unroll
+    for (int q = 0; q < CS_BLOCK / 256; ++q) {
+        const long r = r0 + q * 256 + threadIdx.x;
+        if (r < N) atomicAdd(&cs_lds[bmu[r]], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 256) table[(long)k * B + blockIdx.x] = cs_lds[k];
+}
+
+__global__ __launch_bounds__(256) void cs_scan_kernel(int* __restrict__ table, int K, int B, int* __restrict__ tot) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (k >= K) return;
+    int* t = table + (long)k * B;
+    int carry = 0;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int b = b0 + lane;
+        const int v = b < B ? t[b] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+        if (b < B) t[b] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) tot[k] = carry;
+}
+
+__global__ __launch_bounds__(CS_BLOCK) void cs_scatter_kernel(const int* __restrict__ bmu, long N, int K, int B, int bits,
+                                                             const int* __restrict__ table, const int* __restrict__ tot,
+                                                             int* __restrict__ skey, int* __restrict__ srow) {
+    extern __shared__ int cs_lds[];                        // base[K]: next destination of every unit for this block
+    __shared__ int wsum[CS_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // exclusive scan of tot over the units (every block does it: K <= 8 192), + this block's prefix inside the unit
+    const int per = (K + CS_BLOCK - 1) / CS_BLOCK;         // units per thread, consecutive
+    const int k0 = tid * per;
+    int mine = 0;
+    for (int i = 0; i < per; ++i) if (k0 + i < K) mine += tot[k0 + i];
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    int run = before + incl - mine;
+    for (int i = 0; i < per; ++i)
+        if (k0 + i < K) { cs_lds[k0 + i] = run + table[(long)(k0 + i) * B + blockIdx.x]; run += tot[k0 + i]; }
+    __syncthreads();
+    const long r = (long)blockIdx.x * CS_BLOCK + tid;
+    const bool live = r < N;
+    const int key = live ? bmu[r] : 0;
+    // the lanes of this wave with the same unit
+    unsigned long long peers = __ballot(live);
+    for (int b = 0; b < bits; ++b) {
+        const unsigned long long m = __ballot((key >> b) & 1);
+        peers &= ((key >> b) & 1) ? m : ~m;
+    }
+    const int leader = live ? (int)__builtin_ctzll(peers) : lane;
+    const int rank = (int)__builtin_popcountll(peers & ((1ull << lane) - 1));
+    const int count = (int)__builtin_popcountll(peers);
+    int dest = 0;
+    for (int w = 0; w < CS_BLOCK / 64; ++w) {              // waves in row order: the sort is stable
+        if (wave == w) {
+            int old = 0;
+            if (live && lane == leader) { old = cs_lds[key]; cs_lds[key] = old + count; }
+            old = __shfl(old, leader, 64);
+            dest = old + rank;
+        }
+        __syncthreads();
+    }
+    if (live) { skey[dest] = key; srow[dest] = (int)r; }
+}
+
 __host__ __device__ inline int seg_waves_per_block(int D1p) {
     int nw = SEG_MAX_WAVES;
     while (nw > 1 && (long)2 * nw * (D1p + 1) * 4 > 64 * 1024) nw >>= 1;
