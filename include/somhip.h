@@ -88,6 +88,7 @@ typedef struct som_config {
     void*   stream;              /* hipStream_t to launch on; NULL = the library creates its own */
     int32_t topology;            /* SOM_TOPO_* */
     int32_t norm_p;              /* exponent p of SOM_DIST_NORM_P* (activation_distance_kwargs={'p': ...}); 0 = default 2 */
+    double  norm_p_real;         /* a non-integer exponent p > 0 (distances.py:61-75 takes any real p); 0 = norm_p holds it */
 } som_config;
 
 const char* som_version(void);

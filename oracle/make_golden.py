@@ -588,6 +588,26 @@ def g18():
 FAMILIES = {"g17": g17, "g18": g18, "g1": g1, "g2": g2, "g3": g3, "g4": g4_g5_g7, "g6": g6, "g8": g8, "g9": g9, "g10": g10, "g11": g11,
             "g12": g12, "g13": g13, "g14": g14, "g15": g15, "g16": g16}
 
+# ---------------------------------------------------------------- G19 norm_p with a real exponent
+def g19():
+    """`norm_p` / `norm_p_no_opt` take any real p (distances.py:61-75: np.power of the float32 |x - w|): the reference's
+    winners on g9's trained map for p = 0.5, 1.5, 2.5, 3.7 and the distance matrix of a small block."""
+    g = np.load(os.path.join(OUT, "g9_inference.npz"))
+    X, Y, D = 16, 12, 10
+    probe = gaussian_blobs(700, D, seed=int(g["probe_seed"]))
+    out = {}
+    for p in (0.5, 1.5, 2.5, 3.7):
+        for name in ("norm_p", "norm_p_no_opt"):
+            s2 = RefSom(X, Y, D, random_seed=5, activation_distance=name, activation_distance_kwargs={"p": p}, xp=np)
+            s2._weights = g["w"]
+            out["win_%s_p%s" % (name, str(p).replace(".", "_"))] = ref_winner_ids(s2, probe)
+        out["dist_p%s" % str(p).replace(".", "_")] = rdist.norm_p_power_distance(
+            probe[:40].astype(F32), g["w"].reshape(-1, D)[:60].astype(F32), p=p, xp=np).astype(F32)
+    save("g19_norm_p_real", **out, probe_seed=g["probe_seed"])
+
+
+FAMILIES["g19"] = g19
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     with contextlib.redirect_stdout(io.StringIO()) as _:

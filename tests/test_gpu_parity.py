@@ -1468,6 +1468,29 @@ def test_linear_schedule_ending_at_sigma_zero_with_mexican_hat_raises_like_the_r
 
 
 
+def test_g19_norm_p_with_a_real_exponent():
+    """`norm_p` with p = 0.5, 1.5, 2.5, 3.7 (distances.py:61-75): the reference's winners; a pick may differ from the
+    reference's only on a float32 near-tie (the device's pow is float64 pow rounded once, glibc's powf is < 1 ulp)."""
+    from xpysom_dask_amd import XPySom
+    g = load_golden("g19_norm_p_real")
+    g9 = load_golden("g9_inference")
+    probe = O.gaussian_blobs(700, 10, seed=int(g["probe_seed"]))
+    w = g9["w"].reshape(-1, 10).astype(np.float64)
+    for p in (0.5, 1.5, 2.5, 3.7):
+        tag = str(p).replace(".", "_")
+        for name in ("norm_p", "norm_p_no_opt"):
+            som = XPySom(16, 12, 10, random_seed=5, activation_distance=name, activation_distance_kwargs={"p": p})
+            som._weights = g9["w"]
+            ids = np.array([i * 12 + j for i, j in som.winner(probe)])
+            ref = g["win_%s_p%s" % (name, tag)]
+            diff = np.flatnonzero(ids != ref)
+            assert len(diff) <= 2, (name, p, len(diff))
+            if len(diff):
+                d = (np.abs(probe[diff].astype(np.float64)[:, None, :] - w[None, :, :]) ** p).sum(2)
+                gap = d[np.arange(len(diff)), ids[diff]] - d.min(1)
+                assert (gap <= 1e-5 * d.min(1)).all(), (name, p, gap)
+
+
 # ----------------------------------------------------------------------------- G17 / G18: wide shapes pinned by the reference
 @pytest.mark.parametrize("decay", ["linear", "exponential"])
 @pytest.mark.parametrize("precision", ["f32", "exact", "bf16", "bf16x3"])

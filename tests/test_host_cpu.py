@@ -168,10 +168,11 @@ def test_constructor_refuses_what_the_engine_would_refuse():
     for dist in ("manhattan", "norm_p", "norm_p_no_opt", "euclidean_no_opt"):
         with pytest.raises(ValueError, match="needs precision='f32'"):
             XPySom(5, 5, 3, activation_distance=dist, precision="bf16")
-    for p in (1.5, 0.5, 0, 17, "2"):
+    for p in (0, 17, "2", -1.5, 0.0, float("nan"), float("inf"), 64.5):
         with pytest.raises(NotImplementedError, match="norm_p"):
             XPySom(5, 5, 3, activation_distance="norm_p", activation_distance_kwargs={"p": p})
-    XPySom(5, 5, 3, activation_distance="norm_p", activation_distance_kwargs={"p": 3.0})
+    for p in (3.0, 1.5, 0.5, np.float32(2.5), 63.5):     # integers as floats, and real exponents (distances.py:61-75)
+        XPySom(5, 5, 3, activation_distance="norm_p", activation_distance_kwargs={"p": p})
     XPySom(5, 5, 3, activation_distance="norm_p_no_opt")
 
 

@@ -470,3 +470,19 @@ def test_g18_bmus_256x256x128(state):
     assert zlib.crc32(np.ascontiguousarray(w).tobytes()) == int(g[state + "_w_crc"])
     ids = O.winner_ids(data[:1024], w, n_parallel=1024)          # (a quarter of the rows: 8.6 GFLOP on the CPU)
     assert (ids != g[state + "_bmu"][:1024]).sum() <= 2
+
+
+def test_g19_norm_p_with_a_real_exponent():
+    """distances.py:61-75 takes any real p: the oracle's generic form against the reference's winners and a distance block."""
+    g = load_golden("g19_norm_p_real")
+    g9 = load_golden("g9_inference")
+    D = 10
+    probe = O.gaussian_blobs(700, D, seed=int(g["probe_seed"]))
+    w = g9["w"].reshape(-1, D).astype(F32)
+    for p in (0.5, 1.5, 2.5, 3.7):
+        tag = str(p).replace(".", "_")
+        d = O.dist_norm_p_generic(probe[:40].astype(F32), w[:60], p)
+        assert np.array_equal(d.astype(F32), g["dist_p" + tag])
+        ids = O.bmu_ids_pairwise(probe, w, "norm_p", p)
+        assert np.array_equal(ids, g["win_norm_p_p" + tag])
+        assert np.array_equal(ids, g["win_norm_p_no_opt_p" + tag])

@@ -21,7 +21,7 @@ class SomConfig(C.Structure):
                 ("distance", C.c_int32), ("neighborhood", C.c_int32),
                 ("compact_support", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32),
                 ("std_coeff", C.c_double), ("stream", C.c_void_p),
-                ("topology", C.c_int32), ("norm_p", C.c_int32)]
+                ("topology", C.c_int32), ("norm_p", C.c_int32), ("norm_p_real", C.c_double)]
 
 
 _F = C.POINTER(C.c_float)

@@ -33,31 +33,37 @@ __device__ __forceinline__ float np_ipow_f32(float v, int q) {
     return (float)acc;
 }
 
+// v^p for a real exponent (activation_distance_kwargs={'p': 2.5}): NumPy's float32 power is the C library's powf, which is
+// correctly rounded in all but rare cases; so is float64 pow rounded once to float32
+__device__ __forceinline__ float np_rpow_f32(float v, double pr) { return (float)pow((double)v, pr); }
+// pr != 0: the real exponent; else the integer one
+__device__ __forceinline__ float np_pow_f32(float v, int p, double pr) { return pr != 0.0 ? np_rpow_f32(v, pr) : np_ipow_f32(v, p); }
+
 // sum_{d<n} |x_d - w_d|^p in NumPy's float32 pairwise order (cf. np_pairwise_sq_sum in bmu_f32.hpp)
-__device__ float np_pairwise_absdiff_pow(const float* __restrict__ x, const float* __restrict__ w, int n, int p) {
+__device__ float np_pairwise_absdiff_pow(const float* __restrict__ x, const float* __restrict__ w, int n, int p, double pr) {
     if (n < 8) {
         float res = 0.0f;
-        for (int i = 0; i < n; ++i) res = __fadd_rn(res, np_ipow_f32(__builtin_fabsf(__fsub_rn(x[i], w[i])), p));
+        for (int i = 0; i < n; ++i) res = __fadd_rn(res, np_pow_f32(__builtin_fabsf(__fsub_rn(x[i], w[i])), p, pr));
         return res;
     }
     if (n <= 128) {
         float r[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = np_ipow_f32(__builtin_fabsf(__fsub_rn(x[j], w[j])), p);
+        for (int j = 0; j < 8; ++j) r[j] = np_pow_f32(__builtin_fabsf(__fsub_rn(x[j], w[j])), p, pr);
         int i = 8;
         for (; i < n - (n % 8); i += 8) {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                r[j] = __fadd_rn(r[j], np_ipow_f32(__builtin_fabsf(__fsub_rn(x[i + j], w[i + j])), p));
+                r[j] = __fadd_rn(r[j], np_pow_f32(__builtin_fabsf(__fsub_rn(x[i + j], w[i + j])), p, pr));
         }
         float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
                               __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
-        for (; i < n; ++i) res = __fadd_rn(res, np_ipow_f32(__builtin_fabsf(__fsub_rn(x[i], w[i])), p));
+        for (; i < n; ++i) res = __fadd_rn(res, np_pow_f32(__builtin_fabsf(__fsub_rn(x[i], w[i])), p, pr));
         return res;
     }
     int n2 = n / 2;
     n2 -= n2 % 8;
-    return __fadd_rn(np_pairwise_absdiff_pow(x, w, n2, p), np_pairwise_absdiff_pow(x + n2, w + n2, n - n2, p));
+    return __fadd_rn(np_pairwise_absdiff_pow(x, w, n2, p, pr), np_pairwise_absdiff_pow(x + n2, w + n2, n - n2, p, pr));
 }
 
 // sum_e (-1)^e C(p,e) dot(x^(p-e), w^e), float64 accumulation of float32 terms.  All p+1 dot
@@ -87,7 +93,7 @@ __device__ double norm_p_even(const float* __restrict__ x, const float* __restri
 template <int KIND>
 __global__ __launch_bounds__(PW_SAMPLES) void bmu_pairwise_kernel(const float* __restrict__ X, long N, int D,
                                                                   const float* __restrict__ W, int K, int p,
-                                                                  int x_in_lds, int* __restrict__ out) {
+                                                                  int x_in_lds, int* __restrict__ out, double pr = 0.0) {
     extern __shared__ __attribute__((aligned(16))) float smem_pw[];
     float* Ws = smem_pw;                       // [PW_UNITS][D]
     float* Xs = Ws + PW_UNITS * D;             // [PW_SAMPLES][D+1] when x_in_lds
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(PW_SAMPLES) void bmu_pairwise_kernel(const float* _
         const int nu = (K - u0 < PW_UNITS) ? (K - u0) : PW_UNITS;
         for (int r = 0; r < nu; ++r) {
             const float* w = Ws + r * D;
-            double v = KIND == PW_EVEN ? norm_p_even(x, w, D, p) : (double)np_pairwise_absdiff_pow(x, w, D, p);
+            double v = KIND == PW_EVEN ? norm_p_even(x, w, D, p) : (double)np_pairwise_absdiff_pow(x, w, D, p, pr);
             if (v < best) { best = v; bidx = u0 + r; }
         }
     }

@@ -100,6 +100,7 @@ struct som_handle {
     int nt = 1;              // neighbourhood terms
     bool swapped = false;    // mexican_hat + compact_support, rectangular: row stage, mask, column stage (update.hpp)
     int norm_p = 2;          // exponent of the norm_p distances
+    double norm_pr = 0.0;    // ... when it is not an integer (0: norm_p)
     hipStream_t stream = nullptr;
     bool own_stream = false;
 
@@ -823,6 +824,8 @@ int merge_prep_half(som_handle* h) {
 }
 
 int launch_bmu_pairwise(som_handle* h, const float* X, long N, int p, bool even, int* out) {
+    const double pr = h->norm_pr;                        // (a real exponent: the generic form, whatever `even` says)
+    if (pr != 0.0) even = false;
     size_t w_bytes = (size_t)PW_UNITS * h->D * sizeof(float);
     size_t x_bytes = (size_t)PW_SAMPLES * (h->D + 1) * sizeof(float);
     int x_in_lds = w_bytes + x_bytes <= 150 * 1024;
@@ -835,7 +838,7 @@ int launch_bmu_pairwise(som_handle* h, const float* X, long N, int p, bool even,
         bmu_pairwise_kernel<PW_EVEN><<<dim3((unsigned)grid), dim3(PW_SAMPLES), lds, h->stream>>>(X, N, h->D, h->W, h->K, p, x_in_lds, out);
     } else {
         { int pc; if (int rc = kernel_per_cu(h, (const void*)bmu_pairwise_kernel<PW_GENERIC>, PW_SAMPLES, lds, &pc)) return rc; }
-        bmu_pairwise_kernel<PW_GENERIC><<<dim3((unsigned)grid), dim3(PW_SAMPLES), lds, h->stream>>>(X, N, h->D, h->W, h->K, p, x_in_lds, out);
+        bmu_pairwise_kernel<PW_GENERIC><<<dim3((unsigned)grid), dim3(PW_SAMPLES), lds, h->stream>>>(X, N, h->D, h->W, h->K, p, x_in_lds, out, pr);
     }
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -1550,6 +1553,8 @@ int som_create(const som_config* cfg, som_handle** out) {
     if ((long)cfg->x * cfg->y > (1L << 30)) return fail(nullptr, "som_create: map too large");
     if (cfg->distance < 0 || cfg->distance > SOM_DIST_NORM_P_NO_OPT) return fail(nullptr, "som_create: unknown distance id");
     if (cfg->norm_p < 0 || cfg->norm_p > PW_MAX_P) return fail(nullptr, "som_create: norm_p out of range (1..16)");
+    if (cfg->norm_p_real != 0.0 && !(cfg->norm_p_real > 0.0 && cfg->norm_p_real <= 64.0))
+        return fail(nullptr, "som_create: norm_p_real out of range (0 < p <= 64)");
     if (cfg->distance >= SOM_DIST_MANHATTAN && cfg->precision != SOM_PREC_F32 && cfg->precision != SOM_PREC_EXACT)
         return fail(nullptr, "som_create: manhattan / norm_p distances are float32 VALU kernels (precision f32)");
     if (cfg->neighborhood < 0 || cfg->neighborhood > SOM_NEIGH_TRIANGLE)
@@ -1589,6 +1594,7 @@ int som_create(const som_config* cfg, som_handle** out) {
     h->X = cfg->x; h->Y = cfg->y; h->K = cfg->x * cfg->y; h->D = cfg->input_len;
     h->D1p = (int)round_up(h->D + 1, 4);
     h->norm_p = cfg->norm_p > 0 ? cfg->norm_p : 2;
+    if (cfg->norm_p_real != 0.0 && (cfg->distance == SOM_DIST_NORM_P || cfg->distance == SOM_DIST_NORM_P_NO_OPT)) h->norm_pr = cfg->norm_p_real;
     h->ks32 = (int)cdiv(h->D, 32);
     h->x3 = cfg->precision == SOM_PREC_BF16X3 || cfg->precision == SOM_PREC_F16X3;
     h->f16 = cfg->precision == SOM_PREC_F16 || cfg->precision == SOM_PREC_F16X3 || h->exact;   // (the exact mode's screen: IEEE half)

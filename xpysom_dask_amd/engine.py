@@ -22,7 +22,7 @@ def _f32(a):
 class HipEngine:
     def __init__(self, x, y, input_len, *, distance="euclidean", neighborhood="gaussian",
                  std_coeff=0.5, compact_support=False, precision="f32", device=0, stream=None,
-                 topology="rectangular", norm_p=0):
+                 topology="rectangular", norm_p=0, norm_p_real=0.0):
         self._lib = _lib.load()
         self._h = None
         self.K, self.D = int(x) * int(y), int(input_len)
@@ -32,7 +32,7 @@ class HipEngine:
         cfg = _lib.SomConfig(int(x), int(y), int(input_len), _lib.SOM_DIST[distance],
                              _lib.SOM_NEIGH[neighborhood], int(bool(compact_support)),
                              _lib.SOM_PREC[precision], int(device), float(std_coeff),
-                             C.c_void_p(stream) if stream else None, _lib.SOM_TOPO[topology], int(norm_p))
+                             C.c_void_p(stream) if stream else None, _lib.SOM_TOPO[topology], int(norm_p), float(norm_p_real))
         h = C.c_void_p()
         if self._lib.som_create(C.byref(cfg), C.byref(h)) != 0:
             raise SomHipError(self._lib.som_last_error(None).decode())

@@ -157,10 +157,15 @@ class XPySom:
                              "'%s' needs precision='f32'" % (precision, activation_distance))
         if activation_distance.startswith('norm_p'):
             p = activation_distance_kwargs.get('p', 2)
-            if not isinstance(p, (int, np.integer)) and not (isinstance(p, float) and p.is_integer()):
-                raise NotImplementedError("norm_p: the HIP kernels take an integer exponent p, got %r" % (p,))
-            if not 1 <= int(p) <= 16:
-                raise NotImplementedError("norm_p: exponent p must be in 1..16, got %r" % (p,))
+            if isinstance(p, (int, np.integer)) or (isinstance(p, (float, np.floating)) and float(p).is_integer()):
+                if not 1 <= int(p) <= 16:
+                    raise NotImplementedError("norm_p: an integer exponent p must be in 1..16, got %r" % (p,))
+            elif isinstance(p, (float, np.floating)):
+                # a real exponent (distances.py:61-75 takes any p): the generic |x - w|^p form
+                if not (np.isfinite(p) and 0.0 < float(p) <= 64.0):
+                    raise NotImplementedError("norm_p: a real exponent p must be in (0, 64], got %r" % (p,))
+            else:
+                raise NotImplementedError("norm_p: the exponent p must be a number, got %r" % (p,))
 
         # n_parallel bounded the (n,K) temporaries of the reference (xpysom.py:242-251); nothing of
         # that size exists here, it only sizes host->device staging of winner()/quantization_error().
@@ -181,7 +186,11 @@ class XPySom:
                       std_coeff=self._std_coeff, compact_support=self.compact_support,
                       precision=self._precision, topology=self.topology)
             if self._activation_distance_name.startswith('norm_p'):
-                kw['norm_p'] = int(self._activation_distance_kwargs.get('p', 2))
+                p = self._activation_distance_kwargs.get('p', 2)
+                if isinstance(p, (float, np.floating)) and not float(p).is_integer():
+                    kw['norm_p'], kw['norm_p_real'] = 2, float(p)
+                else:
+                    kw['norm_p'] = int(p)
             from . import engine
             dev = self._device
             if dev is None:
