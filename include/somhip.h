@@ -199,6 +199,10 @@ int som_epoch_accumulate_forced(som_handle* h, const int32_t* bmu_host, double s
 int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, int32_t* ids_out);
 /* best and second-best unit per row under the full Euclidean distance (sqrt + nan_to_num):
  * what XPySom.topographic_error takes from argsort(distances)[:, :2], xpysom.py:727-734 */
+/* float64 query rows (XPySom.winner does not coerce its input, xpysom.py:379-396: float64 x against float32 weights is
+ * computed in float64 by NumPy): the BMUs of fl64(-2 x.w + |w|^2_f32), euclidean activation distance only.  An analysis
+ * call on the vector ALU; rows are staged through device memory as doubles. */
+int som_bmu_f64(som_handle* h, const double* x_host, int64_t n_rows, int32_t* ids_out);
 int som_bmu_top2(som_handle* h, const float* x_host, int64_t n_rows, int32_t* ids1_out, int32_t* ids2_out);
 /* the (n_rows, K) distance matrix itself, row-major, for the analysis calls that return it:
  * mode ACTIVATION = XPySom.activate (xpysom.py:323-354, configured GEMM-form distance),

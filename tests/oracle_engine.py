@@ -80,6 +80,10 @@ class OracleEngine:
             return O.quantization_ids(np.asarray(x, np.float32), W3).astype(np.int32)
         return O.winner_ids(np.asarray(x, np.float32), W3, self.kw["distance"]).astype(np.int32)
 
+    def bmu_f64(self, x):
+        """float64 rows against the float32 codebook: NumPy's own float64 arithmetic (xpysom.py:379-396)."""
+        return O.winner_ids(np.asarray(x, np.float64), self.W.reshape(self.x, self.y, self.D), self.kw["distance"]).astype(np.int32)
+
     def quantization_error(self, x):
         return O.quantization_error(x, self.W.reshape(self.x, self.y, self.D))
 

@@ -1468,6 +1468,31 @@ def test_linear_schedule_ending_at_sigma_zero_with_mexican_hat_raises_like_the_r
 
 
 
+def test_winner_on_float64_rows_uses_float64_arithmetic():
+    """xpysom.py:379-396 does not coerce x: float64 rows against trained float32 weights are scored in float64 by NumPy.  The
+    reference's own answer (G9 `winner64`) must come back, in the float32 mode and in the exact mode; and on rows built to
+    make the two arithmetics disagree, the float64 path agrees with a float64 evaluation where the float32 one does not."""
+    from xpysom_dask_amd import XPySom
+    g = load_golden("g9_inference")
+    probe = O.gaussian_blobs(700, 10, seed=int(g["probe_seed"]))
+    for precision in ("f32", "exact"):
+        som = XPySom(16, 12, 10, random_seed=5, precision=precision)
+        som._weights = g["w"]
+        ids = np.array([i * 12 + j for i, j in som.winner(probe.astype(np.float64))])
+        assert np.array_equal(ids, g["winner64"]), precision
+        assert som.winner(probe[3].astype(np.float64)) == tuple(int(v) for v in divmod(int(g["winner64"][3]), 12))
+    # near-ties only float64 resolves: two units at almost the same distance from x
+    rs = np.random.RandomState(2)
+    w = rs.randn(8, 8, 6).astype(F32)
+    x = ((w[2, 3].astype(np.float64) + w[5, 1].astype(np.float64)) / 2)[None, :] + 1e-9 * rs.randn(200, 6)
+    som = XPySom(8, 8, 6, random_seed=1)
+    som._weights = w
+    ids64 = np.array([i * 8 + j for i, j in som.winner(x)])
+    wf = w.reshape(-1, 6).astype(np.float64)
+    want = np.argmin(-2 * x @ wf.T + (w.reshape(-1, 6) ** 2).sum(1).astype(np.float64)[None, :], axis=1)
+    assert np.array_equal(ids64, want)
+
+
 def test_g19_norm_p_with_a_real_exponent():
     """`norm_p` with p = 0.5, 1.5, 2.5, 3.7 (distances.py:61-75): the reference's winners; a pick may differ from the
     reference's only on a float32 near-tie (the device's pow is float64 pow rounded once, glibc's powf is < 1 ulp)."""

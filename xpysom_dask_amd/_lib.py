@@ -64,6 +64,7 @@ SIGNATURES = {
     "som_epoch_accumulate_forced": (C.c_int, [_H, _I, C.c_double, C.c_double, C.c_int]),
     "som_bmu": (C.c_int, [_H, _F, C.c_int64, C.c_int32, _I]),
     "som_bmu_top2": (C.c_int, [_H, _F, C.c_int64, _I, _I]),
+    "som_bmu_f64": (C.c_int, [_H, C.POINTER(C.c_double), C.c_int64, _I]),
     "som_distance_matrix": (C.c_int, [_H, _F, C.c_int64, C.c_int32, _F]),
     "som_quantization_error": (C.c_int, [_H, _F, C.c_int64, C.POINTER(C.c_double)]),
     "som_set_verify": (C.c_int, [_H, C.c_int32]),

@@ -128,4 +128,38 @@ __global__ __launch_bounds__(PW_SAMPLES) void bmu_pairwise_kernel(const float* _
     if (live) out[row] = bidx;
 }
 
+// float64 query rows against the float32 codebook: XPySom.winner() does not coerce its input (xpysom.py:379-396), so a
+// float64 x makes NumPy compute -2 x.w^T + w_sq in float64 (dgemm on the upcast weights, the float32 w_sq promoted):
+//   score(n, k) = fl64(-2 c + |w_k|^2_f32),  c = the k-ordered float64 fma chain of x_n . w_k,
+// first minimum in unit order.  An analysis path (vector ALU, one thread per row, 16-unit LDS tiles).
+__global__ __launch_bounds__(PW_SAMPLES) void bmu_f64_kernel(const double* __restrict__ X, long N, int D,
+                                                             const float* __restrict__ W, const float* __restrict__ wsq,
+                                                             int K, int* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem_pw[];
+    float* Ws = smem_pw;                       // [PW_UNITS][D]
+    const int tid = threadIdx.x;
+    const long row = (long)blockIdx.x * PW_SAMPLES + tid;
+    const bool live = row < N;
+    const double* x = X + (live ? row : 0) * (long)D;
+    double best = __builtin_inf();
+    int bidx = 0;
+    for (int u0 = 0; u0 < K; u0 += PW_UNITS) {
+        __syncthreads();
+        for (int idx = tid; idx < PW_UNITS * D; idx += PW_SAMPLES) {
+            const int r = idx / D, k = idx - r * D;
+            Ws[idx] = (u0 + r < K) ? W[(long)(u0 + r) * D + k] : 0.0f;
+        }
+        __syncthreads();
+        const int nu = (K - u0 < PW_UNITS) ? (K - u0) : PW_UNITS;
+        for (int r = 0; r < nu; ++r) {
+            const float* w = Ws + r * D;
+            double c = 0.0;
+            for (int d = 0; d < D; ++d) c = __builtin_fma(x[d], (double)w[d], c);
+            const double v = __builtin_fma(-2.0, c, (double)wsq[u0 + r]);
+            if (v < best) { best = v; bidx = u0 + r; }
+        }
+    }
+    if (live) out[row] = bidx;
+}
+
 }  // namespace somhip

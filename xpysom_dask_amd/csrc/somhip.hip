@@ -147,6 +147,7 @@ struct som_handle {
 
     // scratch for som_bmu / som_quantization_error
     float* qX = nullptr; int* qbmu = nullptr; int* qbmu2 = nullptr; float* qxsq = nullptr; __bf16* qXb = nullptr;
+    double* qX64 = nullptr; size_t qX64_cap = 0;   // som_bmu_f64: float64 query rows
     long qcap = 0;
     double* dsum = nullptr;
     // streamed epochs (rows that do not stay resident): per-chunk sort scratch, grown on demand
@@ -1726,7 +1727,7 @@ void som_destroy(som_handle* h) {
     for (auto& ep : h->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     void* bufs[] = {h->Ud, h->W, h->wsq, h->SC, h->T, h->ACC, h->P1, h->P2, h->Wst, h->X_owned, h->bmu, h->xsq, h->Xb,
                     h->xmax2, h->wn, h->wmax2, h->qX, h->qbmu, h->qbmu2, h->qxsq, h->qXb, h->dsum,
-                    h->best64, h->Wfst, h->Wfimg, h->ftX};
+                    h->best64, h->Wfst, h->Wfimg, h->ftX, h->qX64};
     for (void* b : bufs) if (b) (void)hipFree(b);
     seg_free(h->seg);
     seg_free(h->st_seg);
@@ -2295,6 +2296,32 @@ int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, in
         if (h->cfg.precision != SOM_PREC_F32)
             if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1, h->qxsq)) return rc;
         if (int rc = run_activation_bmu(h, h->qX, n_rows, h->qxsq, h->qXb, h->xmax2 + 1, h->qbmu)) return rc;
+    }
+    return d2h_blocking(h, ids_out, h->qbmu, (size_t)n_rows * sizeof(int));
+}
+
+int som_bmu_f64(som_handle* h, const double* x_host, int64_t n_rows, int32_t* ids_out) {
+    DeviceGuard dev_guard(h);
+    if (!h || n_rows < 0 || (n_rows > 0 && (!x_host || !ids_out))) return fail(h, "som_bmu_f64: bad argument");
+    if (h->cfg.distance != SOM_DIST_EUCLIDEAN) return fail(h, "som_bmu_f64: the float64 query path serves the 'euclidean' activation distance");
+    if (n_rows == 0) return 0;
+    const size_t w_bytes = (size_t)PW_UNITS * h->D * sizeof(float);
+    if (w_bytes > 150 * 1024) return fail(h, "som_bmu_f64: input_len too large for the LDS unit tile");
+    if (int rc = ensure_query_scratch(h, n_rows)) return rc;
+    if ((size_t)n_rows * h->D > h->qX64_cap) {
+        (void)hipFree(h->qX64);
+        h->qX64 = nullptr; h->qX64_cap = 0;
+        const size_t cap = (size_t)round_up(n_rows, 1024) * h->D;
+        if (int rc = dev_alloc(h, &h->qX64, cap)) return rc;
+        h->qX64_cap = cap;
+    }
+    if (int rc = h2d_blocking(h, h->qX64, x_host, (size_t)n_rows * h->D * sizeof(double))) return rc;
+    if (int rc = refresh_codebook_operands(h, true)) return rc;       // |w|^2 in NumPy's float32 order
+    {
+        Timed t(h, SOM_K_BMU);
+        bmu_f64_kernel<<<dim3((unsigned)cdiv(n_rows, PW_SAMPLES)), dim3(PW_SAMPLES), w_bytes, h->stream>>>(
+            h->qX64, n_rows, h->D, h->W, h->wsq, h->K, h->qbmu);
+        HIPCHK(h, hipGetLastError());
     }
     return d2h_blocking(h, ids_out, h->qbmu, (size_t)n_rows * sizeof(int));
 }

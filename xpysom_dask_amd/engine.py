@@ -232,6 +232,15 @@ class HipEngine:
         self._check(self._lib.som_bmu(self._h, self._fp(x), x.shape[0], mode, self._ip(ids)))
         return ids
 
+    def bmu_f64(self, x):
+        """BMUs of float64 rows under the float64 arithmetic NumPy applies to them (som_bmu_f64: euclidean only)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.ndim != 2 or x.shape[1] != self.D:
+            raise ValueError("x must be (n, %d), got %r" % (self.D, x.shape))
+        ids = np.empty((x.shape[0],), dtype=np.int32)
+        self._check(self._lib.som_bmu_f64(self._h, x.ctypes.data_as(C.POINTER(C.c_double)), x.shape[0], self._ip(ids)))
+        return ids
+
     def bmu_top2(self, x):
         """(best, second-best) raveled ids under the full Euclidean distance."""
         x = _f32(x)

@@ -377,11 +377,23 @@ class XPySom:
     def winner(self, x):
         """Coordinates of the winning neuron(s): ``(i, j)`` for one sample, a list of
         ``(i, j)`` tuples (numpy.int64) for a matrix -- xpysom.py:370-408."""
+        # the reference does not coerce x (xpysom.py:379-396): float64 rows against trained (float32) weights are scored in
+        # float64 by NumPy.  Served for the 'euclidean' distance in the float32-exact modes; elsewhere x is taken as float32
+        x64 = None
+        if (isinstance(x, np.ndarray) and x.dtype == np.float64 and np.asarray(self._weights).dtype == np.float32
+                and self._activation_distance_name == 'euclidean' and self._precision in ('f32', 'exact')):
+            x64 = x
         x = _host_rows(x, self._engine)
         one = x.ndim == 1
         if one:
             x = x[None, :]
-        ids = self._winner_ids(x).astype(np.int64)
+        if x64 is not None:
+            x64 = x64[None, :] if one else x64
+            eng = self._upload_weights()
+            ids = np.concatenate([eng.bmu_f64(x64[s:s + self._n_parallel])
+                                  for s in range(0, len(x64), self._n_parallel)]).astype(np.int64) if len(x64) else np.zeros(0, np.int64)
+        else:
+            ids = self._winner_ids(x).astype(np.int64)
         wi, wj = np.divmod(ids, self._weights.shape[1])
         if one:
             return (wi[0].item(), wj[0].item())
