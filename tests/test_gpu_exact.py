@@ -359,3 +359,40 @@ def test_exact_one_round_and_two_round_rescore_agree_with_float32(monkeypatch, t
         assert np.array_equal(r["exact"][1], r["f32"][1])
         rows, fb, _ = r["exact"][4]
         assert rows >= n and fb <= n // 20
+
+
+@pytest.mark.parametrize("seed_on", ["1", "0"])
+def test_exact_seeded_epochs_return_the_float32_bmus(monkeypatch, seed_on):
+    """From the second epoch on resident rows the screen and the select kernel are capped by a seed computed from last epoch's
+    BMUs (exact_seed_kernel).  Any ids give a valid cap: after ordinary merges, after a codebook that moved every unit
+    somewhere else, and after set_data with other rows, every epoch's BMUs are the float32 kernel's."""
+    monkeypatch.setenv("SOM_EXACT_SEED", seed_on)
+    X, Y, D, n = 48, 48, 64, 9000
+    data = O.gaussian_blobs(n, D, seed=3)
+    other = O.gaussian_blobs(n, D, seed=4)[::-1].copy()
+    w = O.smooth_sheet_codebook(X, Y, D, seed=6).astype(F32)
+    eng = {p: engine(X, Y, D, precision=p) for p in ("f32", "exact")}
+    for e in eng.values():
+        e.set_weights(w)
+        e.set_data(data)
+    def step(sigma, eta):
+        ids = {}
+        for p, e in eng.items():
+            e.epoch_accumulate(sigma, eta, True)
+            ids[p] = e.epoch_fetch()[2]
+        assert np.array_equal(ids["exact"], ids["f32"])
+    for sigma in (12.0, 8.0, 4.0):                                     # ordinary epochs: merge, next epoch
+        step(sigma, 0.4)
+        for e in eng.values():
+            e.epoch_merge()
+    for e in eng.values():                                             # every unit somewhere else
+        e.set_weights(w[::-1, ::-1].copy() * F32(1.7))
+    step(6.0, 0.3)
+    for e in eng.values():                                             # other rows: the old ids mean nothing
+        e.set_data(other)
+    step(6.0, 0.3)
+    step(3.0, 0.3)
+    rows, fb, _ = eng["exact"].exact_stats()
+    assert rows == 6 * n and fb <= rows // 50
+    for e in eng.values():
+        e.close()
