@@ -396,3 +396,16 @@ def test_exact_seeded_epochs_return_the_float32_bmus(monkeypatch, seed_on):
     assert rows == 6 * n and fb <= rows // 50
     for e in eng.values():
         e.close()
+
+
+def test_exact_falls_back_to_smaller_passes_when_the_scratch_is_refused(monkeypatch):
+    """A device that cannot give a pass its scratch (here: the test hook refuses anything above 2 500 rows) gets passes of half
+    the rows, and half again, instead of an error; the BMUs are the float32 kernel's either way."""
+    monkeypatch.setenv("SOM_EXACT_DEBUG_REFUSE_ABOVE", "2500")
+    X, Y, D, n = 32, 32, 24, 9000
+    data = O.gaussian_blobs(n, D, seed=12)
+    w = O.default_codebook(X, Y, D, 3).astype(F32)
+    r = both(X, Y, D, w, data)
+    assert np.array_equal(r["exact"][0], r["f32"][0]) and np.array_equal(r["exact"][1], r["f32"][1])
+    rows, fb, passes = r["exact"][4]
+    assert passes >= 4 + 1                                   # 9 000 rows in passes of 2 304, + the 777-row query

@@ -87,6 +87,7 @@ struct som_handle {
         int* fb_count_host = nullptr;        // pinned
         int64_t rows_total = 0, rows_fallback = 0, chunks = 0;   // som_exact_stats
         long pass_rows_override = 0;
+        long stride_cap = 0;              // rows per pass the device had memory for (0: no allocation was ever refused)
         long pairs = 64;                  // capacity of a pass: (row, group) pairs per row on average (exact_reserve)
     } ex;
     int n_kchunks = 0;       // tiled: 64-feature chunks
@@ -891,10 +892,31 @@ long exact_chunk_rows(const som_handle* h) {
 // (the screens write group minima and row masks for whole workgroup tiles: a pass's row stride must hold them)
 static_assert(256 % K16_WG_SAMPLES == 0 && 256 % WD_WG_SAMPLES == 0 && K16_WG_SAMPLES % 64 == 0 && WD_WG_SAMPLES % 64 == 0,
               "exact: the pass stride (a multiple of 256 rows) must be a whole number of screen workgroup tiles");
+int exact_reserve_stride(som_handle* h, long stride);
+
+// the pass scratch for `rows` rows: as large a pass as the 4 GiB rule allows -- and, where the device cannot give that much
+// (other handles, other processes on the card), passes of half the rows, and half again: smaller passes cost a few
+// percent, a refused allocation costs the run
 int exact_reserve(som_handle* h, long rows) {
     auto& ex = h->ex;
-    const long stride = round_up(std::min(rows, exact_chunk_rows(h)), 256);
+    long stride = round_up(std::min(rows, exact_chunk_rows(h)), 256);
+    if (ex.stride_cap > 0) stride = std::min(stride, ex.stride_cap);
     if (stride <= ex.stride) return 0;
+    for (;;) {
+        const int rc = exact_reserve_stride(h, stride);
+        if (rc == 0) return 0;
+        if (stride <= 1024) return rc;                   // (the message of the last failed allocation stands)
+        (void)hipGetLastError();
+        stride = round_up(stride / 2, 256);
+        ex.stride_cap = stride;                          // launch_bmu_exact walks passes of this many rows from now on
+        if (h->debug) std::fprintf(stderr, "[somhip] exact: pass scratch refused, retrying with passes of %ld rows\n", stride);
+    }
+}
+
+int exact_reserve_stride(som_handle* h, long stride) {
+    auto& ex = h->ex;
+    // TEST HOOK (tests/test_gpu_exact.py): behave as a device that refuses the scratch of passes above n rows
+    if (const char* e = std::getenv("SOM_EXACT_DEBUG_REFUSE_ABOVE")) if (stride > std::atol(e)) return fail(h, "exact: pass scratch refused (test hook)");
     void* old[] = {ex.gmin, ex.gflags, ex.rowcnt, ex.rowarg, ex.seed, ex.fb_list, ex.plist, ex.tile_tab};
     for (void* p : old) if (p) (void)hipFree(p);
     ex.gmin = nullptr; ex.gflags = nullptr; ex.rowcnt = nullptr; ex.rowarg = nullptr; ex.seed = nullptr; ex.fb_list = nullptr; ex.plist = nullptr; ex.tile_tab = nullptr;
