@@ -409,3 +409,23 @@ def test_exact_falls_back_to_smaller_passes_when_the_scratch_is_refused(monkeypa
     assert np.array_equal(r["exact"][0], r["f32"][0]) and np.array_equal(r["exact"][1], r["f32"][1])
     rows, fb, passes = r["exact"][4]
     assert passes >= 4 + 1                                   # 9 000 rows in passes of 2 304, + the 777-row query
+
+
+@pytest.mark.parametrize("X,Y,D,n", [(512, 512, 64, 20000), (1024, 256, 17, 9000)])
+def test_exact_on_maps_of_a_quarter_million_units(X, Y, D, n):
+    """4 096 groups on the resident screen (configs[4]'s map size with short rows): the per-group lists, the tile table and the
+    stored-row masks at their largest; two epochs (the second one seeded), random and smooth codebook."""
+    data = O.gaussian_blobs(n, D, seed=5)
+    for w in (O.default_codebook(X, Y, D, 3).astype(F32), O.smooth_sheet_codebook(X, Y, D, seed=2).astype(F32)):
+        ids = {}
+        for p in ("f32", "exact"):
+            e = engine(X, Y, D, precision=p)
+            e.set_weights(w)
+            e.set_data(data)
+            e.epoch_accumulate(20.0, 0.4, True)
+            b1 = e.epoch_fetch()[2]
+            e.epoch_merge()
+            e.epoch_accumulate(10.0, 0.3, True)
+            ids[p] = (b1, e.epoch_fetch()[2])
+            e.close()
+        assert np.array_equal(ids["exact"][0], ids["f32"][0]) and np.array_equal(ids["exact"][1], ids["f32"][1])
