@@ -85,6 +85,7 @@ struct som_handle {
         float* fbX = nullptr;                // fallback rows, dense, for the float32 kernel
         long fb_cap = 0;
         int* fb_count_host = nullptr;        // pinned
+        hipEvent_t fb_ready = nullptr;       // recorded behind the counter's copy
         int64_t rows_total = 0, rows_fallback = 0, chunks = 0;   // som_exact_stats
         long pass_rows_override = 0;
         long stride_cap = 0;              // rows per pass the device had memory for (0: no allocation was ever refused)
@@ -125,6 +126,9 @@ struct som_handle {
     long N = 0, Np = 0;
     int* bmu = nullptr;
     bool bmu_valid = false;  // bmu holds the ids of a completed BMU pass over the resident rows
+    // precision 'exact': the update-side work that does not depend on the BMUs (the zeroed segment sums, the neighbourhood
+    // tables) is queued BEFORE the pass's counter read-back, so the GPU has it to do while the host wakes up
+    struct EarlyUpdate { bool armed = false, done = false; double sigma = 0, eta = 0; int neigh_f64 = 0; } early;
     unsigned long long* best64 = nullptr;   // bf16 path: per-row (value bits | unit) merged across codebook parts
     long best64_cap = 0;
     int n_cus = 0;
@@ -1077,6 +1081,8 @@ int exact_rescore_round(som_handle* h, const float* X, const float* xsq, unsigne
     return rc;
 }
 
+int build_tables(som_handle* h, double sigma, double eta, int neigh_f64, hipStream_t st);
+
 // X, xsq, Xb, out: the row set's float32 rows, their |x|^2, their hi / lo operand image, the ids to write.
 int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, const __bf16* Xb, const float* xmax2, int* out) {
     if (h->capturing) return fail(h, "precision 'exact' reads a counter back per pass: not capturable");
@@ -1137,7 +1143,18 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         HIPCHK(h, hipGetLastError());
         // rows the scheme could not settle (normally none): the float32 kernel itself
         HIPCHK(h, hipMemcpyAsync(ex.fb_count_host, ex.ctr + 2 * n_groups, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->early.armed && !h->early.done && out == h->bmu && r0 + n >= N) {
+            // the last pass of a resident epoch: the host waits for the counter only (an event behind the copy); what the
+            // update needs besides the BMUs is queued behind it and runs while the host wakes up
+            if (!ex.fb_ready) HIPCHK(h, hipEventCreateWithFlags(&ex.fb_ready, hipEventDisableTiming));
+            HIPCHK(h, hipEventRecord(ex.fb_ready, h->stream));
+            HIPCHK(h, hipMemsetAsync(h->SC, 0, (size_t)h->K * (h->D1p + 1) * sizeof(float), h->stream));
+            if (int rc = build_tables(h, h->early.sigma, h->early.eta, h->early.neigh_f64, h->stream)) return rc;
+            h->early.done = true;
+            HIPCHK(h, hipEventSynchronize(ex.fb_ready));
+        } else {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
         const int n_fb = *ex.fb_count_host;
         ex.rows_total += n; ex.rows_fallback += n_fb; ex.chunks += 1;
         if (n_fb < 0 || n_fb > n) return fail(h, "exact: fallback counter out of range");
@@ -1344,7 +1361,8 @@ long launch_runsum(som_handle* h, const float* X, const int* keys, const int* sr
 // every unit is written once (plain stores); otherwise the chunk's sums are added to what SC holds.
 int segsum_rows(som_handle* h, const float* X, const int* bmu, long N, som_handle::SegScratch& sg, bool zero_first) {
     Timed t(h, SOM_K_SEGSUM);
-    if (zero_first) HIPCHK(h, hipMemsetAsync(h->SC, 0, (size_t)h->K * (h->D1p + 1) * sizeof(float), h->stream));
+    if (zero_first && !(h->early.done && X == h->Xd))   // (exact mode: already zeroed before the pass's read-back)
+        HIPCHK(h, hipMemsetAsync(h->SC, 0, (size_t)h->K * (h->D1p + 1) * sizeof(float), h->stream));
     if (N > 0) {
         if (N > sg.cap) return fail(h, "segment sum: scratch smaller than the row set");
         int bits = 1;
@@ -1451,7 +1469,8 @@ void launch_leftmul(som_handle* h, const float* H, int Ro, int Ri, const float* 
 int run_transform_stage1(som_handle* h, double sigma, double eta, int neigh_f64) {
     // (built on this stream: handing them to a side stream under the BMU kernel was measured -- the two event
     //  waits cost more than the 7 us kernel, epoch 1.058 vs 1.035 ms at 65 536 rows)
-    if (int rc = build_tables(h, sigma, eta, neigh_f64, h->stream)) return rc;
+    if (!h->early.done)                                  // (exact mode: built before the pass's read-back)
+        if (int rc = build_tables(h, sigma, eta, neigh_f64, h->stream)) return rc;
     const int nyb = (int)cdiv(h->Y, LM_BM);
     const int2* bands1 = h->use_bands ? h->bands : nullptr;             // [nt][nyb]
     const long slab = (long)h->Y * h->D1p;
@@ -1761,6 +1780,7 @@ void som_destroy(som_handle* h) {
         void* eb[] = {h->ex.gmin, h->ex.gflags, h->ex.rowcnt, h->ex.rowarg, h->ex.seed, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab};
         for (void* b : eb) if (b) (void)hipFree(b);
         if (h->ex.fb_count_host) (void)hipHostFree(h->ex.fb_count_host);
+        if (h->ex.fb_ready) (void)hipEventDestroy(h->ex.fb_ready);
     }
     for (auto& sl : h->slot) {
         void* sb[] = {sl.dX, sl.dXb, sl.dxsq, sl.dbmu};
@@ -1871,8 +1891,13 @@ int som_copy_to_host(som_handle* h, const void* x_dev, uint64_t bytes, void* dst
 namespace {
 
 int epoch_accumulate_eager(som_handle* h, double sigma, double eta, int neigh_f64) {
-    if (int rc = run_activation_bmu(h, h->Xd, h->N, h->xsq, h->Xb, h->xmax2, h->bmu)) return rc;
-    return run_update(h, sigma, eta, neigh_f64);
+    h->early = som_handle::EarlyUpdate();
+    h->early.armed = h->exact && !h->capturing && h->N > 0;
+    h->early.sigma = sigma; h->early.eta = eta; h->early.neigh_f64 = neigh_f64;
+    int rc = run_activation_bmu(h, h->Xd, h->N, h->xsq, h->Xb, h->xmax2, h->bmu);
+    if (rc == 0) rc = run_update(h, sigma, eta, neigh_f64);
+    h->early = som_handle::EarlyUpdate();
+    return rc;
 }
 
 void drop_graph(som_handle* h) {
