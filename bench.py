@@ -170,16 +170,25 @@ def pmc_traffic(workload, rows, precision, kernel, build_hash):
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks as CHILD processes of a parent
     that never touches the GPU (no exec from a GPU-initialised process), relay their output, return their code."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes on this host driver)
     env.setdefault("OMP_NUM_THREADS", "4")
-    return subprocess.call(cmd, env=env)
+    rc = 1
+    for attempt in range(3):
+        # a free port, asked for and given back: somebody else can take it before the launcher's store listens there
+        # (EADDRINUSE, seen once in ~100 launches).  A launch that dies within seconds is tried again on another port.
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        t0 = time.time()
+        rc = subprocess.call(cmd, env=env)
+        if rc == 0 or time.time() - t0 > 20.0:
+            break
+        print("bench.py: the launcher exited with %d after %.1f s; trying another port" % (rc, time.time() - t0), file=sys.stderr)
+    return rc
 
 
 def main():

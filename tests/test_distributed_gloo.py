@@ -27,7 +27,9 @@ def _worker(rank, world, port, sharded_input, out_dir, overlap="0"):
     from xpysom_dask_amd import distributed as D
     from xpysom_dask_amd import engine
     engine.HipEngine = OracleEngine                     # test double in THIS worker process only (no GPU here)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # (a file rendezvous: a TCP store on a port "asked for and given back" loses a race for it once in a few hundred runs)
+    dist.init_process_group("gloo", init_method="file://%s" % os.path.join(out_dir, "rendezvous_%d" % port), rank=rank,
+                            world_size=world)
     try:
         assert D.dist_info() == (rank, world)
         data = O.gaussian_blobs(601, 5, seed=11)

@@ -30,12 +30,21 @@ def _free_port():
     return p
 
 
+def _run_ranks(args, env, world, timeout):
+    """torch.distributed.run on a free port; a port asked for and given back can be taken by somebody else before the
+    launcher's store listens on it (EADDRINUSE): such a launch is repeated on another port."""
+    for attempt in range(3):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + args
+        r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
+        if "EADDRINUSE" not in r.stderr and "address already in use" not in r.stderr:
+            break
+    return r
+
+
 def _launch(backend, out_dir, mode, world=2, **extra_env):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", **extra_env)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(REPO, "tests", "dist_worker.py"), backend, str(out_dir), mode]
-    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    r = _run_ranks([os.path.join(REPO, "tests", "dist_worker.py"), backend, str(out_dir), mode], env, world, 600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-5000:]
 
 
@@ -125,9 +134,7 @@ def test_native_collective_with_two_ranks_on_one_gpu_fails_loudly(tmp_path):
     """SOM_COMM=native (RCCL inside libsomhip) needs one GPU per rank: two ranks on ONE card must end with an error from
     ncclCommInitRank on every rank -- promptly, not in a hang -- so that a mis-launched job says what is wrong."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", SOM_COMM="native")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(REPO, "tests", "dist_worker.py"), "gloo", str(tmp_path), "full"]
-    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=180)
+    r = _run_ranks([os.path.join(REPO, "tests", "dist_worker.py"), "gloo", str(tmp_path), "full"], env, 2, 180)
     out = r.stdout + r.stderr
     assert r.returncode != 0
     assert "ncclCommInitRank" in out or "SomHipError" in out, out[-3000:]
