@@ -610,11 +610,14 @@ def test_rccl_allreduce_runs_in_place_on_the_engine_buffer(tmp_path):
     import subprocess
     import sys
     from tests.conftest import REPO
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     script = tmp_path / "nccl_path.py"
     script.write_text(_NCCL_SCRIPT)
-    env = dict(os.environ, SOM_REPO=REPO, SOM_PORT=str(port))
-    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    for attempt in range(3):                                  # (a port given back can be taken before the store listens on it)
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        env = dict(os.environ, SOM_REPO=REPO, SOM_PORT=str(port))
+        r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+        if "EADDRINUSE" not in r.stderr and "address already in use" not in r.stderr:
+            break
     assert r.returncode == 0 and "nccl-path-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
