@@ -1049,6 +1049,29 @@ def test_banded_transform_is_bit_identical(monkeypatch, X, Y, neigh, topo, sigma
     assert np.array_equal(outs["0"][1], outs["1"][1])
 
 
+@pytest.mark.parametrize("X,Y,n", [(64, 64, 100000), (90, 91, 5000), (8, 8, 2048), (30, 30, 70001)])
+def test_counting_sort_by_bmu_equals_the_library_sort(monkeypatch, X, Y, n):
+    """Maps of <= 8192 units bucket the rows of an epoch by BMU with the in-tree stable counting sort
+    (cs_hist / cs_scan / cs_scatter, update.hpp) instead of rocPRIM's radix sort (SOM_COUNTING_SORT=0).
+    Both are stable, the segment sum adds a unit's rows in list order: numerator, denominator and BMUs
+    must be bitwise equal -- on clustered rows too, where a handful of units own every row."""
+    D = 7
+    data = O.gaussian_blobs(n, D, seed=X + n % 97)
+    data[: n // 3] = data[0]                                  # a third of the rows on one unit
+    w = O.default_codebook(X, Y, D, 4).astype(F32)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SOM_COUNTING_SORT", mode)
+        e = engine(X, Y, D)
+        e.set_weights(w)
+        e.set_data(data)
+        e.epoch_accumulate(3.0, 0.4, True)
+        num, den, bmu = e.epoch_fetch()
+        outs[mode] = (num.copy(), den.copy(), bmu.copy())
+    for a, b in zip(outs["0"], outs["1"]):
+        assert np.array_equal(a, b)
+
+
 # ----------------------------------------------------------------------------- rows already in HBM
 def test_train_accepts_device_resident_rows():
     """A torch CUDA tensor (what a CuPy array is to the reference, xpysom.py:487-510) is trained on in

@@ -60,7 +60,7 @@ def up_to_date():
 
 
 def build(force=False, verbose=True, extra=(), out=None):
-    """`extra`/`out` build experiment variants (e.g. -DSOM_K16_SB=8) next to the product library."""
+    """`extra`/`out` build experiment variants (e.g. -DSOM_STAMPS for tools/stamps.py) next to the product library."""
     if not force and not extra and up_to_date():
         return OUT
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

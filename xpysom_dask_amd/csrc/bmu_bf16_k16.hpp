@@ -21,19 +21,10 @@
 
 namespace somhip {
 
-#ifndef SOM_K16_T
-#define SOM_K16_T 4
-#endif
-constexpr int K16_T = SOM_K16_T;      // 16-unit tiles per stage
+constexpr int K16_T = 4;              // 16-unit tiles per stage
 constexpr int K16_STAGE_UNITS = 16 * K16_T;
-#ifndef SOM_K16_SB
-#define SOM_K16_SB 4
-#endif
-constexpr int K16_SB = SOM_K16_SB;    // 16-sample blocks per wave
-#ifndef SOM_K16_NW
-#define SOM_K16_NW 4
-#endif
-constexpr int K16_NW = SOM_K16_NW;    // waves per workgroup (they share one LDS ring)
+constexpr int K16_SB = 4;             // 16-sample blocks per wave
+constexpr int K16_NW = 4;             // waves per workgroup (they share one LDS ring)
 constexpr int K16_WG_SAMPLES = K16_NW * 16 * K16_SB;
 
 __host__ __device__ constexpr int k16_stage_bytes(int ks32) { return (K16_T * ks32 + 1) * 1024; }
@@ -211,9 +202,6 @@ __global__ __launch_bounds__(64 * KS32) void merge_prep_k16_kernel(float* __rest
     }
 }
 
-#ifndef SOM_K16_MINWAVES
-#define SOM_K16_MINWAVES 2
-#endif
 // GM (precision 'exact', bmu_exact.hpp): the kernel keeps VALUES only -- the row minimum (out64's upper half; no unit
 // indices exist in this instance, the float32 re-score names the unit) and, per stage (= one GROUP of 64 units) and row,
 // the group's minimum.  A lane holds its quad's minimum for each of the wave's 4 sample blocks; three v_permlane*_swap +
@@ -223,7 +211,7 @@ __global__ __launch_bounds__(64 * KS32) void merge_prep_k16_kernel(float* __rest
 // stage leaves the 64-bit mask of the lanes it stored in gflags[(row / 64) * n_stages + stage] -- on a random
 // codebook ~2 % of the matrix is written and read, on the smoothest maps 10-25 %.
 template <int KS32, class EL = Bf16, bool GM = false>
-__global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
+__global__ __launch_bounds__(64 * K16_NW, 2) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
                                                               const char* __restrict__ Wst, int n_stages, int K,
                                                               unsigned long long* __restrict__ out64,
                                                               uint32_t* __restrict__ gmin = nullptr, long gm_stride = 0,
@@ -288,15 +276,6 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
         lds_dma_16(Wst + (long)s_begin * STAGE + (long)p * 1024 + lane * 16, smem + p * 1024);
 
     auto reduce_tile = [&](const f32x4 (&acc)[K16_SB], int t16) {
-#if defined(SOM_K16_EXPERIMENT) && SOM_K16_EXPERIMENT == 1
-        // TIMING EXPERIMENT ONLY (wrong unit ids): value-only running minimum, 2 VALU per (tile, sample block)
-#pragma unroll
-        for (int sb = 0; sb < K16_SB; ++sb) {
-            cbest[sb] = min(min(cbest[sb], __float_as_uint(acc[sb][0])), __float_as_uint(acc[sb][1]));
-            cbest[sb] = min(min(cbest[sb], __float_as_uint(acc[sb][2])), __float_as_uint(acc[sb][3]));
-        }
-        return;
-#endif
         if (GM) {
             // the exact mode's screen needs VALUES only (the row minimum and the groups' minima): which unit holds
             // them is decided by the float32 re-score.  Two v_min3 per tile and sample block, no key packing.
@@ -309,9 +288,6 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
         }
 #pragma unroll
         for (int sb = 0; sb < K16_SB; ++sb) {
-#if defined(SOM_K16_EXPERIMENT) && SOM_K16_EXPERIMENT == 2
-            if (sb > 0) { cbest[sb] = min(cbest[sb], __float_as_uint(acc[sb][0])); continue; }   // TIMING EXPERIMENT ONLY
-#endif
             uint32_t key[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -375,9 +351,6 @@ __global__ __launch_bounds__(64 * K16_NW, SOM_K16_MINWAVES) void bmu_bf16_k16_ke
                 for (int ks = 0; ks < KS32; ++ks)
                     aN[ks] = *(const bf16x8*)(st + ((t16 + 1) * KS32 + ks) * 1024 + lane * 16);
             }
-#ifdef SOM_K16_SCHEDFENCE
-            __builtin_amdgcn_sched_barrier(0);            // experiment: keep the next tile's fragment reads up here
-#endif
             f32x4 accT[K16_SB];
 #pragma unroll
             for (int sb = 0; sb < K16_SB; ++sb) accT[sb] = wv;

@@ -18,15 +18,9 @@
 
 namespace somhip {
 
-#ifndef SOM_K3_T
-#define SOM_K3_T 2
-#endif
-#ifndef SOM_K3_SB
-#define SOM_K3_SB 2
-#endif
-constexpr int K3_T = SOM_K3_T;        // 16-unit tiles per stage
+constexpr int K3_T = 2;               // 16-unit tiles per stage
 constexpr int K3_STAGE_UNITS = 16 * K3_T;
-constexpr int K3_SB = SOM_K3_SB;      // 16-sample blocks per wave (hi + lo fragments: 64 VGPRs at 128 features)
+constexpr int K3_SB = 2;              // 16-sample blocks per wave (hi + lo fragments: 64 VGPRs at 128 features)
 constexpr int K3_NW = 4;              // waves per workgroup
 constexpr int K3_WG_SAMPLES = K3_NW * 16 * K3_SB;
 

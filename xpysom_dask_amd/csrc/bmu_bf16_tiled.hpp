@@ -21,9 +21,6 @@
 
 namespace somhip {
 
-#ifndef SOM_TILED_EXPERIMENT
-#define SOM_TILED_EXPERIMENT 0       // timing experiments only (wrong results): 1 = DMA sources never advance (all L2 hits), 2 = one reduction at the end
-#endif
 constexpr int TL_BK = 32;                      // features per stage = one MFMA k-step
 constexpr int TL_KS = TL_BK / 32;
 constexpr int TL_SLOTS = 4;                    // ring depth in stages (power of two)
@@ -196,9 +193,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, 2) void bmu_bf16_tiled_kernel(const
         char* dst = xring + slot_i * TL_TILE;
 #pragma unroll
         for (int i = 0; i < XPW; ++i) lds_dma_16(src + (wc + NG * i) * 1024, dst + (wc + NG * i) * 1024);
-#if SOM_TILED_EXPERIMENT != 1
         if (left_i > 1) { --left_i; if (++kc_i == n_kchunks) kc_i = 0; }
-#endif
         slot_i = (slot_i + 1) & (TL_SLOTS - 1);
     };
     auto issue_w = [&]() {
@@ -206,9 +201,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, 2) void bmu_bf16_tiled_kernel(const
 #pragma unroll
         for (int i = 0; i < WPW; ++i) lds_dma_16(wsrc + (wc + NG * i) * 1024, dst + (wc + NG * i) * 1024);
         if (lane < CIN_LANES) lds_dma_16(wsrc + TL_WFRAG + wc * CIN_BYTES, dst + TL_WFRAG + wc * CIN_BYTES);
-#if SOM_TILED_EXPERIMENT != 1
         if (left_i > 1) { --left_i; wsrc += TL_WTILE; }
-#endif
         slot_i = (slot_i + 1) & (TL_SLOTS - 1);
     };
 
@@ -270,9 +263,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, 2) void bmu_bf16_tiled_kernel(const
             // ---- LOAD(p): fragments to registers, next DMA, reduction of a finished unit block ----
             load_frags(slot, kc);
             if (G1) issue_w(); else issue_x();           // stage p+3 -> the slot stage p-1 was read from
-#if SOM_TILED_EXPERIMENT != 2
             if (done_ub >= 0) { reduce_block(done_ub); done_ub = -1; }
-#endif
             if (G1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LOADS_W) : "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();

@@ -225,9 +225,6 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
     }
 
     auto issue = [&](int s, int slot) {
-#if defined(SOM_WD_EXPERIMENT) && SOM_WD_EXPERIMENT == 1
-        s = s_begin + (s & 1);                               // TIMING EXPERIMENT ONLY (wrong results): every fetch an L2 hit
-#endif
         // (uniform base + a 32-bit lane offset: the scalar-base form of the load, no 64-bit address kept in registers)
         const char* src = Wst + (long)s * STAGE;
         const uint32_t lane16 = (uint32_t)lane * 16u;

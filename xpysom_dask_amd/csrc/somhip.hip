@@ -193,7 +193,7 @@ struct som_handle {
     bool fuse_merge_prep = true; // SOM_FUSE_MERGE=0: separate merge and operand-preparation launches (A/B)
     bool counting_sort = true;   // SOM_COUNTING_SORT=0: rocPRIM's sort on small maps too (A/B)
     // read once in som_create (experiments / A-B runs): forced part counts, launch-geometry printing
-    int env_bf16_parts = 0, env_f32_parts = 0;
+    int env_bf16_parts = 0;
     bool debug = false;
     // per kernel function: the dynamic-LDS attribute is set and the occupancy queried once, not per launch
     struct KernelSlots { const void* fn; size_t lds; int per_cu; };
@@ -464,7 +464,6 @@ int launch_bmu_f32_res_kg(som_handle* h, const float* X, long N, const float* xs
     if (!TOP2) {
         const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
         parts = choose_parts(h, grid, slots, h->fr_stages);
-        if (h->env_f32_parts > 0) parts = h->env_f32_parts;   // experiments
         if (parts > h->fr_stages) parts = h->fr_stages;
         if (h->debug)
             std::fprintf(stderr, "[somhip] bmu_f32_res: blocks=%ld per_cu=%d slots=%ld parts=%d stages=%d\n", grid, per_cu,
@@ -874,10 +873,6 @@ ExactBound exact_bound(const som_handle* h) {
         eb.cA = (float)(slop * (2.0 * gamma + 2.0 * u) * (1.0 + u));   // float32 kernel, relative to A (tau units)
         eb.cW = (float)(slop * u);
     }
-    if (const char* e = std::getenv("SOM_EXACT_BOUND_SCALE")) {   // experiments: how the candidate load grows with the band
-        const float f = (float)std::atof(e);
-        if (f > 1.0f) { eb.cA *= f; eb.cW *= f; eb.cB *= f; eb.cM *= f; }
-    }
     return eb;
 }
 
@@ -1283,7 +1278,7 @@ int row_sq(som_handle* h, const float* X, long N, float* out) {
 // 4-byte keys (ten merge passes at 1 Mi rows: 0.16 ms); two 8-bit Onesweep passes take half of that, but lose
 // to the merge sort at 100 k rows -- so Onesweep from SORT_ONESWEEP_ROWS rows on.
 using SortOnesweep = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 1024>;
-long SORT_ONESWEEP_ROWS = 262144;           // (SOM_SORT_ONESWEEP_ROWS overrides it: experiments)
+constexpr long SORT_ONESWEEP_ROWS = 262144;
 
 template <typename... Args>
 hipError_t sort_bmu_pairs(long n, Args... args) {
@@ -1641,12 +1636,10 @@ int som_create(const som_config* cfg, som_handle** out) {
     h->x3 = cfg->precision == SOM_PREC_BF16X3 || cfg->precision == SOM_PREC_F16X3;
     h->f16 = cfg->precision == SOM_PREC_F16 || cfg->precision == SOM_PREC_F16X3 || h->exact;   // (the exact mode's screen: IEEE half)
     h->x3res = h->x3 && h->D <= 128;
-    if (const char* e = std::getenv("SOM_X3_TILED")) if (std::atoi(e) != 0) h->x3res = false;   // A/B: the tiled split kernel
     h->tiled = ((cfg->precision == SOM_PREC_BF16 || cfg->precision == SOM_PREC_F16 || h->exact) && h->D > 128) || (h->x3 && !h->x3res);
     if (h->tiled) {
         // 256 x 256 tiles need enough units to amortise them; SOM_BF16_TILE=128|256 overrides
         h->tl_big = h->K >= 4096;
-        if (const char* e = std::getenv("SOM_BF16_TILE")) h->tl_big = std::atoi(e) == 256;
         if (h->tl_big) {
             using C = TileCfg<8, 2, 4>;
             h->tl_bm = C::BM; h->tl_bn = C::BN; h->tl_xtile = C::XTILE; h->tl_wfrag = C::WFRAG; h->tl_wtile = C::WTILE;
@@ -1704,7 +1697,6 @@ int som_create(const som_config* cfg, som_handle** out) {
         h->np_dev = npd;
         if (const char* e = std::getenv("SOM_GRAPH")) h->use_graph = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_BF16_PARTS")) h->env_bf16_parts = std::atoi(e);
-        if (const char* e = std::getenv("SOM_F32_PARTS")) h->env_f32_parts = std::atoi(e);
         h->debug = std::getenv("SOM_DEBUG") != nullptr;
         if (const char* e = std::getenv("SOM_VERIFY")) h->verify_rows = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("SOM_EXACT_PASS_ROWS")) h->ex.pass_rows_override = std::atol(e);
@@ -1713,7 +1705,6 @@ int som_create(const som_config* cfg, som_handle** out) {
         if (const char* e = std::getenv("SOM_ASYNC_COPIES")) h->async_copies = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_FUSE_MERGE")) h->fuse_merge_prep = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_COUNTING_SORT")) h->counting_sort = std::atoi(e) != 0;
-        if (const char* e = std::getenv("SOM_SORT_ONESWEEP_ROWS")) SORT_ONESWEEP_ROWS = std::atol(e);
         // a 128-row block of a table already spans most of a map side up to 256: nothing to skip there
         h->use_bands = h->X > 256 || h->Y > 256;
         if (const char* e = std::getenv("SOM_NO_BANDS")) h->use_bands = std::atoi(e) == 0;
