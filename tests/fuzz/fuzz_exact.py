@@ -27,6 +27,8 @@ for case in range(n_cases):
         D = int(rs.choice([129, 130, 160, 161, 200, 256, 257, 300, 512, 600, 784, 800]))
         n = int(rs.choice([1, 2, 31, 32, 33, 255, 256, 257, 1000, 2500]))
         dist = str(rs.choice(["euclidean", "cosine"]))
+    if rs.rand() < 0.5:                                      # map sides multiples of 8: the images in patch order
+        X, Y = 8 * ((X + 7) // 8), 8 * ((Y + 7) // 8)
     kind = str(rs.choice(["random", "random", "sheet", "sheet", "clusters"]))
     data = O.gaussian_blobs(n, D, seed=case)
     if kind == "random":

@@ -429,3 +429,66 @@ def test_exact_on_maps_of_a_quarter_million_units(X, Y, D, n):
             ids[p] = (b1, e.epoch_fetch()[2])
             e.close()
         assert np.array_equal(ids["exact"][0], ids["f32"][0]) and np.array_equal(ids["exact"][1], ids["f32"][1])
+
+
+# ----------------------------------------------------------------------------- patch order (map sides multiples of 8)
+def test_exact_patch_order_ties_prefer_the_lowest_unit(monkeypatch):
+    """On maps whose sides are multiples of 8 the exact mode's operand images hold the units patch by patch (8 x 8 units
+    of the map per 64-unit group, ex_patch_unit); the answer must not know: among equal scores the lowest UNIT id wins,
+    within a patch, across patches, and for rows the float32 fallback settles (several passes here, so that the float32
+    image changes order back and forth between them).  Small integers: every product exact, numpy float64 is the checker."""
+    monkeypatch.setenv("SOM_EXACT_PASS_ROWS", "1024")
+    rng = np.random.RandomState(2)
+    X, Y, D, n = 16, 24, 8, 3000
+    proto = rng.randint(-3, 4, size=(5, D)).astype(F32)
+    w = proto[rng.randint(0, 5, size=X * Y)]                              # five distinct units, scattered over all patches
+    data = rng.randint(-3, 4, size=(n, D)).astype(F32)
+    data[::7] = proto[rng.randint(0, 5, size=len(data[::7]))]             # rows ON units: a whole class of exact ties
+    want = (-2 * data.astype(np.float64) @ w.T.astype(np.float64) + (w.astype(np.float64) ** 2).sum(1)[None]).argmin(1)
+    data[100, 2] = np.nan; data[1500] = np.inf; data[2100, 1] = np.nan    # fallback rows in passes 0, 1 and 2
+    ok = np.ones(n, bool); ok[[100, 1500, 2100]] = False
+    r = both(X, Y, D, w.reshape(X, Y, D), data)
+    assert np.array_equal(r["f32"][0][ok], want[ok])
+    assert np.array_equal(r["exact"][0], r["f32"][0])
+    assert np.array_equal(r["exact"][1], r["f32"][1])
+    rows, fb, passes = r["exact"][4]
+    assert passes >= 4 and fb >= 3
+
+
+@pytest.mark.parametrize("X,Y,D,n,dist", [(64, 64, 32, 12000, "euclidean"), (16, 8, 128, 3000, "euclidean"),
+                                           (72, 64, 200, 3000, "cosine"), (64, 72, 133, 3000, "euclidean")])
+def test_exact_patch_order_equals_strip_order(monkeypatch, X, Y, D, n, dist):
+    """SOM_EXACT_PATCH=0 keeps the units' own order (a group = 64 units of a map row): same BMUs, same accumulators, on a
+    smooth map (where the patches save candidate groups) and in the analysis calls that run float32 kernels on the same
+    handle in between (top-2, the distance matrix: they want the float32 image in the units' own order)."""
+    from xpysom_dask_amd import XPySom
+    data = O.gaussian_blobs(n, D, seed=3)
+    if dist == "cosine":
+        data = np.abs(data)
+    som = XPySom(X, Y, D, sigma=min(X, Y) / 2.0, random_seed=1, precision="f32", activation_distance=dist)
+    som.train(data, 2)                                                    # a smooth early map
+    w = som._weights.astype(F32)
+    ref = engine(X, Y, D, precision="f32", distance=dist)
+    ref.set_weights(w); ref.set_data(data)
+    ref.epoch_accumulate(4.0, 0.3, True)
+    rnum, rden, rbmu = ref.epoch_fetch()
+    r1, r2 = ref.bmu_top2(data[:500])
+    counts = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SOM_EXACT_PATCH", mode)
+        e = engine(X, Y, D, precision="exact", distance=dist)
+        e.set_weights(w); e.set_data(data)
+        for _ in range(2):                                                # (the second epoch: seeded from the first one's BMUs)
+            e.epoch_accumulate(4.0, 0.3, True)
+            num, den, bmu = e.epoch_fetch()
+            assert np.array_equal(bmu, rbmu) and np.array_equal(num, rnum) and np.array_equal(den, rden)
+            t1, t2 = e.bmu_top2(data[:500])
+            assert np.array_equal(t1, r1) and np.array_equal(t2, r2)
+            assert np.array_equal(e.bmu(data[:700]), rbmu[:700])
+        counts[mode] = e.exact_last_counts(min(n, 700)).mean()
+        rows, fb, _ = e.exact_stats()
+        assert fb <= rows // 50
+        e.close()
+    ref.close()
+    if X >= 64:
+        assert counts["1"] < counts["0"]                                  # fewer candidate groups per row: the point of it

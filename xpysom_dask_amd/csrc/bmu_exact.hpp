@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_mfma_kernel(const float*
                                                                     const int4* __restrict__ tile_tab,
                                                                     const int* __restrict__ n_tiles_dev,
                                                                     const int* __restrict__ plist,
-                                                                    unsigned long long* __restrict__ best64) {
+                                                                    unsigned long long* __restrict__ best64, int patch_y) {
     constexpr int STAGE = fr_stage_bytes(KG);
     constexpr int PIECES = FR_UT * KG + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE stage: occupancy (three workgroups per CU), not a
@@ -402,7 +402,8 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_mfma_kernel(const float*
         if (half == 0 && row >= 0) {                      // (best == +inf: no unit of this group scored below it)
             const uint32_t bits = __float_as_uint(best);
             const uint32_t key = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
-            atomicMin(best64 + row, ((unsigned long long)key << 32) | (uint32_t)bidx);
+            // (patch order: positions ascend with the unit ids inside a group; across groups the merge compares UNITS)
+            atomicMin(best64 + row, ((unsigned long long)key << 32) | (uint32_t)ex_patch_unit(bidx, patch_y));
         }
     }
 }
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_tiled_kernel(const float
                                                                      const int4* __restrict__ tile_tab,
                                                                      const int* __restrict__ n_tiles_dev,
                                                                      const int* __restrict__ plist,
-                                                                     unsigned long long* __restrict__ best64) {
+                                                                     unsigned long long* __restrict__ best64, int patch_y) {
     __shared__ __attribute__((aligned(16))) char ring[2][8192];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_tiled_kernel(const float
         if (half == 0 && row >= 0) {
             const uint32_t bits = __float_as_uint(best);
             const uint32_t key = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
-            atomicMin(best64 + row, ((unsigned long long)key << 32) | (uint32_t)bidx);
+            atomicMin(best64 + row, ((unsigned long long)key << 32) | (uint32_t)ex_patch_unit(bidx, patch_y));
         }
     }
 }
@@ -724,6 +725,27 @@ __global__ __launch_bounds__(64) void debug_mfma16_kernel(const uint16_t* __rest
     const f32x4 d = mfma16(a, b, c);
 #pragma unroll
     for (int r = 0; r < 4; ++r) Dout[(quad * 4 + r) * 16 + col] = d[r];
+}
+
+// the codebook and its |w|^2 in patch order (ex_patch_unit): what the exact mode's operand images are prepared from
+__global__ __launch_bounds__(256) void exact_permute_kernel(const float* __restrict__ W, const float* __restrict__ wsq, int K,
+                                                            int D, int patch_y, float* __restrict__ Wp,
+                                                            float* __restrict__ wsq_p) {
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if ((D & 3) == 0) {
+        const int q = D >> 2;
+        if (id >= (long)K * q) return;
+        const int pos = (int)(id / q), c = (int)(id - (long)pos * q);
+        const int u = ex_patch_unit(pos, patch_y);
+        *(f32x4*)(Wp + (long)pos * D + 4 * c) = *(const f32x4*)(W + (long)u * D + 4 * c);
+        if (c == 0) wsq_p[pos] = wsq[u];
+    } else {
+        if (id >= (long)K * D) return;
+        const int pos = (int)(id / D), d = (int)(id - (long)pos * D);
+        const int u = ex_patch_unit(pos, patch_y);
+        Wp[id] = W[(long)u * D + d];
+        if (d == 0) wsq_p[pos] = wsq[u];
+    }
 }
 
 // wn = wsq (the float32 kernel's own |w|^2) and its maximum: the screen's initial accumulator then carries the same

@@ -67,6 +67,12 @@ struct som_handle {
     bool f16 = false;        // precision f16 / f16x3: _Float16 operands instead of __bf16 (the same kernels, som_common.hpp)
     bool x3res = false;      // bf16x3 with input_len <= 128: the register-resident split kernel (bmu_bf16_k16x3.hpp)
     bool exact = false;      // precision 'exact': MFMA screen + float32 re-score of the candidates (bmu_exact.hpp)
+    // exact mode, map sides multiples of 8: the operand images in PATCH ORDER (ex_patch_unit, bmu_bf16.hpp) -- prepared
+    // from a permuted copy of the codebook; wf_patch: the order the float32 image is in right now (the float32 kernels
+    // proper -- fallback rows, top-2, analysis calls -- want the units' own order and rebuild it)
+    bool ex_patch = false, wf_patch = false;
+    float* Wp = nullptr;     // [K][D] codebook in patch order
+    float* wsq_p = nullptr;  // [K]   its |w|^2 (the float32 kernel's own values, permuted)
     struct ExactScratch {
         uint32_t* gmin = nullptr;            // [n_groups][stride] group minima of the chunk being screened (sparse: see gflags)
         unsigned long long* gflags = nullptr;   // [stride / 64][n_groups] which rows' minima the screen stored
@@ -118,7 +124,7 @@ struct som_handle {
     int n_stages = 0;
     // operands derived from W, rebuilt lazily: the bf16 stage image (w_dirty), |w|^2 (wsq_dirty) and the
     // float32 stage / tile images (wf_dirty).  Training in bf16 precision never touches the float32 images.
-    bool w_dirty = true, wsq_dirty = true, wf_dirty = true;
+    bool w_dirty = true, wsq_dirty = true, wf_dirty = true, wp_dirty = true;   // (wp: the patch-order copy, exact mode)
 
     // resident training rows
     const float* Xd = nullptr;
@@ -330,15 +336,19 @@ int resolve_profile(som_handle* h) {
 // the instance from the handle.
 #define SOM_HALF(h, fn, ...) ((h)->f16 ? fn<F16>(__VA_ARGS__) : fn<Bf16>(__VA_ARGS__))
 
-void mark_codebook_changed(som_handle* h) { h->w_dirty = h->wsq_dirty = h->wf_dirty = true; }
+void mark_codebook_changed(som_handle* h) { h->w_dirty = h->wsq_dirty = h->wf_dirty = h->wp_dirty = true; }
 
 // the 16-bit operand images of the codebook: stage / tile image, |w~|^2 per unit and its maximum
 template <class E>
 int prep_codebook_half(som_handle* h) {
     const float* unit = h->cfg.distance == SOM_DIST_COSINE ? h->wsq : nullptr;
+    // exact mode in patch order: the screen's image from the permuted codebook (refresh_codebook_operands wrote it)
+    const float* Wex = h->ex_patch ? h->Wp : h->W;
+    const float* qex = h->ex_patch ? h->wsq_p : h->wsq;
     const dim3 block(256);
     if (h->tiled) {
         if (h->wide && h->exact) {
+            if (unit) unit = qex;
             // exact mode beyond 128 features: the float32 kernel's own |w|^2 as the norm term (euclidean) or none (cosine:
             // unit-length units, max |w| = 1), the units scaled by a power of two, their rounding errors measured
             if (unit) {
@@ -346,13 +356,13 @@ int prep_codebook_half(som_handle* h) {
                 HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)h->wmax2, 0x3F800000, 1, h->stream));
             } else {
                 HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
-                exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(h->K, 1024)), dim3(1024), 0, h->stream>>>(h->wsq, h->K, h->wn, h->wmax2);
+                exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(h->K, 1024)), dim3(1024), 0, h->stream>>>(qex, h->K, h->wn, h->wmax2);
             }
             long total = (long)h->n_stages * WD_T * h->n_kchunks * 64;
             prep_w_bf16_wide_kernel<E><<<dim3((unsigned)cdiv(total, 256)), block, 0, h->stream>>>(
-                h->W, h->K, h->D, h->n_kchunks, h->Wst, h->n_stages, unit, 0, h->wmax2);
+                Wex, h->K, h->D, h->n_kchunks, h->Wst, h->n_stages, unit, 0, h->wmax2);
             HIPCHK(h, hipMemsetAsync(h->wmax2 + 1, 0, sizeof(float), h->stream));
-            exact_werr_kernel<E><<<dim3((unsigned)cdiv(h->K, 4 * EX_WERR_UNITS)), block, 0, h->stream>>>(h->W, h->K, h->D, h->wmax2, h->wmax2 + 1, unit);
+            exact_werr_kernel<E><<<dim3((unsigned)cdiv(h->K, 4 * EX_WERR_UNITS)), block, 0, h->stream>>>(Wex, h->K, h->D, h->wmax2, h->wmax2 + 1, unit);
             return 0;
         }
         if (h->wide) {
@@ -390,13 +400,13 @@ int prep_codebook_half(som_handle* h) {
         // the float32 kernel's own |w|^2 (refreshed just before) and its maximum first: the units go in scaled by
         // ex_scale(max |w|^2); then the scaled stage image and the units' rounding errors in one pass
         HIPCHK(h, hipMemsetAsync(h->wmax2, 0, 2 * sizeof(float), h->stream));     // [0]: max |w|^2, [1]: max_k |w^_k - w~_k|^2
-        exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(h->K, 1024)), dim3(1024), 0, h->stream>>>(h->wsq, h->K, h->wn, h->wmax2);
+        exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(h->K, 1024)), dim3(1024), 0, h->stream>>>(qex, h->K, h->wn, h->wmax2);
         const dim3 tgrid((unsigned)cdiv((long)h->n_stages * K16_T, 4));
         switch (h->ks32) {
-        case 1: prep_w_exact_k16_kernel<1, E><<<tgrid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1); break;
-        case 2: prep_w_exact_k16_kernel<2, E><<<tgrid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1); break;
-        case 3: prep_w_exact_k16_kernel<3, E><<<tgrid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1); break;
-        case 4: prep_w_exact_k16_kernel<4, E><<<tgrid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1); break;
+        case 1: prep_w_exact_k16_kernel<1, E><<<tgrid, block, 0, h->stream>>>(Wex, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1); break;
+        case 2: prep_w_exact_k16_kernel<2, E><<<tgrid, block, 0, h->stream>>>(Wex, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1); break;
+        case 3: prep_w_exact_k16_kernel<3, E><<<tgrid, block, 0, h->stream>>>(Wex, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1); break;
+        case 4: prep_w_exact_k16_kernel<4, E><<<tgrid, block, 0, h->stream>>>(Wex, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1); break;
         default: return fail(h, "the resident half-precision kernel supports input_len <= 128");
         }
         return 0;
@@ -415,10 +425,12 @@ int prep_codebook_half(som_handle* h) {
 }
 
 // need_f32: the caller is about to run a float32 kernel (parity-mode BMU, top-2, distance matrix).
-int refresh_codebook_operands(som_handle* h, bool need_f32) {
+// patch: the caller is the exact mode's screen + re-score (float32 image in patch order, where the handle uses one).
+int refresh_codebook_operands(som_handle* h, bool need_f32, bool patch = false) {
     if (h->exact) need_f32 = true;                       // the re-score reads the float32 stage image and |w|^2
+    patch = patch && h->ex_patch;
     const bool bf = h->cfg.precision != SOM_PREC_F32;
-    const bool do_f32 = (need_f32 || !bf) && h->wf_dirty;
+    const bool do_f32 = (need_f32 || !bf) && (h->wf_dirty || h->wf_patch != patch);
     const bool do_bf = bf && h->w_dirty;
     // (cosine scales the 16-bit images by 1/|w|: |w|^2 is wanted whenever they are rebuilt)
     const bool do_wsq = h->wsq_dirty && (need_f32 || !bf || (do_bf && h->cfg.distance == SOM_DIST_COSINE));
@@ -428,18 +440,27 @@ int refresh_codebook_operands(som_handle* h, bool need_f32) {
         row_sq_f32_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->wsq);
         h->wsq_dirty = false;
     }
+    if (h->ex_patch && h->wp_dirty && ((do_f32 && patch) || do_bf)) {
+        const long total = (long)h->K * ((h->D & 3) == 0 ? h->D / 4 : h->D);
+        exact_permute_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(h->W, h->wsq, h->K, h->D, h->Y, h->Wp,
+                                                                                           h->wsq_p);
+        h->wp_dirty = false;
+    }
     if (do_f32) {
+        const float* Wsrc = patch ? h->Wp : h->W;
+        const float* qsrc = patch ? h->wsq_p : h->wsq;
         if (h->Wfimg) {
             long total = (long)h->ft_ublocks * h->ft_kchunks * (4 * 4 * 64 + 128);
             prep_tiles_f32_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
-                h->W, h->K, h->D, h->ft_kchunks, h->ft_ublocks, FT_WTILE, h->wsq, h->Wfimg);
+                Wsrc, h->K, h->D, h->ft_kchunks, h->ft_ublocks, FT_WTILE, qsrc, h->Wfimg);
         }
         if (h->Wfst) {
             long total = (long)h->fr_stages * ((long)FR_UT * h->fr_kg * 64 + 64);
             prep_w_f32_res_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
-                h->W, h->wsq, h->K, h->D, h->fr_kg, h->Wfst, h->fr_stages);
+                Wsrc, qsrc, h->K, h->D, h->fr_kg, h->Wfst, h->fr_stages);
         }
         h->wf_dirty = false;
+        h->wf_patch = patch;
     }
     if (do_bf) {
         if (int rc = SOM_HALF(h, prep_codebook_half, h)) return rc;
@@ -1030,7 +1051,7 @@ int exact_rescore_kg(som_handle* h, const float* X, int n_groups) {
     // (twice the resident slots: the runs of tiles are uneven -- partial tiles, idle waves -- and finer runs balance them)
     const long grid = std::min<long>(ex.max_tiles, 2L * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
     kern<<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, h->D, h->Wfst, h->K, ex.tile_tab, ex.ctr + 2 * n_groups + 1, ex.plist,
-                                                             h->best64);
+                                                             h->best64, h->ex_patch ? h->Y : 0);
     return 0;
 }
 
@@ -1057,10 +1078,10 @@ int exact_rescore_round(som_handle* h, const float* X, const float* xsq, unsigne
         const long grid = std::min<long>(ex.max_tiles, 2L * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
         if (cosine)
             exact_rescore_tiled_kernel<SCORE_COSINE><<<dim3((unsigned)grid), dim3(256), 0, h->stream>>>(
-                X, h->D, xsq, h->Wfimg, h->ft_kchunks, h->K, ex.tile_tab, n_tiles, ex.plist, best64);
+                X, h->D, xsq, h->Wfimg, h->ft_kchunks, h->K, ex.tile_tab, n_tiles, ex.plist, best64, h->ex_patch ? h->Y : 0);
         else
             exact_rescore_tiled_kernel<SCORE_EUCLID_PART><<<dim3((unsigned)grid), dim3(256), 0, h->stream>>>(
-                X, h->D, xsq, h->Wfimg, h->ft_kchunks, h->K, ex.tile_tab, n_tiles, ex.plist, best64);
+                X, h->D, xsq, h->Wfimg, h->ft_kchunks, h->K, ex.tile_tab, n_tiles, ex.plist, best64, h->ex_patch ? h->Y : 0);
         h->best64 = saved;
         return 0;
     }
@@ -1100,6 +1121,8 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     const long chunk = std::min(exact_chunk_rows(h), ex.stride);
     for (long r0 = 0; r0 < N; r0 += chunk) {
         const long n = std::min(chunk, N - r0);
+        // (a pass behind one whose fallback rows went through the float32 kernel: its image back in patch order)
+        if (h->wf_patch != h->ex_patch) if (int rc = refresh_codebook_operands(h, true, true)) return rc;
         HIPCHK(h, hipMemsetAsync(ex.ctr, 0, (size_t)(2 * n_groups + 3) * sizeof(int), h->stream));
         // resident rows from their second epoch on: last epoch's BMU of every row caps the screen's keep threshold
         ex.seed_live = ex.seed_on && !h->wide && out == h->bmu && h->bmu_valid;
@@ -1162,6 +1185,8 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
                 if (int rc = dev_alloc(h, &ex.fb_ids, (size_t)cap)) return rc;
                 ex.fb_cap = cap;
             }
+            // the float32 kernel names units by their place in its image: the units' own order for it
+            if (h->wf_patch) if (int rc = refresh_codebook_operands(h, true, false)) return rc;
             exact_gather_rows_kernel<<<dim3((unsigned)cdiv((long)n_fb * h->D, 256)), dim3(256), 0, h->stream>>>(
                 X + r0 * h->D, ex.fb_list, n_fb, h->D, ex.fbX);
             // (its part merge may reuse best64[0 .. n_fb): rows this pass has already settled)
@@ -1237,7 +1262,7 @@ int verify_bmu_launch(som_handle* h, const float* X, long N, const int* ids) {
 // BMU of `N` device rows with the configured activation distance (xpysom.py:410-417)
 int run_activation_bmu_launch(som_handle* h, const float* X, long N, const float* xsq, const __bf16* Xb, const float* xmax2,
                               int* out) {
-    if (int rc = refresh_codebook_operands(h, h->cfg.precision == SOM_PREC_F32)) return rc;
+    if (int rc = refresh_codebook_operands(h, h->cfg.precision == SOM_PREC_F32, h->exact)) return rc;
     Timed t(h, SOM_K_BMU);
     if (h->exact) return launch_bmu_exact(h, X, N, xsq, Xb, xmax2, out);
     if (h->cfg.precision != SOM_PREC_F32) return launch_bmu_bf16(h, Xb, xmax2, N, out);
@@ -1656,6 +1681,8 @@ int som_create(const som_config* cfg, som_handle** out) {
         h->exact = false; h->f16 = false; h->tiled = false;
         h->cfg.precision = SOM_PREC_F32;
     }
+    h->ex_patch = h->exact && h->X % 8 == 0 && h->Y % 8 == 0;
+    if (const char* e = std::getenv("SOM_EXACT_PATCH")) if (std::atoi(e) == 0) h->ex_patch = false;   // A/B: groups = strips of a map row
     h->dp = h->tiled ? TL_BK * h->n_kchunks : h->x3res ? 2 * 32 * h->ks32 : 32 * h->ks32;
     h->stage_bytes = h->wide ? wd_stage_bytes(h->n_kchunks) : h->x3res ? k3_stage_bytes(h->ks32) : k16_stage_bytes(h->ks32);
     h->stage_units = h->wide ? WD_STAGE_UNITS : h->x3res ? K3_STAGE_UNITS : K16_STAGE_UNITS;
@@ -1684,6 +1711,10 @@ int som_create(const som_config* cfg, som_handle** out) {
     const size_t KD1 = (size_t)h->K * h->D1p;
     if ((rc = dev_alloc(h, &h->W, (size_t)h->K * h->D))) return bail(rc);
     if ((rc = dev_alloc(h, &h->wsq, (size_t)h->K))) return bail(rc);
+    if (h->ex_patch) {
+        if ((rc = dev_alloc(h, &h->Wp, (size_t)h->K * h->D))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->wsq_p, (size_t)h->K))) return bail(rc);
+    }
     if ((rc = dev_alloc(h, &h->SC, KD1 + (size_t)h->K))) return bail(rc);        // [K][D1p] sums|counts, then the counts densely [K]
     if ((rc = dev_alloc(h, &h->Ud, (size_t)h->nt * h->K))) return bail(rc);
     if ((rc = dev_alloc(h, &h->T, KD1 * h->nt))) return bail(rc);
@@ -1759,7 +1790,7 @@ void som_destroy(som_handle* h) {
     for (auto& ep : h->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     void* bufs[] = {h->Ud, h->W, h->wsq, h->SC, h->T, h->ACC, h->P1, h->P2, h->Wst, h->X_owned, h->bmu, h->xsq, h->Xb,
                     h->xmax2, h->wn, h->wmax2, h->qX, h->qbmu, h->qbmu2, h->qxsq, h->qXb, h->dsum,
-                    h->best64, h->Wfst, h->Wfimg, h->ftX, h->qX64};
+                    h->best64, h->Wfst, h->Wfimg, h->ftX, h->qX64, h->Wp, h->wsq_p};
     for (void* b : bufs) if (b) (void)hipFree(b);
     seg_free(h->seg);
     seg_free(h->st_seg);
@@ -1997,7 +2028,7 @@ int som_epoch_accumulate_forced(som_handle* h, const int32_t* bmu_host, double s
 int som_stream_begin(som_handle* h) {
     DeviceGuard dev_guard(h);
     if (!h) return 1;
-    if (int rc = refresh_codebook_operands(h, h->cfg.precision == SOM_PREC_F32)) return rc;
+    if (int rc = refresh_codebook_operands(h, h->cfg.precision == SOM_PREC_F32, h->exact)) return rc;
     HIPCHK(h, hipMemsetAsync(h->SC, 0, (size_t)h->K * (h->D1p + 1) * sizeof(float), h->stream));
     h->streaming = true;
     return 0;
@@ -2441,7 +2472,7 @@ int som_verify_stats(som_handle* h, int64_t* launches, int64_t* rows_checked) {
 int som_debug_corrupt_operands(som_handle* h, int32_t which) {
     DeviceGuard dev_guard(h);
     if (!h) return 1;
-    if (int rc = refresh_codebook_operands(h, true)) return rc;
+    if (int rc = refresh_codebook_operands(h, true, h->exact)) return rc;   // (in the order the next BMU launch wants: no rebuild there)
     if ((which & 1) && h->Wst) {
         size_t bytes = (size_t)h->n_stages * h->stage_bytes;
         if (h->tiled && !h->wide) bytes = (size_t)h->n_ublocks * h->n_kchunks * h->tl_wtile;
