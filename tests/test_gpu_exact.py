@@ -492,3 +492,29 @@ def test_exact_patch_order_equals_strip_order(monkeypatch, X, Y, D, n, dist):
     ref.close()
     if X >= 64:
         assert counts["1"] < counts["0"]                                  # fewer candidate groups per row: the point of it
+
+
+def test_exact_patch_order_copy_stays_in_step_with_the_merge():
+    """The merge writes the codebook and, in the same launch, its patch-order copy -- only where a unit's denominator
+    is not zero, and only if the copy was in step before (after a forced-BMU epoch on a fresh upload it is not: the
+    next BMU search permutes again).  A tiny sigma leaves most units untouched; every epoch's BMUs equal float32's."""
+    X, Y, D, n = 16, 24, 12, 4000
+    data = O.gaussian_blobs(n, D, seed=8)
+    w = O.default_codebook(X, Y, D, 3).astype(F32)
+    es = {p: engine(X, Y, D, precision=p) for p in ("f32", "exact")}
+    forced = np.random.RandomState(0).randint(0, X * Y, size=n).astype(np.int32)
+    trace = {}
+    for p, e in es.items():
+        e.set_weights(w); e.set_data(data)
+        e.epoch_accumulate_forced(forced, 2.0, 0.5, True)                 # no BMU search yet: the copy was never made
+        e.epoch_merge()
+        out = []
+        for sig in (3.0, 0.3, 0.3, 1.5, 0.2):
+            e.epoch_accumulate(sig, 0.5, True)
+            out.append(e.epoch_fetch()[2].copy())
+            e.epoch_merge()
+        out.append(e.get_weights().copy())
+        trace[p] = out
+        e.close()
+    for a, b in zip(trace["f32"], trace["exact"]):
+        assert np.array_equal(a, b)

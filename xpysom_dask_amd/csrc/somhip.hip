@@ -67,7 +67,7 @@ struct som_handle {
     bool f16 = false;        // precision f16 / f16x3: _Float16 operands instead of __bf16 (the same kernels, som_common.hpp)
     bool x3res = false;      // bf16x3 with input_len <= 128: the register-resident split kernel (bmu_bf16_k16x3.hpp)
     bool exact = false;      // precision 'exact': MFMA screen + float32 re-score of the candidates (bmu_exact.hpp)
-    // exact mode, map sides multiples of 8: the operand images in PATCH ORDER (ex_patch_unit, bmu_bf16.hpp) -- prepared
+    // exact mode, map sides multiples of 8: the operand images in PATCH ORDER (ex_patch_unit, som_common.hpp) -- prepared
     // from a permuted copy of the codebook; wf_patch: the order the float32 image is in right now (the float32 kernels
     // proper -- fallback rows, top-2, analysis calls -- want the units' own order and rebuild it)
     bool ex_patch = false, wf_patch = false;
@@ -437,7 +437,8 @@ int refresh_codebook_operands(som_handle* h, bool need_f32, bool patch = false) 
     if (!do_f32 && !do_wsq && !do_bf) return 0;
     Timed t(h, SOM_K_PREP);
     if (do_wsq) {
-        row_sq_f32_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->wsq);
+        row_sq_f32_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->wsq, h->wsq_p,
+                                                                                        h->ex_patch ? h->Y : 0);
         h->wsq_dirty = false;
     }
     if (h->ex_patch && h->wp_dirty && ((do_f32 && patch) || do_bf)) {
@@ -1224,7 +1225,8 @@ int verify_bmu_launch(som_handle* h, const float* X, long N, const int* ids) {
     exact_gather_rows_kernel<<<dim3((unsigned)cdiv((long)n * h->D, 256)), dim3(256), 0, h->stream>>>(X, h->vf_rows, n, h->D, h->vf_X);
     HIPCHK(h, hipMemsetAsync(h->vf_bad, 0, 4 * sizeof(int), h->stream));
     if (h->wsq_dirty) {                                            // |w|^2 in NumPy's order (the parity kernels' own)
-        row_sq_f32_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->wsq);
+        row_sq_f32_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->wsq, h->wsq_p,
+                                                                                        h->ex_patch ? h->Y : 0);
         h->wsq_dirty = false;
     }
     const dim3 grid((unsigned)n), block(256);
@@ -2141,9 +2143,13 @@ int som_epoch_merge(som_handle* h) {
         return 0;
     }
     long total = (long)h->K * h->D;
-    merge_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p);
+    // (exact mode in patch order: a copy that was in step with the codebook stays in step -- the merge writes both)
+    const bool keep_wp = h->ex_patch && !h->wp_dirty;
+    merge_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p,
+                                                                                keep_wp ? h->Wp : nullptr, h->Y);
     HIPCHK(h, hipGetLastError());
     mark_codebook_changed(h);
+    if (keep_wp) h->wp_dirty = false;
     return 0;
 }
 

@@ -867,14 +867,22 @@ __global__ __launch_bounds__(256) void strided_gemm_f32_kernel(const float* __re
 }
 
 // ---- merge: W = where(den != 0, num/den, W)  (xpysom.py:446-455) ---------------------------------
+// (Wp, patch_y: the exact mode's copy of the codebook in patch order -- ex_patch_pos, som_common.hpp -- kept in step)
 __global__ __launch_bounds__(256) void merge_kernel(float* __restrict__ W, const float* __restrict__ ACC,
-                                                    long K, int D, int D1p) {
+                                                    long K, int D, int D1p, float* __restrict__ Wp = nullptr,
+                                                    int patch_y = 0) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= K * D) return;
     long k = i / D;
     int d = (int)(i - k * D);
     float den = ACC[k * D1p + D];
-    if (den != 0.0f) W[i] = ACC[k * D1p + d] / den;
+    if (den != 0.0f) {
+        const float v = ACC[k * D1p + d] / den;
+        W[i] = v;
+        if (Wp != nullptr) {
+            Wp[(long)ex_patch_pos((int)k, patch_y) * D + d] = v;
+        }
+    }
 }
 
 // ---- quantization error: sum_n |x_n - W[bmu_n]|  (xpysom.py:703-705) -----------------------------
