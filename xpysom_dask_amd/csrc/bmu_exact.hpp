@@ -25,6 +25,12 @@
 //   4. fallback  rows the scheme cannot vouch for -- no candidate at all (NaN / infinite rows or norms), a minimum that
 //                is not finite, a pass with more pairs than re-scoring is worth (a quarter of the groups per row on average: a
 //                degenerate codebook) -- go to the float32 kernel itself (exact_finalize_kernel lists them).
+//   order        which 64 units form a group is free.  On maps whose sides are multiples of 8 the images hold the units
+//                PATCH by patch (8 x 8 units of the map per group: ex_patch_unit, som_common.hpp) -- the units near a
+//                row's best one are a blob of the map, and a blob touches a third to a half as many patches as 64-unit
+//                strips of map rows.  Steps 1-3 work on positions; within a group positions ascend with unit ids, and
+//                the re-score kernels translate a tile's winner to its UNIT id before the merge, so the first minimum
+//                in unit order still wins.  Step 4's float32 kernel wants the units' own order and rebuilds its image.
 //
 // Error bound (euclidean, input_len <= 128).  u = 2^-24, A(n,k) = sum_d |x_d w_kd| <= |x_n| max_k|w_k|.
 //   float32 kernel:  |c - x.w| <= gamma_D A (fma chain of D terms), s = fl(wsq - 2c):
