@@ -57,8 +57,8 @@ enum { SOM_TOPO_RECTANGULAR = 0, SOM_TOPO_HEXAGONAL = 1 };
  *           beyond the range saturate at +-65504
  *   EXACT: the BMUs of F32, row for row and bit for bit (near-ties and exact ties included), at half-precision MFMA
  *           speed: one pass of the MFMA kernel on power-of-two-scaled IEEE-half operands screens every unit and records
- *           the minimum of every 64-unit group per row (a group = an 8 x 8 patch of the map where both sides are
- *           multiples of 8, else 64 consecutive units), and the float32 fma chain itself re-scores the groups the
+ *           the minimum of every 64-unit group per row (a group = a compact patch of the map: 8 x 8 units where both
+ *           sides are multiples of 8), and the float32 fma chain itself re-scores the groups the
  *           screen's rigorous (partly measured) error bound cannot rule out; rows it cannot vouch for (NaN / infinite
  *           values, a pass with more candidate pairs than re-scoring is worth) go to the F32 kernel.  Euclidean distance
  *           with input_len <= 128; euclidean and cosine with 128 < input_len <= 800 on maps of >= 4096 units; other

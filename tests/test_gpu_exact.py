@@ -431,15 +431,17 @@ def test_exact_on_maps_of_a_quarter_million_units(X, Y, D, n):
         assert np.array_equal(ids["exact"][0], ids["f32"][0]) and np.array_equal(ids["exact"][1], ids["f32"][1])
 
 
-# ----------------------------------------------------------------------------- patch order (map sides multiples of 8)
-def test_exact_patch_order_ties_prefer_the_lowest_unit(monkeypatch):
-    """On maps whose sides are multiples of 8 the exact mode's operand images hold the units patch by patch (8 x 8 units
-    of the map per 64-unit group, ex_patch_unit); the answer must not know: among equal scores the lowest UNIT id wins,
+# ----------------------------------------------------------------------------- patch order
+@pytest.mark.parametrize("X,Y", [(16, 24), (13, 21), (9, 100), (70, 3)])
+def test_exact_patch_order_ties_prefer_the_lowest_unit(monkeypatch, X, Y):
+    """The exact mode's operand images hold the units patch by patch (8 x 8 units of the map per 64-unit group where the
+    sides are multiples of 8; bands of 8 map rows cut every 64 units otherwise: som_common.hpp); the answer must not
+    know: among equal scores the lowest UNIT id wins,
     within a patch, across patches, and for rows the float32 fallback settles (several passes here, so that the float32
     image changes order back and forth between them).  Small integers: every product exact, numpy float64 is the checker."""
     monkeypatch.setenv("SOM_EXACT_PASS_ROWS", "1024")
     rng = np.random.RandomState(2)
-    X, Y, D, n = 16, 24, 8, 3000
+    D, n = 8, 3000
     proto = rng.randint(-3, 4, size=(5, D)).astype(F32)
     w = proto[rng.randint(0, 5, size=X * Y)]                              # five distinct units, scattered over all patches
     data = rng.randint(-3, 4, size=(n, D)).astype(F32)
@@ -456,9 +458,11 @@ def test_exact_patch_order_ties_prefer_the_lowest_unit(monkeypatch):
 
 
 @pytest.mark.parametrize("X,Y,D,n,dist", [(64, 64, 32, 12000, "euclidean"), (16, 8, 128, 3000, "euclidean"),
-                                           (72, 64, 200, 3000, "cosine"), (64, 72, 133, 3000, "euclidean")])
+                                           (72, 64, 200, 3000, "cosine"), (64, 72, 133, 3000, "euclidean"),
+                                           (100, 100, 64, 8000, "euclidean"), (90, 75, 200, 3000, "cosine"),
+                                           (67, 131, 17, 5000, "euclidean")])
 def test_exact_patch_order_equals_strip_order(monkeypatch, X, Y, D, n, dist):
-    """SOM_EXACT_PATCH=0 keeps the units' own order (a group = 64 units of a map row): same BMUs, same accumulators, on a
+    """SOM_EXACT_PATCH=0 keeps the units' own order (a group = 64 consecutive units): same BMUs, same accumulators, on a
     smooth map (where the patches save candidate groups) and in the analysis calls that run float32 kernels on the same
     handle in between (top-2, the distance matrix: they want the float32 image in the units' own order)."""
     from xpysom_dask_amd import XPySom
@@ -494,11 +498,12 @@ def test_exact_patch_order_equals_strip_order(monkeypatch, X, Y, D, n, dist):
         assert counts["1"] < counts["0"]                                  # fewer candidate groups per row: the point of it
 
 
-def test_exact_patch_order_copy_stays_in_step_with_the_merge():
+@pytest.mark.parametrize("X,Y", [(16, 24), (21, 19)])
+def test_exact_patch_order_copy_stays_in_step_with_the_merge(X, Y):
     """The merge writes the codebook and, in the same launch, its patch-order copy -- only where a unit's denominator
     is not zero, and only if the copy was in step before (after a forced-BMU epoch on a fresh upload it is not: the
     next BMU search permutes again).  A tiny sigma leaves most units untouched; every epoch's BMUs equal float32's."""
-    X, Y, D, n = 16, 24, 12, 4000
+    D, n = 12, 4000
     data = O.gaussian_blobs(n, D, seed=8)
     w = O.default_codebook(X, Y, D, 3).astype(F32)
     es = {p: engine(X, Y, D, precision=p) for p in ("f32", "exact")}

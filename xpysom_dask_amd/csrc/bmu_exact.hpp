@@ -25,8 +25,8 @@
 //   4. fallback  rows the scheme cannot vouch for -- no candidate at all (NaN / infinite rows or norms), a minimum that
 //                is not finite, a pass with more pairs than re-scoring is worth (a quarter of the groups per row on average: a
 //                degenerate codebook) -- go to the float32 kernel itself (exact_finalize_kernel lists them).
-//   order        which 64 units form a group is free.  On maps whose sides are multiples of 8 the images hold the units
-//                PATCH by patch (8 x 8 units of the map per group: ex_patch_unit, som_common.hpp) -- the units near a
+//   order        which 64 units form a group is free.  The images hold the units
+//                PATCH by patch (8 x 8 units of the map per group where the sides allow: som_common.hpp) -- the units near a
 //                row's best one are a blob of the map, and a blob touches a third to a half as many patches as 64-unit
 //                strips of map rows.  Steps 1-3 work on positions; within a group positions ascend with unit ids, and
 //                the re-score kernels translate a tile's winner to its UNIT id before the merge, so the first minimum
@@ -326,7 +326,8 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_mfma_kernel(const float*
                                                                     const int4* __restrict__ tile_tab,
                                                                     const int* __restrict__ n_tiles_dev,
                                                                     const int* __restrict__ plist,
-                                                                    unsigned long long* __restrict__ best64, int patch_y) {
+                                                                    unsigned long long* __restrict__ best64,
+        const int* __restrict__ perm) {
     constexpr int STAGE = fr_stage_bytes(KG);
     constexpr int PIECES = FR_UT * KG + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE stage: occupancy (three workgroups per CU), not a
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_mfma_kernel(const float*
             const uint32_t bits = __float_as_uint(best);
             const uint32_t key = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
             // (patch order: positions ascend with the unit ids inside a group; across groups the merge compares UNITS)
-            atomicMin(best64 + row, ((unsigned long long)key << 32) | (uint32_t)ex_patch_unit(bidx, patch_y));
+            atomicMin(best64 + row, ((unsigned long long)key << 32) | (uint32_t)(perm != nullptr ? perm[bidx] : bidx));
         }
     }
 }
@@ -426,7 +427,8 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_tiled_kernel(const float
                                                                      const int4* __restrict__ tile_tab,
                                                                      const int* __restrict__ n_tiles_dev,
                                                                      const int* __restrict__ plist,
-                                                                     unsigned long long* __restrict__ best64, int patch_y) {
+                                                                     unsigned long long* __restrict__ best64,
+        const int* __restrict__ perm) {
     __shared__ __attribute__((aligned(16))) char ring[2][8192];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_tiled_kernel(const float
         if (half == 0 && row >= 0) {
             const uint32_t bits = __float_as_uint(best);
             const uint32_t key = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
-            atomicMin(best64 + row, ((unsigned long long)key << 32) | (uint32_t)ex_patch_unit(bidx, patch_y));
+            atomicMin(best64 + row, ((unsigned long long)key << 32) | (uint32_t)(perm != nullptr ? perm[bidx] : bidx));
         }
     }
 }
@@ -733,22 +735,22 @@ __global__ __launch_bounds__(64) void debug_mfma16_kernel(const uint16_t* __rest
     for (int r = 0; r < 4; ++r) Dout[(quad * 4 + r) * 16 + col] = d[r];
 }
 
-// the codebook and its |w|^2 in patch order (ex_patch_unit): what the exact mode's operand images are prepared from
+// the codebook and its |w|^2 in patch order (perm[position] = unit): what the exact mode's operand images are prepared from
 __global__ __launch_bounds__(256) void exact_permute_kernel(const float* __restrict__ W, const float* __restrict__ wsq, int K,
-                                                            int D, int patch_y, float* __restrict__ Wp,
+                                                            int D, const int* __restrict__ perm, float* __restrict__ Wp,
                                                             float* __restrict__ wsq_p) {
     const long id = (long)blockIdx.x * 256 + threadIdx.x;
     if ((D & 3) == 0) {
         const int q = D >> 2;
         if (id >= (long)K * q) return;
         const int pos = (int)(id / q), c = (int)(id - (long)pos * q);
-        const int u = ex_patch_unit(pos, patch_y);
+        const int u = perm[pos];
         *(f32x4*)(Wp + (long)pos * D + 4 * c) = *(const f32x4*)(W + (long)u * D + 4 * c);
         if (c == 0) wsq_p[pos] = wsq[u];
     } else {
         if (id >= (long)K * D) return;
         const int pos = (int)(id / D), d = (int)(id - (long)pos * D);
-        const int u = ex_patch_unit(pos, patch_y);
+        const int u = perm[pos];
         Wp[id] = W[(long)u * D + d];
         if (d == 0) wsq_p[pos] = wsq[u];
     }

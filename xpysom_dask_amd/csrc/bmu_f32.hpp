@@ -163,16 +163,16 @@ __device__ float np_pairwise_sq_sum(const float* __restrict__ a, int n) {
     return __fadd_rn(np_pairwise_sq_sum(a, n2), np_pairwise_sq_sum(a + n2, n - n2));
 }
 
-// (out_p, patch_y: the codebook's |w|^2 a second time in the exact mode's patch order, ex_patch_pos in som_common.hpp)
+// (out_p, inv: the codebook's |w|^2 a second time in the exact mode's patch order, inv[unit] = position: som_common.hpp)
 __global__ __launch_bounds__(256) void row_sq_f32_kernel(const float* __restrict__ A, long rows, int D,
                                                          float* __restrict__ out, float* __restrict__ out_p = nullptr,
-                                                         int patch_y = 0) {
+                                                         const int* __restrict__ inv = nullptr) {
     long row = (long)blockIdx.x * 256 + threadIdx.x;
     if (row >= rows) return;
     const float q = np_pairwise_sq_sum(A + row * (long)D, D);
     out[row] = q;
     if (out_p != nullptr) {
-        out_p[ex_patch_pos((int)row, patch_y)] = q;
+        out_p[inv[row]] = q;
     }
 }
 

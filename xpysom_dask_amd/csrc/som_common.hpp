@@ -77,23 +77,12 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-// PATCH ORDER (exact mode, map sides that are multiples of 8): the operand images hold the units in an order in which a
-// group of 64 consecutive positions is an 8 x 8 PATCH of the map instead of 64 units of one map row.  On a smooth map the
-// units near a row's best one form a blob around it; a blob touches a third to a half as many patches as strips (256 x
-// 256 x 128, the smoothest states: 16.0 -> 6.2 and 18.9 -> 7.5 candidate groups per row; 512 x 512 x 784: 47 -> 26), and
-// every candidate group is 64 x input_len of float32 re-score and one gather of the row.  Within a group positions ascend
-// with the unit ids (so the first-minimum rule holds inside a re-score tile); the re-score translates its winner back to
-// a unit id before the merge, which therefore still prefers the lowest UNIT among equal scores.  patch_y = the map's
-// second side (0: identity, the order is the units' own).
-__host__ __device__ __forceinline__ int ex_patch_unit(int pos, int patch_y) {
-    if (patch_y == 0) return pos;
-    const int g = pos >> 6, j = pos & 63, gy = patch_y >> 3;
-    const int px = g / gy, py = g - px * gy;
-    return ((px << 3) + (j >> 3)) * patch_y + (py << 3) + (j & 7);
-}
-// ... and where unit u sits in patch order
-__host__ __device__ __forceinline__ int ex_patch_pos(int u, int patch_y) {
-    if (patch_y == 0) return u;
-    const int x = u / patch_y, y = u - x * patch_y;
-    return ((((x >> 3) * (patch_y >> 3)) + (y >> 3)) << 6) + ((x & 7) << 3) + (y & 7);
-}
+// PATCH ORDER (exact mode): the operand images hold the units in an order in which a group of 64 consecutive positions
+// is a compact PATCH of the map (8 x 8 units where the sides are multiples of 8) instead of 64 units of one map row.  On
+// a smooth map the units near a row's best one form a blob around it; a blob touches a third to a half as many patches
+// as strips (256 x 256 x 128, the smoothest states: 16.0 -> 4.3 and 18.9 -> 6.0 candidate groups per row; 512 x 512 x 784:
+// 47 -> 26), and every candidate group is 64 x input_len of float32 re-score and one gather of the row.  The order is a
+// table (som_create builds it: bands of 8 map rows, column by column, then every group's units sorted): perm[position] =
+// unit, inv[unit] = position.  Within a group positions ascend with the unit ids (so the first-minimum rule holds
+// inside a re-score tile); the re-score translates its winner back to a unit id before the merge, which therefore still
+// prefers the lowest UNIT among equal scores.  A null table: the units' own order.

@@ -67,10 +67,12 @@ struct som_handle {
     bool f16 = false;        // precision f16 / f16x3: _Float16 operands instead of __bf16 (the same kernels, som_common.hpp)
     bool x3res = false;      // bf16x3 with input_len <= 128: the register-resident split kernel (bmu_bf16_k16x3.hpp)
     bool exact = false;      // precision 'exact': MFMA screen + float32 re-score of the candidates (bmu_exact.hpp)
-    // exact mode, map sides multiples of 8: the operand images in PATCH ORDER (ex_patch_unit, som_common.hpp) -- prepared
+    // exact mode: the operand images in PATCH ORDER (som_common.hpp; ex_perm[position] = unit, ex_inv[unit] = position) -- prepared
     // from a permuted copy of the codebook; wf_patch: the order the float32 image is in right now (the float32 kernels
     // proper -- fallback rows, top-2, analysis calls -- want the units' own order and rebuild it)
     bool ex_patch = false, wf_patch = false;
+    int* ex_perm = nullptr;
+    int* ex_inv = nullptr;
     float* Wp = nullptr;     // [K][D] codebook in patch order
     float* wsq_p = nullptr;  // [K]   its |w|^2 (the float32 kernel's own values, permuted)
     struct ExactScratch {
@@ -438,12 +440,12 @@ int refresh_codebook_operands(som_handle* h, bool need_f32, bool patch = false) 
     Timed t(h, SOM_K_PREP);
     if (do_wsq) {
         row_sq_f32_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->wsq, h->wsq_p,
-                                                                                        h->ex_patch ? h->Y : 0);
+                                                                                        h->ex_inv);
         h->wsq_dirty = false;
     }
     if (h->ex_patch && h->wp_dirty && ((do_f32 && patch) || do_bf)) {
         const long total = (long)h->K * ((h->D & 3) == 0 ? h->D / 4 : h->D);
-        exact_permute_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(h->W, h->wsq, h->K, h->D, h->Y, h->Wp,
+        exact_permute_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(h->W, h->wsq, h->K, h->D, h->ex_perm, h->Wp,
                                                                                            h->wsq_p);
         h->wp_dirty = false;
     }
@@ -1052,7 +1054,7 @@ int exact_rescore_kg(som_handle* h, const float* X, int n_groups) {
     // (twice the resident slots: the runs of tiles are uneven -- partial tiles, idle waves -- and finer runs balance them)
     const long grid = std::min<long>(ex.max_tiles, 2L * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
     kern<<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, h->D, h->Wfst, h->K, ex.tile_tab, ex.ctr + 2 * n_groups + 1, ex.plist,
-                                                             h->best64, h->ex_patch ? h->Y : 0);
+                                                             h->best64, h->ex_perm);
     return 0;
 }
 
@@ -1079,10 +1081,10 @@ int exact_rescore_round(som_handle* h, const float* X, const float* xsq, unsigne
         const long grid = std::min<long>(ex.max_tiles, 2L * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
         if (cosine)
             exact_rescore_tiled_kernel<SCORE_COSINE><<<dim3((unsigned)grid), dim3(256), 0, h->stream>>>(
-                X, h->D, xsq, h->Wfimg, h->ft_kchunks, h->K, ex.tile_tab, n_tiles, ex.plist, best64, h->ex_patch ? h->Y : 0);
+                X, h->D, xsq, h->Wfimg, h->ft_kchunks, h->K, ex.tile_tab, n_tiles, ex.plist, best64, h->ex_perm);
         else
             exact_rescore_tiled_kernel<SCORE_EUCLID_PART><<<dim3((unsigned)grid), dim3(256), 0, h->stream>>>(
-                X, h->D, xsq, h->Wfimg, h->ft_kchunks, h->K, ex.tile_tab, n_tiles, ex.plist, best64, h->ex_patch ? h->Y : 0);
+                X, h->D, xsq, h->Wfimg, h->ft_kchunks, h->K, ex.tile_tab, n_tiles, ex.plist, best64, h->ex_perm);
         h->best64 = saved;
         return 0;
     }
@@ -1226,7 +1228,7 @@ int verify_bmu_launch(som_handle* h, const float* X, long N, const int* ids) {
     HIPCHK(h, hipMemsetAsync(h->vf_bad, 0, 4 * sizeof(int), h->stream));
     if (h->wsq_dirty) {                                            // |w|^2 in NumPy's order (the parity kernels' own)
         row_sq_f32_kernel<<<dim3((unsigned)cdiv(h->K, 256)), dim3(256), 0, h->stream>>>(h->W, h->K, h->D, h->wsq, h->wsq_p,
-                                                                                        h->ex_patch ? h->Y : 0);
+                                                                                        h->ex_inv);
         h->wsq_dirty = false;
     }
     const dim3 grid((unsigned)n), block(256);
@@ -1683,7 +1685,7 @@ int som_create(const som_config* cfg, som_handle** out) {
         h->exact = false; h->f16 = false; h->tiled = false;
         h->cfg.precision = SOM_PREC_F32;
     }
-    h->ex_patch = h->exact && h->X % 8 == 0 && h->Y % 8 == 0;
+    h->ex_patch = h->exact && h->K >= 2 * EX_GROUP;      // (a map of one group has nothing to order)
     if (const char* e = std::getenv("SOM_EXACT_PATCH")) if (std::atoi(e) == 0) h->ex_patch = false;   // A/B: groups = strips of a map row
     h->dp = h->tiled ? TL_BK * h->n_kchunks : h->x3res ? 2 * 32 * h->ks32 : 32 * h->ks32;
     h->stage_bytes = h->wide ? wd_stage_bytes(h->n_kchunks) : h->x3res ? k3_stage_bytes(h->ks32) : k16_stage_bytes(h->ks32);
@@ -1716,6 +1718,21 @@ int som_create(const som_config* cfg, som_handle** out) {
     if (h->ex_patch) {
         if ((rc = dev_alloc(h, &h->Wp, (size_t)h->K * h->D))) return bail(rc);
         if ((rc = dev_alloc(h, &h->wsq_p, (size_t)h->K))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->ex_perm, (size_t)h->K))) return bail(rc);
+        if ((rc = dev_alloc(h, &h->ex_inv, (size_t)h->K))) return bail(rc);
+        // bands of 8 map rows, column by column: 64 consecutive positions = 8 columns of a band = an 8 x 8 patch (where
+        // the sides are no multiples of 8 a group may straddle two bands or hold a narrower band's 64 / h columns: still
+        // compact); then every group's units in ascending order (the first-minimum rule inside a re-score tile)
+        std::vector<int> perm; perm.reserve(h->K);
+        for (int x0 = 0; x0 < h->X; x0 += 8)
+            for (int y = 0; y < h->Y; ++y)
+                for (int x = x0; x < std::min(x0 + 8, h->X); ++x) perm.push_back(x * h->Y + y);
+        for (long g = 0; g < h->K; g += EX_GROUP) std::sort(perm.begin() + g, perm.begin() + std::min<long>(g + EX_GROUP, h->K));
+        std::vector<int> inv((size_t)h->K);
+        for (int p = 0; p < h->K; ++p) inv[(size_t)perm[(size_t)p]] = p;
+        if (hipMemcpy(h->ex_perm, perm.data(), (size_t)h->K * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->ex_inv, inv.data(), (size_t)h->K * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail(h, "hipMemcpy of the patch-order tables failed"));
     }
     if ((rc = dev_alloc(h, &h->SC, KD1 + (size_t)h->K))) return bail(rc);        // [K][D1p] sums|counts, then the counts densely [K]
     if ((rc = dev_alloc(h, &h->Ud, (size_t)h->nt * h->K))) return bail(rc);
@@ -1792,7 +1809,7 @@ void som_destroy(som_handle* h) {
     for (auto& ep : h->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     void* bufs[] = {h->Ud, h->W, h->wsq, h->SC, h->T, h->ACC, h->P1, h->P2, h->Wst, h->X_owned, h->bmu, h->xsq, h->Xb,
                     h->xmax2, h->wn, h->wmax2, h->qX, h->qbmu, h->qbmu2, h->qxsq, h->qXb, h->dsum,
-                    h->best64, h->Wfst, h->Wfimg, h->ftX, h->qX64, h->Wp, h->wsq_p};
+                    h->best64, h->Wfst, h->Wfimg, h->ftX, h->qX64, h->Wp, h->wsq_p, h->ex_perm, h->ex_inv};
     for (void* b : bufs) if (b) (void)hipFree(b);
     seg_free(h->seg);
     seg_free(h->st_seg);
@@ -2146,7 +2163,7 @@ int som_epoch_merge(som_handle* h) {
     // (exact mode in patch order: a copy that was in step with the codebook stays in step -- the merge writes both)
     const bool keep_wp = h->ex_patch && !h->wp_dirty;
     merge_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(h->W, h->ACC, h->K, h->D, h->D1p,
-                                                                                keep_wp ? h->Wp : nullptr, h->Y);
+                                                                                keep_wp ? h->Wp : nullptr, h->ex_inv);
     HIPCHK(h, hipGetLastError());
     mark_codebook_changed(h);
     if (keep_wp) h->wp_dirty = false;

@@ -867,10 +867,10 @@ __global__ __launch_bounds__(256) void strided_gemm_f32_kernel(const float* __re
 }
 
 // ---- merge: W = where(den != 0, num/den, W)  (xpysom.py:446-455) ---------------------------------
-// (Wp, patch_y: the exact mode's copy of the codebook in patch order -- ex_patch_pos, som_common.hpp -- kept in step)
+// (Wp, inv: the exact mode's copy of the codebook in patch order -- inv[unit] = position, som_common.hpp -- kept in step)
 __global__ __launch_bounds__(256) void merge_kernel(float* __restrict__ W, const float* __restrict__ ACC,
                                                     long K, int D, int D1p, float* __restrict__ Wp = nullptr,
-                                                    int patch_y = 0) {
+                                                    const int* __restrict__ inv = nullptr) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= K * D) return;
     long k = i / D;
@@ -880,7 +880,7 @@ __global__ __launch_bounds__(256) void merge_kernel(float* __restrict__ W, const
         const float v = ACC[k * D1p + d] / den;
         W[i] = v;
         if (Wp != nullptr) {
-            Wp[(long)ex_patch_pos((int)k, patch_y) * D + d] = v;
+            Wp[(long)inv[k] * D + d] = v;
         }
     }
 }
