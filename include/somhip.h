@@ -238,6 +238,11 @@ int som_debug_mfma16(som_handle* h, const uint16_t* a_host, const uint16_t* b_ho
  * reads n_pairs pairs back.  The product build refuses both. */
 int som_debug_stamps(som_handle* h, int64_t n_pairs, uint64_t* out_host);
 
+/* precision EXACT, introspection (host arithmetic only, no device needed): the order in which the mode's operand images
+ * hold the units of an x * y map -- perm_out[position] = unit id, x * y entries; every 64 consecutive positions are one
+ * group of the screen / re-score (an 8 x 8 patch of the map where both sides are multiples of 8), ascending inside. */
+int som_patch_order(int32_t x, int32_t y, int32_t* perm_out);
+
 /* precision EXACT bookkeeping: rows screened so far, rows that went to the float32 fallback kernel, screen passes */
 int som_exact_stats(som_handle* h, int64_t* rows, int64_t* rows_fallback, int64_t* passes);
 /* candidate groups per row of the LAST screen pass (its first n rows): how many 64-unit groups the re-score visited */

@@ -72,6 +72,27 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.som_version().startswith(b"somhip")
 
 
+@pytest.mark.parametrize("X,Y", [(256, 256), (16, 24), (100, 100), (13, 21), (9, 100), (70, 3), (1, 1), (1, 200), (5, 5)])
+def test_exact_patch_order_is_a_compact_ascending_bijection(X, Y):
+    """som_patch_order (host arithmetic of the exact mode): a bijection position -> unit; inside every
+    group of 64 positions the unit ids ascend (the re-score's first-minimum rule relies on it); a group is an 8 x 8 patch
+    of the map where both sides are multiples of 8, and a run of whole 8-row bands anywhere."""
+    from xpysom_dask_amd import _lib
+    lib = _lib.load()
+    K = X * Y
+    perm = np.full(K, -1, np.int32)
+    assert lib.som_patch_order(X, Y, perm.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+    assert np.array_equal(np.sort(perm), np.arange(K))
+    for g in range(0, K, 64):
+        grp = perm[g:g + 64]
+        assert (np.diff(grp) > 0).all()
+        xs, ys = grp // Y, grp % Y
+        assert xs.max() - xs.min() < 8 * (-(-64 // (8 * Y)) + 1)            # whole bands of 8 map rows, one more when it straddles
+        if X % 8 == 0 and Y % 8 == 0:
+            assert xs.max() - xs.min() == 7 and ys.max() - ys.min() == 7 and xs.min() % 8 == 0 and ys.min() % 8 == 0
+    assert lib.som_patch_order(0, 4, perm.ctypes.data_as(C.POINTER(C.c_int32))) != 0
+
+
 @pytest.mark.skipif(_gpu_present(), reason="checks the no-GPU failure mode")
 def test_compute_fails_loudly_without_a_gpu():
     from xpysom_dask_amd import XPySom

@@ -1595,6 +1595,16 @@ int launch_dist_matrix(som_handle* h, long N, float* out) {
 }  // namespace
 
 // ==============================================================================================
+// the exact mode's patch order (som_common.hpp): position -> unit.  Host arithmetic only (som_patch_order exports it).
+static void patch_order(int X, int Y, std::vector<int>& perm) {
+    const long K = (long)X * Y;
+    perm.clear(); perm.reserve((size_t)K);
+    for (int x0 = 0; x0 < X; x0 += 8)
+        for (int y = 0; y < Y; ++y)
+            for (int x = x0; x < std::min(x0 + 8, X); ++x) perm.push_back(x * Y + y);
+    for (long g = 0; g < K; g += EX_GROUP) std::sort(perm.begin() + g, perm.begin() + std::min<long>(g + EX_GROUP, K));
+}
+
 extern "C" {
 
 #ifndef SOM_SRC_HASH
@@ -1723,11 +1733,8 @@ int som_create(const som_config* cfg, som_handle** out) {
         // bands of 8 map rows, column by column: 64 consecutive positions = 8 columns of a band = an 8 x 8 patch (where
         // the sides are no multiples of 8 a group may straddle two bands or hold a narrower band's 64 / h columns: still
         // compact); then every group's units in ascending order (the first-minimum rule inside a re-score tile)
-        std::vector<int> perm; perm.reserve(h->K);
-        for (int x0 = 0; x0 < h->X; x0 += 8)
-            for (int y = 0; y < h->Y; ++y)
-                for (int x = x0; x < std::min(x0 + 8, h->X); ++x) perm.push_back(x * h->Y + y);
-        for (long g = 0; g < h->K; g += EX_GROUP) std::sort(perm.begin() + g, perm.begin() + std::min<long>(g + EX_GROUP, h->K));
+        std::vector<int> perm;
+        patch_order(h->X, h->Y, perm);
         std::vector<int> inv((size_t)h->K);
         for (int p = 0; p < h->K; ++p) inv[(size_t)perm[(size_t)p]] = p;
         if (hipMemcpy(h->ex_perm, perm.data(), (size_t)h->K * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
@@ -2555,6 +2562,14 @@ int som_debug_stamps(som_handle* h, int64_t n_pairs, uint64_t* out_host) {
     (void)n_pairs; (void)out_host;
     return fail(h, "som_debug_stamps: this library was built without -DSOM_STAMPS (tools/stamps.py builds the diagnostic one)");
 #endif
+}
+
+int som_patch_order(int32_t x, int32_t y, int32_t* perm_out) {
+    if (x <= 0 || y <= 0 || !perm_out || (int64_t)x * y > 0x7fffffffLL) return 1;
+    std::vector<int> perm;
+    patch_order(x, y, perm);
+    std::copy(perm.begin(), perm.end(), perm_out);
+    return 0;
 }
 
 int som_exact_stats(som_handle* h, int64_t* rows, int64_t* rows_fallback, int64_t* passes) {
