@@ -53,6 +53,10 @@ for case in range(n_cases):
         data[rs.randint(0, n)] = np.nan
     sig = float(rs.choice([max(min(X, Y) / 2, 1.0), 1.0, 2.5]))
     w2 = (w[::-1, ::-1] * F32(rs.choice([1.0, 0.5, 3.0]))).copy()   # (another codebook of the same kind: the units change places)
+    if os.environ.get("FUZZ_ONLY") and case != int(os.environ["FUZZ_ONLY"]):   # (replay one case of a seed)
+        continue
+    if os.environ.get("FUZZ_DUMP"):
+        np.savez(os.environ["FUZZ_DUMP"], data=data, w=w, w2=w2, sig=sig, dims=np.array([X, Y, D, n]))
     try:
         out = {}
         for p in ("f32", "exact"):

@@ -523,3 +523,129 @@ def test_exact_patch_order_copy_stays_in_step_with_the_merge(X, Y):
         e.close()
     for a, b in zip(trace["f32"], trace["exact"]):
         assert np.array_equal(a, b)
+
+
+# ----------------------------------------------------------------------------- block skipping (csrc/exact_skip.hpp)
+@pytest.mark.parametrize("X,Y,D,n,pass_rows", [(64, 64, 32, 20000, 0), (40, 50, 100, 6000, 0), (33, 17, 128, 5000, 1024),
+                                               (128, 128, 16, 30000, 0), (16, 16, 7, 3000, 1024), (100, 100, 64, 9000, 4096)])
+def test_exact_block_skipping_trains_the_float32_map(monkeypatch, X, Y, D, n, pass_rows):
+    """From the second epoch on the screen runs, per 256-row tile of rows sorted by their last BMU's patch, only the groups
+    whose centroid-and-radius bound leaves some row a chance (SOM_EXACT_SKIP=2: on every map of >= 2 groups).  Same BMUs in
+    every epoch of a whole schedule -- smooth maps that skip nothing, trained maps that skip most -- hence the same
+    codebook, bit for bit; and on the trained map most blocks were indeed not run."""
+    monkeypatch.setenv("SOM_EXACT_SKIP", "2")
+    if pass_rows:
+        monkeypatch.setenv("SOM_EXACT_PASS_ROWS", str(pass_rows))
+    data = O.gaussian_blobs(n, D, seed=4)
+    w = O.default_codebook(X, Y, D, 6).astype(F32)
+    f = engine(X, Y, D, precision="f32")
+    x = engine(X, Y, D, precision="exact")
+    for e in (f, x):
+        e.set_weights(w); e.set_data(data)
+    T = 8
+    for t in range(T):
+        sig, eta = O.exponential_decay(min(X, Y) / 2.0, 1.0, t, T), O.exponential_decay(0.5, 0.01, t, T)
+        f.epoch_accumulate(sig, eta, True)
+        x.epoch_accumulate(sig, eta, True)
+        bf, bx = f.epoch_fetch()[2], x.epoch_fetch()[2]
+        assert np.array_equal(bf, bx), "epoch %d: %d rows differ" % (t, (bf != bx).sum())
+        f.epoch_merge(); x.epoch_merge()
+    assert np.array_equal(f.get_weights(), x.get_weights())
+    run, total = x.exact_skip_stats()
+    rows, fb, _ = x.exact_stats()
+    assert rows == n * T and fb <= rows // 50
+    assert 0 < run <= total                               # (a map of a few groups: every tile may need them all)
+    f.close(); x.close()
+
+
+def test_exact_block_skipping_skips_most_of_a_trained_benchmark_map():
+    """configs[2]'s map and data (256 x 256 x 128, Gaussian blobs), 32 768 rows, the benchmark's schedule: from the third
+    epoch on a tenth to a quarter of the blocks run (tools/skip_probe.py counted 7-28 % in real arithmetic)."""
+    from xpysom_dask_amd.synthetic import gaussian_blobs
+    X = Y = 256; D = 128; n = 32768; T = 10
+    data = gaussian_blobs(n, D)
+    rs = np.random.RandomState(1234)
+    w = rs.rand(X, Y, D) * 2 - 1
+    w = (w / np.linalg.norm(w, axis=-1, keepdims=True)).astype(F32)
+    f = engine(X, Y, D, precision="f32"); x = engine(X, Y, D, precision="exact")
+    for e in (f, x):
+        e.set_weights(w); e.set_data(data)
+    shares = []
+    for t in range(T):
+        sig, eta = O.exponential_decay(128.0, 1.0, t, T), O.exponential_decay(0.5, 0.01, t, T)
+        r0, t0 = x.exact_skip_stats()
+        f.epoch_accumulate(sig, eta, True); x.epoch_accumulate(sig, eta, True)
+        r1, t1 = x.exact_skip_stats()
+        shares.append((r1 - r0) / (t1 - t0))
+        assert np.array_equal(f.epoch_fetch()[2], x.epoch_fetch()[2]), t
+        f.epoch_merge(); x.epoch_merge()
+    assert shares[0] == 1.0 and max(shares[3:]) < 0.5 and min(shares[3:]) < 0.2, shares
+    f.close(); x.close()
+
+
+def test_exact_block_skipping_with_ties_fallback_rows_and_a_moved_codebook(monkeypatch):
+    """What the bound must survive: exact ties (duplicated units in different patches), NaN / infinite / zero rows, a
+    codebook replaced between epochs (the last BMUs then say nothing: a valid but useless bound), queries in between."""
+    monkeypatch.setenv("SOM_EXACT_SKIP", "2")
+    rng = np.random.RandomState(5)
+    X, Y, D, n = 24, 32, 8, 4000
+    proto = rng.randint(-3, 4, size=(7, D)).astype(F32)
+    w = proto[rng.randint(0, 7, size=X * Y)].reshape(X, Y, D)
+    data = rng.randint(-3, 4, size=(n, D)).astype(F32)
+    data[::5] = proto[rng.randint(0, 7, size=len(data[::5]))]
+    data[7] = 0.0; data[100, 2] = np.nan; data[1500] = np.inf; data[2100] = 1e30
+    f = engine(X, Y, D, precision="f32"); x = engine(X, Y, D, precision="exact")
+    for e in (f, x):
+        e.set_weights(w); e.set_data(data)
+    w2 = (w[::-1, ::-1] * F32(2.0)).copy()
+    for t, sig in enumerate((4.0, 4.0, 2.0, 1.0, 1.0)):
+        if t == 3:
+            f.set_weights(w2); x.set_weights(w2)
+        f.epoch_accumulate(sig, 0.3, True); x.epoch_accumulate(sig, 0.3, True)
+        assert np.array_equal(f.epoch_fetch()[2], x.epoch_fetch()[2]), t
+        assert np.array_equal(f.bmu(data[:300]), x.bmu(data[:300]))
+        if t != 1:
+            f.epoch_merge(); x.epoch_merge()
+    f.close(); x.close()
+
+
+def test_exact_block_skipping_off_and_auto(monkeypatch):
+    """SOM_EXACT_SKIP=0: every block runs.  Default: on from 4 096 units."""
+    from xpysom_dask_amd.synthetic import gaussian_blobs
+    X, Y, D, n = 64, 64, 64, 8000
+    data = gaussian_blobs(n, D, seed=2, centres=16, spread=6.0)            # well separated: a trained map skips a lot
+    w = O.default_codebook(X, Y, D, 1).astype(F32)
+    got = {}
+    for mode in ("0", None):
+        if mode is None:
+            monkeypatch.delenv("SOM_EXACT_SKIP", raising=False)
+        else:
+            monkeypatch.setenv("SOM_EXACT_SKIP", mode)
+        e = engine(X, Y, D, precision="exact")
+        e.set_weights(w); e.set_data(data)
+        for sig in (8.0, 2.0, 1.0, 1.0):
+            e.epoch(sig, 0.3, True)
+        e.epoch_accumulate(1.0, 0.3, True)
+        got[mode] = (e.epoch_fetch()[2], e.get_weights(), e.exact_skip_stats())
+        e.close()
+    assert np.array_equal(got["0"][0], got[None][0]) and np.array_equal(got["0"][1], got[None][1])
+    assert got["0"][2][0] == got["0"][2][1] and got[None][2][0] < got[None][2][1]
+
+
+def test_exact_block_skipping_with_nan_units_in_the_codebook(monkeypatch):
+    """A NaN row poisons the units its neighbourhood reaches at the merge; rows whose last BMU is such a unit have no bound
+    (found by the fuzzer: an fmax had swallowed that NaN and bounded those rows by zero) and must need every group."""
+    monkeypatch.setenv("SOM_EXACT_SKIP", "2")
+    X, Y, D, n = 16, 80, 32, 5000
+    data = O.gaussian_blobs(n, D, seed=11)
+    data[1234] = np.nan
+    w = (data[:1].mean(0) + 1e-3 * np.random.RandomState(0).randn(X, Y, D)).astype(F32) * F32(100.0)   # epoch 1: one BMU for all
+    f = engine(X, Y, D, precision="f32"); x = engine(X, Y, D, precision="exact")
+    for e in (f, x):
+        e.set_weights(w); e.set_data(data)
+    for sig in (1.0, 0.7, 0.7):
+        f.epoch_accumulate(sig, 0.5, True); x.epoch_accumulate(sig, 0.5, True)
+        assert np.array_equal(f.epoch_fetch()[2], x.epoch_fetch()[2])
+        f.epoch_merge(); x.epoch_merge()
+    assert np.isnan(f.get_weights()).any()
+    f.close(); x.close()

@@ -222,7 +222,9 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void bmu_bf16_k16_kernel(const __bf
                                                               const float* __restrict__ wmax2 = nullptr,
                                                               const float* __restrict__ werr2 = nullptr,
                                                               ExactBound eb = ExactBound(),
-                                                              const float* __restrict__ seed = nullptr) {
+                                                              const float* __restrict__ seed = nullptr,
+                                                              const int* __restrict__ glist = nullptr,
+                                                              const int* __restrict__ gcnt = nullptr) {
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     constexpr int DP = 32 * KS32;
@@ -269,11 +271,18 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void bmu_bf16_k16_kernel(const __bf
             if (sd == sd) run_cap = sd;
         }
     }
-    // this workgroup's share of the codebook stages
-    const int s_begin = (int)((long)n_stages * blockIdx.y / gridDim.y);
-    const int s_end = (int)((long)n_stages * (blockIdx.y + 1) / gridDim.y);
-    for (int p = wave; p < PIECES; p += K16_NW)
-        lds_dma_16(Wst + (long)s_begin * STAGE + (long)p * 1024 + lane * 16, smem + p * 1024);
+    // this workgroup's share of the codebook stages -- or (GM with block skipping, exact_skip.hpp) of the tile's LIST of stages:
+    // the loop index s walks [s_begin, s_end) either way, stage_of(s) is the stage it stands for
+    const int* my_list = (GM && glist != nullptr) ? glist + (long)blockIdx.x * n_stages : nullptr;
+    const int n_walk = my_list != nullptr ? gcnt[blockIdx.x] : n_stages;
+    const int s_begin = (int)((long)n_walk * blockIdx.y / gridDim.y);
+    const int s_end = (int)((long)n_walk * (blockIdx.y + 1) / gridDim.y);
+    // (list entries are read two iterations ahead of their use: no load sits between a barrier and the stage it names)
+    auto stage_of = [&](int s) -> int { return s < s_end ? (my_list != nullptr ? __builtin_amdgcn_readfirstlane(my_list[s]) : s) : 0; };
+    int st_prev = 0, st_cur = stage_of(s_begin), st_next = stage_of(s_begin + 1);
+    if (s_begin < s_end)
+        for (int p = wave; p < PIECES; p += K16_NW)
+            lds_dma_16(Wst + (long)st_cur * STAGE + (long)p * 1024 + lane * 16, smem + p * 1024);
 
     auto reduce_tile = [&](const f32x4 (&acc)[K16_SB], int t16) {
         if (GM) {
@@ -298,8 +307,8 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void bmu_bf16_k16_kernel(const __bf
             cbest[sb] = min(min(cbest[sb], key[2]), key[3]);
         }
     };
-    auto fold_stage = [&](int stage) {
-        if (GM && stage >= s_begin) {
+    auto fold_stage = [&](int stage, bool live) {
+        if (GM && live) {
             static_assert(!GM || K16_SB == 4, "the group-minimum transpose pairs four 16-sample blocks with four lane quads");
             // rows of 16 lanes (quads) q0..q3 each hold (v0, v1, v2, v3): after the three steps quad q holds min over quads of v_q
             auto a = __builtin_amdgcn_permlane16_swap(cbest[0], cbest[K16_SB > 1 ? 1 : 0], false, false);
@@ -328,8 +337,9 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void bmu_bf16_k16_kernel(const __bf
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        const int st_next2 = stage_of(s + 2);
         if (s + 1 < s_end) {
-            const char* src = Wst + (long)(s + 1) * STAGE;
+            const char* src = Wst + (long)st_next * STAGE;
             char* dst = smem + ((s + 1 - s_begin) & 1) * STAGE;
             for (int p = wave; p < PIECES; p += K16_NW) lds_dma_16(src + (long)p * 1024 + lane * 16, dst + p * 1024);
         }
@@ -360,7 +370,7 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void bmu_bf16_k16_kernel(const __bf
                 for (int sb = 0; sb < K16_SB; ++sb)
                     accT[sb] = mfma16(a[ks], xf[sb][ks], accT[sb]);
             reduce_tile(accP, (t16 + K16_T - 1) % K16_T);
-            if (t16 == 0) fold_stage(s - 1);
+            if (t16 == 0) fold_stage(st_prev, s > s_begin);
 #pragma unroll
             for (int sb = 0; sb < K16_SB; ++sb) accP[sb] = accT[sb];
             if (t16 + 1 < K16_T) {
@@ -371,9 +381,10 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void bmu_bf16_k16_kernel(const __bf
         }
         // (explicit sched_group_barrier / iglp_opt interleave requests were measured: equal or worse than
         //  hipcc's own schedule of this block -- DESIGN.md 3.4)
+        st_prev = st_cur; st_cur = st_next; st_next = st_next2;
     }
     reduce_tile(accP, K16_T - 1);
-    fold_stage(s_end - 1);
+    fold_stage(st_prev, s_begin < s_end);
     SOM_STAMP_END();
 
     if (GM) {

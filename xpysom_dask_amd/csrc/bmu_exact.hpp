@@ -213,7 +213,8 @@ __global__ __launch_bounds__(256) void exact_seed_kernel(const float* __restrict
                                                          const int* __restrict__ prev, const float* __restrict__ xsq,
                                                          const float* __restrict__ xerr, const float* __restrict__ wmax2,
                                                          const float* __restrict__ xmax2, const float* __restrict__ werr2,
-                                                         ExactBound eb, float* __restrict__ seed) {
+                                                         ExactBound eb, float* __restrict__ seed,
+                                                         float* __restrict__ tq = nullptr) {
     const int sub = threadIdx.x & 15;
     const long row = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
     const bool live = row < N;
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(256) void exact_seed_kernel(const float* __restrict
     const float dp = __builtin_fmaf(0.5f * S, t, S * sc.big);
     const float sd = dp + 0.5f * e * (1.0f + 1.0f / 1024.0f) + S * sc.bmag * 0x1p-21f;
     seed[r] = (sd > 0.0f && sd < 3.0e38f) ? sd : __builtin_inff();
+    if (tq != nullptr) tq[r] = t;                            // (exact_skip.hpp: the bound on the distance to this epoch's BMU)
 }
 
 // Round 1 of the two-round scheme: every row goes to the list of the group that holds its screen minimum (the screen
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_mfma_kernel(const float*
                                                                     const int* __restrict__ n_tiles_dev,
                                                                     const int* __restrict__ plist,
                                                                     unsigned long long* __restrict__ best64,
-        const int* __restrict__ perm) {
+        const int* __restrict__ perm, const int* __restrict__ order = nullptr) {
     constexpr int STAGE = fr_stage_bytes(KG);
     constexpr int PIECES = FR_UT * KG + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE stage: occupancy (three workgroups per CU), not a
@@ -356,12 +358,15 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_mfma_kernel(const float*
             __builtin_amdgcn_s_barrier();                  // everyone is done with the previous group's stage
             for (int p = wave; p < PIECES; p += 4) lds_dma_16(Wfst + (long)g * STAGE + (long)p * 1024 + lane * 16, smem + p * 1024);
         }
+        // (block skipping, exact_skip.hpp: the pass runs in sorted order, list entries are sorted positions: the row itself
+        //  sits at order[entry]; the merge key stays at the entry)
+        const int xrow = (order != nullptr && row >= 0) ? order[row] : row;
         float xf[4 * KG];
         if ((D & 3) == 0) {
 #pragma unroll
             for (int c = 0; c < 2 * KG; ++c) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (row >= 0 && 4 * c < D) v = *(const f32x4*)(X + (long)row * D + 4 * c);
+                if (row >= 0 && 4 * c < D) v = *(const f32x4*)(X + (long)xrow * D + 4 * c);
                 xf[2 * c] = half ? v[1] : v[0];
                 xf[2 * c + 1] = half ? v[3] : v[2];
             }
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_mfma_kernel(const float*
 #pragma unroll
             for (int s = 0; s < 4 * KG; ++s) {
                 const int k = 2 * s + half;
-                xf[s] = (row >= 0 && k < D) ? X[(long)row * D + k] : 0.0f;
+                xf[s] = (row >= 0 && k < D) ? X[(long)xrow * D + k] : 0.0f;
             }
         }
         row_next = entry(t + 1);                           // (in flight under this tile's MFMAs)
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_tiled_kernel(const float
                                                                      const int* __restrict__ n_tiles_dev,
                                                                      const int* __restrict__ plist,
                                                                      unsigned long long* __restrict__ best64,
-        const int* __restrict__ perm) {
+        const int* __restrict__ perm, const int* __restrict__ order = nullptr) {
     __shared__ __attribute__((aligned(16))) char ring[2][8192];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -535,15 +540,17 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_tiled_kernel(const float
 // that is not finite; an overflowed pass) -> the fallback list
 __global__ __launch_bounds__(256) void exact_finalize_kernel(const unsigned long long* __restrict__ best64, long N, int K,
                                                              const int* __restrict__ overflow, int* __restrict__ out,
-                                                             int* __restrict__ fb_list, int* __restrict__ fb_count) {
+                                                             int* __restrict__ fb_list, int* __restrict__ fb_count,
+                                                             const int* __restrict__ order = nullptr) {
     const long row = (long)blockIdx.x * 256 + threadIdx.x;
     if (row >= N) return;
+    const long orow = order != nullptr ? order[row] : row;   // (sorted pass: the key at position row belongs to row order[row])
     const unsigned long long k64 = best64[row];
     const uint32_t key = (uint32_t)(k64 >> 32), unit = (uint32_t)k64;
     const uint32_t bits = (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key;
     const bool finite = (bits & 0x7F800000u) != 0x7F800000u;
-    if (*overflow || k64 == ~0ull || !finite || unit >= (uint32_t)K) fb_list[atomicAdd(fb_count, 1)] = (int)row;
-    else out[row] = (int)unit;
+    if (*overflow || k64 == ~0ull || !finite || unit >= (uint32_t)K) fb_list[atomicAdd(fb_count, 1)] = (int)orow;
+    else out[orow] = (int)unit;
 }
 
 // fallback rows -> a dense block for the float32 kernel, and its ids back

@@ -24,6 +24,7 @@
 #include "bmu_bf16_tiled.hpp"
 #include "bmu_bf16_wide.hpp"
 #include "bmu_exact.hpp"
+#include "exact_skip.hpp"
 #include "bmu_f32.hpp"
 #include "bmu_f32_res.hpp"
 #include "bmu_f32_tiled.hpp"
@@ -95,9 +96,22 @@ struct som_handle {
         int* fb_count_host = nullptr;        // pinned
         hipEvent_t fb_ready = nullptr;       // recorded behind the counter's copy
         int64_t rows_total = 0, rows_fallback = 0, chunks = 0;   // som_exact_stats
+        int64_t blocks_run = 0, blocks_total = 0;                // som_exact_skip_stats: (256-row tile, group) blocks of the screens
         long pass_rows_override = 0;
         long stride_cap = 0;              // rows per pass the device had memory for (0: no allocation was ever refused)
         long pairs = 64;                  // capacity of a pass: (row, group) pairs per row on average (exact_reserve)
+        // block skipping (exact_skip.hpp): resident rows from their second epoch on, input_len <= 128
+        int skip_mode = 1;                // SOM_EXACT_SKIP: 0 off, 1 on for maps of >= 4096 units (default), 2 on for every map of >= 2 groups (tests)
+        bool skip_live = false;           // this launch plans and skips
+        long sk_stride = 0;               // rows the sorted-pass buffers hold
+        int *order = nullptr, *sk_keys = nullptr, *sk_keys2 = nullptr, *sk_vals = nullptr;
+        void* sk_tmp = nullptr; size_t sk_tmp_bytes = 0;
+        __bf16* Xb_s = nullptr;
+        float *xsq_s = nullptr, *xerr_s = nullptr, *seed_s = nullptr, *tq = nullptr, *tq_s = nullptr;
+        float *Cc = nullptr, *rg = nullptr, *csq = nullptr, *wn_c = nullptr, *cmax2 = nullptr;
+        char* Cst = nullptr; int n_cstages = 0;
+        unsigned long long* need = nullptr;
+        int *glist = nullptr, *gcnt = nullptr;
     } ex;
     int n_kchunks = 0;       // tiled: 64-feature chunks
     int n_ublocks = 0;       // tiled: unit blocks of tl_bn
@@ -961,7 +975,7 @@ int exact_reserve_stride(som_handle* h, long stride) {
     if (int rc = dev_alloc(h, &ex.tile_tab, (size_t)ex.max_tiles)) return rc;
     if (!ex.ctr) {
         if (int rc = dev_alloc(h, &ex.ctr, (size_t)3 * n_groups + 3)) return rc;
-        HIPCHK(h, hipHostMalloc((void**)&ex.fb_count_host, sizeof(int), hipHostMallocDefault));
+        HIPCHK(h, hipHostMalloc((void**)&ex.fb_count_host, 4 * sizeof(int), hipHostMallocDefault));   // fb_count | n_tiles | overflow | blocks run
     }
     ex.stride = stride;
     return 0;
@@ -969,7 +983,7 @@ int exact_reserve_stride(som_handle* h, long stride) {
 
 template <int KS32, class E>
 int exact_screen(som_handle* h, const __bf16* Xb, long n, unsigned long long* best64, const float* xsq, const float* xerr,
-                 const float* xmax2, const ExactBound& eb) {
+                 const float* xmax2, const ExactBound& eb, const float* seed, const int* glist, const int* gcnt) {
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
     // one pass on scaled half operands: a stage IS a group
     auto kern = bmu_bf16_k16_kernel<KS32, E, true>;
@@ -985,7 +999,7 @@ int exact_screen(som_handle* h, const __bf16* Xb, long n, unsigned long long* be
                      slots, parts, n_groups);
     kern<<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * K16_NW), lds, h->stream>>>(
         Xb, n, h->Wst, h->n_stages, h->K, best64, h->ex.gmin, h->ex.stride, h->ex.gflags, xsq, xerr, xmax2, h->wmax2, h->wmax2 + 1, eb,
-        h->ex.seed_live ? h->ex.seed : nullptr);
+        seed, glist, gcnt);
     return 0;
 }
 
@@ -1023,7 +1037,8 @@ int exact_screen_wide(som_handle* h, const __bf16* Ximg, long n, unsigned long l
 
 template <class E>
 int exact_screen_ks(som_handle* h, const __bf16* Xb, long n, unsigned long long* best64, const float* xsq, const float* xerr,
-                    const float* xmax2, const ExactBound& eb) {
+                    const float* xmax2, const ExactBound& eb, const float* seed, const int* glist = nullptr,
+                    const int* gcnt = nullptr) {
     if (h->wide) {
         switch (h->n_kchunks) {
 #define SOM_WIDE_CASE(k) case k: return exact_screen_wide<k, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb);
@@ -1036,12 +1051,113 @@ int exact_screen_ks(som_handle* h, const __bf16* Xb, long n, unsigned long long*
         return fail(h, "exact: no wide screen instance for this input_len");
     }
     switch (h->ks32) {
-    case 1: return exact_screen<1, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb);
-    case 2: return exact_screen<2, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb);
-    case 3: return exact_screen<3, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb);
-    case 4: return exact_screen<4, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb);
+    case 1: return exact_screen<1, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb, seed, glist, gcnt);
+    case 2: return exact_screen<2, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb, seed, glist, gcnt);
+    case 3: return exact_screen<3, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb, seed, glist, gcnt);
+    case 4: return exact_screen<4, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb, seed, glist, gcnt);
     }
     return fail(h, "exact: the screen kernel supports input_len <= 128");
+}
+
+
+// ---- block skipping (exact_skip.hpp): buffers, the centroid image, a pass's plan ------------------------------------------
+int exact_skip_reserve(som_handle* h, long stride) {
+    auto& ex = h->ex;
+    const long n_groups = cdiv(h->K, EX_GROUP);
+    if (!ex.Cc) {
+        ex.n_cstages = (int)cdiv(n_groups, K16_STAGE_UNITS);
+        if (int rc = dev_alloc(h, &ex.Cc, (size_t)n_groups * h->D)) return rc;
+        if (int rc = dev_alloc(h, &ex.rg, (size_t)n_groups)) return rc;
+        if (int rc = dev_alloc(h, &ex.csq, (size_t)n_groups)) return rc;
+        if (int rc = dev_alloc(h, &ex.wn_c, (size_t)n_groups)) return rc;
+        if (int rc = dev_alloc(h, &ex.cmax2, 2)) return rc;
+        if (int rc = dev_alloc(h, &ex.Cst, (size_t)ex.n_cstages * h->stage_bytes)) return rc;
+        HIPCHK(h, hipMemsetAsync(ex.Cst, 0, (size_t)ex.n_cstages * h->stage_bytes, h->stream));
+    }
+    if (stride <= ex.sk_stride) return 0;
+    void* old[] = {ex.order, ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.sk_tmp, ex.Xb_s, ex.xsq_s, ex.xerr_s, ex.seed_s, ex.tq, ex.tq_s,
+                   ex.need, ex.glist, ex.gcnt};
+    for (void* p : old) if (p) (void)hipFree(p);
+    ex.order = ex.sk_keys = ex.sk_keys2 = ex.sk_vals = nullptr; ex.sk_tmp = nullptr; ex.Xb_s = nullptr;
+    ex.xsq_s = ex.xerr_s = ex.seed_s = ex.tq = ex.tq_s = nullptr; ex.need = nullptr; ex.glist = ex.gcnt = nullptr;
+    ex.sk_stride = 0;
+    const long tiles = stride / SK_TILE;
+    if (int rc = dev_alloc(h, &ex.order, (size_t)stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.sk_keys, (size_t)stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.sk_keys2, (size_t)stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.sk_vals, (size_t)stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.Xb_s, (size_t)stride * h->dp)) return rc;
+    if (int rc = dev_alloc(h, &ex.xsq_s, (size_t)stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.xerr_s, (size_t)stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.seed_s, (size_t)stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.tq, (size_t)stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.tq_s, (size_t)stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.need, (size_t)tiles * ex.n_cstages)) return rc;
+    if (int rc = dev_alloc(h, &ex.glist, (size_t)tiles * n_groups)) return rc;
+    if (int rc = dev_alloc(h, &ex.gcnt, (size_t)tiles)) return rc;
+    size_t bytes = 0;
+    HIPCHK(h, rocprim::radix_sort_pairs(nullptr, bytes, ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.order, (size_t)stride, 0, 32, h->stream));
+    char* tmp = nullptr;
+    if (int rc = dev_alloc(h, &tmp, bytes + 256)) return rc;
+    ex.sk_tmp = tmp; ex.sk_tmp_bytes = bytes;
+    ex.sk_stride = stride;
+    return 0;
+}
+
+// centroids and radii of the groups of the current codebook, the centroids' scaled half image and initial accumulators
+template <class E>
+int exact_skip_centroids(som_handle* h, const float* xmax2) {
+    auto& ex = h->ex;
+    const int n_groups = (int)cdiv(h->K, EX_GROUP);
+    const float* Wsrc = h->ex_patch ? h->Wp : h->W;
+    exact_centroid_kernel<<<dim3((unsigned)n_groups), dim3(128), 0, h->stream>>>(Wsrc, h->K, h->D, ex.Cc, ex.rg);
+    row_sq_f32_kernel<<<dim3((unsigned)cdiv(n_groups, 256)), dim3(256), 0, h->stream>>>(ex.Cc, n_groups, h->D, ex.csq);
+    HIPCHK(h, hipMemsetAsync(ex.cmax2, 0, 2 * sizeof(float), h->stream));
+    exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(n_groups, 1024)), dim3(1024), 0, h->stream>>>(ex.csq, n_groups, ex.wn_c, ex.cmax2);
+    const dim3 tgrid((unsigned)cdiv((long)ex.n_cstages * K16_T, 4)), block(256);
+    switch (h->ks32) {
+    case 1: prep_w_exact_k16_kernel<1, E><<<tgrid, block, 0, h->stream>>>(ex.Cc, n_groups, h->D, ex.Cst, ex.n_cstages, ex.cmax2, ex.cmax2 + 1); break;
+    case 2: prep_w_exact_k16_kernel<2, E><<<tgrid, block, 0, h->stream>>>(ex.Cc, n_groups, h->D, ex.Cst, ex.n_cstages, ex.cmax2, ex.cmax2 + 1); break;
+    case 3: prep_w_exact_k16_kernel<3, E><<<tgrid, block, 0, h->stream>>>(ex.Cc, n_groups, h->D, ex.Cst, ex.n_cstages, ex.cmax2, ex.cmax2 + 1); break;
+    case 4: prep_w_exact_k16_kernel<4, E><<<tgrid, block, 0, h->stream>>>(ex.Cc, n_groups, h->D, ex.Cst, ex.n_cstages, ex.cmax2, ex.cmax2 + 1); break;
+    default: return fail(h, "exact: block skipping supports input_len <= 128");
+    }
+    const long units = (long)ex.n_cstages * h->stage_units;
+    prep_wsqh_kernel<<<dim3((unsigned)cdiv(units, 256)), dim3(256), 0, h->stream>>>(
+        ex.wn_c, n_groups, ex.cmax2, xmax2, ex.Cst, ex.n_cstages, h->stage_bytes, h->stage_units, nullptr, 0, 1);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// one pass: rows sorted by their last BMU's group, operands gathered in that order, the plan and the tiles' group lists
+template <class E>
+int exact_skip_plan(som_handle* h, const __bf16* Xb, long n, const float* xsq, const float* xerr, const int* prev, const float* xmax2,
+                    const ExactBound& eb) {
+    auto& ex = h->ex;
+    const int n_groups = (int)cdiv(h->K, EX_GROUP);
+    const long np = round_up(n, SK_TILE);
+    exact_sortkey_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(prev, h->ex_inv, n, h->K, ex.sk_keys, ex.sk_vals);
+    int bits = 1;
+    while ((1L << bits) < n_groups) ++bits;
+    size_t bytes = ex.sk_tmp_bytes;
+    HIPCHK(h, rocprim::radix_sort_pairs(ex.sk_tmp, bytes, ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.order, (size_t)n, 0, (unsigned)bits, h->stream));
+    const long pieces = np * (h->dp / 8);
+    exact_gather_sorted_kernel<<<dim3((unsigned)cdiv(pieces, 256)), dim3(256), 0, h->stream>>>(
+        ex.order, n, np, h->dp, Xb, xsq, xerr, ex.seed, ex.tq, ex.Xb_s, ex.xsq_s, ex.xerr_s, ex.seed_s, ex.tq_s);
+    // skipped (row block, group) pairs are never written by the screen: their masks must read empty
+    HIPCHK(h, hipMemsetAsync(ex.gflags, 0, (size_t)n_groups * (np / 64) * sizeof(unsigned long long), h->stream));
+    const size_t lds = 2 * (size_t)h->stage_bytes;
+    const dim3 grid((unsigned)(np / SK_TILE)), block(64 * K16_NW);
+#define SOM_PLAN_CASE(k) case k: exact_plan_kernel<k, E><<<grid, block, lds, h->stream>>>(ex.Xb_s, n, ex.Cst, ex.n_cstages, ex.rg, n_groups, \
+        ex.xsq_s, ex.xerr_s, ex.tq_s, xmax2, ex.cmax2, h->wmax2, h->wmax2 + 1, eb, ex.need, ex.skip_mode == 3 ? 1 : 0); break;
+    switch (h->ks32) {
+    SOM_PLAN_CASE(1) SOM_PLAN_CASE(2) SOM_PLAN_CASE(3) SOM_PLAN_CASE(4)
+    default: return fail(h, "exact: block skipping supports input_len <= 128");
+    }
+#undef SOM_PLAN_CASE
+    exact_lists_kernel<<<grid, dim3(64), 0, h->stream>>>(ex.need, ex.n_cstages, n_groups, ex.glist, ex.gcnt, ex.ctr + 2 * n_groups + 3);
+    HIPCHK(h, hipGetLastError());
+    return 0;
 }
 
 template <int KG>
@@ -1054,7 +1170,7 @@ int exact_rescore_kg(som_handle* h, const float* X, int n_groups) {
     // (twice the resident slots: the runs of tiles are uneven -- partial tiles, idle waves -- and finer runs balance them)
     const long grid = std::min<long>(ex.max_tiles, 2L * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
     kern<<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, h->D, h->Wfst, h->K, ex.tile_tab, ex.ctr + 2 * n_groups + 1, ex.plist,
-                                                             h->best64, h->ex_perm);
+                                                             h->best64, h->ex_perm, ex.skip_live ? ex.order : nullptr);
     return 0;
 }
 
@@ -1122,26 +1238,43 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     const ExactBound eb = exact_bound(h);
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
     const long chunk = std::min(exact_chunk_rows(h), ex.stride);
+    const bool two_round = ex.two_round >= 0 ? ex.two_round != 0 : h->wide;
+    // block skipping (exact_skip.hpp): where the seed lives (resident rows with last epoch's BMUs, <= 128 features), one round
+    ex.skip_live = ex.skip_mode > 0 && ex.seed_on && !h->wide && out == h->bmu && h->bmu_valid && !two_round &&
+                   (ex.skip_mode > 1 ? n_groups >= 2 : h->K >= 4096);
+    if (ex.skip_live) {
+        if (int rc = exact_skip_reserve(h, ex.stride)) return rc;
+        if (int rc = SOM_HALF(h, exact_skip_centroids, h, xmax2)) return rc;
+    }
     for (long r0 = 0; r0 < N; r0 += chunk) {
         const long n = std::min(chunk, N - r0);
         // (a pass behind one whose fallback rows went through the float32 kernel: its image back in patch order)
         if (h->wf_patch != h->ex_patch) if (int rc = refresh_codebook_operands(h, true, true)) return rc;
-        HIPCHK(h, hipMemsetAsync(ex.ctr, 0, (size_t)(2 * n_groups + 3) * sizeof(int), h->stream));
+        HIPCHK(h, hipMemsetAsync(ex.ctr, 0, (size_t)(2 * n_groups + 4) * sizeof(int), h->stream));
         // resident rows from their second epoch on: last epoch's BMU of every row caps the screen's keep threshold
         ex.seed_live = ex.seed_on && !h->wide && out == h->bmu && h->bmu_valid;
         if (ex.seed_live)
             exact_seed_kernel<<<dim3((unsigned)cdiv(n * 16, 256)), dim3(256), 0, h->stream>>>(
-                X + r0 * h->D, n, h->D, h->W, h->wsq, h->K, out + r0, xsq + r0, xerr + r0, h->wmax2, xmax2, h->wmax2 + 1, eb, ex.seed);
+                X + r0 * h->D, n, h->D, h->W, h->wsq, h->K, out + r0, xsq + r0, xerr + r0, h->wmax2, xmax2, h->wmax2 + 1, eb, ex.seed,
+                ex.skip_live ? ex.tq : nullptr);
+        // (sorted pass: the screen, the select kernel and the merge keys work on positions of the sorted order)
+        const float* p_xsq = xsq + r0; const float* p_xerr = xerr + r0; const float* p_seed = ex.seed_live ? ex.seed : nullptr;
+        const __bf16* p_Xb = Xb + r0 * h->dp;
+        const int* p_order = nullptr;
+        if (ex.skip_live) {
+            if (int rc = SOM_HALF(h, exact_skip_plan, h, Xb + r0 * h->dp, n, xsq + r0, xerr + r0, out + r0, xmax2, eb)) return rc;
+            p_xsq = ex.xsq_s; p_xerr = ex.xerr_s; p_seed = ex.seed_s; p_Xb = ex.Xb_s; p_order = ex.order;
+        }
         {
             Timed ts(h, SOM_K_SCREEN);
-            if (int rc = SOM_HALF(h, exact_screen_ks, h, Xb + r0 * h->dp, n, h->best64 + r0, xsq + r0, xerr + r0, xmax2, eb)) return rc;
+            if (int rc = SOM_HALF(h, exact_screen_ks, h, p_Xb, n, h->best64 + r0, p_xsq, p_xerr, xmax2, eb, p_seed,
+                                  ex.skip_live ? ex.glist : nullptr, ex.skip_live ? ex.gcnt : nullptr)) return rc;
         }
         const dim3 sel_grid((unsigned)cdiv(n, 64)), sel_block(64 * EX_SCAN_SPLIT);
         unsigned long long* best = h->best64 + r0;
         // two rounds beyond 128 features, where a (row, group) pair costs 64 x D flop AND a gather of the row's D floats
         // (configs[4]: 92.8 -> 87.8 ms per epoch); one round up to 128 features, where the three launches more cost more than
         // the pairs they save (256 x 256 x 128, 1 Mi rows: 15.5 vs 15.8 ms; 65 536 rows: +3 % in every map state)
-        const bool two_round = ex.two_round >= 0 ? ex.two_round != 0 : h->wide;
         if (two_round) {
             // round 1: every row against the group that holds its screen minimum; round 2: the groups within the ONE-unit
             // bound of that float32 score (exact_select_kernel<true>: 20-32 % fewer pairs than the one-round scheme on
@@ -1155,15 +1288,15 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
             if (int rc = exact_rescore_round(h, X + r0 * h->D, xsq + r0, best, ex.ctr + n_groups, nullptr)) return rc;
         } else {
             exact_select_kernel<false><<<sel_grid, sel_block, 0, h->stream>>>(
-                ex.gmin, ex.gflags, ex.stride, n_groups, n, best, xsq + r0, h->wmax2, xmax2, eb, xerr + r0, h->wmax2 + 1, ex.plist,
-                ex.ctr, ex.rowcnt, nullptr, ex.seed_live ? ex.seed : nullptr);
+                ex.gmin, ex.gflags, ex.stride, n_groups, n, best, p_xsq, h->wmax2, xmax2, eb, p_xerr, h->wmax2 + 1, ex.plist,
+                ex.ctr, ex.rowcnt, nullptr, p_seed);
             if (int rc = exact_rescore_round(h, X + r0 * h->D, xsq + r0, best, nullptr, nullptr)) return rc;
         }
         exact_finalize_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(
-            best, n, h->K, ex.ctr + 2 * n_groups + 2, out + r0, ex.fb_list, ex.ctr + 2 * n_groups);
+            best, n, h->K, ex.ctr + 2 * n_groups + 2, out + r0, ex.fb_list, ex.ctr + 2 * n_groups, p_order);
         HIPCHK(h, hipGetLastError());
         // rows the scheme could not settle (normally none): the float32 kernel itself
-        HIPCHK(h, hipMemcpyAsync(ex.fb_count_host, ex.ctr + 2 * n_groups, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(ex.fb_count_host, ex.ctr + 2 * n_groups, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         if (h->early.armed && !h->early.done && out == h->bmu && r0 + n >= N) {
             // the last pass of a resident epoch: the host waits for the counter only (an event behind the copy); what the
             // update needs besides the BMUs is queued behind it and runs while the host wakes up
@@ -1176,8 +1309,10 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         } else {
             HIPCHK(h, hipStreamSynchronize(h->stream));
         }
-        const int n_fb = *ex.fb_count_host;
+        const int n_fb = ex.fb_count_host[0];
         ex.rows_total += n; ex.rows_fallback += n_fb; ex.chunks += 1;
+        ex.blocks_total += cdiv(n, SK_TILE) * n_groups;
+        ex.blocks_run += ex.skip_live ? ex.fb_count_host[3] : cdiv(n, SK_TILE) * n_groups;
         if (n_fb < 0 || n_fb > n) return fail(h, "exact: fallback counter out of range");
         if (n_fb > 0) {
             if (n_fb > ex.fb_cap) {
@@ -1759,6 +1894,7 @@ int som_create(const som_config* cfg, som_handle** out) {
         if (const char* e = std::getenv("SOM_EXACT_PASS_ROWS")) h->ex.pass_rows_override = std::atol(e);
         if (const char* e = std::getenv("SOM_EXACT_TWO_ROUND")) h->ex.two_round = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("SOM_EXACT_SEED")) h->ex.seed_on = std::atoi(e) != 0;
+        if (const char* e = std::getenv("SOM_EXACT_SKIP")) h->ex.skip_mode = std::atoi(e);
         if (const char* e = std::getenv("SOM_ASYNC_COPIES")) h->async_copies = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_FUSE_MERGE")) h->fuse_merge_prep = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_COUNTING_SORT")) h->counting_sort = std::atoi(e) != 0;
@@ -1825,7 +1961,9 @@ void som_destroy(som_handle* h) {
         for (void* b : vb) if (b) (void)hipFree(b);
     }
     {
-        void* eb[] = {h->ex.gmin, h->ex.gflags, h->ex.rowcnt, h->ex.rowarg, h->ex.seed, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab};
+        void* eb[] = {h->ex.gmin, h->ex.gflags, h->ex.rowcnt, h->ex.rowarg, h->ex.seed, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab,
+                      h->ex.order, h->ex.sk_keys, h->ex.sk_keys2, h->ex.sk_vals, h->ex.sk_tmp, h->ex.Xb_s, h->ex.xsq_s, h->ex.xerr_s, h->ex.seed_s,
+                      h->ex.tq, h->ex.tq_s, h->ex.Cc, h->ex.rg, h->ex.csq, h->ex.wn_c, h->ex.cmax2, h->ex.Cst, h->ex.need, h->ex.glist, h->ex.gcnt};
         for (void* b : eb) if (b) (void)hipFree(b);
         if (h->ex.fb_count_host) (void)hipHostFree(h->ex.fb_count_host);
         if (h->ex.fb_ready) (void)hipEventDestroy(h->ex.fb_ready);
@@ -2577,6 +2715,12 @@ int som_exact_stats(som_handle* h, int64_t* rows, int64_t* rows_fallback, int64_
     if (rows) *rows = h->ex.rows_total;
     if (rows_fallback) *rows_fallback = h->ex.rows_fallback;
     if (passes) *passes = h->ex.chunks;
+    return 0;
+}
+
+int som_exact_skip_stats(som_handle* h, int64_t* blocks_run, int64_t* blocks_total) {
+    if (!h || !blocks_run || !blocks_total) return 1;
+    *blocks_run = h->ex.blocks_run; *blocks_total = h->ex.blocks_total;
     return 0;
 }
 

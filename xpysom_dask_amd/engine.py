@@ -297,6 +297,12 @@ class HipEngine:
         self._check(self._lib.som_exact_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def exact_skip_stats(self):
+        """precision 'exact': (blocks the screens ran, blocks of full scans) so far -- block skipping's executed share."""
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self._lib.som_exact_skip_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def exact_last_counts(self, n):
         """precision 'exact': candidate groups per row in the last screen pass (first n rows)."""
         out = np.empty((int(n),), dtype=np.int32)
