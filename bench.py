@@ -293,12 +293,17 @@ def main():
         # is taken in a separate pass below.
         eng.profile_reset()
         eng.profile_enable("bmu")
+        sk0 = eng.exact_skip_stats() if precision == "exact" else (0, 0)
         t0 = time.perf_counter()
         for t in range(args.warmup, total):
             D.epoch(eng, sched[t][0], sched[t][1], True)
         fence(eng)
         dt = time.perf_counter() - t0
         eng.profile_enable(False)
+        sk1 = eng.exact_skip_stats() if precision == "exact" else (0, 0)
+        # block skipping (csrc/exact_skip.hpp): the share of the distance GEMM's (256-row tile, 64-unit group) blocks the
+        # screens of the timed epochs actually ran
+        eng.executed_share = (sk1[0] - sk0[0]) / (sk1[1] - sk0[1]) if sk1[1] > sk0[1] else 1.0
         if dist is not None:
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -306,6 +311,8 @@ def main():
         return eng, dt
 
     eng, dt = timed_run(args.precision)
+    head_share = getattr(eng, "executed_share", 1.0)
+    w_after_timed = eng.get_weights() if args.precision == "exact" else None
     bmu_ms, bmu_n = eng.profile_get("bmu")
     scr_ms, scr_n = eng.profile_get("screen")
     # per-kernel-family breakdown: the same epochs once more (the same schedule entries, at most 20), untimed, every
@@ -349,6 +356,23 @@ def main():
         eng = HipEngine(MAP_X, MAP_Y, FEATURES, precision=args.precision, device=dev, distance=wl["distance"],
                         neighborhood=wl["neighborhood"])
 
+    # ... and the headline mode itself with every block of the distance GEMM run (SOM_EXACT_SKIP=0): what the same kernels do
+    # when nothing can be skipped (the first epoch on fresh rows; data without structure)
+    full_scan = None
+    if args.precision == "exact" and exact_has_screen(FEATURES, MAP_X * MAP_Y, wl["distance"]) and not args.no_throughput_mode \
+            and head_share < 1.0:
+        old_env = os.environ.get("SOM_EXACT_SKIP")
+        os.environ["SOM_EXACT_SKIP"] = "0"
+        e_f, dt_f = timed_run("exact")
+        if old_env is None:
+            del os.environ["SOM_EXACT_SKIP"]
+        else:
+            os.environ["SOM_EXACT_SKIP"] = old_env
+        f_ms, f_n = e_f.profile_get("screen")
+        full_scan = {"SOM_EXACT_SKIP": 0, "value": total_rows / (dt_f / args.steps), "unit": "samples/sec/epoch",
+                     "ms_per_step": 1e3 * dt_f / args.steps, "avg_launch_ms": f_ms / max(1, f_n), "launches": f_n,
+                     "codebook_equal_to_headline_run": bool(np.array_equal(e_f.get_weights(), w_after_timed))}
+        e_f.close()
     kernel_name = kernel_name_for(args.precision, FEATURES, MAP_X * MAP_Y)
     peak = MFMA_F32_PEAK_TFLOPS if args.precision == "f32" else MFMA_BF16_PEAK_TFLOPS
     KD2 = 2.0 * (MAP_X * MAP_Y) * FEATURES            # 2*K*D flop per sample
@@ -372,14 +396,17 @@ def main():
         eng.sync()
         eng.profile_reset()
         eng.profile_enable("bmu")
+        bs0 = eng.exact_skip_stats() if args.precision == "exact" else (0, 0)
         tb = time.perf_counter()
         for t in range(reps):
             D.epoch(eng, sched[t % total][0], sched[t % total][1], True)
         eng.sync()
         tb = time.perf_counter() - tb
         eng.profile_enable(False)
+        bs1 = eng.exact_skip_stats() if args.precision == "exact" else (0, 0)
+        b_share = (bs1[0] - bs0[0]) / (bs1[1] - bs0[1]) if bs1[1] > bs0[1] else 1.0
         b_avg, b_n = kernel_ms(eng)
-        b_ach = KD2 * NORTH_STAR_BATCH / (b_avg * 1e-3) / 1e12
+        b_ach = KD2 * NORTH_STAR_BATCH * b_share / (b_avg * 1e-3) / 1e12      # EXECUTED flops
         eng.profile_reset()
         eng.profile_enable(True)                               # breakdown pass (see above)
         for t in range(10):
@@ -390,7 +417,7 @@ def main():
         if args.precision == "exact":
             by_k["bmu_of_which_screen"] = eng.profile_get("screen")[0] / 10
         batch = {"rows": NORTH_STAR_BATCH, "avg_launch_ms": b_avg, "launches": b_n, "achieved": b_ach,
-                 "frac": b_ach / peak, "epoch_ms": 1e3 * tb / reps, "ms_per_epoch_by_kernel": by_k}
+                 "frac": b_ach / peak, "executed_share": b_share, "epoch_ms": 1e3 * tb / reps, "ms_per_epoch_by_kernel": by_k}
 
     # Every precision mode on the same batch: speed AND how far its BMUs / its trained codebook are from float32's --
     # on the seeded codebook (the easiest state a SOM is ever in), on the smooth maps of the early schedule (where a
@@ -517,9 +544,13 @@ def main():
         k_avg = (scr_ms / max(1, scr_n)) if is_exact else (bmu_ms / max(1, bmu_n))
         k_n = scr_n if is_exact else bmu_n
         rows_launch = my_rows * (bmu_n / max(1, k_n)) if is_exact else my_rows     # (the exact mode screens in passes)
-        flops_launch = KD2 * rows_launch
+        share = head_share if is_exact else 1.0
+        flops_launch = KD2 * rows_launch * share
         achieved = flops_launch / (k_avg * 1e-3) / 1e12
-        # algorithmic flops against the peak of the pipe the kernel runs on; bf16x3 executes 3x them
+        # algorithmic flops against the peak of the pipe the kernel runs on; bf16x3 executes 3x them.
+        # Block skipping: the flops of the blocks the screens RAN (the kernel's quality), never the full scan's: a launch
+        # that proves most blocks empty is fast because it does less, not because the pipe runs faster -- the full scan's
+        # algorithmic rate is reported beside it for what it is (rows per second are `value`)
         build_hash = B.built_hash()
         tr = pmc_traffic(args.workload, my_rows, args.precision, kernel_name, build_hash)
         out = {
@@ -552,6 +583,9 @@ def main():
                                              "same_build": tr["build"] == build_hash} if tr else None),
                          "avg_launch_ms": k_avg, "launches": k_n, "rows_per_launch": rows_launch,
                          "flops_per_launch": flops_launch,
+                         "executed_share_of_the_distance_gemm": share,
+                         "full_scan_flops_per_launch": KD2 * rows_launch,
+                         "full_scan_equivalent_tflops": KD2 * rows_launch / (k_avg * 1e-3) / 1e12,
                          "whole_bmu_search_ms_per_step": bmu_ms / max(1, bmu_n)},
             "ms_per_step_by_kernel": parts,
             "ms_per_step_by_kernel_pass": "separate untimed pass of %d epochs after the timed region (events around every kernel family)" % nb,
@@ -562,6 +596,9 @@ def main():
                                   "rows_through_float32_fallback_kernel": exact_stats[1], "screen_passes": exact_stats[2]}
         if thr is not None:
             out["throughput_mode"] = thr
+        if full_scan is not None:
+            full_scan["roofline_frac"] = KD2 * rows_launch / (full_scan["avg_launch_ms"] * 1e-3) / 1e12 / peak
+            out["without_block_skipping"] = full_scan
         if probe is not None:
             out["strong_scaling_probe"] = probe
         if batch is not None:

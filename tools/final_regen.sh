@@ -11,6 +11,7 @@ tools/pmc_all.sh ${TAG}_c5 250000 --workload c5 > gpurun_out/${TAG}_pmc_c5.log 2
 cp gpurun_out/${TAG}_pmc_traffic_rows1048576.json gpurun_out/${TAG}_pmc_traffic_rows65536.json profiles/
 cp gpurun_out/${TAG}_bf16_pmc_traffic_rows1048576.json gpurun_out/${TAG}_c5_pmc_traffic_rows250000.json profiles/
 cp gpurun_out/${TAG}_kernel_stats_rows1048576.csv gpurun_out/${TAG}_kernel_stats_rows65536.csv gpurun_out/${TAG}_c5_kernel_stats_rows250000.csv profiles/
+cp gpurun_out/${TAG}_dispatches_rows1048576.csv gpurun_out/${TAG}_dispatches_rows65536.csv profiles/
 python3 bench.py > gpurun_out/${TAG}_bench_c3.json
 python3 bench.py --precision bf16 --no-modes > gpurun_out/${TAG}_bench_c3_bf16.json
 python3 bench.py --workload c5 > gpurun_out/${TAG}_bench_c5.json

@@ -5,7 +5,9 @@
 # tools/pmc_report.py folds them into gpurun_out/<tag>_pmc_rows<rows>.json (+ the kernel stats csv).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=$1; ROWS=$2; shift 2
-ARGS="--rows $ROWS --steps 3 --warmup 1 --no-cpu-baseline --no-batch65536 --no-throughput-mode $@"
+# (the bench line's own steps and warm-up: under block skipping a launch's duration depends on the epoch it serves)
+STEPS=${PMC_STEPS:-10}; WARM=${PMC_WARMUP:-2}
+ARGS="--rows $ROWS --steps $STEPS --warmup $WARM --no-cpu-baseline --no-batch65536 --no-throughput-mode --no-modes $@"
 OUT=gpurun_out/pmc_${TAG}_${ROWS}
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/trace.log 2>&1 &&
@@ -14,4 +16,4 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/fetch.log 2>&1 &&
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py $ARGS > $OUT/write.log 2>&1 &&
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $OUT/tcc -- python3 bench.py $ARGS > $OUT/tcc.log 2>&1 &&
-python3 tools/pmc_report.py $OUT $TAG $ROWS "$@"
+PMC_STEPS=$STEPS PMC_WARMUP=$WARM python3 tools/pmc_report.py $OUT $TAG $ROWS "$@"

@@ -68,10 +68,34 @@ for f in glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_stats.csv"), re
     stats_copy = os.path.join("gpurun_out", "%s_kernel_stats_rows%d.csv" % (tag, rows))
     open(stats_copy, "w").write(open(f).read())
 
+# the dominant kernels dispatch by dispatch (kernel trace): under block skipping a launch's duration depends on the epoch it
+# serves, so the average over the bench line's TIMED epochs (dispatches warmup .. warmup + steps of the run; the untimed
+# breakdown pass follows them) is what agrees with the line's avg_launch_ms, not the average over every launch of the process
+steps, warm = int(os.environ.get("PMC_STEPS", "10")), int(os.environ.get("PMC_WARMUP", "2"))
+timed = {}
+for f in glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if k.startswith("bmu_") or k.startswith("exact_rescore") or k.startswith("exact_select") or k.startswith("exact_plan"):
+            per[k].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    with open(os.path.join("gpurun_out", "%s_dispatches_rows%d.csv" % (tag, rows)), "w") as g:
+        g.write("kernel,dispatch,duration_us,timed_region\n")
+        for k, v in sorted(per.items()):
+            v.sort()
+            n_ep = steps + warm
+            per_epoch = max(1, round(len(v) / (n_ep + min(steps, 20)))) if len(v) >= n_ep else 1
+            for i, (_, d) in enumerate(v):
+                ep = i // per_epoch
+                g.write("%s,%d,%.1f,%d\n" % (k.replace(",", ";"), i, d, int(warm <= ep < n_ep)))
+            sel = [d for i, (_, d) in enumerate(v) if warm <= i // per_epoch < n_ep]
+            if sel:
+                timed[k] = {"timed_dispatches": len(sel), "timed_avg_us": sum(sel) / len(sel), "per_epoch": per_epoch}
+
 from xpysom_dask_amd import build as B  # noqa: E402
 lib = os.environ.get("SOM_LIB_PATH")
-res = {"note": "rocprofv3 --pmc passes (one counter group per pass) of `python3 bench.py --rows %d --steps 3 --warmup 1 "
-               "--no-cpu-baseline --no-batch65536 --no-throughput-mode %s`; per-dispatch means; durations from a separate --kernel-trace pass. "
+res = {"note": "rocprofv3 --pmc passes (one counter group per pass) of `python3 bench.py --rows %d --steps " + str(steps) + " --warmup " + str(warm) + " "
+               "--no-cpu-baseline --no-batch65536 --no-throughput-mode --no-modes %s`; per-dispatch means; durations from a separate --kernel-trace pass. "
                "FETCH_SIZE / WRITE_SIZE are KB; on gfx950 a wide coalesced read is tallied at half its bytes "
                "(MI355X_MICROARCH.md, HBM): fabric bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024; Infinity-Cache hits "
                "are included, so this bounds HBM traffic from above." % (rows, " ".join(extra)),
@@ -85,6 +109,8 @@ for k, cs in sorted(counters.items()):
     d["dispatches"] = max(len(v) for v in cs.values())
     if k in dur:
         d["duration_us"] = dur[k]["avg_us"]
+    if k in timed:
+        d.update(timed[k])
     if "GRBM_GUI_ACTIVE" in d and "SQ_VALU_MFMA_BUSY_CYCLES" in d and d["GRBM_GUI_ACTIVE"] > 0:
         d["mfma_busy"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
     if "GRBM_GUI_ACTIVE" in d and k in dur and dur[k]["avg_us"] > 0:
