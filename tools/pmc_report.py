@@ -94,11 +94,11 @@ for f in glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_trace.csv"), re
 
 from xpysom_dask_amd import build as B  # noqa: E402
 lib = os.environ.get("SOM_LIB_PATH")
-res = {"note": "rocprofv3 --pmc passes (one counter group per pass) of `python3 bench.py --rows %d --steps " + str(steps) + " --warmup " + str(warm) + " "
+res = {"note": "rocprofv3 --pmc passes (one counter group per pass) of `python3 bench.py --rows %d --steps %d --warmup %d "
                "--no-cpu-baseline --no-batch65536 --no-throughput-mode --no-modes %s`; per-dispatch means; durations from a separate --kernel-trace pass. "
                "FETCH_SIZE / WRITE_SIZE are KB; on gfx950 a wide coalesced read is tallied at half its bytes "
                "(MI355X_MICROARCH.md, HBM): fabric bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024; Infinity-Cache hits "
-               "are included, so this bounds HBM traffic from above." % (rows, " ".join(extra)),
+               "are included, so this bounds HBM traffic from above." % (rows, steps, warm, " ".join(extra)),
        "workload": "c3" if "--workload" not in extra else extra[extra.index("--workload") + 1],
        "rows_per_launch": rows,
        "precision": extra[extra.index("--precision") + 1] if "--precision" in extra else
