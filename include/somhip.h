@@ -62,7 +62,10 @@ enum { SOM_TOPO_RECTANGULAR = 0, SOM_TOPO_HEXAGONAL = 1 };
  *           screen's rigorous (partly measured) error bound cannot rule out; rows it cannot vouch for (NaN / infinite
  *           values, a pass with more candidate pairs than re-scoring is worth) go to the F32 kernel.  Euclidean distance
  *           with input_len <= 128; euclidean and cosine with 128 < input_len <= 800 on maps of >= 4096 units; other
- *           configurations run the F32 kernels under this id (which are the exact mode by definition).  Everything but
+ *           configurations run the F32 kernels under this id (which are the exact mode by definition).  Resident rows,
+ *           from their second epoch on (input_len <= 128, maps of >= 4096 units): the screen skips the (256-row tile,
+ *           group) blocks a centroid-and-radius bound around last epoch's BMU proves empty (csrc/exact_skip.hpp;
+ *           SOM_EXACT_SKIP=0 runs every block) -- the ids do not change, the time does, by the data.  Everything but
  *           the BMU search (update, merge, quantization) is as in F32. */
 enum { SOM_PREC_F32 = 0, SOM_PREC_BF16 = 1, SOM_PREC_BF16X3 = 2,
        SOM_PREC_F16 = 3,      /* the bf16 path on IEEE half operands: 11 significant bits instead of 8, |value| <= 65504 */

@@ -31,6 +31,9 @@
 //                strips of map rows.  Steps 1-3 work on positions; within a group positions ascend with unit ids, and
 //                the re-score kernels translate a tile's winner to its UNIT id before the merge, so the first minimum
 //                in unit order still wins.  Step 4's float32 kernel wants the units' own order and rebuilds its image.
+//   skipping     resident rows, from their second epoch on: exact_skip.hpp plans, per 256-row tile of rows sorted by their
+//                last BMU's patch, which groups step 1 runs at all (centroid / radius bound against the distance to last
+//                epoch's BMU); a group not run is a group outside every row's window.
 //
 // Error bound (euclidean, input_len <= 128).  u = 2^-24, A(n,k) = sum_d |x_d w_kd| <= |x_n| max_k|w_k|.
 //   float32 kernel:  |c - x.w| <= gamma_D A (fma chain of D terms), s = fl(wsq - 2c):
