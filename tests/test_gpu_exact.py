@@ -649,3 +649,23 @@ def test_exact_block_skipping_with_nan_units_in_the_codebook(monkeypatch):
         f.epoch_merge(); x.epoch_merge()
     assert np.isnan(f.get_weights()).any()
     f.close(); x.close()
+
+
+def test_exact_block_skipping_without_memory_for_it_runs_every_block(monkeypatch):
+    """The sorted pass needs buffers of its own; a device that refuses them (SOM_EXACT_DEBUG_REFUSE_SKIP: test hook) gets
+    the full scan -- same ids, no error."""
+    monkeypatch.setenv("SOM_EXACT_SKIP", "2")
+    monkeypatch.setenv("SOM_EXACT_DEBUG_REFUSE_SKIP", "1")
+    X, Y, D, n = 32, 32, 16, 4000
+    data = O.gaussian_blobs(n, D, seed=3)
+    w = O.default_codebook(X, Y, D, 2).astype(F32)
+    f = engine(X, Y, D, precision="f32"); x = engine(X, Y, D, precision="exact")
+    for e in (f, x):
+        e.set_weights(w); e.set_data(data)
+    for sig in (4.0, 2.0, 1.0):
+        f.epoch_accumulate(sig, 0.4, True); x.epoch_accumulate(sig, 0.4, True)
+        assert np.array_equal(f.epoch_fetch()[2], x.epoch_fetch()[2])
+        f.epoch_merge(); x.epoch_merge()
+    run, total = x.exact_skip_stats()
+    assert run == total > 0
+    f.close(); x.close()

@@ -23,6 +23,7 @@
 namespace somhip {
 
 constexpr int SK_TILE = K16_WG_SAMPLES;   // rows per plan / screen workgroup tile
+static_assert(K16_STAGE_UNITS == 64, "block skipping: a stage of the resident screen is one 64-unit group, a plan word one stage of centroids");
 
 // centroid and radius of every group of 64 consecutive units of W (patch order: a patch of the map).  One block per group.
 __global__ __launch_bounds__(128) void exact_centroid_kernel(const float* __restrict__ W, int K, int D, float* __restrict__ C,

@@ -1063,6 +1063,8 @@ int exact_screen_ks(som_handle* h, const __bf16* Xb, long n, unsigned long long*
 // ---- block skipping (exact_skip.hpp): buffers, the centroid image, a pass's plan ------------------------------------------
 int exact_skip_reserve(som_handle* h, long stride) {
     auto& ex = h->ex;
+    // TEST HOOK (tests/test_gpu_exact.py): behave as a device without memory for the sorted pass
+    if (std::getenv("SOM_EXACT_DEBUG_REFUSE_SKIP")) return fail(h, "exact: block-skipping scratch refused (test hook)");
     const long n_groups = cdiv(h->K, EX_GROUP);
     if (!ex.Cc) {
         ex.n_cstages = (int)cdiv(n_groups, K16_STAGE_UNITS);
@@ -1242,10 +1244,15 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     // block skipping (exact_skip.hpp): where the seed lives (resident rows with last epoch's BMUs, <= 128 features), one round
     ex.skip_live = ex.skip_mode > 0 && ex.seed_on && !h->wide && out == h->bmu && h->bmu_valid && !two_round &&
                    (ex.skip_mode > 1 ? n_groups >= 2 : h->K >= 4096);
-    if (ex.skip_live) {
-        if (int rc = exact_skip_reserve(h, ex.stride)) return rc;
-        if (int rc = SOM_HALF(h, exact_skip_centroids, h, xmax2)) return rc;
+    if (ex.skip_live && exact_skip_reserve(h, ex.stride) != 0) {
+        // no memory for the sorted pass's buffers: every block runs, from now on (the ids are the same either way)
+        (void)hipGetLastError();
+        if (h->debug) std::fprintf(stderr, "[somhip] exact: block skipping off (%s)\n", h->err.c_str());
+        h->err.clear();
+        ex.skip_live = false; ex.skip_mode = 0;
     }
+    if (ex.skip_live)
+        if (int rc = SOM_HALF(h, exact_skip_centroids, h, xmax2)) return rc;
     for (long r0 = 0; r0 < N; r0 += chunk) {
         const long n = std::min(chunk, N - r0);
         // (a pass behind one whose fallback rows went through the float32 kernel: its image back in patch order)
