@@ -359,8 +359,9 @@ def main():
     # ... and the headline mode itself with every block of the distance GEMM run (SOM_EXACT_SKIP=0): what the same kernels do
     # when nothing can be skipped (the first epoch on fresh rows; data without structure)
     full_scan = None
+    # (the condition is the same on every rank -- the run below holds collectives: never a rank's own measured share)
     if args.precision == "exact" and exact_has_screen(FEATURES, MAP_X * MAP_Y, wl["distance"]) and not args.no_throughput_mode \
-            and head_share < 1.0:
+            and FEATURES <= 128 and MAP_X * MAP_Y >= 4096 and os.environ.get("SOM_EXACT_SKIP", "1") != "0":
         old_env = os.environ.get("SOM_EXACT_SKIP")
         os.environ["SOM_EXACT_SKIP"] = "0"
         e_f, dt_f = timed_run("exact")
