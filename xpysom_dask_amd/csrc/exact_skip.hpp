@@ -25,31 +25,33 @@ namespace somhip {
 constexpr int SK_TILE = K16_WG_SAMPLES;   // rows per plan / screen workgroup tile
 static_assert(K16_STAGE_UNITS == 64, "block skipping: a stage of the resident screen is one 64-unit group, a plan word one stage of centroids");
 
-// centroid and radius of every group of 64 consecutive units of W (patch order: a patch of the map).  One block per group.
+// centroid and radius of every group of 64 consecutive units of W (patch order: a patch of the map).  One block (two waves)
+// per group, thread d <-> feature d in both passes (rows read whole: coalesced); a unit's |w - c|^2 is a wave reduction.
 __global__ __launch_bounds__(128) void exact_centroid_kernel(const float* __restrict__ W, int K, int D, float* __restrict__ C,
                                                              float* __restrict__ rg) {
-    __shared__ float c[128];
-    __shared__ float d2[64];
-    const int g = blockIdx.x, tid = threadIdx.x;
+    __shared__ float part[2][64];
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int u0 = g * 64, cnt = min(64, K - u0);
+    float c = 0.0f;
     if (tid < D) {
-        float s = 0.0f;
-        for (int k = 0; k < cnt; ++k) s += W[(long)(u0 + k) * D + tid];
-        s /= (float)cnt;
-        c[tid] = s;
-        C[(long)g * D + tid] = s;
+        for (int k = 0; k < cnt; ++k) c += W[(long)(u0 + k) * D + tid];
+        c /= (float)cnt;
+        C[(long)g * D + tid] = c;
     }
-    __syncthreads();
-    if (tid < 64) {
+    for (int k = 0; k < cnt; ++k) {
         float q = 0.0f;
-        if (tid < cnt)
-            for (int d = 0; d < D; ++d) { const float df = W[(long)(u0 + tid) * D + d] - c[d]; q = __builtin_fmaf(df, df, q); }
-        d2[tid] = q;
+        if (tid < D) { const float df = W[(long)(u0 + k) * D + tid] - c; q = df * df; }
+        q = wave_sum(q);                                      // (a NaN anywhere in the unit: NaN)
+        if (lane == 0) part[wave][k] = q;
     }
     __syncthreads();
     if (tid == 0) {
         float m = 0.0f;
-        for (int k = 0; k < 64; ++k) m = d2[k] > m || !(d2[k] == d2[k]) ? d2[k] : m;   // (a NaN unit: a NaN radius, the group is never skipped)
+        for (int k = 0; k < cnt; ++k) {
+            const float d2 = part[0][k] + part[1][k];
+            m = (d2 > m || !(d2 == d2)) ? d2 : m;             // (a NaN unit: a NaN radius, the group is never skipped)
+        }
+        // (the sum of squares in float32, any order: relative error <= 128 * 2^-24; the margin covers it many times over)
         rg[g] = __builtin_sqrtf(m) * (1.0f + 1.0f / 512.0f) + 1.0e-30f;
     }
 }
@@ -149,18 +151,23 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16
     }
     const float hS = 0.5f * S * (1.0f + 1.0f / 1024.0f);
 
-    if (n_cstages > 0)
-        for (int p = wave; p < PIECES; p += K16_NW) lds_dma_16(Cst + (long)p * 1024 + lane * 16, smem + p * 1024);
-    for (int s = 0; s < n_cstages; ++s) {
+    // (gridDim.y workgroups share a tile's centroid stages: few tiles -- a batch of 65 536 rows is 256 -- would otherwise be
+    //  one workgroup per CU walking all the stages alone)
+    const int s_begin = (int)((long)n_cstages * blockIdx.y / gridDim.y);
+    const int s_end = (int)((long)n_cstages * (blockIdx.y + 1) / gridDim.y);
+    if (s_begin < s_end)
+        for (int p = wave; p < PIECES; p += K16_NW)
+            lds_dma_16(Cst + (long)s_begin * STAGE + (long)p * 1024 + lane * 16, smem + p * 1024);
+    for (int s = s_begin; s < s_end; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + 1 < n_cstages) {
+        if (s + 1 < s_end) {
             const char* src = Cst + (long)(s + 1) * STAGE;
-            char* dst = smem + ((s + 1) & 1) * STAGE;
+            char* dst = smem + ((s + 1 - s_begin) & 1) * STAGE;
             for (int p = wave; p < PIECES; p += K16_NW) lds_dma_16(src + (long)p * 1024 + lane * 16, dst + p * 1024);
         }
-        const char* st = smem + (s & 1) * STAGE;
+        const char* st = smem + ((s - s_begin) & 1) * STAGE;
         const float* wq = (const float*)(st + K16_T * KS32 * 1024);
         unsigned long long mine = 0ull;                       // bit (16 t16 + 4 quad + r) <-> centroid of that place in the stage
 #pragma unroll

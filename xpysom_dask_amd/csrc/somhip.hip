@@ -1150,7 +1150,10 @@ int exact_skip_plan(som_handle* h, const __bf16* Xb, long n, const float* xsq, c
     HIPCHK(h, hipMemsetAsync(ex.gflags, 0, (size_t)n_groups * (np / 64) * sizeof(unsigned long long), h->stream));
     const size_t lds = 2 * (size_t)h->stage_bytes;
     const dim3 grid((unsigned)(np / SK_TILE)), block(64 * K16_NW);
-#define SOM_PLAN_CASE(k) case k: exact_plan_kernel<k, E><<<grid, block, lds, h->stream>>>(ex.Xb_s, n, ex.Cst, ex.n_cstages, ex.rg, n_groups, \
+    // (few tiles: their centroid stages split over up to four workgroups each, so that the plan fills the chip)
+    const long want = (1024 + (np / SK_TILE) - 1) / (np / SK_TILE);
+    const dim3 pgrid((unsigned)(np / SK_TILE), (unsigned)std::max<long>(1, std::min<long>({want, 4L, (long)ex.n_cstages})));
+#define SOM_PLAN_CASE(k) case k: exact_plan_kernel<k, E><<<pgrid, block, lds, h->stream>>>(ex.Xb_s, n, ex.Cst, ex.n_cstages, ex.rg, n_groups, \
         ex.xsq_s, ex.xerr_s, ex.tq_s, xmax2, ex.cmax2, h->wmax2, h->wmax2 + 1, eb, ex.need, ex.skip_mode == 3 ? 1 : 0); break;
     switch (h->ks32) {
     SOM_PLAN_CASE(1) SOM_PLAN_CASE(2) SOM_PLAN_CASE(3) SOM_PLAN_CASE(4)
