@@ -558,9 +558,11 @@ def test_exact_block_skipping_trains_the_float32_map(monkeypatch, X, Y, D, n, pa
     f.close(); x.close()
 
 
-def test_exact_block_skipping_skips_most_of_a_trained_benchmark_map():
+def test_exact_block_skipping_skips_most_of_a_trained_benchmark_map(monkeypatch):
     """configs[2]'s map and data (256 x 256 x 128, Gaussian blobs), 32 768 rows, the benchmark's schedule: from the third
-    epoch on a tenth to a quarter of the blocks run (tools/skip_probe.py counted 7-28 % in real arithmetic)."""
+    epoch on a tenth to a quarter of the blocks run (tools/skip_probe.py counted 7-28 % in real arithmetic).  (Mode 2: a
+    plan in every epoch; the default mode pauses the plan for two epochs after two that kept > 97 % of the blocks.)"""
+    monkeypatch.setenv("SOM_EXACT_SKIP", "2")
     from xpysom_dask_amd.synthetic import gaussian_blobs
     X = Y = 256; D = 128; n = 32768; T = 10
     data = gaussian_blobs(n, D)
@@ -668,4 +670,23 @@ def test_exact_block_skipping_without_memory_for_it_runs_every_block(monkeypatch
         f.epoch_merge(); x.epoch_merge()
     run, total = x.exact_skip_stats()
     assert run == total > 0
+    f.close(); x.close()
+
+
+def test_exact_block_skipping_pauses_the_plan_on_rows_without_structure():
+    """Default mode: two launches in a row whose plans kept more than 97 % of the blocks are followed by two launches without
+    a plan (rows of one tight cluster on a big map: every group is near every row).  Same ids either way."""
+    from xpysom_dask_amd.synthetic import gaussian_blobs
+    X, Y, D, n = 64, 64, 16, 8192
+    data = gaussian_blobs(n, D, seed=9, centres=1, spread=0.1)
+    w = O.default_codebook(X, Y, D, 3).astype(F32)
+    f = engine(X, Y, D, precision="f32"); x = engine(X, Y, D, precision="exact")
+    for e in (f, x):
+        e.set_weights(w); e.set_data(data)
+    for t in range(6):
+        f.epoch_accumulate(20.0, 0.3, True); x.epoch_accumulate(20.0, 0.3, True)
+        assert np.array_equal(f.epoch_fetch()[2], x.epoch_fetch()[2]), t
+        f.epoch_merge(); x.epoch_merge()
+    run, total = x.exact_skip_stats()
+    assert run > 0.97 * total
     f.close(); x.close()

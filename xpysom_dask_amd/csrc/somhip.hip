@@ -103,6 +103,8 @@ struct som_handle {
         // block skipping (exact_skip.hpp): resident rows from their second epoch on, input_len <= 128
         int skip_mode = 1;                // SOM_EXACT_SKIP: 0 off, 1 on for maps of >= 4096 units (default), 2 on for every map of >= 2 groups (tests)
         bool skip_live = false;           // this launch plans and skips
+        int skip_cooldown = 0;            // launches to run without a plan (the last two plans kept > 97 % of the blocks)
+        int skip_idle = 0;                // plans in a row that kept > 97 % of the blocks
         long sk_stride = 0;               // rows the sorted-pass buffers hold
         int *order = nullptr, *sk_keys = nullptr, *sk_keys2 = nullptr, *sk_vals = nullptr;
         void* sk_tmp = nullptr; size_t sk_tmp_bytes = 0;
@@ -1247,6 +1249,10 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     // block skipping (exact_skip.hpp): where the seed lives (resident rows with last epoch's BMUs, <= 128 features), one round
     ex.skip_live = ex.skip_mode > 0 && ex.seed_on && !h->wide && out == h->bmu && h->bmu_valid && !two_round &&
                    (ex.skip_mode > 1 ? n_groups >= 2 : h->K >= 4096);
+    // default mode: two launches in a row whose plans kept (nearly) every block -- rows without structure -- are followed
+    // by two launches without a plan (the plan costs 4-8 % of a full scan), and so on while the plans stay idle
+    if (ex.skip_live && ex.skip_mode == 1 && ex.skip_cooldown > 0) { --ex.skip_cooldown; ex.skip_live = false; }
+    const int64_t run_before = ex.blocks_run, total_before = ex.blocks_total;
     if (ex.skip_live && exact_skip_reserve(h, ex.stride) != 0) {
         // no memory for the sorted pass's buffers: every block runs, from now on (the ids are the same either way)
         (void)hipGetLastError();
@@ -1347,6 +1353,15 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
             exact_scatter_ids_kernel<<<dim3((unsigned)cdiv(n_fb, 256)), dim3(256), 0, h->stream>>>(ex.fb_ids, ex.fb_list, n_fb,
                                                                                                 out + r0);
             HIPCHK(h, hipGetLastError());
+        }
+    }
+    if (ex.skip_live && ex.skip_mode == 1 && ex.blocks_total > total_before) {
+        // (two such plans in a row: ONE is what the smooth map of a schedule's second epoch gives, and the third epoch of
+        //  the benchmark's schedule already runs a tenth of the blocks)
+        if ((double)(ex.blocks_run - run_before) > 0.97 * (double)(ex.blocks_total - total_before)) {
+            if (++ex.skip_idle >= 2) ex.skip_cooldown = 2;
+        } else {
+            ex.skip_idle = 0;
         }
     }
     return 0;
