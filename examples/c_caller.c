@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
     som_config cfg = {0};
     cfg.x = X; cfg.y = Y; cfg.input_len = D;
     cfg.distance = SOM_DIST_EUCLIDEAN; cfg.neighborhood = SOM_NEIGH_GAUSSIAN; cfg.topology = SOM_TOPO_RECTANGULAR;
-    cfg.precision = SOM_PREC_F32; cfg.device = 0; cfg.std_coeff = 0.5;
+    cfg.precision = SOM_PREC_EXACT; cfg.device = 0; cfg.std_coeff = 0.5;
     som_handle* h = NULL;
     if (som_create(&cfg, &h) != 0) { fprintf(stderr, "som_create: %s\n", som_last_error(NULL)); return 3; }
     printf("%s, %d device(s)\n", som_version(), som_device_count());

@@ -608,6 +608,103 @@ def g19():
 
 FAMILIES["g19"] = g19
 
+# ---------------------------------------------------------------- G20 two consecutive epochs on resident rows (block skipping)
+def g20_rows_on_a_sheet(w, n, seed, noise):
+    """Rows near the units of a codebook: unit[random] + noise * N(0, I), elementwise float64, rounded to float32 -- any host
+    evaluates them bit for bit (oracle.som_oracle.rows_on_codebook is the same recipe for the tests)."""
+    from oracle.som_oracle import rows_on_codebook
+    return rows_on_codebook(w, n, seed, noise)
+
+
+def g20():
+    """The exact mode's SECOND-epoch path (csrc/exact_skip.hpp: rows visited in the order of last epoch's BMU patch, a plan
+    that skips blocks, seeds from last epoch's BMUs) engages only on rows that stay resident across two epochs; every other
+    golden compares a first epoch.  Here: two consecutive teacher-forced epochs of the reference,
+    train(.., iter_beg=t, iter_end=t+1) from W_t and again from W_{t+1} (xpysom.py:458,481-482,515-577) --
+      a) 64 x 64 x 32 (4 096 units), 8 192 blob rows: W_t is the reference's own state after t = 6 epochs of a 10-epoch
+         schedule, W_{t+1} its own next state; both stored (float32, 512 KB each);
+      b) 256 x 256 x 128, 4 096 rows: codebooks that any host evaluates bit for bit from seeds (a smooth sheet of amplitude
+         3, and 0.9 of it + 0.1 of another sheet as the "next" state), rows scattered around the first sheet's units.
+    Stored per epoch: all BMUs, the whole denominator, every `stride`-th unit's numerator and merged row."""
+    from oracle.som_oracle import smooth_sheet_codebook, sheet_step
+    out = {}
+    # a) the reference's own trajectory
+    X, Y, D, n, T, t = 64, 64, 32, 8192, 10, 6
+    data = gaussian_blobs(n, D, seed=2020)
+    tr = RefSom(X, Y, D, random_seed=1234, n_parallel=2048, xp=np)
+    tr.train(data, T, iter_beg=0, iter_end=t)
+    states = [tr._weights.astype(F32)]
+    tr.train(data, T, iter_beg=t, iter_end=t + 1)
+    states.append(tr._weights.astype(F32))
+    out["a_shape"] = np.array([X, Y, D, n]); out["a_data_seed"] = np.array(2020); out["a_T"] = np.array(T); out["a_t"] = np.array(t)
+    out["a_stride"] = np.array(8)
+    out["a_w0"], out["a_w1"] = states
+    cases = [("a", X, Y, D, data, states, T, t, 8, 2048)]
+    # b) the configs[2] shape on seeded sheets
+    X, Y, D, n, T, t = 256, 256, 128, 4096, 10, 7
+    w0 = smooth_sheet_codebook(X, Y, D, 2021, amplitude=3.0)
+    w1 = sheet_step(w0, smooth_sheet_codebook(X, Y, D, 2022, amplitude=3.0), 0.1)
+    # rows without a float32 near-tie between their two best units under either codebook: n + 256 rows are drawn, those
+    # with a relative gap below 4e-6 (float64) are dropped, the first n of the rest kept.  A near-tie is decided by the
+    # summation order of whoever evaluates it (SURVEY 7, hard part 2); this fixture compares everything BEHIND the BMUs
+    row_seed = 2023
+    gen = g20_rows_on_a_sheet(w0, n + 256, row_seed, 0.5)
+    x64 = gen.astype(np.float64)
+    gap = np.full(len(gen), np.inf)
+    for w in (w0, w1):
+        w64 = w.reshape(-1, D).astype(np.float64)
+        for lo in range(0, len(gen), 1024):
+            tau = (w64 ** 2).sum(1)[None, :] - 2.0 * (x64[lo:lo + 1024] @ w64.T)
+            two = np.partition(tau, 1, axis=1)[:, :2]
+            gap[lo:lo + 1024] = np.minimum(gap[lo:lo + 1024], (two[:, 1] - two[:, 0]) / np.abs(two).max(1))
+    keep = np.flatnonzero(gap > 4e-6)[:n]
+    assert len(keep) == n
+    data = np.ascontiguousarray(gen[keep])
+    out["b_dropped"] = np.setdiff1d(np.arange(keep[-1] + 1), keep).astype(np.int32)
+    worst = float(gap[keep].min())
+    out["b_shape"] = np.array([X, Y, D, n]); out["b_T"] = np.array(T); out["b_t"] = np.array(t); out["b_stride"] = np.array(64)
+    out["b_seeds"] = np.array([2021, 2022, row_seed]); out["b_amplitude"] = np.float64(3.0); out["b_mix"] = np.float64(0.1)
+    out["b_min_rel_gap"] = np.float64(worst)
+    out["b_noise"] = np.float64(0.5)
+    for i, w in enumerate((w0, w1)):
+        out["b_w%d_crc" % i] = np.array(zlib.crc32(np.ascontiguousarray(w).tobytes()), dtype=np.int64)
+    out["b_data_crc"] = np.array(zlib.crc32(np.ascontiguousarray(data).tobytes()), dtype=np.int64)
+    cases.append(("b", X, Y, D, data, [w0, w1], T, t, 64, 1024))
+    for tag, X, Y, D, data, states, T, t, st, npar in cases:
+        n = len(data)
+        for i, w in enumerate(states):
+            som = RefSom(X, Y, D, random_seed=1234, n_parallel=npar, xp=np)
+            eta = som._decay_function(som._learning_rate, som._learning_rateN, t + i, T)
+            sig = som._decay_function(som._sigma, som._sigmaN, t + i, T)
+            bmu = np.empty(n, dtype=np.int32)
+            num = np.zeros((X, Y, D), dtype=F32)
+            den = np.zeros((X, Y, 1), dtype=F32)
+            som._sq_weights_gpu = np.power(w.reshape(-1, D), 2).sum(axis=1, keepdims=True)
+            for s in range(0, n, npar):                      # the mini-batch loop of train(), xpysom.py:560-569
+                wins = som._winner(data[s:s + npar], w)
+                bmu[s:s + npar] = wins[0] * Y + wins[1]
+                a, b = som._update(data[s:s + npar], w, eta, sig)
+                num += a; den += b
+            som._sq_weights_gpu = None
+            e = RefSom(X, Y, D, random_seed=1234, n_parallel=npar, xp=np)
+            e._weights = w.copy()
+            with np.errstate(all="ignore"):
+                e.train(data, T, iter_beg=t + i, iter_end=t + i + 1)
+            key = "%s_e%d" % (tag, i)
+            out[key + "_bmu"] = bmu
+            out[key + "_den"] = den.reshape(-1).astype(F32)
+            out[key + "_num"] = num.reshape(X * Y, D)[::st].astype(F32)
+            out[key + "_wout"] = e._weights.astype(F32).reshape(X * Y, D)[::st]
+            out[key + "_eta"] = np.float64(eta)
+            out[key + "_sig"] = np.float64(sig)
+            if tag == "a" and i == 0:
+                # the stored W_{t+1} IS this epoch's merged codebook (the reference's own trajectory)
+                assert np.array_equal(e._weights.astype(F32), states[1])
+    save("g20_two_resident_epochs", **out)
+
+
+FAMILIES["g20"] = g20
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     with contextlib.redirect_stdout(io.StringIO()) as _:

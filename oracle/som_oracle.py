@@ -449,3 +449,22 @@ def smooth_sheet_codebook(X, Y, D, seed, anchors=9, amplitude=0.5, centre=None):
     w = top * (1.0 - fj)
     w = w + bot * fj
     return w.astype(F32)
+
+
+def sheet_step(w0, w_other, mix):
+    """(1 - mix) * w0 + mix * w_other, elementwise in float64, rounded to float32: a "next" codebook state any host
+    evaluates bit for bit (tests/golden/g20)."""
+    a = np.asarray(w0, dtype=F64) * (1.0 - mix)
+    a = a + np.asarray(w_other, dtype=F64) * mix
+    return a.astype(F32)
+
+
+def rows_on_codebook(w, n, seed, noise):
+    """n rows scattered around randomly chosen units of a codebook: unit + noise * N(0, I), elementwise float64, rounded to
+    float32 (RandomState streams are reproducible across hosts and NumPy versions)."""
+    rs = np.random.RandomState(seed)
+    wf = np.asarray(w, dtype=F64).reshape(-1, np.shape(w)[-1])
+    pick = rs.randint(0, wf.shape[0], size=n)
+    x = wf[pick] + rs.standard_normal((n, wf.shape[1])) * noise
+    return x.astype(F32)
+

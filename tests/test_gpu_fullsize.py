@@ -39,7 +39,8 @@ def separable_update(data, bmu, X, Y, sigma, eta):
 
 @pytest.mark.parametrize("cfg", [
     dict(name="C2", X=64, Y=64, D=32, N=100_000, precision="f32"),       # BASELINE configs[1]
-    dict(name="C3", X=256, Y=256, D=128, N=1 << 20, precision="bf16"),    # BASELINE configs[2]
+    dict(name="C3", X=256, Y=256, D=128, N=1 << 20, precision="bf16"),    # BASELINE configs[2], the throughput mode
+    dict(name="C3-exact", X=256, Y=256, D=128, N=1 << 20, precision="exact"),   # ... and the mode bench.py times
 ], ids=lambda c: c["name"])
 def test_full_size_epoch_properties(cfg):
     X, Y, D, N, precision = cfg["X"], cfg["Y"], cfg["D"], cfg["N"], cfg["precision"]
@@ -61,7 +62,7 @@ def test_full_size_epoch_properties(cfg):
     wf = w.reshape(K, D)
     ref = O.bmu_ids(data[pick], wf)
     bad = np.flatnonzero(bmu[pick] != ref)
-    if precision == "f32":
+    if precision in ("f32", "exact"):
         assert near_tie_mask(data[pick][bad], wf, tol=1e-5).all()
     else:
         assert bf16_misses_are_near_best(data[pick], wf, bmu[pick], bad)
@@ -86,7 +87,7 @@ def test_full_size_epoch_properties(cfg):
         e.set_data(data[lo:hi])
         e.epoch_accumulate(sigma, eta, True)
         pn, pd, pb = e.epoch_fetch()
-        if precision == "f32":
+        if precision in ("f32", "exact"):
             assert np.array_equal(pb, bmu[lo:hi])       # a row's BMU does not depend on its shard
         else:
             # bf16: the positivity offset B = max|x~| max|w~| is a property of the shard, so a
@@ -96,8 +97,55 @@ def test_full_size_epoch_properties(cfg):
             assert bf16_misses_are_near_best(data[lo:hi][moved[:512]], wf, pb[moved[:512]], np.arange(min(512, len(moved))))
         tot_num += pn
         tot_den += pd
-    tol = 2e-6 if precision == "f32" else 2e-3            # bf16: the few moved rows above
+    tol = 2e-6 if precision in ("f32", "exact") else 2e-3   # bf16: the few moved rows above
     assert rel_err(tot_num, num) < tol and rel_err(tot_den, den) < tol
+
+
+def test_full_size_c3_exact_skip_equals_float32():
+    """configs[2] at FULL size in the mode bench.py times: 1 Mi resident rows, the benchmark's 12-epoch schedule from the
+    seeded codebook, precision='exact' with block skipping in its default mode against precision='f32' -- the BMUs of
+    EVERY row in EVERY epoch bit for bit, hence the same trained codebook; and from the fourth epoch on most blocks of
+    the distance GEMM were proved empty, not run (csrc/exact_skip.hpp).  ~1.5 s of float32 kernel per epoch pair."""
+    from xpysom_dask_amd.synthetic import gaussian_blobs
+    X = Y = 256; D = 128; N = 1 << 20; T = 12
+    data = gaussian_blobs(N, D, seed=1234, centre_seed=1234)         # bench.py's rows (workload_rows("c3", ...))
+    w = O.default_codebook(X, Y, D, 1234).astype(F32)
+    f = engine(X, Y, D, precision="f32"); x = engine(X, Y, D, precision="exact")
+    for e in (f, x):
+        e.set_weights(w); e.set_data(data)
+    shares = []
+    for t in range(T):
+        sig, eta = O.exponential_decay(128.0, 1.0, t, T), O.exponential_decay(0.5, 0.01, t, T)
+        r0, t0 = x.exact_skip_stats()
+        f.epoch_accumulate(sig, eta, True); x.epoch_accumulate(sig, eta, True)
+        r1, t1 = x.exact_skip_stats()
+        shares.append((r1 - r0) / (t1 - t0))
+        bf, bx = f.epoch_fetch()[2], x.epoch_fetch()[2]
+        assert np.array_equal(bf, bx), "epoch %d: %d of %d rows differ" % (t, int((bf != bx).sum()), N)
+        f.epoch_merge(); x.epoch_merge()
+    assert np.array_equal(f.get_weights(), x.get_weights())
+    rows, fb, _ = x.exact_stats()
+    assert rows == N * T and fb == 0
+    assert shares[0] == 1.0 and max(shares[4:]) < 0.5 and min(shares[4:]) < 0.15, shares
+    f.close(); x.close()
+
+
+def test_default_constructed_xpysom_trains_through_the_screen_and_equals_float32():
+    """The drop-in's DEFAULT precision is 'exact' (the reference's kwargs and nothing else): a default-constructed
+    XPySom(256, 256, 128) trains through the MFMA screen (rows screened > 0, none through the float32 fallback kernel) and
+    ends on the codebook precision='f32' ends on, bit for bit (xpysom.py:73-82)."""
+    from xpysom_dask_amd import XPySom
+    from xpysom_dask_amd.synthetic import gaussian_blobs
+    X = Y = 256; D = 128; N = 65536; T = 4
+    data = gaussian_blobs(N, D, seed=7)
+    a = XPySom(X, Y, D, random_seed=1234)
+    assert a._precision == "exact"
+    a.train(data, T)
+    rows, fb, _ = a._engine().exact_stats()
+    assert rows == N * T and fb == 0
+    b = XPySom(X, Y, D, random_seed=1234, precision="f32").train(data, T)
+    assert np.array_equal(a._weights, b._weights)
+    assert a.winner(data[:2000]) == b.winner(data[:2000])
 
 
 def test_full_size_quantization_error_and_winner_c2():

@@ -1642,6 +1642,73 @@ def test_g18_bmus_at_the_configs2_shape(state):
         assert (got <= best + slack).all(), precision
 
 
+# ----------------------------------------------------------------------------- G20: two consecutive epochs on resident rows
+@pytest.mark.parametrize("case", ["a", "b"])
+@pytest.mark.parametrize("precision", ["f32", "exact"])
+def test_g20_two_resident_epochs_against_the_reference(case, precision):
+    """The exact mode's SECOND-epoch path -- rows visited in the order of last epoch's BMU patch, a plan that proves blocks
+    of the distance GEMM empty and skips them, seeds from last epoch's BMUs (csrc/exact_skip.hpp) -- engages only on rows
+    that stay resident; every other golden compares a first epoch.  Here the reference ran two consecutive teacher-forced
+    epochs, train(.., iter_beg=t, iter_end=t+1) from W_t and again from W_{t+1} (xpysom.py:458,481-482,515-577): the rows
+    stay resident, epoch t runs (ids compared), W_{t+1} is set, epoch t+1 runs WITH the plan engaged (skipped blocks
+    asserted) and its BMUs, denominator, strided numerator and merged rows are the reference's.
+    a) 64 x 64 x 32: the reference's own trained states; b) 256 x 256 x 128 on seeded sheets (crc-checked recipes)."""
+    import zlib
+    g = load_golden("g20_two_resident_epochs")
+    X, Y, D, n = (int(v) for v in g[case + "_shape"])
+    st = int(g[case + "_stride"])
+    if case == "a":
+        data = O.gaussian_blobs(n, D, seed=int(g["a_data_seed"]))
+        ws = [g["a_w0"], g["a_w1"]]
+    else:
+        s0, s1, s2 = (int(v) for v in g["b_seeds"])
+        w0 = O.smooth_sheet_codebook(X, Y, D, s0, amplitude=float(g["b_amplitude"]))
+        w1 = O.sheet_step(w0, O.smooth_sheet_codebook(X, Y, D, s1, amplitude=float(g["b_amplitude"])), float(g["b_mix"]))
+        gen = O.rows_on_codebook(w0, n + 256, s2, float(g["b_noise"]))
+        # (drawn with 256 spare rows; the generator dropped the float32 near-ties -- top-2 gap below 4e-6 -- it lists)
+        data = np.ascontiguousarray(gen[np.setdiff1d(np.arange(len(gen)), g["b_dropped"])[:n]])
+        ws = [w0, w1]
+        for i, w in enumerate(ws):
+            assert zlib.crc32(np.ascontiguousarray(w).tobytes()) == int(g["b_w%d_crc" % i]), "the codebook recipe left the fixture's"
+        assert zlib.crc32(np.ascontiguousarray(data).tobytes()) == int(g["b_data_crc"]), "the row recipe left the fixture's"
+    e = engine(X, Y, D, precision=precision)
+    e.set_data(data)                                           # resident across both epochs
+    for i, w in enumerate(ws):
+        key = "%s_e%d" % (case, i)
+        e.set_weights(w)                                       # teacher-forced: the reference's own state
+        r0, t0 = e.exact_skip_stats() if precision == "exact" else (0, 0)
+        e.epoch_accumulate(float(g[key + "_sig"]), float(g[key + "_eta"]), True)     # (exponential decay: float64 neighbourhood)
+        num, den, bmu = e.epoch_fetch()
+        if precision == "exact":
+            r1, t1 = e.exact_skip_stats()
+            assert t1 > t0
+            if i == 0:
+                assert r1 - r0 == t1 - t0                      # first epoch on fresh rows: nothing to plan from
+            else:
+                assert r1 - r0 < 0.6 * (t1 - t0), "the second epoch did not skip: %d of %d blocks run" % (r1 - r0, t1 - t0)
+        ref = g[key + "_bmu"]
+        diff = np.flatnonzero(bmu != ref)
+        if case == "b":
+            assert len(diff) == 0, (precision, len(diff))      # one k-ordered fma chain per output on both sides: IDENTICAL ids
+        elif len(diff):
+            assert len(diff) <= max(2, n // 500) and near_tie_mask(data[diff], w.reshape(-1, D)).all()
+        if precision == "f32":
+            (LOST if len(diff) else COMPARED).append(("g20", case, i))
+        if len(diff):
+            continue
+        gden = g[key + "_den"].reshape(-1)
+        ok = gden > 1e-30
+        np.testing.assert_allclose(den[ok], gden[ok], rtol=1e-5)
+        assert rel_err(num[::st], g[key + "_num"]) < 1e-5
+        e.epoch_merge()
+        gw = g[key + "_wout"]
+        np.testing.assert_allclose(e.get_weights()[::st][ok[::st]], gw[ok[::st]], rtol=1e-5, atol=1e-5 * np.abs(gw).max())
+    if precision == "exact":
+        rows, fb, _ = e.exact_stats()
+        assert rows == 2 * n and fb <= n // 100
+    e.close()
+
+
 def test_zz_few_golden_comparisons_were_lost_to_near_ties():
     """The float32 mode's BMUs equal the reference's except on float32 near-ties (G12's one row; G17's K-split sgemm):
     the comparisons of accumulators / merged rows that such a difference makes meaningless are counted here."""

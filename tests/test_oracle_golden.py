@@ -472,6 +472,49 @@ def test_g18_bmus_256x256x128(state):
     assert (ids != g[state + "_bmu"][:1024]).sum() <= 2
 
 
+@pytest.mark.parametrize("i", [0, 1])
+def test_g20_two_resident_epochs_case_a(i):
+    """The oracle's epoch against the reference's two consecutive teacher-forced epochs (64 x 64 x 32, its own states)."""
+    g = load_golden("g20_two_resident_epochs")
+    X, Y, D, n = (int(v) for v in g["a_shape"])
+    st = int(g["a_stride"])
+    data = O.gaussian_blobs(n, D, seed=int(g["a_data_seed"]))
+    w = g["a_w%d" % i]
+    key = "a_e%d" % i
+    bmu, num, den, wout = O.epoch(data, w, np.float64(g[key + "_eta"]), np.float64(g[key + "_sig"]), wide=True, n_parallel=2048)
+    assert (bmu != g[key + "_bmu"]).sum() <= 2
+    if np.array_equal(bmu, g[key + "_bmu"]):
+        gden = g[key + "_den"]
+        np.testing.assert_allclose(den.reshape(-1).astype(F32), gden, rtol=1e-5, atol=1e-5 * np.abs(gden).max())
+        ref = g[key + "_num"]
+        assert np.abs(num.reshape(-1, D)[::st] - ref).max() <= 1e-5 * np.abs(ref).max()
+        ok = gden[::st] > 1e-30
+        np.testing.assert_allclose(wout.reshape(-1, D)[::st][ok], g[key + "_wout"][ok], rtol=1e-5, atol=1e-5 * np.abs(g[key + "_wout"]).max())
+    if i == 0:
+        # the reference's own next state is what the second epoch starts from
+        assert np.array_equal(g["a_w1"].reshape(-1, D)[::st], g["a_e0_wout"])
+
+
+def test_g20_case_b_recipes_and_a_slice_of_its_winners():
+    """256 x 256 x 128: the host-independent recipes of both codebooks and of the rows (crc), and the oracle's winners on a
+    slice of the rows against the reference's, both epochs."""
+    import zlib
+    g = load_golden("g20_two_resident_epochs")
+    X, Y, D, n = (int(v) for v in g["b_shape"])
+    s0, s1, s2 = (int(v) for v in g["b_seeds"])
+    w0 = O.smooth_sheet_codebook(X, Y, D, s0, amplitude=float(g["b_amplitude"]))
+    w1 = O.sheet_step(w0, O.smooth_sheet_codebook(X, Y, D, s1, amplitude=float(g["b_amplitude"])), float(g["b_mix"]))
+    gen = O.rows_on_codebook(w0, n + 256, s2, float(g["b_noise"]))
+    # (drawn with 256 spare rows; the generator dropped the float32 near-ties -- top-2 gap below 4e-6 -- it lists)
+    data = np.ascontiguousarray(gen[np.setdiff1d(np.arange(len(gen)), g["b_dropped"])[:n]])
+    assert zlib.crc32(np.ascontiguousarray(w0).tobytes()) == int(g["b_w0_crc"])
+    assert zlib.crc32(np.ascontiguousarray(w1).tobytes()) == int(g["b_w1_crc"])
+    assert zlib.crc32(np.ascontiguousarray(data).tobytes()) == int(g["b_data_crc"])
+    for i, w in enumerate((w0, w1)):
+        ids = O.winner_ids(data[:512], w, n_parallel=512)
+        assert (ids != g["b_e%d_bmu" % i][:512]).sum() <= 1
+
+
 def test_g19_norm_p_with_a_real_exponent():
     """distances.py:61-75 takes any real p: the oracle's generic form against the reference's winners and a distance block."""
     g = load_golden("g19_norm_p_real")

@@ -1305,7 +1305,7 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         } else {
             exact_select_kernel<false><<<sel_grid, sel_block, 0, h->stream>>>(
                 ex.gmin, ex.gflags, ex.stride, n_groups, n, best, p_xsq, h->wmax2, xmax2, eb, p_xerr, h->wmax2 + 1, ex.plist,
-                ex.ctr, ex.rowcnt, nullptr, p_seed);
+                ex.ctr, ex.rowcnt, nullptr, std::getenv("SOM_EXPERIMENT_NO_SEED_WINDOW") ? nullptr : p_seed);
             if (int rc = exact_rescore_round(h, X + r0 * h->D, xsq + r0, best, nullptr, nullptr)) return rc;
         }
         exact_finalize_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(

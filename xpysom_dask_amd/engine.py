@@ -21,7 +21,7 @@ def _f32(a):
 
 class HipEngine:
     def __init__(self, x, y, input_len, *, distance="euclidean", neighborhood="gaussian",
-                 std_coeff=0.5, compact_support=False, precision="f32", device=0, stream=None,
+                 std_coeff=0.5, compact_support=False, precision="exact", device=0, stream=None,
                  topology="rectangular", norm_p=0, norm_p_real=0.0):
         self._lib = _lib.load()
         self._h = None

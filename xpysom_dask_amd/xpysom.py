@@ -79,15 +79,17 @@ class XPySom:
                  random_seed=None, n_parallel=0, compact_support=False,
                  xp=None,
                  use_dask=False, dask_chunks='auto',
-                 *, precision='f32', device=None, sharded_input=False):
+                 *, precision='exact', device=None, sharded_input=False):
         """Same positional/keyword surface as the reference constructor (xpysom.py:73-82).
 
         ``xp``, ``use_dask`` and ``dask_chunks`` are accepted for source compatibility and
         ignored: there is one backend (HIP) and multi-GPU runs use torch.distributed, not Dask.
         Extra keyword-only arguments:
-          precision      'f32' (exact-float32 MFMA, parity mode), 'exact' (the BMUs of 'f32' bit for bit, found by an
-                         IEEE-half MFMA screen and a float32 re-score of the units its error bound cannot rule out:
-                         the parity contract at six to nine times the float32 kernel's speed), 'bf16' (bf16 MFMA distance GEMM),
+          precision      'exact' (the DEFAULT: the BMUs of 'f32' bit for bit -- hence its accumulators and its trained
+                         codebook --, found by an IEEE-half MFMA screen and a float32 re-score of the units its error
+                         bound cannot rule out; where no screen applies -- small maps, the VALU distances -- the float32
+                         kernels themselves serve it), 'f32' (the exact-float32 MFMA kernels over every unit: the parity
+                         mode the default is checked against), 'bf16' (bf16 MFMA distance GEMM),
                          'bf16x3' (hi/lo-split bf16 MFMA: near-float32 BMUs at a third of the bf16 rate), or the
                          same two paths on IEEE half operands, 'f16' / 'f16x3' (three more mantissa bits at the
                          same MFMA rate; rows and units must fit float16: norms <= 65504)
