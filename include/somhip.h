@@ -249,9 +249,12 @@ int som_patch_order(int32_t x, int32_t y, int32_t* perm_out);
 /* precision EXACT bookkeeping: rows screened so far, rows that went to the float32 fallback kernel, screen passes */
 int som_exact_stats(som_handle* h, int64_t* rows, int64_t* rows_fallback, int64_t* passes);
 /* precision EXACT, block skipping (csrc/exact_skip.hpp: resident rows from their second epoch on, input_len <= 128): how
- * many (256-row tile, 64-unit group) blocks the screens ran, of how many a full scan has -- the EXECUTED share of the
+ * many (256-row tile, 16-unit block) blocks the screens ran, of how many a full scan has -- the EXECUTED share of the
  * distance GEMM (launches without skipping count every block) */
 int som_exact_skip_stats(som_handle* h, int64_t* blocks_run, int64_t* blocks_total);
+/* ... and the resident sorted pass behind it: epochs that ran under a plan, and how many of them (re-)sorted the rows by
+ * their last BMU's patch first (the others reused the order of an earlier epoch) */
+int som_exact_resident_stats(som_handle* h, int64_t* planned_epochs, int64_t* sorts);
 /* candidate groups per row of the LAST screen pass (its first n rows): how many 64-unit groups the re-score visited */
 int som_exact_last_counts(som_handle* h, int32_t* counts_out, int64_t n);
 

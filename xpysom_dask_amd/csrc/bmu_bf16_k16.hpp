@@ -210,7 +210,9 @@ __global__ __launch_bounds__(64 * KS32) void merge_prep_k16_kernel(float* __rest
 // hence of the minimum so far: only those are stored (gmin[stage * gm_stride + row], exec-masked), and every wave and
 // stage leaves the 64-bit mask of the lanes it stored in gflags[(row / 64) * n_stages + stage] -- on a random
 // codebook ~2 % of the matrix is written and read, on the smoothest maps 10-25 %.
-template <int KS32, class EL = Bf16, bool GM = false>
+// TL (GM with block skipping, exact_skip.hpp): the workgroup walks its tile's LIST of items (stage << 4 | mask of the stage's
+// 16-unit tiles to run) instead of all stages; only the listed tiles' fragments are staged and multiplied.
+template <int KS32, class EL = Bf16, bool GM = false, bool TL = false>
 __global__ __launch_bounds__(64 * K16_NW, 2) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
                                                               const char* __restrict__ Wst, int n_stages, int K,
                                                               unsigned long long* __restrict__ out64,
@@ -271,18 +273,22 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void bmu_bf16_k16_kernel(const __bf
             if (sd == sd) run_cap = sd;
         }
     }
-    // this workgroup's share of the codebook stages -- or (GM with block skipping, exact_skip.hpp) of the tile's LIST of stages:
-    // the loop index s walks [s_begin, s_end) either way, stage_of(s) is the stage it stands for
-    const int* my_list = (GM && glist != nullptr) ? glist + (long)blockIdx.x * n_stages : nullptr;
-    const int n_walk = my_list != nullptr ? gcnt[blockIdx.x] : n_stages;
+    // this workgroup's share of the codebook stages -- or (TL) of the tile's LIST of items: the loop index s walks
+    // [s_begin, s_end) either way, item_of(s) = (stage << 4 | tile mask) is what it stands for
+    static_assert(!TL || GM, "tile lists belong to the exact mode's screen");
+    const int* my_list = TL ? glist + (long)blockIdx.x * n_stages : nullptr;
+    const int n_walk = TL ? gcnt[blockIdx.x] : n_stages;
     const int s_begin = (int)((long)n_walk * blockIdx.y / gridDim.y);
     const int s_end = (int)((long)n_walk * (blockIdx.y + 1) / gridDim.y);
     // (list entries are read two iterations ahead of their use: no load sits between a barrier and the stage it names)
-    auto stage_of = [&](int s) -> int { return s < s_end ? (my_list != nullptr ? __builtin_amdgcn_readfirstlane(my_list[s]) : s) : 0; };
-    int st_prev = 0, st_cur = stage_of(s_begin), st_next = stage_of(s_begin + 1);
-    if (s_begin < s_end)
+    auto item_of = [&](int s) -> int { return s < s_end ? (TL ? __builtin_amdgcn_readfirstlane(my_list[s]) : ((s << 4) | 15)) : 15; };
+    auto dma_item = [&](int it, char* dst) {
+        const char* src = Wst + (long)(it >> 4) * STAGE;
         for (int p = wave; p < PIECES; p += K16_NW)
-            lds_dma_16(Wst + (long)st_cur * STAGE + (long)p * 1024 + lane * 16, smem + p * 1024);
+            if (!TL || p == PIECES - 1 || ((it >> (p / KS32)) & 1)) lds_dma_16(src + (long)p * 1024 + lane * 16, dst + p * 1024);
+    };
+    int it_prev = 15, it_cur = item_of(s_begin), it_next = item_of(s_begin + 1);
+    if (s_begin < s_end) dma_item(it_cur, smem);
 
     auto reduce_tile = [&](const f32x4 (&acc)[K16_SB], int t16) {
         if (GM) {
@@ -337,14 +343,52 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void bmu_bf16_k16_kernel(const __bf
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const int st_next2 = stage_of(s + 2);
-        if (s + 1 < s_end) {
-            const char* src = Wst + (long)st_next * STAGE;
-            char* dst = smem + ((s + 1 - s_begin) & 1) * STAGE;
-            for (int p = wave; p < PIECES; p += K16_NW) lds_dma_16(src + (long)p * 1024 + lane * 16, dst + p * 1024);
-        }
+        const int it_next2 = item_of(s + 2);
+        if (s + 1 < s_end) dma_item(it_next, smem + ((s + 1 - s_begin) & 1) * STAGE);
         const char* st = smem + ((s - s_begin) & 1) * STAGE;
         const float* wq = (const float*)(st + K16_T * KS32 * 1024);
+
+        if (TL) {
+            // the item's tiles in ascending order, the next one's fragments read under this one's MFMAs; the reduction of a
+            // tile's accumulators runs one tile behind (accP), across stage boundaries too
+            uint32_t m = (uint32_t)it_cur & 15u;             // (never empty: exact_lists_kernel lists no group without a block)
+            int t = __builtin_ctz(m);
+            f32x4 wv = *(const f32x4*)(wq + t * 16 + 4 * quad);
+            bf16x8 a[KS32];
+#pragma unroll
+            for (int ks = 0; ks < KS32; ++ks) a[ks] = *(const bf16x8*)(st + (t * KS32 + ks) * 1024 + lane * 16);
+            bool first = true;
+            while (m != 0u) {
+                m &= m - 1u;
+                f32x4 wvN;
+                bf16x8 aN[KS32];
+                if (m != 0u) {
+                    const int tn = __builtin_ctz(m);
+                    wvN = *(const f32x4*)(wq + tn * 16 + 4 * quad);
+#pragma unroll
+                    for (int ks = 0; ks < KS32; ++ks) aN[ks] = *(const bf16x8*)(st + (tn * KS32 + ks) * 1024 + lane * 16);
+                }
+                f32x4 accT[K16_SB];
+#pragma unroll
+                for (int sb = 0; sb < K16_SB; ++sb) accT[sb] = wv;
+#pragma unroll
+                for (int ks = 0; ks < KS32; ++ks)
+#pragma unroll
+                    for (int sb = 0; sb < K16_SB; ++sb)
+                        accT[sb] = mfma16(a[ks], xf[sb][ks], accT[sb]);
+                reduce_tile(accP, 0);
+                if (first) { fold_stage(it_prev >> 4, s > s_begin); first = false; }
+#pragma unroll
+                for (int sb = 0; sb < K16_SB; ++sb) accP[sb] = accT[sb];
+                if (m != 0u) {
+                    wv = wvN;
+#pragma unroll
+                    for (int ks = 0; ks < KS32; ++ks) a[ks] = aN[ks];
+                }
+            }
+            it_prev = it_cur; it_cur = it_next; it_next = it_next2;
+            continue;
+        }
 
         f32x4 wv = *(const f32x4*)(wq + 4 * quad);
         bf16x8 a[KS32];
@@ -370,7 +414,7 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void bmu_bf16_k16_kernel(const __bf
                 for (int sb = 0; sb < K16_SB; ++sb)
                     accT[sb] = mfma16(a[ks], xf[sb][ks], accT[sb]);
             reduce_tile(accP, (t16 + K16_T - 1) % K16_T);
-            if (t16 == 0) fold_stage(st_prev, s > s_begin);
+            if (t16 == 0) fold_stage(it_prev >> 4, s > s_begin);
 #pragma unroll
             for (int sb = 0; sb < K16_SB; ++sb) accP[sb] = accT[sb];
             if (t16 + 1 < K16_T) {
@@ -381,10 +425,10 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void bmu_bf16_k16_kernel(const __bf
         }
         // (explicit sched_group_barrier / iglp_opt interleave requests were measured: equal or worse than
         //  hipcc's own schedule of this block -- DESIGN.md 3.4)
-        st_prev = st_cur; st_cur = st_next; st_next = st_next2;
+        it_prev = it_cur; it_cur = it_next; it_next = it_next2;
     }
     reduce_tile(accP, K16_T - 1);
-    fold_stage(st_prev, s_begin < s_end);
+    fold_stage(it_prev >> 4, s_begin < s_end);
     SOM_STAMP_END();
 
     if (GM) {

@@ -2,45 +2,61 @@
 //
 // The screen (bmu_bf16_k16_kernel<.., GM>) is the exact epoch; what is left is not to run it where no BMU can be.  Two facts:
 //   * last epoch's BMU u of a row x gives an upper bound on the distance to this epoch's BMU k*: the float32 kernel picks
-//     k* with fl(tau(k*)) <= fl(tau(u)), so  |x - w_k*|^2 <= U(x) := |x|^2 + t + 1.5 share,  t the float32 score of u under
-//     the CURRENT codebook (exact_seed_kernel evaluates it anyway), share the float32 kernel's error window in tau units;
-//   * a group of 64 units (a patch of the map) with centroid c and radius r = max |w - c| has  |x - w| >= |x - c| - r  for
+//     k* with fl(tau(k*)) <= fl(tau(u)), so  |x - w_k*|^2 <= U(x) := |x|^2 + tau_up(u) + share,  tau_up an upper bound of
+//     u's real score tau(u) = |w_u|^2 - 2 x.w_u under the CURRENT codebook, share the float32 kernel's error window;
+//   * a block of units (a patch of the map) with centroid c and radius r = max |w - c| has  |x - w| >= |x - c| - r  for
 //     each of its units.
-// So group g holds no candidate of row x if  |x - c_g| > sqrt(U(x)) + r_g.  Rows are visited in the order of their last
-// BMU's patch (a sort of row ids per pass; the pass runs in that order: operand image, norms, seeds, merge keys are
-// permuted copies, the re-score gathers rows and the ids are written through the permutation), so the 256 rows of a
-// workgroup tile lie in one region of the map and share most of their groups.  The PLAN kernel below is the screen's
-// MFMA loop on the centroids (1/64 of the units) with this test as its epilogue and an OR over the tile's rows; the screen
-// then walks, per tile, the list of groups some row of it needs.  A skipped (row, group) stores no minimum: to the select
-// kernel it is a group outside the window, which is what the test proved.  The row minimum m(n) is over the groups run:
-// never below the true one, and the float32 winner's group is among them, so the selection argument of bmu_exact.hpp
-// holds unchanged.  Rigour: |x - c|^2 = |x|^2 + tau_c is taken from the plan's screen value d'_c = S'(B' + tau_c / 2)
-// less the screen's error bound for the centroid image (E_c / 2 of ex_row_bound on the centroids' scales), norms and
-// radii are rounded outwards; a row whose quantities are not finite needs every group.
+// So a block holds no candidate of row x if  |x - c| > sqrt(U(x)) + r.
+//
+// ROWS stay resident in the order of their last BMU's patch (somhip.hip: a sorted copy of the operand image, the float32
+// rows, the norms; re-sorted only when the order has gone stale -- most rows move to a neighbouring patch at most from
+// one epoch to the next, and a 256-row tile of neighbours shares its blocks either way), so the 256 rows of a workgroup
+// tile lie in one region of the map.
+// BLOCKS come at two levels: the 64-unit GROUPS of the screen (one stage of its image = an 8 x 8 patch of the map) and
+// their four 16-unit SUB-BLOCKS (the stage's four MFMA tiles = 2 x 8 strips of the patch).  Late in a schedule the units
+// of a patch spread out (its radius grows to the scale of the data) and the group bound alone keeps a quarter of all
+// blocks; the sub-blocks' own centroids and radii cut that to a third.  The PLAN kernel below is the screen's MFMA loop
+// on centroids with the test as its epilogue and an OR over the tile's rows: level 1 over the group centroids (1/64 of
+// the units), level 2 over the sub-block centroids of the groups level 1 kept.  The screen then walks, per tile, the list
+// of (group, 4-bit sub-block mask) items some row of it needs.
+// A skipped (row, block) stores no minimum: to the select kernel it is a block outside the window, which is what the test
+// proved.  The row minimum m(n) is over the blocks run: never below the true one, and the float32 winner's block is
+// among them, so the selection argument of bmu_exact.hpp holds unchanged (the re-score evaluates whole groups).
+// SEED: tau_up(u) comes from the operands the plan holds anyway -- the row's half image and unit u's fragments of the
+// screen's stage image, a vector-ALU dot product in the plan's prologue: v_u = S (B + tau(u) / 2) up to the screen's
+// one-unit error (measured operand rounding + accumulation), which is charged.  The same v_u caps what the screen
+// stores at all (bmu_exact.hpp, seed).
+// Rigour: |x - c|^2 = |x|^2 + tau_c is taken from the plan's screen value d'_c = S'(B' + tau_c / 2) less the screen's
+// error bound for the centroid image (E_c / 2 of ex_row_bound on the centroids' scales), norms and radii are rounded
+// outwards; a row whose quantities are not finite needs every block.
 #pragma once
 #include "bmu_bf16_k16.hpp"
 
 namespace somhip {
 
 constexpr int SK_TILE = K16_WG_SAMPLES;   // rows per plan / screen workgroup tile
-static_assert(K16_STAGE_UNITS == 64, "block skipping: a stage of the resident screen is one 64-unit group, a plan word one stage of centroids");
+static_assert(K16_STAGE_UNITS == 64 && K16_T == 4, "block skipping: a stage of the resident screen is one 64-unit group of four 16-unit tiles");
 
-// centroid and radius of every group of 64 consecutive units of W (patch order: a patch of the map).  One block (two waves)
-// per group, thread d <-> feature d in both passes (rows read whole: coalesced); a unit's |w - c|^2 is a wave reduction.
+// Centroid and radius of blocks of consecutive units of W (patch order: a patch of the map).  One workgroup (two waves)
+// per output slot, thread d <-> feature d in both passes (rows read whole: coalesced); a unit's |w - c|^2 is a wave
+// reduction.  sub == 0: slot g = group g (64 units).  sub == 1: slot j = sub-block `j & 3` (16 units) of group
+// 4 (j >> 4) + ((j >> 2) & 3) -- sixteen consecutive slots are the sub-blocks of four consecutive groups, one 16-row MFMA
+// tile of the level-2 centroid image.  A slot without units: centroid 0, radius -1 (never needed).
 __global__ __launch_bounds__(128) void exact_centroid_kernel(const float* __restrict__ W, int K, int D, float* __restrict__ C,
-                                                             float* __restrict__ rg) {
+                                                             float* __restrict__ rg, int sub) {
     __shared__ float part[2][64];
-    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int u0 = g * 64, cnt = min(64, K - u0);
+    const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long u0 = sub ? ((long)(4 * (j >> 4) + ((j >> 2) & 3)) * 64 + (j & 3) * 16) : (long)j * 64;
+    const int cnt = (int)max(0L, min((long)(sub ? 16 : 64), (long)K - u0));
     float c = 0.0f;
     if (tid < D) {
-        for (int k = 0; k < cnt; ++k) c += W[(long)(u0 + k) * D + tid];
-        c /= (float)cnt;
-        C[(long)g * D + tid] = c;
+        for (int k = 0; k < cnt; ++k) c += W[(u0 + k) * D + tid];
+        if (cnt > 0) c /= (float)cnt;
+        C[(long)j * D + tid] = c;
     }
     for (int k = 0; k < cnt; ++k) {
         float q = 0.0f;
-        if (tid < D) { const float df = W[(long)(u0 + k) * D + tid] - c; q = df * df; }
+        if (tid < D) { const float df = W[(u0 + k) * D + tid] - c; q = df * df; }
         q = wave_sum(q);                                      // (a NaN anywhere in the unit: NaN)
         if (lane == 0) part[wave][k] = q;
     }
@@ -49,10 +65,10 @@ __global__ __launch_bounds__(128) void exact_centroid_kernel(const float* __rest
         float m = 0.0f;
         for (int k = 0; k < cnt; ++k) {
             const float d2 = part[0][k] + part[1][k];
-            m = (d2 > m || !(d2 == d2)) ? d2 : m;             // (a NaN unit: a NaN radius, the group is never skipped)
+            m = (d2 > m || !(d2 == d2)) ? d2 : m;             // (a NaN unit: a NaN radius, the block is never skipped)
         }
         // (the sum of squares in float32, any order: relative error <= 128 * 2^-24; the margin covers it many times over)
-        rg[g] = __builtin_sqrtf(m) * (1.0f + 1.0f / 512.0f) + 1.0e-30f;
+        rg[j] = cnt > 0 ? __builtin_sqrtf(m) * (1.0f + 1.0f / 512.0f) + 1.0e-30f : -1.0f;
     }
 }
 
@@ -67,53 +83,101 @@ __global__ __launch_bounds__(256) void exact_sortkey_kernel(const int* __restric
     vals[i] = (int)i;
 }
 
-// the pass's operands in sorted order: image rows (DP halves), |x|^2, rounding error, seed, the float32 score of the last BMU.
-// Positions behind the pass's rows (up to the tile multiple) get zero rows and NaN norms (they keep nothing, need nothing).
-__global__ __launch_bounds__(256) void exact_gather_sorted_kernel(const int* __restrict__ order, long n, long np, int dp,
-                                                                  const __bf16* __restrict__ Xb, const float* __restrict__ xsq,
-                                                                  const float* __restrict__ xerr, const float* __restrict__ seed,
-                                                                  const float* __restrict__ tq, __bf16* __restrict__ Xb_s,
-                                                                  float* __restrict__ xsq_s, float* __restrict__ xerr_s,
-                                                                  float* __restrict__ seed_s, float* __restrict__ tq_s) {
-    const int per = dp / 8;                                   // 16-byte pieces per row
-    const long id = (long)blockIdx.x * 256 + threadIdx.x;
-    if (id >= np * per) return;
-    const long p = id / per;
-    const int c = (int)(id - p * per);
-    u32x4 v = {0u, 0u, 0u, 0u};
-    long r = -1;
-    if (p < n) { r = order[p]; v = *(const u32x4*)((const char*)Xb + (r * dp + c * 8) * 2); }
-    *(u32x4*)((char*)Xb_s + (p * dp + c * 8) * 2) = v;
-    if (c == 0) {
+// The pass in sorted order: image rows (DP halves), the float32 rows themselves (what the re-score reads: a candidate
+// group's rows are then neighbours in memory), |x|^2, rounding error.  Positions behind the pass's rows (up to the tile
+// multiple) get zero rows and NaN norms (they keep nothing, need nothing).  One workgroup per 4 rows.
+__global__ __launch_bounds__(256) void exact_gather_sorted_kernel(const int* __restrict__ order, long n, long np, int dp, int D,
+                                                                  const __bf16* __restrict__ Xb, const float* __restrict__ X,
+                                                                  const float* __restrict__ xsq, const float* __restrict__ xerr,
+                                                                  __bf16* __restrict__ Xb_s, float* __restrict__ Xf_s,
+                                                                  float* __restrict__ xsq_s, float* __restrict__ xerr_s) {
+    const int lane = threadIdx.x & 63;
+    const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= np) return;
+    const long r = p < n ? (long)order[p] : -1;
+    for (int c = lane; c < dp / 8; c += 64) {                 // 16-byte pieces of the half image
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r >= 0) v = *(const u32x4*)((const char*)Xb + (r * dp + c * 8) * 2);
+        *(u32x4*)((char*)Xb_s + (p * dp + c * 8) * 2) = v;
+    }
+    if (p < n) {
+        if ((D & 3) == 0)
+            for (int c = lane; c < D / 4; c += 64) *(f32x4*)(Xf_s + p * D + 4 * c) = *(const f32x4*)(X + r * D + 4 * c);
+        else
+            for (int c = lane; c < D; c += 64) Xf_s[p * D + c] = X[r * D + c];
+    }
+    if (lane == 0) {
         const float nanv = __builtin_nanf("");
         xsq_s[p] = r >= 0 ? xsq[r] : nanv;
         xerr_s[p] = r >= 0 ? xerr[r] : nanv;
-        seed_s[p] = r >= 0 ? seed[r] : nanv;
-        tq_s[p] = r >= 0 ? tq[r] : nanv;
     }
 }
 
-// The plan: which groups does a tile of SK_TILE (sorted) rows need?  The resident kernel's MFMA loop over the centroid
-// stage image (one centroid per group; 64 centroids per stage), epilogue: need(row, g) = not (d'_c > A(row) + (S'/2) (sU(row)
-// + r_g)^2), OR over the tile's rows into need[tile][stage] (bit j <-> group 64 stage + j).  eb / scales: the centroid
-// image's (cmax2 = {max |c|^2, max rounding error^2}); wmax2 / werr2: the codebook's (for the float32 share).
-template <int KS32, class EL>
+// a positive float32 rounded UP to a NORMAL IEEE half (what one MFMA operand can carry of it without ever reading less):
+// at least 2^-14 (an MFMA that flushes subnormal inputs would read 0 below that), +inf beyond 65504, NaN stays NaN
+__device__ __forceinline__ float up_to_half(float v) {
+    if (!(v == v)) return v;
+    if (v > 65504.0f) return __builtin_inff();
+    if (v < 0x1p-14f) return 0x1p-14f;
+    const _Float16 hv = (_Float16)v;                         // round to nearest even
+    float f = (float)hv;
+    if (f < v) f = (float)__builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned short, hv) + 1));   // next half up
+    return f;
+}
+
+// The test of the plan, arranged so that the MFMA evaluates all of it but one comparison per (row, centroid):
+//   skip  <=>  d'_c > A(row) + hS (sU(row) + r_c)^2  =  [A + hS sU^2] + hS r_c^2 + 2 hS sU r_c
+//         <=>  (d'_c - hS r_c^2) - (sx sU (1 + 2^-10)) (sw r_c)  >  P(row) := A + hS sU^2,        2 hS = S (1 + 2^-10), S = sx sw.
+// hS r_c^2 leaves the initial accumulator (this kernel rewrites the stage's tail), the cross term is ONE more feature: the
+// rows carry up_to_half(sx sU (1 + 2^-10)), the centroids -up_to_half(sw r_c) -- both rounded up, so the product the MFMA
+// forms is never below the real one (the test errs towards "needed") -- in the first slot of an extra 32-feature step.
+// Tail of stage s afterwards: [0, 64) floats: initial accumulators S'(B' + |c|^2 / 2) - hS r^2, [64, 128): -up_to_half(sw r)
+// (an empty slot: +inf and 0: never needed; a NaN radius: NaN: always needed).
+__global__ __launch_bounds__(256) void exact_plan_tail_kernel(char* __restrict__ Cst, int n_cstages, int stage_bytes,
+                                                              const float* __restrict__ rg, int n_slots,
+                                                              const float* __restrict__ xmax2, const float* __restrict__ cmax2) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= (long)n_cstages * 64) return;
+    const ExactScales sc = ex_scales(xmax2, cmax2, cmax2 + 1);
+    const float hS = 0.5f * sc.sx * sc.sw * (1.0f + 1.0f / 1024.0f);
+    float* tail = (float*)(Cst + (j / 64 + 1) * (long)stage_bytes - 1024);
+    const int within = (int)(j % 64);
+    const float rad = j < n_slots ? rg[j] : -1.0f;
+    if (rad < 0.0f) { tail[within] = __builtin_inff(); tail[64 + within] = 0.0f; return; }
+    tail[within] = tail[within] - hS * rad * rad * (1.0f + 0x1p-20f);
+    tail[64 + within] = -up_to_half(sc.sw * rad);
+}
+
+// The plan: which blocks does a tile of SK_TILE (sorted) rows need?  The resident kernel's MFMA loop over a centroid
+// stage image (64 centroids per stage), epilogue: need(row, j) = not (d'_c > A(row) + (S'/2) (sU(row) + r_j)^2), OR over
+// the tile's rows into need[tile][stage] (bit i <-> centroid slot 64 stage + i).
+//   LEVEL2 == false: the centroids of the groups.  The prologue also forms, per row, the screen value v_u of the row's last
+//     BMU u (vector ALU, from the row's half image and u's fragments of the screen's stage image Wst), from it the seed of
+//     the screen (seed_s) and sqrt(U) (sU_s: kept for level 2; +inf: the row needs everything).
+//   LEVEL2 == true: the centroids of the 16-unit sub-blocks, slot order as exact_centroid_kernel's (a 16-slot MFMA tile =
+//     the sub-blocks of four consecutive groups); only the tiles whose groups level 1 kept (need1) are loaded and run.
+// eb / scales: the centroid image's (cmax2 = {max |c|^2, max rounding error^2}); wmax2 / werr2: the codebook's.
+template <int KS32, class EL, bool LEVEL2>
 __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16* __restrict__ Xb, long N,
                                                                     const char* __restrict__ Cst, int n_cstages,
-                                                                    const float* __restrict__ rg, int n_groups,
+                                                                    const float* __restrict__ rg, int n_slots,
                                                                     const float* __restrict__ xsq, const float* __restrict__ xerr,
-                                                                    const float* __restrict__ tq,
+                                                                    float* __restrict__ sU_s,
                                                                     const float* __restrict__ xmax2, const float* __restrict__ cmax2,
                                                                     const float* __restrict__ wmax2, const float* __restrict__ werr2,
                                                                     ExactBound eb, unsigned long long* __restrict__ need,
-                                                                    int force_all = 0) {
+                                                                    const int* __restrict__ prev, const int* __restrict__ order,
+                                                                    const int* __restrict__ inv, const char* __restrict__ Wst, int K,
+                                                                    float* __restrict__ seed_s,
+                                                                    const unsigned long long* __restrict__ need1, int n_cstages1,
+                                                                    int force_all) {
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     constexpr int DP = 32 * KS32;
     constexpr int STAGE = k16_stage_bytes(KS32);
     constexpr int PIECES = K16_T * KS32 + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ unsigned long long wneed[K16_NW];
+    __shared__ int act_n;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,7 +185,8 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16
     const long wave_s0 = (long)blockIdx.x * K16_WG_SAMPLES + wave * (16 * K16_SB);
 
     bf16x8 xf[K16_SB][KS32];
-    float A[K16_SB], sU[K16_SB];
+    bf16x8 xe[K16_SB];                                       // the extra feature step: slot 0 = up_to_half(sx sU (1 + 2^-10)), else 0
+    float A[K16_SB], sU[K16_SB], P[K16_SB];
     const ExactScales sc = ex_scales(xmax2, cmax2, cmax2 + 1);
     const ExactScales sw = ex_scales(xmax2, wmax2, werr2);
     const float S = sc.sx * sc.sw;
@@ -133,46 +198,128 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16
         // rows behind the pass need nothing (A = -inf: d' > rhs always); a row whose numbers are not finite needs everything
         A[sb] = -__builtin_inff(); sU[sb] = 0.0f;
         if (row < N) {
-            const float q = xsq[row], t = tq[row];
-            const float ec = 0.5f * ex_row_bound(eb, sc, q, xerr[row]) * (1.0f + 1.0f / 1024.0f);
-            const float xn = __builtin_sqrtf(q) * (1.0f + 1.0f / 1024.0f);
-            const float share = 2.0f * (eb.cA * xn * sw.wm + eb.cW * sw.wm * sw.wm);          // tau units, one float32 window
-            // (no fmax here: it would swallow the NaN of a row whose last BMU is a NaN unit, and bound that row by zero)
-            const float U0 = q * (1.0f + 1.0f / 1024.0f) + t + 1.5f * share * (1.0f + 1.0f / 1024.0f) + 0x1p-18f * (q + __builtin_fabsf(t));
-            const float U = U0 < 0.0f ? 0.0f : U0;
-            sU[sb] = __builtin_sqrtf(U) * (1.0f + 1.0f / 1024.0f);
+            const float q = xsq[row], xe = xerr[row];
+            float su;
+            if (!LEVEL2) {
+                // v_u: the screen's value of unit u = the row's last BMU on the operands the screen reads (-w~ fragments of
+                // the stage image, the row's x~), a float32 fma chain: every product of two halves is exact, the chain and
+                // the two cross-quad adds err by < 40 ulps of the largest accumulator magnitude (charged: e_valu)
+                int u = prev[order != nullptr ? order[row] : row];
+                u = u < 0 ? 0 : u >= K ? K - 1 : u;               // (any unit gives a valid bound)
+                const int pos = inv != nullptr ? inv[u] : u;
+                const char* stg = Wst + (long)(pos >> 6) * STAGE;
+                const int t16 = (pos >> 4) & 3, c = pos & 15;
+                float d = 0.0f;
+#pragma unroll
+                for (int ks = 0; ks < KS32; ++ks) {
+                    const bf16x8 a = *(const bf16x8*)(stg + ((t16 * KS32 + ks) * 64 + quad * 16 + c) * 16);
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) d = __builtin_fmaf((float)a[jj], (float)xf[sb][ks][jj], d);
+                }
+                d += __shfl_xor(d, 16, 64);
+                d += __shfl_xor(d, 32, 64);
+                const float vu = *(const float*)(stg + K16_T * KS32 * 1024 + (t16 * 16 + c) * 4) + d;
+                const float Sw = sw.sx * sw.sw;
+                const float e = ex_row_bound(eb, sw, q, xe);          // two-unit window E of the screen (d' units)
+                const float f32s = ex_f32_share(eb, sw, q);           // its float32 share (two evaluations)
+                const float e_valu = 48.0f * 0x1p-24f * Sw * sw.bmag;
+                // seed: whatever beats u in the float32 kernel has a screen value of at most v_u + E + e_valu = seed + f32s
+                const float sd = vu + (e - f32s) * (1.0f + 1.0f / 1024.0f) + e_valu + Sw * sw.bmag * 0x1p-21f;
+                if (quad == 0) seed_s[row] = (sd > 0.0f && sd < 3.0e38f) ? sd : __builtin_inff();
+                // tau_up >= u's real score: d'_real(u) <= v_u + (one-unit screen error) + e_valu,  tau = 2 (d' / S - B)
+                const float e_one = 0.5f * (e - f32s) * (1.0f + 1.0f / 1024.0f) + e_valu;
+                const float tau_up = 2.0f * (((vu + e_one) - Sw * sw.big) / Sw) + 0x1p-20f * (sw.big + __builtin_fabsf(vu) / Sw);
+                const float xn = __builtin_sqrtf(q) * (1.0f + 1.0f / 1024.0f);
+                const float share = 2.0f * (eb.cA * xn * sw.wm + eb.cW * sw.wm * sw.wm);      // tau units, one float32 window
+                // (no fmax here: it would swallow the NaN of a row whose last BMU is a NaN unit, and bound that row by zero)
+                const float U0 = q * (1.0f + 1.0f / 1024.0f) + tau_up + share * (1.0f + 1.0f / 1024.0f) + 0x1p-18f * (q + __builtin_fabsf(tau_up));
+                const float U = U0 < 0.0f ? 0.0f : U0;
+                su = __builtin_sqrtf(U) * (1.0f + 1.0f / 1024.0f);
+                if (force_all || !(su == su) || !(su < 3.0e38f) || !(e == e)) su = __builtin_inff();
+                if (quad == 0) sU_s[row] = su;
+            } else {
+                su = sU_s[row];
+            }
+            const float ec = 0.5f * ex_row_bound(eb, sc, q, xe) * (1.0f + 1.0f / 1024.0f);
+            sU[sb] = su;
             // d'_c > S' (B' + ((sU + r)^2 - |x|^2_lo) / 2) + e_c   <=>   skip
             // (+ margins: the float32 rounding of this line, and |c|^2 as float32 summed it against the real |c|^2)
             A[sb] = S * sc.big + ec - 0.5f * S * q * (1.0f - 1.0f / 1024.0f) + 0x1p-12f * S * (sc.big + q) + 0x1p-16f * S * sc.wm * sc.wm;
-            if (force_all || !(A[sb] == A[sb]) || !(sU[sb] == sU[sb]) || !(A[sb] < 3.0e38f) || !(sU[sb] < 3.0e38f)) {
+            if (!(A[sb] == A[sb]) || !(A[sb] < 3.0e38f) || !(su < 3.0e38f)) {
                 A[sb] = __builtin_inff(); sU[sb] = 0.0f;                                         // need everything
             }
         }
+        // P = A + hS sU^2 (+ the extra feature step's and the larger accumulators' share of the MFMA rounding: the cross term
+        // can double the accumulator's magnitude, and there is one more MFMA in the chain: 4 (KS32 + 1) x 6 ulps of S' Bm')
+        const float bx = up_to_half(sc.sx * sU[sb] * (1.0f + 1.0f / 1024.0f));
+        P[sb] = A[sb] + 0.5f * S * (1.0f + 1.0f / 1024.0f) * sU[sb] * sU[sb] * (1.0f + 0x1p-20f) + (float)(24 * (KS32 + 1)) * 0x1p-23f * S * sc.bmag;
+        if (!(bx < 3.0e38f) || !(P[sb] == P[sb])) P[sb] = __builtin_inff();                      // (sU beyond the half range: need everything)
+        if (A[sb] == -__builtin_inff()) P[sb] = -__builtin_inff();                               // (rows behind the pass)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) xe[sb][jj] = (E)0.0f;
+        if (quad == 0 && bx < 3.0e38f) xe[sb][0] = (E)bx;
     }
-    const float hS = 0.5f * S * (1.0f + 1.0f / 1024.0f);
 
+    // level 2: the stages that hold a sub-block tile of a group level 1 kept, in ascending order, each with the 4-bit mask of
+    // its 16-slot tiles to run (tile t <-> groups 16 s + 4 t .. + 3): an LDS list of (stage << 4 | mask), built by wave 0
+    int* act = (int*)(smem + 2 * STAGE);
+    if (LEVEL2) {
+        if (wave == 0) {
+            int cnt = 0;
+            for (int base = 0; base < n_cstages; base += 64) {
+                const int s2 = base + lane;
+                uint32_t tm = 0u;
+                if (s2 < n_cstages && (s2 >> 2) < n_cstages1) {
+                    const uint32_t sl = (uint32_t)((need1[(long)blockIdx.x * n_cstages1 + (s2 >> 2)] >> (16 * (s2 & 3))) & 0xFFFFull);
+                    tm = ((sl & 0xFu) ? 1u : 0u) | ((sl & 0xF0u) ? 2u : 0u) | ((sl & 0xF00u) ? 4u : 0u) | ((sl & 0xF000u) ? 8u : 0u);
+                }
+                const unsigned long long mk = __ballot(tm != 0u);
+                if (tm != 0u) act[cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (s2 << 4) | (int)tm;
+                cnt += __popcll(mk);
+            }
+            if (lane == 0) act_n = cnt;
+        }
+        __syncthreads();
+    }
+    const int n_walk = LEVEL2 ? act_n : n_cstages;
     // (gridDim.y workgroups share a tile's centroid stages: few tiles -- a batch of 65 536 rows is 256 -- would otherwise be
     //  one workgroup per CU walking all the stages alone)
-    const int s_begin = (int)((long)n_cstages * blockIdx.y / gridDim.y);
-    const int s_end = (int)((long)n_cstages * (blockIdx.y + 1) / gridDim.y);
-    if (s_begin < s_end)
+    const int s_begin = (int)((long)n_walk * blockIdx.y / gridDim.y);
+    const int s_end = (int)((long)n_walk * (blockIdx.y + 1) / gridDim.y);
+    auto item_of = [&](int i) -> int { return __builtin_amdgcn_readfirstlane(LEVEL2 ? act[i] : ((i << 4) | 15)); };
+    auto dma_stage = [&](int s, uint32_t tm, char* dst) {
+        const char* src = Cst + (long)s * STAGE;
         for (int p = wave; p < PIECES; p += K16_NW)
-            lds_dma_16(Cst + (long)s_begin * STAGE + (long)p * 1024 + lane * 16, smem + p * 1024);
-    for (int s = s_begin; s < s_end; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (p == PIECES - 1 || ((tm >> (p / KS32)) & 1u)) lds_dma_16(src + (long)p * 1024 + lane * 16, dst + p * 1024);
+    };
+    int st_cur = 0, st_next = 0;
+    uint32_t tm_cur = 0, tm_next = 0;
+    if (s_begin < s_end) {
+        const int it = item_of(s_begin);
+        st_cur = it >> 4; tm_cur = (uint32_t)it & 15u;
+        dma_stage(st_cur, tm_cur, smem);
+    }
+    for (int i = s_begin; i < s_end; ++i) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + 1 < s_end) {
-            const char* src = Cst + (long)(s + 1) * STAGE;
-            char* dst = smem + ((s + 1 - s_begin) & 1) * STAGE;
-            for (int p = wave; p < PIECES; p += K16_NW) lds_dma_16(src + (long)p * 1024 + lane * 16, dst + p * 1024);
+        if (i + 1 < s_end) {
+            const int it = item_of(i + 1);
+            st_next = it >> 4; tm_next = (uint32_t)it & 15u;
+            dma_stage(st_next, tm_next, smem + ((i + 1 - s_begin) & 1) * STAGE);
         }
-        const char* st = smem + ((s - s_begin) & 1) * STAGE;
+        const int s = st_cur;
+        const char* st = smem + ((i - s_begin) & 1) * STAGE;
         const float* wq = (const float*)(st + K16_T * KS32 * 1024);
-        unsigned long long mine = 0ull;                       // bit (16 t16 + 4 quad + r) <-> centroid of that place in the stage
+        unsigned long long mine = 0ull;                       // bit (16 t16 + 4 quad + r) <-> centroid slot of that place in the stage
 #pragma unroll
         for (int t16 = 0; t16 < K16_T; ++t16) {
+            if (LEVEL2 && !((tm_cur >> t16) & 1u)) continue;  // (wave-uniform)
             const f32x4 wv = *(const f32x4*)(wq + t16 * 16 + 4 * quad);
+            bf16x8 ae;                                        // the centroids' side of the extra step: slot 0 = -up_to_half(sw r)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) ae[jj] = (E)0.0f;
+            if (quad == 0) ae[0] = (E)wq[64 + t16 * 16 + col];
             f32x4 acc[K16_SB];
 #pragma unroll
             for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = wv;
@@ -183,47 +330,50 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16
                 for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = mfma16(a, xf[sb][ks], acc[sb]);
             }
 #pragma unroll
+            for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = mfma16(ae, xe[sb], acc[sb]);
+#pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int g = s * K16_STAGE_UNITS + t16 * 16 + 4 * quad + r;
-                const float rad = g < n_groups ? rg[g] : 0.0f;
                 bool nd = false;
 #pragma unroll
-                for (int sb = 0; sb < K16_SB; ++sb) {
-                    const float q = sU[sb] + rad;
-                    const float rhs = __builtin_fmaf(q * q, hS, A[sb]);
-                    nd = nd || !(acc[sb][r] > rhs);
-                }
-                const unsigned long long b = __ballot(nd && g < n_groups);
+                for (int sb = 0; sb < K16_SB; ++sb) nd = nd || !(acc[sb][r] > P[sb]);
+                const unsigned long long b = __ballot(nd);
                 // lanes of quad qd vote for centroid 4 qd + r of the tile
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd)
                     if ((b >> (16 * qd)) & 0xFFFFull) mine |= 1ull << (t16 * 16 + 4 * qd + r);
             }
         }
-        if (lane == 0) wneed[wave] = mine;
-        __builtin_amdgcn_s_barrier();
-        if (tid == 0) {
-            unsigned long long all = 0ull;
-#pragma unroll
-            for (int w = 0; w < K16_NW; ++w) all |= wneed[w];
-            need[(long)blockIdx.x * n_cstages + s] = all;
-        }
+        // (the words start from zero: the host clears them; a wave adds its rows' bits)
+        if (lane == 0 && mine != 0ull) atomicOr(need + (long)blockIdx.x * n_cstages + s, mine);
+        st_cur = st_next; tm_cur = tm_next;
     }
 }
 
-// need bitmap -> per tile the ascending list of groups to run, and its length.  One wave per tile.
-__global__ __launch_bounds__(64) void exact_lists_kernel(const unsigned long long* __restrict__ need, int n_cstages, int n_groups,
+// need bitmaps -> per tile the ascending list of items (group << 4 | mask of the group's 16-unit sub-blocks to run), and its
+// length.  need1: bit j of word s <-> group 64 s + j (level 1).  need2 (or null: every sub-block of a kept group runs):
+// word 4 s + k holds, for the groups 64 s + 16 k .. + 15, a nibble each (bit 4 (g & 15) + sub <-> sub-block `sub` of group g).
+// One wave per tile.  blocks_run counts 16-unit blocks.
+__global__ __launch_bounds__(64) void exact_lists_kernel(const unsigned long long* __restrict__ need1, int n_cstages,
+                                                         const unsigned long long* __restrict__ need2, int n_groups,
                                                          int* __restrict__ glist, int* __restrict__ gcnt,
                                                          int* __restrict__ blocks_run) {
     const long tile = blockIdx.x;
     const int lane = threadIdx.x;
-    int base = 0;
+    int base = 0, blk = 0;
     for (int s = 0; s < n_cstages; ++s) {
-        const unsigned long long w = need[tile * n_cstages + s];
-        if ((w >> lane) & 1ull) glist[tile * n_groups + base + __popcll(w & ((1ull << lane) - 1ull))] = s * 64 + lane;
-        base += __popcll(w);
+        const unsigned long long w = need1[tile * n_cstages + s];
+        if (w == 0ull) continue;
+        uint32_t nib = 15u;
+        if (need2 != nullptr) nib = (uint32_t)(need2[tile * 4 * n_cstages + 4 * s + (lane >> 4)] >> (4 * (lane & 15))) & 15u;
+        const int g = s * 64 + lane;
+        const bool on = ((w >> lane) & 1ull) && nib != 0u && g < n_groups;
+        const unsigned long long mk = __ballot(on);
+        if (on) glist[tile * n_groups + base + __popcll(mk & ((1ull << lane) - 1ull))] = (g << 4) | (int)nib;
+        base += __popcll(mk);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) blk += __popcll(__ballot(on && ((nib >> b) & 1u)));
     }
-    if (lane == 0) { gcnt[tile] = base; atomicAdd(blocks_run, base); }
+    if (lane == 0) { gcnt[tile] = base; atomicAdd(blocks_run, blk); }
 }
 
 }  // namespace somhip

@@ -96,23 +96,37 @@ struct som_handle {
         int* fb_count_host = nullptr;        // pinned
         hipEvent_t fb_ready = nullptr;       // recorded behind the counter's copy
         int64_t rows_total = 0, rows_fallback = 0, chunks = 0;   // som_exact_stats
-        int64_t blocks_run = 0, blocks_total = 0;                // som_exact_skip_stats: (256-row tile, group) blocks of the screens
+        int64_t blocks_run = 0, blocks_total = 0;                // som_exact_skip_stats: (256-row tile, 16-unit block) blocks of the screens
         long pass_rows_override = 0;
         long stride_cap = 0;              // rows per pass the device had memory for (0: no allocation was ever refused)
         long pairs = 64;                  // capacity of a pass: (row, group) pairs per row on average (exact_reserve)
         // block skipping (exact_skip.hpp): resident rows from their second epoch on, input_len <= 128
-        int skip_mode = 1;                // SOM_EXACT_SKIP: 0 off, 1 on for maps of >= 4096 units (default), 2 on for every map of >= 2 groups (tests)
+        int skip_mode = 1;                // SOM_EXACT_SKIP: 0 off, 1 on for maps of >= 4096 units (default), 2 on for every map of >= 2 groups (tests), 3: plan, keep everything
         bool skip_live = false;           // this launch plans and skips
         int skip_cooldown = 0;            // launches to run without a plan (the last two plans kept > 97 % of the blocks)
         int skip_idle = 0;                // plans in a row that kept > 97 % of the blocks
-        long sk_stride = 0;               // rows the sorted-pass buffers hold
+        bool sub_blocks = true;           // SOM_EXACT_SUBBLOCKS=0: the plan stops at the groups (A/B)
+        // the RESIDENT SORTED PASS: the rows in the order of their BMU's patch at the time of the last sort (position ->
+        // row: `order`), with sorted copies of the half image, the float32 rows and the norms.  Valid for (res_rows, res_n);
+        // re-sorted when the order has gone stale (res_* below), not every epoch.
+        long sk_rows = 0;                 // positions the sorted buffers hold (all passes, each padded to the tile)
+        long sk_stride = 0;               // rows per pass the per-pass plan buffers hold
+        const void* res_rows = nullptr; long res_n = -1;
+        bool res_valid = false;
+        int res_every = 0;                // SOM_EXACT_RESORT=n: re-sort every n-th planned epoch (0: when the order has gone stale)
+        int res_since = 0;                // planned epochs since the last sort
+        int res_wait = 1;                 // ... to wait at least before the next one (doubles after a sort that did not pay)
+        double res_share_sort = 1.0;      // executed share of the first epoch after the last sort
+        double res_share_last = 1.0;      // ... of the last planned epoch
+        int64_t resorts = 0, planned = 0; // som_exact_resident_stats
         int *order = nullptr, *sk_keys = nullptr, *sk_keys2 = nullptr, *sk_vals = nullptr;
         void* sk_tmp = nullptr; size_t sk_tmp_bytes = 0;
         __bf16* Xb_s = nullptr;
-        float *xsq_s = nullptr, *xerr_s = nullptr, *seed_s = nullptr, *tq = nullptr, *tq_s = nullptr;
-        float *Cc = nullptr, *rg = nullptr, *csq = nullptr, *wn_c = nullptr, *cmax2 = nullptr;
-        char* Cst = nullptr; int n_cstages = 0;
-        unsigned long long* need = nullptr;
+        float *Xf_s = nullptr, *xsq_s = nullptr, *xerr_s = nullptr, *seed_s = nullptr, *sU_s = nullptr;
+        // the centroid sets of the plan: [0] the 64-unit groups, [1] their 16-unit sub-blocks (exact_centroid_kernel's slot order)
+        struct Centroids { float *Cc = nullptr, *rg = nullptr, *csq = nullptr, *wn_c = nullptr, *cmax2 = nullptr; char* Cst = nullptr;
+                           int n_slots = 0, n_cstages = 0; } cen[2];
+        unsigned long long *need = nullptr, *need2 = nullptr;
         int *glist = nullptr, *gcnt = nullptr;
     } ex;
     int n_kchunks = 0;       // tiled: 64-feature chunks
@@ -988,20 +1002,27 @@ int exact_screen(som_handle* h, const __bf16* Xb, long n, unsigned long long* be
                  const float* xmax2, const ExactBound& eb, const float* seed, const int* glist, const int* gcnt) {
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
     // one pass on scaled half operands: a stage IS a group
-    auto kern = bmu_bf16_k16_kernel<KS32, E, true>;
+    const bool tl = glist != nullptr;
+    const void* kern = tl ? (const void*)bmu_bf16_k16_kernel<KS32, E, true, true> : (const void*)bmu_bf16_k16_kernel<KS32, E, true, false>;
     size_t lds = 2 * (size_t)k16_stage_bytes(KS32);
     int per_cu = 1;
-    if (int rc = kernel_per_cu(h, (const void*)kern, 64 * K16_NW, lds, &per_cu)) return rc;
+    if (int rc = kernel_per_cu(h, kern, 64 * K16_NW, lds, &per_cu)) return rc;
     const long blocks = cdiv(n, K16_WG_SAMPLES);
     const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
     int parts = choose_parts(h, blocks, slots, h->n_stages);
     if (h->env_bf16_parts > 0) parts = std::min(h->env_bf16_parts, h->n_stages);
     if (h->debug)
-        std::fprintf(stderr, "[somhip] exact screen: blocks=%ld per_cu=%d slots=%ld parts=%d groups=%d\n", blocks, per_cu,
-                     slots, parts, n_groups);
-    kern<<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * K16_NW), lds, h->stream>>>(
-        Xb, n, h->Wst, h->n_stages, h->K, best64, h->ex.gmin, h->ex.stride, h->ex.gflags, xsq, xerr, xmax2, h->wmax2, h->wmax2 + 1, eb,
-        seed, glist, gcnt);
+        std::fprintf(stderr, "[somhip] exact screen: blocks=%ld per_cu=%d slots=%ld parts=%d groups=%d lists=%d\n", blocks, per_cu,
+                     slots, parts, n_groups, tl ? 1 : 0);
+    const dim3 grid((unsigned)blocks, (unsigned)parts), block(64 * K16_NW);
+    if (tl)
+        bmu_bf16_k16_kernel<KS32, E, true, true><<<grid, block, lds, h->stream>>>(
+            Xb, n, h->Wst, h->n_stages, h->K, best64, h->ex.gmin, h->ex.stride, h->ex.gflags, xsq, xerr, xmax2, h->wmax2, h->wmax2 + 1, eb,
+            seed, glist, gcnt);
+    else
+        bmu_bf16_k16_kernel<KS32, E, true, false><<<grid, block, lds, h->stream>>>(
+            Xb, n, h->Wst, h->n_stages, h->K, best64, h->ex.gmin, h->ex.stride, h->ex.gflags, xsq, xerr, xmax2, h->wmax2, h->wmax2 + 1, eb,
+            seed, nullptr, nullptr);
     return 0;
 }
 
@@ -1062,45 +1083,81 @@ int exact_screen_ks(som_handle* h, const __bf16* Xb, long n, unsigned long long*
 }
 
 
-// ---- block skipping (exact_skip.hpp): buffers, the centroid image, a pass's plan ------------------------------------------
-int exact_skip_reserve(som_handle* h, long stride) {
+// BMU ids are <= 20-bit keys in 4-byte ints: rocPRIM's default picks its merge sort up to 1 Mi items for
+// 4-byte keys (ten merge passes at 1 Mi rows: 0.16 ms); two 8-bit Onesweep passes take half of that, but lose
+// to the merge sort at 100 k rows -- so Onesweep from SORT_ONESWEEP_ROWS rows on.
+using SortOnesweep = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 1024>;
+constexpr long SORT_ONESWEEP_ROWS = 262144;
+
+template <typename... Args>
+hipError_t sort_bmu_pairs(long n, Args... args) {
+    if (n >= SORT_ONESWEEP_ROWS) return rocprim::radix_sort_pairs<SortOnesweep>(args...);
+    return rocprim::radix_sort_pairs(args...);
+}
+// temporary storage that serves both algorithms for up to n rows
+template <typename K, typename V>
+hipError_t sort_bmu_pairs_storage(size_t& bytes, K* kin, K* kout, V* vin, V* vout, long n, unsigned bits, hipStream_t st) {
+    size_t b1 = 0, b2 = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, b1, kin, kout, vin, vout, (size_t)n, 0u, bits, st);
+    if (e != hipSuccess) return e;
+    e = rocprim::radix_sort_pairs<SortOnesweep>(nullptr, b2, kin, kout, vin, vout, (size_t)n, 0u, bits, st);
+    bytes = b1 > b2 ? b1 : b2;
+    return e;
+}
+
+// ---- block skipping (exact_skip.hpp): buffers, the centroid images, the resident sorted pass, a pass's plan ------------------
+// rows_all: every resident row (the sorted copies hold all passes); stride: rows of one pass (the plan's own buffers)
+int exact_skip_reserve(som_handle* h, long rows_all, long stride) {
     auto& ex = h->ex;
     // TEST HOOK (tests/test_gpu_exact.py): behave as a device without memory for the sorted pass
     if (std::getenv("SOM_EXACT_DEBUG_REFUSE_SKIP")) return fail(h, "exact: block-skipping scratch refused (test hook)");
     const long n_groups = cdiv(h->K, EX_GROUP);
-    if (!ex.Cc) {
-        ex.n_cstages = (int)cdiv(n_groups, K16_STAGE_UNITS);
-        if (int rc = dev_alloc(h, &ex.Cc, (size_t)n_groups * h->D)) return rc;
-        if (int rc = dev_alloc(h, &ex.rg, (size_t)n_groups)) return rc;
-        if (int rc = dev_alloc(h, &ex.csq, (size_t)n_groups)) return rc;
-        if (int rc = dev_alloc(h, &ex.wn_c, (size_t)n_groups)) return rc;
-        if (int rc = dev_alloc(h, &ex.cmax2, 2)) return rc;
-        if (int rc = dev_alloc(h, &ex.Cst, (size_t)ex.n_cstages * h->stage_bytes)) return rc;
-        HIPCHK(h, hipMemsetAsync(ex.Cst, 0, (size_t)ex.n_cstages * h->stage_bytes, h->stream));
+    if (!ex.cen[0].Cc) {
+        const int ncs = (int)cdiv(n_groups, K16_STAGE_UNITS);
+        for (int lv = 0; lv < 2; ++lv) {
+            auto& c = ex.cen[lv];
+            // level 2: sixteen slots per four groups, 4 * ncs stages (need2 is addressed [tile][4 * ncs]: exact_lists_kernel)
+            c.n_slots = lv == 0 ? (int)n_groups : (int)cdiv(n_groups, 4) * 16;
+            c.n_cstages = lv == 0 ? ncs : 4 * ncs;
+            if (int rc = dev_alloc(h, &c.Cc, (size_t)c.n_slots * h->D)) return rc;
+            if (int rc = dev_alloc(h, &c.rg, (size_t)c.n_slots)) return rc;
+            if (int rc = dev_alloc(h, &c.csq, (size_t)c.n_slots)) return rc;
+            if (int rc = dev_alloc(h, &c.wn_c, (size_t)c.n_slots)) return rc;
+            if (int rc = dev_alloc(h, &c.cmax2, 2)) return rc;
+            if (int rc = dev_alloc(h, &c.Cst, (size_t)c.n_cstages * h->stage_bytes)) return rc;
+            HIPCHK(h, hipMemsetAsync(c.Cst, 0, (size_t)c.n_cstages * h->stage_bytes, h->stream));
+        }
+    }
+    const long need_rows = round_up(rows_all, SK_TILE);
+    if (need_rows > ex.sk_rows) {
+        void* old[] = {ex.order, ex.Xb_s, ex.Xf_s, ex.xsq_s, ex.xerr_s, ex.seed_s, ex.sU_s};
+        for (void* p : old) if (p) (void)hipFree(p);
+        ex.order = nullptr; ex.Xb_s = nullptr; ex.Xf_s = ex.xsq_s = ex.xerr_s = ex.seed_s = ex.sU_s = nullptr;
+        ex.sk_rows = 0; ex.res_valid = false;
+        if (int rc = dev_alloc(h, &ex.order, (size_t)need_rows)) return rc;
+        if (int rc = dev_alloc(h, &ex.Xb_s, (size_t)need_rows * h->dp)) return rc;
+        if (int rc = dev_alloc(h, &ex.Xf_s, (size_t)need_rows * h->D)) return rc;
+        if (int rc = dev_alloc(h, &ex.xsq_s, (size_t)need_rows)) return rc;
+        if (int rc = dev_alloc(h, &ex.xerr_s, (size_t)need_rows)) return rc;
+        if (int rc = dev_alloc(h, &ex.seed_s, (size_t)need_rows)) return rc;
+        if (int rc = dev_alloc(h, &ex.sU_s, (size_t)need_rows)) return rc;
+        ex.sk_rows = need_rows;
     }
     if (stride <= ex.sk_stride) return 0;
-    void* old[] = {ex.order, ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.sk_tmp, ex.Xb_s, ex.xsq_s, ex.xerr_s, ex.seed_s, ex.tq, ex.tq_s,
-                   ex.need, ex.glist, ex.gcnt};
+    void* old[] = {ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.sk_tmp, ex.need, ex.need2, ex.glist, ex.gcnt};
     for (void* p : old) if (p) (void)hipFree(p);
-    ex.order = ex.sk_keys = ex.sk_keys2 = ex.sk_vals = nullptr; ex.sk_tmp = nullptr; ex.Xb_s = nullptr;
-    ex.xsq_s = ex.xerr_s = ex.seed_s = ex.tq = ex.tq_s = nullptr; ex.need = nullptr; ex.glist = ex.gcnt = nullptr;
+    ex.sk_keys = ex.sk_keys2 = ex.sk_vals = nullptr; ex.sk_tmp = nullptr; ex.need = ex.need2 = nullptr; ex.glist = ex.gcnt = nullptr;
     ex.sk_stride = 0;
     const long tiles = stride / SK_TILE;
-    if (int rc = dev_alloc(h, &ex.order, (size_t)stride)) return rc;
     if (int rc = dev_alloc(h, &ex.sk_keys, (size_t)stride)) return rc;
     if (int rc = dev_alloc(h, &ex.sk_keys2, (size_t)stride)) return rc;
     if (int rc = dev_alloc(h, &ex.sk_vals, (size_t)stride)) return rc;
-    if (int rc = dev_alloc(h, &ex.Xb_s, (size_t)stride * h->dp)) return rc;
-    if (int rc = dev_alloc(h, &ex.xsq_s, (size_t)stride)) return rc;
-    if (int rc = dev_alloc(h, &ex.xerr_s, (size_t)stride)) return rc;
-    if (int rc = dev_alloc(h, &ex.seed_s, (size_t)stride)) return rc;
-    if (int rc = dev_alloc(h, &ex.tq, (size_t)stride)) return rc;
-    if (int rc = dev_alloc(h, &ex.tq_s, (size_t)stride)) return rc;
-    if (int rc = dev_alloc(h, &ex.need, (size_t)tiles * ex.n_cstages)) return rc;
+    if (int rc = dev_alloc(h, &ex.need, (size_t)tiles * ex.cen[0].n_cstages)) return rc;
+    if (int rc = dev_alloc(h, &ex.need2, (size_t)tiles * ex.cen[1].n_cstages)) return rc;
     if (int rc = dev_alloc(h, &ex.glist, (size_t)tiles * n_groups)) return rc;
     if (int rc = dev_alloc(h, &ex.gcnt, (size_t)tiles)) return rc;
     size_t bytes = 0;
-    HIPCHK(h, rocprim::radix_sort_pairs(nullptr, bytes, ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.order, (size_t)stride, 0, 32, h->stream));
+    HIPCHK(h, sort_bmu_pairs_storage(bytes, ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.order, stride, 32u, h->stream));
     char* tmp = nullptr;
     if (int rc = dev_alloc(h, &tmp, bytes + 256)) return rc;
     ex.sk_tmp = tmp; ex.sk_tmp_bytes = bytes;
@@ -1108,35 +1165,38 @@ int exact_skip_reserve(som_handle* h, long stride) {
     return 0;
 }
 
-// centroids and radii of the groups of the current codebook, the centroids' scaled half image and initial accumulators
+// centroids and radii of the groups and of their sub-blocks under the current codebook, the centroids' scaled half images
+// and initial accumulators
 template <class E>
 int exact_skip_centroids(som_handle* h, const float* xmax2) {
     auto& ex = h->ex;
-    const int n_groups = (int)cdiv(h->K, EX_GROUP);
     const float* Wsrc = h->ex_patch ? h->Wp : h->W;
-    exact_centroid_kernel<<<dim3((unsigned)n_groups), dim3(128), 0, h->stream>>>(Wsrc, h->K, h->D, ex.Cc, ex.rg);
-    row_sq_f32_kernel<<<dim3((unsigned)cdiv(n_groups, 256)), dim3(256), 0, h->stream>>>(ex.Cc, n_groups, h->D, ex.csq);
-    HIPCHK(h, hipMemsetAsync(ex.cmax2, 0, 2 * sizeof(float), h->stream));
-    exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(n_groups, 1024)), dim3(1024), 0, h->stream>>>(ex.csq, n_groups, ex.wn_c, ex.cmax2);
-    const dim3 tgrid((unsigned)cdiv((long)ex.n_cstages * K16_T, 4)), block(256);
-    switch (h->ks32) {
-    case 1: prep_w_exact_k16_kernel<1, E><<<tgrid, block, 0, h->stream>>>(ex.Cc, n_groups, h->D, ex.Cst, ex.n_cstages, ex.cmax2, ex.cmax2 + 1); break;
-    case 2: prep_w_exact_k16_kernel<2, E><<<tgrid, block, 0, h->stream>>>(ex.Cc, n_groups, h->D, ex.Cst, ex.n_cstages, ex.cmax2, ex.cmax2 + 1); break;
-    case 3: prep_w_exact_k16_kernel<3, E><<<tgrid, block, 0, h->stream>>>(ex.Cc, n_groups, h->D, ex.Cst, ex.n_cstages, ex.cmax2, ex.cmax2 + 1); break;
-    case 4: prep_w_exact_k16_kernel<4, E><<<tgrid, block, 0, h->stream>>>(ex.Cc, n_groups, h->D, ex.Cst, ex.n_cstages, ex.cmax2, ex.cmax2 + 1); break;
-    default: return fail(h, "exact: block skipping supports input_len <= 128");
+    for (int lv = 0; lv < (ex.sub_blocks ? 2 : 1); ++lv) {
+        auto& c = ex.cen[lv];
+        exact_centroid_kernel<<<dim3((unsigned)c.n_slots), dim3(128), 0, h->stream>>>(Wsrc, h->K, h->D, c.Cc, c.rg, lv);
+        row_sq_f32_kernel<<<dim3((unsigned)cdiv(c.n_slots, 256)), dim3(256), 0, h->stream>>>(c.Cc, c.n_slots, h->D, c.csq);
+        HIPCHK(h, hipMemsetAsync(c.cmax2, 0, 2 * sizeof(float), h->stream));
+        exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(c.n_slots, 1024)), dim3(1024), 0, h->stream>>>(c.csq, c.n_slots, c.wn_c, c.cmax2);
+        const dim3 tgrid((unsigned)cdiv((long)c.n_cstages * K16_T, 4)), block(256);
+        switch (h->ks32) {
+        case 1: prep_w_exact_k16_kernel<1, E><<<tgrid, block, 0, h->stream>>>(c.Cc, c.n_slots, h->D, c.Cst, c.n_cstages, c.cmax2, c.cmax2 + 1); break;
+        case 2: prep_w_exact_k16_kernel<2, E><<<tgrid, block, 0, h->stream>>>(c.Cc, c.n_slots, h->D, c.Cst, c.n_cstages, c.cmax2, c.cmax2 + 1); break;
+        case 3: prep_w_exact_k16_kernel<3, E><<<tgrid, block, 0, h->stream>>>(c.Cc, c.n_slots, h->D, c.Cst, c.n_cstages, c.cmax2, c.cmax2 + 1); break;
+        case 4: prep_w_exact_k16_kernel<4, E><<<tgrid, block, 0, h->stream>>>(c.Cc, c.n_slots, h->D, c.Cst, c.n_cstages, c.cmax2, c.cmax2 + 1); break;
+        default: return fail(h, "exact: block skipping supports input_len <= 128");
+        }
+        const long units = (long)c.n_cstages * h->stage_units;
+        prep_wsqh_kernel<<<dim3((unsigned)cdiv(units, 256)), dim3(256), 0, h->stream>>>(
+            c.wn_c, c.n_slots, c.cmax2, xmax2, c.Cst, c.n_cstages, h->stage_bytes, h->stage_units, nullptr, 0, 1);
+        exact_plan_tail_kernel<<<dim3((unsigned)cdiv(units, 256)), dim3(256), 0, h->stream>>>(c.Cst, c.n_cstages, h->stage_bytes, c.rg, c.n_slots,
+                                                                                           xmax2, c.cmax2);
     }
-    const long units = (long)ex.n_cstages * h->stage_units;
-    prep_wsqh_kernel<<<dim3((unsigned)cdiv(units, 256)), dim3(256), 0, h->stream>>>(
-        ex.wn_c, n_groups, ex.cmax2, xmax2, ex.Cst, ex.n_cstages, h->stage_bytes, h->stage_units, nullptr, 0, 1);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
 
-// one pass: rows sorted by their last BMU's group, operands gathered in that order, the plan and the tiles' group lists
-template <class E>
-int exact_skip_plan(som_handle* h, const __bf16* Xb, long n, const float* xsq, const float* xerr, const int* prev, const float* xmax2,
-                    const ExactBound& eb) {
+// (re-)sort one pass: the rows [r0, r0 + n) in the order of their last BMU's group, the operands gathered in that order
+int exact_skip_sort(som_handle* h, const float* X, const __bf16* Xb, long r0, long n, const float* xsq, const float* xerr, const int* prev) {
     auto& ex = h->ex;
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
     const long np = round_up(n, SK_TILE);
@@ -1144,25 +1204,54 @@ int exact_skip_plan(som_handle* h, const __bf16* Xb, long n, const float* xsq, c
     int bits = 1;
     while ((1L << bits) < n_groups) ++bits;
     size_t bytes = ex.sk_tmp_bytes;
-    HIPCHK(h, rocprim::radix_sort_pairs(ex.sk_tmp, bytes, ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.order, (size_t)n, 0, (unsigned)bits, h->stream));
-    const long pieces = np * (h->dp / 8);
-    exact_gather_sorted_kernel<<<dim3((unsigned)cdiv(pieces, 256)), dim3(256), 0, h->stream>>>(
-        ex.order, n, np, h->dp, Xb, xsq, xerr, ex.seed, ex.tq, ex.Xb_s, ex.xsq_s, ex.xerr_s, ex.seed_s, ex.tq_s);
+    HIPCHK(h, sort_bmu_pairs(n, ex.sk_tmp, bytes, ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.order + r0, (size_t)n, 0u, (unsigned)bits, h->stream));
+    exact_gather_sorted_kernel<<<dim3((unsigned)cdiv(np, 4)), dim3(256), 0, h->stream>>>(
+        ex.order + r0, n, np, h->dp, h->D, Xb, X, xsq, xerr, ex.Xb_s + r0 * h->dp, ex.Xf_s + r0 * h->D, ex.xsq_s + r0, ex.xerr_s + r0);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// one pass's plan on the resident sorted rows [r0, r0 + n): level 1 (+ the seeds), level 2, the tiles' item lists
+template <class E>
+int exact_skip_plan(som_handle* h, long r0, long n, const int* prev, const float* xmax2, const ExactBound& eb) {
+    auto& ex = h->ex;
+    const int n_groups = (int)cdiv(h->K, EX_GROUP);
+    const long np = round_up(n, SK_TILE);
+    const long tiles = np / SK_TILE;
     // skipped (row block, group) pairs are never written by the screen: their masks must read empty
     HIPCHK(h, hipMemsetAsync(ex.gflags, 0, (size_t)n_groups * (np / 64) * sizeof(unsigned long long), h->stream));
-    const size_t lds = 2 * (size_t)h->stage_bytes;
-    const dim3 grid((unsigned)(np / SK_TILE)), block(64 * K16_NW);
+    const dim3 block(64 * K16_NW);
+    const auto& c0 = ex.cen[0];
+    const auto& c1 = ex.cen[1];
     // (few tiles: their centroid stages split over up to four workgroups each, so that the plan fills the chip)
-    const long want = (1024 + (np / SK_TILE) - 1) / (np / SK_TILE);
-    const dim3 pgrid((unsigned)(np / SK_TILE), (unsigned)std::max<long>(1, std::min<long>({want, 4L, (long)ex.n_cstages})));
-#define SOM_PLAN_CASE(k) case k: exact_plan_kernel<k, E><<<pgrid, block, lds, h->stream>>>(ex.Xb_s, n, ex.Cst, ex.n_cstages, ex.rg, n_groups, \
-        ex.xsq_s, ex.xerr_s, ex.tq_s, xmax2, ex.cmax2, h->wmax2, h->wmax2 + 1, eb, ex.need, ex.skip_mode == 3 ? 1 : 0); break;
+    const long want = (1024 + tiles - 1) / tiles;
+    const dim3 pgrid((unsigned)tiles, (unsigned)std::max<long>(1, std::min<long>({want, 4L, (long)c0.n_cstages})));
+    const size_t lds1 = 2 * (size_t)h->stage_bytes;
+    const size_t lds2 = 2 * (size_t)h->stage_bytes + (size_t)c1.n_cstages * sizeof(int);
+    if (ex.sub_blocks && lds2 > 150 * 1024) return fail(h, "exact: map too large for the level-2 plan's stage list");
+    const int force = ex.skip_mode == 3 ? 1 : 0;
+    const __bf16* Xs = ex.Xb_s + r0 * h->dp;
+    // (the plan's waves OR their rows' bits into the words)
+    HIPCHK(h, hipMemsetAsync(ex.need, 0, (size_t)tiles * c0.n_cstages * sizeof(unsigned long long), h->stream));
+    if (ex.sub_blocks) HIPCHK(h, hipMemsetAsync(ex.need2, 0, (size_t)tiles * c1.n_cstages * sizeof(unsigned long long), h->stream));
+#define SOM_PLAN_CASE(k) case k: { \
+        { int pc; if (int rc = kernel_per_cu(h, (const void*)exact_plan_kernel<k, E, false>, 64 * K16_NW, lds1, &pc)) return rc; } \
+        exact_plan_kernel<k, E, false><<<pgrid, block, lds1, h->stream>>>(Xs, n, c0.Cst, c0.n_cstages, c0.rg, c0.n_slots, \
+            ex.xsq_s + r0, ex.xerr_s + r0, ex.sU_s + r0, xmax2, c0.cmax2, h->wmax2, h->wmax2 + 1, eb, ex.need, prev, ex.order + r0, \
+            h->ex_inv, h->Wst, h->K, ex.seed_s + r0, nullptr, 0, force); \
+        if (ex.sub_blocks) { \
+            { int pc; if (int rc = kernel_per_cu(h, (const void*)exact_plan_kernel<k, E, true>, 64 * K16_NW, lds2, &pc)) return rc; } \
+            exact_plan_kernel<k, E, true><<<dim3((unsigned)tiles, pgrid.y), block, lds2, h->stream>>>(Xs, n, c1.Cst, c1.n_cstages, c1.rg, c1.n_slots, \
+                ex.xsq_s + r0, ex.xerr_s + r0, ex.sU_s + r0, xmax2, c1.cmax2, h->wmax2, h->wmax2 + 1, eb, ex.need2, nullptr, nullptr, \
+                nullptr, nullptr, h->K, nullptr, ex.need, c0.n_cstages, force); \
+        } } break;
     switch (h->ks32) {
     SOM_PLAN_CASE(1) SOM_PLAN_CASE(2) SOM_PLAN_CASE(3) SOM_PLAN_CASE(4)
     default: return fail(h, "exact: block skipping supports input_len <= 128");
     }
 #undef SOM_PLAN_CASE
-    exact_lists_kernel<<<grid, dim3(64), 0, h->stream>>>(ex.need, ex.n_cstages, n_groups, ex.glist, ex.gcnt, ex.ctr + 2 * n_groups + 3);
+    exact_lists_kernel<<<dim3((unsigned)tiles), dim3(64), 0, h->stream>>>(ex.need, c0.n_cstages, ex.sub_blocks ? ex.need2 : nullptr, n_groups,
+                                                                         ex.glist, ex.gcnt, ex.ctr + 2 * n_groups + 3);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -1177,7 +1266,7 @@ int exact_rescore_kg(som_handle* h, const float* X, int n_groups) {
     // (twice the resident slots: the runs of tiles are uneven -- partial tiles, idle waves -- and finer runs balance them)
     const long grid = std::min<long>(ex.max_tiles, 2L * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
     kern<<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, h->D, h->Wfst, h->K, ex.tile_tab, ex.ctr + 2 * n_groups + 1, ex.plist,
-                                                             h->best64, h->ex_perm, ex.skip_live ? ex.order : nullptr);
+                                                             h->best64, h->ex_perm, nullptr);
     return 0;
 }
 
@@ -1253,33 +1342,48 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     // by two launches without a plan (the plan costs 4-8 % of a full scan), and so on while the plans stay idle
     if (ex.skip_live && ex.skip_mode == 1 && ex.skip_cooldown > 0) { --ex.skip_cooldown; ex.skip_live = false; }
     const int64_t run_before = ex.blocks_run, total_before = ex.blocks_total;
-    if (ex.skip_live && exact_skip_reserve(h, ex.stride) != 0) {
+    if (ex.skip_live && exact_skip_reserve(h, N, ex.stride) != 0) {
         // no memory for the sorted pass's buffers: every block runs, from now on (the ids are the same either way)
         (void)hipGetLastError();
         if (h->debug) std::fprintf(stderr, "[somhip] exact: block skipping off (%s)\n", h->err.c_str());
         h->err.clear();
         ex.skip_live = false; ex.skip_mode = 0;
     }
-    if (ex.skip_live)
+    // the resident sorted pass: (re-)sort when there is none for these rows, when asked to (SOM_EXACT_RESORT=n: every n-th
+    // planned epoch), or when the order has gone stale: while a quarter of the blocks or more still run a sort costs a few
+    // percent of the screen it sharpens (the early epochs of a schedule, where rows still travel across the map); later,
+    // when the executed share has grown by a fifth since the epoch after the last sort; and every eighth planned epoch at
+    // the latest (a sort that did not pay doubles the wait).  A stale order costs speed, never correctness: the plan tests
+    // every row of a tile where it sits.
+    bool resort = false;
+    if (ex.skip_live) {
+        if (!ex.res_valid || ex.res_rows != (const void*)X || ex.res_n != N) resort = true;
+        else if (ex.res_every > 0) resort = ex.res_since >= ex.res_every;
+        else resort = ex.res_share_last >= 0.25 || (ex.res_since >= ex.res_wait && (ex.res_share_last > 1.2 * ex.res_share_sort + 0.003 || ex.res_since >= 8));
         if (int rc = SOM_HALF(h, exact_skip_centroids, h, xmax2)) return rc;
+    }
     for (long r0 = 0; r0 < N; r0 += chunk) {
         const long n = std::min(chunk, N - r0);
         // (a pass behind one whose fallback rows went through the float32 kernel: its image back in patch order)
         if (h->wf_patch != h->ex_patch) if (int rc = refresh_codebook_operands(h, true, true)) return rc;
         HIPCHK(h, hipMemsetAsync(ex.ctr, 0, (size_t)(2 * n_groups + 4) * sizeof(int), h->stream));
-        // resident rows from their second epoch on: last epoch's BMU of every row caps the screen's keep threshold
+        // resident rows from their second epoch on: last epoch's BMU of every row caps the screen's keep threshold -- under a
+        // plan the plan's prologue forms that seed from the operands it holds (exact_skip.hpp), else exact_seed_kernel
         ex.seed_live = ex.seed_on && !h->wide && out == h->bmu && h->bmu_valid;
-        if (ex.seed_live)
+        if (ex.seed_live && !ex.skip_live)
             exact_seed_kernel<<<dim3((unsigned)cdiv(n * 16, 256)), dim3(256), 0, h->stream>>>(
-                X + r0 * h->D, n, h->D, h->W, h->wsq, h->K, out + r0, xsq + r0, xerr + r0, h->wmax2, xmax2, h->wmax2 + 1, eb, ex.seed,
-                ex.skip_live ? ex.tq : nullptr);
+                X + r0 * h->D, n, h->D, h->W, h->wsq, h->K, out + r0, xsq + r0, xerr + r0, h->wmax2, xmax2, h->wmax2 + 1, eb, ex.seed);
         // (sorted pass: the screen, the select kernel and the merge keys work on positions of the sorted order)
         const float* p_xsq = xsq + r0; const float* p_xerr = xerr + r0; const float* p_seed = ex.seed_live ? ex.seed : nullptr;
         const __bf16* p_Xb = Xb + r0 * h->dp;
+        const float* p_X = X + r0 * h->D;                    // the rows the re-score reads, indexed like the lists' entries
         const int* p_order = nullptr;
         if (ex.skip_live) {
-            if (int rc = SOM_HALF(h, exact_skip_plan, h, Xb + r0 * h->dp, n, xsq + r0, xerr + r0, out + r0, xmax2, eb)) return rc;
-            p_xsq = ex.xsq_s; p_xerr = ex.xerr_s; p_seed = ex.seed_s; p_Xb = ex.Xb_s; p_order = ex.order;
+            if (resort)
+                if (int rc = exact_skip_sort(h, X + r0 * h->D, Xb + r0 * h->dp, r0, n, xsq + r0, xerr + r0, out + r0)) return rc;
+            if (int rc = SOM_HALF(h, exact_skip_plan, h, r0, n, out + r0, xmax2, eb)) return rc;
+            p_xsq = ex.xsq_s + r0; p_xerr = ex.xerr_s + r0; p_seed = ex.seed_s + r0; p_Xb = ex.Xb_s + r0 * h->dp; p_order = ex.order + r0;
+            p_X = ex.Xf_s + r0 * h->D;
         }
         {
             Timed ts(h, SOM_K_SCREEN);
@@ -1305,8 +1409,8 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         } else {
             exact_select_kernel<false><<<sel_grid, sel_block, 0, h->stream>>>(
                 ex.gmin, ex.gflags, ex.stride, n_groups, n, best, p_xsq, h->wmax2, xmax2, eb, p_xerr, h->wmax2 + 1, ex.plist,
-                ex.ctr, ex.rowcnt, nullptr, std::getenv("SOM_EXPERIMENT_NO_SEED_WINDOW") ? nullptr : p_seed);
-            if (int rc = exact_rescore_round(h, X + r0 * h->D, xsq + r0, best, nullptr, nullptr)) return rc;
+                ex.ctr, ex.rowcnt, nullptr, p_seed);
+            if (int rc = exact_rescore_round(h, p_X, xsq + r0, best, nullptr, nullptr)) return rc;
         }
         exact_finalize_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(
             best, n, h->K, ex.ctr + 2 * n_groups + 2, out + r0, ex.fb_list, ex.ctr + 2 * n_groups, p_order);
@@ -1327,8 +1431,9 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         }
         const int n_fb = ex.fb_count_host[0];
         ex.rows_total += n; ex.rows_fallback += n_fb; ex.chunks += 1;
-        ex.blocks_total += cdiv(n, SK_TILE) * n_groups;
-        ex.blocks_run += ex.skip_live ? ex.fb_count_host[3] : cdiv(n, SK_TILE) * n_groups;
+        // (counted in 16-unit blocks: four per (256-row tile, group))
+        ex.blocks_total += cdiv(n, SK_TILE) * n_groups * K16_T;
+        ex.blocks_run += ex.skip_live ? ex.fb_count_host[3] : cdiv(n, SK_TILE) * n_groups * K16_T;
         if (n_fb < 0 || n_fb > n) return fail(h, "exact: fallback counter out of range");
         if (n_fb > 0) {
             if (n_fb > ex.fb_cap) {
@@ -1355,13 +1460,25 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
             HIPCHK(h, hipGetLastError());
         }
     }
-    if (ex.skip_live && ex.skip_mode == 1 && ex.blocks_total > total_before) {
-        // (two such plans in a row: ONE is what the smooth map of a schedule's second epoch gives, and the third epoch of
+    if (ex.skip_live && ex.blocks_total > total_before) {
+        const double share = (double)(ex.blocks_run - run_before) / (double)(ex.blocks_total - total_before);
+        ex.planned += 1;
+        if (resort) {
+            // a sort that did not pay (the share it left is no better than the stale order's: the schedule, not the order,
+            // moves the share) doubles the wait before the next one, up to eight epochs; one that paid resets it
+            if (ex.res_valid && ex.res_share_last < 0.25) ex.res_wait = share > 0.93 * ex.res_share_last ? std::min(2 * ex.res_wait, 8) : 1;
+            ex.resorts += 1; ex.res_since = 0; ex.res_share_sort = share; ex.res_valid = true; ex.res_rows = (const void*)X; ex.res_n = N;
+        }
+        ex.res_since += 1;
+        ex.res_share_last = share;
+        // (two idle plans in a row: ONE is what the smooth map of a schedule's second epoch gives, and the third epoch of
         //  the benchmark's schedule already runs a tenth of the blocks)
-        if ((double)(ex.blocks_run - run_before) > 0.97 * (double)(ex.blocks_total - total_before)) {
-            if (++ex.skip_idle >= 2) ex.skip_cooldown = 2;
-        } else {
-            ex.skip_idle = 0;
+        if (ex.skip_mode == 1) {
+            if (share > 0.97) {
+                if (++ex.skip_idle >= 2) ex.skip_cooldown = 2;
+            } else {
+                ex.skip_idle = 0;
+            }
         }
     }
     return 0;
@@ -1461,28 +1578,6 @@ int row_sq(som_handle* h, const float* X, long N, float* out) {
     row_sq_f32_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(X, N, h->D, out);
     HIPCHK(h, hipGetLastError());
     return 0;
-}
-
-// BMU ids are <= 20-bit keys in 4-byte ints: rocPRIM's default picks its merge sort up to 1 Mi items for
-// 4-byte keys (ten merge passes at 1 Mi rows: 0.16 ms); two 8-bit Onesweep passes take half of that, but lose
-// to the merge sort at 100 k rows -- so Onesweep from SORT_ONESWEEP_ROWS rows on.
-using SortOnesweep = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 1024>;
-constexpr long SORT_ONESWEEP_ROWS = 262144;
-
-template <typename... Args>
-hipError_t sort_bmu_pairs(long n, Args... args) {
-    if (n >= SORT_ONESWEEP_ROWS) return rocprim::radix_sort_pairs<SortOnesweep>(args...);
-    return rocprim::radix_sort_pairs(args...);
-}
-// temporary storage that serves both algorithms for up to n rows
-template <typename K, typename V>
-hipError_t sort_bmu_pairs_storage(size_t& bytes, K* kin, K* kout, V* vin, V* vout, long n, unsigned bits, hipStream_t st) {
-    size_t b1 = 0, b2 = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, b1, kin, kout, vin, vout, (size_t)n, 0u, bits, st);
-    if (e != hipSuccess) return e;
-    e = rocprim::radix_sort_pairs<SortOnesweep>(nullptr, b2, kin, kout, vin, vout, (size_t)n, 0u, bits, st);
-    bytes = b1 > b2 ? b1 : b2;
-    return e;
 }
 
 // ---- update path: segment sum + separable neighbourhood transform --------------------------
@@ -1920,6 +2015,8 @@ int som_create(const som_config* cfg, som_handle** out) {
         if (const char* e = std::getenv("SOM_EXACT_TWO_ROUND")) h->ex.two_round = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("SOM_EXACT_SEED")) h->ex.seed_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_EXACT_SKIP")) h->ex.skip_mode = std::atoi(e);
+        if (const char* e = std::getenv("SOM_EXACT_SUBBLOCKS")) h->ex.sub_blocks = std::atoi(e) != 0;
+        if (const char* e = std::getenv("SOM_EXACT_RESORT")) h->ex.res_every = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("SOM_ASYNC_COPIES")) h->async_copies = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_FUSE_MERGE")) h->fuse_merge_prep = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_COUNTING_SORT")) h->counting_sort = std::atoi(e) != 0;
@@ -1987,9 +2084,13 @@ void som_destroy(som_handle* h) {
     }
     {
         void* eb[] = {h->ex.gmin, h->ex.gflags, h->ex.rowcnt, h->ex.rowarg, h->ex.seed, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab,
-                      h->ex.order, h->ex.sk_keys, h->ex.sk_keys2, h->ex.sk_vals, h->ex.sk_tmp, h->ex.Xb_s, h->ex.xsq_s, h->ex.xerr_s, h->ex.seed_s,
-                      h->ex.tq, h->ex.tq_s, h->ex.Cc, h->ex.rg, h->ex.csq, h->ex.wn_c, h->ex.cmax2, h->ex.Cst, h->ex.need, h->ex.glist, h->ex.gcnt};
+                      h->ex.order, h->ex.sk_keys, h->ex.sk_keys2, h->ex.sk_vals, h->ex.sk_tmp, h->ex.Xb_s, h->ex.Xf_s, h->ex.xsq_s, h->ex.xerr_s,
+                      h->ex.seed_s, h->ex.sU_s, h->ex.need, h->ex.need2, h->ex.glist, h->ex.gcnt};
         for (void* b : eb) if (b) (void)hipFree(b);
+        for (auto& c : h->ex.cen) {
+            void* cb[] = {c.Cc, c.rg, c.csq, c.wn_c, c.cmax2, c.Cst};
+            for (void* b : cb) if (b) (void)hipFree(b);
+        }
         if (h->ex.fb_count_host) (void)hipHostFree(h->ex.fb_count_host);
         if (h->ex.fb_ready) (void)hipEventDestroy(h->ex.fb_ready);
     }
@@ -2032,6 +2133,7 @@ static int adopt_rows(som_handle* h, int64_t n_rows) {
     (void)hipFree(h->bmu); (void)hipFree(h->xsq); (void)hipFree(h->Xb);
     h->bmu = nullptr; h->xsq = nullptr; h->Xb = nullptr;
     h->bmu_valid = false;
+    h->ex.res_valid = false;                             // (the resident sorted pass belongs to the rows it was sorted from)
     seg_free(h->seg);
     h->N = n_rows;
     h->Np = round_up(n_rows, ROW_PAD);
@@ -2746,6 +2848,12 @@ int som_exact_stats(som_handle* h, int64_t* rows, int64_t* rows_fallback, int64_
 int som_exact_skip_stats(som_handle* h, int64_t* blocks_run, int64_t* blocks_total) {
     if (!h || !blocks_run || !blocks_total) return 1;
     *blocks_run = h->ex.blocks_run; *blocks_total = h->ex.blocks_total;
+    return 0;
+}
+
+int som_exact_resident_stats(som_handle* h, int64_t* planned_epochs, int64_t* sorts) {
+    if (!h || !planned_epochs || !sorts) return 1;
+    *planned_epochs = h->ex.planned; *sorts = h->ex.resorts;
     return 0;
 }
 

@@ -303,6 +303,12 @@ class HipEngine:
         self._check(self._lib.som_exact_skip_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def exact_resident_stats(self):
+        """precision 'exact': (epochs run under a plan, of which (re-)sorted the resident rows by their last BMU's patch)."""
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self._lib.som_exact_resident_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def exact_last_counts(self, n):
         """precision 'exact': candidate groups per row in the last screen pass (first n rows)."""
         out = np.empty((int(n),), dtype=np.int32)
