@@ -206,6 +206,8 @@ def main():
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the bf16 run beside the exact headline (profiling passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch65536", action="store_true")
+    ap.add_argument("--no-schedule", action="store_true", help="skip the epoch-by-epoch / whole-schedule / unstructured-rows block")
+    ap.add_argument("--no-f32-check", action="store_true", help="skip the float32 run the headline codebook is compared with")
     args = ap.parse_args()
 
     have_rank_env = "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -374,6 +376,63 @@ def main():
                      "ms_per_step": 1e3 * dt_f / args.steps, "avg_launch_ms": f_ms / max(1, f_n), "launches": f_n,
                      "codebook_equal_to_headline_run": bool(np.array_equal(e_f.get_weights(), w_after_timed))}
         e_f.close()
+    # What `value` is and is not.  `value` = the mean of the K timed epochs BEHIND the W warm-up epochs of a (W + K)-epoch
+    # schedule.  Under block skipping an epoch's cost depends on where in the schedule it sits (the first epochs scan
+    # everything) and on the rows (rows without structure skip nothing), so the same line carries: every epoch of the
+    # schedule from a FRESH engine, one by one (`per_epoch_ms`, `executed_share_per_epoch`, `first_epoch_ms`), what
+    # train(data, W + K) costs as a whole (`whole_schedule`), the same run on rows WITHOUT structure (`unstructured_rows`), and
+    # the headline codebook against precision='f32' run over the same schedule (`codebook_equal_to_f32_run`).
+    schedule_block, unstructured, equal_f32 = None, None, None
+    if args.precision == "exact" and not args.no_schedule and dist is None:
+        def one_by_one(rows, prec="exact"):
+            e = HipEngine(MAP_X, MAP_Y, FEATURES, precision=prec, device=dev, distance=wl["distance"], neighborhood=wl["neighborhood"])
+            e.set_weights(w)
+            e.set_data(rows)
+            e.sync()
+            ms, sh = [], []
+            for t in range(total):
+                s0 = e.exact_skip_stats() if prec == "exact" else (0, 0)
+                t0 = time.perf_counter()
+                D.epoch(e, sched[t][0], sched[t][1], True)
+                e.sync()
+                ms.append(1e3 * (time.perf_counter() - t0))
+                s1 = e.exact_skip_stats() if prec == "exact" else (0, 0)
+                sh.append((s1[0] - s0[0]) / (s1[1] - s0[1]) if s1[1] > s0[1] else 1.0)
+            return e, ms, sh
+        e_s, ms_s, sh_s = one_by_one(rows_host)
+        w_sched = e_s.get_weights()
+        res = e_s.exact_resident_stats()
+        e_s.close()
+        schedule_block = {
+            "per_epoch_ms": [round(v, 4) for v in ms_s], "executed_share_per_epoch": [round(v, 5) for v in sh_s],
+            "first_epoch_ms": ms_s[0],
+            "whole_schedule": {"epochs": total, "ms_per_epoch": sum(ms_s) / total, "value": my_rows / (sum(ms_s) / total * 1e-3),
+                               "unit": "samples/sec/epoch",
+                               "note": "a fresh engine, epochs 0..%d one by one with a host sync after each (what train(data, %d) costs)" % (total - 1, total)},
+            "epochs_under_a_plan": res[0], "of_which_sorted_the_rows": res[1],
+            "codebook_equal_to_headline_run": bool(np.array_equal(w_sched, w_after_timed)),
+        }
+        if not args.no_f32_check and FEATURES <= 128:
+            e_f, ms_f, _ = one_by_one(rows_host, "f32")
+            equal_f32 = bool(np.array_equal(e_f.get_weights(), w_sched))
+            schedule_block["f32_run_ms_per_epoch"] = sum(ms_f) / total
+            e_f.close()
+            assert equal_f32, "the exact mode's trained codebook is not the float32 mode's"
+        # rows without structure: N(0, I), no centres -- nothing for a centroid bound to separate
+        rows_u = np.random.default_rng(4321 + rank).standard_normal((my_rows, FEATURES)).astype(np.float32)
+        if args.workload == "c5":
+            rows_u = np.abs(rows_u)
+            rows_u /= np.linalg.norm(rows_u, axis=1, keepdims=True)
+        e_u, ms_u, sh_u = one_by_one(rows_u)
+        res_u = e_u.exact_resident_stats()
+        e_u.close()
+        del rows_u
+        k_ms = ms_u[args.warmup:]
+        unstructured = {"rows": "N(0, I) rows, no centres (same map, same schedule)", "value": my_rows / (sum(k_ms) / len(k_ms) * 1e-3),
+                        "unit": "samples/sec/epoch", "ms_per_step": sum(k_ms) / len(k_ms),
+                        "executed_share": sum(sh_u[args.warmup:]) / len(k_ms), "epochs_under_a_plan": res_u[0],
+                        "plan_paused_epochs": total - 1 - res_u[0], "whole_schedule_ms_per_epoch": sum(ms_u) / total}
+
     kernel_name = kernel_name_for(args.precision, FEATURES, MAP_X * MAP_Y)
     peak = MFMA_F32_PEAK_TFLOPS if args.precision == "f32" else MFMA_BF16_PEAK_TFLOPS
     KD2 = 2.0 * (MAP_X * MAP_Y) * FEATURES            # 2*K*D flop per sample
@@ -575,6 +634,8 @@ def main():
                                  "the reference's g^T.x GEMM, xpysom.py:434-438; both forms timed: update_forms)",
                        "parallelism": "dp%d (sample shards, 1 all-reduce/epoch)" % world,
                        "epochs_per_sec": args.steps / dt, "build": build_hash,
+                       "value_is": "mean of epochs %d..%d of a %d-epoch schedule (the %d warm-up epochs hold the schedule's full scans)"
+                                   % (args.warmup, total - 1, total, args.warmup),
                        "codebook_crc32_after_run": w_crc},
             "roofline": {"bound": "mfma", "kernel": kernel_name + (" (IEEE-half distance GEMM of the exact mode's screen, fused "
                                                                    "argmin + per-group minima)" if is_exact else " (fused distance GEMM + argmin)"),
@@ -597,6 +658,11 @@ def main():
                                   "rows_through_float32_fallback_kernel": exact_stats[1], "screen_passes": exact_stats[2]}
         if thr is not None:
             out["throughput_mode"] = thr
+        if schedule_block is not None:
+            out.update(schedule_block)
+            out["codebook_equal_to_f32_run"] = equal_f32
+        if unstructured is not None:
+            out["unstructured_rows"] = unstructured
         if full_scan is not None:
             full_scan["roofline_frac"] = KD2 * rows_launch / (full_scan["avg_launch_ms"] * 1e-3) / 1e12 / peak
             out["without_block_skipping"] = full_scan

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64 * KS32) void merge_prep_k16_kernel(float* __rest
 // TL (GM with block skipping, exact_skip.hpp): the workgroup walks its tile's LIST of items (stage << 4 | mask of the stage's
 // 16-unit tiles to run) instead of all stages; only the listed tiles' fragments are staged and multiplied.
 template <int KS32, class EL = Bf16, bool GM = false, bool TL = false>
-__global__ __launch_bounds__(64 * K16_NW, 2) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
+__global__ __launch_bounds__(64 * K16_NW, TL ? 3 : 2) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
                                                               const char* __restrict__ Wst, int n_stages, int K,
                                                               unsigned long long* __restrict__ out64,
                                                               uint32_t* __restrict__ gmin = nullptr, long gm_stride = 0,
@@ -349,43 +349,47 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void bmu_bf16_k16_kernel(const __bf
         const float* wq = (const float*)(st + K16_T * KS32 * 1024);
 
         if (TL) {
-            // the item's tiles in ascending order, the next one's fragments read under this one's MFMAs; the reduction of a
-            // tile's accumulators runs one tile behind (accP), across stage boundaries too
-            uint32_t m = (uint32_t)it_cur & 15u;             // (never empty: exact_lists_kernel lists no group without a block)
-            int t = __builtin_ctz(m);
-            f32x4 wv = *(const f32x4*)(wq + t * 16 + 4 * quad);
-            bf16x8 a[KS32];
+            // the item's tiles (up to four) in ascending order, their operands alternating between two register sets (no
+            // copies): the next tile's fragments are read under this tile's MFMAs; the group is folded when its last tile is in
+            const uint32_t m0 = (uint32_t)it_cur & 15u;      // (never empty: exact_lists_kernel lists no group without a block)
+            const uint32_t m1 = m0 & (m0 - 1u), m2 = m1 & (m1 - 1u), m3 = m2 & (m2 - 1u);
+            const int t0 = __builtin_ctz(m0), t1 = m1 ? __builtin_ctz(m1) : -1, t2 = m2 ? __builtin_ctz(m2) : -1, t3 = m3 ? __builtin_ctz(m3) : -1;
+            auto load_tile = [&](int t, bf16x8 (&a)[KS32], f32x4& wv) {
 #pragma unroll
-            for (int ks = 0; ks < KS32; ++ks) a[ks] = *(const bf16x8*)(st + (t * KS32 + ks) * 1024 + lane * 16);
-            bool first = true;
-            while (m != 0u) {
-                m &= m - 1u;
-                f32x4 wvN;
-                bf16x8 aN[KS32];
-                if (m != 0u) {
-                    const int tn = __builtin_ctz(m);
-                    wvN = *(const f32x4*)(wq + tn * 16 + 4 * quad);
+                for (int ks = 0; ks < KS32; ++ks) a[ks] = *(const bf16x8*)(st + (t * KS32 + ks) * 1024 + lane * 16);
+                wv = *(const f32x4*)(wq + t * 16 + 4 * quad);
+            };
+            auto run_tile = [&](const bf16x8 (&a)[KS32], const f32x4& wv, f32x4 (&acc)[K16_SB]) {
 #pragma unroll
-                    for (int ks = 0; ks < KS32; ++ks) aN[ks] = *(const bf16x8*)(st + (tn * KS32 + ks) * 1024 + lane * 16);
-                }
-                f32x4 accT[K16_SB];
-#pragma unroll
-                for (int sb = 0; sb < K16_SB; ++sb) accT[sb] = wv;
+                for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = wv;
 #pragma unroll
                 for (int ks = 0; ks < KS32; ++ks)
 #pragma unroll
-                    for (int sb = 0; sb < K16_SB; ++sb)
-                        accT[sb] = mfma16(a[ks], xf[sb][ks], accT[sb]);
-                reduce_tile(accP, 0);
-                if (first) { fold_stage(it_prev >> 4, s > s_begin); first = false; }
-#pragma unroll
-                for (int sb = 0; sb < K16_SB; ++sb) accP[sb] = accT[sb];
-                if (m != 0u) {
-                    wv = wvN;
-#pragma unroll
-                    for (int ks = 0; ks < KS32; ++ks) a[ks] = aN[ks];
+                    for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = mfma16(a[ks], xf[sb][ks], acc[sb]);
+            };
+            // (one set of accumulators: a tile's reduction waits for its own MFMAs -- the workgroup's other waves and the
+            //  CU's other two workgroups fill the pipe meanwhile -- and two sets would cost the third workgroup per CU)
+            bf16x8 aA[KS32], aB[KS32];
+            f32x4 wvA, wvB, acc[K16_SB];
+            load_tile(t0, aA, wvA);
+            if (t1 >= 0) load_tile(t1, aB, wvB);
+            run_tile(aA, wvA, acc);
+            reduce_tile(acc, 0);
+            if (t1 >= 0) {
+                if (t2 >= 0) load_tile(t2, aA, wvA);
+                run_tile(aB, wvB, acc);
+                reduce_tile(acc, 0);
+                if (t2 >= 0) {
+                    if (t3 >= 0) load_tile(t3, aB, wvB);
+                    run_tile(aA, wvA, acc);
+                    reduce_tile(acc, 0);
+                    if (t3 >= 0) {
+                        run_tile(aB, wvB, acc);
+                        reduce_tile(acc, 0);
+                    }
                 }
             }
+            fold_stage(it_cur >> 4, true);
             it_prev = it_cur; it_cur = it_next; it_next = it_next2;
             continue;
         }
@@ -427,8 +431,10 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void bmu_bf16_k16_kernel(const __bf
         //  hipcc's own schedule of this block -- DESIGN.md 3.4)
         it_prev = it_cur; it_cur = it_next; it_next = it_next2;
     }
-    reduce_tile(accP, K16_T - 1);
-    fold_stage(it_prev >> 4, s_begin < s_end);
+    if (!TL) {
+        reduce_tile(accP, K16_T - 1);
+        fold_stage(it_prev >> 4, s_begin < s_end);
+    }
     SOM_STAMP_END();
 
     if (GM) {

@@ -103,7 +103,10 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_select_kernel(const 
                                                                          int* __restrict__ plist, int* __restrict__ gcount,
                                                                          int* __restrict__ rowcnt,
                                                                          const int* __restrict__ rowarg = nullptr,
-                                                                         const float* __restrict__ seed = nullptr) {
+                                                                         const float* __restrict__ seed = nullptr,
+                                                                         const int* __restrict__ glist = nullptr,
+                                                                         const int* __restrict__ gcnt = nullptr,
+                                                                         int rows_per_list = 0) {
     __shared__ int cnt_s[EX_SCAN_SPLIT][64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const long row0 = (long)blockIdx.x * 64;
@@ -128,9 +131,8 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_select_kernel(const 
         arg = rowarg[r];
     } else {
         thr_f = __uint_as_float((uint32_t)(best64[r] >> 32)) + e;
-        // seed (exact_seed_kernel): d'(t) + E/2 of one unit's float32 score t, computed outside the float32 kernel: whoever
-        // beats that unit THERE scores at most t + twice a float32 evaluation's error, so its screen value is at most
-        // seed + the float32 share of E -- often half the two-unit window m + E
+        // seed (exact_seed_kernel / the plan's prologue): an upper bound, less the float32 share, on the screen value of
+        // whatever beats one given unit in the float32 kernel
         if (seed != nullptr) thr_f = __builtin_fminf(thr_f, seed[r] + ex_f32_share(eb, sc, xsq[r]));
     }
     // a threshold that is not a finite positive number (a row the bound does not cover, a NaN minimum) selects nothing
@@ -141,16 +143,22 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_select_kernel(const 
         __syncthreads();
         if (part == 0 && live) best64[row] = ~0ull;
     }
-    const int g_begin = (int)((long)n_groups * part / EX_SCAN_SPLIT), g_end = (int)((long)n_groups * (part + 1) / EX_SCAN_SPLIT);
+    // the groups this wave walks: a quarter of all groups -- or (block skipping: the screen ran a LIST of groups per
+    // rows_per_list-row tile and wrote masks for those only) of the tile's list
+    const int* my_list = glist != nullptr ? glist + (row0 / rows_per_list) * (long)n_groups : nullptr;
+    const int n_walk = my_list != nullptr ? gcnt[row0 / rows_per_list] : n_groups;
+    const int g_begin = (int)((long)n_walk * part / EX_SCAN_SPLIT), g_end = (int)((long)n_walk * (part + 1) / EX_SCAN_SPLIT);
     const uint32_t* src = gmin + r;
     const unsigned long long below = (1ull << lane) - 1;
     int mine = 0;
     for (int gb = g_begin; gb < g_end; gb += 64) {
-        const unsigned long long fw = gb + lane < g_end ? gflags[ex_flag_index(blockIdx.x, gb + lane, n_groups, gm_stride)] : 0ull;
+        // lane j <-> the j-th group of this chunk
+        const int gid = gb + lane < g_end ? (my_list != nullptr ? (my_list[gb + lane] >> 4) : gb + lane) : -1;
+        const unsigned long long fw = gid >= 0 ? gflags[ex_flag_index(blockIdx.x, gid, n_groups, gm_stride)] : 0ull;
         const unsigned long long any = __ballot(fw != 0ull);
         if (any == 0) continue;
         const uint32_t fw_lo = (uint32_t)fw, fw_hi = (uint32_t)(fw >> 32);
-        unsigned long long hits = 0;                       // bit j: group gb + j is a candidate of this lane's row
+        unsigned long long hits = 0;                       // bit j: the chunk's j-th group is a candidate of this lane's row
         unsigned long long todo = any;
         while (todo != 0) {
             int j[8];
@@ -166,7 +174,8 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_select_kernel(const 
                 if (j[q] >= 0) {                           // (wave-uniform)
                     const unsigned long long stored = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)fw_hi, j[q]) << 32) |
                                                       (uint32_t)__builtin_amdgcn_readlane((int)fw_lo, j[q]);
-                    if ((stored >> lane) & 1ull) v[q] = src[(long)(gb + j[q]) * gm_stride];   // (only the rows the screen stored)
+                    const int g = __builtin_amdgcn_readlane(gid, j[q]);
+                    if ((stored >> lane) & 1ull) v[q] = src[(long)g * gm_stride];   // (only the rows the screen stored)
                 }
             }
 #pragma unroll
@@ -174,22 +183,23 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_select_kernel(const 
                 if (j[q] >= 0) hits |= (unsigned long long)(v[q] <= thr) << j[q];
         }
         if (!ok) hits = 0;
-        if (ROUND2 && arg >= gb && arg < gb + 64) hits &= ~(1ull << (arg - gb));   // (round 1 scored that group)
+        if (ROUND2 && arg >= gb && arg < gb + 64) hits &= ~(1ull << (arg - gb));   // (round 1 scored that group; no lists in two rounds)
         if (__ballot(hits != 0ull) == 0) continue;
-        int c = 0;                                         // lane j: the wave's hits in group gb + j
+        int c = 0;                                         // lane j: the wave's hits in the chunk's j-th group
         for (todo = any; todo != 0; todo &= todo - 1) {
             const int jj = (int)__builtin_ctzll(todo);
             const unsigned long long mk = __ballot((hits >> jj) & 1ull);
             if (lane == jj) c = (int)__builtin_popcountll(mk);
         }
         int base = 0;
-        if (c > 0) base = atomicAdd(gcount + gb + lane, c);
+        if (c > 0) base = atomicAdd(gcount + gid, c);
         for (todo = any; todo != 0; todo &= todo - 1) {
             const int jj = (int)__builtin_ctzll(todo);
             const unsigned long long mk = __ballot((hits >> jj) & 1ull);
             if (mk == 0) continue;
             const int o = __builtin_amdgcn_readlane(base, jj);
-            if ((hits >> jj) & 1ull) plist[(long)(gb + jj) * gm_stride + o + (int)__builtin_popcountll(mk & below)] = (int)row;
+            const int g = __builtin_amdgcn_readlane(gid, jj);
+            if ((hits >> jj) & 1ull) plist[(long)g * gm_stride + o + (int)__builtin_popcountll(mk & below)] = (int)row;
         }
         mine += (int)__builtin_popcountll(hits);
     }

@@ -83,6 +83,16 @@ __global__ __launch_bounds__(256) void exact_sortkey_kernel(const int* __restric
     vals[i] = (int)i;
 }
 
+// position (patch order) of every sorted row's last BMU: what the plan's prologue reads instead of three dependent loads
+__global__ __launch_bounds__(256) void exact_lastpos_kernel(const int* __restrict__ prev, const int* __restrict__ order,
+                                                            const int* __restrict__ inv, long n, int K, int* __restrict__ lastpos) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    int u = prev[order[p]];
+    u = u < 0 ? 0 : u >= K ? K - 1 : u;                      // (any unit gives a valid bound)
+    lastpos[p] = inv != nullptr ? inv[u] : u;
+}
+
 // The pass in sorted order: image rows (DP halves), the float32 rows themselves (what the re-score reads: a candidate
 // group's rows are then neighbours in memory), |x|^2, rounding error.  Positions behind the pass's rows (up to the tile
 // multiple) get zero rows and NaN norms (they keep nothing, need nothing).  One workgroup per 4 rows.
@@ -166,8 +176,7 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16
                                                                     const float* __restrict__ xmax2, const float* __restrict__ cmax2,
                                                                     const float* __restrict__ wmax2, const float* __restrict__ werr2,
                                                                     ExactBound eb, unsigned long long* __restrict__ need,
-                                                                    const int* __restrict__ prev, const int* __restrict__ order,
-                                                                    const int* __restrict__ inv, const char* __restrict__ Wst, int K,
+                                                                    const int* __restrict__ lastpos, const char* __restrict__ Wst,
                                                                     float* __restrict__ seed_s,
                                                                     const unsigned long long* __restrict__ need1, int n_cstages1,
                                                                     int force_all) {
@@ -204,9 +213,7 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16
                 // v_u: the screen's value of unit u = the row's last BMU on the operands the screen reads (-w~ fragments of
                 // the stage image, the row's x~), a float32 fma chain: every product of two halves is exact, the chain and
                 // the two cross-quad adds err by < 40 ulps of the largest accumulator magnitude (charged: e_valu)
-                int u = prev[order != nullptr ? order[row] : row];
-                u = u < 0 ? 0 : u >= K ? K - 1 : u;               // (any unit gives a valid bound)
-                const int pos = inv != nullptr ? inv[u] : u;
+                const int pos = lastpos[row];                     // (exact_lastpos_kernel: a position below K)
                 const char* stg = Wst + (long)(pos >> 6) * STAGE;
                 const int t16 = (pos >> 4) & 3, c = pos & 15;
                 float d = 0.0f;
@@ -263,6 +270,10 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16
     // level 2: the stages that hold a sub-block tile of a group level 1 kept, in ascending order, each with the 4-bit mask of
     // its 16-slot tiles to run (tile t <-> groups 16 s + 4 t .. + 3): an LDS list of (stage << 4 | mask), built by wave 0
     int* act = (int*)(smem + 2 * STAGE);
+    // the words this workgroup produces (one per stage it walks), gathered in LDS and stored once at the end: the waves OR
+    // their rows' bits in with LDS atomics (a global atomic per wave and stage sat in front of the next stage's barrier)
+    unsigned long long* nl = (unsigned long long*)(smem + 2 * STAGE + (LEVEL2 ? (size_t)n_cstages * sizeof(int) : 0));
+    for (int i = tid; i < n_cstages; i += 64 * K16_NW) nl[i] = 0ull;
     if (LEVEL2) {
         if (wave == 0) {
             int cnt = 0;
@@ -308,27 +319,30 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16
             st_next = it >> 4; tm_next = (uint32_t)it & 15u;
             dma_stage(st_next, tm_next, smem + ((i + 1 - s_begin) & 1) * STAGE);
         }
-        const int s = st_cur;
         const char* st = smem + ((i - s_begin) & 1) * STAGE;
         const float* wq = (const float*)(st + K16_T * KS32 * 1024);
         unsigned long long mine = 0ull;                       // bit (16 t16 + 4 quad + r) <-> centroid slot of that place in the stage
+        // a tile's operands: its KS32 fragments, its initial accumulators, the centroids' side of the extra step (slot 0 =
+        // -up_to_half(sw r)); the NEXT tile's are read under this tile's MFMAs and epilogue
+        auto load_tile = [&](int t, bf16x8 (&a)[KS32], f32x4& wv, float& rneg) {
 #pragma unroll
-        for (int t16 = 0; t16 < K16_T; ++t16) {
-            if (LEVEL2 && !((tm_cur >> t16) & 1u)) continue;  // (wave-uniform)
-            const f32x4 wv = *(const f32x4*)(wq + t16 * 16 + 4 * quad);
-            bf16x8 ae;                                        // the centroids' side of the extra step: slot 0 = -up_to_half(sw r)
+            for (int ks = 0; ks < KS32; ++ks) a[ks] = *(const bf16x8*)(st + ((t * KS32 + ks) * 64 + lane) * 16);
+            wv = *(const f32x4*)(wq + t * 16 + 4 * quad);
+            rneg = wq[64 + t * 16 + col];
+        };
+        // MFMAs + test of one tile; its operands in (a, wv, rneg)
+        auto run_tile = [&](int t16, const bf16x8 (&a)[KS32], const f32x4& wv, float rneg) {
+            bf16x8 ae;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) ae[jj] = (E)0.0f;
-            if (quad == 0) ae[0] = (E)wq[64 + t16 * 16 + col];
+            if (quad == 0) ae[0] = (E)rneg;
             f32x4 acc[K16_SB];
 #pragma unroll
             for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = wv;
 #pragma unroll
-            for (int ks = 0; ks < KS32; ++ks) {
-                const bf16x8 a = *(const bf16x8*)(st + ((t16 * KS32 + ks) * 64 + lane) * 16);
+            for (int ks = 0; ks < KS32; ++ks)
 #pragma unroll
-                for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = mfma16(a, xf[sb][ks], acc[sb]);
-            }
+                for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = mfma16(a[ks], xf[sb][ks], acc[sb]);
 #pragma unroll
             for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = mfma16(ae, xe[sb], acc[sb]);
 #pragma unroll
@@ -342,38 +356,87 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16
                 for (int qd = 0; qd < 4; ++qd)
                     if ((b >> (16 * qd)) & 0xFFFFull) mine |= 1ull << (t16 * 16 + 4 * qd + r);
             }
+        };
+        // up to four tiles, their operands alternating between two register sets (no copies): the next tile's are read
+        // under this tile's MFMAs and test
+        const uint32_t m0 = LEVEL2 ? tm_cur : 15u, m1 = m0 & (m0 - 1u), m2 = m1 & (m1 - 1u), m3 = m2 & (m2 - 1u);
+        const int t0 = __builtin_ctz(m0), t1 = m1 ? __builtin_ctz(m1) : -1, t2 = m2 ? __builtin_ctz(m2) : -1, t3 = m3 ? __builtin_ctz(m3) : -1;
+        bf16x8 aA[KS32], aB[KS32];
+        f32x4 wvA, wvB;
+        float rnA, rnB;
+        load_tile(t0, aA, wvA, rnA);
+        if (t1 >= 0) load_tile(t1, aB, wvB, rnB);
+        run_tile(t0, aA, wvA, rnA);
+        if (t1 >= 0) {
+            if (t2 >= 0) load_tile(t2, aA, wvA, rnA);
+            run_tile(t1, aB, wvB, rnB);
+            if (t2 >= 0) {
+                if (t3 >= 0) load_tile(t3, aB, wvB, rnB);
+                run_tile(t2, aA, wvA, rnA);
+                if (t3 >= 0) run_tile(t3, aB, wvB, rnB);
+            }
         }
-        // (the words start from zero: the host clears them; a wave adds its rows' bits)
-        if (lane == 0 && mine != 0ull) atomicOr(need + (long)blockIdx.x * n_cstages + s, mine);
+        if (lane == 0 && mine != 0ull) atomicOr(nl + (i - s_begin), mine);
         st_cur = st_next; tm_cur = tm_next;
     }
+    __syncthreads();
+    // (level 2: the stages no workgroup walks keep the zeros the host cleared the words to)
+    for (int i = s_begin + tid; i < s_end; i += 64 * K16_NW)
+        need[(long)blockIdx.x * n_cstages + (LEVEL2 ? (act[i] >> 4) : i)] = nl[i - s_begin];
 }
 
 // need bitmaps -> per tile the ascending list of items (group << 4 | mask of the group's 16-unit sub-blocks to run), and its
 // length.  need1: bit j of word s <-> group 64 s + j (level 1).  need2 (or null: every sub-block of a kept group runs):
 // word 4 s + k holds, for the groups 64 s + 16 k .. + 15, a nibble each (bit 4 (g & 15) + sub <-> sub-block `sub` of group g).
-// One wave per tile.  blocks_run counts 16-unit blocks.
+// One wave per tile; tile_counts[tile] = (16-unit blocks listed, groups level 1 kept).
 __global__ __launch_bounds__(64) void exact_lists_kernel(const unsigned long long* __restrict__ need1, int n_cstages,
                                                          const unsigned long long* __restrict__ need2, int n_groups,
                                                          int* __restrict__ glist, int* __restrict__ gcnt,
-                                                         int* __restrict__ blocks_run) {
+                                                         int2* __restrict__ tile_counts) {
     const long tile = blockIdx.x;
     const int lane = threadIdx.x;
-    int base = 0, blk = 0;
-    for (int s = 0; s < n_cstages; ++s) {
-        const unsigned long long w = need1[tile * n_cstages + s];
-        if (w == 0ull) continue;
-        uint32_t nib = 15u;
-        if (need2 != nullptr) nib = (uint32_t)(need2[tile * 4 * n_cstages + 4 * s + (lane >> 4)] >> (4 * (lane & 15))) & 15u;
-        const int g = s * 64 + lane;
-        const bool on = ((w >> lane) & 1ull) && nib != 0u && g < n_groups;
-        const unsigned long long mk = __ballot(on);
-        if (on) glist[tile * n_groups + base + __popcll(mk & ((1ull << lane) - 1ull))] = (g << 4) | (int)nib;
-        base += __popcll(mk);
+    int base = 0, blk = 0, kept = 0;
+    for (int s0 = 0; s0 < n_cstages; s0 += 64) {
+        // (the tile's level-1 words in one load, lane <-> stage; then stage by stage out of registers)
+        const unsigned long long mine = s0 + lane < n_cstages ? need1[tile * n_cstages + s0 + lane] : 0ull;
+        const uint32_t lo = (uint32_t)mine, hi = (uint32_t)(mine >> 32);
+        unsigned long long todo = __ballot(mine != 0ull);
+        for (; todo != 0ull; todo &= todo - 1ull) {
+            const int sl = (int)__builtin_ctzll(todo), s = s0 + sl;
+            const unsigned long long w = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)hi, sl) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readlane((int)lo, sl);
+            uint32_t nib = 15u;
+            if (need2 != nullptr) nib = (uint32_t)(need2[tile * 4 * n_cstages + 4 * s + (lane >> 4)] >> (4 * (lane & 15))) & 15u;
+            const int g = s * 64 + lane;
+            const bool l1 = ((w >> lane) & 1ull) && g < n_groups;
+            const bool on = l1 && nib != 0u;
+            const unsigned long long mk = __ballot(on);
+            if (on) glist[tile * n_groups + base + __popcll(mk & ((1ull << lane) - 1ull))] = (g << 4) | (int)nib;
+            base += __popcll(mk);
+            kept += __popcll(__ballot(l1));
 #pragma unroll
-        for (int b = 0; b < 4; ++b) blk += __popcll(__ballot(on && ((nib >> b) & 1u)));
+            for (int b = 0; b < 4; ++b) blk += __popcll(__ballot(on && ((nib >> b) & 1u)));
+        }
     }
-    if (lane == 0) { gcnt[tile] = base; atomicAdd(blocks_run, blk); }
+    // (per tile: 4 096 waves adding into two words of one cache line took as long as the rest of this kernel)
+    if (lane == 0) { gcnt[tile] = base; tile_counts[tile] = make_int2(blk, kept); }
+}
+
+// sum of the tiles' (16-unit blocks listed, groups level 1 kept) into the pass's counters.  One workgroup.
+__global__ __launch_bounds__(1024) void exact_list_totals_kernel(const int2* __restrict__ tile_counts, long tiles, int* __restrict__ blocks_run,
+                                                                 int* __restrict__ groups_run) {
+    __shared__ int sb[16], sk[16];
+    int b = 0, k = 0;
+    for (long t = threadIdx.x; t < tiles; t += 1024) { const int2 c = tile_counts[t]; b += c.x; k += c.y; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { b += __shfl_xor(b, o, 64); k += __shfl_xor(k, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = b; sk[threadIdx.x >> 6] = k; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        b = 0; k = 0;
+        for (int w = 0; w < 16; ++w) { b += sb[w]; k += sk[w]; }
+        *blocks_run = b; *groups_run = k;
+    }
 }
 
 }  // namespace somhip

@@ -105,6 +105,7 @@ struct som_handle {
         bool skip_live = false;           // this launch plans and skips
         int skip_cooldown = 0;            // launches to run without a plan (the last two plans kept > 97 % of the blocks)
         int skip_idle = 0;                // plans in a row that kept > 97 % of the blocks
+        int skip_pause = 2;               // launches the next pause lasts (doubles while the plans stay idle)
         bool sub_blocks = true;           // SOM_EXACT_SUBBLOCKS=0: the plan stops at the groups (A/B)
         // the RESIDENT SORTED PASS: the rows in the order of their BMU's patch at the time of the last sort (position ->
         // row: `order`), with sorted copies of the half image, the float32 rows and the norms.  Valid for (res_rows, res_n);
@@ -123,11 +124,18 @@ struct som_handle {
         void* sk_tmp = nullptr; size_t sk_tmp_bytes = 0;
         __bf16* Xb_s = nullptr;
         float *Xf_s = nullptr, *xsq_s = nullptr, *xerr_s = nullptr, *seed_s = nullptr, *sU_s = nullptr;
+        int* lastpos_s = nullptr;         // position (patch order) of every sorted row's last BMU
+        // level 2 of the plan runs where it pays (l2_pays: measured whenever it runs), is probed again after l2_wait epochs or
+        // when level 1's share has moved by half since the last probe
+        double l1_share_last = 1.0, l1_share_probe = -1.0;
+        bool l2_live = false, l2_pays = true;
+        int l2_wait = 0;
         // the centroid sets of the plan: [0] the 64-unit groups, [1] their 16-unit sub-blocks (exact_centroid_kernel's slot order)
         struct Centroids { float *Cc = nullptr, *rg = nullptr, *csq = nullptr, *wn_c = nullptr, *cmax2 = nullptr; char* Cst = nullptr;
                            int n_slots = 0, n_cstages = 0; } cen[2];
         unsigned long long *need = nullptr, *need2 = nullptr;
         int *glist = nullptr, *gcnt = nullptr;
+        int2* tile_counts = nullptr;
     } ex;
     int n_kchunks = 0;       // tiled: 64-feature chunks
     int n_ublocks = 0;       // tiled: unit blocks of tl_bn
@@ -990,8 +998,8 @@ int exact_reserve_stride(som_handle* h, long stride) {
     ex.max_tiles = cdiv(stride * ex.pairs, EX_TR) + n_groups;
     if (int rc = dev_alloc(h, &ex.tile_tab, (size_t)ex.max_tiles)) return rc;
     if (!ex.ctr) {
-        if (int rc = dev_alloc(h, &ex.ctr, (size_t)3 * n_groups + 3)) return rc;
-        HIPCHK(h, hipHostMalloc((void**)&ex.fb_count_host, 4 * sizeof(int), hipHostMallocDefault));   // fb_count | n_tiles | overflow | blocks run
+        if (int rc = dev_alloc(h, &ex.ctr, (size_t)3 * n_groups + 8)) return rc;
+        HIPCHK(h, hipHostMalloc((void**)&ex.fb_count_host, 8 * sizeof(int), hipHostMallocDefault));   // fb_count | n_tiles | overflow | 16-unit blocks run | groups run
     }
     ex.stride = stride;
     return 0;
@@ -1010,6 +1018,13 @@ int exact_screen(som_handle* h, const __bf16* Xb, long n, unsigned long long* be
     const long blocks = cdiv(n, K16_WG_SAMPLES);
     const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
     int parts = choose_parts(h, blocks, slots, h->n_stages);
+    if (tl && blocks >= slots) {
+        // a tile's list is short where the plan works (tens of items of 1 024): every part of a tile loads the tile's 64 KB
+        // of rows again, so the scan is split only where the lists are long enough to carry that (the last plan's share
+        // is the forecast; 1 Mi rows, mid-schedule: three parts re-read 0.8 GB for 0.3 ms of screen)
+        const double items = h->ex.res_share_last * (double)n_groups;
+        parts = items < 64.0 ? 1 : items < 160.0 ? std::min(parts, 2) : parts;
+    }
     if (h->env_bf16_parts > 0) parts = std::min(h->env_bf16_parts, h->n_stages);
     if (h->debug)
         std::fprintf(stderr, "[somhip] exact screen: blocks=%ld per_cu=%d slots=%ld parts=%d groups=%d lists=%d\n", blocks, per_cu,
@@ -1130,9 +1145,9 @@ int exact_skip_reserve(som_handle* h, long rows_all, long stride) {
     }
     const long need_rows = round_up(rows_all, SK_TILE);
     if (need_rows > ex.sk_rows) {
-        void* old[] = {ex.order, ex.Xb_s, ex.Xf_s, ex.xsq_s, ex.xerr_s, ex.seed_s, ex.sU_s};
+        void* old[] = {ex.order, ex.Xb_s, ex.Xf_s, ex.xsq_s, ex.xerr_s, ex.seed_s, ex.sU_s, ex.lastpos_s};
         for (void* p : old) if (p) (void)hipFree(p);
-        ex.order = nullptr; ex.Xb_s = nullptr; ex.Xf_s = ex.xsq_s = ex.xerr_s = ex.seed_s = ex.sU_s = nullptr;
+        ex.order = nullptr; ex.Xb_s = nullptr; ex.Xf_s = ex.xsq_s = ex.xerr_s = ex.seed_s = ex.sU_s = nullptr; ex.lastpos_s = nullptr;
         ex.sk_rows = 0; ex.res_valid = false;
         if (int rc = dev_alloc(h, &ex.order, (size_t)need_rows)) return rc;
         if (int rc = dev_alloc(h, &ex.Xb_s, (size_t)need_rows * h->dp)) return rc;
@@ -1141,12 +1156,13 @@ int exact_skip_reserve(som_handle* h, long rows_all, long stride) {
         if (int rc = dev_alloc(h, &ex.xerr_s, (size_t)need_rows)) return rc;
         if (int rc = dev_alloc(h, &ex.seed_s, (size_t)need_rows)) return rc;
         if (int rc = dev_alloc(h, &ex.sU_s, (size_t)need_rows)) return rc;
+        if (int rc = dev_alloc(h, &ex.lastpos_s, (size_t)need_rows)) return rc;
         ex.sk_rows = need_rows;
     }
     if (stride <= ex.sk_stride) return 0;
-    void* old[] = {ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.sk_tmp, ex.need, ex.need2, ex.glist, ex.gcnt};
+    void* old[] = {ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.sk_tmp, ex.need, ex.need2, ex.glist, ex.gcnt, ex.tile_counts};
     for (void* p : old) if (p) (void)hipFree(p);
-    ex.sk_keys = ex.sk_keys2 = ex.sk_vals = nullptr; ex.sk_tmp = nullptr; ex.need = ex.need2 = nullptr; ex.glist = ex.gcnt = nullptr;
+    ex.sk_keys = ex.sk_keys2 = ex.sk_vals = nullptr; ex.sk_tmp = nullptr; ex.need = ex.need2 = nullptr; ex.glist = ex.gcnt = nullptr; ex.tile_counts = nullptr;
     ex.sk_stride = 0;
     const long tiles = stride / SK_TILE;
     if (int rc = dev_alloc(h, &ex.sk_keys, (size_t)stride)) return rc;
@@ -1156,6 +1172,7 @@ int exact_skip_reserve(som_handle* h, long rows_all, long stride) {
     if (int rc = dev_alloc(h, &ex.need2, (size_t)tiles * ex.cen[1].n_cstages)) return rc;
     if (int rc = dev_alloc(h, &ex.glist, (size_t)tiles * n_groups)) return rc;
     if (int rc = dev_alloc(h, &ex.gcnt, (size_t)tiles)) return rc;
+    if (int rc = dev_alloc(h, &ex.tile_counts, (size_t)tiles)) return rc;
     size_t bytes = 0;
     HIPCHK(h, sort_bmu_pairs_storage(bytes, ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.order, stride, 32u, h->stream));
     char* tmp = nullptr;
@@ -1171,7 +1188,7 @@ template <class E>
 int exact_skip_centroids(som_handle* h, const float* xmax2) {
     auto& ex = h->ex;
     const float* Wsrc = h->ex_patch ? h->Wp : h->W;
-    for (int lv = 0; lv < (ex.sub_blocks ? 2 : 1); ++lv) {
+    for (int lv = 0; lv < (ex.l2_live ? 2 : 1); ++lv) {
         auto& c = ex.cen[lv];
         exact_centroid_kernel<<<dim3((unsigned)c.n_slots), dim3(128), 0, h->stream>>>(Wsrc, h->K, h->D, c.Cc, c.rg, lv);
         row_sq_f32_kernel<<<dim3((unsigned)cdiv(c.n_slots, 256)), dim3(256), 0, h->stream>>>(c.Cc, c.n_slots, h->D, c.csq);
@@ -1218,40 +1235,41 @@ int exact_skip_plan(som_handle* h, long r0, long n, const int* prev, const float
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
     const long np = round_up(n, SK_TILE);
     const long tiles = np / SK_TILE;
-    // skipped (row block, group) pairs are never written by the screen: their masks must read empty
-    HIPCHK(h, hipMemsetAsync(ex.gflags, 0, (size_t)n_groups * (np / 64) * sizeof(unsigned long long), h->stream));
+    // (the select kernel walks the tiles' lists too: the masks of the blocks the screen does not run are never read)
+    exact_lastpos_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(prev, ex.order + r0, h->ex_inv, n, h->K, ex.lastpos_s + r0);
     const dim3 block(64 * K16_NW);
     const auto& c0 = ex.cen[0];
     const auto& c1 = ex.cen[1];
     // (few tiles: their centroid stages split over up to four workgroups each, so that the plan fills the chip)
     const long want = (1024 + tiles - 1) / tiles;
     const dim3 pgrid((unsigned)tiles, (unsigned)std::max<long>(1, std::min<long>({want, 4L, (long)c0.n_cstages})));
-    const size_t lds1 = 2 * (size_t)h->stage_bytes;
-    const size_t lds2 = 2 * (size_t)h->stage_bytes + (size_t)c1.n_cstages * sizeof(int);
-    if (ex.sub_blocks && lds2 > 150 * 1024) return fail(h, "exact: map too large for the level-2 plan's stage list");
+    // (two stage slots + the words the workgroup produces; level 2: + its list of active stages)
+    const size_t lds1 = 2 * (size_t)h->stage_bytes + (size_t)c0.n_cstages * 8;
+    const size_t lds2 = 2 * (size_t)h->stage_bytes + (size_t)c1.n_cstages * (sizeof(int) + 8);
+    const bool l2 = ex.l2_live;
     const int force = ex.skip_mode == 3 ? 1 : 0;
     const __bf16* Xs = ex.Xb_s + r0 * h->dp;
-    // (the plan's waves OR their rows' bits into the words)
-    HIPCHK(h, hipMemsetAsync(ex.need, 0, (size_t)tiles * c0.n_cstages * sizeof(unsigned long long), h->stream));
-    if (ex.sub_blocks) HIPCHK(h, hipMemsetAsync(ex.need2, 0, (size_t)tiles * c1.n_cstages * sizeof(unsigned long long), h->stream));
+    // (level 1 stores every word; level 2 only those of the stages it walks)
+    if (l2) HIPCHK(h, hipMemsetAsync(ex.need2, 0, (size_t)tiles * c1.n_cstages * sizeof(unsigned long long), h->stream));
 #define SOM_PLAN_CASE(k) case k: { \
         { int pc; if (int rc = kernel_per_cu(h, (const void*)exact_plan_kernel<k, E, false>, 64 * K16_NW, lds1, &pc)) return rc; } \
         exact_plan_kernel<k, E, false><<<pgrid, block, lds1, h->stream>>>(Xs, n, c0.Cst, c0.n_cstages, c0.rg, c0.n_slots, \
-            ex.xsq_s + r0, ex.xerr_s + r0, ex.sU_s + r0, xmax2, c0.cmax2, h->wmax2, h->wmax2 + 1, eb, ex.need, prev, ex.order + r0, \
-            h->ex_inv, h->Wst, h->K, ex.seed_s + r0, nullptr, 0, force); \
-        if (ex.sub_blocks) { \
+            ex.xsq_s + r0, ex.xerr_s + r0, ex.sU_s + r0, xmax2, c0.cmax2, h->wmax2, h->wmax2 + 1, eb, ex.need, ex.lastpos_s + r0, \
+            h->Wst, ex.seed_s + r0, nullptr, 0, force); \
+        if (l2) { \
             { int pc; if (int rc = kernel_per_cu(h, (const void*)exact_plan_kernel<k, E, true>, 64 * K16_NW, lds2, &pc)) return rc; } \
             exact_plan_kernel<k, E, true><<<dim3((unsigned)tiles, pgrid.y), block, lds2, h->stream>>>(Xs, n, c1.Cst, c1.n_cstages, c1.rg, c1.n_slots, \
-                ex.xsq_s + r0, ex.xerr_s + r0, ex.sU_s + r0, xmax2, c1.cmax2, h->wmax2, h->wmax2 + 1, eb, ex.need2, nullptr, nullptr, \
-                nullptr, nullptr, h->K, nullptr, ex.need, c0.n_cstages, force); \
+                ex.xsq_s + r0, ex.xerr_s + r0, ex.sU_s + r0, xmax2, c1.cmax2, h->wmax2, h->wmax2 + 1, eb, ex.need2, nullptr, \
+                nullptr, nullptr, ex.need, c0.n_cstages, force); \
         } } break;
     switch (h->ks32) {
     SOM_PLAN_CASE(1) SOM_PLAN_CASE(2) SOM_PLAN_CASE(3) SOM_PLAN_CASE(4)
     default: return fail(h, "exact: block skipping supports input_len <= 128");
     }
 #undef SOM_PLAN_CASE
-    exact_lists_kernel<<<dim3((unsigned)tiles), dim3(64), 0, h->stream>>>(ex.need, c0.n_cstages, ex.sub_blocks ? ex.need2 : nullptr, n_groups,
-                                                                         ex.glist, ex.gcnt, ex.ctr + 2 * n_groups + 3);
+    exact_lists_kernel<<<dim3((unsigned)tiles), dim3(64), 0, h->stream>>>(ex.need, c0.n_cstages, l2 ? ex.need2 : nullptr, n_groups,
+                                                                         ex.glist, ex.gcnt, ex.tile_counts);
+    exact_list_totals_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(ex.tile_counts, tiles, ex.ctr + 2 * n_groups + 3, ex.ctr + 2 * n_groups + 4);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -1360,13 +1378,24 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         if (!ex.res_valid || ex.res_rows != (const void*)X || ex.res_n != N) resort = true;
         else if (ex.res_every > 0) resort = ex.res_since >= ex.res_every;
         else resort = ex.res_share_last >= 0.25 || (ex.res_since >= ex.res_wait && (ex.res_share_last > 1.2 * ex.res_share_sort + 0.003 || ex.res_since >= 8));
+        // level 2 of the plan (the groups' 16-unit sub-blocks) where it pays.  Whether it does is MEASURED each time it runs
+        // (both levels' shares come back with the pass's counters): it costs about a tenth of level 1's share of a full scan
+        // (four centroids per kept group), it saves the blocks it drops -- on the smooth maps of a schedule's first epochs
+        // and on the compact patches of its middle it drops next to nothing, late, when the patches have spread out, more
+        // than half.  While it does not pay it is probed again every fourth planned epoch, or at once when level 1's share
+        // has moved by half since the last probe.
+        bool probe = ex.l1_share_probe < 0.0 || ex.l2_wait <= 0 || ex.l1_share_last > 1.5 * ex.l1_share_probe || ex.l1_share_last < ex.l1_share_probe / 1.5;
+        if (ex.l1_share_last > 0.9 && ex.l1_share_probe >= 0.0 && !ex.l2_pays) probe = false;   // (nothing for four times the centroids to find)
+        ex.l2_live = ex.sub_blocks && (ex.l2_pays || probe || ex.skip_mode >= 2) &&
+                     2 * (size_t)h->stage_bytes + 4 * (size_t)cdiv(n_groups, K16_STAGE_UNITS) * (sizeof(int) + 8) <= 150 * 1024;   // (its stage list lives in LDS)
         if (int rc = SOM_HALF(h, exact_skip_centroids, h, xmax2)) return rc;
     }
+    int64_t groups_run = 0;
     for (long r0 = 0; r0 < N; r0 += chunk) {
         const long n = std::min(chunk, N - r0);
         // (a pass behind one whose fallback rows went through the float32 kernel: its image back in patch order)
         if (h->wf_patch != h->ex_patch) if (int rc = refresh_codebook_operands(h, true, true)) return rc;
-        HIPCHK(h, hipMemsetAsync(ex.ctr, 0, (size_t)(2 * n_groups + 4) * sizeof(int), h->stream));
+        HIPCHK(h, hipMemsetAsync(ex.ctr, 0, (size_t)(2 * n_groups + 5) * sizeof(int), h->stream));
         // resident rows from their second epoch on: last epoch's BMU of every row caps the screen's keep threshold -- under a
         // plan the plan's prologue forms that seed from the operands it holds (exact_skip.hpp), else exact_seed_kernel
         ex.seed_live = ex.seed_on && !h->wide && out == h->bmu && h->bmu_valid;
@@ -1409,14 +1438,14 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         } else {
             exact_select_kernel<false><<<sel_grid, sel_block, 0, h->stream>>>(
                 ex.gmin, ex.gflags, ex.stride, n_groups, n, best, p_xsq, h->wmax2, xmax2, eb, p_xerr, h->wmax2 + 1, ex.plist,
-                ex.ctr, ex.rowcnt, nullptr, p_seed);
+                ex.ctr, ex.rowcnt, nullptr, p_seed, ex.skip_live ? ex.glist : nullptr, ex.skip_live ? ex.gcnt : nullptr, SK_TILE);
             if (int rc = exact_rescore_round(h, p_X, xsq + r0, best, nullptr, nullptr)) return rc;
         }
         exact_finalize_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(
             best, n, h->K, ex.ctr + 2 * n_groups + 2, out + r0, ex.fb_list, ex.ctr + 2 * n_groups, p_order);
         HIPCHK(h, hipGetLastError());
         // rows the scheme could not settle (normally none): the float32 kernel itself
-        HIPCHK(h, hipMemcpyAsync(ex.fb_count_host, ex.ctr + 2 * n_groups, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(ex.fb_count_host, ex.ctr + 2 * n_groups, 5 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         if (h->early.armed && !h->early.done && out == h->bmu && r0 + n >= N) {
             // the last pass of a resident epoch: the host waits for the counter only (an event behind the copy); what the
             // update needs besides the BMUs is queued behind it and runs while the host wakes up
@@ -1434,6 +1463,7 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         // (counted in 16-unit blocks: four per (256-row tile, group))
         ex.blocks_total += cdiv(n, SK_TILE) * n_groups * K16_T;
         ex.blocks_run += ex.skip_live ? ex.fb_count_host[3] : cdiv(n, SK_TILE) * n_groups * K16_T;
+        groups_run += ex.skip_live ? ex.fb_count_host[4] : cdiv(n, SK_TILE) * n_groups;
         if (n_fb < 0 || n_fb > n) return fail(h, "exact: fallback counter out of range");
         if (n_fb > 0) {
             if (n_fb > ex.fb_cap) {
@@ -1471,13 +1501,24 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         }
         ex.res_since += 1;
         ex.res_share_last = share;
+        ex.l1_share_last = (double)groups_run * K16_T / (double)(ex.blocks_total - total_before);
+        if (ex.l2_live) {
+            ex.l2_pays = 1.5 * (ex.l1_share_last - share) > 0.1 * ex.l1_share_last + 0.006;
+            ex.l1_share_probe = ex.l1_share_last;
+            ex.l2_wait = 4;
+        } else {
+            ex.l2_wait -= 1;
+        }
         // (two idle plans in a row: ONE is what the smooth map of a schedule's second epoch gives, and the third epoch of
         //  the benchmark's schedule already runs a tenth of the blocks)
+        // rows without structure: two idle plans in a row (> 97 % of the blocks kept; ONE is what the smooth map of a schedule's
+        // second epoch gives) pause the plan for two epochs, the next idle one for four, then eight, sixteen: the plan's
+        // cost on such rows falls below a percent; a plan that skips again resets the pause
         if (ex.skip_mode == 1) {
             if (share > 0.97) {
-                if (++ex.skip_idle >= 2) ex.skip_cooldown = 2;
+                if (++ex.skip_idle >= 2) { ex.skip_cooldown = ex.skip_pause; ex.skip_pause = std::min(2 * ex.skip_pause, 16); }
             } else {
-                ex.skip_idle = 0;
+                ex.skip_idle = 0; ex.skip_pause = 2;
             }
         }
     }
@@ -2085,7 +2126,7 @@ void som_destroy(som_handle* h) {
     {
         void* eb[] = {h->ex.gmin, h->ex.gflags, h->ex.rowcnt, h->ex.rowarg, h->ex.seed, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab,
                       h->ex.order, h->ex.sk_keys, h->ex.sk_keys2, h->ex.sk_vals, h->ex.sk_tmp, h->ex.Xb_s, h->ex.Xf_s, h->ex.xsq_s, h->ex.xerr_s,
-                      h->ex.seed_s, h->ex.sU_s, h->ex.need, h->ex.need2, h->ex.glist, h->ex.gcnt};
+                      h->ex.seed_s, h->ex.sU_s, h->ex.lastpos_s, h->ex.need, h->ex.need2, h->ex.glist, h->ex.gcnt, h->ex.tile_counts};
         for (void* b : eb) if (b) (void)hipFree(b);
         for (auto& c : h->ex.cen) {
             void* cb[] = {c.Cc, c.rg, c.csq, c.wn_c, c.cmax2, c.Cst};
