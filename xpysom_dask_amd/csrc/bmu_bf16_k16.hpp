@@ -273,19 +273,15 @@ __global__ __launch_bounds__(64 * K16_NW, TL ? 3 : 2) void bmu_bf16_k16_kernel(c
             if (sd == sd) run_cap = sd;
         }
     }
-    // this workgroup's share of the codebook stages -- or (TL) of the tile's LIST of items: the loop index s walks
-    // [s_begin, s_end) either way, item_of(s) = (stage << 4 | tile mask) is what it stands for
+    // this workgroup's share of the codebook stages: the loop index s walks [s_begin, s_end)  (TL: see the tile-list loop below)
     static_assert(!TL || GM, "tile lists belong to the exact mode's screen");
-    const int* my_list = TL ? glist + (long)blockIdx.x * n_stages : nullptr;
-    const int n_walk = TL ? gcnt[blockIdx.x] : n_stages;
-    const int s_begin = (int)((long)n_walk * blockIdx.y / gridDim.y);
-    const int s_end = (int)((long)n_walk * (blockIdx.y + 1) / gridDim.y);
-    // (list entries are read two iterations ahead of their use: no load sits between a barrier and the stage it names)
-    auto item_of = [&](int s) -> int { return s < s_end ? (TL ? __builtin_amdgcn_readfirstlane(my_list[s]) : ((s << 4) | 15)) : 15; };
+    const int n_walk = n_stages;
+    const int s_begin = TL ? 0 : (int)((long)n_walk * blockIdx.y / gridDim.y);
+    const int s_end = TL ? 0 : (int)((long)n_walk * (blockIdx.y + 1) / gridDim.y);
+    auto item_of = [&](int s) -> int { return s < s_end ? ((s << 4) | 15) : 15; };
     auto dma_item = [&](int it, char* dst) {
         const char* src = Wst + (long)(it >> 4) * STAGE;
-        for (int p = wave; p < PIECES; p += K16_NW)
-            if (!TL || p == PIECES - 1 || ((it >> (p / KS32)) & 1)) lds_dma_16(src + (long)p * 1024 + lane * 16, dst + p * 1024);
+        for (int p = wave; p < PIECES; p += K16_NW) lds_dma_16(src + (long)p * 1024 + lane * 16, dst + p * 1024);
     };
     int it_prev = 15, it_cur = item_of(s_begin), it_next = item_of(s_begin + 1);
     if (s_begin < s_end) dma_item(it_cur, smem);
@@ -339,6 +335,94 @@ __global__ __launch_bounds__(64 * K16_NW, TL ? 3 : 2) void bmu_bf16_k16_kernel(c
     };
 
     SOM_STAMP_BEGIN();
+    if (TL) {
+        // TILE LISTS (block skipping, exact_skip.hpp): the workgroup walks its tile's dense list of 16-unit tiles
+        // (group << 2 | sub-block, ascending), FOUR to a barrier whatever groups they belong to -- late in a schedule a
+        // group keeps one or two of its four tiles, and a barrier per group left the pipe waiting.  A slot of the ring holds
+        // the four tiles' fragments (by LDS-DMA) and their 16 initial accumulators each (a wave per tile: a plain load one
+        // chunk ahead, written into the slot's tail before the next barrier).  A group's minimum is folded when its last
+        // tile is in (its tiles are consecutive in the list, across chunks too).  The parts of a tile's list are cut at
+        // group boundaries: one part stores a group's minima.
+        const int* tl = glist + (long)blockIdx.x * (4 * n_stages);
+        const int n_t = gcnt[blockIdx.x];
+        auto bound = [&](int y) -> int {
+            int b = (int)((long)n_t * y / gridDim.y);
+            while (b > 0 && b < n_t && (tl[b] >> 2) == (tl[b - 1] >> 2)) ++b;
+            return __builtin_amdgcn_readfirstlane(b);
+        };
+        const int b0 = bound(blockIdx.y), e0 = bound(blockIdx.y + 1);
+        auto ent = [&](int i) -> int { return i < e0 ? __builtin_amdgcn_readfirstlane(tl[i]) : -1; };
+        constexpr int TQ = K16_T * KS32 * 1024;              // the slot's tail: [tile j][16] initial accumulators
+        auto dma_chunk = [&](const int (&en)[4], char* dst) {
+            for (int p = wave; p < K16_T * KS32; p += K16_NW) {
+                const int j = p / KS32, ks = p - j * KS32;
+                if (en[j] >= 0)
+                    lds_dma_16(Wst + (long)(en[j] >> 2) * STAGE + (long)(((en[j] & 3) * KS32 + ks) * 1024) + lane * 16, dst + p * 1024);
+            }
+        };
+        // wave w <-> the chunk's tile w: its 16 initial accumulators (lanes 0..15)
+        auto load_wq = [&](const int (&en)[4]) -> float {
+            const int e = en[wave];
+            return (e >= 0 && lane < 16) ? *(const float*)(Wst + (long)(e >> 2) * STAGE + TQ + ((e & 3) * 16 + lane) * 4) : 0.0f;
+        };
+        int cur[4], nxt[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { cur[j] = ent(b0 + j); nxt[j] = ent(b0 + 4 + j); }
+        if (b0 < e0) {
+            dma_chunk(cur, smem);
+            const float w0 = load_wq(cur);
+            if (lane < 16) *(float*)(smem + TQ + (wave * 16 + lane) * 4) = w0;
+        }
+        int k = 0;
+        for (int c = b0; c < e0; c += 4, ++k) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int nn[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nn[j] = ent(c + 8 + j);
+            char* sn = smem + ((k + 1) & 1) * STAGE;
+            float wqn = 0.0f;
+            if (c + 4 < e0) { dma_chunk(nxt, sn); wqn = load_wq(nxt); }
+            const char* st = smem + (k & 1) * STAGE;
+            const float* wq = (const float*)(st + TQ);
+            auto load_tile = [&](int j, bf16x8 (&a)[KS32], f32x4& wv) {
+#pragma unroll
+                for (int ks = 0; ks < KS32; ++ks) a[ks] = *(const bf16x8*)(st + (j * KS32 + ks) * 1024 + lane * 16);
+                wv = *(const f32x4*)(wq + j * 16 + 4 * quad);
+            };
+            // MFMAs of one tile, its reduction, and the group's fold when the next tile belongs to another group
+            auto run_tile = [&](const bf16x8 (&a)[KS32], const f32x4& wv, int e, int e_next) {
+                f32x4 acc[K16_SB];
+#pragma unroll
+                for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = wv;
+#pragma unroll
+                for (int ks = 0; ks < KS32; ++ks)
+#pragma unroll
+                    for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = mfma16(a[ks], xf[sb][ks], acc[sb]);
+                reduce_tile(acc, 0);
+                if (e_next < 0 || (e_next >> 2) != (e >> 2)) fold_stage(e >> 2, true);
+            };
+            // (the tiles' operands alternate between two register sets: the next tile's are read under this tile's MFMAs)
+            bf16x8 aA[KS32], aB[KS32];
+            f32x4 wvA, wvB;
+            load_tile(0, aA, wvA);
+            if (cur[1] >= 0) load_tile(1, aB, wvB);
+            run_tile(aA, wvA, cur[0], cur[1] >= 0 ? cur[1] : -1);
+            if (cur[1] >= 0) {
+                if (cur[2] >= 0) load_tile(2, aA, wvA);
+                run_tile(aB, wvB, cur[1], cur[2] >= 0 ? cur[2] : -1);
+                if (cur[2] >= 0) {
+                    if (cur[3] >= 0) load_tile(3, aB, wvB);
+                    run_tile(aA, wvA, cur[2], cur[3] >= 0 ? cur[3] : -1);
+                    if (cur[3] >= 0) run_tile(aB, wvB, cur[3], nxt[0]);
+                }
+            }
+            if (c + 4 < e0 && lane < 16) *(float*)(sn + TQ + (wave * 16 + lane) * 4) = wqn;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cur[j] = nxt[j]; nxt[j] = nn[j]; }
+        }
+    }
     for (int s = s_begin; s < s_end; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -347,52 +431,6 @@ __global__ __launch_bounds__(64 * K16_NW, TL ? 3 : 2) void bmu_bf16_k16_kernel(c
         if (s + 1 < s_end) dma_item(it_next, smem + ((s + 1 - s_begin) & 1) * STAGE);
         const char* st = smem + ((s - s_begin) & 1) * STAGE;
         const float* wq = (const float*)(st + K16_T * KS32 * 1024);
-
-        if (TL) {
-            // the item's tiles (up to four) in ascending order, their operands alternating between two register sets (no
-            // copies): the next tile's fragments are read under this tile's MFMAs; the group is folded when its last tile is in
-            const uint32_t m0 = (uint32_t)it_cur & 15u;      // (never empty: exact_lists_kernel lists no group without a block)
-            const uint32_t m1 = m0 & (m0 - 1u), m2 = m1 & (m1 - 1u), m3 = m2 & (m2 - 1u);
-            const int t0 = __builtin_ctz(m0), t1 = m1 ? __builtin_ctz(m1) : -1, t2 = m2 ? __builtin_ctz(m2) : -1, t3 = m3 ? __builtin_ctz(m3) : -1;
-            auto load_tile = [&](int t, bf16x8 (&a)[KS32], f32x4& wv) {
-#pragma unroll
-                for (int ks = 0; ks < KS32; ++ks) a[ks] = *(const bf16x8*)(st + (t * KS32 + ks) * 1024 + lane * 16);
-                wv = *(const f32x4*)(wq + t * 16 + 4 * quad);
-            };
-            auto run_tile = [&](const bf16x8 (&a)[KS32], const f32x4& wv, f32x4 (&acc)[K16_SB]) {
-#pragma unroll
-                for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = wv;
-#pragma unroll
-                for (int ks = 0; ks < KS32; ++ks)
-#pragma unroll
-                    for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = mfma16(a[ks], xf[sb][ks], acc[sb]);
-            };
-            // (one set of accumulators: a tile's reduction waits for its own MFMAs -- the workgroup's other waves and the
-            //  CU's other two workgroups fill the pipe meanwhile -- and two sets would cost the third workgroup per CU)
-            bf16x8 aA[KS32], aB[KS32];
-            f32x4 wvA, wvB, acc[K16_SB];
-            load_tile(t0, aA, wvA);
-            if (t1 >= 0) load_tile(t1, aB, wvB);
-            run_tile(aA, wvA, acc);
-            reduce_tile(acc, 0);
-            if (t1 >= 0) {
-                if (t2 >= 0) load_tile(t2, aA, wvA);
-                run_tile(aB, wvB, acc);
-                reduce_tile(acc, 0);
-                if (t2 >= 0) {
-                    if (t3 >= 0) load_tile(t3, aB, wvB);
-                    run_tile(aA, wvA, acc);
-                    reduce_tile(acc, 0);
-                    if (t3 >= 0) {
-                        run_tile(aB, wvB, acc);
-                        reduce_tile(acc, 0);
-                    }
-                }
-            }
-            fold_stage(it_cur >> 4, true);
-            it_prev = it_cur; it_cur = it_next; it_next = it_next2;
-            continue;
-        }
 
         f32x4 wv = *(const f32x4*)(wq + 4 * quad);
         bf16x8 a[KS32];

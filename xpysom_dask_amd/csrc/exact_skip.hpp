@@ -388,13 +388,16 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16
 // need bitmaps -> per tile the ascending list of items (group << 4 | mask of the group's 16-unit sub-blocks to run), and its
 // length.  need1: bit j of word s <-> group 64 s + j (level 1).  need2 (or null: every sub-block of a kept group runs):
 // word 4 s + k holds, for the groups 64 s + 16 k .. + 15, a nibble each (bit 4 (g & 15) + sub <-> sub-block `sub` of group g).
-// One wave per tile; tile_counts[tile] = (16-unit blocks listed, groups level 1 kept).
+// ... and the same blocks as the tile's dense list of 16-unit tiles (tlist / tcnt: what the screen walks; glist / gcnt: what
+// the select kernel walks).  One wave per tile; tile_counts[tile] = (16-unit blocks listed, groups level 1 kept).
 __global__ __launch_bounds__(64) void exact_lists_kernel(const unsigned long long* __restrict__ need1, int n_cstages,
                                                          const unsigned long long* __restrict__ need2, int n_groups,
                                                          int* __restrict__ glist, int* __restrict__ gcnt,
-                                                         int2* __restrict__ tile_counts) {
+                                                         int2* __restrict__ tile_counts, int* __restrict__ tlist,
+                                                         int* __restrict__ tcnt) {
     const long tile = blockIdx.x;
     const int lane = threadIdx.x;
+    const unsigned long long below = (1ull << lane) - 1ull;
     int base = 0, blk = 0, kept = 0;
     for (int s0 = 0; s0 < n_cstages; s0 += 64) {
         // (the tile's level-1 words in one load, lane <-> stage; then stage by stage out of registers)
@@ -414,12 +417,26 @@ __global__ __launch_bounds__(64) void exact_lists_kernel(const unsigned long lon
             if (on) glist[tile * n_groups + base + __popcll(mk & ((1ull << lane) - 1ull))] = (g << 4) | (int)nib;
             base += __popcll(mk);
             kept += __popcll(__ballot(l1));
+            // the same blocks as a DENSE list of 16-unit tiles (group << 2 | sub-block), ascending: what the screen walks, four
+            // to a barrier, whatever group they belong to
+            int before = 0, total = 0;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) blk += __popcll(__ballot(on && ((nib >> b) & 1u)));
+            for (int b = 0; b < 4; ++b) {
+                const unsigned long long mb = __ballot(on && ((nib >> b) & 1u));
+                before += __popcll(mb & below);
+                total += __popcll(mb);
+            }
+            if (on) {
+                int o = blk + before;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if ((nib >> b) & 1u) tlist[tile * 4 * n_groups + o++] = (g << 2) | b;
+            }
+            blk += total;
         }
     }
     // (per tile: 4 096 waves adding into two words of one cache line took as long as the rest of this kernel)
-    if (lane == 0) { gcnt[tile] = base; tile_counts[tile] = make_int2(blk, kept); }
+    if (lane == 0) { gcnt[tile] = base; tcnt[tile] = blk; tile_counts[tile] = make_int2(blk, kept); }
 }
 
 // sum of the tiles' (16-unit blocks listed, groups level 1 kept) into the pass's counters.  One workgroup.

@@ -134,7 +134,8 @@ struct som_handle {
         struct Centroids { float *Cc = nullptr, *rg = nullptr, *csq = nullptr, *wn_c = nullptr, *cmax2 = nullptr; char* Cst = nullptr;
                            int n_slots = 0, n_cstages = 0; } cen[2];
         unsigned long long *need = nullptr, *need2 = nullptr;
-        int *glist = nullptr, *gcnt = nullptr;
+        int *glist = nullptr, *gcnt = nullptr;   // per tile: (group << 4 | sub-block mask) items: what the select kernel walks
+        int *tlist = nullptr, *tcnt = nullptr;   // per tile: the same blocks as a dense list of 16-unit tiles: what the screen walks
         int2* tile_counts = nullptr;
     } ex;
     int n_kchunks = 0;       // tiled: 64-feature chunks
@@ -1022,8 +1023,8 @@ int exact_screen(som_handle* h, const __bf16* Xb, long n, unsigned long long* be
         // a tile's list is short where the plan works (tens of items of 1 024): every part of a tile loads the tile's 64 KB
         // of rows again, so the scan is split only where the lists are long enough to carry that (the last plan's share
         // is the forecast; 1 Mi rows, mid-schedule: three parts re-read 0.8 GB for 0.3 ms of screen)
-        const double items = h->ex.res_share_last * (double)n_groups;
-        parts = items < 64.0 ? 1 : items < 160.0 ? std::min(parts, 2) : parts;
+        const double tiles16 = h->ex.res_share_last * (double)n_groups * K16_T;
+        parts = tiles16 < 128.0 ? 1 : tiles16 < 320.0 ? std::min(parts, 2) : parts;
     }
     if (h->env_bf16_parts > 0) parts = std::min(h->env_bf16_parts, h->n_stages);
     if (h->debug)
@@ -1160,9 +1161,9 @@ int exact_skip_reserve(som_handle* h, long rows_all, long stride) {
         ex.sk_rows = need_rows;
     }
     if (stride <= ex.sk_stride) return 0;
-    void* old[] = {ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.sk_tmp, ex.need, ex.need2, ex.glist, ex.gcnt, ex.tile_counts};
+    void* old[] = {ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.sk_tmp, ex.need, ex.need2, ex.glist, ex.gcnt, ex.tile_counts, ex.tlist, ex.tcnt};
     for (void* p : old) if (p) (void)hipFree(p);
-    ex.sk_keys = ex.sk_keys2 = ex.sk_vals = nullptr; ex.sk_tmp = nullptr; ex.need = ex.need2 = nullptr; ex.glist = ex.gcnt = nullptr; ex.tile_counts = nullptr;
+    ex.sk_keys = ex.sk_keys2 = ex.sk_vals = nullptr; ex.sk_tmp = nullptr; ex.need = ex.need2 = nullptr; ex.glist = ex.gcnt = nullptr; ex.tile_counts = nullptr; ex.tlist = ex.tcnt = nullptr;
     ex.sk_stride = 0;
     const long tiles = stride / SK_TILE;
     if (int rc = dev_alloc(h, &ex.sk_keys, (size_t)stride)) return rc;
@@ -1173,6 +1174,8 @@ int exact_skip_reserve(som_handle* h, long rows_all, long stride) {
     if (int rc = dev_alloc(h, &ex.glist, (size_t)tiles * n_groups)) return rc;
     if (int rc = dev_alloc(h, &ex.gcnt, (size_t)tiles)) return rc;
     if (int rc = dev_alloc(h, &ex.tile_counts, (size_t)tiles)) return rc;
+    if (int rc = dev_alloc(h, &ex.tlist, (size_t)tiles * n_groups * K16_T)) return rc;
+    if (int rc = dev_alloc(h, &ex.tcnt, (size_t)tiles)) return rc;
     size_t bytes = 0;
     HIPCHK(h, sort_bmu_pairs_storage(bytes, ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.order, stride, 32u, h->stream));
     char* tmp = nullptr;
@@ -1268,7 +1271,7 @@ int exact_skip_plan(som_handle* h, long r0, long n, const int* prev, const float
     }
 #undef SOM_PLAN_CASE
     exact_lists_kernel<<<dim3((unsigned)tiles), dim3(64), 0, h->stream>>>(ex.need, c0.n_cstages, l2 ? ex.need2 : nullptr, n_groups,
-                                                                         ex.glist, ex.gcnt, ex.tile_counts);
+                                                                         ex.glist, ex.gcnt, ex.tile_counts, ex.tlist, ex.tcnt);
     exact_list_totals_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(ex.tile_counts, tiles, ex.ctr + 2 * n_groups + 3, ex.ctr + 2 * n_groups + 4);
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -1417,7 +1420,7 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         {
             Timed ts(h, SOM_K_SCREEN);
             if (int rc = SOM_HALF(h, exact_screen_ks, h, p_Xb, n, h->best64 + r0, p_xsq, p_xerr, xmax2, eb, p_seed,
-                                  ex.skip_live ? ex.glist : nullptr, ex.skip_live ? ex.gcnt : nullptr)) return rc;
+                                  ex.skip_live ? ex.tlist : nullptr, ex.skip_live ? ex.tcnt : nullptr)) return rc;
         }
         const dim3 sel_grid((unsigned)cdiv(n, 64)), sel_block(64 * EX_SCAN_SPLIT);
         unsigned long long* best = h->best64 + r0;
@@ -2126,7 +2129,7 @@ void som_destroy(som_handle* h) {
     {
         void* eb[] = {h->ex.gmin, h->ex.gflags, h->ex.rowcnt, h->ex.rowarg, h->ex.seed, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab,
                       h->ex.order, h->ex.sk_keys, h->ex.sk_keys2, h->ex.sk_vals, h->ex.sk_tmp, h->ex.Xb_s, h->ex.Xf_s, h->ex.xsq_s, h->ex.xerr_s,
-                      h->ex.seed_s, h->ex.sU_s, h->ex.lastpos_s, h->ex.need, h->ex.need2, h->ex.glist, h->ex.gcnt, h->ex.tile_counts};
+                      h->ex.seed_s, h->ex.sU_s, h->ex.lastpos_s, h->ex.need, h->ex.need2, h->ex.glist, h->ex.gcnt, h->ex.tile_counts, h->ex.tlist, h->ex.tcnt};
         for (void* b : eb) if (b) (void)hipFree(b);
         for (auto& c : h->ex.cen) {
             void* cb[] = {c.Cc, c.rg, c.csq, c.wn_c, c.cmax2, c.Cst};
