@@ -690,3 +690,85 @@ def test_exact_block_skipping_pauses_the_plan_on_rows_without_structure():
     run, total = x.exact_skip_stats()
     assert run > 0.97 * total
     f.close(); x.close()
+
+
+# ----------------------------------------------------------------------------- the resident sorted pass, the sub-block plan
+def _train_states(monkeypatch, env, X, Y, D, n, T, data, w):
+    for k in ("SOM_EXACT_RESORT", "SOM_EXACT_SUBBLOCKS", "SOM_EXACT_SKIP", "SOM_EXACT_PASS_ROWS"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    e = engine(X, Y, D, precision="exact")
+    e.set_weights(w); e.set_data(data)
+    ids = []
+    for t in range(T):
+        sig, eta = O.exponential_decay(min(X, Y) / 2.0, 1.0, t, T), O.exponential_decay(0.5, 0.01, t, T)
+        e.epoch_accumulate(sig, eta, True)
+        ids.append(e.epoch_fetch()[2])
+        e.epoch_merge()
+    out = (ids, e.get_weights(), e.exact_skip_stats(), e.exact_resident_stats())
+    e.close()
+    return out
+
+
+def test_exact_resident_order_is_resorted_lazily_and_never_changes_the_ids(monkeypatch):
+    """The rows stay resident in the order of their BMU's patch at the time of the last sort; the plan tests every row of a
+    tile where it sits, so a stale order costs blocks, never a BMU.  Re-sorting every planned epoch (SOM_EXACT_RESORT=1),
+    never again after the first sort (=1000) and the default policy (when the order has gone stale) give the same ids in
+    every epoch and the same codebook as precision='f32'; the default sorts in fewer epochs than it plans."""
+    X, Y, D, n, T = 64, 64, 32, 30000, 12
+    data = O.gaussian_blobs(n, D, seed=21)
+    w = O.default_codebook(X, Y, D, 2).astype(F32)
+    f = engine(X, Y, D, precision="f32")
+    f.set_weights(w); f.set_data(data)
+    ref = []
+    for t in range(T):
+        f.epoch_accumulate(O.exponential_decay(32.0, 1.0, t, T), O.exponential_decay(0.5, 0.01, t, T), True)
+        ref.append(f.epoch_fetch()[2]); f.epoch_merge()
+    wf = f.get_weights(); f.close()
+    runs = {tag: _train_states(monkeypatch, env, X, Y, D, n, T, data, w)
+            for tag, env in (("every", {"SOM_EXACT_RESORT": "1"}), ("never", {"SOM_EXACT_RESORT": "1000"}), ("default", {}))}
+    for tag, (ids, wx, skip, res) in runs.items():
+        for t in range(T):
+            assert np.array_equal(ids[t], ref[t]), (tag, t, int((ids[t] != ref[t]).sum()))
+        assert np.array_equal(wx, wf), tag
+    planned, sorts = runs["default"][3]
+    assert planned >= T - 3 and 1 <= sorts < planned, (planned, sorts)
+    assert runs["every"][3][1] == runs["every"][3][0] and runs["never"][3][1] == 1
+    # a fresher order never runs more blocks than the order of the first planned epoch kept forever
+    assert runs["every"][2][0] <= runs["never"][2][0]
+
+
+def test_exact_sub_block_plan_drops_blocks_and_keeps_the_ids(monkeypatch):
+    """Level 2 of the plan (the groups' four 16-unit sub-blocks with their own centroids and radii) only removes blocks from
+    what level 1 keeps: same ids with it (SOM_EXACT_SKIP=2 forces it on every planned epoch) and without it
+    (SOM_EXACT_SUBBLOCKS=0), fewer blocks run with it on a trained map."""
+    X, Y, D, n, T = 64, 64, 32, 20000, 8
+    data = O.gaussian_blobs(n, D, seed=4)
+    w = O.default_codebook(X, Y, D, 6).astype(F32)
+    a = _train_states(monkeypatch, {"SOM_EXACT_SKIP": "2"}, X, Y, D, n, T, data, w)
+    b = _train_states(monkeypatch, {"SOM_EXACT_SKIP": "2", "SOM_EXACT_SUBBLOCKS": "0"}, X, Y, D, n, T, data, w)
+    for t in range(T):
+        assert np.array_equal(a[0][t], b[0][t]), t
+    assert np.array_equal(a[1], b[1])
+    assert a[2][1] == b[2][1] and a[2][0] < 0.9 * b[2][0], (a[2], b[2])
+
+
+def test_exact_new_rows_of_the_same_size_drop_the_resident_order():
+    """som_set_data with another row set of the same shape (the allocator may hand back the same address): the sorted copies
+    of the old rows must not survive."""
+    X, Y, D, n = 64, 64, 16, 12000
+    w = O.default_codebook(X, Y, D, 5).astype(F32)
+    d1, d2 = O.gaussian_blobs(n, D, seed=1), O.gaussian_blobs(n, D, seed=2)
+    f = engine(X, Y, D, precision="f32"); x = engine(X, Y, D, precision="exact")
+    for e in (f, x):
+        e.set_weights(w)
+    for data in (d1, d2, d1):
+        for e in (f, x):
+            e.set_data(data)
+        for sig in (8.0, 3.0, 1.5):
+            f.epoch_accumulate(sig, 0.3, True); x.epoch_accumulate(sig, 0.3, True)
+            assert np.array_equal(f.epoch_fetch()[2], x.epoch_fetch()[2])
+            f.epoch_merge(); x.epoch_merge()
+    assert x.exact_resident_stats()[1] >= 3               # at least one sort per row set
+    f.close(); x.close()

@@ -71,3 +71,43 @@ def test_canary_from_the_environment(monkeypatch):
     data = O.gaussian_blobs(800, 6, seed=1)
     som = XPySom(9, 9, 6, random_seed=1, precision="exact").train(data, 3)
     assert som._engine().verify_stats() == (3, 96)
+
+
+def test_wide_kernel_hand_placed_lds_reads_equal_the_plain_reads(tmp_path):
+    """The wide BMU kernel (more than 128 features on big maps: bf16 / f16 modes and the exact mode's screen) reads its LDS
+    fragments with inline-assembly `ds_read_b128` and hand-counted waits (csrc/bmu_bf16_wide.hpp).  That is only as good as
+    the register allocation around it, so a second library is built here with plain C++ reads (-DSOM_WIDE_PLAIN_READS:
+    what build.py gives any compiler but the validated one) and both must return the same ids, bit for bit, on the same
+    rows -- the bf16 kernel, the f16 kernel and the exact mode's screen + re-score."""
+    import json, os, subprocess, sys
+    from xpysom_dask_amd import build as B
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    plain = str(tmp_path / "libsomhip_plain.so")
+    B.build(force=True, verbose=False, extra=("-DSOM_WIDE_PLAIN_READS",), out=plain)
+    prog = r"""
+import sys, json, zlib, numpy as np
+sys.path.insert(0, %r)
+from oracle import som_oracle as O
+from xpysom_dask_amd.engine import HipEngine
+out = {}
+for D, dist in ((200, "euclidean"), (784, "cosine")):
+    data = np.abs(O.gaussian_blobs(6000, D, seed=D))
+    w = np.abs(O.default_codebook(64, 64, D, 3)).astype(np.float32)
+    for prec in ("bf16", "f16", "exact"):
+        e = HipEngine(64, 64, D, precision=prec, distance=dist)
+        e.set_weights(w); e.set_data(data)
+        e.epoch_accumulate(6.0, 0.3, True)
+        out["%%d_%%s_%%s" %% (D, dist, prec)] = int(zlib.crc32(e.epoch_fetch()[2].tobytes()))
+        e.close()
+print(json.dumps(out))
+""" % REPO
+    res = {}
+    for tag, lib in (("asm", None), ("plain", plain)):
+        env = dict(os.environ)
+        env.pop("SOM_LIB_PATH", None)
+        if lib:
+            env["SOM_LIB_PATH"] = lib
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["asm"] == res["plain"], (res["asm"], res["plain"])

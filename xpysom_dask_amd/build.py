@@ -55,6 +55,27 @@ def hipcc():
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
+# The wide BMU kernel (csrc/bmu_bf16_wide.hpp) places its LDS fragment reads and their counted waits by hand (inline
+# assembly); that is only as good as the register allocation around it.  It was validated -- every `-m gpu` test, the
+# fuzzers, SOM_VERIFY -- with this compiler; any other gets the plain C++ reads (-DSOM_WIDE_PLAIN_READS: the compiler's own
+# waits, ~3 % slower at 512 x 512 x 784) unless SOM_WIDE_ASM=1 insists.
+VALIDATED_HIPCC = "roc-7.2.0"
+
+
+def hipcc_version(cc=None):
+    try:
+        return subprocess.run([cc or hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout
+    except (OSError, subprocess.SubprocessError):
+        return ""
+
+
+def wide_reads_flags(cc=None):
+    if os.environ.get("SOM_WIDE_ASM") == "1" or VALIDATED_HIPCC in hipcc_version(cc):
+        return []
+    print("xpysom_dask_amd.build: hipcc is not the validated %s: building the wide kernel with plain LDS reads" % VALIDATED_HIPCC, file=sys.stderr)
+    return ["-DSOM_WIDE_PLAIN_READS"]
+
+
 def up_to_date():
     return os.path.exists(OUT) and built_hash(OUT) == source_hash()
 
@@ -66,7 +87,7 @@ def build(force=False, verbose=True, extra=(), out=None):
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-command-line-argument",
            '-DSOM_SRC_HASH="%s"' % source_hash(),
-           SRC, "-o", out or OUT, "-Wl,-rpath,/opt/rocm/lib"] + list(extra)
+           SRC, "-o", out or OUT, "-Wl,-rpath,/opt/rocm/lib"] + wide_reads_flags() + list(extra)
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -271,11 +271,19 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
     auto chunks = [&](const char* st, auto k0, auto k1) {
         constexpr int K0 = decltype(k0)::value, K1 = decltype(k1)::value;
         const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)st + (uint32_t)lane * 16u;
+        // SOM_WIDE_PLAIN_READS (build.py sets it for a hipcc other than the one this schedule was validated with; the test
+        // suite builds such a library and compares): plain C++ reads, the compiler's own waits.  The hand-placed form relies
+        // on the register allocator renaming an[] into a[] (no copy of a register whose read is still in flight) and on
+        // no spill of them: true of the validated compiler's output, checked per build by SOM_VERIFY in smoke().
+#ifdef SOM_WIDE_PLAIN_READS
+        auto read16 = [&](int piece) { return *(const f32x4*)(st + lane * 16 + piece * 1024); };
+#else
         auto read16 = [&](int piece) {
             f32x4 v;
             asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(base + (uint32_t)piece * 1024u));
             return v;
         };
+#endif
         f32x4 a[WD_T], an[WD_T];
 #pragma unroll
         for (int t = 0; t < WD_T; ++t) a[t] = read16(t * KS32 + K0);
@@ -285,9 +293,11 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
             if (ks + 1 < K1) {
 #pragma unroll
                 for (int t = 0; t < WD_T; ++t) an[t] = read16(t * KS32 + ks + 1);
+#ifndef SOM_WIDE_PLAIN_READS
                 asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a[0]), "+v"(a[1]));
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]));
+#endif
             }
 #pragma unroll
             for (int t = 0; t < WD_T; ++t)
