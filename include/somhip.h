@@ -224,22 +224,9 @@ int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, d
  * precision mode's operand-rounding bound of them; otherwise the call fails with a message naming a row.  Costs one
  * small float32 launch and one host synchronisation per BMU launch: for smoke tests and stress runs (also: the
  * environment variable SOM_VERIFY=n at som_create).  som_verify_stats: launches / rows checked so far.
- * som_debug_corrupt_operands is the canary's TEST HOOK: it zeroes the operand images the kernels read (bit 0: the
- * 16-bit image, bit 1: the float32 image) without marking them stale, as a lost staging copy would. */
+ * (The test hooks that go with it -- som_debug_* -- are declared in include/somhip_test.h, not here.) */
 int som_set_verify(som_handle* h, int32_t n_rows);
 int som_verify_stats(som_handle* h, int64_t* launches, int64_t* rows_checked);
-int som_debug_corrupt_operands(som_handle* h, int32_t which);
-
-/* measurement hook: ONE v_mfma_f32_16x16x32 (_f16 when is_f16, else _bf16) on the caller's operands -- a [16][32] and
- * b [32][16] as 16-bit patterns, c and d [16][16] float32, row-major.  tests/test_gpu_exact.py uses it to measure the
- * rounding error the exact mode's bound charges per MFMA (the hardware's internal summation is not documented). */
-int som_debug_mfma16(som_handle* h, const uint16_t* a_host, const uint16_t* b_host, const float* c_host, float* d_host,
-                     int32_t is_f16);
-
-/* diagnostic builds only (-DSOM_STAMPS, tools/stamps.py): out_host == NULL attaches a buffer of n_pairs (shader-clock
- * ticks, 100 MHz ticks) pairs, one per workgroup of the next BMU launches (n_pairs == 0 detaches); out_host != NULL
- * reads n_pairs pairs back.  The product build refuses both. */
-int som_debug_stamps(som_handle* h, int64_t n_pairs, uint64_t* out_host);
 
 /* precision EXACT, introspection (host arithmetic only, no device needed): the order in which the mode's operand images
  * hold the units of an x * y map -- perm_out[position] = unit id, x * y entries; every 64 consecutive positions are one

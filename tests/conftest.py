@@ -9,6 +9,8 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
+# the library reads its developer switches (forced pass sizes, kernel A/B variants, refused allocations) only under this one
+os.environ.setdefault("SOM_TEST_HOOKS", "1")
 
 
 def pytest_configure(config):

@@ -64,8 +64,10 @@ def test_synthetic_generator_is_the_oracles():
 def test_c_abi_exports_every_declared_symbol():
     from xpysom_dask_amd import _lib
     lib = _lib.load()
-    header = open(REPO + "/include/somhip.h").read()
+    # (the boundary, include/somhip.h, + the test-only entry points of include/somhip_test.h)
+    header = open(REPO + "/include/somhip.h").read() + open(REPO + "/include/somhip_test.h").read()
     declared = set(re.findall(r"\b(som_[a-z0-9_]+)\s*\(", header))
+    assert not re.search(r"\bsom_debug_[a-z0-9_]+\s*\(", open(REPO + "/include/somhip.h").read()), "test hooks belong in somhip_test.h"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)

@@ -17,6 +17,7 @@ original copy path, so the hypothesis can be confirmed or killed.
 import argparse
 import json
 import os
+os.environ.setdefault("SOM_TEST_HOOKS", "1")   # (the library reads its developer switches only under this one)
 import subprocess
 import sys
 import tempfile

@@ -1,4 +1,5 @@
 #!/bin/bash
+export SOM_TEST_HOOKS=1   # (the library reads its developer switches only under this one)
 out=gpurun_out/r03_fuzz_patch_order.txt   # (kept as profiles/r03_fuzz_patch_order.txt)
 python - <<'PY' > $out
 from xpysom_dask_amd import build as B

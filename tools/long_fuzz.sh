@@ -1,4 +1,5 @@
 #!/bin/bash
+export SOM_TEST_HOOKS=1   # (the library reads its developer switches only under this one)
 # long fuzz run on the final build: every fuzzer, several seeds; one summary line each
 out=gpurun_out/r03_fuzz_summary.txt
 python - <<'PY' > $out

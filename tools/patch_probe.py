@@ -1,6 +1,7 @@
 """how many candidate groups a row would have if a group were an a x b patch of the map instead of a 1 x 64 strip
 (run with SOM_EXACT_PATCH=0: the engine's strip counts calibrate the per-row band)"""
 import os, sys, numpy as np, torch
+os.environ.setdefault("SOM_TEST_HOOKS", "1")   # (the library reads its developer switches only under this one)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from xpysom_dask_amd.engine import HipEngine
 from xpysom_dask_amd.decays import exponential_decay

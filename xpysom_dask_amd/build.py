@@ -17,11 +17,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "somhip.hip")
 OUT = os.path.join(HERE, "libsomhip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "somhip.h")
+TEST_HEADER = os.path.join(os.path.dirname(HERE), "include", "somhip_test.h")
 
 
 def sources():
-    """Every file the library is compiled from: csrc/* and the public header."""
-    return sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")) + glob.glob(os.path.join(HERE, "csrc", "*.hpp"))) + [HEADER]
+    """Every file the library is compiled from: csrc/* and the two headers."""
+    return sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")) + glob.glob(os.path.join(HERE, "csrc", "*.hpp"))) + [HEADER, TEST_HEADER]
 
 
 def source_hash():

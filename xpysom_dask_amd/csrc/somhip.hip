@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/somhip.h"
+#include "../../include/somhip_test.h"
 #include "bmu_bf16_k16.hpp"
 #include "bmu_bf16_k16x3.hpp"
 #include "bmu_bf16_tiled.hpp"
@@ -36,6 +37,14 @@ using namespace somhip;
 namespace {
 
 thread_local std::string g_create_error;
+
+// Environment switches.  Four are for users (SOM_VERIFY, SOM_DEBUG, SOM_EXACT_SKIP, SOM_GRAPH).  Everything
+// else -- A/B switches of kernel variants, forced pass sizes, refused allocations -- belongs to the tests and the tools and is
+// read ONLY when SOM_TEST_HOOKS=1 is set (tests/conftest.py sets it): a stray variable in a user's environment changes nothing.
+const char* dev_env(const char* name) {
+    static const bool on = std::getenv("SOM_TEST_HOOKS") != nullptr;
+    return on ? std::getenv(name) : nullptr;
+}
 
 struct EventPair { hipEvent_t a, b; int kernel; };
 
@@ -98,6 +107,7 @@ struct som_handle {
         int64_t rows_total = 0, rows_fallback = 0, chunks = 0;   // som_exact_stats
         int64_t blocks_run = 0, blocks_total = 0;                // som_exact_skip_stats: (256-row tile, 16-unit block) blocks of the screens
         long pass_rows_override = 0;
+        long hook_refuse_above = 0, hook_pairs = 0; bool hook_refuse_skip = false;   // test hooks, read once in som_create (SOM_TEST_HOOKS=1)
         long stride_cap = 0;              // rows per pass the device had memory for (0: no allocation was ever refused)
         long pairs = 64;                  // capacity of a pass: (row, group) pairs per row on average (exact_reserve)
         // block skipping (exact_skip.hpp): resident rows from their second epoch on, input_len <= 128
@@ -977,8 +987,8 @@ int exact_reserve(som_handle* h, long rows) {
 
 int exact_reserve_stride(som_handle* h, long stride) {
     auto& ex = h->ex;
-    // TEST HOOK (tests/test_gpu_exact.py): behave as a device that refuses the scratch of passes above n rows
-    if (const char* e = std::getenv("SOM_EXACT_DEBUG_REFUSE_ABOVE")) if (stride > std::atol(e)) return fail(h, "exact: pass scratch refused (test hook)");
+    // TEST HOOK (tests/test_gpu_exact.py; SOM_TEST_HOOKS=1): behave as a device that refuses the scratch of passes above n rows
+    if (ex.hook_refuse_above > 0 && stride > ex.hook_refuse_above) return fail(h, "exact: pass scratch refused (test hook)");
     void* old[] = {ex.gmin, ex.gflags, ex.rowcnt, ex.rowarg, ex.seed, ex.fb_list, ex.plist, ex.tile_tab};
     for (void* p : old) if (p) (void)hipFree(p);
     ex.gmin = nullptr; ex.gflags = nullptr; ex.rowcnt = nullptr; ex.rowarg = nullptr; ex.seed = nullptr; ex.fb_list = nullptr; ex.plist = nullptr; ex.tile_tab = nullptr;
@@ -987,7 +997,7 @@ int exact_reserve_stride(som_handle* h, long stride) {
     // capacity of a pass in (row, group) pairs per row on average: a quarter of the groups -- past that the float32
     // kernel over all of them costs about what the re-score would
     ex.pairs = std::max<long>(EX_PAIRS, std::min<long>(n_groups / 4, 512));
-    if (const char* e = std::getenv("SOM_EXACT_PAIRS")) ex.pairs = std::max(1L, std::atol(e));
+    if (ex.hook_pairs > 0) ex.pairs = ex.hook_pairs;
     if (stride * ex.pairs > 0x7fffffffL) return fail(h, "exact: pass too large");
     if (int rc = dev_alloc(h, &ex.gmin, (size_t)n_groups * stride)) return rc;
     if (int rc = dev_alloc(h, &ex.gflags, (size_t)n_groups * (stride / 64))) return rc;
@@ -1126,7 +1136,7 @@ hipError_t sort_bmu_pairs_storage(size_t& bytes, K* kin, K* kout, V* vin, V* vou
 int exact_skip_reserve(som_handle* h, long rows_all, long stride) {
     auto& ex = h->ex;
     // TEST HOOK (tests/test_gpu_exact.py): behave as a device without memory for the sorted pass
-    if (std::getenv("SOM_EXACT_DEBUG_REFUSE_SKIP")) return fail(h, "exact: block-skipping scratch refused (test hook)");
+    if (ex.hook_refuse_skip) return fail(h, "exact: block-skipping scratch refused (test hook)");
     const long n_groups = cdiv(h->K, EX_GROUP);
     if (!ex.cen[0].Cc) {
         const int ncs = (int)cdiv(n_groups, K16_STAGE_UNITS);
@@ -1989,13 +1999,13 @@ int som_create(const som_config* cfg, som_handle** out) {
         h->n_ublocks = (int)cdiv(h->K, h->tl_bn);
     }
     h->wide = h->tiled && h->tl_big && h->n_kchunks <= 25;     // (bf16x3: the tripled feature axis, input_len <= 266)
-    if (const char* e = std::getenv("SOM_BF16_WIDE")) if (std::atoi(e) == 0) h->wide = false;   // A/B: the two-sided tiling
+    if (const char* e = dev_env("SOM_BF16_WIDE")) if (std::atoi(e) == 0) h->wide = false;   // A/B: the two-sided tiling
     if (h->exact && h->tiled && !h->wide) {              // no exact screen on the two-sided tiling: the float32 kernels serve
         h->exact = false; h->f16 = false; h->tiled = false;
         h->cfg.precision = SOM_PREC_F32;
     }
     h->ex_patch = h->exact && h->K >= 2 * EX_GROUP;      // (a map of one group has nothing to order)
-    if (const char* e = std::getenv("SOM_EXACT_PATCH")) if (std::atoi(e) == 0) h->ex_patch = false;   // A/B: groups = strips of a map row
+    if (const char* e = dev_env("SOM_EXACT_PATCH")) if (std::atoi(e) == 0) h->ex_patch = false;   // A/B: groups = strips of a map row
     h->dp = h->tiled ? TL_BK * h->n_kchunks : h->x3res ? 2 * 32 * h->ks32 : 32 * h->ks32;
     h->stage_bytes = h->wide ? wd_stage_bytes(h->n_kchunks) : h->x3res ? k3_stage_bytes(h->ks32) : k16_stage_bytes(h->ks32);
     h->stage_units = h->wide ? WD_STAGE_UNITS : h->x3res ? K3_STAGE_UNITS : K16_STAGE_UNITS;
@@ -2052,21 +2062,24 @@ int som_create(const som_config* cfg, som_handle** out) {
         if ((rc = dev_alloc(h, &npd, 1))) return bail(rc);
         h->np_dev = npd;
         if (const char* e = std::getenv("SOM_GRAPH")) h->use_graph = std::atoi(e) != 0;
-        if (const char* e = std::getenv("SOM_BF16_PARTS")) h->env_bf16_parts = std::atoi(e);
+        if (const char* e = dev_env("SOM_BF16_PARTS")) h->env_bf16_parts = std::atoi(e);
         h->debug = std::getenv("SOM_DEBUG") != nullptr;
         if (const char* e = std::getenv("SOM_VERIFY")) h->verify_rows = std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("SOM_EXACT_PASS_ROWS")) h->ex.pass_rows_override = std::atol(e);
-        if (const char* e = std::getenv("SOM_EXACT_TWO_ROUND")) h->ex.two_round = std::atoi(e) != 0 ? 1 : 0;
-        if (const char* e = std::getenv("SOM_EXACT_SEED")) h->ex.seed_on = std::atoi(e) != 0;
+        if (const char* e = dev_env("SOM_EXACT_PASS_ROWS")) h->ex.pass_rows_override = std::atol(e);
+        if (const char* e = dev_env("SOM_EXACT_DEBUG_REFUSE_ABOVE")) h->ex.hook_refuse_above = std::atol(e);
+        if (const char* e = dev_env("SOM_EXACT_PAIRS")) h->ex.hook_pairs = std::max(1L, std::atol(e));
+        h->ex.hook_refuse_skip = dev_env("SOM_EXACT_DEBUG_REFUSE_SKIP") != nullptr;
+        if (const char* e = dev_env("SOM_EXACT_TWO_ROUND")) h->ex.two_round = std::atoi(e) != 0 ? 1 : 0;
+        if (const char* e = dev_env("SOM_EXACT_SEED")) h->ex.seed_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_EXACT_SKIP")) h->ex.skip_mode = std::atoi(e);
-        if (const char* e = std::getenv("SOM_EXACT_SUBBLOCKS")) h->ex.sub_blocks = std::atoi(e) != 0;
-        if (const char* e = std::getenv("SOM_EXACT_RESORT")) h->ex.res_every = std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("SOM_ASYNC_COPIES")) h->async_copies = std::atoi(e) != 0;
-        if (const char* e = std::getenv("SOM_FUSE_MERGE")) h->fuse_merge_prep = std::atoi(e) != 0;
-        if (const char* e = std::getenv("SOM_COUNTING_SORT")) h->counting_sort = std::atoi(e) != 0;
+        if (const char* e = dev_env("SOM_EXACT_SUBBLOCKS")) h->ex.sub_blocks = std::atoi(e) != 0;
+        if (const char* e = dev_env("SOM_EXACT_RESORT")) h->ex.res_every = std::max(0, std::atoi(e));
+        if (const char* e = dev_env("SOM_ASYNC_COPIES")) h->async_copies = std::atoi(e) != 0;
+        if (const char* e = dev_env("SOM_FUSE_MERGE")) h->fuse_merge_prep = std::atoi(e) != 0;
+        if (const char* e = dev_env("SOM_COUNTING_SORT")) h->counting_sort = std::atoi(e) != 0;
         // a 128-row block of a table already spans most of a map side up to 256: nothing to skip there
         h->use_bands = h->X > 256 || h->Y > 256;
-        if (const char* e = std::getenv("SOM_NO_BANDS")) h->use_bands = std::atoi(e) == 0;
+        if (const char* e = dev_env("SOM_NO_BANDS")) h->use_bands = std::atoi(e) == 0;
         const size_t nb = (size_t)h->nt * (cdiv(h->Y, LM_BM) + cdiv(h->X, LM_BM));
         if ((rc = dev_alloc(h, &h->bands, nb))) return bail(rc);
     }
