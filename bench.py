@@ -206,6 +206,8 @@ def main():
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the bf16 run beside the exact headline (profiling passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch65536", action="store_true")
+    ap.add_argument("--unstructured-ranks", type=int, default=0,
+                    help="weak scaling: the first k ranks draw rows WITHOUT structure (N(0, I)): shards that skip nothing beside shards that skip most")
     ap.add_argument("--no-schedule", action="store_true", help="skip the epoch-by-epoch / whole-schedule / unstructured-rows block")
     ap.add_argument("--no-f32-check", action="store_true", help="skip the float32 run the headline codebook is compared with")
     args = ap.parse_args()
@@ -264,6 +266,11 @@ def main():
     # the same rows, so their codebooks can be compared); weak scaling: each rank draws its own rows
     rows_host = (workload_rows(args.workload, args.total_rows, 1234)[lo:hi] if args.scaling == "strong"
                  else workload_rows(args.workload, my_rows, 1234 + rank))
+    if args.scaling == "weak" and rank < args.unstructured_ranks:
+        rows_host = np.random.default_rng(4321 + rank).standard_normal((my_rows, FEATURES)).astype(np.float32)
+        if args.workload == "c5":
+            rows_host = np.abs(rows_host)
+            rows_host /= np.linalg.norm(rows_host, axis=1, keepdims=True)
 
     total = args.warmup + args.steps
     sched = [(exponential_decay(min(MAP_X, MAP_Y) / 2, 1, t, total), exponential_decay(0.5, 0.01, t, total))
@@ -314,6 +321,19 @@ def main():
 
     eng, dt = timed_run(args.precision)
     head_share = getattr(eng, "executed_share", 1.0)
+    # N > 1: the all-reduce waits for the slowest rank, and under block skipping a rank's BMU search depends on ITS rows:
+    # every rank's own search time per epoch (hipEvents around its BMU kernels: no waiting in it) and executed share
+    rank_spread = None
+    if dist is not None:
+        mine = torch.tensor([eng.profile_get("bmu")[0] / max(1, args.steps), head_share], dtype=torch.float64, device="cuda")
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        ms_r = [float(v[0].item()) for v in allv]
+        sh_r = [float(v[1].item()) for v in allv]
+        rank_spread = {"rank_epoch_ms": {"min": min(ms_r), "mean": sum(ms_r) / world, "max": max(ms_r), "by_rank": ms_r,
+                                         "what": "each rank's own BMU search per epoch (hipEvents on its stream; the all-reduce is not in it)"},
+                       "rank_executed_share": {"min": min(sh_r), "mean": sum(sh_r) / world, "max": max(sh_r), "by_rank": sh_r},
+                       "unstructured_ranks": args.unstructured_ranks}
     w_after_timed = eng.get_weights() if args.precision == "exact" else None
     bmu_ms, bmu_n = eng.profile_get("bmu")
     scr_ms, scr_n = eng.profile_get("screen")
@@ -666,8 +686,13 @@ def main():
         if full_scan is not None:
             full_scan["roofline_frac"] = KD2 * rows_launch / (full_scan["avg_launch_ms"] * 1e-3) / 1e12 / peak
             out["without_block_skipping"] = full_scan
+        if rank_spread is not None:
+            out.update(rank_spread)
         if probe is not None:
             out["strong_scaling_probe"] = probe
+            # the same rows on N ranks train the one-GPU map to float32 summation order (one epoch from the seeded codebook)
+            if world > 1 and "codebook_max_rel_vs_n1" in probe:
+                assert probe["codebook_max_rel_vs_n1"] <= 2e-6, "strong scaling: the N-rank codebook left the one-GPU run's: %g" % probe["codebook_max_rel_vs_n1"]
         if batch is not None:
             out["roofline"]["batch65536"] = batch
         if modes is not None:

@@ -170,3 +170,26 @@ def test_bench_launches_its_own_ranks(scaling):
     assert out["config"]["rows_total"] == (131072 if scaling == "weak" else 131073)
     assert out["value"] > 0 and 0 < out["roofline"]["frac"] < 1
     assert out["codebooks_identical_on_all_ranks"] is True      # every rank merged the same all-reduced sums
+
+
+def test_bench_reports_the_rank_spread_when_shards_differ_in_structure():
+    """Under block skipping a rank's epoch depends on ITS rows, and the all-reduce waits for the slowest rank.  Four
+    real-engine ranks on this box's one GPU (gloo), exact mode with skipping on, the first rank's rows WITHOUT structure
+    (N(0, I): it skips nothing) beside three ranks of Gaussian blobs: the line carries every rank's own BMU search time
+    and executed share, the structureless rank is the slowest and ran several times the others' blocks, and every rank still
+    ends on the same codebook (xpysom.py:545-558: one sum of all partials, one merge)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SOM_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--steps", "6", "--warmup", "3", "--rows", "65536",
+           "--no-cpu-baseline", "--no-throughput-mode", "--no-batch65536", "--no-modes", "--unstructured-ranks", "1"]
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-5000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 4 and out["codebooks_identical_on_all_ranks"] is True
+    ms, sh = out["rank_epoch_ms"], out["rank_executed_share"]
+    assert len(ms["by_rank"]) == 4 and ms["min"] <= ms["mean"] <= ms["max"]
+    # (the map is trained on every rank's rows, so even the structureless shard skips -- but it runs several times the blocks
+    #  of the others, and its BMU search is the one the all-reduce waits for)
+    assert sh["by_rank"][0] == sh["max"] and sh["by_rank"][0] > 2.0 * max(sh["by_rank"][1:]), sh
+    assert ms["by_rank"][0] == ms["max"], ms
+

@@ -66,11 +66,13 @@ __global__ __launch_bounds__(256) void prep_w_bf16_k16_kernel(const float* __res
 // (half_operand_error), in one pass -- prep_w_bf16_k16_kernel + exact_werr_kernel.  One wave per 16-unit tile walks the
 // tile's KS32 feature chunks (lane = (unit, 8 features) of each: one 16-byte fragment chunk of the image per chunk), so a
 // unit's error is four lanes of one wave.
+// Wst_lo (or null): the same fragments of the units' SECOND half -- lo = half(2^11 ((-w^) - hi)), so that -w^ = hi + 2^-11 lo up
+// to 2^-11 of lo's own magnitude: what the exact mode's refinement pass (bmu_exact.hpp) multiplies beside hi.
 template <int KS32, class EL = Bf16>
 __global__ __launch_bounds__(256) void prep_w_exact_k16_kernel(const float* __restrict__ W, int K, int D,
                                                                char* __restrict__ Wst, int n_stages,
                                                                const float* __restrict__ scale_max2,
-                                                               float* __restrict__ werr2) {
+                                                               float* __restrict__ werr2, char* __restrict__ Wst_lo = nullptr) {
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     const int lane = threadIdx.x & 63;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void prep_w_exact_k16_kernel(const float* __re
 #pragma unroll
     for (int ks = 0; ks < KS32; ++ks) {
         const int k0 = ks * 32 + (lane >> 4) * 8;
-        bf16x8 v;
+        bf16x8 v, vl;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float f = (u < K && k0 + j < D) ? W[u * D + k0 + j] * scale : 0.0f;
@@ -92,8 +94,11 @@ __global__ __launch_bounds__(256) void prep_w_exact_k16_kernel(const float* __re
             v[j] = hb;
             const float e = half_operand_error(-f, (float)hb);
             er = __builtin_fmaf(e, e, er);
+            const float r = ((-f) - (float)hb) * 2048.0f;     // (exact: a float32 difference of neighbours, a power of two)
+            vl[j] = cvt<E>(r == r && __builtin_fabsf(r) < 3.0e38f ? r : 0.0f);
         }
         *(bf16x8*)(Wst + stage * k16_stage_bytes(KS32) + ((long)(t16 * KS32 + ks) * 64 + lane) * 16) = v;
+        if (Wst_lo != nullptr) *(bf16x8*)(Wst_lo + stage * k16_stage_bytes(KS32) + ((long)(t16 * KS32 + ks) * 64 + lane) * 16) = vl;
     }
     er += __shfl_xor(er, 16, 64);                            // the unit's four feature quarters
     er += __shfl_xor(er, 32, 64);

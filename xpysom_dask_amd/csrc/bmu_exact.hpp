@@ -329,6 +329,163 @@ __global__ __launch_bounds__(1024) void exact_tiles_kernel(const int* __restrict
     if (tid == 1023) *n_tiles_out = tsums[1023];
 }
 
+// ---- REFINEMENT (resident sorted rows, input_len <= 128): the candidate (row, group) pairs once more on the half-precision
+// pipe, with BOTH operands' second halves -- x^ = hi + 2^-11 lo, -w^ = hi + 2^-11 lo (exact_gather_sorted_kernel,
+// prep_w_exact_k16_kernel) --:   V = [wq + (-wh).xh] + 2^-11 [(-wh).xl + (-wl).xh],   three MFMAs where the float32 re-score
+// spends sixteen times that.  What V misses of the real score is the product of the two FIRST-half rounding errors
+// (|dw| |dx|, both measured), the second halves' own rounding (2^-11 of them) and the accumulation of the first chain (the
+// screen's own charge): a window E2 some twenty times narrower than the screen's E (ex_refine_bound).  exact_refine_kernel leaves
+// every pair's group minimum of V (rmin, indexed like plist: the screen's spent minima) and the row's minimum over its
+// pairs (rowmin2); exact_select2_kernel keeps, in place, the pairs within E2 of that minimum.  On the smooth maps of a
+// schedule's middle a row has five candidate groups by the screen's window and one or two by this one: the float32
+// re-score, the exact mode's largest item there, shrinks accordingly.  The float32 winner survives: its V is within
+// E2 / 2 + (float32 share) / 2 of its real score, and so is the V that defines rowmin2.
+// Two-unit window of the refined values, in d' units (scales: the codebook's).
+__device__ __forceinline__ float ex_refine_bound(const ExactBound& eb, const ExactScales& s, float xsq, float xerr) {
+    const float xn = __builtin_sqrtf(xsq) * (1.0f + 1.0f / 1024.0f);
+    const float S = s.sx * s.sw;
+    // float32 kernel's share + accumulation of the first chain (as in E) + 2 x [ |dw| |dx| + 2^-10 (|w^| |dx| + |x^| |dw|)
+    // (the second halves' own rounding, subnormal second halves included: < 2^-25 an element) ] + the final additions
+    const float e = S * (eb.cA * xn * s.wm + eb.cW * s.wm * s.wm + eb.cB * s.bmag) +
+                    eb.cM * (xerr * s.we + 0x1p-10f * (xerr * s.sw * s.wm + (s.sx * xn + xerr) * s.we)) + 0x1p-21f * S * s.bmag +
+                    eb.cM * 0x1p-20f * (s.sw * s.wm + s.sx * xn);
+    const bool ok = e > 0.0f && e < 3.0e38f && !eb.unit;
+    return ok ? e : __builtin_inff();                        // (no bound: keep every pair)
+}
+
+// One tile (up to EX_TR rows of a group's list x the group's 64 units) per step, persistent workgroups over the tile table
+// as exact_rescore_mfma_kernel; the group's two stages (first and second halves) stay in LDS across its tiles.  Wave w takes
+// the tile's rows 32 w .. 32 w + 31 (two 16-row MFMA blocks): lane (quad, col) loads the row's 8-feature pieces of both
+// images, as the screen's B operand.
+template <int KS32, class EL>
+__global__ __launch_bounds__(256, 3) void exact_refine_kernel(const __bf16* __restrict__ Xh, const __bf16* __restrict__ Xl,
+                                                              const char* __restrict__ Wst, const char* __restrict__ Wst_lo,
+                                                              const int4* __restrict__ tile_tab, const int* __restrict__ n_tiles_dev,
+                                                              const int* __restrict__ plist, uint32_t* __restrict__ rmin,
+                                                              uint32_t* __restrict__ rowmin2) {
+    using E = typename EL::T;
+    using bf16x8 = typename V8<E>::t;
+    constexpr int DP = 32 * KS32;
+    constexpr int STAGE = k16_stage_bytes(KS32);
+    constexpr int FR = K16_T * KS32;                         // fragment pieces (1 KB) of a stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [first-half stage incl. its tail][second-half fragments]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int quad = lane >> 4, col = lane & 15;
+    const int n_tiles = *n_tiles_dev;
+    const int per = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t_begin = blockIdx.x * per, t_end = min(t_begin + per, n_tiles);
+    int g_have = -1;
+    for (int t = t_begin; t < t_end; ++t) {
+        const int4 tt = tile_tab[t];
+        const int g = tt.x;
+        if (g != g_have) {                                   // (uniform over the workgroup)
+            __builtin_amdgcn_s_barrier();                    // everyone is done with the previous group's stages
+            for (int p = wave; p < FR + 1; p += 4) lds_dma_16(Wst + (long)g * STAGE + (long)p * 1024 + lane * 16, smem + p * 1024);
+            for (int p = wave; p < FR; p += 4) lds_dma_16(Wst_lo + (long)g * STAGE + (long)p * 1024 + lane * 16, smem + STAGE + p * 1024);
+        }
+        int row[2];
+        bf16x8 xh[2][KS32], xl[2][KS32];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int i = wave * 32 + rb * 16 + col;
+            row[rb] = i < tt.z ? plist[tt.y + i] : -1;
+#pragma unroll
+            for (int ks = 0; ks < KS32; ++ks) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { xh[rb][ks][j] = (E)0.0f; xl[rb][ks][j] = (E)0.0f; }
+                if (row[rb] >= 0) {
+                    xh[rb][ks] = *(const bf16x8*)(Xh + (long)row[rb] * DP + ks * 32 + quad * 8);
+                    xl[rb][ks] = *(const bf16x8*)(Xl + (long)row[rb] * DP + ks * 32 + quad * 8);
+                }
+            }
+        }
+        if (g != g_have) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            g_have = g;
+        }
+        if (__ballot(row[0] >= 0 || row[1] >= 0) == 0ull) continue;   // (wave-uniform: this wave's 32 list entries are empty)
+        const float* wq = (const float*)(smem + FR * 1024);
+        uint32_t best[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};       // unsigned: positive floats order as their bits, NaN patterns are above
+#pragma unroll
+        for (int ut = 0; ut < K16_T; ++ut) {
+            const f32x4 wv = *(const f32x4*)(wq + ut * 16 + 4 * quad);
+            f32x4 ah[2] = {wv, wv}, al[2];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) al[rb][r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < KS32; ++ks) {
+                const bf16x8 wh = *(const bf16x8*)(smem + ((ut * KS32 + ks) * 64 + lane) * 16);
+                const bf16x8 wl = *(const bf16x8*)(smem + STAGE + ((ut * KS32 + ks) * 64 + lane) * 16);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    ah[rb] = mfma16(wh, xh[rb][ks], ah[rb]);
+                    al[rb] = mfma16(wh, xl[rb][ks], al[rb]);
+                    al[rb] = mfma16(wl, xh[rb][ks], al[rb]);
+                }
+            }
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) best[rb] = min(best[rb], __float_as_uint(__builtin_fmaf(al[rb][r], 0x1p-11f, ah[rb][r])));
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            uint32_t m = best[rb];
+            m = min(m, (uint32_t)__shfl_xor((int)m, 16, 64));
+            m = min(m, (uint32_t)__shfl_xor((int)m, 32, 64));
+            if (quad == 0 && row[rb] >= 0) {
+                rmin[tt.y + wave * 32 + rb * 16 + col] = m;
+                atomicMin(rowmin2 + row[rb], m);
+            }
+        }
+    }
+}
+
+// One workgroup per group: its list compacted IN PLACE to the pairs whose refined minimum is within E2 of the row's
+// (chunks of 256 entries in order: a chunk is read whole before the survivors are written, never beyond where it was read).
+__global__ __launch_bounds__(256) void exact_select2_kernel(int* __restrict__ plist, const uint32_t* __restrict__ rmin, long gm_stride,
+                                                            int* __restrict__ gcount, const uint32_t* __restrict__ rowmin2,
+                                                            const float* __restrict__ xsq, const float* __restrict__ xerr,
+                                                            const float* __restrict__ wmax2, const float* __restrict__ xmax2,
+                                                            const float* __restrict__ werr2, ExactBound eb, int* __restrict__ kept_total) {
+    __shared__ int wsum[4];
+    __shared__ int out_s;
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cnt = gcount[g];
+    if (cnt <= 0) return;
+    const ExactScales sc = ex_scales(xmax2, wmax2, werr2);
+    int* list = plist + (long)g * gm_stride;
+    const uint32_t* rm = rmin + (long)g * gm_stride;
+    if (tid == 0) out_s = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < cnt; c0 += 256) {
+        const int i = c0 + tid;
+        int row = -1;
+        bool keep = false;
+        if (i < cnt) {
+            row = list[i];
+            const float thr = __uint_as_float(rowmin2[row]) + ex_refine_bound(eb, sc, xsq[row], xerr[row]);
+            // (a threshold that is not a finite positive number -- no bound, a NaN minimum -- keeps the pair)
+            keep = !(thr > 0.0f && thr < 3.0e38f) || rm[i] <= __float_as_uint(thr);
+        }
+        const unsigned long long mk = __ballot(keep);
+        if (lane == 0) wsum[wave] = __popcll(mk);
+        __syncthreads();                                     // (every entry of the chunk is in registers)
+        int before = out_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (keep) list[before + __popcll(mk & ((1ull << lane) - 1ull))] = row;
+        __syncthreads();
+        if (tid == 0) out_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (tid == 0) { gcount[g] = out_s; atomicAdd(kept_total, out_s); }
+}
+
 // The float32 scores of one tile -- up to EX_TR rows of a group's list against the group's 64 units -- on
 // v_mfma_f32_32x32x2_f32, exactly as bmu_f32_res_kernel<SCORE_EUCLID_PART> forms them (same stage image, same k order,
 // same epilogue, same first-minimum rule); a row's best (value, unit) over its groups merges through the same

@@ -94,21 +94,39 @@ __global__ __launch_bounds__(256) void exact_lastpos_kernel(const int* __restric
 }
 
 // The pass in sorted order: image rows (DP halves), the float32 rows themselves (what the re-score reads: a candidate
-// group's rows are then neighbours in memory), |x|^2, rounding error.  Positions behind the pass's rows (up to the tile
-// multiple) get zero rows and NaN norms (they keep nothing, need nothing).  One workgroup per 4 rows.
+// group's rows are then neighbours in memory), |x|^2, rounding error -- and the rows' SECOND half image for the refinement
+// pass (bmu_exact.hpp): lo = half(2^11 (x^ - hi)), x^ = sx x.  Positions behind the pass's rows (up to the tile multiple) get
+// zero rows and NaN norms (they keep nothing, need nothing).  One wave per row.
+template <class EL>
 __global__ __launch_bounds__(256) void exact_gather_sorted_kernel(const int* __restrict__ order, long n, long np, int dp, int D,
                                                                   const __bf16* __restrict__ Xb, const float* __restrict__ X,
                                                                   const float* __restrict__ xsq, const float* __restrict__ xerr,
-                                                                  __bf16* __restrict__ Xb_s, float* __restrict__ Xf_s,
+                                                                  const float* __restrict__ xmax2,
+                                                                  __bf16* __restrict__ Xb_s, __bf16* __restrict__ Xl_s,
+                                                                  float* __restrict__ Xf_s,
                                                                   float* __restrict__ xsq_s, float* __restrict__ xerr_s) {
+    using E = typename EL::T;
+    using bf16x8 = typename V8<E>::t;
     const int lane = threadIdx.x & 63;
     const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= np) return;
     const long r = p < n ? (long)order[p] : -1;
-    for (int c = lane; c < dp / 8; c += 64) {                 // 16-byte pieces of the half image
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (r >= 0) v = *(const u32x4*)((const char*)Xb + (r * dp + c * 8) * 2);
-        *(u32x4*)((char*)Xb_s + (p * dp + c * 8) * 2) = v;
+    const float sx = ex_scale(*xmax2);
+    for (int c = lane; c < dp / 8; c += 64) {                 // 16-byte pieces of the half images
+        bf16x8 v, vl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = (E)0.0f; vl[j] = (E)0.0f; }
+        if (r >= 0) {
+            v = *(const bf16x8*)((const char*)Xb + (r * dp + c * 8) * 2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = c * 8 + j < D ? X[r * D + c * 8 + j] * sx : 0.0f;
+                const float d = (f - (float)v[j]) * 2048.0f;
+                vl[j] = cvt<E>(d == d && __builtin_fabsf(d) < 3.0e38f ? d : 0.0f);
+            }
+        }
+        *(bf16x8*)((char*)Xb_s + (p * dp + c * 8) * 2) = v;
+        *(bf16x8*)((char*)Xl_s + (p * dp + c * 8) * 2) = vl;
     }
     if (p < n) {
         if ((D & 3) == 0)
