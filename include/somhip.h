@@ -242,6 +242,10 @@ int som_exact_skip_stats(som_handle* h, int64_t* blocks_run, int64_t* blocks_tot
 /* ... and the resident sorted pass behind it: epochs that ran under a plan, and how many of them (re-)sorted the rows by
  * their last BMU's patch first (the others reused the order of an earlier epoch) */
 int som_exact_resident_stats(som_handle* h, int64_t* planned_epochs, int64_t* sorts);
+/* ... and the refinement pass between the screen and the float32 re-score (csrc/bmu_exact.hpp: both operands' second
+ * half-precision halves, a window some twenty times narrower than the screen's): candidate (row, group) pairs it was
+ * given, and how many of them it left for the re-score */
+int som_exact_refine_stats(som_handle* h, int64_t* pairs_in, int64_t* pairs_out);
 /* candidate groups per row of the LAST screen pass (its first n rows): how many 64-unit groups the re-score visited */
 int som_exact_last_counts(som_handle* h, int32_t* counts_out, int64_t n);
 

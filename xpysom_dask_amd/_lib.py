@@ -76,6 +76,7 @@ SIGNATURES = {
     "som_exact_stats": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "som_exact_skip_stats": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "som_exact_resident_stats": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "som_exact_refine_stats": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "som_exact_last_counts": (C.c_int, [_H, _I, C.c_int64]),
     "som_sync": (C.c_int, [_H]),
     "som_profile_enable": (C.c_int, [_H, C.c_int32]),

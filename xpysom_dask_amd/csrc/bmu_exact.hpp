@@ -293,7 +293,8 @@ __global__ __launch_bounds__(1024) void exact_tiles_kernel(const int* __restrict
                                                            long capacity, int4* __restrict__ tile_tab,
                                                            int* __restrict__ n_tiles_out, int* __restrict__ overflow,
                                                            const int* __restrict__ gstart = nullptr,
-                                                           int* __restrict__ gstart_out = nullptr) {
+                                                           int* __restrict__ gstart_out = nullptr,
+                                                           int* __restrict__ pairs_out = nullptr) {
     __shared__ long sums[1024];
     __shared__ int tsums[1024];
     const int tid = threadIdx.x;
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(1024) void exact_tiles_kernel(const int* __restrict
         sums[tid] += a; tsums[tid] += c;
         __syncthreads();
     }
+    if (tid == 0 && pairs_out != nullptr) *pairs_out = (int)min(sums[1023], 0x7fffffffL);
     if (sums[1023] > capacity) {
         if (tid == 0) { *overflow = 1; *n_tiles_out = 0; }
         return;
@@ -374,7 +376,11 @@ __global__ __launch_bounds__(256, 3) void exact_refine_kernel(const __bf16* __re
     const int quad = lane >> 4, col = lane & 15;
     const int n_tiles = *n_tiles_dev;
     const int per = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int t_begin = blockIdx.x * per, t_end = min(t_begin + per, n_tiles);
+    // (workgroups go to the XCDs round robin: consecutive runs of tiles -- neighbouring groups, whose candidate rows are
+    //  largely the same -- to workgroups of ONE XCD, so that a row read for one group is in that L2 for the next)
+    const int nx = (int)gridDim.x / 8;
+    const int run = ((int)gridDim.x % 8 == 0) ? ((int)blockIdx.x % 8) * nx + (int)blockIdx.x / 8 : (int)blockIdx.x;
+    const int t_begin = run * per, t_end = min(t_begin + per, n_tiles);
     int g_have = -1;
     for (int t = t_begin; t < t_end; ++t) {
         const int4 tt = tile_tab[t];

@@ -112,27 +112,35 @@ __global__ __launch_bounds__(256) void exact_gather_sorted_kernel(const int* __r
     if (p >= np) return;
     const long r = p < n ? (long)order[p] : -1;
     const float sx = ex_scale(*xmax2);
-    for (int c = lane; c < dp / 8; c += 64) {                 // 16-byte pieces of the half images
+    const bool vec = (D & 7) == 0;
+    for (int c = lane; c < dp / 8; c += 64) {                 // 16-byte pieces of the half images = 8 features
         bf16x8 v, vl;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { v[j] = (E)0.0f; vl[j] = (E)0.0f; }
         if (r >= 0) {
             v = *(const bf16x8*)((const char*)Xb + (r * dp + c * 8) * 2);
+            float f[8];
+            if (vec && c * 8 < D) {                           // (one read of the float32 row: its copy and its second half)
+                const f32x4 a = *(const f32x4*)(X + r * D + c * 8), b = *(const f32x4*)(X + r * D + c * 8 + 4);
+                *(f32x4*)(Xf_s + p * D + c * 8) = a;
+                *(f32x4*)(Xf_s + p * D + c * 8 + 4) = b;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[4 + j] = b[j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    f[j] = c * 8 + j < D ? X[r * D + c * 8 + j] : 0.0f;
+                    if (c * 8 + j < D) Xf_s[p * D + c * 8 + j] = f[j];
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float f = c * 8 + j < D ? X[r * D + c * 8 + j] * sx : 0.0f;
-                const float d = (f - (float)v[j]) * 2048.0f;
+                const float d = (f[j] * sx - (float)v[j]) * 2048.0f;
                 vl[j] = cvt<E>(d == d && __builtin_fabsf(d) < 3.0e38f ? d : 0.0f);
             }
         }
         *(bf16x8*)((char*)Xb_s + (p * dp + c * 8) * 2) = v;
         *(bf16x8*)((char*)Xl_s + (p * dp + c * 8) * 2) = vl;
-    }
-    if (p < n) {
-        if ((D & 3) == 0)
-            for (int c = lane; c < D / 4; c += 64) *(f32x4*)(Xf_s + p * D + 4 * c) = *(const f32x4*)(X + r * D + 4 * c);
-        else
-            for (int c = lane; c < D; c += 64) Xf_s[p * D + c] = X[r * D + c];
     }
     if (lane == 0) {
         const float nanv = __builtin_nanf("");

@@ -133,6 +133,11 @@ struct som_handle {
         int *order = nullptr, *sk_keys = nullptr, *sk_keys2 = nullptr, *sk_vals = nullptr;
         void* sk_tmp = nullptr; size_t sk_tmp_bytes = 0;
         __bf16* Xb_s = nullptr;
+        __bf16* Xl_s = nullptr;           // ... and the rows' second half image (the refinement pass)
+        bool refine_on = true;            // SOM_EXACT_REFINE=0: no refinement pass (A/B)
+        bool refine_live = false;
+        double pairs_per_row_last = 0.0;  // candidate (row, group) pairs per row of the last planned epoch
+        int64_t pairs_refined_in = 0, pairs_refined_out = 0;   // som_exact_refine_stats
         float *Xf_s = nullptr, *xsq_s = nullptr, *xerr_s = nullptr, *seed_s = nullptr, *sU_s = nullptr;
         int* lastpos_s = nullptr;         // position (patch order) of every sorted row's last BMU
         // level 2 of the plan runs where it pays (l2_pays: measured whenever it runs), is probed again after l2_wait epochs or
@@ -166,6 +171,7 @@ struct som_handle {
     float *W = nullptr, *wsq = nullptr, *SC = nullptr, *T = nullptr, *ACC = nullptr, *P1 = nullptr, *P2 = nullptr;
     float* Ud = nullptr;     // the count column after stage 1 of the transform, dense [nt][X][Y]
     char* Wst = nullptr;
+    char* Wst_lo = nullptr;  // exact mode, input_len <= 128: the units' second half image (the refinement pass, bmu_exact.hpp)
     char* Wfst = nullptr;    // f32 parity mode, input_len <= 128: float32 stage image (bmu_f32_res.hpp)
     int fr_kg = 0, fr_stages = 0;
     char* Wfimg = nullptr;   // f32 parity mode, input_len > 128: float32 tile image (bmu_f32_tiled.hpp)
@@ -454,10 +460,10 @@ int prep_codebook_half(som_handle* h) {
         exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(h->K, 1024)), dim3(1024), 0, h->stream>>>(qex, h->K, h->wn, h->wmax2);
         const dim3 tgrid((unsigned)cdiv((long)h->n_stages * K16_T, 4));
         switch (h->ks32) {
-        case 1: prep_w_exact_k16_kernel<1, E><<<tgrid, block, 0, h->stream>>>(Wex, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1); break;
-        case 2: prep_w_exact_k16_kernel<2, E><<<tgrid, block, 0, h->stream>>>(Wex, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1); break;
-        case 3: prep_w_exact_k16_kernel<3, E><<<tgrid, block, 0, h->stream>>>(Wex, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1); break;
-        case 4: prep_w_exact_k16_kernel<4, E><<<tgrid, block, 0, h->stream>>>(Wex, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1); break;
+        case 1: prep_w_exact_k16_kernel<1, E><<<tgrid, block, 0, h->stream>>>(Wex, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1, h->Wst_lo); break;
+        case 2: prep_w_exact_k16_kernel<2, E><<<tgrid, block, 0, h->stream>>>(Wex, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1, h->Wst_lo); break;
+        case 3: prep_w_exact_k16_kernel<3, E><<<tgrid, block, 0, h->stream>>>(Wex, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1, h->Wst_lo); break;
+        case 4: prep_w_exact_k16_kernel<4, E><<<tgrid, block, 0, h->stream>>>(Wex, h->K, h->D, h->Wst, h->n_stages, h->wmax2, h->wmax2 + 1, h->Wst_lo); break;
         default: return fail(h, "the resident half-precision kernel supports input_len <= 128");
         }
         return 0;
@@ -1010,7 +1016,7 @@ int exact_reserve_stride(som_handle* h, long stride) {
     if (int rc = dev_alloc(h, &ex.tile_tab, (size_t)ex.max_tiles)) return rc;
     if (!ex.ctr) {
         if (int rc = dev_alloc(h, &ex.ctr, (size_t)3 * n_groups + 8)) return rc;
-        HIPCHK(h, hipHostMalloc((void**)&ex.fb_count_host, 8 * sizeof(int), hipHostMallocDefault));   // fb_count | n_tiles | overflow | 16-unit blocks run | groups run
+        HIPCHK(h, hipHostMalloc((void**)&ex.fb_count_host, 8 * sizeof(int), hipHostMallocDefault));   // fb_count | n_tiles | overflow | 16-unit blocks run | groups run | pairs selected | pairs kept by the refinement
     }
     ex.stride = stride;
     return 0;
@@ -1156,12 +1162,13 @@ int exact_skip_reserve(som_handle* h, long rows_all, long stride) {
     }
     const long need_rows = round_up(rows_all, SK_TILE);
     if (need_rows > ex.sk_rows) {
-        void* old[] = {ex.order, ex.Xb_s, ex.Xf_s, ex.xsq_s, ex.xerr_s, ex.seed_s, ex.sU_s, ex.lastpos_s};
+        void* old[] = {ex.order, ex.Xb_s, ex.Xl_s, ex.Xf_s, ex.xsq_s, ex.xerr_s, ex.seed_s, ex.sU_s, ex.lastpos_s};
         for (void* p : old) if (p) (void)hipFree(p);
-        ex.order = nullptr; ex.Xb_s = nullptr; ex.Xf_s = ex.xsq_s = ex.xerr_s = ex.seed_s = ex.sU_s = nullptr; ex.lastpos_s = nullptr;
+        ex.order = nullptr; ex.Xb_s = nullptr; ex.Xl_s = nullptr; ex.Xf_s = ex.xsq_s = ex.xerr_s = ex.seed_s = ex.sU_s = nullptr; ex.lastpos_s = nullptr;
         ex.sk_rows = 0; ex.res_valid = false;
         if (int rc = dev_alloc(h, &ex.order, (size_t)need_rows)) return rc;
         if (int rc = dev_alloc(h, &ex.Xb_s, (size_t)need_rows * h->dp)) return rc;
+        if (int rc = dev_alloc(h, &ex.Xl_s, (size_t)need_rows * h->dp)) return rc;
         if (int rc = dev_alloc(h, &ex.Xf_s, (size_t)need_rows * h->D)) return rc;
         if (int rc = dev_alloc(h, &ex.xsq_s, (size_t)need_rows)) return rc;
         if (int rc = dev_alloc(h, &ex.xerr_s, (size_t)need_rows)) return rc;
@@ -1226,7 +1233,9 @@ int exact_skip_centroids(som_handle* h, const float* xmax2) {
 }
 
 // (re-)sort one pass: the rows [r0, r0 + n) in the order of their last BMU's group, the operands gathered in that order
-int exact_skip_sort(som_handle* h, const float* X, const __bf16* Xb, long r0, long n, const float* xsq, const float* xerr, const int* prev) {
+template <class E>
+int exact_skip_sort(som_handle* h, const float* X, const __bf16* Xb, long r0, long n, const float* xsq, const float* xerr, const int* prev,
+                    const float* xmax2) {
     auto& ex = h->ex;
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
     const long np = round_up(n, SK_TILE);
@@ -1235,8 +1244,9 @@ int exact_skip_sort(som_handle* h, const float* X, const __bf16* Xb, long r0, lo
     while ((1L << bits) < n_groups) ++bits;
     size_t bytes = ex.sk_tmp_bytes;
     HIPCHK(h, sort_bmu_pairs(n, ex.sk_tmp, bytes, ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.order + r0, (size_t)n, 0u, (unsigned)bits, h->stream));
-    exact_gather_sorted_kernel<<<dim3((unsigned)cdiv(np, 4)), dim3(256), 0, h->stream>>>(
-        ex.order + r0, n, np, h->dp, h->D, Xb, X, xsq, xerr, ex.Xb_s + r0 * h->dp, ex.Xf_s + r0 * h->D, ex.xsq_s + r0, ex.xerr_s + r0);
+    exact_gather_sorted_kernel<E><<<dim3((unsigned)cdiv(np, 4)), dim3(256), 0, h->stream>>>(
+        ex.order + r0, n, np, h->dp, h->D, Xb, X, xsq, xerr, xmax2, ex.Xb_s + r0 * h->dp, ex.Xl_s + r0 * h->dp, ex.Xf_s + r0 * h->D,
+        ex.xsq_s + r0, ex.xerr_s + r0);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -1301,6 +1311,39 @@ int exact_rescore_kg(som_handle* h, const float* X, int n_groups) {
     return 0;
 }
 
+// the refinement pass over a sorted pass's candidate pairs (bmu_exact.hpp): tiles -> refined minima -> lists compacted in place
+template <int KS32, class E>
+int exact_refine_ks(som_handle* h, long r0, long n, const float* xmax2, const ExactBound& eb) {
+    auto& ex = h->ex;
+    const int n_groups = (int)cdiv(h->K, EX_GROUP);
+    int* gcount = ex.ctr; int* fb_count = ex.ctr + 2 * n_groups;
+    int* n_tiles = fb_count + 1; int* overflow = fb_count + 2;
+    exact_tiles_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(gcount, n_groups, ex.stride, ex.stride * ex.pairs, ex.tile_tab, n_tiles,
+                                                             overflow, nullptr, nullptr, fb_count + 5);
+    uint32_t* rowmin2 = (uint32_t*)ex.rowarg;              // (round 1's scratch: unused in the one-round scheme)
+    HIPCHK(h, hipMemsetAsync(rowmin2, 0xFF, (size_t)n * sizeof(uint32_t), h->stream));
+    const size_t lds = (size_t)k16_stage_bytes(KS32) + (size_t)K16_T * KS32 * 1024;
+    int per_cu = 1;
+    if (int rc = kernel_per_cu(h, (const void*)exact_refine_kernel<KS32, E>, 256, lds, &per_cu)) return rc;
+    const long grid = std::min<long>(ex.max_tiles, 2L * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
+    exact_refine_kernel<KS32, E><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(
+        ex.Xb_s + r0 * h->dp, ex.Xl_s + r0 * h->dp, h->Wst, h->Wst_lo, ex.tile_tab, n_tiles, ex.plist, ex.gmin, rowmin2);
+    exact_select2_kernel<<<dim3((unsigned)n_groups), dim3(256), 0, h->stream>>>(
+        ex.plist, ex.gmin, ex.stride, gcount, rowmin2, ex.xsq_s + r0, ex.xerr_s + r0, h->wmax2, xmax2, h->wmax2 + 1, eb, fb_count + 6);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+template <class E>
+int exact_refine(som_handle* h, long r0, long n, const float* xmax2, const ExactBound& eb) {
+    switch (h->ks32) {
+    case 1: return exact_refine_ks<1, E>(h, r0, n, xmax2, eb);
+    case 2: return exact_refine_ks<2, E>(h, r0, n, xmax2, eb);
+    case 3: return exact_refine_ks<3, E>(h, r0, n, xmax2, eb);
+    case 4: return exact_refine_ks<4, E>(h, r0, n, xmax2, eb);
+    }
+    return fail(h, "exact: the refinement pass supports input_len <= 128");
+}
+
 // the lists' entries from gstart on -> tiles -> float32 scores merged into best64 (the pass's slice of the merge keys)
 int exact_rescore_round(som_handle* h, const float* X, const float* xsq, unsigned long long* best64, const int* gstart,
                         int* gstart_out) {
@@ -1308,8 +1351,10 @@ int exact_rescore_round(som_handle* h, const float* X, const float* xsq, unsigne
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
     int* gcount = ex.ctr; int* fb_count = ex.ctr + 2 * n_groups;
     int* n_tiles = fb_count + 1; int* overflow = fb_count + 2;
+    // (the pairs the select kernel found go back with the pass's counters -- unless the refinement pass has counted them already)
     exact_tiles_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(gcount, n_groups, ex.stride, ex.stride * ex.pairs, ex.tile_tab, n_tiles,
-                                                             overflow, gstart, gstart_out);
+                                                             overflow, gstart, gstart_out,
+                                                             (gstart == nullptr && gstart_out == nullptr && !ex.refine_live) ? fb_count + 5 : nullptr);
     unsigned long long* saved = h->best64;
     h->best64 = best64;                                   // (exact_rescore_kg reads it from the handle)
     int rc = 0;
@@ -1403,12 +1448,16 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
                      2 * (size_t)h->stage_bytes + 4 * (size_t)cdiv(n_groups, K16_STAGE_UNITS) * (sizeof(int) + 8) <= 150 * 1024;   // (its stage list lives in LDS)
         if (int rc = SOM_HALF(h, exact_skip_centroids, h, xmax2)) return rc;
     }
-    int64_t groups_run = 0;
+    // the refinement pass (bmu_exact.hpp) where it pays: it costs about a third of the float32 re-score of the pairs it is
+    // given (it is bound by the same gather of rows) and leaves one to one and a half pairs a row, at two small launches more:
+    // worth it from three candidate pairs a row on (the last planned epoch's count) -- the smooth maps of a schedule's middle
+    ex.refine_live = ex.skip_live && ex.refine_on && h->Wst_lo != nullptr && (ex.pairs_per_row_last >= 3.0 || ex.skip_mode >= 2);
+    int64_t groups_run = 0, pairs_in = 0, pairs_out = 0;
     for (long r0 = 0; r0 < N; r0 += chunk) {
         const long n = std::min(chunk, N - r0);
         // (a pass behind one whose fallback rows went through the float32 kernel: its image back in patch order)
         if (h->wf_patch != h->ex_patch) if (int rc = refresh_codebook_operands(h, true, true)) return rc;
-        HIPCHK(h, hipMemsetAsync(ex.ctr, 0, (size_t)(2 * n_groups + 5) * sizeof(int), h->stream));
+        HIPCHK(h, hipMemsetAsync(ex.ctr, 0, (size_t)(2 * n_groups + 7) * sizeof(int), h->stream));
         // resident rows from their second epoch on: last epoch's BMU of every row caps the screen's keep threshold -- under a
         // plan the plan's prologue forms that seed from the operands it holds (exact_skip.hpp), else exact_seed_kernel
         ex.seed_live = ex.seed_on && !h->wide && out == h->bmu && h->bmu_valid;
@@ -1422,7 +1471,7 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         const int* p_order = nullptr;
         if (ex.skip_live) {
             if (resort)
-                if (int rc = exact_skip_sort(h, X + r0 * h->D, Xb + r0 * h->dp, r0, n, xsq + r0, xerr + r0, out + r0)) return rc;
+                if (int rc = SOM_HALF(h, exact_skip_sort, h, X + r0 * h->D, Xb + r0 * h->dp, r0, n, xsq + r0, xerr + r0, out + r0, xmax2)) return rc;
             if (int rc = SOM_HALF(h, exact_skip_plan, h, r0, n, out + r0, xmax2, eb)) return rc;
             p_xsq = ex.xsq_s + r0; p_xerr = ex.xerr_s + r0; p_seed = ex.seed_s + r0; p_Xb = ex.Xb_s + r0 * h->dp; p_order = ex.order + r0;
             p_X = ex.Xf_s + r0 * h->D;
@@ -1452,13 +1501,15 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
             exact_select_kernel<false><<<sel_grid, sel_block, 0, h->stream>>>(
                 ex.gmin, ex.gflags, ex.stride, n_groups, n, best, p_xsq, h->wmax2, xmax2, eb, p_xerr, h->wmax2 + 1, ex.plist,
                 ex.ctr, ex.rowcnt, nullptr, p_seed, ex.skip_live ? ex.glist : nullptr, ex.skip_live ? ex.gcnt : nullptr, SK_TILE);
+            if (ex.refine_live)
+                if (int rc = SOM_HALF(h, exact_refine, h, r0, n, xmax2, eb)) return rc;
             if (int rc = exact_rescore_round(h, p_X, xsq + r0, best, nullptr, nullptr)) return rc;
         }
         exact_finalize_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(
             best, n, h->K, ex.ctr + 2 * n_groups + 2, out + r0, ex.fb_list, ex.ctr + 2 * n_groups, p_order);
         HIPCHK(h, hipGetLastError());
         // rows the scheme could not settle (normally none): the float32 kernel itself
-        HIPCHK(h, hipMemcpyAsync(ex.fb_count_host, ex.ctr + 2 * n_groups, 5 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(ex.fb_count_host, ex.ctr + 2 * n_groups, 7 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         if (h->early.armed && !h->early.done && out == h->bmu && r0 + n >= N) {
             // the last pass of a resident epoch: the host waits for the counter only (an event behind the copy); what the
             // update needs besides the BMUs is queued behind it and runs while the host wakes up
@@ -1477,6 +1528,8 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         ex.blocks_total += cdiv(n, SK_TILE) * n_groups * K16_T;
         ex.blocks_run += ex.skip_live ? ex.fb_count_host[3] : cdiv(n, SK_TILE) * n_groups * K16_T;
         groups_run += ex.skip_live ? ex.fb_count_host[4] : cdiv(n, SK_TILE) * n_groups;
+        pairs_in += ex.fb_count_host[5];
+        if (ex.refine_live) pairs_out += ex.fb_count_host[6];
         if (n_fb < 0 || n_fb > n) return fail(h, "exact: fallback counter out of range");
         if (n_fb > 0) {
             if (n_fb > ex.fb_cap) {
@@ -1515,6 +1568,8 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         ex.res_since += 1;
         ex.res_share_last = share;
         ex.l1_share_last = (double)groups_run * K16_T / (double)(ex.blocks_total - total_before);
+        ex.pairs_per_row_last = (double)pairs_in / (double)std::max<long>(N, 1);
+        if (ex.refine_live) { ex.pairs_refined_in += pairs_in; ex.pairs_refined_out += pairs_out; }
         if (ex.l2_live) {
             ex.l2_pays = 1.5 * (ex.l1_share_last - share) > 0.1 * ex.l1_share_last + 0.006;
             ex.l1_share_probe = ex.l1_share_last;
@@ -2073,6 +2128,7 @@ int som_create(const som_config* cfg, som_handle** out) {
         if (const char* e = dev_env("SOM_EXACT_SEED")) h->ex.seed_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("SOM_EXACT_SKIP")) h->ex.skip_mode = std::atoi(e);
         if (const char* e = dev_env("SOM_EXACT_SUBBLOCKS")) h->ex.sub_blocks = std::atoi(e) != 0;
+        if (const char* e = dev_env("SOM_EXACT_REFINE")) h->ex.refine_on = std::atoi(e) != 0;
         if (const char* e = dev_env("SOM_EXACT_RESORT")) h->ex.res_every = std::max(0, std::atoi(e));
         if (const char* e = dev_env("SOM_ASYNC_COPIES")) h->async_copies = std::atoi(e) != 0;
         if (const char* e = dev_env("SOM_FUSE_MERGE")) h->fuse_merge_prep = std::atoi(e) != 0;
@@ -2106,6 +2162,10 @@ int som_create(const som_config* cfg, som_handle** out) {
         size_t bytes = (size_t)h->n_stages * h->stage_bytes;
         if (h->tiled && !h->wide) bytes = (size_t)h->n_ublocks * h->n_kchunks * h->tl_wtile;
         if ((rc = dev_alloc(h, &h->Wst, bytes))) return bail(rc);
+        if (h->exact && !h->tiled) {
+            if ((rc = dev_alloc(h, &h->Wst_lo, bytes))) return bail(rc);
+            if (hipMemsetAsync(h->Wst_lo, 0, bytes, h->stream) != hipSuccess) return bail(fail(h, "hipMemsetAsync failed"));
+        }
         if ((rc = dev_alloc(h, &h->xmax2, 2))) return bail(rc);
         if ((rc = dev_alloc(h, &h->wn, (size_t)h->K))) return bail(rc);
         if ((rc = dev_alloc(h, &h->wmax2, 2))) return bail(rc);
@@ -2131,7 +2191,7 @@ void som_destroy(som_handle* h) {
     for (auto& ep : h->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     void* bufs[] = {h->Ud, h->W, h->wsq, h->SC, h->T, h->ACC, h->P1, h->P2, h->Wst, h->X_owned, h->bmu, h->xsq, h->Xb,
                     h->xmax2, h->wn, h->wmax2, h->qX, h->qbmu, h->qbmu2, h->qxsq, h->qXb, h->dsum,
-                    h->best64, h->Wfst, h->Wfimg, h->ftX, h->qX64, h->Wp, h->wsq_p, h->ex_perm, h->ex_inv};
+                    h->best64, h->Wfst, h->Wfimg, h->ftX, h->qX64, h->Wp, h->wsq_p, h->ex_perm, h->ex_inv, h->Wst_lo};
     for (void* b : bufs) if (b) (void)hipFree(b);
     seg_free(h->seg);
     seg_free(h->st_seg);
@@ -2141,7 +2201,7 @@ void som_destroy(som_handle* h) {
     }
     {
         void* eb[] = {h->ex.gmin, h->ex.gflags, h->ex.rowcnt, h->ex.rowarg, h->ex.seed, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab,
-                      h->ex.order, h->ex.sk_keys, h->ex.sk_keys2, h->ex.sk_vals, h->ex.sk_tmp, h->ex.Xb_s, h->ex.Xf_s, h->ex.xsq_s, h->ex.xerr_s,
+                      h->ex.order, h->ex.sk_keys, h->ex.sk_keys2, h->ex.sk_vals, h->ex.sk_tmp, h->ex.Xb_s, h->ex.Xl_s, h->ex.Xf_s, h->ex.xsq_s, h->ex.xerr_s,
                       h->ex.seed_s, h->ex.sU_s, h->ex.lastpos_s, h->ex.need, h->ex.need2, h->ex.glist, h->ex.gcnt, h->ex.tile_counts, h->ex.tlist, h->ex.tcnt};
         for (void* b : eb) if (b) (void)hipFree(b);
         for (auto& c : h->ex.cen) {
@@ -2911,6 +2971,12 @@ int som_exact_skip_stats(som_handle* h, int64_t* blocks_run, int64_t* blocks_tot
 int som_exact_resident_stats(som_handle* h, int64_t* planned_epochs, int64_t* sorts) {
     if (!h || !planned_epochs || !sorts) return 1;
     *planned_epochs = h->ex.planned; *sorts = h->ex.resorts;
+    return 0;
+}
+
+int som_exact_refine_stats(som_handle* h, int64_t* pairs_in, int64_t* pairs_out) {
+    if (!h || !pairs_in || !pairs_out) return 1;
+    *pairs_in = h->ex.pairs_refined_in; *pairs_out = h->ex.pairs_refined_out;
     return 0;
 }
 

@@ -309,6 +309,12 @@ class HipEngine:
         self._check(self._lib.som_exact_resident_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def exact_refine_stats(self):
+        """precision 'exact': (candidate pairs handed to the refinement pass, pairs it left for the float32 re-score)."""
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self._lib.som_exact_refine_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def exact_last_counts(self, n):
         """precision 'exact': candidate groups per row in the last screen pass (first n rows)."""
         out = np.empty((int(n),), dtype=np.int32)
