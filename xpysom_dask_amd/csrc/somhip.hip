@@ -5,7 +5,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include <dlfcn.h>
 
@@ -1115,26 +1114,28 @@ int exact_screen_ks(som_handle* h, const __bf16* Xb, long n, unsigned long long*
 }
 
 
-// BMU ids are <= 20-bit keys in 4-byte ints: rocPRIM's default picks its merge sort up to 1 Mi items for
-// 4-byte keys (ten merge passes at 1 Mi rows: 0.16 ms); two 8-bit Onesweep passes take half of that, but lose
-// to the merge sort at 100 k rows -- so Onesweep from SORT_ONESWEEP_ROWS rows on.
-using SortOnesweep = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 1024>;
-constexpr long SORT_ONESWEEP_ROWS = 262144;
-
-template <typename... Args>
-hipError_t sort_bmu_pairs(long n, Args... args) {
-    if (n >= SORT_ONESWEEP_ROWS) return rocprim::radix_sort_pairs<SortOnesweep>(args...);
-    return rocprim::radix_sort_pairs(args...);
-}
-// temporary storage that serves both algorithms for up to n rows
-template <typename K, typename V>
-hipError_t sort_bmu_pairs_storage(size_t& bytes, K* kin, K* kout, V* vin, V* vout, long n, unsigned bits, hipStream_t st) {
-    size_t b1 = 0, b2 = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, b1, kin, kout, vin, vout, (size_t)n, 0u, bits, st);
-    if (e != hipSuccess) return e;
-    e = rocprim::radix_sort_pairs<SortOnesweep>(nullptr, b2, kin, kout, vin, vout, (size_t)n, 0u, bits, st);
-    bytes = b1 > b2 ? b1 : b2;
-    return e;
+// The stable radix sort of update.hpp: (keys_in, row index) -> (keys_out, vals_out), `bits` key bits, 8 a pass.  scratch: two
+// pairs of n ints + the 256 x blocks table (radix_scratch_ints).  keys_in is left intact.
+inline size_t radix_scratch_ints(long n) { return 4 * (size_t)n + 256 * (size_t)cdiv(std::max<long>(n, 1), RS_BLOCK) + 256; }
+int radix_sort_rows(som_handle* h, const int* keys_in, long n, int bits, int* keys_out, int* vals_out, int* scratch) {
+    if (n <= 0) return 0;
+    const int B = (int)cdiv(n, RS_BLOCK);
+    int* ka = scratch; int* va = scratch + n; int* kb = scratch + 2 * n; int* vb = scratch + 3 * n;
+    int* table = scratch + 4 * n;
+    int* tot = table + 256L * B;
+    const int passes = std::max(1, (int)cdiv(bits, 8));
+    const int* kin = keys_in; const int* vin = nullptr;
+    for (int p = 0; p < passes; ++p) {
+        const bool last = p == passes - 1;
+        int* ko = last ? keys_out : (p & 1) ? kb : ka;
+        int* vo = last ? vals_out : (p & 1) ? vb : va;
+        rs_hist_kernel<<<dim3((unsigned)B), dim3(256), 0, h->stream>>>(kin, n, 8 * p, B, table);
+        rs_scan_kernel<<<dim3(64), dim3(256), 0, h->stream>>>(table, B, tot);
+        rs_scatter_kernel<<<dim3((unsigned)B), dim3(256), 0, h->stream>>>(kin, vin, n, 8 * p, B, table, tot, ko, vo);
+        kin = ko; vin = vo;
+    }
+    HIPCHK(h, hipGetLastError());
+    return 0;
 }
 
 // ---- block skipping (exact_skip.hpp): buffers, the centroid images, the resident sorted pass, a pass's plan ------------------
@@ -1193,11 +1194,9 @@ int exact_skip_reserve(som_handle* h, long rows_all, long stride) {
     if (int rc = dev_alloc(h, &ex.tile_counts, (size_t)tiles)) return rc;
     if (int rc = dev_alloc(h, &ex.tlist, (size_t)tiles * n_groups * K16_T)) return rc;
     if (int rc = dev_alloc(h, &ex.tcnt, (size_t)tiles)) return rc;
-    size_t bytes = 0;
-    HIPCHK(h, sort_bmu_pairs_storage(bytes, ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.order, stride, 32u, h->stream));
-    char* tmp = nullptr;
-    if (int rc = dev_alloc(h, &tmp, bytes + 256)) return rc;
-    ex.sk_tmp = tmp; ex.sk_tmp_bytes = bytes;
+    int* tmp = nullptr;
+    if (int rc = dev_alloc(h, &tmp, radix_scratch_ints(stride))) return rc;
+    ex.sk_tmp = tmp; ex.sk_tmp_bytes = radix_scratch_ints(stride) * sizeof(int);
     ex.sk_stride = stride;
     return 0;
 }
@@ -1242,8 +1241,7 @@ int exact_skip_sort(som_handle* h, const float* X, const __bf16* Xb, long r0, lo
     exact_sortkey_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(prev, h->ex_inv, n, h->K, ex.sk_keys, ex.sk_vals);
     int bits = 1;
     while ((1L << bits) < n_groups) ++bits;
-    size_t bytes = ex.sk_tmp_bytes;
-    HIPCHK(h, sort_bmu_pairs(n, ex.sk_tmp, bytes, ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.order + r0, (size_t)n, 0u, (unsigned)bits, h->stream));
+    if (int rc = radix_sort_rows(h, ex.sk_keys, n, bits, ex.sk_keys2, ex.order + r0, (int*)ex.sk_tmp)) return rc;
     exact_gather_sorted_kernel<E><<<dim3((unsigned)cdiv(np, 4)), dim3(256), 0, h->stream>>>(
         ex.order + r0, n, np, h->dp, h->D, Xb, X, xsq, xerr, xmax2, ex.Xb_s + r0 * h->dp, ex.Xl_s + r0 * h->dp, ex.Xf_s + r0 * h->D,
         ex.xsq_s + r0, ex.xerr_s + r0);
@@ -1703,13 +1701,9 @@ int seg_reserve(som_handle* h, som_handle::SegScratch& sg, long rows) {
     if (rows <= sg.cap) return 0;
     seg_free(sg);
     if (rows > 0x7fffffffL) return fail(h, "more than 2^31-1 rows per GPU in one row set");
-    if (int rc = dev_alloc(h, &sg.iota, (size_t)rows)) return rc;
     if (int rc = dev_alloc(h, &sg.skey, (size_t)rows)) return rc;
     if (int rc = dev_alloc(h, &sg.srow, (size_t)rows)) return rc;
-    iota_kernel<<<dim3((unsigned)cdiv(rows, 256)), dim3(256), 0, h->stream>>>(sg.iota, rows);
-    size_t bytes = 0;
-    hipError_t e = sort_bmu_pairs_storage(bytes, sg.skey, sg.skey, sg.iota, sg.srow, rows, 32u, h->stream);
-    if (e != hipSuccess) return fail_hip(h, "rocprim::radix_sort_pairs(size query)", e);
+    const size_t bytes = radix_scratch_ints(rows) * sizeof(int);
     if (int rc = dev_alloc(h, (char**)&sg.tmp, bytes)) return rc;
     sg.tmp_bytes = bytes;
     const int nw = seg_waves_per_block(h->D1p);
@@ -1766,8 +1760,7 @@ int segsum_rows(som_handle* h, const float* X, const int* bmu, long N, som_handl
                                                                                     sg.srow);
             HIPCHK(h, hipGetLastError());
         } else {
-            hipError_t e = sort_bmu_pairs(N, sg.tmp, sg.tmp_bytes, bmu, sg.skey, sg.iota, sg.srow, (size_t)N, 0u, (unsigned)bits, h->stream);
-            if (e != hipSuccess) return fail_hip(h, "rocprim::radix_sort_pairs", e);
+            if (int rc = radix_sort_rows(h, bmu, N, bits, sg.skey, sg.srow, (int*)sg.tmp)) return rc;
         }
         const int acc = zero_first ? 0 : 1;
         long blocks = launch_runsum<true>(h, X, sg.skey, sg.srow, nullptr, N, acc, sg.kA, sg.vA);

@@ -52,6 +52,99 @@ __global__ __launch_bounds__(256) void iota_kernel(int* __restrict__ v, long n) 
     if (i < n) v[i] = (int)i;
 }
 
+// ---- stable LSD radix sort of (key, value) pairs, 8 bits a pass: the rows by BMU for the segment sum (maps too large for the
+// counting sort below), the rows by their last BMU's patch for the exact mode's resident order (exact_skip.hpp).  Hand-written
+// for these two jobs (keys of 10 .. 20 bits, values = row indices, 10^5 .. 10^7 items): per pass
+//   rs_hist_kernel     block = RS_BLOCK consecutive items: LDS histogram of the pass's digit -> table[digit * B + block]
+//   rs_scan_kernel     a wave per digit: exclusive scan of its block counts in place, its total -> tot[digit]
+//   rs_scatter_kernel  block = the same RS_BLOCK items, 256 at a time in item order, the waves one after the other: the first
+//                      destination of a (digit, block) run = the totals of the lower digits + the block's place in its digit; an item's
+//                      destination = its run's cursor + its rank among the wave's items of the same digit: the order of equal
+//                      digits is the order of the items -- STABLE, and the same order on every run (no atomics decide a place)
+// vin == nullptr: the values are the items' own indices (first pass of a sort of row ids).
+constexpr int RS_BLOCK = 2048;
+
+__global__ __launch_bounds__(256) void rs_hist_kernel(const int* __restrict__ keys, long n, int shift, int B, int* __restrict__ table) {
+    __shared__ int hist[256];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const long i0 = (long)blockIdx.x * RS_BLOCK;
+#pragma unroll
+    for (int q = 0; q < RS_BLOCK / 256; ++q) {
+        const long i = i0 + q * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&hist[(keys[i] >> shift) & 255], 1);
+    }
+    __syncthreads();
+    table[(long)threadIdx.x * B + blockIdx.x] = hist[threadIdx.x];
+}
+
+// one wave per digit: exclusive scan of the digit's B block counts in place, the digit's total -> tot[digit]
+__global__ __launch_bounds__(256) void rs_scan_kernel(int* __restrict__ table, int B, int* __restrict__ tot) {
+    const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int* t = table + (long)d * B;
+    int carry = 0;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int b = b0 + lane;
+        const int v = b < B ? t[b] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+        if (b < B) t[b] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) tot[d] = carry;
+}
+
+__global__ __launch_bounds__(256) void rs_scatter_kernel(const int* __restrict__ kin, const int* __restrict__ vin, long n, int shift,
+                                                         int B, const int* __restrict__ table, const int* __restrict__ tot,
+                                                         int* __restrict__ kout, int* __restrict__ vout) {
+    __shared__ int cur[256];                                 // next destination of every digit for this block
+    __shared__ int wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {   // first destination of digit `tid`: the totals of the digits below it + this block's place inside the digit
+        const int mine = tot[tid];
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        cur[tid] = before + incl - mine + table[(long)tid * B + blockIdx.x];
+    }
+    __syncthreads();
+    const long i0 = (long)blockIdx.x * RS_BLOCK;
+    for (int q = 0; q < RS_BLOCK / 256; ++q) {
+        const long i = i0 + q * 256 + tid;
+        const bool live = i < n;
+        const int key = live ? kin[i] : 0;
+        const int val = live ? (vin != nullptr ? vin[i] : (int)i) : 0;
+        const int dg = (key >> shift) & 255;
+        // the lanes of this wave with the same digit
+        unsigned long long peers = __ballot(live);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long m = __ballot((dg >> b) & 1);
+            peers &= ((dg >> b) & 1) ? m : ~m;
+        }
+        const int leader = live ? (int)__builtin_ctzll(peers) : lane;
+        const int rank = (int)__builtin_popcountll(peers & ((1ull << lane) - 1ull));
+        const int count = (int)__builtin_popcountll(peers);
+        int dest = 0;
+        for (int w = 0; w < 4; ++w) {                        // waves in item order: the sort is stable
+            if (wave == w) {
+                int old = 0;
+                if (live && lane == leader) { old = cur[dg]; cur[dg] = old + count; }
+                old = __shfl(old, leader, 64);
+                dest = old + rank;
+            }
+            __syncthreads();
+        }
+        if (live) { kout[dest] = key; vout[dest] = val; }
+    }
+}
+
 // ---- stable counting sort of the rows by BMU for maps of at most CS_MAX_K units ------------------------------------
 // (sorted by unit, rows ascending inside a unit: exactly what the stable radix sort returns, so the run sum adds in the same
 // fixed order.)  rocPRIM's merge sort takes six to seven launches at 100 000 rows (55 us of a 0.4 ms epoch at 64 x 64 x 32);
