@@ -293,37 +293,143 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16
         if (quad == 0 && bx < 3.0e38f) xe[sb][0] = (E)bx;
     }
 
-    // level 2: the stages that hold a sub-block tile of a group level 1 kept, in ascending order, each with the 4-bit mask of
-    // its 16-slot tiles to run (tile t <-> groups 16 s + 4 t .. + 3): an LDS list of (stage << 4 | mask), built by wave 0
+    // the words this workgroup produces (one per stage), gathered in LDS with LDS atomics (a global atomic per wave and stage
+    // sat in front of the next stage's barrier)
     int* act = (int*)(smem + 2 * STAGE);
-    // the words this workgroup produces (one per stage it walks), gathered in LDS and stored once at the end: the waves OR
-    // their rows' bits in with LDS atomics (a global atomic per wave and stage sat in front of the next stage's barrier)
-    unsigned long long* nl = (unsigned long long*)(smem + 2 * STAGE + (LEVEL2 ? (size_t)n_cstages * sizeof(int) : 0));
+    unsigned long long* nl = (unsigned long long*)(smem + 2 * STAGE + (LEVEL2 ? (size_t)n_cstages1 * 64 * sizeof(int) : 0));
     for (int i = tid; i < n_cstages; i += 64 * K16_NW) nl[i] = 0ull;
-    if (LEVEL2) {
+    if constexpr (LEVEL2) {
+        // LEVEL 2 walks a DENSE list of the groups level 1 kept, sixteen to a barrier: four MFMA tiles of four groups' sub-blocks
+        // each, GATHERED -- late in a schedule a quarter of the groups is kept, spread so evenly that nearly every tile of
+        // four consecutive groups holds one: walking image tiles ran four times level 1's work to test a quarter of it.
+        // A tile's fragments come by LDS-DMA with per-lane addresses (lane (quad, c) <-> sub-block c & 3 of the tile's
+        // (c >> 2)-th group), its initial accumulators and radii by plain loads one chunk ahead (a wave per tile), written
+        // into the slot's tail (laid out like a stage's) before the next barrier.
+        static_assert(K16_NW == 4, "a wave per tile fills the slot's tail");
         if (wave == 0) {
             int cnt = 0;
-            for (int base = 0; base < n_cstages; base += 64) {
-                const int s2 = base + lane;
-                uint32_t tm = 0u;
-                if (s2 < n_cstages && (s2 >> 2) < n_cstages1) {
-                    const uint32_t sl = (uint32_t)((need1[(long)blockIdx.x * n_cstages1 + (s2 >> 2)] >> (16 * (s2 & 3))) & 0xFFFFull);
-                    tm = ((sl & 0xFu) ? 1u : 0u) | ((sl & 0xF0u) ? 2u : 0u) | ((sl & 0xF00u) ? 4u : 0u) | ((sl & 0xF000u) ? 8u : 0u);
-                }
-                const unsigned long long mk = __ballot(tm != 0u);
-                if (tm != 0u) act[cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (s2 << 4) | (int)tm;
+            for (int s1 = 0; s1 < n_cstages1; ++s1) {
+                const unsigned long long w = need1[(long)blockIdx.x * n_cstages1 + s1];
+                const int g = s1 * 64 + lane;
+                const bool on = ((w >> lane) & 1ull) && 4 * (g >> 2) * 4 < n_slots;
+                const unsigned long long mk = __ballot(on);
+                if (on) act[cnt + __popcll(mk & ((1ull << lane) - 1ull))] = g;
                 cnt += __popcll(mk);
             }
             if (lane == 0) act_n = cnt;
         }
         __syncthreads();
+        const int n_act = act_n;
+        const int c_all = (n_act + 15) / 16;
+        const int b0 = 16 * (int)((long)c_all * blockIdx.y / gridDim.y);
+        const int e0 = min(n_act, 16 * (int)((long)c_all * (blockIdx.y + 1) / gridDim.y));
+        constexpr int TQ = K16_T * KS32 * 1024;              // the slot's tail: [0, 64) initial accumulators, [64, 128) -up_to_half(sw r)
+        // where sub-block `sub` of group g sits in the level-2 image: stage g >> 4, tile (g >> 2) & 3, row 4 (g & 3) + sub
+        auto frag_of = [&](int g, int sub, int ks, int q) -> const char* {
+            return Cst + (long)(g >> 4) * STAGE + (((((g >> 2) & 3) * KS32 + ks) * 64 + q * 16 + 4 * (g & 3) + sub) * 16);
+        };
+        auto dma_chunk = [&](int c0, char* dst) {
+            for (int p = wave; p < K16_T * KS32; p += K16_NW) {
+                const int j = p / KS32, ks = p - j * KS32;
+                if (c0 + 4 * j < e0) {                        // (wave-uniform)
+                    const int gi = c0 + 4 * j + (col >> 2);
+                    const int g = gi < e0 ? act[gi] : act[c0 + 4 * j];   // (a slot behind the list: any valid address; its bits are dropped)
+                    lds_dma_16(frag_of(g, col & 3, ks, quad), dst + p * 1024);
+                }
+            }
+        };
+        // wave w <-> the chunk's tile w: lanes 0..15 its initial accumulators, lanes 16..31 its radii (row i <-> sub-block i & 3 of
+        // the tile's (i >> 2)-th group)
+        auto load_tail = [&](int c0) -> float {
+            const int i = lane & 15, gi = c0 + 4 * wave + (i >> 2);
+            if (lane >= 32 || gi >= e0) return lane < 16 ? __builtin_inff() : 0.0f;     // (an empty slot: never needed)
+            const int g = act[gi];
+            return *(const float*)(Cst + (long)(g >> 4) * STAGE + TQ + (((lane >> 4) * 64) + ((g >> 2) & 3) * 16 + 4 * (g & 3) + (i & 3)) * 4);
+        };
+        auto store_tail = [&](char* dst, float v) {
+            if (lane < 32) *(float*)(dst + TQ + (((lane >> 4) * 64) + wave * 16 + (lane & 15)) * 4) = v;
+        };
+        if (b0 < e0) { dma_chunk(b0, smem); store_tail(smem, load_tail(b0)); }
+        int k = 0;
+        for (int c0 = b0; c0 < e0; c0 += 16, ++k) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            char* sn = smem + ((k + 1) & 1) * STAGE;
+            float tail_n = 0.0f;
+            if (c0 + 16 < e0) { dma_chunk(c0 + 16, sn); tail_n = load_tail(c0 + 16); }
+            const char* st = smem + (k & 1) * STAGE;
+            const float* wq = (const float*)(st + TQ);
+            auto load_tile = [&](int j, bf16x8 (&a)[KS32], f32x4& wv, float& rneg) {
+#pragma unroll
+                for (int ks = 0; ks < KS32; ++ks) a[ks] = *(const bf16x8*)(st + ((j * KS32 + ks) * 64 + lane) * 16);
+                wv = *(const f32x4*)(wq + j * 16 + 4 * quad);
+                rneg = wq[64 + j * 16 + col];
+            };
+            auto run_tile = [&](int j, const bf16x8 (&a)[KS32], const f32x4& wv, float rneg) {
+                bf16x8 ae;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) ae[jj] = (E)0.0f;
+                if (quad == 0) ae[0] = (E)rneg;
+                f32x4 acc[K16_SB];
+#pragma unroll
+                for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = wv;
+#pragma unroll
+                for (int ks = 0; ks < KS32; ++ks)
+#pragma unroll
+                    for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = mfma16(a[ks], xf[sb][ks], acc[sb]);
+#pragma unroll
+                for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = mfma16(ae, xe[sb], acc[sb]);
+                uint32_t nib[4] = {0u, 0u, 0u, 0u};            // nib[qd]: the sub-blocks of the tile's qd-th group some row needs
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    bool nd = false;
+#pragma unroll
+                    for (int sb = 0; sb < K16_SB; ++sb) nd = nd || !(acc[sb][r] > P[sb]);
+                    const unsigned long long b = __ballot(nd);
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd)
+                        if ((b >> (16 * qd)) & 0xFFFFull) nib[qd] |= 1u << r;
+                }
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int gi = c0 + 4 * j + qd;
+                    if (nib[qd] != 0u && gi < e0) {           // (wave-uniform)
+                        const int g = __builtin_amdgcn_readfirstlane(act[gi]);
+                        if (lane == 0) atomicOr(nl + (g >> 4), (unsigned long long)nib[qd] << (4 * (g & 15)));
+                    }
+                }
+            };
+            bf16x8 aA[KS32], aB[KS32];
+            f32x4 wvA, wvB;
+            float rnA, rnB;
+            const bool h1 = c0 + 4 < e0, h2 = c0 + 8 < e0, h3 = c0 + 12 < e0;
+            load_tile(0, aA, wvA, rnA);
+            if (h1) load_tile(1, aB, wvB, rnB);
+            run_tile(0, aA, wvA, rnA);
+            if (h1) {
+                if (h2) load_tile(2, aA, wvA, rnA);
+                run_tile(1, aB, wvB, rnB);
+                if (h2) {
+                    if (h3) load_tile(3, aB, wvB, rnB);
+                    run_tile(2, aA, wvA, rnA);
+                    if (h3) run_tile(3, aB, wvB, rnB);
+                }
+            }
+            if (c0 + 16 < e0) store_tail(sn, tail_n);
+        }
+        __syncthreads();
+        // (two parts of a tile's walk may share a stage: OR into the words the host cleared)
+        for (int i = tid; i < n_cstages; i += 64 * K16_NW)
+            if (nl[i] != 0ull) atomicOr(need + (long)blockIdx.x * n_cstages + i, nl[i]);
+        return;
     }
-    const int n_walk = LEVEL2 ? act_n : n_cstages;
+    const int n_walk = n_cstages;
     // (gridDim.y workgroups share a tile's centroid stages: few tiles -- a batch of 65 536 rows is 256 -- would otherwise be
     //  one workgroup per CU walking all the stages alone)
     const int s_begin = (int)((long)n_walk * blockIdx.y / gridDim.y);
     const int s_end = (int)((long)n_walk * (blockIdx.y + 1) / gridDim.y);
-    auto item_of = [&](int i) -> int { return __builtin_amdgcn_readfirstlane(LEVEL2 ? act[i] : ((i << 4) | 15)); };
+    auto item_of = [&](int i) -> int { return (i << 4) | 15; };
     auto dma_stage = [&](int s, uint32_t tm, char* dst) {
         const char* src = Cst + (long)s * STAGE;
         for (int p = wave; p < PIECES; p += K16_NW)
@@ -385,7 +491,7 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16
         };
         // up to four tiles, their operands alternating between two register sets (no copies): the next tile's are read
         // under this tile's MFMAs and test
-        const uint32_t m0 = LEVEL2 ? tm_cur : 15u, m1 = m0 & (m0 - 1u), m2 = m1 & (m1 - 1u), m3 = m2 & (m2 - 1u);
+        const uint32_t m0 = 15u, m1 = m0 & (m0 - 1u), m2 = m1 & (m1 - 1u), m3 = m2 & (m2 - 1u);
         const int t0 = __builtin_ctz(m0), t1 = m1 ? __builtin_ctz(m1) : -1, t2 = m2 ? __builtin_ctz(m2) : -1, t3 = m3 ? __builtin_ctz(m3) : -1;
         bf16x8 aA[KS32], aB[KS32];
         f32x4 wvA, wvB;
@@ -406,9 +512,7 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16
         st_cur = st_next; tm_cur = tm_next;
     }
     __syncthreads();
-    // (level 2: the stages no workgroup walks keep the zeros the host cleared the words to)
-    for (int i = s_begin + tid; i < s_end; i += 64 * K16_NW)
-        need[(long)blockIdx.x * n_cstages + (LEVEL2 ? (act[i] >> 4) : i)] = nl[i - s_begin];
+    for (int i = s_begin + tid; i < s_end; i += 64 * K16_NW) need[(long)blockIdx.x * n_cstages + i] = nl[i - s_begin];
 }
 
 // need bitmaps -> per tile the ascending list of items (group << 4 | mask of the group's 16-unit sub-blocks to run), and its

@@ -1266,7 +1266,7 @@ int exact_skip_plan(som_handle* h, long r0, long n, const int* prev, const float
     const dim3 pgrid((unsigned)tiles, (unsigned)std::max<long>(1, std::min<long>({want, 4L, (long)c0.n_cstages})));
     // (two stage slots + the words the workgroup produces; level 2: + its list of active stages)
     const size_t lds1 = 2 * (size_t)h->stage_bytes + (size_t)c0.n_cstages * 8;
-    const size_t lds2 = 2 * (size_t)h->stage_bytes + (size_t)c1.n_cstages * (sizeof(int) + 8);
+    const size_t lds2 = 2 * (size_t)h->stage_bytes + (size_t)c0.n_cstages * 64 * sizeof(int) + (size_t)c1.n_cstages * 8;   // (+ its list of kept groups, its words)
     const bool l2 = ex.l2_live;
     const int force = ex.skip_mode == 3 ? 1 : 0;
     const __bf16* Xs = ex.Xb_s + r0 * h->dp;
@@ -1443,7 +1443,7 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         bool probe = ex.l1_share_probe < 0.0 || ex.l2_wait <= 0 || ex.l1_share_last > 1.5 * ex.l1_share_probe || ex.l1_share_last < ex.l1_share_probe / 1.5;
         if (ex.l1_share_last > 0.9 && ex.l1_share_probe >= 0.0 && !ex.l2_pays) probe = false;   // (nothing for four times the centroids to find)
         ex.l2_live = ex.sub_blocks && (ex.l2_pays || probe || ex.skip_mode >= 2) &&
-                     2 * (size_t)h->stage_bytes + 4 * (size_t)cdiv(n_groups, K16_STAGE_UNITS) * (sizeof(int) + 8) <= 150 * 1024;   // (its stage list lives in LDS)
+                     2 * (size_t)h->stage_bytes + (size_t)cdiv(n_groups, K16_STAGE_UNITS) * (64 * sizeof(int) + 4 * 8) <= 150 * 1024;   // (its list of kept groups lives in LDS)
         if (int rc = SOM_HALF(h, exact_skip_centroids, h, xmax2)) return rc;
     }
     // the refinement pass (bmu_exact.hpp) where it pays: it costs about a third of the float32 re-score of the pairs it is
