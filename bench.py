@@ -157,8 +157,12 @@ def pmc_traffic(workload, rows, precision, kernel, build_hash):
             if pm.get("rows_per_launch") != rows or pm.get("workload", "c3") != workload \
                     or pm.get("precision", "bf16") != precision or pm.get("library", "libsomhip.so") != "libsomhip.so":
                 continue                                   # (another workload, or a timing-experiment build)
-            k = next(v for name, v in pm.items() if name.startswith(kernel) and isinstance(v, dict) and
-                     (precision != "exact" or "F16" in name or "f16" in name))   # "<kernel><4>" too; exact: the IEEE-half screen instance
+            # "<kernel><4>" too; exact: the IEEE-half screen instance -- the tile-list instance (block skipping: the launches of the
+            # timed epochs) before the full-scan one
+            cands = sorted(((name, v) for name, v in pm.items() if name.startswith(kernel) and isinstance(v, dict) and
+                            (precision != "exact" or "F16" in name or "f16" in name)),
+                           key=lambda nv: (0 if nv[0].rstrip().endswith("true, true>") else 1, nv[0]))
+            k = cands[0][1]
             cand = {"bytes": k["fabric_bytes_corrected"], "file": os.path.basename(path), "build": pm.get("build")}
         except Exception:
             continue

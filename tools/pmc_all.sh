@@ -6,8 +6,8 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=$1; ROWS=$2; shift 2
 # (the bench line's own steps and warm-up: under block skipping a launch's duration depends on the epoch it serves)
-STEPS=${PMC_STEPS:-10}; WARM=${PMC_WARMUP:-2}
-ARGS="--rows $ROWS --steps $STEPS --warmup $WARM --no-cpu-baseline --no-batch65536 --no-throughput-mode --no-modes $@"
+STEPS=${PMC_STEPS:-20}; WARM=${PMC_WARMUP:-5}
+ARGS="--rows $ROWS --steps $STEPS --warmup $WARM --no-cpu-baseline --no-batch65536 --no-throughput-mode --no-modes --no-schedule $@"
 OUT=gpurun_out/pmc_${TAG}_${ROWS}
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/trace.log 2>&1 &&

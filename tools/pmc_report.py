@@ -71,13 +71,13 @@ for f in glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_stats.csv"), re
 # the dominant kernels dispatch by dispatch (kernel trace): under block skipping a launch's duration depends on the epoch it
 # serves, so the average over the bench line's TIMED epochs (dispatches warmup .. warmup + steps of the run; the untimed
 # breakdown pass follows them) is what agrees with the line's avg_launch_ms, not the average over every launch of the process
-steps, warm = int(os.environ.get("PMC_STEPS", "10")), int(os.environ.get("PMC_WARMUP", "2"))
+steps, warm = int(os.environ.get("PMC_STEPS", "20")), int(os.environ.get("PMC_WARMUP", "5"))
 timed = {}
 for f in glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_trace.csv"), recursive=True):
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
-        if k.startswith("bmu_") or k.startswith("exact_rescore") or k.startswith("exact_select") or k.startswith("exact_plan"):
+        if k.startswith("bmu_") or k.startswith("exact_rescore") or k.startswith("exact_select") or k.startswith("exact_plan") or k.startswith("exact_refine"):
             per[k].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
     with open(os.path.join("gpurun_out", "%s_dispatches_rows%d.csv" % (tag, rows)), "w") as g:
         g.write("kernel,dispatch,duration_us,timed_region\n")
