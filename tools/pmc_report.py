@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fold the passes of tools/pmc_all.sh into one JSON per (tag, rows): per kernel the mean counter values per dispatch
-(timed launches only: the first `warmup` dispatches of each kernel are dropped where the kernel runs once per epoch),
-its mean duration from the kernel trace, and the derived figures DESIGN.md quotes:
+(over every launch of the process, and `timed_*`: over the launches of the bench line's timed epochs, epochs delimited by the
+merge kernel), its mean duration from the kernel trace, and the derived figures DESIGN.md quotes:
   mfma_busy      SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs)
   clock_ghz      GRBM_GUI_ACTIVE / 8 / duration   (MI355X_MICROARCH.md, DVFS give-back)
   valu_per_mfma  (SQ_INSTS_VALU - SQ_INSTS_MFMA) / SQ_INSTS_MFMA
@@ -55,11 +55,33 @@ def short(name):
     return name
 
 
+steps, warm = int(os.environ.get("PMC_STEPS", "20")), int(os.environ.get("PMC_WARMUP", "5"))
+
+
+def by_epoch(rows_of_pass):
+    """(order key, kernel, payload) of one profiler pass -> [(epoch, kernel, payload)]: an epoch ends with its merge kernel
+    (one per epoch in every mode), so a dispatch belongs to the TIMED region of the bench line iff warm <= epoch < warm + steps
+    whichever kernels the epoch happened to launch (the first epoch of an exact-mode run has no plan and no tile-list screen)."""
+    out, ep = [], 0
+    for _, k, payload in sorted(rows_of_pass, key=lambda r: r[0]):
+        out.append((ep, k, payload))
+        if k == "merge_kernel":
+            ep += 1
+    return out
+
+
 counters = collections.defaultdict(lambda: collections.defaultdict(list))
+counters_timed = collections.defaultdict(lambda: collections.defaultdict(list))
 for sub in ("sq_a", "sq_b", "fetch", "write", "tcc"):
     for f in glob.glob(os.path.join(out_dir, sub, "**", "*counter_collection.csv"), recursive=True):
+        per_dispatch = collections.OrderedDict()
         for r in csv.DictReader(open(f)):
-            counters[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            per_dispatch.setdefault(int(r["Dispatch_Id"]), (short(r["Kernel_Name"]), []))[1].append((r["Counter_Name"], float(r["Counter_Value"])))
+        for ep, k, vals in by_epoch([(i, k, v) for i, (k, v) in per_dispatch.items()]):
+            for c, v in vals:
+                counters[k][c].append(v)
+                if warm <= ep < warm + steps:
+                    counters_timed[k][c].append(v)
 dur = {}
 for f in glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_stats.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -68,29 +90,28 @@ for f in glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_stats.csv"), re
     stats_copy = os.path.join("gpurun_out", "%s_kernel_stats_rows%d.csv" % (tag, rows))
     open(stats_copy, "w").write(open(f).read())
 
-# the dominant kernels dispatch by dispatch (kernel trace): under block skipping a launch's duration depends on the epoch it
-# serves, so the average over the bench line's TIMED epochs (dispatches warmup .. warmup + steps of the run; the untimed
-# breakdown pass follows them) is what agrees with the line's avg_launch_ms, not the average over every launch of the process
-steps, warm = int(os.environ.get("PMC_STEPS", "20")), int(os.environ.get("PMC_WARMUP", "5"))
+# the kernels dispatch by dispatch (kernel trace): under block skipping a launch's duration depends on the epoch it serves, so
+# the average over the bench line's TIMED epochs is what agrees with the line's avg_launch_ms, not the average over every
+# launch of the process (the profiler's own --stats table, copied beside this file, averages over all of them)
 timed = {}
 for f in glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    rows_of_pass = [(int(r["Start_Timestamp"]), short(r["Kernel_Name"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+                    for r in csv.DictReader(open(f))]
     per = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        k = short(r["Kernel_Name"])
-        if k.startswith("bmu_") or k.startswith("exact_rescore") or k.startswith("exact_select") or k.startswith("exact_plan") or k.startswith("exact_refine"):
-            per[k].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    for ep, k, d in by_epoch(rows_of_pass):
+        per[k].append((ep, d))
     with open(os.path.join("gpurun_out", "%s_dispatches_rows%d.csv" % (tag, rows)), "w") as g:
-        g.write("kernel,dispatch,duration_us,timed_region\n")
+        g.write("kernel,epoch,duration_us,timed_region\n")
         for k, v in sorted(per.items()):
-            v.sort()
-            n_ep = steps + warm
-            per_epoch = max(1, round(len(v) / (n_ep + min(steps, 20)))) if len(v) >= n_ep else 1
-            for i, (_, d) in enumerate(v):
-                ep = i // per_epoch
-                g.write("%s,%d,%.1f,%d\n" % (k.replace(",", ";"), i, d, int(warm <= ep < n_ep)))
-            sel = [d for i, (_, d) in enumerate(v) if warm <= i // per_epoch < n_ep]
-            if sel:
-                timed[k] = {"timed_dispatches": len(sel), "timed_avg_us": sum(sel) / len(sel), "per_epoch": per_epoch}
+            if not (k.startswith("bmu_") or k.startswith("exact_") or k.startswith("runsum") or k.startswith("rs_") or k.startswith("leftmul")):
+                continue
+            for ep, d in v:
+                g.write("%s,%d,%.1f,%d\n" % (k.replace(",", ";"), ep, d, int(warm <= ep < warm + steps)))
+    for k, v in per.items():
+        sel = [d for ep, d in v if warm <= ep < warm + steps]
+        if sel:
+            timed[k] = {"timed_dispatches": len(sel), "timed_avg_us": sum(sel) / len(sel), "timed_epochs_with_a_launch": len({ep for ep, _ in v if warm <= ep < warm + steps}),
+                        "timed_us_per_epoch": sum(sel) / steps}
 
 from xpysom_dask_amd import build as B  # noqa: E402
 lib = os.environ.get("SOM_LIB_PATH")
@@ -123,6 +144,13 @@ for k, cs in sorted(counters.items()):
                 d[c.lower() + "_share"] = d[c] / d["SQ_WAVE_CYCLES"]
     if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
         d["fabric_bytes_corrected"] = 2.0 * d.get("FETCH_SIZE", 0.0) * 1024.0 + d.get("WRITE_SIZE", 0.0) * 1024.0
+    t = {c: sum(v) / len(v) for c, v in counters_timed.get(k, {}).items() if v}
+    if "FETCH_SIZE" in t or "WRITE_SIZE" in t:
+        d["timed_fabric_bytes_corrected"] = 2.0 * t.get("FETCH_SIZE", 0.0) * 1024.0 + t.get("WRITE_SIZE", 0.0) * 1024.0
+    if t.get("GRBM_GUI_ACTIVE", 0) > 0 and "SQ_VALU_MFMA_BUSY_CYCLES" in t:
+        d["timed_mfma_busy"] = t["SQ_VALU_MFMA_BUSY_CYCLES"] / (t["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+    if t.get("TCC_HIT_sum", 0) + t.get("TCC_MISS_sum", 0) > 0:
+        d["timed_l2_hit"] = t["TCC_HIT_sum"] / (t["TCC_HIT_sum"] + t["TCC_MISS_sum"])
     if d.get("TCC_HIT_sum", 0) + d.get("TCC_MISS_sum", 0) > 0:
         d["l2_hit"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
     res[k] = d
