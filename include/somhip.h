@@ -230,7 +230,9 @@ int som_verify_stats(som_handle* h, int64_t* launches, int64_t* rows_checked);
 
 /* precision EXACT, introspection (host arithmetic only, no device needed): the order in which the mode's operand images
  * hold the units of an x * y map -- perm_out[position] = unit id, x * y entries; every 64 consecutive positions are one
- * group of the screen / re-score (an 8 x 8 patch of the map where both sides are multiples of 8), ascending inside. */
+ * group of the screen / re-score: where both sides are multiples of 8 an 8 x 8 patch of the map held as four 4 x 4 blocks
+ * (positions 0..15: rows 0..3 x columns 0..3 of the patch, row by row; 16..31: columns 4..7; 32..63: rows 4..7 likewise --
+ * the 16-unit blocks the exact mode's plan tests); elsewhere a run of whole 8-row bands, ascending inside. */
 int som_patch_order(int32_t x, int32_t y, int32_t* perm_out);
 
 /* precision EXACT bookkeeping: rows screened so far, rows that went to the float32 fallback kernel, screen passes */

@@ -432,7 +432,7 @@ def test_exact_on_maps_of_a_quarter_million_units(X, Y, D, n):
 
 
 # ----------------------------------------------------------------------------- patch order
-@pytest.mark.parametrize("X,Y", [(16, 24), (13, 21), (9, 100), (70, 3)])
+@pytest.mark.parametrize("X,Y", [(16, 24), (32, 32), (64, 8), (13, 21), (9, 100), (70, 3)])
 def test_exact_patch_order_ties_prefer_the_lowest_unit(monkeypatch, X, Y):
     """The exact mode's operand images hold the units patch by patch (8 x 8 units of the map per 64-unit group where the
     sides are multiples of 8; bands of 8 map rows cut every 64 units otherwise: som_common.hpp); the answer must not

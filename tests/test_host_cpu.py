@@ -76,9 +76,9 @@ def test_c_abi_exports_every_declared_symbol():
 
 @pytest.mark.parametrize("X,Y", [(256, 256), (16, 24), (100, 100), (13, 21), (9, 100), (70, 3), (1, 1), (1, 200), (5, 5)])
 def test_exact_patch_order_is_a_compact_ascending_bijection(X, Y):
-    """som_patch_order (host arithmetic of the exact mode): a bijection position -> unit; inside every
-    group of 64 positions the unit ids ascend (the re-score's first-minimum rule relies on it); a group is an 8 x 8 patch
-    of the map where both sides are multiples of 8, and a run of whole 8-row bands anywhere."""
+    """som_patch_order (host arithmetic of the exact mode): a bijection position -> unit; a group of 64 positions
+    is an 8 x 8 patch of the map where both sides are multiples of 8 -- held as four 4 x 4 blocks, the plan's 16-unit sub-blocks
+    (the re-score decides equal scores by rank there) -- and a run of whole 8-row bands, unit ids ascending, anywhere else."""
     from xpysom_dask_amd import _lib
     lib = _lib.load()
     K = X * Y
@@ -87,8 +87,13 @@ def test_exact_patch_order_is_a_compact_ascending_bijection(X, Y):
     assert np.array_equal(np.sort(perm), np.arange(K))
     for g in range(0, K, 64):
         grp = perm[g:g + 64]
-        assert (np.diff(grp) > 0).all()
         xs, ys = grp // Y, grp % Y
+        if X % 8 == 0 and Y % 8 == 0:
+            for b in range(4):                                                  # block b: rows 4 (b >> 1).., columns 4 (b & 1)..
+                bx, by = xs[16 * b:16 * b + 16] - xs.min(), ys[16 * b:16 * b + 16] - ys.min()
+                assert np.array_equal(bx, 4 * (b >> 1) + np.arange(16) // 4) and np.array_equal(by, 4 * (b & 1) + np.arange(16) % 4)
+        else:
+            assert (np.diff(grp) > 0).all()
         assert xs.max() - xs.min() < 8 * (-(-64 // (8 * Y)) + 1)            # whole bands of 8 map rows, one more when it straddles
         if X % 8 == 0 and Y % 8 == 0:
             assert xs.max() - xs.min() == 7 and ys.max() - ys.min() == 7 and xs.min() % 8 == 0 and ys.min() % 8 == 0

@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_mfma_kernel(const float*
                                                                     const int* __restrict__ n_tiles_dev,
                                                                     const int* __restrict__ plist,
                                                                     unsigned long long* __restrict__ best64,
-        const int* __restrict__ perm, const int* __restrict__ order = nullptr) {
+        const int* __restrict__ perm, const int* __restrict__ order = nullptr, int sub44 = 0) {
     constexpr int STAGE = fr_stage_bytes(KG);
     constexpr int PIECES = FR_UT * KG + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE stage: occupancy (three workgroups per CU), not a
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_mfma_kernel(const float*
         const char* st = smem;
         const float* wq = (const float*)(st + FR_UT * KG * 1024);
         float best = __builtin_inff();
-        int bkey = 0;
+        int bkey = 0, brank = 0;
 #pragma unroll
         for (int ut = 0; ut < FR_UT; ++ut) {
             f32x16 acc;
@@ -580,17 +580,20 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_mfma_kernel(const float*
 #pragma unroll
             for (int q = 0; q < 4; ++q) wv[q] = *(const f32x4*)(wq + ut * 32 + 8 * q + 4 * half);
             const int tile = g * FR_UT + ut;
-            if ((tile + 1) * 32 > K) f32_tile_argmin<SCORE_EUCLID_PART, true>(acc, wv, 0.0f, tile, half, K, best, bkey);
+            static_assert(FR_UT == 2, "ex_rank44: a group is two 32-unit MFMA tiles");
+            if (sub44) f32_tile_argmin_ranked<SCORE_EUCLID_PART>(acc, wv, 0.0f, tile, half, best, bkey, brank);   // (whole 8 x 8 patches: no tail)
+            else if ((tile + 1) * 32 > K) f32_tile_argmin<SCORE_EUCLID_PART, true>(acc, wv, 0.0f, tile, half, K, best, bkey);
             else f32_tile_argmin<SCORE_EUCLID_PART, false>(acc, wv, 0.0f, tile, half, K, best, bkey);
         }
         int bidx = f32_key_unit(bkey, half);
+        if (!sub44) brank = bidx;                         // (positions ascend with the unit ids inside the group)
         const float ob = __shfl_xor(best, 32, 64);
-        const int oi = __shfl_xor(bidx, 32, 64);
-        if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+        const int oi = __shfl_xor(bidx, 32, 64), ork = __shfl_xor(brank, 32, 64);
+        if (ob < best || (ob == best && ork < brank)) { best = ob; bidx = oi; }
         if (half == 0 && row >= 0) {                      // (best == +inf: no unit of this group scored below it)
             const uint32_t bits = __float_as_uint(best);
             const uint32_t key = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
-            // (patch order: positions ascend with the unit ids inside a group; across groups the merge compares UNITS)
+            // (patch order: inside a group the lowest unit id among equal scores was kept; across groups the merge compares UNITS)
             atomicMin(best64 + row, ((unsigned long long)key << 32) | (uint32_t)(perm != nullptr ? perm[bidx] : bidx));
         }
     }
@@ -609,7 +612,7 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_tiled_kernel(const float
                                                                      const int* __restrict__ n_tiles_dev,
                                                                      const int* __restrict__ plist,
                                                                      unsigned long long* __restrict__ best64,
-        const int* __restrict__ perm, const int* __restrict__ order = nullptr) {
+        const int* __restrict__ perm, const int* __restrict__ order = nullptr, int sub44 = 0) {
     __shared__ __attribute__((aligned(16))) char ring[2][8192];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -690,20 +693,22 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_tiled_kernel(const float
         if (!wave_live) continue;
         const float* wq = (const float*)(wtile + FT_TILE);     // the block's 128 |w|^2 (+inf behind the last unit)
         float best = __builtin_inff();
-        int bkey = 0;
+        int bkey = 0, brank = 0;
 #pragma unroll
         for (int tu = 0; tu < 2; ++tu) {
             f32x4 wv[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) wv[q] = *(const f32x4*)(wq + uh * 64 + tu * 32 + 8 * q + 4 * half);
             const int tile = ub * (FT_BN / 32) + uh * 2 + tu;
-            if ((tile + 1) * 32 > K) f32_tile_argmin<MODE, true>(acc[tu], wv, xs, tile, half, K, best, bkey);
+            if (sub44) f32_tile_argmin_ranked<MODE>(acc[tu], wv, xs, tile, half, best, bkey, brank);
+            else if ((tile + 1) * 32 > K) f32_tile_argmin<MODE, true>(acc[tu], wv, xs, tile, half, K, best, bkey);
             else f32_tile_argmin<MODE, false>(acc[tu], wv, xs, tile, half, K, best, bkey);
         }
         int bidx = f32_key_unit(bkey, half);
+        if (!sub44) brank = bidx;
         const float ob = __shfl_xor(best, 32, 64);
-        const int oi = __shfl_xor(bidx, 32, 64);
-        if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+        const int oi = __shfl_xor(bidx, 32, 64), ork = __shfl_xor(brank, 32, 64);
+        if (ob < best || (ob == best && ork < brank)) { best = ob; bidx = oi; }
         if (half == 0 && row >= 0) {
             const uint32_t bits = __float_as_uint(best);
             const uint32_t key = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);

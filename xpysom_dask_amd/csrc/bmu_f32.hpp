@@ -74,6 +74,34 @@ __device__ __forceinline__ void f32_tile_argmin(const f32x16& acc, const f32x4 (
 
 __device__ __forceinline__ int f32_key_unit(int key, int half) { return (key >> 4) * 32 + mfma32_row(key & 15, half); }
 
+// The exact mode's groups whose 64 positions are an 8 x 8 patch of the map in FOUR-BY-FOUR blocks (som_common.hpp, the 16-unit
+// sub-blocks of exact_skip.hpp): position w of the group = block (w >> 4) -- (0,0), (0,4), (4,0), (4,4) -- row (w >> 2) & 3 and
+// column w & 3 inside it; the unit's RANK among the group's 64 units in ascending unit id = 8 (patch row) + patch column.
+__device__ __forceinline__ int ex_rank44(int w) { return 8 * (4 * ((w >> 5) & 1) + ((w >> 2) & 3)) + 4 * ((w >> 4) & 1) + (w & 3); }
+
+// f32_tile_argmin for such a group: positions no longer ascend with the unit ids, so "first minimum" is decided by rank -- among
+// equal scores (within the tile, against the running best) the lowest RANK wins, which is the lowest unit id.  brank: the
+// running best's rank (any value while best = +inf).  `tile` odd <-> the group's second 32 positions.
+template <int MODE>
+__device__ __forceinline__ void f32_tile_argmin_ranked(const f32x16& acc, const f32x4 (&wv)[4], float xsq, int tile, int half,
+                                                       float& best, int& bkey, int& brank) {
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = score_f32<MODE>(acc[r], wv[r >> 2][r & 3], xsq);
+    float m = __builtin_fminf(v[0], v[1]);
+#pragma unroll
+    for (int r = 2; r < 16; ++r) m = __builtin_fminf(m, v[r]);
+    if (m <= best) {                                     // (a NaN minimum: neither; '<' as in the sequential scan, '==' by rank)
+        int code = -1, rk = m < best ? 64 : brank;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = ex_rank44(((tile & 1) << 5) | mfma32_row(r, half));
+            if (v[r] == m && q < rk) { rk = q; code = r; }
+        }
+        if (code >= 0) { best = m; bkey = (tile << 4) | code; brank = rk; }
+    }
+}
+
 // The (n, K) distance matrix itself, for the analysis calls that return it: XPySom.activate
 // (xpysom.py:323-354, configured distance) and distance_from_weights (:647-671, sqrt'd Euclidean).
 // Same tiling and the same bit-exact arithmetic as bmu_f32_kernel; the epilogue stores instead of

@@ -80,6 +80,7 @@ struct som_handle {
     // from a permuted copy of the codebook; wf_patch: the order the float32 image is in right now (the float32 kernels
     // proper -- fallback rows, top-2, analysis calls -- want the units' own order and rebuild it)
     bool ex_patch = false, wf_patch = false;
+    bool ex_sub44 = false;                              // ... with every group an 8 x 8 patch in 4 x 4 blocks (patch_order)
     int* ex_perm = nullptr;
     int* ex_inv = nullptr;
     float* Wp = nullptr;     // [K][D] codebook in patch order
@@ -1305,7 +1306,7 @@ int exact_rescore_kg(som_handle* h, const float* X, int n_groups) {
     // (twice the resident slots: the runs of tiles are uneven -- partial tiles, idle waves -- and finer runs balance them)
     const long grid = std::min<long>(ex.max_tiles, 2L * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
     kern<<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, h->D, h->Wfst, h->K, ex.tile_tab, ex.ctr + 2 * n_groups + 1, ex.plist,
-                                                             h->best64, h->ex_perm, nullptr);
+                                                             h->best64, h->ex_perm, nullptr, h->ex_sub44 ? 1 : 0);
     return 0;
 }
 
@@ -1367,10 +1368,10 @@ int exact_rescore_round(som_handle* h, const float* X, const float* xsq, unsigne
         const long grid = std::min<long>(ex.max_tiles, 2L * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
         if (cosine)
             exact_rescore_tiled_kernel<SCORE_COSINE><<<dim3((unsigned)grid), dim3(256), 0, h->stream>>>(
-                X, h->D, xsq, h->Wfimg, h->ft_kchunks, h->K, ex.tile_tab, n_tiles, ex.plist, best64, h->ex_perm);
+                X, h->D, xsq, h->Wfimg, h->ft_kchunks, h->K, ex.tile_tab, n_tiles, ex.plist, best64, h->ex_perm, nullptr, h->ex_sub44 ? 1 : 0);
         else
             exact_rescore_tiled_kernel<SCORE_EUCLID_PART><<<dim3((unsigned)grid), dim3(256), 0, h->stream>>>(
-                X, h->D, xsq, h->Wfimg, h->ft_kchunks, h->K, ex.tile_tab, n_tiles, ex.plist, best64, h->ex_perm);
+                X, h->D, xsq, h->Wfimg, h->ft_kchunks, h->K, ex.tile_tab, n_tiles, ex.plist, best64, h->ex_perm, nullptr, h->ex_sub44 ? 1 : 0);
         h->best64 = saved;
         return 0;
     }
@@ -1953,13 +1954,25 @@ int launch_dist_matrix(som_handle* h, long N, float* out) {
 
 // ==============================================================================================
 // the exact mode's patch order (som_common.hpp): position -> unit.  Host arithmetic only (som_patch_order exports it).
-static void patch_order(int X, int Y, std::vector<int>& perm) {
+// Where both sides are multiples of 8 every group is a whole 8 x 8 patch, held in FOUR-BY-FOUR blocks (ex_rank44, bmu_f32.hpp):
+// the 16-unit sub-blocks the plan tests (exact_skip.hpp) are then 4 x 4 squares of the map -- at the end of the benchmark's
+// schedule a third fewer of them must run than of 2 x 8 strips (tools/bound_probe.py) -- and the re-score kernels decide equal
+// scores by rank.  Elsewhere the units of a group ascend.
+static bool patch_order_blocks(int X, int Y) { return X % 8 == 0 && Y % 8 == 0; }
+static void patch_order(int X, int Y, std::vector<int>& perm, bool blocks = true) {
     const long K = (long)X * Y;
     perm.clear(); perm.reserve((size_t)K);
     for (int x0 = 0; x0 < X; x0 += 8)
         for (int y = 0; y < Y; ++y)
             for (int x = x0; x < std::min(x0 + 8, X); ++x) perm.push_back(x * Y + y);
     for (long g = 0; g < K; g += EX_GROUP) std::sort(perm.begin() + g, perm.begin() + std::min<long>(g + EX_GROUP, K));
+    if (!blocks || !patch_order_blocks(X, Y)) return;
+    int sorted[EX_GROUP];
+    for (long g = 0; g < K; g += EX_GROUP) {
+        for (int i = 0; i < EX_GROUP; ++i) sorted[i] = perm[g + i];
+        for (int w = 0; w < EX_GROUP; ++w)
+            perm[g + w] = sorted[8 * (4 * ((w >> 5) & 1) + ((w >> 2) & 3)) + 4 * ((w >> 4) & 1) + (w & 3)];
+    }
 }
 
 extern "C" {
@@ -2091,7 +2104,10 @@ int som_create(const som_config* cfg, som_handle** out) {
         // the sides are no multiples of 8 a group may straddle two bands or hold a narrower band's 64 / h columns: still
         // compact); then every group's units in ascending order (the first-minimum rule inside a re-score tile)
         std::vector<int> perm;
-        patch_order(h->X, h->Y, perm);
+        bool blocks = true;
+        if (const char* e = dev_env("SOM_EXACT_SUB44")) blocks = std::atoi(e) != 0;   // A/B: every group's units ascending (2 x 8 sub-blocks)
+        h->ex_sub44 = blocks && patch_order_blocks(h->X, h->Y);
+        patch_order(h->X, h->Y, perm, blocks);
         std::vector<int> inv((size_t)h->K);
         for (int p = 0; p < h->K; ++p) inv[(size_t)perm[(size_t)p]] = p;
         if (hipMemcpy(h->ex_perm, perm.data(), (size_t)h->K * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
