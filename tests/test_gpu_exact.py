@@ -754,6 +754,12 @@ def test_exact_sub_block_plan_drops_blocks_and_keeps_the_ids(monkeypatch):
         assert np.array_equal(a[0][t], b[0][t]), t
     assert np.array_equal(a[1], b[1])
     assert a[2][1] == b[2][1] and a[2][0] < 0.9 * b[2][0], (a[2], b[2])
+    # the sub-blocks are 4 x 4 squares of the map where both sides are multiples of 8 (som_patch_order); as 2 x 8 strips
+    # (SOM_EXACT_SUB44=0: every group's units ascending) the ids are the same
+    c = _train_states(monkeypatch, {"SOM_EXACT_SKIP": "2", "SOM_EXACT_SUB44": "0"}, X, Y, D, n, T, data, w)
+    for t in range(T):
+        assert np.array_equal(a[0][t], c[0][t]), t
+    assert np.array_equal(a[1], c[1]) and a[2][1] == c[2][1]
 
 
 def test_exact_new_rows_of_the_same_size_drop_the_resident_order():

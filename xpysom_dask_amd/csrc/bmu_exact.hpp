@@ -295,9 +295,9 @@ __global__ __launch_bounds__(1024) void exact_tiles_kernel(const int* __restrict
                                                            const int* __restrict__ gstart = nullptr,
                                                            int* __restrict__ gstart_out = nullptr,
                                                            int* __restrict__ pairs_out = nullptr) {
-    __shared__ long sums[1024];
-    __shared__ int tsums[1024];
-    const int tid = threadIdx.x;
+    __shared__ long wsum[16];
+    __shared__ int wtsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (n_groups + 1023) / 1024;
     const int b = tid * per, e = min(b + per, n_groups);
     long s = 0;
@@ -306,21 +306,30 @@ __global__ __launch_bounds__(1024) void exact_tiles_kernel(const int* __restrict
         const int c = gcount[g] - (gstart ? gstart[g] : 0);
         s += c; ts += (c + EX_TR - 1) / EX_TR;
     }
-    sums[tid] = s; tsums[tid] = ts;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {                  // inclusive Hillis-Steele scan of both
-        const long a = tid >= o ? sums[tid - o] : 0;
-        const int c = tid >= o ? tsums[tid - o] : 0;
-        __syncthreads();
-        sums[tid] += a; tsums[tid] += c;
-        __syncthreads();
+    // inclusive scan of both over the 1 024 threads: inside each wave by shuffles, then over the sixteen wave totals
+    long si = s;
+    int ti = ts;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long a = (long)__shfl_up((long long)si, o, 64);
+        const int c = __shfl_up(ti, o, 64);
+        if (lane >= o) { si += a; ti += c; }
     }
-    if (tid == 0 && pairs_out != nullptr) *pairs_out = (int)min(sums[1023], 0x7fffffffL);
-    if (sums[1023] > capacity) {
+    if (lane == 63) { wsum[wave] = si; wtsum[wave] = ti; }
+    __syncthreads();
+    long total = 0, before = 0;
+    int ttotal = 0, tbefore = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) { before += wsum[w]; tbefore += wtsum[w]; }
+        total += wsum[w]; ttotal += wtsum[w];
+    }
+    if (tid == 0 && pairs_out != nullptr) *pairs_out = (int)min(total, 0x7fffffffL);
+    if (total > capacity) {
         if (tid == 0) { *overflow = 1; *n_tiles_out = 0; }
         return;
     }
-    int toff = tsums[tid] - ts;
+    int toff = tbefore + ti - ts;
     for (int g = b; g < e; ++g) {
         const int first = gstart ? gstart[g] : 0;
         const int c = gcount[g] - first;
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(1024) void exact_tiles_kernel(const int* __restrict
         for (int i = 0; i * EX_TR < c; ++i) tile_tab[toff++] = make_int4(g, off + i * EX_TR, min(EX_TR, c - i * EX_TR), 0);
         if (gstart_out) gstart_out[g] = first + c;
     }
-    if (tid == 1023) *n_tiles_out = tsums[1023];
+    if (tid == 1023) *n_tiles_out = ttotal;
 }
 
 // ---- REFINEMENT (resident sorted rows, input_len <= 128): the candidate (row, group) pairs once more on the half-precision

@@ -37,38 +37,74 @@ namespace somhip {
 constexpr int SK_TILE = K16_WG_SAMPLES;   // rows per plan / screen workgroup tile
 static_assert(K16_STAGE_UNITS == 64 && K16_T == 4, "block skipping: a stage of the resident screen is one 64-unit group of four 16-unit tiles");
 
-// Centroid and radius of blocks of consecutive units of W (patch order: a patch of the map).  One workgroup (two waves)
-// per output slot, thread d <-> feature d in both passes (rows read whole: coalesced); a unit's |w - c|^2 is a wave
-// reduction.  sub == 0: slot g = group g (64 units).  sub == 1: slot j = sub-block `j & 3` (16 units) of group
-// 4 (j >> 4) + ((j >> 2) & 3) -- sixteen consecutive slots are the sub-blocks of four consecutive groups, one 16-row MFMA
-// tile of the level-2 centroid image.  A slot without units: centroid 0, radius -1 (never needed).
-__global__ __launch_bounds__(128) void exact_centroid_kernel(const float* __restrict__ W, int K, int D, float* __restrict__ C,
-                                                             float* __restrict__ rg, int sub) {
-    __shared__ float part[2][64];
-    const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long u0 = sub ? ((long)(4 * (j >> 4) + ((j >> 2) & 3)) * 64 + (j & 3) * 16) : (long)j * 64;
-    const int cnt = (int)max(0L, min((long)(sub ? 16 : 64), (long)K - u0));
-    float c = 0.0f;
-    if (tid < D) {
-        for (int k = 0; k < cnt; ++k) c += W[(u0 + k) * D + tid];
-        if (cnt > 0) c /= (float)cnt;
-        C[(long)j * D + tid] = c;
+// Centroids and radii of the blocks of W (patch order), both levels in one launch: workgroup g holds group g's 64
+// units in registers (thread <-> a feature of a sub-block; rows read whole: coalesced) and forms the centroid of the group and of each of
+// its four 16-unit sub-blocks, their |c|^2, and the radii r = max |w - c| (a unit's |w - c|^2 is a wave reduction).
+// Level 1: slot g = group g.  Level 2: slot 16 (g >> 2) + 4 (g & 3) + b = sub-block b of group g -- sixteen consecutive slots are
+// the sub-blocks of four consecutive groups, one 16-row MFMA tile of the level-2 centroid image.  A slot without units:
+// centroid 0, radius -1 (never needed).  The grid covers whole level-2 tiles (n_groups rounded up to four).
+// cmax2 (per level {max |c|^2, max rounding error^2}): a centroid is a mean of units, |c| <= max |w|: the images take the
+// codebook's own scale (no reduction over the centroids); the error slot is reset here and filled by the image kernel.
+struct CentroidLevel { float* C; float* rg; float* csq; float* cmax2; int n_slots; };
+// (eight waves: thread (feature d, quarter q) holds the sixteen units of sub-block q -- a group's 32 KB are in flight at once)
+__global__ __launch_bounds__(512) void exact_centroids_kernel(const float* __restrict__ W, int K, int D, int n_groups,
+                                                              CentroidLevel l1, CentroidLevel l2, const float* __restrict__ wmax2) {
+    __shared__ float qsum[4][128];                            // the sub-blocks' feature sums
+    __shared__ float part[2][64][2];                          // [feature half][unit][group / sub-block]: partial |w - c|^2
+    __shared__ float csq_s[2][5];
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int d = tid & 127, q = tid >> 7, fh = (tid >> 6) & 1;   // feature, sub-block, which 64 features of the 128
+    const long u0 = (long)g * 64 + 16 * q;
+    const int cnt = (int)max(0L, min(64L, (long)K - (long)g * 64));
+    const int cb = max(0, min(16, cnt - 16 * q));
+    if (g == 0 && tid == 0) { l1.cmax2[0] = *wmax2; l1.cmax2[1] = 0.0f; l2.cmax2[0] = *wmax2; l2.cmax2[1] = 0.0f; }
+    float w[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w[k] = (d < D && k < cb) ? W[(u0 + k) * D + d] : 0.0f;
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum += w[k];
+    qsum[q][d] = sum;
+    __syncthreads();
+    const float cs = cb > 0 ? sum / (float)cb : 0.0f;
+    const float cg = cnt > 0 ? ((qsum[0][d] + qsum[1][d]) + (qsum[2][d] + qsum[3][d])) / (float)cnt : 0.0f;
+    if (d < D) {
+        if (q == 0 && g < l1.n_slots) l1.C[(long)g * D + d] = cg;
+        const int j = 16 * (g >> 2) + 4 * (g & 3) + q;
+        if (j < l2.n_slots) l2.C[(long)j * D + d] = cs;
     }
-    for (int k = 0; k < cnt; ++k) {
-        float q = 0.0f;
-        if (tid < D) { const float df = W[(u0 + k) * D + tid] - c; q = df * df; }
-        q = wave_sum(q);                                      // (a NaN anywhere in the unit: NaN)
-        if (lane == 0) part[wave][k] = q;
+    // |c|^2 of the five centroids (float32, any order: the plan's margin covers it)
+    {
+        const float a = wave_sum(cs * cs);
+        if (lane == 0) csq_s[fh][1 + q] = a;
+        if (q == 0) { const float bq = wave_sum(cg * cg); if (lane == 0) csq_s[fh][0] = bq; }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (k >= cb) break;                                   // (uniform over the wave)
+        const float dg = w[k] - cg, ds = w[k] - cs;
+        const float qg = wave_sum(d < D ? dg * dg : 0.0f);    // (a NaN anywhere in the unit: NaN)
+        const float qs = wave_sum(d < D ? ds * ds : 0.0f);
+        if (lane == 0) { part[fh][16 * q + k][0] = qg; part[fh][16 * q + k][1] = qs; }
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < 5) {
+        // thread 0: the group; threads 1..4: its sub-blocks
+        const int b = tid - 1;
+        const int k0 = tid == 0 ? 0 : 16 * b, k1 = tid == 0 ? cnt : min(cnt, 16 * b + 16);
         float m = 0.0f;
-        for (int k = 0; k < cnt; ++k) {
-            const float d2 = part[0][k] + part[1][k];
+        for (int k = k0; k < k1; ++k) {
+            const float d2 = part[0][k][tid == 0 ? 0 : 1] + part[1][k][tid == 0 ? 0 : 1];
             m = (d2 > m || !(d2 == d2)) ? d2 : m;             // (a NaN unit: a NaN radius, the block is never skipped)
         }
         // (the sum of squares in float32, any order: relative error <= 128 * 2^-24; the margin covers it many times over)
-        rg[j] = cnt > 0 ? __builtin_sqrtf(m) * (1.0f + 1.0f / 512.0f) + 1.0e-30f : -1.0f;
+        const float r = k1 > k0 ? __builtin_sqrtf(m) * (1.0f + 1.0f / 512.0f) + 1.0e-30f : -1.0f;
+        const float sq = csq_s[0][tid] + csq_s[1][tid];
+        if (tid == 0) { if (g < l1.n_slots) { l1.rg[g] = r; l1.csq[g] = sq; } }
+        else {
+            const int j = 16 * (g >> 2) + 4 * (g & 3) + b;
+            if (j < l2.n_slots) { l2.rg[j] = r; l2.csq[j] = sq; }
+        }
     }
 }
 
@@ -164,24 +200,66 @@ __device__ __forceinline__ float up_to_half(float v) {
 // The test of the plan, arranged so that the MFMA evaluates all of it but one comparison per (row, centroid):
 //   skip  <=>  d'_c > A(row) + hS (sU(row) + r_c)^2  =  [A + hS sU^2] + hS r_c^2 + 2 hS sU r_c
 //         <=>  (d'_c - hS r_c^2) - (sx sU (1 + 2^-10)) (sw r_c)  >  P(row) := A + hS sU^2,        2 hS = S (1 + 2^-10), S = sx sw.
-// hS r_c^2 leaves the initial accumulator (this kernel rewrites the stage's tail), the cross term is ONE more feature: the
-// rows carry up_to_half(sx sU (1 + 2^-10)), the centroids -up_to_half(sw r_c) -- both rounded up, so the product the MFMA
-// forms is never below the real one (the test errs towards "needed") -- in the first slot of an extra 32-feature step.
-// Tail of stage s afterwards: [0, 64) floats: initial accumulators S'(B' + |c|^2 / 2) - hS r^2, [64, 128): -up_to_half(sw r)
-// (an empty slot: +inf and 0: never needed; a NaN radius: NaN: always needed).
-__global__ __launch_bounds__(256) void exact_plan_tail_kernel(char* __restrict__ Cst, int n_cstages, int stage_bytes,
-                                                              const float* __restrict__ rg, int n_slots,
-                                                              const float* __restrict__ xmax2, const float* __restrict__ cmax2) {
-    const long j = (long)blockIdx.x * 256 + threadIdx.x;
-    if (j >= (long)n_cstages * 64) return;
-    const ExactScales sc = ex_scales(xmax2, cmax2, cmax2 + 1);
-    const float hS = 0.5f * sc.sx * sc.sw * (1.0f + 1.0f / 1024.0f);
-    float* tail = (float*)(Cst + (j / 64 + 1) * (long)stage_bytes - 1024);
-    const int within = (int)(j % 64);
-    const float rad = j < n_slots ? rg[j] : -1.0f;
-    if (rad < 0.0f) { tail[within] = __builtin_inff(); tail[64 + within] = 0.0f; return; }
-    tail[within] = tail[within] - hS * rad * rad * (1.0f + 0x1p-20f);
-    tail[64 + within] = -up_to_half(sc.sw * rad);
+// hS r_c^2 leaves the initial accumulator, the cross term is ONE more feature: the rows carry up_to_half(sx sU (1 + 2^-10)), the
+// centroids -up_to_half(sw r_c) -- both rounded up, so the product the MFMA forms is never below the real one (the test errs
+// towards "needed") -- in the first slot of an extra 32-feature step.
+// The centroid stage images of both levels in one launch (a wave per 16-slot MFMA tile; the tiles of level 1 first): the
+// fragments of -c~ as prep_w_exact_k16_kernel lays out the units' (scaled by the codebook's power of two; the measured rounding
+// error's maximum into cmax2[1]), and the stage's tail: [0, 64) floats: initial accumulators S'(B' + |c|^2 / 2) - hS r^2,
+// [64, 128): -up_to_half(sw r) (an empty slot: +inf and 0: never needed; a NaN radius: NaN: always needed).
+template <int KS32, class EL>
+__global__ __launch_bounds__(256) void exact_centroid_image_kernel(CentroidLevel l1, char* __restrict__ Cst1, int n_cstages1,
+                                                                   CentroidLevel l2, char* __restrict__ Cst2, int n_cstages2, int D,
+                                                                   const float* __restrict__ xmax2, const float* __restrict__ wmax2) {
+    using E = typename EL::T;
+    using bf16x8 = typename V8<E>::t;
+    constexpr int STAGE = k16_stage_bytes(KS32);
+    const int lane = threadIdx.x & 63;
+    long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long t1 = (long)n_cstages1 * K16_T;
+    const bool second = tile >= t1;
+    if (second) tile -= t1;
+    if (tile >= (long)(second ? n_cstages2 : n_cstages1) * K16_T) return;
+    const CentroidLevel& lv = second ? l2 : l1;
+    char* Cst = second ? Cst2 : Cst1;
+    const long stage = tile / K16_T;
+    const int t16 = (int)(tile - stage * K16_T);
+    const long slot = stage * K16_STAGE_UNITS + t16 * 16 + (lane & 15);
+    const float sw = ex_scale(*wmax2), sx = ex_scale(*xmax2);
+    float er = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS32; ++ks) {
+        const int k0 = ks * 32 + (lane >> 4) * 8;
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = (slot < lv.n_slots && k0 + j < D) ? lv.C[slot * D + k0 + j] * sw : 0.0f;
+            const E hb = cvt<E>(-f);
+            v[j] = hb;
+            const float e = half_operand_error(-f, (float)hb);
+            er = __builtin_fmaf(e, e, er);
+        }
+        *(bf16x8*)(Cst + stage * STAGE + ((long)(t16 * KS32 + ks) * 64 + lane) * 16) = v;
+    }
+    er += __shfl_xor(er, 16, 64);                            // the centroid's four feature quarters
+    er += __shfl_xor(er, 32, 64);
+    float m = (er == er) ? er : 0.0f;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) atomic_max_pos_f32(lv.cmax2 + 1, m);
+    if (lane < 16) {
+        float* tail = (float*)(Cst + (stage + 1) * (long)STAGE - 1024);
+        const int within = t16 * 16 + lane;
+        const float rad = slot < lv.n_slots ? lv.rg[slot] : -1.0f;
+        if (rad < 0.0f) { tail[within] = __builtin_inff(); tail[64 + within] = 0.0f; }
+        else {
+            const float big = __builtin_sqrtf(*wmax2) * __builtin_sqrtf(*xmax2) * (1.0f + 1.0f / 1024.0f);   // (ex_scales: B')
+            const float S = sx * sw, hS = 0.5f * S * (1.0f + 1.0f / 1024.0f);
+            const float s0 = __builtin_fmaf(0.5f * S, lv.csq[slot], S * big);
+            tail[within] = s0 - hS * rad * rad * (1.0f + 0x1p-20f);
+            tail[64 + within] = -up_to_half(sw * rad);
+        }
+    }
 }
 
 // The plan: which blocks does a tile of SK_TILE (sorted) rows need?  The resident kernel's MFMA loop over a centroid

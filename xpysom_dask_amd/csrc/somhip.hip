@@ -126,8 +126,9 @@ struct som_handle {
         bool res_valid = false;
         int res_every = 0;                // SOM_EXACT_RESORT=n: re-sort every n-th planned epoch (0: when the order has gone stale)
         int res_since = 0;                // planned epochs since the last sort
-        int res_wait = 1;                 // ... to wait at least before the next one (doubles after a sort that did not pay)
         double res_share_sort = 1.0;      // executed share of the first epoch after the last sort
+        bool res_l2_sort = false, res_l2_last = false;   // ... whether level 2 ran in that epoch / in the last one (shares compare like with like)
+        int res_forced = 8;               // planned epochs after which the rows are sorted in any case (doubles after a forced sort that did not pay)
         double res_share_last = 1.0;      // ... of the last planned epoch
         int64_t resorts = 0, planned = 0; // som_exact_resident_stats
         int *order = nullptr, *sk_keys = nullptr, *sk_keys2 = nullptr, *sk_vals = nullptr;
@@ -1208,25 +1209,20 @@ template <class E>
 int exact_skip_centroids(som_handle* h, const float* xmax2) {
     auto& ex = h->ex;
     const float* Wsrc = h->ex_patch ? h->Wp : h->W;
-    for (int lv = 0; lv < (ex.l2_live ? 2 : 1); ++lv) {
-        auto& c = ex.cen[lv];
-        exact_centroid_kernel<<<dim3((unsigned)c.n_slots), dim3(128), 0, h->stream>>>(Wsrc, h->K, h->D, c.Cc, c.rg, lv);
-        row_sq_f32_kernel<<<dim3((unsigned)cdiv(c.n_slots, 256)), dim3(256), 0, h->stream>>>(c.Cc, c.n_slots, h->D, c.csq);
-        HIPCHK(h, hipMemsetAsync(c.cmax2, 0, 2 * sizeof(float), h->stream));
-        exact_copy_wsq_kernel<<<dim3((unsigned)cdiv(c.n_slots, 1024)), dim3(1024), 0, h->stream>>>(c.csq, c.n_slots, c.wn_c, c.cmax2);
-        const dim3 tgrid((unsigned)cdiv((long)c.n_cstages * K16_T, 4)), block(256);
-        switch (h->ks32) {
-        case 1: prep_w_exact_k16_kernel<1, E><<<tgrid, block, 0, h->stream>>>(c.Cc, c.n_slots, h->D, c.Cst, c.n_cstages, c.cmax2, c.cmax2 + 1); break;
-        case 2: prep_w_exact_k16_kernel<2, E><<<tgrid, block, 0, h->stream>>>(c.Cc, c.n_slots, h->D, c.Cst, c.n_cstages, c.cmax2, c.cmax2 + 1); break;
-        case 3: prep_w_exact_k16_kernel<3, E><<<tgrid, block, 0, h->stream>>>(c.Cc, c.n_slots, h->D, c.Cst, c.n_cstages, c.cmax2, c.cmax2 + 1); break;
-        case 4: prep_w_exact_k16_kernel<4, E><<<tgrid, block, 0, h->stream>>>(c.Cc, c.n_slots, h->D, c.Cst, c.n_cstages, c.cmax2, c.cmax2 + 1); break;
-        default: return fail(h, "exact: block skipping supports input_len <= 128");
-        }
-        const long units = (long)c.n_cstages * h->stage_units;
-        prep_wsqh_kernel<<<dim3((unsigned)cdiv(units, 256)), dim3(256), 0, h->stream>>>(
-            c.wn_c, c.n_slots, c.cmax2, xmax2, c.Cst, c.n_cstages, h->stage_bytes, h->stage_units, nullptr, 0, 1);
-        exact_plan_tail_kernel<<<dim3((unsigned)cdiv(units, 256)), dim3(256), 0, h->stream>>>(c.Cst, c.n_cstages, h->stage_bytes, c.rg, c.n_slots,
-                                                                                           xmax2, c.cmax2);
+    const int n_groups = (int)cdiv(h->K, EX_GROUP);
+    auto& c0 = ex.cen[0];
+    auto& c1 = ex.cen[1];
+    const CentroidLevel l1{c0.Cc, c0.rg, c0.csq, c0.cmax2, c0.n_slots}, l2{c1.Cc, c1.rg, c1.csq, c1.cmax2, c1.n_slots};
+    // two launches for both levels: centroids + radii + |c|^2, then the stage images with their tails (the images take the
+    // codebook's own power of two: a centroid is no longer than the longest unit)
+    exact_centroids_kernel<<<dim3((unsigned)(cdiv(n_groups, 4) * 4)), dim3(512), 0, h->stream>>>(Wsrc, h->K, h->D, n_groups, l1, l2, h->wmax2);
+    const int nst2 = ex.l2_live ? c1.n_cstages : 0;
+    const dim3 tgrid((unsigned)cdiv((long)(c0.n_cstages + nst2) * K16_T, 4)), block(256);
+    switch (h->ks32) {
+#define SOM_CIMG_CASE(k) case k: exact_centroid_image_kernel<k, E><<<tgrid, block, 0, h->stream>>>(l1, c0.Cst, c0.n_cstages, l2, c1.Cst, nst2, h->D, xmax2, h->wmax2); break;
+    SOM_CIMG_CASE(1) SOM_CIMG_CASE(2) SOM_CIMG_CASE(3) SOM_CIMG_CASE(4)
+#undef SOM_CIMG_CASE
+    default: return fail(h, "exact: block skipping supports input_len <= 128");
     }
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -1426,15 +1422,18 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     }
     // the resident sorted pass: (re-)sort when there is none for these rows, when asked to (SOM_EXACT_RESORT=n: every n-th
     // planned epoch), or when the order has gone stale: while a quarter of the blocks or more still run a sort costs a few
-    // percent of the screen it sharpens (the early epochs of a schedule, where rows still travel across the map); later,
-    // when the executed share has grown by a fifth since the epoch after the last sort; and every eighth planned epoch at
-    // the latest (a sort that did not pay doubles the wait).  A stale order costs speed, never correctness: the plan tests
-    // every row of a tile where it sits.
+    // percent of the screen it sharpens (the early epochs of a schedule, where rows still travel across the map); later
+    // every eighth planned epoch, and a sort that did not pay (the share it left is within 7 % of the stale order's, level 2 on
+    // or off in both: the schedule, not the order, moves the share) doubles that interval, up to 64; one that paid resets it.
+    // (Measured, tools/resid_probe.py + bound_probe.py: past a schedule's first epochs an order three epochs old runs the same
+    // blocks as a fresh one; a trigger on the share's growth fired on the schedule's own late growth, where sorting buys nothing.)
+    // A stale order costs speed, never correctness: the plan tests every row of a tile where it sits.
     bool resort = false;
     if (ex.skip_live) {
-        if (!ex.res_valid || ex.res_rows != (const void*)X || ex.res_n != N) resort = true;
+        const bool fresh = !ex.res_valid || ex.res_rows != (const void*)X || ex.res_n != N;
+        if (fresh) resort = true;
         else if (ex.res_every > 0) resort = ex.res_since >= ex.res_every;
-        else resort = ex.res_share_last >= 0.25 || (ex.res_since >= ex.res_wait && (ex.res_share_last > 1.2 * ex.res_share_sort + 0.003 || ex.res_since >= 8));
+        else resort = ex.res_share_last >= 0.25 || ex.res_since >= ex.res_forced;
         // level 2 of the plan (the groups' 16-unit sub-blocks) where it pays.  Whether it does is MEASURED each time it runs
         // (both levels' shares come back with the pass's counters): it costs about a tenth of level 1's share of a full scan
         // (four centroids per kept group), it saves the blocks it drops -- on the smooth maps of a schedule's first epochs
@@ -1442,6 +1441,9 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         // than half.  While it does not pay it is probed again every fourth planned epoch, or at once when level 1's share
         // has moved by half since the last probe.
         bool probe = ex.l1_share_probe < 0.0 || ex.l2_wait <= 0 || ex.l1_share_last > 1.5 * ex.l1_share_probe || ex.l1_share_last < ex.l1_share_probe / 1.5;
+        // (the first plan for these rows: nothing is known about level 1 yet, and on the smooth map of a schedule's second epoch
+        //  it keeps nearly everything -- a probe there ran four times level 1's work to drop 1 % of the blocks)
+        if (fresh) probe = false;
         if (ex.l1_share_last > 0.9 && ex.l1_share_probe >= 0.0 && !ex.l2_pays) probe = false;   // (nothing for four times the centroids to find)
         ex.l2_live = ex.sub_blocks && (ex.l2_pays || probe || ex.skip_mode >= 2) &&
                      2 * (size_t)h->stage_bytes + (size_t)cdiv(n_groups, K16_STAGE_UNITS) * (64 * sizeof(int) + 4 * 8) <= 150 * 1024;   // (its list of kept groups lives in LDS)
@@ -1561,14 +1563,19 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         if (resort) {
             // a sort that did not pay (the share it left is no better than the stale order's: the schedule, not the order,
             // moves the share) doubles the wait before the next one, up to eight epochs; one that paid resets it
-            if (ex.res_valid && ex.res_share_last < 0.25) ex.res_wait = share > 0.93 * ex.res_share_last ? std::min(2 * ex.res_wait, 8) : 1;
-            ex.resorts += 1; ex.res_since = 0; ex.res_share_sort = share; ex.res_valid = true; ex.res_rows = (const void*)X; ex.res_n = N;
+            if (ex.res_valid && ex.res_share_last < 0.25 && ex.res_l2_last == ex.l2_live)
+                ex.res_forced = share <= 0.93 * ex.res_share_last ? 8 : std::min(2 * ex.res_forced, 64);
+            ex.resorts += 1; ex.res_since = 0; ex.res_share_sort = share; ex.res_l2_sort = ex.l2_live; ex.res_valid = true; ex.res_rows = (const void*)X; ex.res_n = N;
         }
         ex.res_since += 1;
-        ex.res_share_last = share;
+        ex.res_share_last = share; ex.res_l2_last = ex.l2_live;
         ex.l1_share_last = (double)groups_run * K16_T / (double)(ex.blocks_total - total_before);
         ex.pairs_per_row_last = (double)pairs_in / (double)std::max<long>(N, 1);
         if (ex.refine_live) { ex.pairs_refined_in += pairs_in; ex.pairs_refined_out += pairs_out; }
+        if (h->debug)
+            std::fprintf(stderr, "[somhip] exact plan %ld: share %.4f level-1 %.4f level-2 %d (paid %d) sorted %d (since %d, next forced at %d) refine %d pairs/row %.2f -> %.2f\n",
+                         (long)ex.planned, share, ex.l1_share_last, ex.l2_live ? 1 : 0, ex.l2_pays ? 1 : 0, resort ? 1 : 0, ex.res_since, ex.res_forced,
+                         ex.refine_live ? 1 : 0, ex.pairs_per_row_last, (double)pairs_out / (double)std::max<long>(N, 1));
         if (ex.l2_live) {
             ex.l2_pays = 1.5 * (ex.l1_share_last - share) > 0.1 * ex.l1_share_last + 0.006;
             ex.l1_share_probe = ex.l1_share_last;
