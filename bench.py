@@ -90,10 +90,6 @@ def kernel_name_for(precision, features, units=1 << 16):
         return "bmu_bf16_k16_kernel"
     if precision == "f32":
         return "bmu_f32_tiled_kernel" if features > 128 else "bmu_f32_res_kernel"
-    if precision in ("bf16x3", "f16x3"):                    # ('f16' / 'f16x3': the bf16 kernels' _Float16 instances)
-        if features > 128:
-            return "bmu_bf16_wide_kernel" if units >= 4096 and 3 * features <= 800 else "bmu_bf16_tiled_kernel"
-        return "bmu_bf16_k16x3_kernel"
     if features > 128:
         wide = units >= 4096 and features <= 800 and os.environ.get("SOM_BF16_WIDE", "1") != "0"
         return "bmu_bf16_wide_kernel" if wide else "bmu_bf16_tiled_kernel"
@@ -209,7 +205,7 @@ def main():
                     help="weak: --rows per GPU (default); strong: --total-rows split over the ranks")
     ap.add_argument("--rows", type=int, default=None, help="weak scaling: rows per GPU (default: the workload's)")
     ap.add_argument("--total-rows", type=int, default=STRONG_TOTAL_ROWS, help="strong scaling: rows of the whole job")
-    ap.add_argument("--precision", default=None, choices=["exact", "bf16", "f32", "bf16x3", "f16", "f16x3"])
+    ap.add_argument("--precision", default=None, choices=["exact", "bf16", "f32", "f16"])
     ap.add_argument("--no-modes", action="store_true", help="skip the per-precision-mode block at batch 65 536")
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the bf16 run beside the exact headline (profiling passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -531,8 +527,8 @@ def main():
         modes = {}
         ref = {}
         w_f32_end = None
-        for prec, flop_peak in (("f32", MFMA_F32_PEAK_TFLOPS), ("exact", MFMA_BF16_PEAK_TFLOPS), ("bf16x3", MFMA_BF16_PEAK_TFLOPS),
-                                ("f16x3", MFMA_BF16_PEAK_TFLOPS), ("f16", MFMA_BF16_PEAK_TFLOPS), ("bf16", MFMA_BF16_PEAK_TFLOPS)):
+        for prec, flop_peak in (("f32", MFMA_F32_PEAK_TFLOPS), ("exact", MFMA_BF16_PEAK_TFLOPS), ("f16", MFMA_BF16_PEAK_TFLOPS),
+                                ("bf16", MFMA_BF16_PEAK_TFLOPS)):
             e2 = mk(prec)
             e2.set_data(xb)
             agree, ep_ms, k_ms = {}, {}, {}
@@ -635,7 +631,7 @@ def main():
         share = head_share if is_exact else 1.0
         flops_launch = KD2 * rows_launch * share
         achieved = flops_launch / (k_avg * 1e-3) / 1e12
-        # algorithmic flops against the peak of the pipe the kernel runs on; bf16x3 executes 3x them.
+        # algorithmic flops against the peak of the pipe the kernel runs on.
         # Block skipping: the flops of the blocks the screens RAN (the kernel's quality), never the full scan's: a launch
         # that proves most blocks empty is fast because it does less, not because the pipe runs faster -- the full scan's
         # algorithmic rate is reported beside it for what it is (rows per second are `value`)
@@ -646,7 +642,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "codebooks_identical_on_all_ranks": ranks_agree,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": {"f32": "f32", "f16": "f16", "f16x3": "f16", "exact": "f16"}.get(args.precision, "bf16"), "data": "synthetic",
+            "dtype": {"f32": "f32", "f16": "f16", "exact": "f16"}.get(args.precision, "bf16"), "data": "synthetic",
             "config": {"workload": "batch-SOM epoch, %dx%d map, %d features, %d Gaussian-blob rows %s resident "
                                    "in HBM (%s), one launch over all resident rows"
                                    % (MAP_X, MAP_Y, FEATURES, my_rows if args.scaling == "weak" else total_rows,
@@ -705,7 +701,7 @@ def main():
         if batch is not None:
             out["roofline"]["batch65536"] = batch
         if modes is not None:
-            out["precision_modes_at_batch65536"] = modes   # 'f32' = the parity mode itself, 'exact' = its BMUs at MFMA-half speed, '*x3' = hi/lo split, 'f16*' = IEEE half operands
+            out["precision_modes_at_batch65536"] = modes   # 'f32' = the parity mode itself, 'exact' = its BMUs at MFMA-half speed, 'f16' = IEEE half operands
         if update_forms is not None:
             out["update_forms"] = update_forms
         if world == 1 and not args.no_cpu_baseline:

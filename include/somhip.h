@@ -48,9 +48,7 @@ enum { SOM_TOPO_RECTANGULAR = 0, SOM_TOPO_HEXAGONAL = 1 };
 /* arithmetic of the distance GEMM (the -2 x.w^T term, distances.py:22):
  *   F32  : v_mfma_f32_32x32x2_f32, exact float32 fma chain -- the parity mode
  *   BF16 : v_mfma_f32_16x16x32_bf16 on bf16-rounded x and w, f32 accumulate -- the throughput mode
- *   BF16X3: the same MFMA on hi/lo-split operands (x_hi.w_hi + x_hi.w_lo + x_lo.w_hi, exact float32
- *           |w|^2): ~2^-16 relative error in x.w at 3x the bf16 work -- near-f32 BMUs, faster than F32
- *   F16 / F16X3: the BF16 / BF16X3 kernels instantiated on IEEE half (v_mfma_f32_16x16x32_f16): 11 significant
+ *   F16  : the BF16 kernels instantiated on IEEE half (v_mfma_f32_16x16x32_f16): 11 significant
  *           bits per operand instead of 8 at the same MFMA rate (97 % of the bf16 throughput under the chip's power
  *           limit); rows and units must fit float16 -- som_set_data / som_set_weights refuse rows and units whose
  *           norm exceeds 65504; streamed chunks and query rows (som_stream_rows, som_bmu) are not checked: values
@@ -67,9 +65,11 @@ enum { SOM_TOPO_RECTANGULAR = 0, SOM_TOPO_HEXAGONAL = 1 };
  *           group) blocks a centroid-and-radius bound around last epoch's BMU proves empty (csrc/exact_skip.hpp;
  *           SOM_EXACT_SKIP=0 runs every block) -- the ids do not change, the time does, by the data.  Everything but
  *           the BMU search (update, merge, quantization) is as in F32. */
-enum { SOM_PREC_F32 = 0, SOM_PREC_BF16 = 1, SOM_PREC_BF16X3 = 2,
+enum { SOM_PREC_F32 = 0, SOM_PREC_BF16 = 1,
+       SOM_PREC_RETIRED_2 = 2,  /* was BF16X3 (hi/lo-split operands, three MFMAs per product): som_create refuses it --
+                                   EXACT returns float32's own BMUs at three to ten times its speed; the id stays reserved */
        SOM_PREC_F16 = 3,      /* the bf16 path on IEEE half operands: 11 significant bits instead of 8, |value| <= 65504 */
-       SOM_PREC_F16X3 = 4,    /* the bf16x3 path on IEEE half hi/lo pairs */
+       SOM_PREC_RETIRED_4 = 4,  /* was F16X3: refused likewise */
        SOM_PREC_EXACT = 5 };  /* F32's BMUs through an IEEE-half MFMA screen + float32 re-score (bmu_exact.hpp) */
 
 /* which BMU rule som_bmu applies */
@@ -214,7 +214,7 @@ int som_bmu_top2(som_handle* h, const float* x_host, int64_t n_rows, int32_t* id
 int som_distance_matrix(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, float* dist_out);
 /* mean_n |x_n - W[bmu_n]|: XPySom.quantization_error, xpysom.py:673-707.  The distance to the chosen unit is
  * always evaluated exactly (float32 differences, float64 sum).  The BMU search is the reference's sqrt'd
- * Euclidean argmin in F32 precision; in BF16 / BF16X3 precision with the 'euclidean' activation distance it
+ * Euclidean argmin in F32 precision; in BF16 / F16 precision with the 'euclidean' activation distance it
  * runs through the configured MFMA path (same argmin up to the operand rounding), as does som_bmu's
  * QUANTIZATION mode. */
 int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, double* qe_out);

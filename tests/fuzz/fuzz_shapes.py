@@ -18,7 +18,7 @@ for case in range(n_cases):
     if os.environ.get("FUZZ_BIGD") and rs.rand() < 0.6:       # with FUZZ_MAXSIDE > 64: the wide kernel's instances (<= 800) and past them
         D = int(rs.choice([160, 224, 333, 416, 512, 640, 784, 800, 801, 900]))
     n = int(rs.choice([1, 2, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1000, 3000]))
-    prec = str(rs.choice(["f32", "bf16", "bf16x3", "f16", "f16x3"]))
+    prec = str(rs.choice(["f32", "bf16", "exact", "f16", "exact"]))
     dist = str(rs.choice(["euclidean", "cosine"]))
     neigh = str(rs.choice(["gaussian", "gaussian", "mexican_hat", "bubble", "triangle"]))
     topo = str(rs.choice(["rectangular", "rectangular", "hexagonal"]))
@@ -31,7 +31,7 @@ for case in range(n_cases):
             Y = X
     std_coeff = float(rs.choice([0.5, 0.5, 0.25, 1.0]))
     p_norm = 2
-    if prec == "f32" and rs.rand() < 0.3:                     # the VALU distances exist in f32 only
+    if prec in ("f32", "exact") and rs.rand() < 0.3:          # the VALU distances exist in f32 only (and serve 'exact')
         dist = str(rs.choice(["manhattan", "norm_p", "norm_p_no_opt", "euclidean_no_opt"]))
         p_norm = int(rs.choice([1, 2, 3, 4]))
         D = min(D, 64)
@@ -74,7 +74,7 @@ for case in range(n_cases):
             scale = np.ones(n)
         # (two units are compared, each with its own operand and norm rounding: 2 * (2^-8 |x||w| + 2^-9 |w|^2) in d^2 for
         #  bf16 -- up to 2^-6.4 of the scale when |w| >> |x|; seed 32 case 377 sits at 1.11 x 2^-7)
-        tol = {"f32": 2.0 ** -18, "bf16x3": 2.0 ** -14, "bf16": 2.0 ** -6, "f16": 2.0 ** -9, "f16x3": 2.0 ** -14}[prec]
+        tol = {"f32": 2.0 ** -18, "exact": 2.0 ** -18, "bf16": 2.0 ** -6, "f16": 2.0 ** -9}[prec]
         ok_bmu = (dd[np.arange(n), bmu] <= dd.min(1) + tol * scale).all() and (dd[np.arange(n), q] <= dd.min(1) + tol * scale).all()
         _, onum, oden = O.update(data, w, np.float64(eta), np.float64(sig), wide=True, forced_bmu=bmu, compact=compact,
                                  std_coeff=std_coeff, neighbourhood=neigh + ("_hex" if topo == "hexagonal" else ""))

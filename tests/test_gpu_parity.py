@@ -318,7 +318,7 @@ def test_reference_unit_test_known_answers():
 # ----------------------------------------------------------------------------- shapes at the edges
 @pytest.mark.parametrize("X,Y,D,n", [(1, 1, 1, 1), (1, 7, 3, 5), (9, 1, 2, 130), (13, 11, 33, 257),
                                      (40, 36, 70, 1000), (3, 3, 130, 64), (50, 50, 5, 129)])
-@pytest.mark.parametrize("precision", ["f32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16", "exact"])
 def test_ragged_shapes_against_oracle(X, Y, D, n, precision):
     data = O.gaussian_blobs(n, D, seed=X * 100 + D)
     w = O.default_codebook(X, Y, D, 42).astype(F32) * 3
@@ -330,11 +330,8 @@ def test_ragged_shapes_against_oracle(X, Y, D, n, precision):
     num, den, bmu = e.epoch_fetch()
     ref = O.bmu_ids(data, w.reshape(-1, D))
     bad = np.flatnonzero(bmu != ref)
-    if precision == "f32":
+    if precision in ("f32", "exact"):
         assert near_tie_mask(data[bad], w.reshape(-1, D)).all()
-    elif precision == "bf16x3":
-        assert len(bad) <= 2e-3 * n + 1
-        assert near_tie_mask(data[bad], w.reshape(-1, D), tol=2.0 ** -13).all()
     else:
         assert len(bad) <= 0.12 * n + 1
         assert bf16_misses_are_near_best(data, w.reshape(-1, D), bmu, bad)
@@ -868,54 +865,21 @@ def test_streamed_epoch_from_pinned_double_buffers():
         assert rel_err(num2, num) < 2e-6 and rel_err(den2, den) < 2e-6
 
 
-# ----------------------------------------------------------------------------- bf16x3 precision
-@pytest.mark.parametrize("X,Y,D,n", [(6, 6, 4, 150), (24, 24, 16, 4096), (20, 30, 12, 3000), (12, 11, 200, 700),
-                                     (64, 64, 32, 20000), (40, 52, 128, 6000)])
-def test_bf16x3_bmus_are_float32_quality(X, Y, D, n):
-    """precision='bf16x3' (hi/lo-split operands, SURVEY §8(b) precision modes): x.w is good to
-    ~2^-16, so a pick differs from the float32 BMU only on float32-scale near-ties, and a differing
-    pick is within 2^-15 (|x| + |w|) of the best distance.  The update path is the shared exact one."""
-    data = O.gaussian_blobs(n, D, seed=D + 1)
-    w = O.default_codebook(X, Y, D, 5).astype(F32) * 3
-    wf = w.reshape(-1, D)
-    e = engine(X, Y, D, precision="bf16x3")
-    e.set_weights(w)
-    e.set_data(data)
-    e.epoch_accumulate(2.0, 0.3, True)
-    num, den, bmu = e.epoch_fetch()
-    ref = O.bmu_ids(data, wf)
-    bad = np.flatnonzero(bmu != ref)
-    assert len(bad) <= max(1, 2e-3 * n), len(bad)
-    if len(bad):
-        x64, w64 = data[bad].astype(np.float64), wf.astype(np.float64)
-        dd = np.sqrt(((x64[:, None, :] - w64[None, :, :]) ** 2).sum(-1))
-        got = dd[np.arange(len(bad)), bmu[bad]]
-        slack = 2.0 ** -15 * (np.linalg.norm(x64, axis=1) + np.linalg.norm(w64, axis=1).max())
-        assert (got <= dd.min(1) + slack).all()
-    _, onum, oden = O.update(data, w, 0.3, 2.0, wide=True, forced_bmu=bmu)
-    assert rel_err(num, onum.reshape(-1, D)) < 1e-5 and rel_err(den, oden.reshape(-1)) < 1e-5
-    q = e.bmu(data[:97])
-    assert (q != bmu[:97]).sum() <= 1
-
-
-def test_bf16x3_exact_ties_and_cosine():
-    g = load_golden("g1_ties")
-    x, w = g["x"].astype(F32), g["w"].astype(F32)
-    X, Y, D = w.shape
-    e = engine(X, Y, D, precision="bf16x3")
-    e.set_weights(w)
-    assert np.array_equal(e.bmu(x), g["ids"])            # small integers: hi is exact, lo is zero
-    e.set_weights(np.zeros_like(w))
-    assert np.array_equal(e.bmu(x), g["ids_zero"])
-    n, D2 = 2000, 48
-    pos = np.abs(O.gaussian_blobs(n, D2, seed=3))
-    wpos = np.abs(O.default_codebook(16, 16, D2, 2).astype(F32))
-    ec = engine(16, 16, D2, precision="bf16x3", distance="cosine")
-    ec.set_weights(wpos)
-    got = ec.bmu(pos)
-    x64, w64 = pos.astype(np.float64), wpos.reshape(-1, D2).astype(np.float64)
-    sim = (x64 @ w64.T) / np.sqrt((x64 ** 2).sum(1)[:, None] * (w64 ** 2).sum(1)[None, :])
-    assert (sim[np.arange(n), got] >= sim.max(1) - 2.0 ** -14).all()
+# ----------------------------------------------------------------------------- retired precisions
+def test_the_split_operand_precisions_are_refused():
+    """'bf16x3' / 'f16x3' (hi/lo-split operands, ids 2 and 4) are retired: precision='exact' returns float32's own BMUs,
+    faster.  The class refuses the names, the library the ids, each with a message that says so."""
+    import ctypes as C
+    from xpysom_dask_amd import XPySom, _lib
+    for name in ("bf16x3", "f16x3"):
+        with pytest.raises(ValueError, match="retired"):
+            XPySom(8, 8, 4, precision=name)
+    lib = _lib.load()
+    for pid in (2, 4):
+        cfg = _lib.SomConfig(8, 8, 4, 0, 0, 0, pid, 0, 0.5, None, 0, 0, 0.0)
+        h = C.c_void_p()
+        assert lib.som_create(C.byref(cfg), C.byref(h)) != 0
+        assert b"retired" in lib.som_last_error(None)
 
 
 # ----------------------------------------------------------------------------- opt-in epoch hipGraph
@@ -947,11 +911,10 @@ def test_epoch_graph_replay_matches_eager_launches(monkeypatch):
 
 # ----------------------------------------------------------------------------- tiled kernel: schedule races
 @pytest.mark.parametrize("X,Y,D,n,precision", [(64, 64, 784, 5000, "bf16"), (100, 90, 257, 7000, "bf16"),
-                                               (256, 256, 128, 20000, "bf16x3"), (2, 2, 129, 257, "bf16"),
+                                               (256, 256, 128, 20000, "f16"), (2, 2, 129, 257, "bf16"),
                                                (256, 16, 640, 3333, "bf16"), (64, 64, 900, 3000, "bf16"),
-                                               (64, 70, 150, 2500, "bf16x3"), (30, 30, 300, 1000, "bf16"),
-                                               (64, 64, 300, 1500, "bf16x3"), (64, 64, 784, 4000, "f16"),
-                                               (40, 40, 400, 2000, "f16"), (64, 64, 128, 9000, "f16x3")])
+                                               (64, 70, 150, 2500, "f16"), (30, 30, 300, 1000, "bf16"),
+                                               (64, 64, 784, 4000, "f16"), (40, 40, 400, 2000, "f16")])
 def test_tiled_kernel_is_repeatable_and_near_best(X, Y, D, n, precision):
     """bmu_bf16_tiled_kernel runs two wave groups one barrier apart over a 4-slot LDS-DMA ring with
     counted vmcnt waits; bmu_bf16_wide_kernel (bf16, 128 < input_len <= 800, maps of >= 4096 units: the
@@ -982,7 +945,7 @@ def test_tiled_kernel_is_repeatable_and_near_best(X, Y, D, n, precision):
     (70, 70, 257, 2049, "euclidean", "3", "bf16"), (64, 64, 400, 1, "euclidean", None, "bf16"),
     (80, 80, 784, 5001, "cosine", None, "bf16"), (64, 64, 800, 257, "euclidean", "7", "bf16"),
     (72, 64, 540, 256, "euclidean", None, "bf16"),
-    (64, 70, 150, 2500, "euclidean", None, "bf16x3"), (64, 64, 266, 700, "cosine", "5", "bf16x3")])   # 3 D <= 800
+    (64, 70, 150, 2500, "euclidean", None, "f16"), (64, 64, 266, 700, "cosine", "5", "f16")])
 def test_wide_kernel_matches_tiled_kernel(monkeypatch, X, Y, D, n, dist, parts, prec):
     """The two bf16 kernels for input_len > 128 compute the same accumulation chain (same operand images, same
     offset B, features in the same order): bmu_bf16_wide_kernel (samples resident in registers, the default on
@@ -1126,7 +1089,7 @@ def test_cosine_resolves_short_rows_as_well_as_long_ones():
     w = np.abs(O.default_codebook(X, Y, D, 406).astype(F32) * 3)
     x64, w64 = data.astype(np.float64), w.reshape(-1, D).astype(np.float64)
     dd = 1 - (x64 @ w64.T) / np.sqrt((x64 ** 2).sum(1)[:, None] * (w64 ** 2).sum(1)[None, :])
-    for precision, tol in (("bf16x3", 2.0 ** -14), ("bf16", 2.0 ** -6)):
+    for precision, tol in (("f16", 2.0 ** -9), ("bf16", 2.0 ** -6)):
         e = engine(X, Y, D, precision=precision, distance="cosine")
         e.set_weights(w)
         got = e.bmu(data)
@@ -1324,13 +1287,13 @@ def test_staged_epoch_equals_the_monolithic_one():
 
 
 @pytest.mark.parametrize("precision,shape", [("f32", (4, 5, 6)), ("bf16", (4, 5, 6)), ("bf16", (64, 65, 200)),
-                                             ("bf16", (5, 5, 200)), ("bf16x3", (4, 5, 6)), ("f32", (6, 6, 150)),
+                                             ("bf16", (5, 5, 200)), ("exact", (4, 5, 6)), ("exact", (64, 64, 16)), ("f32", (6, 6, 150)),
                                              ("f16", (4, 5, 6)), ("f16", (64, 65, 200))])
 def test_nan_semantics_documented_in_design(precision, shape):
     """DESIGN.md 4, known difference: a unit whose distance is NaN never wins (`<` semantics), where numpy.argmin
     returns the FIRST NaN unit; a row whose distances are ALL NaN returns unit 0, as numpy.argmin does.  Only a
     codebook (or a row) that already holds NaN can get there; this pins what the engine does -- in every BMU kernel
-    (resident, wide and tiled bf16 forms, the split kernel, both float32 forms)."""
+    (resident, wide and tiled bf16 forms, the exact mode, both float32 forms)."""
     X, Y, D = shape
     rs = np.random.RandomState(2)
     w = rs.randn(X * Y, D).astype(F32)
@@ -1544,7 +1507,7 @@ def test_g19_norm_p_with_a_real_exponent():
 
 # ----------------------------------------------------------------------------- G17 / G18: wide shapes pinned by the reference
 @pytest.mark.parametrize("decay", ["linear", "exponential"])
-@pytest.mark.parametrize("precision", ["f32", "exact", "bf16", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "exact", "bf16"])
 def test_g17_configs4_semantics_at_a_wide_kernel_shape(decay, precision):
     """cosine + mexican_hat, 784 features, non-negative unit rows (BASELINE configs[4]) on a 64 x 64 map: the reference's
     own BMUs, denominator, strided numerator and merged rows (distances.py:45-59, neighborhoods.py:57-74).  With 784
@@ -1568,9 +1531,9 @@ def test_g17_configs4_semantics_at_a_wide_kernel_shape(decay, precision):
     x64, w64 = data.astype(np.float64), w.reshape(-1, D).astype(np.float64)
     cosd = 1.0 - (x64 @ w64.T) / np.sqrt((x64 ** 2).sum(1)[:, None] * (w64 ** 2).sum(1)[None, :])
     gap = cosd[diff, bmu[diff]] - cosd[diff].min(1)         # how much worse than the best unit the engine's pick is
-    tol = {"f32": 2e-6, "exact": 2e-6, "bf16x3": 2.0 ** -13, "bf16": 2.0 ** -6}[precision]
+    tol = {"f32": 2e-6, "exact": 2e-6, "bf16": 2.0 ** -6}[precision]
     assert (gap <= tol).all(), (precision, gap.max())
-    assert len(diff) <= {"f32": max(2, n // 500), "exact": max(2, n // 500), "bf16x3": n // 100, "bf16": n // 4}[precision], len(diff)
+    assert len(diff) <= {"f32": max(2, n // 500), "exact": max(2, n // 500), "bf16": n // 4}[precision], len(diff)
     if precision == "exact":                                 # (the wide screen served, not the float32 fallback)
         rows, fb, _ = e.exact_stats()
         assert rows == n and fb <= n // 50
@@ -1626,7 +1589,7 @@ def test_g18_bmus_at_the_configs2_shape(state):
     assert zlib.crc32(np.ascontiguousarray(w).tobytes()) == int(g[state + "_w_crc"]), "the codebook recipe left the fixture's"
     ref = g[state + "_bmu"]
     x64, w64 = data.astype(np.float64), w.reshape(-1, D).astype(np.float64)
-    for precision in ("f32", "exact", "bf16x3", "f16", "bf16"):
+    for precision in ("f32", "exact", "f16", "bf16"):
         e = engine(X, Y, D, precision=precision)
         e.set_weights(w)
         ids = e.bmu(data)
@@ -1637,7 +1600,7 @@ def test_g18_bmus_at_the_configs2_shape(state):
         diff = np.flatnonzero(ids != ref)
         got = ((x64[diff] - w64[ids[diff]]) ** 2).sum(1)
         best = ((x64[diff] - w64[ref[diff]]) ** 2).sum(1)
-        slack = {"bf16x3": 2.0 ** -14, "f16": 2.0 ** -9, "bf16": 2.0 ** -6}[precision] * \
+        slack = {"f16": 2.0 ** -9, "bf16": 2.0 ** -6}[precision] * \
             (np.linalg.norm(x64[diff], axis=1) + np.linalg.norm(w64, axis=1).max()) ** 2
         assert (got <= best + slack).all(), precision
 

@@ -11,11 +11,11 @@ from oracle import som_oracle as O
 pytestmark = pytest.mark.gpu
 F32 = np.float32
 
-# every BMU kernel family: float32 resident / tiled, exact (screen + re-score), 16x16x32 resident, split resident, wide, tiled
+# every BMU kernel family: float32 resident / tiled, exact (screen + re-score, resident and wide), 16x16x32 resident, wide, tiled
 CASES = [("f32", 20, 24, 32, "euclidean"), ("f32", 12, 12, 200, "euclidean"), ("f32", 16, 16, 40, "cosine"),
          ("exact", 64, 64, 32, "euclidean"), ("exact", 30, 30, 128, "euclidean"), ("bf16", 64, 64, 96, "euclidean"),
-         ("f16", 24, 20, 17, "euclidean"), ("bf16x3", 20, 24, 100, "euclidean"), ("f16x3", 20, 24, 64, "euclidean"),
-         ("bf16", 64, 66, 200, "cosine"), ("bf16", 12, 12, 300, "euclidean"), ("bf16x3", 64, 64, 150, "euclidean")]
+         ("f16", 24, 20, 17, "euclidean"), ("exact", 64, 64, 150, "euclidean"),
+         ("bf16", 64, 66, 200, "cosine"), ("bf16", 12, 12, 300, "euclidean")]
 
 
 def make(prec, X, Y, D, dist):

@@ -1,4 +1,4 @@
-"""precision='exact' against 'f32', 'bf16x3' and 'bf16' at the north-star batch (256 x 256 x 128, 65 536 rows): epoch
+"""precision='exact' against 'f32', 'f16' and 'bf16' at the north-star batch (256 x 256 x 128, 65 536 rows): epoch
 time, BMU time, agreement with the float32 BMUs and the re-score's load (candidate groups per row, fallback rows) on
 the seeded codebook and on the codebooks of a float32-trained schedule (smooth early maps are the hard case)."""
 import os, sys, time, numpy as np
@@ -11,7 +11,7 @@ X = Y = int(os.environ.get("EX_SIDE", "256"))
 D = int(os.environ.get("EX_D", "128"))
 N = int(os.environ.get("EX_ROWS", "65536"))
 T = int(os.environ.get("EX_EPOCHS", "10"))
-MODES = os.environ.get("EX_MODES", "f32,exact,bf16x3,bf16").split(",")
+MODES = os.environ.get("EX_MODES", "f32,exact,f16,bf16").split(",")
 DIST = os.environ.get("EX_DIST", "euclidean")
 NEIGH = os.environ.get("EX_NEIGH", "gaussian")
 

@@ -32,8 +32,7 @@ sys.path.insert(0, REPO)
 CASES = [
     (16, 16, 12, 3000, "f32"), (24, 20, 32, 2561, "f32"), (40, 33, 7, 1000, "f32"), (13, 9, 130, 700, "f32"),
     (16, 16, 12, 3000, "bf16"), (24, 20, 32, 2561, "bf16"), (32, 32, 128, 4096, "bf16"), (13, 9, 130, 700, "bf16"),
-    (20, 20, 16, 2000, "bf16x3"),
-    (64, 64, 200, 1500, "bf16"), (24, 20, 32, 2561, "f16"), (64, 66, 160, 1200, "f16"), (20, 20, 16, 2000, "f16x3"),   # wide kernel, IEEE half
+    (64, 64, 200, 1500, "bf16"), (24, 20, 32, 2561, "f16"), (64, 66, 160, 1200, "f16"),   # wide kernel, IEEE half
     (24, 20, 32, 2561, "exact"), (64, 64, 128, 4096, "exact"),
     (64, 64, 200, 1500, "exact"), (72, 64, 784, 900, "exact"),                     # the wide screen + two-round re-score
 ]
@@ -61,7 +60,7 @@ def child(case_file, idx):
         x64, w64 = data[wrong].astype(np.float64), w.reshape(-1, D).astype(np.float64)
         dd = (x64 ** 2).sum(1)[:, None] - 2 * x64 @ w64.T + (w64 ** 2).sum(1)[None, :]
         scale = (np.linalg.norm(x64, axis=1) + np.linalg.norm(w64, axis=1).max()) ** 2
-        tol = {"f32": 2.0 ** -18, "exact": 2.0 ** -18, "bf16": 2.0 ** -6, "bf16x3": 2.0 ** -14, "f16": 2.0 ** -9, "f16x3": 2.0 ** -14}[prec]
+        tol = {"f32": 2.0 ** -18, "exact": 2.0 ** -18, "bf16": 2.0 ** -6, "f16": 2.0 ** -9}[prec]
         wrong = wrong[dd[np.arange(len(wrong)), bmu1[wrong]] > dd.min(1) + tol * scale]
     out["wrong_vs_oracle"] = int(len(wrong))
     out["first_vs_second_epoch"] = int((bmu1 != bmu2).sum())

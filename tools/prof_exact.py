@@ -19,7 +19,7 @@ w = rs.rand(X, Y, D) * 2 - 1
 w /= np.linalg.norm(w, axis=-1, keepdims=True)
 data = gaussian_blobs(N, D)
 if state > 0:
-    tr = HipEngine(X, Y, D, precision="bf16x3" if D <= 128 else "exact", distance=DIST, neighborhood=NEIGH)
+    tr = HipEngine(X, Y, D, precision="exact", distance=DIST, neighborhood=NEIGH)
     tr.set_data(data); tr.set_weights(w.astype(np.float32))
     for t in range(state):
         tr.epoch(exponential_decay(min(X, Y) / 2, 1, t, T), exponential_decay(0.5, 0.01, t, T), True)

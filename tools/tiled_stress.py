@@ -6,8 +6,8 @@ rs = np.random.RandomState(7)
 bad_total = 0
 t0 = time.time()
 cases = [(8,8,130,300,"bf16"),(20,13,200,1100,"bf16"),(64,64,784,5000,"bf16"),(100,90,257,7000,"bf16"),
-         (256,256,784,20000,"bf16"),(128,128,1000,9000,"bf16"),(30,30,33,4000,"bf16x3"),(64,64,128,30000,"bf16x3"),
-         (256,256,128,40000,"bf16x3"),(300,200,160,12345,"bf16"),(512,512,784,8192,"bf16"),(70,70,4,50000,"bf16x3"),
+         (256,256,784,20000,"bf16"),(128,128,1000,9000,"bf16"),(30,30,33,4000,"f16"),(64,64,128,30000,"f16"),
+         (256,256,128,40000,"f16"),(300,200,160,12345,"bf16"),(512,512,784,8192,"bf16"),(70,70,4,50000,"f16"),
          (1,5,300,100,"bf16"),(2,2,129,257,"bf16"),(256,16,640,3333,"bf16"),
          # bmu_bf16_wide_kernel (>= 4096 units, <= 800 features): every third instance, ragged rows and units, many parts
          (64,64,129,100000,"bf16"),(67,64,224,77777,"bf16"),(64,70,330,65537,"bf16"),(90,90,416,30001,"bf16"),

@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("SOM_LIB_PATH") or os.path.join(HERE, "libsomhip.so") 
 SOM_DIST = {"euclidean": 0, "euclidean_no_opt": 1, "cosine": 2, "manhattan": 3, "manhattan_no_opt": 3,
             "norm_p": 4, "norm_p_no_opt": 5}
 SOM_NEIGH = {"gaussian": 0, "mexican_hat": 1, "bubble": 2, "triangle": 3}
-SOM_PREC = {"f32": 0, "bf16": 1, "bf16x3": 2, "f16": 3, "f16x3": 4, "exact": 5}
+SOM_PREC = {"f32": 0, "bf16": 1, "f16": 3, "exact": 5}      # (ids 2 and 4: the retired split-operand modes)
 SOM_TOPO = {"rectangular": 0, "hexagonal": 1}
 SOM_BMU_ACTIVATION, SOM_BMU_QUANTIZATION = 0, 1
 SOM_KERNELS = {"bmu": 0, "segsum": 1, "kron": 2, "merge": 3, "prep": 4, "screen": 5}

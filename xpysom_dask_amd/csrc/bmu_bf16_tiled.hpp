@@ -40,16 +40,11 @@ struct TileCfg {
 
 // rows (samples or units) -> fragment-ordered tiles.  One thread per 16-byte chunk.
 // img layout: [block of `brows` rows][kchunk][t16][ks 0..1][lane][8 bf16]  (tile_bytes per (block,kchunk))
-//
-// split (precision 'bf16x3'): every value is split into hi = bf16(v), lo = bf16(v - hi) and the
-// feature axis is tripled -- samples carry [hi | hi | lo], units [hi | lo | hi] -- so the same MFMA
-// contraction yields x_hi.w_hi + x_hi.w_lo + x_lo.w_hi, i.e. x.w to ~2^-16 relative (only lo.lo is
-// dropped) at three times the bf16 work.  split: 0 = plain bf16, 1 = sample pattern, 2 = unit pattern.
 template <class EL = Bf16>
 __global__ __launch_bounds__(256) void prep_tiles_bf16_kernel(const float* __restrict__ A, long rows, int D,
                                                               int n_kchunks, long n_blocks, int brows, int tile_bytes,
                                                               float sign, const float* __restrict__ unit_sq,
-                                                              char* __restrict__ img, int split,
+                                                              char* __restrict__ img,
                                                               const float* __restrict__ scale_max2 = nullptr) {
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
@@ -72,27 +67,17 @@ __global__ __launch_bounds__(256) void prep_tiles_bf16_kernel(const float* __res
     bf16x8 v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        if (split == 0) {
-            float f = (row < rows && k0 + j < D) ? A[row * D + k0 + j] * scale * pow2 : 0.0f;
-            v[j] = cvt<E>(f);
-        } else {
-            const int kv = k0 + j, seg = kv / D, k = kv - seg * D;
-            float f = (row < rows && seg < 3) ? A[row * D + k] * scale : 0.0f;
-            const E hi = cvt<E>(f);
-            const bool want_lo = split == 1 ? seg == 2 : seg == 1;
-            v[j] = want_lo ? cvt<E>(f - (float)hi) : hi;
-        }
+        const float f = (row < rows && k0 + j < D) ? A[row * D + k0 + j] * scale * pow2 : 0.0f;
+        v[j] = cvt<E>(f);
     }
     *(bf16x8*)(img + (blk * n_kchunks + kc) * (long)tile_bytes + ((long)(t16 * TL_KS + ks) * 64 + lane) * 16) = v;
 }
 
 // |a~_row|^2 of bf16-rounded (optionally unit-scaled) rows and their maximum.  One wave per row.
-// exact != 0 ('bf16x3'): the float32 rows themselves, not their bf16 roundings.
 template <class EL = Bf16>
 __global__ __launch_bounds__(256) void rownorm_bf16_kernel(const float* __restrict__ A, long rows, int D,
                                                            const float* __restrict__ unit_sq, int zero_norm,
-                                                           float* __restrict__ norm2, float* __restrict__ max2,
-                                                           int exact) {
+                                                           float* __restrict__ norm2, float* __restrict__ max2) {
     using E = typename EL::T;
     long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
@@ -101,8 +86,7 @@ __global__ __launch_bounds__(256) void rownorm_bf16_kernel(const float* __restri
     if (unit_sq != nullptr) { float q = unit_sq[row]; scale = q > 0.0f ? 1.0f / __builtin_sqrtf(q) : 0.0f; }
     float s = 0.0f;
     for (int k = lane; k < D; k += 64) {
-        float f = A[row * D + k] * scale;
-        if (!exact) f = (float)cvt<E>(f);
+        const float f = (float)cvt<E>(A[row * D + k] * scale);
         s = __builtin_fmaf(f, f, s);
     }
     s = wave_sum(s);

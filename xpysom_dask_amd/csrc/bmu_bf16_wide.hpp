@@ -35,11 +35,10 @@ static_assert(WD_WG_SAMPLES == TileCfg<8, 2, 4>::BM && WD_XTILE == TileCfg<8, 2,
 __host__ __device__ constexpr int wd_stage_bytes(int ks32) { return (WD_T * ks32 + 1) * 1024; }
 
 // codebook -> stage image (the initial accumulators are written by prep_wsqh_kernel: they depend on the row set).
-// split != 0 (precision 'bf16x3', prep_tiles_bf16_kernel): the feature axis is tripled, units carry [hi | lo | hi].
 template <class EL = Bf16>
 __global__ __launch_bounds__(256) void prep_w_bf16_wide_kernel(const float* __restrict__ W, int K, int D, int ks32,
                                                                char* __restrict__ Wst, int n_stages,
-                                                               const float* __restrict__ unit_wsq, int split,
+                                                               const float* __restrict__ unit_wsq,
                                                                const float* __restrict__ scale_max2 = nullptr) {
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
@@ -59,15 +58,8 @@ __global__ __launch_bounds__(256) void prep_w_bf16_wide_kernel(const float* __re
     bf16x8 v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        if (split == 0) {
-            float f = (u < K && k0 + j < D) ? W[u * D + k0 + j] * scale * pow2 : 0.0f;
-            v[j] = cvt<E>(-f);
-        } else {
-            const int kv = k0 + j, seg = kv / D, k = kv - seg * D;
-            float f = (u < K && seg < 3) ? -W[u * D + k] * scale : 0.0f;
-            const E hi = cvt<E>(f);
-            v[j] = seg == 1 ? cvt<E>(f - (float)hi) : hi;
-        }
+        const float f = (u < K && k0 + j < D) ? W[u * D + k0 + j] * scale * pow2 : 0.0f;
+        v[j] = cvt<E>(-f);
     }
     *(bf16x8*)(Wst + stage * wd_stage_bytes(ks32) + ((long)(t16 * ks32 + ks) * 64 + lane) * 16) = v;
 }

@@ -35,8 +35,8 @@ struct SomStamp {
 #define SOM_STAMP_END() do {} while (0)
 #endif
 
-// The 16-bit operand type of the half-precision BMU kernels: __bf16 (precision 'bf16' / 'bf16x3') or _Float16
-// ('f16' / 'f16x3': three more mantissa bits at the same MFMA rate, range 6e-8 .. 65504).  The kernels are templates on
+// The 16-bit operand type of the half-precision BMU kernels: __bf16 (precision 'bf16') or _Float16
+// ('f16', and the exact mode's screen: three more mantissa bits at the same MFMA rate, range 6e-8 .. 65504).  The kernels are templates on
 // its tag (`class EL`, `using E = typename EL::T`); their operand images are the same bytes either way.
 // (kernels take the TAG, not the type: rocprofv3 cannot demangle a 16-bit float type in a kernel's template arguments)
 struct Bf16 { typedef __bf16 T; };

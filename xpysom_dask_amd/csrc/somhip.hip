@@ -20,7 +20,6 @@
 #include "../../include/somhip.h"
 #include "../../include/somhip_test.h"
 #include "bmu_bf16_k16.hpp"
-#include "bmu_bf16_k16x3.hpp"
 #include "bmu_bf16_tiled.hpp"
 #include "bmu_bf16_wide.hpp"
 #include "bmu_exact.hpp"
@@ -71,10 +70,8 @@ struct som_handle {
     hipEvent_t ev_block = nullptr, ev_comm = nullptr;
     int X = 0, Y = 0, K = 0, D = 0, D1p = 0;
     int ks32 = 0;            // bf16, 16x16x32 shape: ceil(D/32)
-    bool tiled = false;      // bf16, input_len > 128 (and bf16x3 always): two-sided tiling (bmu_bf16_tiled.hpp)
-    int x3 = 0;              // precision bf16x3 / f16x3: hi/lo split operands, tripled feature axis
-    bool f16 = false;        // precision f16 / f16x3: _Float16 operands instead of __bf16 (the same kernels, som_common.hpp)
-    bool x3res = false;      // bf16x3 with input_len <= 128: the register-resident split kernel (bmu_bf16_k16x3.hpp)
+    bool tiled = false;      // bf16, input_len > 128: two-sided tiling (bmu_bf16_tiled.hpp)
+    bool f16 = false;        // precision f16: _Float16 operands instead of __bf16 (the same kernels, som_common.hpp)
     bool exact = false;      // precision 'exact': MFMA screen + float32 re-score of the candidates (bmu_exact.hpp)
     // exact mode: the operand images in PATCH ORDER (som_common.hpp; ex_perm[position] = unit, ex_inv[unit] = position) -- prepared
     // from a permuted copy of the codebook; wf_patch: the order the float32 image is in right now (the float32 kernels
@@ -418,7 +415,7 @@ int prep_codebook_half(som_handle* h) {
             }
             long total = (long)h->n_stages * WD_T * h->n_kchunks * 64;
             prep_w_bf16_wide_kernel<E><<<dim3((unsigned)cdiv(total, 256)), block, 0, h->stream>>>(
-                Wex, h->K, h->D, h->n_kchunks, h->Wst, h->n_stages, unit, 0, h->wmax2);
+                Wex, h->K, h->D, h->n_kchunks, h->Wst, h->n_stages, unit, h->wmax2);
             HIPCHK(h, hipMemsetAsync(h->wmax2 + 1, 0, sizeof(float), h->stream));
             exact_werr_kernel<E><<<dim3((unsigned)cdiv(h->K, 4 * EX_WERR_UNITS)), block, 0, h->stream>>>(Wex, h->K, h->D, h->wmax2, h->wmax2 + 1, unit);
             return 0;
@@ -426,30 +423,15 @@ int prep_codebook_half(som_handle* h) {
         if (h->wide) {
             long total = (long)h->n_stages * WD_T * h->n_kchunks * 64;
             prep_w_bf16_wide_kernel<E><<<dim3((unsigned)cdiv(total, 256)), block, 0, h->stream>>>(
-                h->W, h->K, h->D, h->n_kchunks, h->Wst, h->n_stages, unit, h->x3 ? 1 : 0);
+                h->W, h->K, h->D, h->n_kchunks, h->Wst, h->n_stages, unit);
         } else {
             long total = (long)h->n_ublocks * h->n_kchunks * (h->tl_bn / 16) * TL_KS * 64;
             prep_tiles_bf16_kernel<E><<<dim3((unsigned)cdiv(total, 256)), block, 0, h->stream>>>(
-                h->W, h->K, h->D, h->n_kchunks, h->n_ublocks, h->tl_bn, h->tl_wtile, -1.0f, unit, h->Wst, h->x3 ? 2 : 0);
+                h->W, h->K, h->D, h->n_kchunks, h->n_ublocks, h->tl_bn, h->tl_wtile, -1.0f, unit, h->Wst);
         }
         HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
         rownorm_bf16_kernel<E><<<dim3((unsigned)cdiv(h->K, 4)), block, 0, h->stream>>>(
-            h->W, h->K, h->D, unit, unit != nullptr, h->wn, h->wmax2, h->x3);
-        return 0;
-    }
-    if (h->x3res) {
-        const long total = (long)h->n_stages * 2 * K3_T * h->ks32 * 64;
-        const dim3 grid((unsigned)cdiv(total, 256));
-        switch (h->ks32) {
-        case 1: prep_w_bf16_k16x3_kernel<1, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
-        case 2: prep_w_bf16_k16x3_kernel<2, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
-        case 3: prep_w_bf16_k16x3_kernel<3, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
-        case 4: prep_w_bf16_k16x3_kernel<4, E><<<grid, block, 0, h->stream>>>(h->W, h->K, h->D, h->Wst, h->n_stages, unit); break;
-        default: return fail(h, "the split resident kernel supports input_len <= 128");
-        }
-        HIPCHK(h, hipMemsetAsync(h->wmax2, 0, sizeof(float), h->stream));
-        rownorm_bf16_kernel<E><<<dim3((unsigned)cdiv(h->K, 4)), block, 0, h->stream>>>(   // exact float32 |w|^2
-            h->W, h->K, h->D, unit, unit != nullptr, h->wn, h->wmax2, 1);
+            h->W, h->K, h->D, unit, unit != nullptr, h->wn, h->wmax2);
         return 0;
     }
     const long total = (long)h->n_stages * K16_T * h->ks32 * 64;
@@ -665,27 +647,6 @@ int launch_bmu_bf16_k16(som_handle* h, const __bf16* Xb, long N, int* out) {
     return 0;
 }
 
-template <int KS32, class E>
-int launch_bmu_bf16_k16x3(som_handle* h, const __bf16* Xb, long N, int* out) {
-    size_t lds = 2 * (size_t)k3_stage_bytes(KS32);
-    int per_cu = 1;
-    if (int rc = kernel_per_cu(h, (const void*)bmu_bf16_k16x3_kernel<KS32, E>, 64 * K3_NW, lds, &per_cu)) return rc;
-    long blocks = cdiv(N, K3_WG_SAMPLES);
-    if (blocks <= 0 || blocks > 0x7fffffffL) return fail(h, "bmu_bf16x3: row count out of range");
-    const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
-    int parts = choose_parts(h, blocks, slots, h->n_stages);
-    if (h->env_bf16_parts > 0) parts = std::min(h->env_bf16_parts, h->n_stages);
-    if (h->debug)
-        std::fprintf(stderr, "[somhip] bmu_bf16_k16x3: blocks=%ld per_cu=%d slots=%ld parts=%d stages=%d\n", blocks, per_cu, slots,
-                     parts, h->n_stages);
-    // (best64[0..N) was reset by prep_wsqh_kernel, launch_bmu_bf16)
-    bmu_bf16_k16x3_kernel<KS32, E><<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * K3_NW), lds, h->stream>>>(
-        Xb, N, h->Wst, h->n_stages, h->K, h->best64);
-    bmu_finalize_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(h->best64, N, h->K, out);
-    HIPCHK(h, hipGetLastError());
-    return 0;
-}
-
 template <int WS, int NWR, int NWC, class E>
 int launch_bmu_bf16_tiled_cfg(som_handle* h, const __bf16* Ximg, long N, int* out) {
     using C = TileCfg<WS, NWR, NWC>;
@@ -793,15 +754,6 @@ int launch_bmu_half(som_handle* h, const __bf16* Xb, const float* xmax2, long N,
     }
     prep_wsqh_kernel<<<dim3((unsigned)cdiv(std::max(units, N), 256)), dim3(256), 0, h->stream>>>(
         h->wn, h->K, h->wmax2, xmax2, h->Wst, h->n_stages, h->stage_bytes, h->stage_units, h->best64, N);
-    if (h->x3res) {
-        switch (h->ks32) {
-        case 1: return launch_bmu_bf16_k16x3<1, E>(h, Xb, N, out);
-        case 2: return launch_bmu_bf16_k16x3<2, E>(h, Xb, N, out);
-        case 3: return launch_bmu_bf16_k16x3<3, E>(h, Xb, N, out);
-        case 4: return launch_bmu_bf16_k16x3<4, E>(h, Xb, N, out);
-        }
-        return fail(h, "bf16x3 resident kernel supports input_len <= 128");
-    }
     switch (h->ks32) {
     case 1: return launch_bmu_bf16_k16<1, E>(h, Xb, N, out);
     case 2: return launch_bmu_bf16_k16<2, E>(h, Xb, N, out);
@@ -843,7 +795,7 @@ int prep_rows_half(som_handle* h, const float* X, long N, long Np, __bf16* Xb, f
         const long n_blocks = Np / h->tl_bm;
         const long total = n_blocks * h->n_kchunks * (h->tl_bm / 16) * TL_KS * 64;
         prep_tiles_bf16_kernel<E><<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
-            X, N, h->D, h->n_kchunks, n_blocks, h->tl_bm, h->tl_xtile, 1.0f, usq, (char*)Xb, 0, xmax2);
+            X, N, h->D, h->n_kchunks, n_blocks, h->tl_bm, h->tl_xtile, 1.0f, usq, (char*)Xb, xmax2);
         if (N > 0) exact_rowerr_kernel<E><<<dim3((unsigned)cdiv(N, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, usq, xmax2, xerr);
         HIPCHK(h, hipGetLastError());
         return 0;
@@ -858,17 +810,13 @@ int prep_rows_half(som_handle* h, const float* X, long N, long Np, __bf16* Xb, f
         long n_blocks = Np / h->tl_bm;
         long total = n_blocks * h->n_kchunks * (h->tl_bm / 16) * TL_KS * 64;
         prep_tiles_bf16_kernel<E><<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
-            X, N, h->D, h->n_kchunks, n_blocks, h->tl_bm, h->tl_xtile, 1.0f, usq, (char*)Xb, h->x3 ? 1 : 0);
+            X, N, h->D, h->n_kchunks, n_blocks, h->tl_bm, h->tl_xtile, 1.0f, usq, (char*)Xb);
         if (N > 0)
-            rownorm_bf16_kernel<E><<<dim3((unsigned)cdiv(N, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, usq, 0, nullptr, xmax2,
-                                                                                        h->x3);
+            rownorm_bf16_kernel<E><<<dim3((unsigned)cdiv(N, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, usq, 0, nullptr, xmax2);
         HIPCHK(h, hipGetLastError());
         return 0;
     }
-    if (h->x3res)
-        prep_x_bf16x3_kernel<E><<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, 32 * h->ks32, Np, Xb, xmax2,
-                                                                                       unit ? 1 : 0);
-    else if (h->exact) {
+    if (h->exact) {
         // max |x|^2 from the rows' float32 norms (xsq_scratch: computed by the caller), then the rows scaled by ex_scale of it
         if (!xsq_scratch && N > 0) return fail(h, "exact: no row norms");
         float* xerr = exact_err_of(h, xsq_scratch);
@@ -1632,13 +1580,12 @@ int verify_bmu_launch(som_handle* h, const float* X, long N, const int* ids) {
     default: verify_best_kernel<SCORE_COSINE><<<grid, block, lds, h->stream>>>(h->vf_X, h->D, h->W, h->wsq, h->K, h->vf_best); break;
     }
     // the mode's bound on the score gap: 0 = the float32 pick itself (f32, exact); half operands: 4 ub |x||w| (two
-    // units, two operands each) with a margin; split operands: their dropped lo.lo terms
+    // units, two operands each) with a margin
     float tol = 0.0f;
     const int prec = h->cfg.precision;
     const bool cosine = h->cfg.distance == SOM_DIST_COSINE;
     if (prec == SOM_PREC_BF16) tol = 8.0f / 256.0f;
     else if (prec == SOM_PREC_F16) tol = 8.0f / 2048.0f;
-    else if (prec == SOM_PREC_BF16X3 || prec == SOM_PREC_F16X3) tol = 1.0f / 4096.0f;
     if (cosine && tol > 0.0f) tol *= 0.5f;                         // (unit-length operands: |x||w| = 1)
     verify_picks_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(
         h->vf_X, n, h->D, h->W, h->wsq, h->wmax2 ? h->wmax2 : h->wsq, h->vf_rows, h->vf_picks, h->vf_best, cosine ? 1 : 0, tol, h->vf_bad);
@@ -2022,6 +1969,9 @@ int som_create(const som_config* cfg, som_handle** out) {
         return fail(nullptr, "som_create: the hexagonal topology has no triangle neighbourhood (xpysom.py:271-279)");
     if (cfg->precision < SOM_PREC_F32 || cfg->precision > SOM_PREC_EXACT)
         return fail(nullptr, "som_create: unknown precision id");
+    if (cfg->precision == SOM_PREC_RETIRED_2 || cfg->precision == SOM_PREC_RETIRED_4)
+        return fail(nullptr, "som_create: the split-operand precisions (ids 2 and 4: 'bf16x3', 'f16x3') are retired -- "
+                             "precision 'exact' returns float32's own BMUs, faster");
     if (cfg->precision != SOM_PREC_F32 && cfg->precision != SOM_PREC_EXACT) {
         if (cfg->distance == SOM_DIST_EUCLIDEAN_NO_OPT)
             return fail(nullptr, "som_create: bf16 precision implements 'euclidean' and 'cosine' "
@@ -2049,10 +1999,8 @@ int som_create(const som_config* cfg, som_handle** out) {
     h->norm_p = cfg->norm_p > 0 ? cfg->norm_p : 2;
     if (cfg->norm_p_real != 0.0 && (cfg->distance == SOM_DIST_NORM_P || cfg->distance == SOM_DIST_NORM_P_NO_OPT)) h->norm_pr = cfg->norm_p_real;
     h->ks32 = (int)cdiv(h->D, 32);
-    h->x3 = cfg->precision == SOM_PREC_BF16X3 || cfg->precision == SOM_PREC_F16X3;
-    h->f16 = cfg->precision == SOM_PREC_F16 || cfg->precision == SOM_PREC_F16X3 || h->exact;   // (the exact mode's screen: IEEE half)
-    h->x3res = h->x3 && h->D <= 128;
-    h->tiled = ((cfg->precision == SOM_PREC_BF16 || cfg->precision == SOM_PREC_F16 || h->exact) && h->D > 128) || (h->x3 && !h->x3res);
+    h->f16 = cfg->precision == SOM_PREC_F16 || h->exact;   // (the exact mode's screen: IEEE half)
+    h->tiled = (cfg->precision == SOM_PREC_BF16 || cfg->precision == SOM_PREC_F16 || h->exact) && h->D > 128;
     if (h->tiled) {
         // 256 x 256 tiles need enough units to amortise them; SOM_BF16_TILE=128|256 overrides
         h->tl_big = h->K >= 4096;
@@ -2063,10 +2011,10 @@ int som_create(const som_config* cfg, som_handle** out) {
             using C = TileCfg<4, 2, 2>;
             h->tl_bm = C::BM; h->tl_bn = C::BN; h->tl_xtile = C::XTILE; h->tl_wfrag = C::WFRAG; h->tl_wtile = C::WTILE;
         }
-        h->n_kchunks = (int)cdiv(h->x3 ? 3L * h->D : (long)h->D, TL_BK);
+        h->n_kchunks = (int)cdiv((long)h->D, TL_BK);
         h->n_ublocks = (int)cdiv(h->K, h->tl_bn);
     }
-    h->wide = h->tiled && h->tl_big && h->n_kchunks <= 25;     // (bf16x3: the tripled feature axis, input_len <= 266)
+    h->wide = h->tiled && h->tl_big && h->n_kchunks <= 25;
     if (const char* e = dev_env("SOM_BF16_WIDE")) if (std::atoi(e) == 0) h->wide = false;   // A/B: the two-sided tiling
     if (h->exact && h->tiled && !h->wide) {              // no exact screen on the two-sided tiling: the float32 kernels serve
         h->exact = false; h->f16 = false; h->tiled = false;
@@ -2074,9 +2022,9 @@ int som_create(const som_config* cfg, som_handle** out) {
     }
     h->ex_patch = h->exact && h->K >= 2 * EX_GROUP;      // (a map of one group has nothing to order)
     if (const char* e = dev_env("SOM_EXACT_PATCH")) if (std::atoi(e) == 0) h->ex_patch = false;   // A/B: groups = strips of a map row
-    h->dp = h->tiled ? TL_BK * h->n_kchunks : h->x3res ? 2 * 32 * h->ks32 : 32 * h->ks32;
-    h->stage_bytes = h->wide ? wd_stage_bytes(h->n_kchunks) : h->x3res ? k3_stage_bytes(h->ks32) : k16_stage_bytes(h->ks32);
-    h->stage_units = h->wide ? WD_STAGE_UNITS : h->x3res ? K3_STAGE_UNITS : K16_STAGE_UNITS;
+    h->dp = h->tiled ? TL_BK * h->n_kchunks : 32 * h->ks32;
+    h->stage_bytes = h->wide ? wd_stage_bytes(h->n_kchunks) : k16_stage_bytes(h->ks32);
+    h->stage_units = h->wide ? WD_STAGE_UNITS : K16_STAGE_UNITS;
     h->nt = cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT ? (cfg->compact_support ? 4 : 2) : 1;
     h->swapped = cfg->neighborhood == SOM_NEIGH_MEXICAN_HAT && cfg->compact_support && cfg->topology == SOM_TOPO_RECTANGULAR;
     // hexagonal: one copy of the terms per parity class of (unit row, BMU row) -- three classes by the x offset
@@ -2557,7 +2505,7 @@ int som_epoch_merge(som_handle* h) {
     // the half-precision paths whose operand image is a stage image (resident kernel, euclidean; wide kernel,
     // euclidean and cosine): the merge also writes the next epoch's 16-bit operands
     if (h->fuse_merge_prep && ((is_half1(h) && !h->tiled && h->cfg.distance == SOM_DIST_EUCLIDEAN) ||
-                               (h->wide && !h->x3 && !h->exact && h->n_kchunks <= 4 * WD_MP_ITERS))) {
+                               (h->wide && !h->exact && h->n_kchunks <= 4 * WD_MP_ITERS))) {
         if (int rc = SOM_HALF(h, merge_prep_half, h)) return rc;
         HIPCHK(h, hipGetLastError());
         mark_codebook_changed(h);
@@ -2765,7 +2713,7 @@ int som_epoch_fetch(som_handle* h, float* num, float* den, int32_t* bmu) {
 namespace {
 // BMU under the full Euclidean distance for quantization / quantization_error (xpysom.py:632-645, 699-707)
 // of the n_rows rows in the query scratch.  f32 precision: the reference's sqrt'd distance, bit for bit.
-// bf16 / bf16x3 precision with the 'euclidean' activation distance: the same argmin through the configured
+// bf16 / f16 precision with the 'euclidean' activation distance: the same argmin through the configured
 // MFMA path (the squared distance is monotone in it); the caller evaluates the distance itself exactly.
 int run_quantization_bmu(som_handle* h, long n_rows) {
     if (h->cfg.precision != SOM_PREC_F32 && !h->exact && h->cfg.distance == SOM_DIST_EUCLIDEAN) {

@@ -89,10 +89,9 @@ class XPySom:
                          codebook --, found by an IEEE-half MFMA screen and a float32 re-score of the units its error
                          bound cannot rule out; where no screen applies -- small maps, the VALU distances -- the float32
                          kernels themselves serve it), 'f32' (the exact-float32 MFMA kernels over every unit: the parity
-                         mode the default is checked against), 'bf16' (bf16 MFMA distance GEMM),
-                         'bf16x3' (hi/lo-split bf16 MFMA: near-float32 BMUs at a third of the bf16 rate), or the
-                         same two paths on IEEE half operands, 'f16' / 'f16x3' (three more mantissa bits at the
-                         same MFMA rate; rows and units must fit float16: norms <= 65504)
+                         mode the default is checked against), 'bf16' (bf16 MFMA distance GEMM: BMUs within the operand
+                         rounding of float32's), or the same path on IEEE half operands, 'f16' (three more mantissa bits
+                         at the same MFMA rate; rows and units must fit float16: norms <= 65504)
           device         HIP device ordinal (default: LOCAL_RANK or 0)
           sharded_input  under an initialised process group: ``train(data)`` receives only this
                          rank's rows (default: every rank passes the full array and takes its slice)
@@ -145,8 +144,10 @@ class XPySom:
         if not DISTANCES[activation_distance]:
             raise NotImplementedError("activation_distance '%s' is not in the HIP engine yet "
                                       "(SURVEY 8(f) rank 3)" % activation_distance)
-        if precision not in ('f32', 'exact', 'bf16', 'bf16x3', 'f16', 'f16x3'):
-            raise ValueError("precision must be 'f32', 'exact', 'bf16', 'bf16x3', 'f16' or 'f16x3'")
+        if precision in ('bf16x3', 'f16x3'):
+            raise ValueError("precision '%s' is retired: 'exact' returns float32's own BMUs, faster" % precision)
+        if precision not in ('f32', 'exact', 'bf16', 'f16'):
+            raise ValueError("precision must be 'exact', 'f32', 'bf16' or 'f16'")
         # what som_create would refuse is refused here, at construction, as the reference raises at
         # construction (the engine itself is created lazily, on the first train() / winner())
         if neighborhood_function == 'mexican_hat' and compact_support and topology == 'rectangular' and x != y:
