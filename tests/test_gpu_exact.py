@@ -694,7 +694,7 @@ def test_exact_block_skipping_pauses_the_plan_on_rows_without_structure():
 
 # ----------------------------------------------------------------------------- the resident sorted pass, the sub-block plan
 def _train_states(monkeypatch, env, X, Y, D, n, T, data, w):
-    for k in ("SOM_EXACT_RESORT", "SOM_EXACT_SUBBLOCKS", "SOM_EXACT_SKIP", "SOM_EXACT_PASS_ROWS"):
+    for k in ("SOM_EXACT_RESORT", "SOM_EXACT_SUBBLOCKS", "SOM_EXACT_SKIP", "SOM_EXACT_PASS_ROWS", "SOM_EXACT_SUB44"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)

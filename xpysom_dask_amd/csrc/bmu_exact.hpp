@@ -317,11 +317,11 @@ __global__ __launch_bounds__(1024) void exact_tiles_kernel(const int* __restrict
     }
     if (lane == 63) { wsum[wave] = si; wtsum[wave] = ti; }
     __syncthreads();
-    long total = 0, before = 0;
+    long total = 0;
     int ttotal = 0, tbefore = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) {
-        if (w < wave) { before += wsum[w]; tbefore += wtsum[w]; }
+        if (w < wave) tbefore += wtsum[w];
         total += wsum[w]; ttotal += wtsum[w];
     }
     if (tid == 0 && pairs_out != nullptr) *pairs_out = (int)min(total, 0x7fffffffL);

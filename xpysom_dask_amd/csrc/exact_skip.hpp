@@ -81,11 +81,12 @@ __global__ __launch_bounds__(512) void exact_centroids_kernel(const float* __res
     }
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        if (k >= cb) break;                                   // (uniform over the wave)
-        const float dg = w[k] - cg, ds = w[k] - cs;
-        const float qg = wave_sum(d < D ? dg * dg : 0.0f);    // (a NaN anywhere in the unit: NaN)
-        const float qs = wave_sum(d < D ? ds * ds : 0.0f);
-        if (lane == 0) { part[fh][16 * q + k][0] = qg; part[fh][16 * q + k][1] = qs; }
+        if (k < cb) {                                         // (uniform over the wave)
+            const float dg = w[k] - cg, ds = w[k] - cs;
+            const float qg = wave_sum(d < D ? dg * dg : 0.0f);    // (a NaN anywhere in the unit: NaN)
+            const float qs = wave_sum(d < D ? ds * ds : 0.0f);
+            if (lane == 0) { part[fh][16 * q + k][0] = qg; part[fh][16 * q + k][1] = qs; }
+        }
     }
     __syncthreads();
     if (tid < 5) {

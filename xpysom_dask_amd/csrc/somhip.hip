@@ -144,7 +144,7 @@ struct som_handle {
         bool l2_live = false, l2_pays = true;
         int l2_wait = 0;
         // the centroid sets of the plan: [0] the 64-unit groups, [1] their 16-unit sub-blocks (exact_centroid_kernel's slot order)
-        struct Centroids { float *Cc = nullptr, *rg = nullptr, *csq = nullptr, *wn_c = nullptr, *cmax2 = nullptr; char* Cst = nullptr;
+        struct Centroids { float *Cc = nullptr, *rg = nullptr, *csq = nullptr, *cmax2 = nullptr; char* Cst = nullptr;
                            int n_slots = 0, n_cstages = 0; } cen[2];
         unsigned long long *need = nullptr, *need2 = nullptr;
         int *glist = nullptr, *gcnt = nullptr;   // per tile: (group << 4 | sub-block mask) items: what the select kernel walks
@@ -1105,7 +1105,6 @@ int exact_skip_reserve(som_handle* h, long rows_all, long stride) {
             if (int rc = dev_alloc(h, &c.Cc, (size_t)c.n_slots * h->D)) return rc;
             if (int rc = dev_alloc(h, &c.rg, (size_t)c.n_slots)) return rc;
             if (int rc = dev_alloc(h, &c.csq, (size_t)c.n_slots)) return rc;
-            if (int rc = dev_alloc(h, &c.wn_c, (size_t)c.n_slots)) return rc;
             if (int rc = dev_alloc(h, &c.cmax2, 2)) return rc;
             if (int rc = dev_alloc(h, &c.Cst, (size_t)c.n_cstages * h->stage_bytes)) return rc;
             HIPCHK(h, hipMemsetAsync(c.Cst, 0, (size_t)c.n_cstages * h->stage_bytes, h->stream));
@@ -2169,7 +2168,7 @@ void som_destroy(som_handle* h) {
                       h->ex.seed_s, h->ex.sU_s, h->ex.lastpos_s, h->ex.need, h->ex.need2, h->ex.glist, h->ex.gcnt, h->ex.tile_counts, h->ex.tlist, h->ex.tcnt};
         for (void* b : eb) if (b) (void)hipFree(b);
         for (auto& c : h->ex.cen) {
-            void* cb[] = {c.Cc, c.rg, c.csq, c.wn_c, c.cmax2, c.Cst};
+            void* cb[] = {c.Cc, c.rg, c.csq, c.cmax2, c.Cst};
             for (void* b : cb) if (b) (void)hipFree(b);
         }
         if (h->ex.fb_count_host) (void)hipHostFree(h->ex.fb_count_host);
