@@ -2237,6 +2237,16 @@ static int adopt_rows(som_handle* h, int64_t n_rows) {
         if (!(m2 <= HALF_MAX * HALF_MAX))
             return fail(h, "som_set_data: precision 'f16' needs rows of norm <= 65504 (float16 range): scale the data, or use 'bf16' / 'f32'");
     }
+    if (h->exact && n_rows > 0) {
+        // the exact mode's pass scratch and, where block skipping can engage, the resident sorted pass's buffers: allocated with
+        // the rows, not inside the first epochs (gigabytes of fresh device memory can take a driver tens to hundreds of
+        // milliseconds).  A refusal here is not an error: launch_bmu_exact asks again and settles it (smaller passes, no plan).
+        bool ok = exact_reserve(h, n_rows) == 0;
+        const long n_groups = cdiv(h->K, EX_GROUP);
+        if (ok && h->ex.skip_mode > 0 && h->ex.seed_on && !h->wide && (h->ex.skip_mode > 1 ? n_groups >= 2 : h->K >= 4096))
+            ok = exact_skip_reserve(h, n_rows, h->ex.stride) == 0;
+        if (!ok) { (void)hipGetLastError(); h->err.clear(); }
+    }
     return 0;
 }
 
