@@ -1388,9 +1388,8 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         // than half.  While it does not pay it is probed again every fourth planned epoch, or at once when level 1's share
         // has moved by half since the last probe.
         bool probe = ex.l1_share_probe < 0.0 || ex.l2_wait <= 0 || ex.l1_share_last > 1.5 * ex.l1_share_probe || ex.l1_share_last < ex.l1_share_probe / 1.5;
-        // (the first plan for these rows: nothing is known about level 1 yet, and on the smooth map of a schedule's second epoch
-        //  it keeps nearly everything -- a probe there ran four times level 1's work to drop 1 % of the blocks)
-        if (fresh) probe = false;
+        // (a new row set starts like a new engine: level 2 is taken to pay until it has been measured on these rows)
+        if (fresh) { ex.l2_pays = true; ex.l1_share_probe = -1.0; }
         if (ex.l1_share_last > 0.9 && ex.l1_share_probe >= 0.0 && !ex.l2_pays) probe = false;   // (nothing for four times the centroids to find)
         ex.l2_live = ex.sub_blocks && (ex.l2_pays || probe || ex.skip_mode >= 2) &&
                      2 * (size_t)h->stage_bytes + (size_t)cdiv(n_groups, K16_STAGE_UNITS) * (64 * sizeof(int) + 4 * 8) <= 150 * 1024;   // (its list of kept groups lives in LDS)
