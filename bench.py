@@ -198,8 +198,8 @@ def self_launch(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS), help="c3 = the metric's configuration (default)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --rows per GPU (default); strong: --total-rows split over the ranks")
