@@ -201,6 +201,12 @@ int som_epoch_accumulate_forced(som_handle* h, const int32_t* bmu_host, double s
 /* BMU ids for arbitrary rows: XPySom.winner, xpysom.py:370-408 (mode ACTIVATION)
  * and XPySom._quantization, xpysom.py:632-645 (mode QUANTIZATION). */
 int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, int32_t* ids_out);
+/* ... for rows that already live in HBM (float32 [n_rows][input_len], borrowed for the call; order the engine behind their
+ * producer with som_sync_producer first): no host round trip -- what the reference's winner() is on a CuPy array
+ * (xpysom.py:379-396).  ids_out: host memory.  In EXACT precision large row sets run under a plan (the scout of
+ * csrc/exact_skip.hpp gives every row a pseudo last BMU from the current codebook's own group centroids): the same ids,
+ * a fraction of the distance GEMM. */
+int som_bmu_device(som_handle* h, const void* x_dev, int64_t n_rows, int32_t mode, int32_t* ids_out);
 /* best and second-best unit per row under the full Euclidean distance (sqrt + nan_to_num):
  * what XPySom.topographic_error takes from argsort(distances)[:, :2], xpysom.py:727-734 */
 /* float64 query rows (XPySom.winner does not coerce its input, xpysom.py:379-396: float64 x against float32 weights is
@@ -218,6 +224,10 @@ int som_distance_matrix(som_handle* h, const float* x_host, int64_t n_rows, int3
  * runs through the configured MFMA path (same argmin up to the operand rounding), as does som_bmu's
  * QUANTIZATION mode. */
 int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, double* qe_out);
+/* ... of rows that already live in HBM (see som_bmu_device).  In EXACT precision with the 'euclidean' activation distance
+ * the BMU search of both calls is the screen + float32 re-score (the float32 argmin of |w|^2 - 2 x.w: where the sqrt'd
+ * distance ties two units this may name the other one -- at the same distance, which is all this call returns). */
+int som_quantization_error_device(som_handle* h, const void* x_dev, int64_t n_rows, double* qe_out);
 
 /* The canary.  n_rows > 0: after every BMU launch (epochs, streamed chunks, som_bmu) n_rows strided rows are scored
  * again by the float32 parity kernel and the launch's own picks must be the float32 picks (F32, EXACT) or within the
@@ -244,6 +254,10 @@ int som_exact_skip_stats(som_handle* h, int64_t* blocks_run, int64_t* blocks_tot
 /* ... and the resident sorted pass behind it: epochs that ran under a plan, and how many of them (re-)sorted the rows by
  * their last BMU's patch first (the others reused the order of an earlier epoch) */
 int som_exact_resident_stats(som_handle* h, int64_t* planned_epochs, int64_t* sorts);
+/* ... and the scout (csrc/exact_skip.hpp: pseudo last BMUs from the current codebook's own group centroids, for rows that
+ * have no last BMU -- query rows, streamed chunks, a row set's first epoch -- and for a schedule's first epochs): BMU
+ * launches that ran it, and launches over transient row sets (queries, streamed chunks) that ran under a plan */
+int som_exact_scout_stats(som_handle* h, int64_t* scouted_launches, int64_t* transient_planned);
 /* ... and the refinement pass between the screen and the float32 re-score (csrc/bmu_exact.hpp: both operands' second
  * half-precision halves, a window some twenty times narrower than the screen's): candidate (row, group) pairs it was
  * given, and how many of them it left for the re-score */

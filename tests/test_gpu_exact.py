@@ -581,7 +581,8 @@ def test_exact_block_skipping_skips_most_of_a_trained_benchmark_map(monkeypatch)
         shares.append((r1 - r0) / (t1 - t0))
         assert np.array_equal(f.epoch_fetch()[2], x.epoch_fetch()[2]), t
         f.epoch_merge(); x.epoch_merge()
-    assert shares[0] == 1.0 and max(shares[3:]) < 0.5 and min(shares[3:]) < 0.2, shares
+    # (epoch 0: a random codebook -- the scout's plan runs and keeps (nearly) everything)
+    assert shares[0] > 0.9 and max(shares[3:]) < 0.5 and min(shares[3:]) < 0.2, shares
     f.close(); x.close()
 
 

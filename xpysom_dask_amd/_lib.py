@@ -63,10 +63,12 @@ SIGNATURES = {
     "som_epoch_fetch": (C.c_int, [_H, _F, _F, _I]),
     "som_epoch_accumulate_forced": (C.c_int, [_H, _I, C.c_double, C.c_double, C.c_int]),
     "som_bmu": (C.c_int, [_H, _F, C.c_int64, C.c_int32, _I]),
+    "som_bmu_device": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_int32, _I]),
     "som_bmu_top2": (C.c_int, [_H, _F, C.c_int64, _I, _I]),
     "som_bmu_f64": (C.c_int, [_H, C.POINTER(C.c_double), C.c_int64, _I]),
     "som_distance_matrix": (C.c_int, [_H, _F, C.c_int64, C.c_int32, _F]),
     "som_quantization_error": (C.c_int, [_H, _F, C.c_int64, C.POINTER(C.c_double)]),
+    "som_quantization_error_device": (C.c_int, [_H, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]),
     "som_set_verify": (C.c_int, [_H, C.c_int32]),
     "som_verify_stats": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "som_debug_corrupt_operands": (C.c_int, [_H, C.c_int32]),
@@ -76,6 +78,7 @@ SIGNATURES = {
     "som_exact_stats": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "som_exact_skip_stats": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "som_exact_resident_stats": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "som_exact_scout_stats": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "som_exact_refine_stats": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "som_exact_last_counts": (C.c_int, [_H, _I, C.c_int64]),
     "som_sync": (C.c_int, [_H]),

@@ -215,10 +215,11 @@ __global__ __launch_bounds__(64 * KS32) void merge_prep_k16_kernel(float* __rest
 // hence of the minimum so far: only those are stored (gmin[stage * gm_stride + row], exec-masked), and every wave and
 // stage leaves the 64-bit mask of the lanes it stored in gflags[(row / 64) * n_stages + stage] -- on a random
 // codebook ~2 % of the matrix is written and read, on the smoothest maps 10-25 %.
-// TL (GM with block skipping, exact_skip.hpp): the workgroup walks its tile's LIST of items (stage << 4 | mask of the stage's
-// 16-unit tiles to run) instead of all stages; only the listed tiles' fragments are staged and multiplied.
+// TL (block skipping, exact_skip.hpp): the workgroup walks its tile's dense LIST of 16-unit tiles (group << 2 | sub-block)
+// instead of all stages; only the listed tiles' fragments are staged and multiplied.  With GM: the exact mode's screen
+// under a plan.  Without: the scout's pick of a pseudo last BMU among a tile's few listed groups (unit indices kept).
 template <int KS32, class EL = Bf16, bool GM = false, bool TL = false>
-__global__ __launch_bounds__(64 * K16_NW, TL ? 3 : 2) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
+__global__ __launch_bounds__(64 * K16_NW, (TL && GM) ? 3 : 2) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
                                                               const char* __restrict__ Wst, int n_stages, int K,
                                                               unsigned long long* __restrict__ out64,
                                                               uint32_t* __restrict__ gmin = nullptr, long gm_stride = 0,
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(64 * K16_NW, TL ? 3 : 2) void bmu_bf16_k16_kernel(c
         }
     }
     // this workgroup's share of the codebook stages: the loop index s walks [s_begin, s_end)  (TL: see the tile-list loop below)
-    static_assert(!TL || GM, "tile lists belong to the exact mode's screen");
+    // (TL without GM: the scout of exact_skip.hpp -- the plain kernel, unit indices kept, over a tile's few listed groups)
     const int n_walk = n_stages;
     const int s_begin = TL ? 0 : (int)((long)n_walk * blockIdx.y / gridDim.y);
     const int s_end = TL ? 0 : (int)((long)n_walk * (blockIdx.y + 1) / gridDim.y);
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(64 * K16_NW, TL ? 3 : 2) void bmu_bf16_k16_kernel(c
                 for (int ks = 0; ks < KS32; ++ks)
 #pragma unroll
                     for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = mfma16(a[ks], xf[sb][ks], acc[sb]);
-                reduce_tile(acc, 0);
+                reduce_tile(acc, e & 3);                       // (GM: values only, the tile's place in its group is not kept)
                 if (e_next < 0 || (e_next >> 2) != (e >> 2)) fold_stage(e >> 2, true);
             };
             // (the tiles' operands alternate between two register sets: the next tile's are read under this tile's MFMAs)

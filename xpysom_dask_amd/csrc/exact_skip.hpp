@@ -211,7 +211,8 @@ __device__ __forceinline__ float up_to_half(float v) {
 template <int KS32, class EL>
 __global__ __launch_bounds__(256) void exact_centroid_image_kernel(CentroidLevel l1, char* __restrict__ Cst1, int n_cstages1,
                                                                    CentroidLevel l2, char* __restrict__ Cst2, int n_cstages2, int D,
-                                                                   const float* __restrict__ xmax2, const float* __restrict__ wmax2) {
+                                                                   const float* __restrict__ xmax2, const float* __restrict__ wmax2,
+                                                                   char* __restrict__ Cst1_plain = nullptr) {
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     constexpr int STAGE = k16_stage_bytes(KS32);
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(256) void exact_centroid_image_kernel(CentroidLevel
             er = __builtin_fmaf(e, e, er);
         }
         *(bf16x8*)(Cst + stage * STAGE + ((long)(t16 * KS32 + ks) * 64 + lane) * 16) = v;
+        if (!second && Cst1_plain != nullptr) *(bf16x8*)(Cst1_plain + stage * STAGE + ((long)(t16 * KS32 + ks) * 64 + lane) * 16) = v;
     }
     er += __shfl_xor(er, 16, 64);                            // the centroid's four feature quarters
     er += __shfl_xor(er, 32, 64);
@@ -252,13 +254,16 @@ __global__ __launch_bounds__(256) void exact_centroid_image_kernel(CentroidLevel
         float* tail = (float*)(Cst + (stage + 1) * (long)STAGE - 1024);
         const int within = t16 * 16 + lane;
         const float rad = slot < lv.n_slots ? lv.rg[slot] : -1.0f;
-        if (rad < 0.0f) { tail[within] = __builtin_inff(); tail[64 + within] = 0.0f; }
+        // (the scout's copy of the level-1 image: the plain screen value of the centroid, S'(B' + |c|^2 / 2) -- nearest centroid)
+        float* ptail = (!second && Cst1_plain != nullptr) ? (float*)(Cst1_plain + (stage + 1) * (long)STAGE - 1024) : nullptr;
+        if (rad < 0.0f) { tail[within] = __builtin_inff(); tail[64 + within] = 0.0f; if (ptail) ptail[within] = __builtin_inff(); }
         else {
             const float big = __builtin_sqrtf(*wmax2) * __builtin_sqrtf(*xmax2) * (1.0f + 1.0f / 1024.0f);   // (ex_scales: B')
             const float S = sx * sw, hS = 0.5f * S * (1.0f + 1.0f / 1024.0f);
             const float s0 = __builtin_fmaf(0.5f * S, lv.csq[slot], S * big);
             tail[within] = s0 - hS * rad * rad * (1.0f + 0x1p-20f);
             tail[64 + within] = -up_to_half(sw * rad);
+            if (ptail) ptail[within] = (s0 == s0 && s0 < 3.0e38f) ? s0 : __builtin_inff();
         }
     }
 }
@@ -284,7 +289,8 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16
                                                                     const int* __restrict__ lastpos, const char* __restrict__ Wst,
                                                                     float* __restrict__ seed_s,
                                                                     const unsigned long long* __restrict__ need1, int n_cstages1,
-                                                                    int force_all) {
+                                                                    int force_all, const int* __restrict__ lastpos2 = nullptr,
+                                                                    int gate = 0) {
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     constexpr int DP = 32 * KS32;
@@ -318,19 +324,26 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16
                 // v_u: the screen's value of unit u = the row's last BMU on the operands the screen reads (-w~ fragments of
                 // the stage image, the row's x~), a float32 fma chain: every product of two halves is exact, the chain and
                 // the two cross-quad adds err by < 40 ulps of the largest accumulator magnitude (charged: e_valu)
-                const int pos = lastpos[row];                     // (exact_lastpos_kernel: a position below K)
-                const char* stg = Wst + (long)(pos >> 6) * STAGE;
-                const int t16 = (pos >> 4) & 3, c = pos & 15;
-                float d = 0.0f;
+                // (lastpos2: a second unit per row -- the scout's pick beside the real last BMU --: the smaller value bounds as well)
+                auto value_of = [&](int pos) -> float {           // (a position below K: exact_lastpos_kernel, exact_scout_pos_kernel)
+                    const char* stg = Wst + (long)(pos >> 6) * STAGE;
+                    const int t16 = (pos >> 4) & 3, c = pos & 15;
+                    float d = 0.0f;
 #pragma unroll
-                for (int ks = 0; ks < KS32; ++ks) {
-                    const bf16x8 a = *(const bf16x8*)(stg + ((t16 * KS32 + ks) * 64 + quad * 16 + c) * 16);
+                    for (int ks = 0; ks < KS32; ++ks) {
+                        const bf16x8 a = *(const bf16x8*)(stg + ((t16 * KS32 + ks) * 64 + quad * 16 + c) * 16);
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) d = __builtin_fmaf((float)a[jj], (float)xf[sb][ks][jj], d);
+                        for (int jj = 0; jj < 8; ++jj) d = __builtin_fmaf((float)a[jj], (float)xf[sb][ks][jj], d);
+                    }
+                    d += __shfl_xor(d, 16, 64);
+                    d += __shfl_xor(d, 32, 64);
+                    return *(const float*)(stg + K16_T * KS32 * 1024 + (t16 * 16 + c) * 4) + d;
+                };
+                float vu = value_of(lastpos[row]);
+                if (lastpos2 != nullptr) {
+                    const float v2 = value_of(lastpos2[row]);
+                    vu = (v2 < vu || !(vu == vu)) ? v2 : vu;      // (a NaN value -- a NaN unit -- gives way to the other unit's)
                 }
-                d += __shfl_xor(d, 16, 64);
-                d += __shfl_xor(d, 32, 64);
-                const float vu = *(const float*)(stg + K16_T * KS32 * 1024 + (t16 * 16 + c) * 4) + d;
                 const float Sw = sw.sx * sw.sw;
                 const float e = ex_row_bound(eb, sw, q, xe);          // two-unit window E of the screen (d' units)
                 const float f32s = ex_f32_share(eb, sw, q);           // its float32 share (two evaluations)
@@ -399,6 +412,19 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16
         }
         __syncthreads();
         const int n_act = act_n;
+        // GATE (launches for which the host has no measurement of level 2's worth yet: a row set's first planned epoch, query
+        // rows): a tile that level 1 left with more than half of all groups has rows far from the whole map (the smooth maps of
+        // a schedule's first epochs, rows without structure) -- the sub-blocks' radii are small against that distance and their
+        // centroids prove little more (tools/ucent_probe.py: 0.86 -> 0.78 of the blocks where level 1 keeps 0.86), while level
+        // 2 would cost a sixteenth of the full scan and more: every sub-block of every kept group runs, no MFMA here
+        if (gate && 2 * n_act > n_slots / 4) {
+            if (blockIdx.y == 0)
+                for (int i = tid; i < n_act; i += 64 * K16_NW) {
+                    const int g = act[i];
+                    atomicOr(need + (long)blockIdx.x * n_cstages + (g >> 4), 15ull << (4 * (g & 15)));
+                }
+            return;
+        }
         const int c_all = (n_act + 15) / 16;
         const int b0 = 16 * (int)((long)c_all * blockIdx.y / gridDim.y);
         const int e0 = min(n_act, 16 * (int)((long)c_all * (blockIdx.y + 1) / gridDim.y));
@@ -663,6 +689,96 @@ __global__ __launch_bounds__(1024) void exact_list_totals_kernel(const int2* __r
         for (int w = 0; w < 16; ++w) { b += sb[w]; k += sk[w]; }
         *blocks_run = b; *groups_run = k;
     }
+}
+
+// ---- the SCOUT: a bound for rows WITHOUT a last BMU (query rows, streamed chunks, a row set's first epoch) and for the
+// epochs in which last epoch's BMU says little (a schedule's first epochs: rows still travel across the map).
+//   1. every row's nearest GROUP centroid g*: the plain resident kernel (bmu_bf16_k16_kernel<.., false, false>) on the plain
+//      copy of the level-1 centroid image -- 1/64 of a full scan.
+//   2. the rows sorted by g* (the radix sort of update.hpp), their operands gathered in that order: the 256 rows of a tile
+//      then share one or two groups.
+//   3. per tile the set of its rows' groups (+, where last epoch's BMUs exist, those units' groups) as a tile list
+//      (exact_scout_lists_kernel), and the resident kernel once more over those few groups, unit indices kept
+//      (bmu_bf16_k16_kernel<.., GM = false, TL = true>): the best unit among them is the row's PSEUDO last BMU.
+// Every unit of g* is within r of the centroid, so that unit is no farther than |x - c_g*| + r_g*: the centroid-only bound
+// U_c of tools/ucent_probe.py, and usually much nearer.  Any unit gives a valid bound: the plan's prologue (exact_plan_kernel)
+// evaluates the unit it is handed rigorously, whatever picked it -- the scout runs in half precision and owes nothing.
+__global__ __launch_bounds__(256) void exact_groupkey_kernel(const int* __restrict__ g, long n, int n_groups, int* __restrict__ keys,
+                                                             int* __restrict__ vals) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int v = g[i];
+    keys[i] = v < 0 ? 0 : v >= n_groups ? n_groups - 1 : v;
+    vals[i] = (int)i;
+}
+
+// per 256-row tile of the sorted pass: the distinct groups of its rows' keys (gkey[p]: ascending over the pass) and, where
+// lastpos is given, of their last BMUs (lastpos[p] >> 6) -- a bitmap of the groups in LDS -- as the tile's dense list of
+// 16-unit tiles (all four of every group, ascending: what bmu_bf16_k16_kernel<.., TL> walks).  One wave per tile.
+__global__ __launch_bounds__(64) void exact_scout_lists_kernel(const int* __restrict__ gkey, const int* __restrict__ lastpos, long n,
+                                                               int n_groups, int* __restrict__ tlist, int* __restrict__ tcnt) {
+    extern __shared__ unsigned long long sbm[];
+    const long tile = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int nw = (n_groups + 63) / 64;
+    for (int w = lane; w < nw; w += 64) sbm[w] = 0ull;
+    __syncthreads();
+    for (int i = 0; i < SK_TILE / 64; ++i) {
+        const long p = tile * SK_TILE + i * 64 + lane;
+        if (p < n) {
+            int g = gkey[p];
+            g = g < 0 ? 0 : g >= n_groups ? n_groups - 1 : g;
+            atomicOr(sbm + (g >> 6), 1ull << (g & 63));
+            if (lastpos != nullptr) {
+                int g2 = lastpos[p] >> 6;
+                g2 = g2 < 0 ? 0 : g2 >= n_groups ? n_groups - 1 : g2;
+                atomicOr(sbm + (g2 >> 6), 1ull << (g2 & 63));
+            }
+        }
+    }
+    __syncthreads();
+    int base = 0;
+    int* out = tlist + tile * 4 * (long)n_groups;
+    for (int w0 = 0; w0 < nw; w0 += 64) {
+        unsigned long long word = w0 + lane < nw ? sbm[w0 + lane] : 0ull;
+        const int c = __popcll(word);
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        int at = base + incl - c;
+        for (; word != 0ull; word &= word - 1ull) {
+            const int g = (w0 + lane) * 64 + (int)__builtin_ctzll(word);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) out[4 * at + b] = (g << 2) | b;
+            ++at;
+        }
+        base += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) tcnt[tile] = 4 * base;
+}
+
+// Is a plan from the scout worth its launches at all?  SAMPLE TILES: every stride-th 256-row tile of the pass in its sorted
+// order -- the very tiles the plan would see -- copied out (their rows' ids and sort keys) as a small pass of its own; the host
+// gathers, picks and plans that sample exactly as it would the pass and reads the executed share back before committing the
+// whole pass to the gather, the pick and the plan (somhip.hip, launch_bmu_exact).
+__global__ __launch_bounds__(256) void exact_sample_tiles_kernel(const int* __restrict__ order, const int* __restrict__ keys, long stride_tiles,
+                                                                 int* __restrict__ order_out, int* __restrict__ keys_out) {
+    const long src = (long)blockIdx.x * stride_tiles * SK_TILE + threadIdx.x;
+    const long dst = (long)blockIdx.x * SK_TILE + threadIdx.x;
+    static_assert(SK_TILE == 256, "one thread per row of a tile");
+    order_out[dst] = order[src];
+    keys_out[dst] = keys[src];
+}
+
+// the scout's pick per sorted position -> lastpos (a position below K: what the plan's prologue evaluates), and the merge
+// keys back to all ones for the screen proper
+__global__ __launch_bounds__(256) void exact_scout_pos_kernel(unsigned long long* __restrict__ best64, long n, int K,
+                                                              int* __restrict__ lastpos) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t u = (uint32_t)best64[p];
+    lastpos[p] = u < (uint32_t)K ? (int)u : 0;               // (a NaN row: any unit gives a valid bound)
+    best64[p] = ~0ull;
 }
 
 }  // namespace somhip

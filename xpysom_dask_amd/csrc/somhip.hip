@@ -40,7 +40,7 @@ thread_local std::string g_create_error;
 // else -- A/B switches of kernel variants, forced pass sizes, refused allocations -- belongs to the tests and the tools and is
 // read ONLY when SOM_TEST_HOOKS=1 is set (tests/conftest.py sets it): a stray variable in a user's environment changes nothing.
 const char* dev_env(const char* name) {
-    static const bool on = std::getenv("SOM_TEST_HOOKS") != nullptr;
+    static const bool on = [] { const char* v = std::getenv("SOM_TEST_HOOKS"); return v != nullptr && std::atoi(v) != 0; }();
     return on ? std::getenv(name) : nullptr;
 }
 
@@ -114,10 +114,19 @@ struct som_handle {
         int skip_idle = 0;                // plans in a row that kept > 97 % of the blocks
         int skip_pause = 2;               // launches the next pause lasts (doubles while the plans stay idle)
         bool sub_blocks = true;           // SOM_EXACT_SUBBLOCKS=0: the plan stops at the groups (A/B)
-        // the RESIDENT SORTED PASS: the rows in the order of their BMU's patch at the time of the last sort (position ->
-        // row: `order`), with sorted copies of the half image, the float32 rows and the norms.  Valid for (res_rows, res_n);
-        // re-sorted when the order has gone stale (res_* below), not every epoch.
-        long sk_rows = 0;                 // positions the sorted buffers hold (all passes, each padded to the tile)
+        // the SORTED PASS: rows in the order of their (pseudo) last BMU's patch (position -> row: `order`), with sorted copies of
+        // the half image, its second half, the float32 rows and the norms.  srt[0]: the RESIDENT rows (all passes; valid for
+        // (res_rows, res_n), re-sorted when the order has gone stale -- res_* below --, not every epoch); srt[1]: ONE pass of
+        // a TRANSIENT row set (query rows, streamed chunks: sorted by the scout of exact_skip.hpp, used once).
+        struct SortedRows {
+            long cap = 0;                 // positions the buffers hold (each pass padded to the tile)
+            int* order = nullptr;
+            __bf16* Xb_s = nullptr;
+            __bf16* Xl_s = nullptr;       // ... the rows' second half image (the refinement pass)
+            float *Xf_s = nullptr, *xsq_s = nullptr, *xerr_s = nullptr, *seed_s = nullptr, *sU_s = nullptr;
+            int* lastpos_s = nullptr;     // position (patch order) of every sorted row's (pseudo) last BMU
+        } srt[2];
+        bool cen_ready = false;           // both centroid levels are allocated
         long sk_stride = 0;               // rows per pass the per-pass plan buffers hold
         const void* res_rows = nullptr; long res_n = -1;
         bool res_valid = false;
@@ -128,23 +137,31 @@ struct som_handle {
         int res_forced = 8;               // planned epochs after which the rows are sorted in any case (doubles after a forced sort that did not pay)
         double res_share_last = 1.0;      // ... of the last planned epoch
         int64_t resorts = 0, planned = 0; // som_exact_resident_stats
-        int *order = nullptr, *sk_keys = nullptr, *sk_keys2 = nullptr, *sk_vals = nullptr;
+        int *sk_keys = nullptr, *sk_keys2 = nullptr, *sk_vals = nullptr;
         void* sk_tmp = nullptr; size_t sk_tmp_bytes = 0;
-        __bf16* Xb_s = nullptr;
-        __bf16* Xl_s = nullptr;           // ... and the rows' second half image (the refinement pass)
         bool refine_on = true;            // SOM_EXACT_REFINE=0: no refinement pass (A/B)
         bool refine_live = false;
         double pairs_per_row_last = 0.0;  // candidate (row, group) pairs per row of the last planned epoch
         int64_t pairs_refined_in = 0, pairs_refined_out = 0;   // som_exact_refine_stats
-        float *Xf_s = nullptr, *xsq_s = nullptr, *xerr_s = nullptr, *seed_s = nullptr, *sU_s = nullptr;
-        int* lastpos_s = nullptr;         // position (patch order) of every sorted row's last BMU
+        // the SCOUT (exact_skip.hpp): pseudo last BMUs for rows that have none, or whose last BMUs say little
+        bool scout_on = true;             // SOM_EXACT_SCOUT=0: plans only from last epoch's BMUs (A/B)
+        bool scout_live = false;          // this launch runs the scout
+        int* scout_g = nullptr;           // [stride] nearest group centroid of every row of the pass
+        double scout_est_last = 0.0;      // executed share the sample tiles forecast at the last estimate
+        int64_t scout_declined = 0;       // launches whose estimate said: nothing to skip, no plan
+        int64_t scouted = 0, tr_planned = 0;   // som_exact_scout_stats: launches that ran the scout; transient launches under a plan
+        double tr_share_last = 1.0;       // executed share of the last transient launch under a plan
+        double share_forecast = 1.0;      // ... of the launch about to run (the screen sizes its codebook parts by it)
+        int tr_idle = 0, tr_cooldown = 0, tr_pause = 2;   // transient launches: idle plans pause the plan as for the resident rows
         // level 2 of the plan runs where it pays (l2_pays: measured whenever it runs), is probed again after l2_wait epochs or
         // when level 1's share has moved by half since the last probe
         double l1_share_last = 1.0, l1_share_probe = -1.0;
         bool l2_live = false, l2_pays = true;
+        bool l2_gate = false;             // this launch: level 2 leaves out the tiles that kept more than half of the groups (exact_plan_kernel)
         int l2_wait = 0;
         // the centroid sets of the plan: [0] the 64-unit groups, [1] their 16-unit sub-blocks (exact_centroid_kernel's slot order)
         struct Centroids { float *Cc = nullptr, *rg = nullptr, *csq = nullptr, *cmax2 = nullptr; char* Cst = nullptr;
+                           char* Cst_plain = nullptr;   // level 1 only: the scout's copy (plain initial accumulators)
                            int n_slots = 0, n_cstages = 0; } cen[2];
         unsigned long long *need = nullptr, *need2 = nullptr;
         int *glist = nullptr, *gcnt = nullptr;   // per tile: (group << 4 | sub-block mask) items: what the select kernel walks
@@ -214,7 +231,7 @@ struct som_handle {
     // scratch for som_bmu / som_quantization_error
     float* qX = nullptr; int* qbmu = nullptr; int* qbmu2 = nullptr; float* qxsq = nullptr; __bf16* qXb = nullptr;
     double* qX64 = nullptr; size_t qX64_cap = 0;   // som_bmu_f64: float64 query rows
-    long qcap = 0;
+    long qcap = 0, qX_cap = 0;
     double* dsum = nullptr;
     // streamed epochs (rows that do not stay resident): per-chunk sort scratch, grown on demand
     SegScratch st_seg;
@@ -948,6 +965,7 @@ int exact_reserve_stride(som_handle* h, long stride) {
     for (void* p : old) if (p) (void)hipFree(p);
     ex.gmin = nullptr; ex.gflags = nullptr; ex.rowcnt = nullptr; ex.rowarg = nullptr; ex.seed = nullptr; ex.fb_list = nullptr; ex.plist = nullptr; ex.tile_tab = nullptr;
     ex.stride = 0;
+    ex.res_valid = false;                               // (the resident order was built pass by pass: new passes, new order)
     const long n_groups = cdiv(h->K, EX_GROUP);
     // capacity of a pass in (row, group) pairs per row on average: a quarter of the groups -- past that the float32
     // kernel over all of them costs about what the re-score would
@@ -988,7 +1006,7 @@ int exact_screen(som_handle* h, const __bf16* Xb, long n, unsigned long long* be
         // a tile's list is short where the plan works (tens of items of 1 024): every part of a tile loads the tile's 64 KB
         // of rows again, so the scan is split only where the lists are long enough to carry that (the last plan's share
         // is the forecast; 1 Mi rows, mid-schedule: three parts re-read 0.8 GB for 0.3 ms of screen)
-        const double tiles16 = h->ex.res_share_last * (double)n_groups * K16_T;
+        const double tiles16 = h->ex.share_forecast * (double)n_groups * K16_T;
         parts = tiles16 < 128.0 ? 1 : tiles16 < 320.0 ? std::min(parts, 2) : parts;
     }
     if (h->env_bf16_parts > 0) parts = std::min(h->env_bf16_parts, h->n_stages);
@@ -1088,14 +1106,20 @@ int radix_sort_rows(som_handle* h, const int* keys_in, long n, int bits, int* ke
     return 0;
 }
 
-// ---- block skipping (exact_skip.hpp): buffers, the centroid images, the resident sorted pass, a pass's plan ------------------
-// rows_all: every resident row (the sorted copies hold all passes); stride: rows of one pass (the plan's own buffers)
-int exact_skip_reserve(som_handle* h, long rows_all, long stride) {
+// ---- block skipping (exact_skip.hpp): buffers, the centroid images, the sorted pass, the scout, a pass's plan -----------------
+// sr: the sorted copies to (re)size for `rows` positions; stride: rows of one pass (the plan's own buffers)
+int exact_skip_reserve(som_handle* h, som_handle::ExactScratch::SortedRows& sr, long rows, long stride) {
     auto& ex = h->ex;
     // TEST HOOK (tests/test_gpu_exact.py): behave as a device without memory for the sorted pass
     if (ex.hook_refuse_skip) return fail(h, "exact: block-skipping scratch refused (test hook)");
     const long n_groups = cdiv(h->K, EX_GROUP);
-    if (!ex.cen[0].Cc) {
+    if (!ex.cen_ready) {
+        // (a refusal part of the way leaves cen_ready unset: the whole block is tried again, nothing half allocated is used)
+        for (auto& c : ex.cen) {
+            void* cb[] = {c.Cc, c.rg, c.csq, c.cmax2, c.Cst, c.Cst_plain};
+            for (void* q : cb) if (q) (void)hipFree(q);
+            c = som_handle::ExactScratch::Centroids();
+        }
         const int ncs = (int)cdiv(n_groups, K16_STAGE_UNITS);
         for (int lv = 0; lv < 2; ++lv) {
             auto& c = ex.cen[lv];
@@ -1108,34 +1132,44 @@ int exact_skip_reserve(som_handle* h, long rows_all, long stride) {
             if (int rc = dev_alloc(h, &c.cmax2, 2)) return rc;
             if (int rc = dev_alloc(h, &c.Cst, (size_t)c.n_cstages * h->stage_bytes)) return rc;
             HIPCHK(h, hipMemsetAsync(c.Cst, 0, (size_t)c.n_cstages * h->stage_bytes, h->stream));
+            if (lv == 0) {
+                if (int rc = dev_alloc(h, &c.Cst_plain, (size_t)c.n_cstages * h->stage_bytes)) return rc;
+                HIPCHK(h, hipMemsetAsync(c.Cst_plain, 0, (size_t)c.n_cstages * h->stage_bytes, h->stream));
+            }
         }
+        ex.cen_ready = true;
     }
-    const long need_rows = round_up(rows_all, SK_TILE);
-    if (need_rows > ex.sk_rows) {
-        void* old[] = {ex.order, ex.Xb_s, ex.Xl_s, ex.Xf_s, ex.xsq_s, ex.xerr_s, ex.seed_s, ex.sU_s, ex.lastpos_s};
+    const long need_rows = round_up(rows, SK_TILE);
+    if (need_rows > sr.cap) {
+        // (kernels of an earlier launch may still read the old copies: a transient set's buffers are reused launch after launch)
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        void* old[] = {sr.order, sr.Xb_s, sr.Xl_s, sr.Xf_s, sr.xsq_s, sr.xerr_s, sr.seed_s, sr.sU_s, sr.lastpos_s};
         for (void* p : old) if (p) (void)hipFree(p);
-        ex.order = nullptr; ex.Xb_s = nullptr; ex.Xl_s = nullptr; ex.Xf_s = ex.xsq_s = ex.xerr_s = ex.seed_s = ex.sU_s = nullptr; ex.lastpos_s = nullptr;
-        ex.sk_rows = 0; ex.res_valid = false;
-        if (int rc = dev_alloc(h, &ex.order, (size_t)need_rows)) return rc;
-        if (int rc = dev_alloc(h, &ex.Xb_s, (size_t)need_rows * h->dp)) return rc;
-        if (int rc = dev_alloc(h, &ex.Xl_s, (size_t)need_rows * h->dp)) return rc;
-        if (int rc = dev_alloc(h, &ex.Xf_s, (size_t)need_rows * h->D)) return rc;
-        if (int rc = dev_alloc(h, &ex.xsq_s, (size_t)need_rows)) return rc;
-        if (int rc = dev_alloc(h, &ex.xerr_s, (size_t)need_rows)) return rc;
-        if (int rc = dev_alloc(h, &ex.seed_s, (size_t)need_rows)) return rc;
-        if (int rc = dev_alloc(h, &ex.sU_s, (size_t)need_rows)) return rc;
-        if (int rc = dev_alloc(h, &ex.lastpos_s, (size_t)need_rows)) return rc;
-        ex.sk_rows = need_rows;
+        sr = som_handle::ExactScratch::SortedRows();
+        if (&sr == &ex.srt[0]) ex.res_valid = false;
+        if (int rc = dev_alloc(h, &sr.order, (size_t)need_rows)) return rc;
+        if (int rc = dev_alloc(h, &sr.Xb_s, (size_t)need_rows * h->dp)) return rc;
+        if (int rc = dev_alloc(h, &sr.Xl_s, (size_t)need_rows * h->dp)) return rc;
+        if (int rc = dev_alloc(h, &sr.Xf_s, (size_t)need_rows * h->D)) return rc;
+        if (int rc = dev_alloc(h, &sr.xsq_s, (size_t)need_rows)) return rc;
+        if (int rc = dev_alloc(h, &sr.xerr_s, (size_t)need_rows)) return rc;
+        if (int rc = dev_alloc(h, &sr.seed_s, (size_t)need_rows)) return rc;
+        if (int rc = dev_alloc(h, &sr.sU_s, (size_t)need_rows)) return rc;
+        if (int rc = dev_alloc(h, &sr.lastpos_s, (size_t)need_rows)) return rc;
+        sr.cap = need_rows;
     }
     if (stride <= ex.sk_stride) return 0;
-    void* old[] = {ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.sk_tmp, ex.need, ex.need2, ex.glist, ex.gcnt, ex.tile_counts, ex.tlist, ex.tcnt};
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    void* old[] = {ex.sk_keys, ex.sk_keys2, ex.sk_vals, ex.sk_tmp, ex.need, ex.need2, ex.glist, ex.gcnt, ex.tile_counts, ex.tlist, ex.tcnt, ex.scout_g};
     for (void* p : old) if (p) (void)hipFree(p);
     ex.sk_keys = ex.sk_keys2 = ex.sk_vals = nullptr; ex.sk_tmp = nullptr; ex.need = ex.need2 = nullptr; ex.glist = ex.gcnt = nullptr; ex.tile_counts = nullptr; ex.tlist = ex.tcnt = nullptr;
+    ex.scout_g = nullptr;
     ex.sk_stride = 0;
     const long tiles = stride / SK_TILE;
     if (int rc = dev_alloc(h, &ex.sk_keys, (size_t)stride)) return rc;
     if (int rc = dev_alloc(h, &ex.sk_keys2, (size_t)stride)) return rc;
     if (int rc = dev_alloc(h, &ex.sk_vals, (size_t)stride)) return rc;
+    if (int rc = dev_alloc(h, &ex.scout_g, (size_t)stride)) return rc;
     if (int rc = dev_alloc(h, &ex.need, (size_t)tiles * ex.cen[0].n_cstages)) return rc;
     if (int rc = dev_alloc(h, &ex.need2, (size_t)tiles * ex.cen[1].n_cstages)) return rc;
     if (int rc = dev_alloc(h, &ex.glist, (size_t)tiles * n_groups)) return rc;
@@ -1164,9 +1198,10 @@ int exact_skip_centroids(som_handle* h, const float* xmax2) {
     // codebook's own power of two: a centroid is no longer than the longest unit)
     exact_centroids_kernel<<<dim3((unsigned)(cdiv(n_groups, 4) * 4)), dim3(512), 0, h->stream>>>(Wsrc, h->K, h->D, n_groups, l1, l2, h->wmax2);
     const int nst2 = ex.l2_live ? c1.n_cstages : 0;
+    char* plain = ex.scout_live ? c0.Cst_plain : nullptr;
     const dim3 tgrid((unsigned)cdiv((long)(c0.n_cstages + nst2) * K16_T, 4)), block(256);
     switch (h->ks32) {
-#define SOM_CIMG_CASE(k) case k: exact_centroid_image_kernel<k, E><<<tgrid, block, 0, h->stream>>>(l1, c0.Cst, c0.n_cstages, l2, c1.Cst, nst2, h->D, xmax2, h->wmax2); break;
+#define SOM_CIMG_CASE(k) case k: exact_centroid_image_kernel<k, E><<<tgrid, block, 0, h->stream>>>(l1, c0.Cst, c0.n_cstages, l2, c1.Cst, nst2, h->D, xmax2, h->wmax2, plain); break;
     SOM_CIMG_CASE(1) SOM_CIMG_CASE(2) SOM_CIMG_CASE(3) SOM_CIMG_CASE(4)
 #undef SOM_CIMG_CASE
     default: return fail(h, "exact: block skipping supports input_len <= 128");
@@ -1175,33 +1210,101 @@ int exact_skip_centroids(som_handle* h, const float* xmax2) {
     return 0;
 }
 
-// (re-)sort one pass: the rows [r0, r0 + n) in the order of their last BMU's group, the operands gathered in that order
-template <class E>
-int exact_skip_sort(som_handle* h, const float* X, const __bf16* Xb, long r0, long n, const float* xsq, const float* xerr, const int* prev,
-                    const float* xmax2) {
+// (re-)sort one pass: the rows [r0, r0 + n) of the row set in the order of their last BMU's group (prev: last epoch's ids) or
+// of their nearest group centroid (scout_g: the scout's): the order (position -> row) into sr at s0, the sorted keys into sk_keys2
+int exact_skip_sortkeys(som_handle* h, som_handle::ExactScratch::SortedRows& sr, long s0, long n, const int* prev, const int* scout_g) {
     auto& ex = h->ex;
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
-    const long np = round_up(n, SK_TILE);
-    exact_sortkey_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(prev, h->ex_inv, n, h->K, ex.sk_keys, ex.sk_vals);
+    if (scout_g != nullptr)
+        exact_groupkey_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(scout_g, n, n_groups, ex.sk_keys, ex.sk_vals);
+    else
+        exact_sortkey_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(prev, h->ex_inv, n, h->K, ex.sk_keys, ex.sk_vals);
     int bits = 1;
     while ((1L << bits) < n_groups) ++bits;
-    if (int rc = radix_sort_rows(h, ex.sk_keys, n, bits, ex.sk_keys2, ex.order + r0, (int*)ex.sk_tmp)) return rc;
+    return radix_sort_rows(h, ex.sk_keys, n, bits, ex.sk_keys2, sr.order + s0, (int*)ex.sk_tmp);
+}
+// ... and the operands gathered in that order (`order`: n positions -> rows of the pass) into sr at positions s0 ...
+template <class E>
+int exact_skip_gather(som_handle* h, som_handle::ExactScratch::SortedRows& sr, long s0, const int* order, const float* X, const __bf16* Xb, long n,
+                      const float* xsq, const float* xerr, const float* xmax2) {
+    const long np = round_up(n, SK_TILE);
     exact_gather_sorted_kernel<E><<<dim3((unsigned)cdiv(np, 4)), dim3(256), 0, h->stream>>>(
-        ex.order + r0, n, np, h->dp, h->D, Xb, X, xsq, xerr, xmax2, ex.Xb_s + r0 * h->dp, ex.Xl_s + r0 * h->dp, ex.Xf_s + r0 * h->D,
-        ex.xsq_s + r0, ex.xerr_s + r0);
+        order, n, np, h->dp, h->D, Xb, X, xsq, xerr, xmax2, sr.Xb_s + s0 * h->dp, sr.Xl_s + s0 * h->dp, sr.Xf_s + s0 * h->D,
+        sr.xsq_s + s0, sr.xerr_s + s0);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
 
-// one pass's plan on the resident sorted rows [r0, r0 + n): level 1 (+ the seeds), level 2, the tiles' item lists
+// the scout, step 1: every row's nearest group centroid (the plain resident kernel on the plain level-1 centroid image)
+template <int KS32, class E>
+int exact_scout_nearest_ks(som_handle* h, const __bf16* Xb, long n, unsigned long long* best64, int* g_out) {
+    auto& ex = h->ex;
+    const auto& c0 = ex.cen[0];
+    const void* kern = (const void*)bmu_bf16_k16_kernel<KS32, E, false, false>;
+    const size_t lds = 2 * (size_t)k16_stage_bytes(KS32);
+    int per_cu = 1;
+    if (int rc = kernel_per_cu(h, kern, 64 * K16_NW, lds, &per_cu)) return rc;
+    const long blocks = cdiv(n, K16_WG_SAMPLES);
+    const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
+    const int parts = std::max(1, std::min(choose_parts(h, blocks, slots, c0.n_cstages), c0.n_cstages));
+    bmu_bf16_k16_kernel<KS32, E, false, false><<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * K16_NW), lds, h->stream>>>(
+        Xb, n, c0.Cst_plain, c0.n_cstages, c0.n_slots, best64);
+    bmu_finalize_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(best64, n, c0.n_slots, g_out);
+    HIPCHK(h, hipMemsetAsync(best64, 0xFF, (size_t)n * sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
 template <class E>
-int exact_skip_plan(som_handle* h, long r0, long n, const int* prev, const float* xmax2, const ExactBound& eb) {
+int exact_scout_nearest(som_handle* h, const __bf16* Xb, long n, unsigned long long* best64, int* g_out) {
+    switch (h->ks32) {
+    case 1: return exact_scout_nearest_ks<1, E>(h, Xb, n, best64, g_out);
+    case 2: return exact_scout_nearest_ks<2, E>(h, Xb, n, best64, g_out);
+    case 3: return exact_scout_nearest_ks<3, E>(h, Xb, n, best64, g_out);
+    case 4: return exact_scout_nearest_ks<4, E>(h, Xb, n, best64, g_out);
+    }
+    return fail(h, "exact: the scout supports input_len <= 128");
+}
+
+// the scout, step 3: per tile of the SORTED pass the groups of its rows' keys (`keys`: the pass's sorted keys), the plain
+// kernel over those groups' units with indices kept: the best of them -> lastpos (the pseudo last BMU)
+template <int KS32, class E>
+int exact_scout_pick_ks(som_handle* h, som_handle::ExactScratch::SortedRows& sr, long s0, long n, const int* keys, unsigned long long* best64) {
+    auto& ex = h->ex;
+    const int n_groups = (int)cdiv(h->K, EX_GROUP);
+    const long tiles = round_up(n, SK_TILE) / SK_TILE;
+    const size_t lds_l = (size_t)cdiv(n_groups, 64) * sizeof(unsigned long long);
+    exact_scout_lists_kernel<<<dim3((unsigned)tiles), dim3(64), lds_l, h->stream>>>(keys, nullptr, n, n_groups, ex.tlist, ex.tcnt);
+    const void* kern = (const void*)bmu_bf16_k16_kernel<KS32, E, false, true>;
+    const size_t lds = 2 * (size_t)k16_stage_bytes(KS32);
+    int per_cu = 1;
+    if (int rc = kernel_per_cu(h, kern, 64 * K16_NW, lds, &per_cu)) return rc;
+    bmu_bf16_k16_kernel<KS32, E, false, true><<<dim3((unsigned)tiles, 1), dim3(64 * K16_NW), lds, h->stream>>>(
+        sr.Xb_s + s0 * h->dp, n, h->Wst, h->n_stages, h->K, best64, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ExactBound(),
+        nullptr, ex.tlist, ex.tcnt);
+    exact_scout_pos_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(best64, n, h->K, sr.lastpos_s + s0);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+template <class E>
+int exact_scout_pick(som_handle* h, som_handle::ExactScratch::SortedRows& sr, long s0, long n, const int* keys, unsigned long long* best64) {
+    switch (h->ks32) {
+    case 1: return exact_scout_pick_ks<1, E>(h, sr, s0, n, keys, best64);
+    case 2: return exact_scout_pick_ks<2, E>(h, sr, s0, n, keys, best64);
+    case 3: return exact_scout_pick_ks<3, E>(h, sr, s0, n, keys, best64);
+    case 4: return exact_scout_pick_ks<4, E>(h, sr, s0, n, keys, best64);
+    }
+    return fail(h, "exact: the scout supports input_len <= 128");
+}
+
+// one pass's plan on the sorted rows sr[s0, s0 + n): level 1 (+ the seeds, from lastpos_s), level 2, the tiles' item lists
+template <class E>
+int exact_skip_plan(som_handle* h, som_handle::ExactScratch::SortedRows& sr, long s0, long n, const float* xmax2, const ExactBound& eb,
+                    const int* lastpos2) {
     auto& ex = h->ex;
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
     const long np = round_up(n, SK_TILE);
     const long tiles = np / SK_TILE;
     // (the select kernel walks the tiles' lists too: the masks of the blocks the screen does not run are never read)
-    exact_lastpos_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(prev, ex.order + r0, h->ex_inv, n, h->K, ex.lastpos_s + r0);
     const dim3 block(64 * K16_NW);
     const auto& c0 = ex.cen[0];
     const auto& c1 = ex.cen[1];
@@ -1213,19 +1316,19 @@ int exact_skip_plan(som_handle* h, long r0, long n, const int* prev, const float
     const size_t lds2 = 2 * (size_t)h->stage_bytes + (size_t)c0.n_cstages * 64 * sizeof(int) + (size_t)c1.n_cstages * 8;   // (+ its list of kept groups, its words)
     const bool l2 = ex.l2_live;
     const int force = ex.skip_mode == 3 ? 1 : 0;
-    const __bf16* Xs = ex.Xb_s + r0 * h->dp;
+    const __bf16* Xs = sr.Xb_s + s0 * h->dp;
     // (level 1 stores every word; level 2 only those of the stages it walks)
     if (l2) HIPCHK(h, hipMemsetAsync(ex.need2, 0, (size_t)tiles * c1.n_cstages * sizeof(unsigned long long), h->stream));
 #define SOM_PLAN_CASE(k) case k: { \
         { int pc; if (int rc = kernel_per_cu(h, (const void*)exact_plan_kernel<k, E, false>, 64 * K16_NW, lds1, &pc)) return rc; } \
         exact_plan_kernel<k, E, false><<<pgrid, block, lds1, h->stream>>>(Xs, n, c0.Cst, c0.n_cstages, c0.rg, c0.n_slots, \
-            ex.xsq_s + r0, ex.xerr_s + r0, ex.sU_s + r0, xmax2, c0.cmax2, h->wmax2, h->wmax2 + 1, eb, ex.need, ex.lastpos_s + r0, \
-            h->Wst, ex.seed_s + r0, nullptr, 0, force); \
+            sr.xsq_s + s0, sr.xerr_s + s0, sr.sU_s + s0, xmax2, c0.cmax2, h->wmax2, h->wmax2 + 1, eb, ex.need, sr.lastpos_s + s0, \
+            h->Wst, sr.seed_s + s0, nullptr, 0, force, lastpos2); \
         if (l2) { \
             { int pc; if (int rc = kernel_per_cu(h, (const void*)exact_plan_kernel<k, E, true>, 64 * K16_NW, lds2, &pc)) return rc; } \
             exact_plan_kernel<k, E, true><<<dim3((unsigned)tiles, pgrid.y), block, lds2, h->stream>>>(Xs, n, c1.Cst, c1.n_cstages, c1.rg, c1.n_slots, \
-                ex.xsq_s + r0, ex.xerr_s + r0, ex.sU_s + r0, xmax2, c1.cmax2, h->wmax2, h->wmax2 + 1, eb, ex.need2, nullptr, \
-                nullptr, nullptr, ex.need, c0.n_cstages, force); \
+                sr.xsq_s + s0, sr.xerr_s + s0, sr.sU_s + s0, xmax2, c1.cmax2, h->wmax2, h->wmax2 + 1, eb, ex.need2, nullptr, \
+                nullptr, nullptr, ex.need, c0.n_cstages, force, nullptr, ex.l2_gate ? 1 : 0); \
         } } break;
     switch (h->ks32) {
     SOM_PLAN_CASE(1) SOM_PLAN_CASE(2) SOM_PLAN_CASE(3) SOM_PLAN_CASE(4)
@@ -1255,7 +1358,7 @@ int exact_rescore_kg(som_handle* h, const float* X, int n_groups) {
 
 // the refinement pass over a sorted pass's candidate pairs (bmu_exact.hpp): tiles -> refined minima -> lists compacted in place
 template <int KS32, class E>
-int exact_refine_ks(som_handle* h, long r0, long n, const float* xmax2, const ExactBound& eb) {
+int exact_refine_ks(som_handle* h, som_handle::ExactScratch::SortedRows& sr, long r0, long n, const float* xmax2, const ExactBound& eb) {
     auto& ex = h->ex;
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
     int* gcount = ex.ctr; int* fb_count = ex.ctr + 2 * n_groups;
@@ -1269,19 +1372,19 @@ int exact_refine_ks(som_handle* h, long r0, long n, const float* xmax2, const Ex
     if (int rc = kernel_per_cu(h, (const void*)exact_refine_kernel<KS32, E>, 256, lds, &per_cu)) return rc;
     const long grid = std::min<long>(ex.max_tiles, 2L * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
     exact_refine_kernel<KS32, E><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(
-        ex.Xb_s + r0 * h->dp, ex.Xl_s + r0 * h->dp, h->Wst, h->Wst_lo, ex.tile_tab, n_tiles, ex.plist, ex.gmin, rowmin2);
+        sr.Xb_s + r0 * h->dp, sr.Xl_s + r0 * h->dp, h->Wst, h->Wst_lo, ex.tile_tab, n_tiles, ex.plist, ex.gmin, rowmin2);
     exact_select2_kernel<<<dim3((unsigned)n_groups), dim3(256), 0, h->stream>>>(
-        ex.plist, ex.gmin, ex.stride, gcount, rowmin2, ex.xsq_s + r0, ex.xerr_s + r0, h->wmax2, xmax2, h->wmax2 + 1, eb, fb_count + 6);
+        ex.plist, ex.gmin, ex.stride, gcount, rowmin2, sr.xsq_s + r0, sr.xerr_s + r0, h->wmax2, xmax2, h->wmax2 + 1, eb, fb_count + 6);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
 template <class E>
-int exact_refine(som_handle* h, long r0, long n, const float* xmax2, const ExactBound& eb) {
+int exact_refine(som_handle* h, som_handle::ExactScratch::SortedRows& sr, long r0, long n, const float* xmax2, const ExactBound& eb) {
     switch (h->ks32) {
-    case 1: return exact_refine_ks<1, E>(h, r0, n, xmax2, eb);
-    case 2: return exact_refine_ks<2, E>(h, r0, n, xmax2, eb);
-    case 3: return exact_refine_ks<3, E>(h, r0, n, xmax2, eb);
-    case 4: return exact_refine_ks<4, E>(h, r0, n, xmax2, eb);
+    case 1: return exact_refine_ks<1, E>(h, sr, r0, n, xmax2, eb);
+    case 2: return exact_refine_ks<2, E>(h, sr, r0, n, xmax2, eb);
+    case 3: return exact_refine_ks<3, E>(h, sr, r0, n, xmax2, eb);
+    case 4: return exact_refine_ks<4, E>(h, sr, r0, n, xmax2, eb);
     }
     return fail(h, "exact: the refinement pass supports input_len <= 128");
 }
@@ -1353,14 +1456,27 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
     const long chunk = std::min(exact_chunk_rows(h), ex.stride);
     const bool two_round = ex.two_round >= 0 ? ex.two_round != 0 : h->wide;
-    // block skipping (exact_skip.hpp): where the seed lives (resident rows with last epoch's BMUs, <= 128 features), one round
-    ex.skip_live = ex.skip_mode > 0 && ex.seed_on && !h->wide && out == h->bmu && h->bmu_valid && !two_round &&
-                   (ex.skip_mode > 1 ? n_groups >= 2 : h->K >= 4096);
+    // block skipping (exact_skip.hpp), one round, <= 128 features, maps of >= 4096 units: a plan needs, per row, SOME unit whose
+    // distance bounds the distance to the BMU.  RESIDENT rows from their second epoch on have last epoch's BMU; every other row
+    // set (query rows, streamed chunks, a row set's first epoch) -- and resident rows while last epoch's BMUs say little, a
+    // schedule's first epochs -- gets a pseudo last BMU from the SCOUT.  The scout pays where a full scan costs more than its
+    // own fixed part (some thirty small launches) several times over: 2 N K D flop at the screen's rate against a quarter of a
+    // millisecond, i.e. from some 40 000 rows of a 256 x 256 x 128 map on.
+    const bool resident = out == h->bmu;
+    const bool have_last = resident && h->bmu_valid;
+    const bool can_skip = ex.skip_mode > 0 && ex.seed_on && !h->wide && !two_round && (ex.skip_mode > 1 ? n_groups >= 2 : h->K >= 4096);
+    const bool scout_ok = can_skip && ex.scout_on && n_groups <= 262144 &&
+                          (ex.skip_mode > 1 || (double)N * (double)h->K * (double)h->D >= 3.0e11);
+    ex.skip_live = can_skip && (have_last || scout_ok);
     // default mode: two launches in a row whose plans kept (nearly) every block -- rows without structure -- are followed
     // by two launches without a plan (the plan costs 4-8 % of a full scan), and so on while the plans stay idle
-    if (ex.skip_live && ex.skip_mode == 1 && ex.skip_cooldown > 0) { --ex.skip_cooldown; ex.skip_live = false; }
+    if (ex.skip_live && ex.skip_mode == 1) {
+        int& cool = resident ? ex.skip_cooldown : ex.tr_cooldown;
+        if (cool > 0) { --cool; ex.skip_live = false; }
+    }
+    auto& sr = ex.srt[resident ? 0 : 1];
     const int64_t run_before = ex.blocks_run, total_before = ex.blocks_total;
-    if (ex.skip_live && exact_skip_reserve(h, N, ex.stride) != 0) {
+    if (ex.skip_live && exact_skip_reserve(h, sr, resident ? N : std::min(N, chunk), ex.stride) != 0) {
         // no memory for the sorted pass's buffers: every block runs, from now on (the ids are the same either way)
         (void)hipGetLastError();
         if (h->debug) std::fprintf(stderr, "[somhip] exact: block skipping off (%s)\n", h->err.c_str());
@@ -1375,26 +1491,40 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     // (Measured, tools/resid_probe.py + bound_probe.py: past a schedule's first epochs an order three epochs old runs the same
     // blocks as a fresh one; a trigger on the share's growth fired on the schedule's own late growth, where sorting buys nothing.)
     // A stale order costs speed, never correctness: the plan tests every row of a tile where it sits.
-    bool resort = false;
+    // A transient row set is sorted by the scout every time (there is nothing to keep).
+    bool resort = false, scout = false;
     if (ex.skip_live) {
-        const bool fresh = !ex.res_valid || ex.res_rows != (const void*)X || ex.res_n != N;
+        const bool fresh = !resident || !have_last || !ex.res_valid || ex.res_rows != (const void*)X || ex.res_n != N;
         if (fresh) resort = true;
         else if (ex.res_every > 0) resort = ex.res_since >= ex.res_every;
         else resort = ex.res_share_last >= 0.25 || ex.res_since >= ex.res_forced;
+        // the scout: always where there is no last BMU; with one, in the epochs that sort anyway because much of the map still
+        // runs -- there the bound from the current codebook's own centroids is the better one (tools/ucent_probe.py: 0.78 against
+        // 0.95 of the blocks in a schedule's second epoch, 0.28 against 0.52 in its third), and the plan takes the better of the
+        // two units row by row
+        scout = scout_ok && (!have_last || (resort && (fresh || ex.res_share_last >= 0.25)));
         // level 2 of the plan (the groups' 16-unit sub-blocks) where it pays.  Whether it does is MEASURED each time it runs
         // (both levels' shares come back with the pass's counters): it costs about a tenth of level 1's share of a full scan
         // (four centroids per kept group), it saves the blocks it drops -- on the smooth maps of a schedule's first epochs
         // and on the compact patches of its middle it drops next to nothing, late, when the patches have spread out, more
         // than half.  While it does not pay it is probed again every fourth planned epoch, or at once when level 1's share
-        // has moved by half since the last probe.
+        // has moved by half since the last probe.  (Tile by tile the kernel itself leaves level 2 out where level 1 kept more
+        // than half of the groups: exact_plan_kernel.)
         bool probe = ex.l1_share_probe < 0.0 || ex.l2_wait <= 0 || ex.l1_share_last > 1.5 * ex.l1_share_probe || ex.l1_share_last < ex.l1_share_probe / 1.5;
         // (a new row set starts like a new engine: level 2 is taken to pay until it has been measured on these rows)
-        if (fresh) { ex.l2_pays = true; ex.l1_share_probe = -1.0; }
+        if (fresh && resident) { ex.l2_pays = true; ex.l1_share_probe = -1.0; }
         if (ex.l1_share_last > 0.9 && ex.l1_share_probe >= 0.0 && !ex.l2_pays) probe = false;   // (nothing for four times the centroids to find)
-        ex.l2_live = ex.sub_blocks && (ex.l2_pays || probe || ex.skip_mode >= 2) &&
+        ex.l2_live = ex.sub_blocks && (ex.l2_pays || probe || ex.skip_mode >= 2 || !resident) &&
                      2 * (size_t)h->stage_bytes + (size_t)cdiv(n_groups, K16_STAGE_UNITS) * (64 * sizeof(int) + 4 * 8) <= 150 * 1024;   // (its list of kept groups lives in LDS)
+        ex.l2_gate = ex.skip_mode < 2 && (!resident || ex.l1_share_probe < 0.0);   // (no measurement of level 2 on these rows yet)
+        ex.scout_live = scout;
         if (int rc = SOM_HALF(h, exact_skip_centroids, h, xmax2)) return rc;
     }
+    ex.scout_live = scout;
+    // (the forecast from sample tiles: where the scout plans and there is no good recent plan of the same kind to go by)
+    bool estimate = ex.skip_live && scout && ex.skip_mode == 1 && (resident || ex.tr_share_last >= 0.5);
+    if (estimate && exact_skip_reserve(h, ex.srt[1], 128 * SK_TILE, ex.stride) != 0) { (void)hipGetLastError(); h->err.clear(); estimate = false; }
+    ex.share_forecast = resident ? ex.res_share_last : ex.tr_share_last;
     // the refinement pass (bmu_exact.hpp) where it pays: it costs about a third of the float32 re-score of the pairs it is
     // given (it is bound by the same gather of rows) and leaves one to one and a half pairs a row, at two small launches more:
     // worth it from three candidate pairs a row on (the last planned epoch's count) -- the smooth maps of a schedule's middle
@@ -1402,26 +1532,83 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     int64_t groups_run = 0, pairs_in = 0, pairs_out = 0;
     for (long r0 = 0; r0 < N; r0 += chunk) {
         const long n = std::min(chunk, N - r0);
+        const long s0 = resident ? r0 : 0;                   // where the pass sits in the sorted copies
         // (a pass behind one whose fallback rows went through the float32 kernel: its image back in patch order)
         if (h->wf_patch != h->ex_patch) if (int rc = refresh_codebook_operands(h, true, true)) return rc;
         HIPCHK(h, hipMemsetAsync(ex.ctr, 0, (size_t)(2 * n_groups + 7) * sizeof(int), h->stream));
-        // resident rows from their second epoch on: last epoch's BMU of every row caps the screen's keep threshold -- under a
-        // plan the plan's prologue forms that seed from the operands it holds (exact_skip.hpp), else exact_seed_kernel
-        ex.seed_live = ex.seed_on && !h->wide && out == h->bmu && h->bmu_valid;
-        if (ex.seed_live && !ex.skip_live)
-            exact_seed_kernel<<<dim3((unsigned)cdiv(n * 16, 256)), dim3(256), 0, h->stream>>>(
-                X + r0 * h->D, n, h->D, h->W, h->wsq, h->K, out + r0, xsq + r0, xerr + r0, h->wmax2, xmax2, h->wmax2 + 1, eb, ex.seed);
         // (sorted pass: the screen, the select kernel and the merge keys work on positions of the sorted order)
-        const float* p_xsq = xsq + r0; const float* p_xerr = xerr + r0; const float* p_seed = ex.seed_live ? ex.seed : nullptr;
+        const float* p_xsq = xsq + r0; const float* p_xerr = xerr + r0; const float* p_seed = nullptr;
         const __bf16* p_Xb = Xb + r0 * h->dp;
         const float* p_X = X + r0 * h->D;                    // the rows the re-score reads, indexed like the lists' entries
         const int* p_order = nullptr;
         if (ex.skip_live) {
+            unsigned long long* best = h->best64 + r0;
+            if (scout)
+                if (int rc = SOM_HALF(h, exact_scout_nearest, h, Xb + r0 * h->dp, n, best, ex.scout_g)) return rc;
             if (resort)
-                if (int rc = SOM_HALF(h, exact_skip_sort, h, X + r0 * h->D, Xb + r0 * h->dp, r0, n, xsq + r0, xerr + r0, out + r0, xmax2)) return rc;
-            if (int rc = SOM_HALF(h, exact_skip_plan, h, r0, n, out + r0, xmax2, eb)) return rc;
-            p_xsq = ex.xsq_s + r0; p_xerr = ex.xerr_s + r0; p_seed = ex.seed_s + r0; p_Xb = ex.Xb_s + r0 * h->dp; p_order = ex.order + r0;
-            p_X = ex.Xf_s + r0 * h->D;
+                if (int rc = exact_skip_sortkeys(h, sr, s0, n, out + r0, scout ? ex.scout_g : nullptr)) return rc;
+            // Is there anything for the plan to skip?  The scout, the gather and the plan cost a fifth of a full scan: before the
+            // pass is committed to them, every stride-th TILE of its sorted order -- up to 128 of the very tiles the plan would see
+            // -- goes through gather, pick and plan as a small pass of its own and the executed share comes back (one host wait).
+            // Where more than 0.8 of the sample's blocks would run -- a random codebook, the smooth map of a schedule's second
+            // epoch, rows without structure -- the launch runs every block, unsorted, without a plan.
+            const long tiles_all = n / SK_TILE;
+            if (estimate && r0 == 0 && tiles_all > 256) {
+                auto& ss = ex.srt[1];
+                const long st = tiles_all / 128, n_st = std::min<long>(128, tiles_all / st), ns = n_st * SK_TILE;
+                int* s_order = ex.sk_keys;                    // (the sort's input keys and row ids: free since the sort)
+                int* s_keys = ex.sk_vals;
+                exact_sample_tiles_kernel<<<dim3((unsigned)n_st), dim3(SK_TILE), 0, h->stream>>>(sr.order + s0, ex.sk_keys2, st, s_order, s_keys);
+                if (int rc = SOM_HALF(h, exact_skip_gather, h, ss, 0L, s_order, X + r0 * h->D, Xb + r0 * h->dp, ns, xsq + r0, xerr + r0, xmax2)) return rc;
+                if (int rc = SOM_HALF(h, exact_scout_pick, h, ss, 0L, ns, s_keys, best)) return rc;
+                const int* lp2 = nullptr;
+                if (have_last) {
+                    exact_lastpos_kernel<<<dim3((unsigned)cdiv(ns, 256)), dim3(256), 0, h->stream>>>(out + r0, s_order, h->ex_inv, ns, h->K, ex.scout_g);
+                    lp2 = ex.scout_g;                         // (the nearest groups have gone into the sort keys: free)
+                }
+                if (int rc = SOM_HALF(h, exact_skip_plan, h, ss, 0L, ns, xmax2, eb, lp2)) return rc;
+                HIPCHK(h, hipMemcpyAsync(ex.fb_count_host, ex.ctr + 2 * n_groups, 7 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                const double est = (double)ex.fb_count_host[3] / (double)(n_st * n_groups * K16_T);
+                ex.scout_est_last = est;
+                if (h->debug) std::fprintf(stderr, "[somhip] exact scout: %ld sample tiles of %ld would run %.4f of their blocks\n", n_st, tiles_all, est);
+                if (est > 0.8) {
+                    ex.skip_live = false; scout = false; resort = false; ex.scout_live = false; ex.refine_live = false; ex.scout_declined += 1;
+                    if (resident) ex.res_valid = false;       // (the order was rebuilt, the sorted copies were not)
+                    // (a declined plan counts as an idle one: rows without structure are asked less and less often)
+                    int& idle = resident ? ex.skip_idle : ex.tr_idle;
+                    int& cool = resident ? ex.skip_cooldown : ex.tr_cooldown;
+                    int& pause = resident ? ex.skip_pause : ex.tr_pause;
+                    if (++idle >= 2) { cool = pause; pause = std::min(2 * pause, 16); }
+                }
+            }
+        }
+        // resident rows from their second epoch on: last epoch's BMU of every row caps the screen's keep threshold -- under a
+        // plan the plan's prologue forms that seed from the operands it holds (exact_skip.hpp), else exact_seed_kernel
+        ex.seed_live = ex.seed_on && !h->wide && have_last;
+        if (ex.seed_live && !ex.skip_live) {
+            exact_seed_kernel<<<dim3((unsigned)cdiv(n * 16, 256)), dim3(256), 0, h->stream>>>(
+                X + r0 * h->D, n, h->D, h->W, h->wsq, h->K, out + r0, xsq + r0, xerr + r0, h->wmax2, xmax2, h->wmax2 + 1, eb, ex.seed);
+            p_seed = ex.seed;
+        }
+        if (ex.skip_live) {
+            unsigned long long* best = h->best64 + r0;
+            if (resort)
+                if (int rc = SOM_HALF(h, exact_skip_gather, h, sr, s0, sr.order + s0, X + r0 * h->D, Xb + r0 * h->dp, n, xsq + r0, xerr + r0, xmax2)) return rc;
+            const int* lastpos2 = nullptr;
+            if (scout) {
+                if (int rc = SOM_HALF(h, exact_scout_pick, h, sr, s0, n, ex.sk_keys2, best)) return rc;
+                if (have_last) {
+                    // (the rows' real last BMUs beside the scout's picks: the plan's prologue keeps the better unit; sk_vals: free since the sort)
+                    exact_lastpos_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(out + r0, sr.order + s0, h->ex_inv, n, h->K, ex.sk_vals);
+                    lastpos2 = ex.sk_vals;
+                }
+            } else {
+                exact_lastpos_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(out + r0, sr.order + s0, h->ex_inv, n, h->K, sr.lastpos_s + s0);
+            }
+            if (int rc = SOM_HALF(h, exact_skip_plan, h, sr, s0, n, xmax2, eb, lastpos2)) return rc;
+            p_xsq = sr.xsq_s + s0; p_xerr = sr.xerr_s + s0; p_seed = sr.seed_s + s0; p_Xb = sr.Xb_s + s0 * h->dp; p_order = sr.order + s0;
+            p_X = sr.Xf_s + s0 * h->D;
         }
         {
             Timed ts(h, SOM_K_SCREEN);
@@ -1449,7 +1636,7 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
                 ex.gmin, ex.gflags, ex.stride, n_groups, n, best, p_xsq, h->wmax2, xmax2, eb, p_xerr, h->wmax2 + 1, ex.plist,
                 ex.ctr, ex.rowcnt, nullptr, p_seed, ex.skip_live ? ex.glist : nullptr, ex.skip_live ? ex.gcnt : nullptr, SK_TILE);
             if (ex.refine_live)
-                if (int rc = SOM_HALF(h, exact_refine, h, r0, n, xmax2, eb)) return rc;
+                if (int rc = SOM_HALF(h, exact_refine, h, sr, s0, n, xmax2, eb)) return rc;
             if (int rc = exact_rescore_round(h, p_X, xsq + r0, best, nullptr, nullptr)) return rc;
         }
         exact_finalize_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(
@@ -1505,6 +1692,25 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     }
     if (ex.skip_live && ex.blocks_total > total_before) {
         const double share = (double)(ex.blocks_run - run_before) / (double)(ex.blocks_total - total_before);
+        const double l1_share = (double)groups_run * K16_T / (double)(ex.blocks_total - total_before);
+        if (scout) ex.scouted += 1;
+        ex.pairs_per_row_last = (double)pairs_in / (double)std::max<long>(N, 1);
+        if (ex.refine_live) { ex.pairs_refined_in += pairs_in; ex.pairs_refined_out += pairs_out; }
+        if (!resident) {
+            ex.tr_planned += 1;
+            ex.tr_share_last = share;
+            if (h->debug)
+                std::fprintf(stderr, "[somhip] exact plan (transient, %ld rows): share %.4f level-1 %.4f level-2 %d refine %d pairs/row %.2f -> %.2f\n",
+                             N, share, l1_share, ex.l2_live ? 1 : 0, ex.refine_live ? 1 : 0, ex.pairs_per_row_last, (double)pairs_out / (double)std::max<long>(N, 1));
+            if (ex.skip_mode == 1) {
+                if (share > 0.97) {
+                    if (++ex.tr_idle >= 2) { ex.tr_cooldown = ex.tr_pause; ex.tr_pause = std::min(2 * ex.tr_pause, 16); }
+                } else {
+                    ex.tr_idle = 0; ex.tr_pause = 2;
+                }
+            }
+            return 0;
+        }
         ex.planned += 1;
         if (resort) {
             // a sort that did not pay (the share it left is no better than the stale order's: the schedule, not the order,
@@ -1515,12 +1721,10 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         }
         ex.res_since += 1;
         ex.res_share_last = share; ex.res_l2_last = ex.l2_live;
-        ex.l1_share_last = (double)groups_run * K16_T / (double)(ex.blocks_total - total_before);
-        ex.pairs_per_row_last = (double)pairs_in / (double)std::max<long>(N, 1);
-        if (ex.refine_live) { ex.pairs_refined_in += pairs_in; ex.pairs_refined_out += pairs_out; }
+        ex.l1_share_last = l1_share;
         if (h->debug)
-            std::fprintf(stderr, "[somhip] exact plan %ld: share %.4f level-1 %.4f level-2 %d (paid %d) sorted %d (since %d, next forced at %d) refine %d pairs/row %.2f -> %.2f\n",
-                         (long)ex.planned, share, ex.l1_share_last, ex.l2_live ? 1 : 0, ex.l2_pays ? 1 : 0, resort ? 1 : 0, ex.res_since, ex.res_forced,
+            std::fprintf(stderr, "[somhip] exact plan %ld: share %.4f level-1 %.4f level-2 %d (paid %d) sorted %d scout %d (since %d, next forced at %d) refine %d pairs/row %.2f -> %.2f\n",
+                         (long)ex.planned, share, ex.l1_share_last, ex.l2_live ? 1 : 0, ex.l2_pays ? 1 : 0, resort ? 1 : 0, scout ? 1 : 0, ex.res_since, ex.res_forced,
                          ex.refine_live ? 1 : 0, ex.pairs_per_row_last, (double)pairs_out / (double)std::max<long>(N, 1));
         if (ex.l2_live) {
             ex.l2_pays = 1.5 * (ex.l1_share_last - share) > 0.1 * ex.l1_share_last + 0.006;
@@ -1529,8 +1733,6 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         } else {
             ex.l2_wait -= 1;
         }
-        // (two idle plans in a row: ONE is what the smooth map of a schedule's second epoch gives, and the third epoch of
-        //  the benchmark's schedule already runs a tenth of the blocks)
         // rows without structure: two idle plans in a row (> 97 % of the blocks kept; ONE is what the smooth map of a schedule's
         // second epoch gives) pause the plan for two epochs, the next idle one for four, then eight, sixteen: the plan's
         // cost on such rows falls below a percent; a plan that skips again resets the pause
@@ -1875,12 +2077,18 @@ int run_transform(som_handle* h, double sigma, double eta, int neigh_f64) {
     return run_transform_stage2(h, 0, (int)cdiv(h->X, LM_BM));
 }
 
-int ensure_query_scratch(som_handle* h, long n) {
+// with_rows: the caller stages host rows through qX (device rows of the caller's are read where they are)
+int ensure_query_scratch(som_handle* h, long n, bool with_rows = true) {
+    if (with_rows && n > h->qX_cap) {
+        (void)hipFree(h->qX);
+        h->qX = nullptr; h->qX_cap = 0;
+        if (int rc = dev_alloc(h, &h->qX, (size_t)round_up(n, 1024) * h->D)) return rc;
+        h->qX_cap = round_up(n, 1024);
+    }
     if (n <= h->qcap) return 0;
     long cap = round_up(n, 1024);
-    (void)hipFree(h->qX); (void)hipFree(h->qbmu); (void)hipFree(h->qbmu2); (void)hipFree(h->qxsq); (void)hipFree(h->qXb);
-    h->qX = nullptr; h->qbmu = nullptr; h->qbmu2 = nullptr; h->qxsq = nullptr; h->qXb = nullptr; h->qcap = 0;
-    if (int rc = dev_alloc(h, &h->qX, (size_t)cap * h->D)) return rc;
+    (void)hipFree(h->qbmu); (void)hipFree(h->qbmu2); (void)hipFree(h->qxsq); (void)hipFree(h->qXb);
+    h->qbmu = nullptr; h->qbmu2 = nullptr; h->qxsq = nullptr; h->qXb = nullptr; h->qcap = 0;
     if (int rc = dev_alloc(h, &h->qbmu, (size_t)cap)) return rc;
     if (int rc = dev_alloc(h, &h->qbmu2, (size_t)cap)) return rc;
     if (int rc = dev_alloc(h, &h->qxsq, (size_t)cap * (h->exact ? 2 : 1))) return rc;
@@ -2091,6 +2299,7 @@ int som_create(const som_config* cfg, som_handle** out) {
         if (const char* e = std::getenv("SOM_EXACT_SKIP")) h->ex.skip_mode = std::atoi(e);
         if (const char* e = dev_env("SOM_EXACT_SUBBLOCKS")) h->ex.sub_blocks = std::atoi(e) != 0;
         if (const char* e = dev_env("SOM_EXACT_REFINE")) h->ex.refine_on = std::atoi(e) != 0;
+        if (const char* e = dev_env("SOM_EXACT_SCOUT")) h->ex.scout_on = std::atoi(e) != 0;
         if (const char* e = dev_env("SOM_EXACT_RESORT")) h->ex.res_every = std::max(0, std::atoi(e));
         if (const char* e = dev_env("SOM_ASYNC_COPIES")) h->async_copies = std::atoi(e) != 0;
         if (const char* e = dev_env("SOM_FUSE_MERGE")) h->fuse_merge_prep = std::atoi(e) != 0;
@@ -2163,11 +2372,15 @@ void som_destroy(som_handle* h) {
     }
     {
         void* eb[] = {h->ex.gmin, h->ex.gflags, h->ex.rowcnt, h->ex.rowarg, h->ex.seed, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab,
-                      h->ex.order, h->ex.sk_keys, h->ex.sk_keys2, h->ex.sk_vals, h->ex.sk_tmp, h->ex.Xb_s, h->ex.Xl_s, h->ex.Xf_s, h->ex.xsq_s, h->ex.xerr_s,
-                      h->ex.seed_s, h->ex.sU_s, h->ex.lastpos_s, h->ex.need, h->ex.need2, h->ex.glist, h->ex.gcnt, h->ex.tile_counts, h->ex.tlist, h->ex.tcnt};
+                      h->ex.sk_keys, h->ex.sk_keys2, h->ex.sk_vals, h->ex.sk_tmp, h->ex.scout_g,
+                      h->ex.need, h->ex.need2, h->ex.glist, h->ex.gcnt, h->ex.tile_counts, h->ex.tlist, h->ex.tcnt};
         for (void* b : eb) if (b) (void)hipFree(b);
+        for (auto& sr : h->ex.srt) {
+            void* sb[] = {sr.order, sr.Xb_s, sr.Xl_s, sr.Xf_s, sr.xsq_s, sr.xerr_s, sr.seed_s, sr.sU_s, sr.lastpos_s};
+            for (void* b : sb) if (b) (void)hipFree(b);
+        }
         for (auto& c : h->ex.cen) {
-            void* cb[] = {c.Cc, c.rg, c.csq, c.cmax2, c.Cst};
+            void* cb[] = {c.Cc, c.rg, c.csq, c.cmax2, c.Cst, c.Cst_plain};
             for (void* b : cb) if (b) (void)hipFree(b);
         }
         if (h->ex.fb_count_host) (void)hipHostFree(h->ex.fb_count_host);
@@ -2243,7 +2456,7 @@ static int adopt_rows(som_handle* h, int64_t n_rows) {
         bool ok = exact_reserve(h, n_rows) == 0;
         const long n_groups = cdiv(h->K, EX_GROUP);
         if (ok && h->ex.skip_mode > 0 && h->ex.seed_on && !h->wide && (h->ex.skip_mode > 1 ? n_groups >= 2 : h->K >= 4096))
-            ok = exact_skip_reserve(h, n_rows, h->ex.stride) == 0;
+            ok = exact_skip_reserve(h, h->ex.srt[0], n_rows, h->ex.stride) == 0;
         if (!ok) { (void)hipGetLastError(); h->err.clear(); }
     }
     return 0;
@@ -2723,15 +2936,39 @@ namespace {
 // of the n_rows rows in the query scratch.  f32 precision: the reference's sqrt'd distance, bit for bit.
 // bf16 / f16 precision with the 'euclidean' activation distance: the same argmin through the configured
 // MFMA path (the squared distance is monotone in it); the caller evaluates the distance itself exactly.
-int run_quantization_bmu(som_handle* h, long n_rows) {
-    if (h->cfg.precision != SOM_PREC_F32 && !h->exact && h->cfg.distance == SOM_DIST_EUCLIDEAN) {
-        if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1, h->qxsq)) return rc;
-        return run_activation_bmu(h, h->qX, n_rows, h->qxsq, h->qXb, h->xmax2 + 1, h->qbmu);
+// value_only (quantization_error): the caller evaluates the distance to the chosen unit itself and wants no id -- in EXACT
+// precision with the 'euclidean' activation distance the screen + re-score then serves (its pick is float32's argmin of the
+// squared distance's unit part; the sqrt'd distance can only tie where that one is within an ulp: the same distance).
+int run_quantization_bmu(som_handle* h, const float* X, long n_rows, bool value_only = false) {
+    if (h->cfg.precision != SOM_PREC_F32 && h->cfg.distance == SOM_DIST_EUCLIDEAN && (!h->exact || value_only)) {
+        if (h->exact) if (int rc = row_sq(h, X, n_rows, h->qxsq)) return rc;
+        if (int rc = prep_rows_bf16(h, X, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1, h->qxsq)) return rc;
+        return run_activation_bmu(h, X, n_rows, h->qxsq, h->qXb, h->xmax2 + 1, h->qbmu);
     }
     if (int rc = refresh_codebook_operands(h, true)) return rc;
-    if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
+    if (int rc = row_sq(h, X, n_rows, h->qxsq)) return rc;
     Timed t(h, SOM_K_BMU);
-    return launch_bmu_f32_any<SCORE_EUCLID_SQRT>(h, h->qX, n_rows, h->qxsq, h->qbmu);
+    return launch_bmu_f32_any<SCORE_EUCLID_SQRT>(h, X, n_rows, h->qxsq, h->qbmu);
+}
+
+// BMUs (activation or quantization rule) of n device rows into qbmu
+int run_query_bmu(som_handle* h, const float* X, long n_rows, int mode) {
+    if (mode == SOM_BMU_QUANTIZATION) return run_quantization_bmu(h, X, n_rows);
+    if (needs_xsq(h)) if (int rc = row_sq(h, X, n_rows, h->qxsq)) return rc;
+    if (h->cfg.precision != SOM_PREC_F32)
+        if (int rc = prep_rows_bf16(h, X, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1, h->qxsq)) return rc;
+    return run_activation_bmu(h, X, n_rows, h->qxsq, h->qXb, h->xmax2 + 1, h->qbmu);
+}
+
+int run_quantization_error(som_handle* h, const float* X, long n_rows, double* qe_out) {
+    if (int rc = run_quantization_bmu(h, X, n_rows, true)) return rc;
+    HIPCHK(h, hipMemsetAsync(h->dsum, 0, sizeof(double), h->stream));
+    qe_kernel<<<dim3((unsigned)cdiv(n_rows, 4)), dim3(256), 0, h->stream>>>(X, h->qbmu, h->W, n_rows, h->D, h->dsum);
+    HIPCHK(h, hipGetLastError());
+    double s = 0.0;
+    if (int rc = d2h_blocking(h, &s, h->dsum, sizeof(double))) return rc;
+    *qe_out = s / (double)n_rows;
+    return 0;
 }
 }  // namespace
 
@@ -2742,15 +2979,28 @@ int som_bmu(som_handle* h, const float* x_host, int64_t n_rows, int32_t mode, in
     if (n_rows == 0) return 0;
     if (int rc = ensure_query_scratch(h, n_rows)) return rc;
     if (int rc = h2d_blocking(h, h->qX, x_host, (size_t)n_rows * h->D * sizeof(float))) return rc;
-    if (mode == SOM_BMU_QUANTIZATION) {
-        if (int rc = run_quantization_bmu(h, n_rows)) return rc;
-    } else {
-        if (needs_xsq(h)) if (int rc = row_sq(h, h->qX, n_rows, h->qxsq)) return rc;
-        if (h->cfg.precision != SOM_PREC_F32)
-            if (int rc = prep_rows_bf16(h, h->qX, n_rows, round_up(n_rows, ROW_PAD), h->qXb, h->xmax2 + 1, h->qxsq)) return rc;
-        if (int rc = run_activation_bmu(h, h->qX, n_rows, h->qxsq, h->qXb, h->xmax2 + 1, h->qbmu)) return rc;
-    }
+    if (int rc = run_query_bmu(h, h->qX, n_rows, mode)) return rc;
     return d2h_blocking(h, ids_out, h->qbmu, (size_t)n_rows * sizeof(int));
+}
+
+int som_bmu_device(som_handle* h, const void* x_dev, int64_t n_rows, int32_t mode, int32_t* ids_out) {
+    DeviceGuard dev_guard(h);
+    if (!h || n_rows < 0 || (n_rows > 0 && (!x_dev || !ids_out))) return fail(h, "som_bmu_device: bad argument");
+    if (mode != SOM_BMU_ACTIVATION && mode != SOM_BMU_QUANTIZATION) return fail(h, "som_bmu_device: unknown mode");
+    if (n_rows == 0) return 0;
+    if (n_rows > 0x7fffffffL) return fail(h, "som_bmu_device: more than 2^31-1 rows in one call");
+    if (int rc = ensure_query_scratch(h, n_rows, false)) return rc;
+    if (int rc = run_query_bmu(h, (const float*)x_dev, n_rows, mode)) return rc;
+    return d2h_blocking(h, ids_out, h->qbmu, (size_t)n_rows * sizeof(int));
+}
+
+int som_quantization_error_device(som_handle* h, const void* x_dev, int64_t n_rows, double* qe_out) {
+    DeviceGuard dev_guard(h);
+    if (!h || !qe_out || n_rows < 0 || (n_rows > 0 && !x_dev)) return fail(h, "som_quantization_error_device: bad argument");
+    if (n_rows == 0) { *qe_out = NAN; return 0; }
+    if (n_rows > 0x7fffffffL) return fail(h, "som_quantization_error_device: more than 2^31-1 rows in one call");
+    if (int rc = ensure_query_scratch(h, n_rows, false)) return rc;
+    return run_quantization_error(h, (const float*)x_dev, n_rows, qe_out);
 }
 
 int som_bmu_f64(som_handle* h, const double* x_host, int64_t n_rows, int32_t* ids_out) {
@@ -2828,14 +3078,7 @@ int som_quantization_error(som_handle* h, const float* x_host, int64_t n_rows, d
     if (n_rows == 0) { *qe_out = NAN; return 0; }     // numpy: mean of an empty array
     if (int rc = ensure_query_scratch(h, n_rows)) return rc;
     if (int rc = h2d_blocking(h, h->qX, x_host, (size_t)n_rows * h->D * sizeof(float))) return rc;
-    if (int rc = run_quantization_bmu(h, n_rows)) return rc;
-    HIPCHK(h, hipMemsetAsync(h->dsum, 0, sizeof(double), h->stream));
-    qe_kernel<<<dim3((unsigned)cdiv(n_rows, 4)), dim3(256), 0, h->stream>>>(h->qX, h->qbmu, h->W, n_rows, h->D, h->dsum);
-    HIPCHK(h, hipGetLastError());
-    double s = 0.0;
-    if (int rc = d2h_blocking(h, &s, h->dsum, sizeof(double))) return rc;
-    *qe_out = s / (double)n_rows;
-    return 0;
+    return run_quantization_error(h, h->qX, n_rows, qe_out);
 }
 
 int som_set_verify(som_handle* h, int32_t n_rows) {
@@ -2943,6 +3186,12 @@ int som_exact_skip_stats(som_handle* h, int64_t* blocks_run, int64_t* blocks_tot
 int som_exact_resident_stats(som_handle* h, int64_t* planned_epochs, int64_t* sorts) {
     if (!h || !planned_epochs || !sorts) return 1;
     *planned_epochs = h->ex.planned; *sorts = h->ex.resorts;
+    return 0;
+}
+
+int som_exact_scout_stats(som_handle* h, int64_t* scouted_launches, int64_t* transient_planned) {
+    if (!h || !scouted_launches || !transient_planned) return 1;
+    *scouted_launches = h->ex.scouted; *transient_planned = h->ex.tr_planned;
     return 0;
 }
 

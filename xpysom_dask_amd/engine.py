@@ -232,6 +232,18 @@ class HipEngine:
         self._check(self._lib.som_bmu(self._h, self._fp(x), x.shape[0], mode, self._ip(ids)))
         return ids
 
+    def bmu_device(self, dev_ptr, n_rows, quantization=False):
+        """BMU ids of float32 rows that already live in HBM (`dev_ptr`: [n_rows][D], borrowed for the call)."""
+        ids = np.empty((int(n_rows),), dtype=np.int32)
+        mode = _lib.SOM_BMU_QUANTIZATION if quantization else _lib.SOM_BMU_ACTIVATION
+        self._check(self._lib.som_bmu_device(self._h, C.c_void_p(dev_ptr), int(n_rows), mode, self._ip(ids)))
+        return ids
+
+    def quantization_error_device(self, dev_ptr, n_rows):
+        out = C.c_double()
+        self._check(self._lib.som_quantization_error_device(self._h, C.c_void_p(dev_ptr), int(n_rows), C.byref(out)))
+        return out.value
+
     def bmu_f64(self, x):
         """BMUs of float64 rows under the float64 arithmetic NumPy applies to them (som_bmu_f64: euclidean only)."""
         x = np.ascontiguousarray(x, dtype=np.float64)
@@ -307,6 +319,12 @@ class HipEngine:
         """precision 'exact': (epochs run under a plan, of which (re-)sorted the resident rows by their last BMU's patch)."""
         a, b = C.c_int64(), C.c_int64()
         self._check(self._lib.som_exact_resident_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def exact_scout_stats(self):
+        """precision 'exact': (BMU launches that ran the scout, launches over transient row sets that ran under a plan)."""
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self._lib.som_exact_scout_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def exact_refine_stats(self):

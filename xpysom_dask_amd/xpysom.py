@@ -371,6 +371,33 @@ class XPySom:
         return self.train(data, num_iteration, verbose=verbose)
 
     # ------------------------------------------------------------------ inference
+    def _device_query(self, x):
+        """(engine, pointer, n_rows) for 2-D float32 rows that already live in HBM, else None: such rows are searched where
+        they are (som_bmu_device), whole -- no host round trip, no n_parallel chunks (xpysom.py:379-396 on a CuPy array)."""
+        shape = getattr(x, 'shape', None)
+        if shape is None or len(shape) != 2:
+            return None
+        dev = _device_rows(x)
+        if dev is None:
+            return None
+        ptr, n, d, dev_index, owner, stream = dev
+        if d != self._input_len:
+            raise ValueError('Received %d features, expected %d.' % (d, self._input_len))
+        eng = self._upload_weights()
+        if dev_index is not None and dev_index != eng.device:
+            raise ValueError('device data lives on cuda:%d, the engine on cuda:%d' % (dev_index, eng.device))
+        if stream != "done":
+            eng.sync_producer(stream)
+        return eng, ptr, n, owner
+
+    def _ids_of(self, x, quantization=False):
+        """Raveled BMU ids of host or device rows."""
+        q = self._device_query(x)
+        if q is not None:
+            eng, ptr, n, _owner = q
+            return eng.bmu_device(ptr, n, quantization=quantization)
+        return self._winner_ids(_host_rows(x, self._engine), quantization=quantization)
+
     def _winner_ids(self, x2d, quantization=False):
         eng = self._upload_weights()
         out = [eng.bmu(x2d[s:s + self._n_parallel], quantization=quantization)
@@ -386,6 +413,10 @@ class XPySom:
         if (isinstance(x, np.ndarray) and x.dtype == np.float64 and np.asarray(self._weights).dtype == np.float32
                 and self._activation_distance_name == 'euclidean' and self._precision in ('f32', 'exact')):
             x64 = x
+        if self._device_query(x) is not None:               # rows in HBM: searched there
+            ids = self._ids_of(x).astype(np.int64)
+            wi, wj = np.divmod(ids, self._weights.shape[1])
+            return list(map(tuple, np.vstack([wi, wj]).T))
         x = _host_rows(x, self._engine)
         one = x.ndim == 1
         if one:
@@ -404,15 +435,20 @@ class XPySom:
 
     def quantization(self, data):
         """Assigns a code book (weights vector of the winning neuron) to each sample in data."""
-        data = _host_rows(data, self._engine)
-        self._check_input_len(data)
-        ids = self._winner_ids(data, quantization=True)
+        if self._device_query(data) is None:
+            data = _host_rows(data, self._engine)
+            self._check_input_len(data)
+        ids = self._ids_of(data, quantization=True)
         w = np.asarray(self._weights)
         return w.reshape(-1, w.shape[2])[ids]
 
     def quantization_error(self, data):
         """Average distance between each input sample and its best matching unit
         (always Euclidean, xpysom.py:673-707).  Returns a Python float."""
+        q = self._device_query(data)
+        if q is not None:
+            eng, ptr, n, _owner = q
+            return eng.quantization_error_device(ptr, n) if n else float('nan')
         data = _host_rows(data, self._engine)
         self._check_input_len(data)
         eng = self._upload_weights()
@@ -460,13 +496,12 @@ class XPySom:
 
     def predict(self, data):
         """Raveled BMU index of every sample (xpysom.py:608-617), batched."""
-        data = _host_rows(data, self._engine)
-        return self._winner_ids(data).astype(np.int64)
+        return self._ids_of(data).astype(np.int64)
 
     def _rows_by_unit(self, data):
         """BMU ids of `data` grouped: yields ((i, j), row indices in data order), units in order of first win --
         one batched BMU call and one stable sort instead of a winner() call per sample."""
-        ids = self._winner_ids(_host_rows(data, self._engine)).astype(np.int64)
+        ids = self._ids_of(data).astype(np.int64)
         if not len(ids):
             return
         order = np.argsort(ids, kind='stable')
@@ -479,10 +514,11 @@ class XPySom:
 
     def activation_response(self, data):
         """Matrix where element i,j is the number of times neuron i,j won (xpysom.py:819-829)."""
-        data = _host_rows(data, self._engine)
-        self._check_input_len(data)
+        if self._device_query(data) is None:
+            data = _host_rows(data, self._engine)
+            self._check_input_len(data)
         X, Y = self._weights.shape[:2]
-        return np.bincount(self._winner_ids(data), minlength=X * Y).astype(float).reshape(X, Y)
+        return np.bincount(self._ids_of(data), minlength=X * Y).astype(float).reshape(X, Y)
 
     def win_map(self, data):
         """Dictionary wm where wm[(i,j)] lists the patterns mapped to i,j (xpysom.py:831-840)."""
