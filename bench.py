@@ -74,12 +74,22 @@ def workload_rows(name, n, seed):
     return out
 
 
+def _hook(name, default):
+    """A developer switch of the library: read, as the library reads it, only under SOM_TEST_HOOKS=1."""
+    on = os.environ.get("SOM_TEST_HOOKS")
+    try:
+        on = on is not None and int(on) != 0
+    except ValueError:
+        on = False
+    return os.environ.get(name, default) if on else default
+
+
 def exact_has_screen(features, units, distance):
     """precision='exact' screens on half operands (<= 128 features: euclidean; 129..800 features on maps of >= 4096
     units: euclidean and cosine -- som_create); elsewhere the float32 kernels serve it."""
     if features <= 128:
         return distance == "euclidean"
-    return features <= 800 and units >= 4096 and distance in ("euclidean", "cosine") and os.environ.get("SOM_BF16_WIDE", "1") != "0"
+    return features <= 800 and units >= 4096 and distance in ("euclidean", "cosine") and _hook("SOM_BF16_WIDE", "1") != "0"
 
 
 def kernel_name_for(precision, features, units=1 << 16):
@@ -91,7 +101,7 @@ def kernel_name_for(precision, features, units=1 << 16):
     if precision == "f32":
         return "bmu_f32_tiled_kernel" if features > 128 else "bmu_f32_res_kernel"
     if features > 128:
-        wide = units >= 4096 and features <= 800 and os.environ.get("SOM_BF16_WIDE", "1") != "0"
+        wide = units >= 4096 and features <= 800 and _hook("SOM_BF16_WIDE", "1") != "0"
         return "bmu_bf16_wide_kernel" if wide else "bmu_bf16_tiled_kernel"
     return "bmu_bf16_k16_kernel"
 
@@ -214,6 +224,7 @@ def main():
                     help="weak scaling: the first k ranks draw rows WITHOUT structure (N(0, I)): shards that skip nothing beside shards that skip most")
     ap.add_argument("--no-schedule", action="store_true", help="skip the epoch-by-epoch / whole-schedule / unstructured-rows block")
     ap.add_argument("--no-f32-check", action="store_true", help="skip the float32 run the headline codebook is compared with")
+    ap.add_argument("--no-variants", action="store_true", help="skip the data_variants / survey_schedule / queries blocks")
     args = ap.parse_args()
 
     have_rank_env = "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -457,6 +468,117 @@ def main():
                         "executed_share": sum(sh_u[args.warmup:]) / len(k_ms), "epochs_under_a_plan": res_u[0],
                         "plan_paused_epochs": total - 1 - res_u[0], "whole_schedule_ms_per_epoch": sum(ms_u) / total}
 
+    # What the headline is worth elsewhere.  `survey_schedule`: SURVEY 8(d)'s own definition of the metric -- a 10-epoch schedule
+    # from the seeded codebook, the mean of epochs 1..9.  `data_variants`: the same map and (W + K)-epoch schedule on rows
+    # between "64 separated blobs" and "no structure" (xpysom_dask_amd/synthetic.py, variant()), each with block skipping on
+    # and off and against precision='f32'.  `queries`: winner() / quantization_error() on device-resident rows of the trained map.
+    survey, variants, queries = None, None, None
+    if args.precision == "exact" and not args.no_schedule and not args.no_variants and dist is None and FEATURES <= 128 \
+            and exact_has_screen(FEATURES, MAP_X * MAP_Y, wl["distance"]):
+        from xpysom_dask_amd import synthetic
+
+        def run_schedule(rows, n_epochs, prec="exact", skip=None):
+            old = os.environ.get("SOM_EXACT_SKIP")
+            if skip is not None:
+                os.environ["SOM_EXACT_SKIP"] = skip
+            e = HipEngine(MAP_X, MAP_Y, FEATURES, precision=prec, device=dev, distance=wl["distance"], neighborhood=wl["neighborhood"])
+            if skip is not None:
+                if old is None:
+                    del os.environ["SOM_EXACT_SKIP"]
+                else:
+                    os.environ["SOM_EXACT_SKIP"] = old
+            e.set_weights(w)
+            e.set_data(rows)
+            e.sync()
+            sc = [(exponential_decay(min(MAP_X, MAP_Y) / 2, 1, t, n_epochs), exponential_decay(0.5, 0.01, t, n_epochs)) for t in range(n_epochs)]
+            ms, sh = [], []
+            for t in range(n_epochs):
+                s0 = e.exact_skip_stats() if prec == "exact" else (0, 0)
+                t0 = time.perf_counter()
+                D.epoch(e, sc[t][0], sc[t][1], True)
+                e.sync()
+                ms.append(1e3 * (time.perf_counter() - t0))
+                s1 = e.exact_skip_stats() if prec == "exact" else (0, 0)
+                sh.append((s1[0] - s0[0]) / (s1[1] - s0[1]) if s1[1] > s0[1] else 1.0)
+            wv = e.get_weights()
+            return e, ms, sh, wv
+
+        e_v, ms_v, sh_v, w_v = run_schedule(rows_host, 10)
+        e_v.close()
+        e_o, ms_o, _, w_o = run_schedule(rows_host, 10, skip="0")
+        e_o.close()
+        survey = {"epochs": 10, "what": "SURVEY 8(d): 10-epoch default schedule from the seeded codebook, mean of epochs 1..9",
+                  "ms_per_epoch": sum(ms_v[1:]) / 9, "value": my_rows / (sum(ms_v[1:]) / 9 * 1e-3), "unit": "samples/sec/epoch",
+                  "per_epoch_ms": [round(v, 4) for v in ms_v], "executed_share_per_epoch": [round(v, 5) for v in sh_v],
+                  "without_block_skipping_ms_per_epoch": sum(ms_o[1:]) / 9,
+                  "without_block_skipping_per_epoch_ms": [round(v, 4) for v in ms_o],
+                  "codebook_equal_with_and_without_skipping": bool(np.array_equal(w_v, w_o))}
+        variants = {}
+        for kind in ("overlap", "manifold", "heavy"):
+            rows_k = synthetic.variant(kind, my_rows, FEATURES, seed=1234 + rank)
+            e_k, ms_k, sh_k, w_k = run_schedule(rows_k, total)
+            res_k, sc_k = e_k.exact_resident_stats(), e_k.exact_scout_stats()
+            e_k.close()
+            e_0, ms_0, _, w_0 = run_schedule(rows_k, total, skip="0")
+            e_0.close()
+            e_f, ms_f, _, w_f = run_schedule(rows_k, total, prec="f32")
+            e_f.close()
+            k_ms, k_0 = ms_k[args.warmup:], ms_0[args.warmup:]
+            variants[kind] = {
+                "ms_per_step": sum(k_ms) / len(k_ms), "value": my_rows / (sum(k_ms) / len(k_ms) * 1e-3), "unit": "samples/sec/epoch",
+                "executed_share": sum(sh_k[args.warmup:]) / len(k_ms), "whole_schedule_ms_per_epoch": sum(ms_k) / total,
+                "without_block_skipping_ms_per_step": sum(k_0) / len(k_0), "without_block_skipping_whole_schedule_ms_per_epoch": sum(ms_0) / total,
+                "slowest_epoch_vs_without_skipping": max(a / b for a, b in zip(ms_k, ms_0)),
+                "epochs_under_a_plan": res_k[0], "launches_scouted": sc_k[0],
+                "codebook_equal_to_f32_run": bool(np.array_equal(w_k, w_f)), "codebook_equal_without_skipping": bool(np.array_equal(w_k, w_0)),
+                "per_epoch_ms": [round(v, 3) for v in ms_k], "executed_share_per_epoch": [round(v, 4) for v in sh_k]}
+            assert variants[kind]["codebook_equal_to_f32_run"], "data variant %s: the exact mode's trained codebook is not the float32 mode's" % kind
+            del rows_k
+        variants["what"] = ("the headline's map and %d-epoch schedule on other rows (synthetic.variant): overlap = 1024 centres whose noise has the centres' own "
+                            "spread; manifold = a 2-D sheet embedded in %d-D; heavy = 64 blobs with power-law sizes; ms_per_step = mean of epochs %d..%d as in "
+                            "`value`" % (total, FEATURES, args.warmup, total - 1))
+        # queries on the trained map: rows already in HBM (a torch tensor), other rows of the same mixture
+        qrows = torch.from_numpy(workload_rows(args.workload, my_rows, 99 + rank)).cuda()
+        torch.cuda.synchronize()
+        queries = {"rows": my_rows, "what": "winner() / quantization_error() ids for device-resident rows (som_bmu_device, som_quantization_error_device) on the "
+                                            "headline run's trained map; wall ms per call incl. the ids' copy to the host, mean of 5 calls after one"}
+        ids_by = {}
+        for tag, skip in (("planned", None), ("without_block_skipping", "0")):
+            old = os.environ.get("SOM_EXACT_SKIP")
+            if skip is not None:
+                os.environ["SOM_EXACT_SKIP"] = skip
+            e_q = HipEngine(MAP_X, MAP_Y, FEATURES, precision="exact", device=dev, distance=wl["distance"], neighborhood=wl["neighborhood"])
+            if skip is not None:
+                if old is None:
+                    del os.environ["SOM_EXACT_SKIP"]
+                else:
+                    os.environ["SOM_EXACT_SKIP"] = old
+            e_q.set_weights(w_after_timed)
+            ids_by[tag] = e_q.bmu_device(qrows.data_ptr(), my_rows)
+            e_q.sync()
+            e_q.profile_reset()
+            e_q.profile_enable("bmu")
+            s0, t0 = e_q.exact_skip_stats(), time.perf_counter()
+            for _ in range(5):
+                e_q.bmu_device(qrows.data_ptr(), my_rows)
+            t_w = (time.perf_counter() - t0) / 5
+            e_q.profile_enable(False)
+            s1 = e_q.exact_skip_stats()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                qe_v = e_q.quantization_error_device(qrows.data_ptr(), my_rows)
+            t_q = (time.perf_counter() - t0) / 5
+            queries[tag] = {"winner_ms": 1e3 * t_w, "bmu_search_on_the_stream_ms": e_q.profile_get("bmu")[0] / 5,
+                            "executed_share": (s1[0] - s0[0]) / max(1, s1[1] - s0[1]), "quantization_error_ms": 1e3 * t_q, "quantization_error": qe_v}
+            e_q.close()
+        e_q = HipEngine(MAP_X, MAP_Y, FEATURES, precision="f32", device=dev, distance=wl["distance"], neighborhood=wl["neighborhood"])
+        e_q.set_weights(w_after_timed)
+        ids_f = e_q.bmu_device(qrows.data_ptr(), my_rows)
+        e_q.close()
+        queries["ids_equal_to_f32"] = bool(np.array_equal(ids_by["planned"], ids_f) and np.array_equal(ids_by["without_block_skipping"], ids_f))
+        assert queries["ids_equal_to_f32"], "the planned query path left the float32 ids"
+        del qrows
+
     kernel_name = kernel_name_for(args.precision, FEATURES, MAP_X * MAP_Y)
     peak = MFMA_F32_PEAK_TFLOPS if args.precision == "f32" else MFMA_BF16_PEAK_TFLOPS
     KD2 = 2.0 * (MAP_X * MAP_Y) * FEATURES            # 2*K*D flop per sample
@@ -688,9 +810,19 @@ def main():
             out["codebook_equal_to_f32_run"] = equal_f32
         if unstructured is not None:
             out["unstructured_rows"] = unstructured
+        if survey is not None:
+            out["survey_schedule"] = survey
+        if variants is not None:
+            out["data_variants"] = variants
+        if queries is not None:
+            out["queries"] = queries
         if full_scan is not None:
             full_scan["roofline_frac"] = KD2 * rows_launch / (full_scan["avg_launch_ms"] * 1e-3) / 1e12 / peak
             out["without_block_skipping"] = full_scan
+            # SURVEY 8(d)'s figure: the ALGORITHMIC 2 N K D flop over the kernel that executes all of them
+            out["roofline"]["frac_full_scan"] = full_scan["roofline_frac"]
+            out["roofline"]["frac_is"] = ("executed work: the flops of the blocks the planned screens ran / their launch time; frac_full_scan: the "
+                                          "algorithmic 2 N K D flop / the screen that runs every block (SOM_EXACT_SKIP=0, same epochs)")
         if rank_spread is not None:
             out.update(rank_spread)
         if probe is not None:

@@ -729,13 +729,15 @@ def test_exact_resident_order_is_resorted_lazily_and_never_changes_the_ids(monke
     wf = f.get_weights(); f.close()
     runs = {tag: _train_states(monkeypatch, env, X, Y, D, n, T, data, w)
             for tag, env in (("every", {"SOM_EXACT_RESORT": "1"}), ("third", {"SOM_EXACT_RESORT": "3"}),
-                             ("never", {"SOM_EXACT_RESORT": "1000"}), ("default", {}))}
+                             ("never", {"SOM_EXACT_RESORT": "1000"}), ("default", {"SOM_EXACT_SKIP": "2"}), ("auto", {}))}
     for tag, (ids, wx, skip, res) in runs.items():
         for t in range(T):
             assert np.array_equal(ids[t], ref[t]), (tag, t, int((ids[t] != ref[t]).sum()))
         assert np.array_equal(wx, wf), tag
-    planned, sorts = runs["default"][3]
+    planned, sorts = runs["default"][3]                      # (mode 2: a plan in every epoch, the default sort policy)
     assert planned >= T - 3 and 1 <= sorts <= planned, (planned, sorts)     # (a map this small keeps a quarter of its blocks: it sorts often)
+    # (default mode: on a map this small a planned launch costs what a full scan costs -- measured -- and the plan is paused)
+    assert 1 <= runs["auto"][3][0] <= T
     assert runs["every"][3][1] == runs["every"][3][0] and runs["never"][3][1] == 1
     assert 1 < runs["third"][3][1] < runs["third"][3][0]
     # a fresher order never runs more blocks than the order of the first planned epoch kept forever

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16
                                                                     float* __restrict__ seed_s,
                                                                     const unsigned long long* __restrict__ need1, int n_cstages1,
                                                                     int force_all, const int* __restrict__ lastpos2 = nullptr,
-                                                                    int gate = 0) {
+                                                                    int* __restrict__ scout_wins = nullptr) {
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     constexpr int DP = 32 * KS32;
@@ -341,7 +341,15 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16
                 };
                 float vu = value_of(lastpos[row]);
                 if (lastpos2 != nullptr) {
+                    // (lastpos: the scout's pick, lastpos2: the real last BMU.  A WIN of the scout: its unit's squared distance --
+                    //  |x|^2 + tau(v), tau(v) = 2 (v / S - B) -- is a tenth or more below the last BMU's: counted, so that the host
+                    //  knows whether the scout is still worth its launches next epoch)
                     const float v2 = value_of(lastpos2[row]);
+                    const float Sq = sw.sx * sw.sw;
+                    const float ua = q + 2.0f * (vu / Sq - sw.big), ub = q + 2.0f * (v2 / Sq - sw.big);
+                    const bool win = ua < 0.9f * ub;
+                    const unsigned long long wm = __ballot(win && quad == 0);
+                    if (scout_wins != nullptr && lane == __builtin_ctzll(__ballot(true)) && wm != 0ull) atomicAdd(scout_wins, (int)__popcll(wm));
                     vu = (v2 < vu || !(vu == vu)) ? v2 : vu;      // (a NaN value -- a NaN unit -- gives way to the other unit's)
                 }
                 const float Sw = sw.sx * sw.sw;
@@ -412,19 +420,6 @@ __global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16
         }
         __syncthreads();
         const int n_act = act_n;
-        // GATE (launches for which the host has no measurement of level 2's worth yet: a row set's first planned epoch, query
-        // rows): a tile that level 1 left with more than half of all groups has rows far from the whole map (the smooth maps of
-        // a schedule's first epochs, rows without structure) -- the sub-blocks' radii are small against that distance and their
-        // centroids prove little more (tools/ucent_probe.py: 0.86 -> 0.78 of the blocks where level 1 keeps 0.86), while level
-        // 2 would cost a sixteenth of the full scan and more: every sub-block of every kept group runs, no MFMA here
-        if (gate && 2 * n_act > n_slots / 4) {
-            if (blockIdx.y == 0)
-                for (int i = tid; i < n_act; i += 64 * K16_NW) {
-                    const int g = act[i];
-                    atomicOr(need + (long)blockIdx.x * n_cstages + (g >> 4), 15ull << (4 * (g & 15)));
-                }
-            return;
-        }
         const int c_all = (n_act + 15) / 16;
         const int b0 = 16 * (int)((long)c_all * blockIdx.y / gridDim.y);
         const int e0 = min(n_act, 16 * (int)((long)c_all * (blockIdx.y + 1) / gridDim.y));
@@ -757,7 +752,59 @@ __global__ __launch_bounds__(64) void exact_scout_lists_kernel(const int* __rest
     if (lane == 0) tcnt[tile] = 4 * base;
 }
 
-// Is a plan from the scout worth its launches at all?  SAMPLE TILES: every stride-th 256-row tile of the pass in its sorted
+// Is a plan from the scout worth its launches at all?  First the cheap question: how much of the map does a ROW need?  A sample of
+// the rows (one workgroup each, strided through the row set) against every group centroid in float32: with sqrt(U) = min_g (|x -
+// c_g| + r_g) -- the centroid-only bound -- how many groups pass level 1's test |x - c_g| - r_g <= sqrt(U)?  counts[0] += groups
+// needed, counts[1] += rows sampled.  A tile needs the union over its 256 rows: where a row alone needs nearly every group (a
+// random codebook, rows without structure) there is nothing to plan, and the launch is spared the scout altogether.
+__global__ __launch_bounds__(256) void exact_scout_rowneed_kernel(const float* __restrict__ X, long N, int D, int n_samples,
+                                                                  const float* __restrict__ Cc, const float* __restrict__ rg,
+                                                                  int n_groups, int* __restrict__ counts) {
+    extern __shared__ float xs[];                            // the row, then four wave minima / counts
+    __shared__ float wmin[4];
+    __shared__ int wcnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long step = N / n_samples;
+    const float* x = X + ((long)blockIdx.x * step + step / 2) * D;
+    for (int k = tid; k < D; k += 256) xs[k] = x[k];
+    __syncthreads();
+    auto dist = [&](int g) -> float {
+        const float* c = Cc + (long)g * D;
+        float q = 0.0f;
+        if ((D & 3) == 0) {
+            for (int k = 0; k < D; k += 4) {
+                const f32x4 v = *(const f32x4*)(c + k);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float t = xs[k + j] - v[j]; q = __builtin_fmaf(t, t, q); }
+            }
+        } else {
+            for (int k = 0; k < D; ++k) { const float t = xs[k] - c[k]; q = __builtin_fmaf(t, t, q); }
+        }
+        return __builtin_sqrtf(q);
+    };
+    float m = __builtin_inff();
+    for (int g = tid; g < n_groups; g += 256) {
+        const float r = rg[g];
+        if (r >= 0.0f) m = __builtin_fminf(m, dist(g) + r);  // (a slot without units: r < 0)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = __builtin_fminf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) wmin[wave] = m;
+    __syncthreads();
+    m = __builtin_fminf(__builtin_fminf(wmin[0], wmin[1]), __builtin_fminf(wmin[2], wmin[3]));
+    int need = 0;
+    for (int g = tid; g < n_groups; g += 256) {
+        const float r = rg[g];
+        if (r >= 0.0f) need += !(dist(g) - r > m) ? 1 : 0;   // (NaN distances: needed)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) need += __shfl_xor(need, o, 64);
+    if (lane == 0) wcnt[wave] = need;
+    __syncthreads();
+    if (tid == 0) { atomicAdd(counts, wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]); atomicAdd(counts + 1, 1); }
+}
+
+// ... then the exact one, on SAMPLE TILES: every stride-th 256-row tile of the pass in its sorted
 // order -- the very tiles the plan would see -- copied out (their rows' ids and sort keys) as a small pass of its own; the host
 // gathers, picks and plans that sample exactly as it would the pass and reads the executed share back before committing the
 // whole pass to the gather, the pick and the plan (somhip.hip, launch_bmu_exact).

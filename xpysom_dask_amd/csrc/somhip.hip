@@ -148,6 +148,8 @@ struct som_handle {
         bool scout_live = false;          // this launch runs the scout
         int* scout_g = nullptr;           // [stride] nearest group centroid of every row of the pass
         double scout_est_last = 0.0;      // executed share the sample tiles forecast at the last estimate
+        double scout_f_now = 0.0, scout_f_declined = 0.0; int scout_f_age = 0;   // the sampled rows' need now / when the sample tiles last declined a plan
+        double scout_win_share = 0.0;     // rows of the last launch whose scout pick beat their last BMU by a tenth of the squared distance
         int64_t scout_declined = 0;       // launches whose estimate said: nothing to skip, no plan
         int64_t scouted = 0, tr_planned = 0;   // som_exact_scout_stats: launches that ran the scout; transient launches under a plan
         double tr_share_last = 1.0;       // executed share of the last transient launch under a plan
@@ -157,8 +159,26 @@ struct som_handle {
         // when level 1's share has moved by half since the last probe
         double l1_share_last = 1.0, l1_share_probe = -1.0;
         bool l2_live = false, l2_pays = true;
-        bool l2_gate = false;             // this launch: level 2 leaves out the tiles that kept more than half of the groups (exact_plan_kernel)
         int l2_wait = 0;
+        // MEASURED COSTS (hipEvents on the handle's stream; per ROW, in ms, so that launches of different sizes compare): what the
+        // policy decides from -- is a plan worth its launches, does level 2 pay, did a sort pay, is the plan idle.  The launch as
+        // a whole is timed every time (two records); its phases under a plan -- screen, level 2, sort + gather -- in the first
+        // planned launches, in every launch that sorts, and every fourth one after that (a record costs a few microseconds of
+        // stream bubble: eight of them a launch would be 2 % of a 1.8 ms epoch).
+        struct Cost {
+            hipEvent_t ev[8] = {};            // [0] launch / pass start, [1, 2] screen, [3, 4] level 2, [5, 6] sort + gather, [7] pass end
+            bool have = false;
+            int since = 99;                   // planned launches since the phases were last timed
+            double full_total = 0.0;          // BMU search of the last launch WITHOUT a plan
+            double full_screen = 0.0;         //   ... of which its screen
+            double plan_total = 0.0;          // BMU search of the last launch under a plan
+            double plan_over = 0.0;           //   ... less its screen (plan, lists, select, refine, re-score): launches without the scout
+            double plan_over_scout = 0.0;     //   ... launches with the scout (+ nearest centroid, sort, gather, pick)
+            double blk_ms = 0.0;              // screen ms per 16-unit block run under a plan (NOT per row)
+            double l2_ms_group = 0.0;         // level-2 ms per (tile, group) pair level 1 kept, when it last ran
+            double l2_ratio = 1.0;            // blocks after level 2 / blocks after level 1, when it last ran
+            double sort_ms = 0.0;             // sort + gather, per row
+        } cost;
         // the centroid sets of the plan: [0] the 64-unit groups, [1] their 16-unit sub-blocks (exact_centroid_kernel's slot order)
         struct Centroids { float *Cc = nullptr, *rg = nullptr, *csq = nullptr, *cmax2 = nullptr; char* Cst = nullptr;
                            char* Cst_plain = nullptr;   // level 1 only: the scout's copy (plain initial accumulators)
@@ -982,7 +1002,7 @@ int exact_reserve_stride(som_handle* h, long stride) {
     ex.max_tiles = cdiv(stride * ex.pairs, EX_TR) + n_groups;
     if (int rc = dev_alloc(h, &ex.tile_tab, (size_t)ex.max_tiles)) return rc;
     if (!ex.ctr) {
-        if (int rc = dev_alloc(h, &ex.ctr, (size_t)3 * n_groups + 8)) return rc;
+        if (int rc = dev_alloc(h, &ex.ctr, (size_t)3 * n_groups + 16)) return rc;
         HIPCHK(h, hipHostMalloc((void**)&ex.fb_count_host, 8 * sizeof(int), hipHostMallocDefault));   // fb_count | n_tiles | overflow | 16-unit blocks run | groups run | pairs selected | pairs kept by the refinement
     }
     ex.stride = stride;
@@ -1299,7 +1319,7 @@ int exact_scout_pick(som_handle* h, som_handle::ExactScratch::SortedRows& sr, lo
 // one pass's plan on the sorted rows sr[s0, s0 + n): level 1 (+ the seeds, from lastpos_s), level 2, the tiles' item lists
 template <class E>
 int exact_skip_plan(som_handle* h, som_handle::ExactScratch::SortedRows& sr, long s0, long n, const float* xmax2, const ExactBound& eb,
-                    const int* lastpos2) {
+                    const int* lastpos2, bool time_l2 = false) {
     auto& ex = h->ex;
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
     const long np = round_up(n, SK_TILE);
@@ -1323,12 +1343,14 @@ int exact_skip_plan(som_handle* h, som_handle::ExactScratch::SortedRows& sr, lon
         { int pc; if (int rc = kernel_per_cu(h, (const void*)exact_plan_kernel<k, E, false>, 64 * K16_NW, lds1, &pc)) return rc; } \
         exact_plan_kernel<k, E, false><<<pgrid, block, lds1, h->stream>>>(Xs, n, c0.Cst, c0.n_cstages, c0.rg, c0.n_slots, \
             sr.xsq_s + s0, sr.xerr_s + s0, sr.sU_s + s0, xmax2, c0.cmax2, h->wmax2, h->wmax2 + 1, eb, ex.need, sr.lastpos_s + s0, \
-            h->Wst, sr.seed_s + s0, nullptr, 0, force, lastpos2); \
+            h->Wst, sr.seed_s + s0, nullptr, 0, force, lastpos2, lastpos2 != nullptr ? ex.ctr + 2 * n_groups + 7 : nullptr); \
         if (l2) { \
+            if (time_l2) (void)hipEventRecord(ex.cost.ev[3], h->stream); \
             { int pc; if (int rc = kernel_per_cu(h, (const void*)exact_plan_kernel<k, E, true>, 64 * K16_NW, lds2, &pc)) return rc; } \
             exact_plan_kernel<k, E, true><<<dim3((unsigned)tiles, pgrid.y), block, lds2, h->stream>>>(Xs, n, c1.Cst, c1.n_cstages, c1.rg, c1.n_slots, \
                 sr.xsq_s + s0, sr.xerr_s + s0, sr.sU_s + s0, xmax2, c1.cmax2, h->wmax2, h->wmax2 + 1, eb, ex.need2, nullptr, \
-                nullptr, nullptr, ex.need, c0.n_cstages, force, nullptr, ex.l2_gate ? 1 : 0); \
+                nullptr, nullptr, ex.need, c0.n_cstages, force); \
+            if (time_l2) (void)hipEventRecord(ex.cost.ev[4], h->stream); \
         } } break;
     switch (h->ks32) {
     SOM_PLAN_CASE(1) SOM_PLAN_CASE(2) SOM_PLAN_CASE(3) SOM_PLAN_CASE(4)
@@ -1442,6 +1464,7 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     const float* xerr = exact_err_of(h, xsq);
     if (!xerr) return fail(h, "exact: unknown row-norm buffer");
     auto& ex = h->ex;
+    auto& cost = ex.cost;
     if (int rc = exact_reserve(h, N)) return rc;
     if (N > h->best64_cap) {
         (void)hipFree(h->best64);
@@ -1449,6 +1472,11 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         if (int rc = dev_alloc(h, &h->best64, (size_t)round_up(N, 1024))) return rc;
         h->best64_cap = round_up(N, 1024);
     }
+    if (!cost.have) {
+        for (auto& e : cost.ev) HIPCHK(h, hipEventCreate(&e));
+        cost.have = true;
+    }
+    HIPCHK(h, hipEventRecord(cost.ev[0], h->stream));
     const long units = (long)h->n_stages * h->stage_units;
     prep_wsqh_kernel<<<dim3((unsigned)cdiv(std::max(units, N), 256)), dim3(256), 0, h->stream>>>(
         h->wn, h->K, h->wmax2, xmax2, h->Wst, h->n_stages, h->stage_bytes, h->stage_units, h->best64, N, 1);
@@ -1502,40 +1530,77 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         // runs -- there the bound from the current codebook's own centroids is the better one (tools/ucent_probe.py: 0.78 against
         // 0.95 of the blocks in a schedule's second epoch, 0.28 against 0.52 in its third), and the plan takes the better of the
         // two units row by row
-        scout = scout_ok && (!have_last || (resort && (fresh || ex.res_share_last >= 0.25)));
+        // ... and goes on, sorting the rows by its keys, while its picks still beat last epoch's BMUs by a tenth of the squared
+        // distance or more on a quarter of the rows (counted in the plan's prologue) AND halving the screen would still pay for
+        // it: (last share) x (measured screen time per block) / 2 against what a scouted launch spends beyond an unscouted one
+        // outside its screen (measured; before that: a tenth of a full screen)
+        bool scout_on_wins = false;
+        if (scout_ok && have_last && !fresh && ex.scout_win_share >= 0.25) {
+            const double bpr = (double)n_groups * K16_T / (double)SK_TILE;
+            const double blk = cost.blk_ms > 0.0 ? cost.blk_ms : cost.full_screen > 0.0 ? cost.full_screen / bpr : 0.0;
+            const double sc = (cost.plan_over_scout > 0.0 && cost.plan_over > 0.0) ? cost.plan_over_scout - cost.plan_over : 0.1 * cost.full_screen;
+            scout_on_wins = blk > 0.0 && sc > 0.0 && 0.5 * ex.res_share_last * bpr * blk > sc;
+        }
+        if (scout_on_wins) resort = true;
+        scout = scout_ok && (!have_last || (resort && (fresh || ex.res_share_last >= 0.25 || scout_on_wins)));
         // level 2 of the plan (the groups' 16-unit sub-blocks) where it pays.  Whether it does is MEASURED each time it runs
         // (both levels' shares come back with the pass's counters): it costs about a tenth of level 1's share of a full scan
         // (four centroids per kept group), it saves the blocks it drops -- on the smooth maps of a schedule's first epochs
         // and on the compact patches of its middle it drops next to nothing, late, when the patches have spread out, more
         // than half.  While it does not pay it is probed again every fourth planned epoch, or at once when level 1's share
-        // has moved by half since the last probe.  (Tile by tile the kernel itself leaves level 2 out where level 1 kept more
-        // than half of the groups: exact_plan_kernel.)
+        // has moved by half since the last probe.
         bool probe = ex.l1_share_probe < 0.0 || ex.l2_wait <= 0 || ex.l1_share_last > 1.5 * ex.l1_share_probe || ex.l1_share_last < ex.l1_share_probe / 1.5;
         // (a new row set starts like a new engine: level 2 is taken to pay until it has been measured on these rows)
         if (fresh && resident) { ex.l2_pays = true; ex.l1_share_probe = -1.0; }
         if (ex.l1_share_last > 0.9 && ex.l1_share_probe >= 0.0 && !ex.l2_pays) probe = false;   // (nothing for four times the centroids to find)
         ex.l2_live = ex.sub_blocks && (ex.l2_pays || probe || ex.skip_mode >= 2 || !resident) &&
                      2 * (size_t)h->stage_bytes + (size_t)cdiv(n_groups, K16_STAGE_UNITS) * (64 * sizeof(int) + 4 * 8) <= 150 * 1024;   // (its list of kept groups lives in LDS)
-        ex.l2_gate = ex.skip_mode < 2 && (!resident || ex.l1_share_probe < 0.0);   // (no measurement of level 2 on these rows yet)
         ex.scout_live = scout;
         if (int rc = SOM_HALF(h, exact_skip_centroids, h, xmax2)) return rc;
     }
     ex.scout_live = scout;
     // (the forecast from sample tiles: where the scout plans and there is no good recent plan of the same kind to go by)
     bool estimate = ex.skip_live && scout && ex.skip_mode == 1 && (resident || ex.tr_share_last >= 0.5);
+    if (estimate) {
+        // the cheap question first (exact_scout_rowneed_kernel): 128 sampled rows against the group centroids.  A tile needs at
+        // least what its rows need: where a row alone needs more than 0.9 of the groups -- a random codebook, rows without
+        // structure -- the launch runs without the scout, the sort and the plan (one small launch and one host wait spent)
+        const int n_samples = (int)std::min<long>(128, N);
+        HIPCHK(h, hipMemsetAsync(ex.ctr, 0, 2 * sizeof(int), h->stream));
+        exact_scout_rowneed_kernel<<<dim3((unsigned)n_samples), dim3(256), (size_t)h->D * sizeof(float), h->stream>>>(
+            X, N, h->D, n_samples, ex.cen[0].Cc, ex.cen[0].rg, n_groups, ex.ctr);
+        HIPCHK(h, hipMemcpyAsync(ex.fb_count_host, ex.ctr, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const double f = (double)ex.fb_count_host[0] / std::max(1.0, (double)ex.fb_count_host[1] * n_groups);
+        if (h->debug) std::fprintf(stderr, "[somhip] exact scout: a sampled row needs %.4f of the groups\n", f);
+        // (... or about as much as when the sample tiles last said no, up to eight launches ago: the same answer without asking them)
+        if (ex.scout_f_age < 8) ex.scout_f_age += 1; else ex.scout_f_declined = 0.0;
+        ex.scout_f_now = f;
+        if (f > 0.9 || (ex.scout_f_declined > 0.0 && f >= 0.9 * ex.scout_f_declined)) {
+            // (nearly free: not counted as an idle plan, asked again at the next launch)
+            ex.skip_live = false; scout = false; resort = false; ex.scout_live = false; estimate = false; ex.scout_declined += 1;
+        }
+    }
     if (estimate && exact_skip_reserve(h, ex.srt[1], 128 * SK_TILE, ex.stride) != 0) { (void)hipGetLastError(); h->err.clear(); estimate = false; }
     ex.share_forecast = resident ? ex.res_share_last : ex.tr_share_last;
     // the refinement pass (bmu_exact.hpp) where it pays: it costs about a third of the float32 re-score of the pairs it is
     // given (it is bound by the same gather of rows) and leaves one to one and a half pairs a row, at two small launches more:
     // worth it from three candidate pairs a row on (the last planned epoch's count) -- the smooth maps of a schedule's middle
     ex.refine_live = ex.skip_live && ex.refine_on && h->Wst_lo != nullptr && (ex.pairs_per_row_last >= 3.0 || ex.skip_mode >= 2);
-    int64_t groups_run = 0, pairs_in = 0, pairs_out = 0;
+    int64_t groups_run = 0, pairs_in = 0, pairs_out = 0, scout_wins = 0;
+    // which phases this launch times (the launch as a whole: always)
+    const bool planned_at_start = ex.skip_live;
+    bool time_phases = !ex.skip_live || cost.since >= 3 || cost.blk_ms == 0.0 || resort || scout;
+    double t_total = 0.0, t_screen = 0.0, t_l2 = 0.0, t_sort = 0.0;
+    bool l2_timed = false, sort_timed = false, screen_timed = false;
+    const double blocks_per_row = (double)n_groups * K16_T / (double)SK_TILE;
     for (long r0 = 0; r0 < N; r0 += chunk) {
         const long n = std::min(chunk, N - r0);
         const long s0 = resident ? r0 : 0;                   // where the pass sits in the sorted copies
+        if (r0 > 0) HIPCHK(h, hipEventRecord(cost.ev[0], h->stream));
         // (a pass behind one whose fallback rows went through the float32 kernel: its image back in patch order)
         if (h->wf_patch != h->ex_patch) if (int rc = refresh_codebook_operands(h, true, true)) return rc;
-        HIPCHK(h, hipMemsetAsync(ex.ctr, 0, (size_t)(2 * n_groups + 7) * sizeof(int), h->stream));
+        HIPCHK(h, hipMemsetAsync(ex.ctr, 0, (size_t)(2 * n_groups + 8) * sizeof(int), h->stream));
         // (sorted pass: the screen, the select kernel and the merge keys work on positions of the sorted order)
         const float* p_xsq = xsq + r0; const float* p_xerr = xerr + r0; const float* p_seed = nullptr;
         const __bf16* p_Xb = Xb + r0 * h->dp;
@@ -1545,13 +1610,20 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
             unsigned long long* best = h->best64 + r0;
             if (scout)
                 if (int rc = SOM_HALF(h, exact_scout_nearest, h, Xb + r0 * h->dp, n, best, ex.scout_g)) return rc;
-            if (resort)
+            if (resort) {
+                if (time_phases) { HIPCHK(h, hipEventRecord(cost.ev[5], h->stream)); }
                 if (int rc = exact_skip_sortkeys(h, sr, s0, n, out + r0, scout ? ex.scout_g : nullptr)) return rc;
+            }
             // Is there anything for the plan to skip?  The scout, the gather and the plan cost a fifth of a full scan: before the
             // pass is committed to them, every stride-th TILE of its sorted order -- up to 128 of the very tiles the plan would see
             // -- goes through gather, pick and plan as a small pass of its own and the executed share comes back (one host wait).
-            // Where more than 0.8 of the sample's blocks would run -- a random codebook, the smooth map of a schedule's second
-            // epoch, rows without structure -- the launch runs every block, unsorted, without a plan.
+            // The launch runs every block, unsorted, without a plan where the forecast says that is cheaper -- share x (screen
+            // time per block under a plan) + (what a scouted launch spends outside its screen) against the last launch without
+            // a plan, all MEASURED (before the first measurements: a scouted plan's overhead taken as a fifth of a full screen;
+            // with no full scan on record either: declined above 0.8 of the blocks) -- a random codebook, the smooth map of a
+            // schedule's second epoch, rows without structure.  The sample also says what level 2 is worth before it runs on
+            // the whole pass: it removes (1 - ratio) of a kept group's four blocks at its measured (else: a sixth of the
+            // group's screen) cost per kept group.
             const long tiles_all = n / SK_TILE;
             if (estimate && r0 == 0 && tiles_all > 256) {
                 auto& ss = ex.srt[1];
@@ -1567,12 +1639,30 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
                     lp2 = ex.scout_g;                         // (the nearest groups have gone into the sort keys: free)
                 }
                 if (int rc = SOM_HALF(h, exact_skip_plan, h, ss, 0L, ns, xmax2, eb, lp2)) return rc;
-                HIPCHK(h, hipMemcpyAsync(ex.fb_count_host, ex.ctr + 2 * n_groups, 7 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipMemcpyAsync(ex.fb_count_host, ex.ctr + 2 * n_groups, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
                 HIPCHK(h, hipStreamSynchronize(h->stream));
+                // (the sample's count of the scout's wins is not the pass's: cleared again)
+                HIPCHK(h, hipMemsetAsync(ex.ctr + 2 * n_groups + 7, 0, sizeof(int), h->stream));
                 const double est = (double)ex.fb_count_host[3] / (double)(n_st * n_groups * K16_T);
+                const double est1 = (double)ex.fb_count_host[4] / (double)(n_st * n_groups);
                 ex.scout_est_last = est;
-                if (h->debug) std::fprintf(stderr, "[somhip] exact scout: %ld sample tiles of %ld would run %.4f of their blocks\n", n_st, tiles_all, est);
-                if (est > 0.8) {
+                const double blk = cost.blk_ms > 0.0 ? cost.blk_ms : cost.full_screen > 0.0 ? 1.05 * cost.full_screen / blocks_per_row : 0.0;
+                const double over = cost.plan_over_scout > 0.0 ? cost.plan_over_scout
+                                  : cost.full_total > 0.0 ? (cost.full_total - cost.full_screen) + 0.2 * cost.full_screen : 0.0;
+                const bool priced = blk > 0.0 && over > 0.0 && cost.full_total > 0.0;
+                const bool decline = priced ? est * blocks_per_row * blk + over >= 0.97 * cost.full_total : est > 0.8;
+                if (ex.l2_live && est1 > 0.0 && ex.skip_mode == 1) {
+                    const double ratio = est / est1;
+                    const double l2c = cost.l2_ms_group > 0.0 ? cost.l2_ms_group : blk > 0.0 ? K16_T * blk / 6.0 : 0.0;
+                    if (l2c > 0.0 && blk > 0.0) ex.l2_live = (1.0 - ratio) * K16_T * blk > l2c;
+                    else ex.l2_live = ratio < 0.85;
+                }
+                if (h->debug)
+                    std::fprintf(stderr, "[somhip] exact scout: %ld sample tiles of %ld would run %.4f of their blocks (level 1: %.4f) -> %s, level 2 %d "
+                                 "[per row: full %.3g us, block %.3g us, overhead %.3g us]\n", n_st, tiles_all, est, est1,
+                                 decline ? "no plan" : "plan", ex.l2_live ? 1 : 0, 1e3 * cost.full_total, 1e3 * blk, 1e3 * over);
+                if (decline) { ex.scout_f_declined = ex.scout_f_now; ex.scout_f_age = 0; } else ex.scout_f_declined = 0.0;
+                if (decline) {
                     ex.skip_live = false; scout = false; resort = false; ex.scout_live = false; ex.refine_live = false; ex.scout_declined += 1;
                     if (resident) ex.res_valid = false;       // (the order was rebuilt, the sorted copies were not)
                     // (a declined plan counts as an idle one: rows without structure are asked less and less often)
@@ -1593,8 +1683,10 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         }
         if (ex.skip_live) {
             unsigned long long* best = h->best64 + r0;
-            if (resort)
+            if (resort) {
                 if (int rc = SOM_HALF(h, exact_skip_gather, h, sr, s0, sr.order + s0, X + r0 * h->D, Xb + r0 * h->dp, n, xsq + r0, xerr + r0, xmax2)) return rc;
+                if (time_phases) { HIPCHK(h, hipEventRecord(cost.ev[6], h->stream)); sort_timed = true; }
+            }
             const int* lastpos2 = nullptr;
             if (scout) {
                 if (int rc = SOM_HALF(h, exact_scout_pick, h, sr, s0, n, ex.sk_keys2, best)) return rc;
@@ -1606,14 +1698,17 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
             } else {
                 exact_lastpos_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(out + r0, sr.order + s0, h->ex_inv, n, h->K, sr.lastpos_s + s0);
             }
-            if (int rc = SOM_HALF(h, exact_skip_plan, h, sr, s0, n, xmax2, eb, lastpos2)) return rc;
+            if (int rc = SOM_HALF(h, exact_skip_plan, h, sr, s0, n, xmax2, eb, lastpos2, time_phases && ex.l2_live)) return rc;
+            if (time_phases && ex.l2_live) l2_timed = true;
             p_xsq = sr.xsq_s + s0; p_xerr = sr.xerr_s + s0; p_seed = sr.seed_s + s0; p_Xb = sr.Xb_s + s0 * h->dp; p_order = sr.order + s0;
             p_X = sr.Xf_s + s0 * h->D;
         }
         {
             Timed ts(h, SOM_K_SCREEN);
+            if (time_phases) { HIPCHK(h, hipEventRecord(cost.ev[1], h->stream)); }
             if (int rc = SOM_HALF(h, exact_screen_ks, h, p_Xb, n, h->best64 + r0, p_xsq, p_xerr, xmax2, eb, p_seed,
                                   ex.skip_live ? ex.tlist : nullptr, ex.skip_live ? ex.tcnt : nullptr)) return rc;
+            if (time_phases) { HIPCHK(h, hipEventRecord(cost.ev[2], h->stream)); screen_timed = true; }
         }
         const dim3 sel_grid((unsigned)cdiv(n, 64)), sel_block(64 * EX_SCAN_SPLIT);
         unsigned long long* best = h->best64 + r0;
@@ -1643,7 +1738,8 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
             best, n, h->K, ex.ctr + 2 * n_groups + 2, out + r0, ex.fb_list, ex.ctr + 2 * n_groups, p_order);
         HIPCHK(h, hipGetLastError());
         // rows the scheme could not settle (normally none): the float32 kernel itself
-        HIPCHK(h, hipMemcpyAsync(ex.fb_count_host, ex.ctr + 2 * n_groups, 7 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(ex.fb_count_host, ex.ctr + 2 * n_groups, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipEventRecord(cost.ev[7], h->stream));
         if (h->early.armed && !h->early.done && out == h->bmu && r0 + n >= N) {
             // the last pass of a resident epoch: the host waits for the counter only (an event behind the copy); what the
             // update needs besides the BMUs is queued behind it and runs while the host wakes up
@@ -1656,6 +1752,14 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         } else {
             HIPCHK(h, hipStreamSynchronize(h->stream));
         }
+        {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, cost.ev[0], cost.ev[7]) == hipSuccess) t_total += ms;
+            if (screen_timed && hipEventElapsedTime(&ms, cost.ev[1], cost.ev[2]) == hipSuccess) t_screen += ms;
+            if (l2_timed && hipEventElapsedTime(&ms, cost.ev[3], cost.ev[4]) == hipSuccess) t_l2 += ms;
+            if (sort_timed && hipEventElapsedTime(&ms, cost.ev[5], cost.ev[6]) == hipSuccess) t_sort += ms;
+            (void)hipGetLastError();
+        }
         const int n_fb = ex.fb_count_host[0];
         ex.rows_total += n; ex.rows_fallback += n_fb; ex.chunks += 1;
         // (counted in 16-unit blocks: four per (256-row tile, group))
@@ -1664,6 +1768,7 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         groups_run += ex.skip_live ? ex.fb_count_host[4] : cdiv(n, SK_TILE) * n_groups;
         pairs_in += ex.fb_count_host[5];
         if (ex.refine_live) pairs_out += ex.fb_count_host[6];
+        if (ex.skip_live && scout && have_last) scout_wins += ex.fb_count_host[7];
         if (n_fb < 0 || n_fb > n) return fail(h, "exact: fallback counter out of range");
         if (n_fb > 0) {
             if (n_fb > ex.fb_cap) {
@@ -1690,20 +1795,51 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
             HIPCHK(h, hipGetLastError());
         }
     }
+    // what this launch cost, per row
+    if (N > 0 && t_total > 0.0) {
+        if (!ex.skip_live) {
+            cost.full_total = t_total / (double)N;
+            if (screen_timed && t_screen > 0.0) cost.full_screen = t_screen / (double)N;
+        } else {
+            cost.plan_total = t_total / (double)N;
+            if (screen_timed && t_screen > 0.0) {
+                (scout ? cost.plan_over_scout : cost.plan_over) = (t_total - t_screen) / (double)N;
+                const double run = (double)(ex.blocks_run - run_before);
+                if (run > 0.0) cost.blk_ms = t_screen / run;
+                cost.since = 0;
+            } else {
+                cost.since += 1;
+            }
+            if (sort_timed && t_sort > 0.0) cost.sort_ms = t_sort / (double)N;
+        }
+    }
+    (void)planned_at_start;
     if (ex.skip_live && ex.blocks_total > total_before) {
         const double share = (double)(ex.blocks_run - run_before) / (double)(ex.blocks_total - total_before);
         const double l1_share = (double)groups_run * K16_T / (double)(ex.blocks_total - total_before);
         if (scout) ex.scouted += 1;
+        if (resident) ex.scout_win_share = (scout && have_last) ? (double)scout_wins / (double)std::max<long>(N, 1) : 0.0;
         ex.pairs_per_row_last = (double)pairs_in / (double)std::max<long>(N, 1);
         if (ex.refine_live) { ex.pairs_refined_in += pairs_in; ex.pairs_refined_out += pairs_out; }
+        if (ex.l2_live && l2_timed && t_l2 > 0.0 && groups_run > 0) {
+            cost.l2_ms_group = t_l2 / (double)groups_run;
+            cost.l2_ratio = l1_share > 0.0 ? share / l1_share : 1.0;
+        }
+        // an IDLE plan: the launch cost what the last launch without a plan cost (per row; with no such launch on record: it
+        // kept more than 0.97 of the blocks).  Rows without structure: two idle plans in a row pause the plan for two launches,
+        // the next idle one for four, then eight, sixteen; a plan that pays again resets the pause.
+        // (... and ran more than half of the blocks: with most of them proven empty a slow launch is somebody else's kernels on
+        //  the card, not an idle plan)
+        const bool idle_plan = share > 0.5 && (cost.full_total > 0.0 ? cost.plan_total >= 0.97 * cost.full_total : share > 0.97);
         if (!resident) {
             ex.tr_planned += 1;
             ex.tr_share_last = share;
             if (h->debug)
-                std::fprintf(stderr, "[somhip] exact plan (transient, %ld rows): share %.4f level-1 %.4f level-2 %d refine %d pairs/row %.2f -> %.2f\n",
-                             N, share, l1_share, ex.l2_live ? 1 : 0, ex.refine_live ? 1 : 0, ex.pairs_per_row_last, (double)pairs_out / (double)std::max<long>(N, 1));
+                std::fprintf(stderr, "[somhip] exact plan (transient, %ld rows): share %.4f level-1 %.4f level-2 %d refine %d pairs/row %.2f -> %.2f; %.3f ms (screen %.3f)\n",
+                             N, share, l1_share, ex.l2_live ? 1 : 0, ex.refine_live ? 1 : 0, ex.pairs_per_row_last, (double)pairs_out / (double)std::max<long>(N, 1),
+                             t_total, t_screen);
             if (ex.skip_mode == 1) {
-                if (share > 0.97) {
+                if (idle_plan) {
                     if (++ex.tr_idle >= 2) { ex.tr_cooldown = ex.tr_pause; ex.tr_pause = std::min(2 * ex.tr_pause, 16); }
                 } else {
                     ex.tr_idle = 0; ex.tr_pause = 2;
@@ -1713,31 +1849,38 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         }
         ex.planned += 1;
         if (resort) {
-            // a sort that did not pay (the share it left is no better than the stale order's: the schedule, not the order,
-            // moves the share) doubles the wait before the next one, up to eight epochs; one that paid resets it
-            if (ex.res_valid && ex.res_share_last < 0.25 && ex.res_l2_last == ex.l2_live)
-                ex.res_forced = share <= 0.93 * ex.res_share_last ? 8 : std::min(2 * ex.res_forced, 64);
+            // a sort that did not pay doubles the wait before the next one, up to 64 epochs; one that paid resets it to eight.  Paid:
+            // the blocks it saved against the stale order's share, at the measured screen time per block, over the epochs the order
+            // will serve, outweigh the measured sort + gather (before those are measured: the share fell by 7 % or more)
+            if (ex.res_valid && ex.res_share_last < 0.25 && ex.res_l2_last == ex.l2_live) {
+                bool paid = share <= 0.93 * ex.res_share_last;
+                if (cost.blk_ms > 0.0 && cost.sort_ms > 0.0)
+                    paid = (ex.res_share_last - share) * blocks_per_row * cost.blk_ms * (double)ex.res_forced > cost.sort_ms;
+                ex.res_forced = paid ? 8 : std::min(2 * ex.res_forced, 64);
+            }
             ex.resorts += 1; ex.res_since = 0; ex.res_share_sort = share; ex.res_l2_sort = ex.l2_live; ex.res_valid = true; ex.res_rows = (const void*)X; ex.res_n = N;
         }
         ex.res_since += 1;
         ex.res_share_last = share; ex.res_l2_last = ex.l2_live;
         ex.l1_share_last = l1_share;
         if (h->debug)
-            std::fprintf(stderr, "[somhip] exact plan %ld: share %.4f level-1 %.4f level-2 %d (paid %d) sorted %d scout %d (since %d, next forced at %d) refine %d pairs/row %.2f -> %.2f\n",
+            std::fprintf(stderr, "[somhip] exact plan %ld: share %.4f level-1 %.4f level-2 %d (paid %d) sorted %d scout %d (since %d, next forced at %d) refine %d pairs/row %.2f -> %.2f; "
+                         "scout wins %.3f; %.3f ms (screen %.3f, level 2 %.3f, sort %.3f) [block %.3g us, level 2 per kept group %.3g us, ratio %.3f]\n",
                          (long)ex.planned, share, ex.l1_share_last, ex.l2_live ? 1 : 0, ex.l2_pays ? 1 : 0, resort ? 1 : 0, scout ? 1 : 0, ex.res_since, ex.res_forced,
-                         ex.refine_live ? 1 : 0, ex.pairs_per_row_last, (double)pairs_out / (double)std::max<long>(N, 1));
+                         ex.refine_live ? 1 : 0, ex.pairs_per_row_last, (double)pairs_out / (double)std::max<long>(N, 1), ex.scout_win_share, t_total, t_screen, t_l2, t_sort,
+                         1e3 * cost.blk_ms, 1e3 * cost.l2_ms_group, cost.l2_ratio);
         if (ex.l2_live) {
-            ex.l2_pays = 1.5 * (ex.l1_share_last - share) > 0.1 * ex.l1_share_last + 0.006;
+            // level 2 pays where the blocks it removes from a kept group -- (1 - ratio) of four, at the measured screen time per block
+            // -- cost more than its own measured time per kept group (before both are measured: round 4's fitted rule)
+            if (cost.l2_ms_group > 0.0 && cost.blk_ms > 0.0) ex.l2_pays = (1.0 - cost.l2_ratio) * K16_T * cost.blk_ms > cost.l2_ms_group;
+            else ex.l2_pays = 1.5 * (ex.l1_share_last - share) > 0.1 * ex.l1_share_last + 0.006;
             ex.l1_share_probe = ex.l1_share_last;
             ex.l2_wait = 4;
         } else {
             ex.l2_wait -= 1;
         }
-        // rows without structure: two idle plans in a row (> 97 % of the blocks kept; ONE is what the smooth map of a schedule's
-        // second epoch gives) pause the plan for two epochs, the next idle one for four, then eight, sixteen: the plan's
-        // cost on such rows falls below a percent; a plan that skips again resets the pause
         if (ex.skip_mode == 1) {
-            if (share > 0.97) {
+            if (idle_plan) {
                 if (++ex.skip_idle >= 2) { ex.skip_cooldown = ex.skip_pause; ex.skip_pause = std::min(2 * ex.skip_pause, 16); }
             } else {
                 ex.skip_idle = 0; ex.skip_pause = 2;
@@ -2383,6 +2526,7 @@ void som_destroy(som_handle* h) {
             void* cb[] = {c.Cc, c.rg, c.csq, c.cmax2, c.Cst, c.Cst_plain};
             for (void* b : cb) if (b) (void)hipFree(b);
         }
+        if (h->ex.cost.have) for (auto& e : h->ex.cost.ev) (void)hipEventDestroy(e);
         if (h->ex.fb_count_host) (void)hipHostFree(h->ex.fb_count_host);
         if (h->ex.fb_ready) (void)hipEventDestroy(h->ex.fb_ready);
     }
