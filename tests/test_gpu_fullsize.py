@@ -279,3 +279,40 @@ def test_full_size_c5_shard_exact_mode_equals_float32(monkeypatch):
                     assert fb <= N // 100
             e.close()
         assert np.array_equal(ids["exact"], ids["f32"]), (state, int((ids["exact"] != ids["f32"]).sum()))
+
+
+def test_full_size_wide_euclidean_shard_skips_blocks_and_equals_float32():
+    """512 x 512 x 784 with the euclidean distance and the gaussian neighbourhood (the G17 family at configs[4]'s size), one
+    GPU's shard of 65 536 rows, the first five epochs of a 12-epoch schedule: the wide screen runs under a plan from the second
+    epoch on (csrc/exact_skip_wide.hpp), every epoch's BMUs are float32's, and from the third epoch on most blocks are skipped
+    (tools/skip_probe_wide.py counted 1-14 % of the groups; profiles/r05_skip_probe_wide.txt)."""
+    from xpysom_dask_amd.synthetic import gaussian_blobs
+    X = Y = 512
+    D, n, T = 784, 65536, 12
+    data = gaussian_blobs(n, D, seed=1234, centre_seed=1234)
+    rs = np.random.RandomState(1234)
+    w = rs.rand(X, Y, D) * 2 - 1
+    w = (w / np.linalg.norm(w, axis=-1, keepdims=True)).astype(F32)
+    f = engine(X, Y, D, precision="f32")
+    x = engine(X, Y, D, precision="exact")
+    for e in (f, x):
+        e.set_weights(w)
+        e.set_data(data)
+    shares = []
+    for t in range(5):
+        sig, eta = O.exponential_decay(256.0, 1.0, t, T), O.exponential_decay(0.5, 0.01, t, T)
+        r0, t0 = x.exact_skip_stats()
+        f.epoch_accumulate(sig, eta, True)
+        x.epoch_accumulate(sig, eta, True)
+        r1, t1 = x.exact_skip_stats()
+        shares.append((r1 - r0) / (t1 - t0))
+        a, b = f.epoch_fetch()[2], x.epoch_fetch()[2]
+        assert np.array_equal(a, b), (t, int((a != b).sum()))
+        f.epoch_merge()
+        x.epoch_merge()
+    assert np.array_equal(f.get_weights(), x.get_weights())
+    assert shares[0] == 1.0 and max(shares[3:]) < 0.3, shares
+    rows, fb, _ = x.exact_stats()
+    assert fb <= rows // 100
+    f.close()
+    x.close()

@@ -170,7 +170,13 @@ __global__ __launch_bounds__(256) void merge_prep_wide_kernel(float* __restrict_
 // GM (precision 'exact' beyond 128 features, bmu_exact.hpp): as in bmu_bf16_k16_kernel<.., GM = true> -- values only,
 // the minimum of every GROUP of 64 units (two stages) per row stored where it is within the row's bound of the
 // minimum so far, and the mask of the rows stored (32 per wave) per group; the parts split on group boundaries.
-template <int KS32, class EL = Bf16, bool GM = false>
+// TL (GM under a plan, exact_skip_wide.hpp): the workgroup walks its tile's list of GROUPS (glist: group << 4 | 15 items,
+// gcnt of them) -- both stages of each -- instead of every stage.
+// PLAN (exact_skip_wide.hpp): the same scan over a stage image of group CENTROIDS (32 to a stage; the stage's tail holds,
+// behind the 32 initial accumulators S'(B' + |c|^2 / 2) - hS r^2, the 32 radii sw r) with the plan's test as its epilogue:
+// need(row, c) = not (acc - (sx sqrt(U))(sw r) > P(row)), rows' P and sx sqrt(U) in planP / planXs; OR over the tile's 256
+// rows into need[tile][word] (bit g & 63 of word g >> 6 <-> group g): what exact_lists_kernel turns into the tile's list.
+template <int KS32, class EL = Bf16, bool GM = false, bool TL = false, bool PLAN = false>
 __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* __restrict__ Ximg, long N,
                                                                    const char* __restrict__ Wst, int n_stages,
                                                                    unsigned long long* __restrict__ out64,
@@ -181,12 +187,19 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
                                                                    const float* __restrict__ xmax2 = nullptr,
                                                                    const float* __restrict__ wmax2 = nullptr,
                                                                    const float* __restrict__ werr2 = nullptr,
-                                                                   ExactBound eb = ExactBound()) {
+                                                                   ExactBound eb = ExactBound(),
+                                                                   const int* __restrict__ glist = nullptr,
+                                                                   const int* __restrict__ gcnt = nullptr, int n_groups_all = 0,
+                                                                   const float* __restrict__ planP = nullptr,
+                                                                   const float* __restrict__ planXs = nullptr,
+                                                                   unsigned long long* __restrict__ need = nullptr, int n_words = 0) {
+    static_assert(!TL || GM, "tile lists belong to the exact mode's screen");
+    static_assert(!PLAN || (!GM && !TL), "the plan is a mode of its own");
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     constexpr int STAGE = wd_stage_bytes(KS32);
     constexpr int PIECES = WD_T * KS32;                      // whole 1 KiB pieces; the C-in row follows them
-    constexpr int CIN_LANES = WD_STAGE_UNITS * 4 / 16;
+    constexpr int CIN_LANES = (PLAN ? 2 : 1) * WD_STAGE_UNITS * 4 / 16;   // (PLAN: the 32 radii behind the 32 initial accumulators)
     constexpr uint32_t IDX_MASK = 4 * WD_T - 1;              // (tile << 2 | register) in the low mantissa bits
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -194,7 +207,7 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int quad = lane >> 4, col = lane & 15;
 
-    // this workgroup's share of the codebook stages
+    // this workgroup's share of the codebook stages: POSITIONS [s_begin, s_end) of its walk; sid(position) = the stage there
     int s_begin = (int)((long)n_stages * blockIdx.y / gridDim.y);
     int s_end = (int)((long)n_stages * (blockIdx.y + 1) / gridDim.y);
     if (GM) {                                                // parts of whole groups (pairs of stages)
@@ -202,6 +215,14 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
         s_begin = 2 * (int)((long)n_groups * blockIdx.y / gridDim.y);
         s_end = min(2 * (int)((long)n_groups * (blockIdx.y + 1) / gridDim.y), n_stages);
     }
+    const int* my_list = nullptr;
+    if (TL) {                                                // the tile's listed groups, two stages each (the host: K % 64 == 0)
+        my_list = glist + (long)blockIdx.x * n_groups_all;
+        const int n_g = gcnt[blockIdx.x];
+        s_begin = 2 * (int)((long)n_g * blockIdx.y / gridDim.y);
+        s_end = 2 * (int)((long)n_g * (blockIdx.y + 1) / gridDim.y);
+    }
+    auto sid = [&](int i) -> int { return TL ? 2 * (__builtin_amdgcn_readfirstlane(my_list[i >> 1]) >> 4) + (i & 1) : i; };
     if (s_begin >= s_end) return;                            // (whole workgroup: no barrier is left behind)
     // GM: lane l < 32 <-> row (block, wave, l): its minimum so far, its bound E; pmin: this lane's minimum over the group
     const long wave_row0 = (long)blockIdx.x * WD_WG_SAMPLES + wave * (WD_SB * 16);
@@ -216,9 +237,9 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
         if (e == e) row_e = e;                               // (a row the bound does not cover keeps everything: the scan drops it)
     }
 
-    auto issue = [&](int s, int slot) {
+    auto issue = [&](int i, int slot) {
         // (uniform base + a 32-bit lane offset: the scalar-base form of the load, no 64-bit address kept in registers)
-        const char* src = Wst + (long)s * STAGE;
+        const char* src = Wst + (long)sid(i) * STAGE;
         const uint32_t lane16 = (uint32_t)lane * 16u;
         char* dst = smem + slot * STAGE;
         for (int p = wave; p < PIECES; p += WD_NW) lds_dma_16(src + p * 1024 + lane16, dst + p * 1024);
@@ -316,7 +337,38 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
         if (lane == 0) gflags32[ex_flag_index(wave_row0 >> 6, pend_group, (n_stages + 1) >> 1, gm_stride) * 2 + ((wave_row0 >> 5) & 1)] = (uint32_t)mask;
         pend_group = -1;
     };
-    auto finish_stage = [&](int s) {
+    float pP[WD_SB], pXs[WD_SB];                             // PLAN: the rows' thresholds and sx sqrt(U) (1 + 2^-10)
+    unsigned long long* nl = (unsigned long long*)(smem + WD_SLOTS * STAGE);
+    if (PLAN) {
+#pragma unroll
+        for (int sb = 0; sb < WD_SB; ++sb) {
+            const long r = wave_row0 + sb * 16 + col;
+            pP[sb] = r < N ? planP[r] : -__builtin_inff();   // (rows behind the pass need nothing)
+            pXs[sb] = r < N ? planXs[r] : 0.0f;
+        }
+        for (int i = tid; i < n_words; i += 64 * WD_NW) nl[i] = 0ull;
+    }
+    auto finish_stage = [&](int s, bool last, const char* st) {
+        if (PLAN) {
+            const float* rq = (const float*)(st + PIECES * 1024) + WD_STAGE_UNITS;
+            uint32_t mine = 0u;                              // bit (16 t + 4 quad + r) <-> centroid of that place in the stage
+#pragma unroll
+            for (int t = 0; t < WD_T; ++t) {
+                const f32x4 swr = *(const f32x4*)(rq + t * 16 + 4 * quad);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    bool nd = false;
+#pragma unroll
+                    for (int sb = 0; sb < WD_SB; ++sb) nd = nd || !(__builtin_fmaf(-pXs[sb], swr[r], acc[t][sb][r]) > pP[sb]);
+                    const unsigned long long b = __ballot(nd);
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd)
+                        if ((b >> (16 * qd)) & 0xFFFFull) mine |= 1u << (t * 16 + 4 * qd + r);
+                }
+            }
+            if (lane == 0 && mine != 0u) atomicOr(nl + (s >> 1), (unsigned long long)mine << (32 * (s & 1)));
+            return;
+        }
         if (GM) {
         static_assert(!GM || WD_SB == 2, "the group-minimum store pairs two 16-sample blocks per wave");
 #pragma unroll
@@ -329,7 +381,7 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
             }
             pmin[sb] = min(pmin[sb], c);
         }
-        if ((s & 1) || s == s_end - 1) {                 // the group is complete: join the four lane quads, store
+        if ((s & 1) || last) {                           // the group is complete: join the four lane quads, store
             uint32_t v[WD_SB];
 #pragma unroll
             for (int sb = 0; sb < WD_SB; ++sb) {
@@ -389,10 +441,17 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
         const char* st = slot_of(s);
         begin_stage(st);
         chunks(st, KC0(), KCN());
-        finish_stage(s);
+        finish_stage(sid(s), s == s_end - 1, st);
     }
     SOM_STAMP_END();
     flush_group();
+    if (PLAN) {
+        __syncthreads();
+        // (the parts of a tile's walk share words: OR into the words the host cleared)
+        for (int i = tid; i < n_words; i += 64 * WD_NW)
+            if (nl[i] != 0ull) atomicOr(need + (long)blockIdx.x * n_words + i, nl[i]);
+        return;
+    }
 
     if (GM) {
         // the row minimum IS the minimum so far after the last group (lanes 0..31 <-> rows wave_row0 + lane): the plain

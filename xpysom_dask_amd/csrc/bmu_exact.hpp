@@ -180,10 +180,14 @@ __global__ __launch_bounds__(64 * EX_SCAN_SPLIT) void exact_select_kernel(const 
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                if (j[q] >= 0) hits |= (unsigned long long)(v[q] <= thr) << j[q];
+                if (j[q] >= 0) {
+                    // (ROUND2: the group round 1 scored for this row is not selected again -- by its id: under a tile list
+                    //  the chunk's j-th group is not group gb + j)
+                    const int g = __builtin_amdgcn_readlane(gid, j[q]);
+                    hits |= (unsigned long long)(v[q] <= thr && !(ROUND2 && g == arg)) << j[q];
+                }
         }
         if (!ok) hits = 0;
-        if (ROUND2 && arg >= gb && arg < gb + 64) hits &= ~(1ull << (arg - gb));   // (round 1 scored that group; no lists in two rounds)
         if (__ballot(hits != 0ull) == 0) continue;
         int c = 0;                                         // lane j: the wave's hits in the chunk's j-th group
         for (todo = any; todo != 0; todo &= todo - 1) {

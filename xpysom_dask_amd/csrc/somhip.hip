@@ -24,6 +24,7 @@
 #include "bmu_bf16_wide.hpp"
 #include "bmu_exact.hpp"
 #include "exact_skip.hpp"
+#include "exact_skip_wide.hpp"
 #include "bmu_f32.hpp"
 #include "bmu_f32_res.hpp"
 #include "bmu_f32_tiled.hpp"
@@ -147,6 +148,7 @@ struct som_handle {
         bool scout_on = true;             // SOM_EXACT_SCOUT=0: plans only from last epoch's BMUs (A/B)
         bool scout_live = false;          // this launch runs the scout
         int* scout_g = nullptr;           // [stride] nearest group centroid of every row of the pass
+        float* tq = nullptr;              // [stride] wide plan: the float32 score of every sorted row's last BMU under the current codebook
         double scout_est_last = 0.0;      // executed share the sample tiles forecast at the last estimate
         double scout_f_now = 0.0, scout_f_declined = 0.0; int scout_f_age = 0;   // the sampled rows' need now / when the sample tiles last declined a plan
         double scout_win_share = 0.0;     // rows of the last launch whose scout pick beat their last BMU by a tenth of the squared distance
@@ -182,7 +184,7 @@ struct som_handle {
         // the centroid sets of the plan: [0] the 64-unit groups, [1] their 16-unit sub-blocks (exact_centroid_kernel's slot order)
         struct Centroids { float *Cc = nullptr, *rg = nullptr, *csq = nullptr, *cmax2 = nullptr; char* Cst = nullptr;
                            char* Cst_plain = nullptr;   // level 1 only: the scout's copy (plain initial accumulators)
-                           int n_slots = 0, n_cstages = 0; } cen[2];
+                           int n_slots = 0, n_cstages = 0, n_img_stages = 0; } cen[2];
         unsigned long long *need = nullptr, *need2 = nullptr;
         int *glist = nullptr, *gcnt = nullptr;   // per tile: (group << 4 | sub-block mask) items: what the select kernel walks
         int *tlist = nullptr, *tcnt = nullptr;   // per tile: the same blocks as a dense list of 16-unit tiles: what the screen walks
@@ -1048,7 +1050,28 @@ int exact_screen(som_handle* h, const __bf16* Xb, long n, unsigned long long* be
 // beyond 128 features: the wide kernel's GM instance (groups = pairs of its 32-unit stages)
 template <int KS32, class E>
 int exact_screen_wide(som_handle* h, const __bf16* Ximg, long n, unsigned long long* best64, const float* xsq, const float* xerr,
-                      const float* xmax2, const ExactBound& eb) {
+                      const float* xmax2, const ExactBound& eb, const int* glist = nullptr, const int* gcnt = nullptr) {
+    if (glist != nullptr) {
+        // under a plan (exact_skip_wide.hpp): every workgroup walks its tile's list of groups; parts where the lists are long
+        auto kern = bmu_bf16_wide_kernel<KS32, E, true, true>;
+        const size_t lds = (size_t)WD_SLOTS * wd_stage_bytes(KS32);
+        int per_cu = 1;
+        if (int rc = kernel_per_cu(h, (const void*)kern, 64 * WD_NW, lds, &per_cu)) return rc;
+        const long blocks = cdiv(n, WD_WG_SAMPLES);
+        const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
+        const int n_groups = (int)cdiv(h->n_stages, 2);
+        const double groups_forecast = h->ex.share_forecast * (double)n_groups;
+        int parts = blocks >= slots ? (groups_forecast < 64.0 ? 1 : groups_forecast < 256.0 ? 2 : 4)
+                                    : (int)std::min<long>(cdiv(slots, blocks), 16);
+        if (h->env_bf16_parts > 0) parts = h->env_bf16_parts;
+        parts = std::max(1, std::min(parts, n_groups));
+        if (h->debug)
+            std::fprintf(stderr, "[somhip] exact screen (wide, lists): blocks=%ld per_cu=%d slots=%ld parts=%d groups=%d\n", blocks, per_cu, slots, parts, n_groups);
+        bmu_bf16_wide_kernel<KS32, E, true, true><<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * WD_NW), lds, h->stream>>>(
+            (const char*)Ximg, n, h->Wst, h->n_stages, best64, h->ex.gmin, h->ex.stride, (uint32_t*)h->ex.gflags, xsq, xerr, xmax2,
+            h->wmax2, h->wmax2 + 1, eb, glist, gcnt, n_groups);
+        return 0;
+    }
     auto kern = bmu_bf16_wide_kernel<KS32, E, true>;
     const size_t lds = (size_t)WD_SLOTS * wd_stage_bytes(KS32);
     int per_cu = 1;
@@ -1071,7 +1094,7 @@ int exact_screen_wide(som_handle* h, const __bf16* Ximg, long n, unsigned long l
     if (h->debug)
         std::fprintf(stderr, "[somhip] exact screen (wide): blocks=%ld per_cu=%d slots=%ld parts=%d groups=%d\n", blocks, per_cu, slots,
                      parts, n_groups);
-    kern<<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * WD_NW), lds, h->stream>>>(
+    bmu_bf16_wide_kernel<KS32, E, true><<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * WD_NW), lds, h->stream>>>(
         (const char*)Ximg, n, h->Wst, h->n_stages, best64, h->ex.gmin, h->ex.stride, (uint32_t*)h->ex.gflags, xsq, xerr, xmax2,
         h->wmax2, h->wmax2 + 1, eb);
     return 0;
@@ -1083,7 +1106,7 @@ int exact_screen_ks(som_handle* h, const __bf16* Xb, long n, unsigned long long*
                     const int* gcnt = nullptr) {
     if (h->wide) {
         switch (h->n_kchunks) {
-#define SOM_WIDE_CASE(k) case k: return exact_screen_wide<k, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb);
+#define SOM_WIDE_CASE(k) case k: return exact_screen_wide<k, E>(h, Xb, n, best64, xsq, xerr, xmax2, eb, glist, gcnt);
         SOM_WIDE_CASE(5) SOM_WIDE_CASE(6) SOM_WIDE_CASE(7) SOM_WIDE_CASE(8) SOM_WIDE_CASE(9) SOM_WIDE_CASE(10)
         SOM_WIDE_CASE(11) SOM_WIDE_CASE(12) SOM_WIDE_CASE(13) SOM_WIDE_CASE(14) SOM_WIDE_CASE(15) SOM_WIDE_CASE(16)
         SOM_WIDE_CASE(17) SOM_WIDE_CASE(18) SOM_WIDE_CASE(19) SOM_WIDE_CASE(20) SOM_WIDE_CASE(21) SOM_WIDE_CASE(22)
@@ -1141,18 +1164,21 @@ int exact_skip_reserve(som_handle* h, som_handle::ExactScratch::SortedRows& sr, 
             c = som_handle::ExactScratch::Centroids();
         }
         const int ncs = (int)cdiv(n_groups, K16_STAGE_UNITS);
-        for (int lv = 0; lv < 2; ++lv) {
+        for (int lv = 0; lv < (h->wide ? 1 : 2); ++lv) {
             auto& c = ex.cen[lv];
             // level 2: sixteen slots per four groups, 4 * ncs stages (need2 is addressed [tile][4 * ncs]: exact_lists_kernel)
             c.n_slots = lv == 0 ? (int)n_groups : (int)cdiv(n_groups, 4) * 16;
             c.n_cstages = lv == 0 ? ncs : 4 * ncs;
+            // (the centroid image's own stages: 64 centroids each up to 128 features, 32 on the wide kernel's tiling -- where
+            //  n_cstages stays the number of 64-group WORDS of the need bitmaps)
+            c.n_img_stages = h->wide ? (int)cdiv(n_groups, WD_STAGE_UNITS) : c.n_cstages;
             if (int rc = dev_alloc(h, &c.Cc, (size_t)c.n_slots * h->D)) return rc;
             if (int rc = dev_alloc(h, &c.rg, (size_t)c.n_slots)) return rc;
             if (int rc = dev_alloc(h, &c.csq, (size_t)c.n_slots)) return rc;
             if (int rc = dev_alloc(h, &c.cmax2, 2)) return rc;
-            if (int rc = dev_alloc(h, &c.Cst, (size_t)c.n_cstages * h->stage_bytes)) return rc;
-            HIPCHK(h, hipMemsetAsync(c.Cst, 0, (size_t)c.n_cstages * h->stage_bytes, h->stream));
-            if (lv == 0) {
+            if (int rc = dev_alloc(h, &c.Cst, (size_t)c.n_img_stages * h->stage_bytes)) return rc;
+            HIPCHK(h, hipMemsetAsync(c.Cst, 0, (size_t)c.n_img_stages * h->stage_bytes, h->stream));
+            if (lv == 0 && !h->wide) {
                 if (int rc = dev_alloc(h, &c.Cst_plain, (size_t)c.n_cstages * h->stage_bytes)) return rc;
                 HIPCHK(h, hipMemsetAsync(c.Cst_plain, 0, (size_t)c.n_cstages * h->stage_bytes, h->stream));
             }
@@ -1169,7 +1195,7 @@ int exact_skip_reserve(som_handle* h, som_handle::ExactScratch::SortedRows& sr, 
         if (&sr == &ex.srt[0]) ex.res_valid = false;
         if (int rc = dev_alloc(h, &sr.order, (size_t)need_rows)) return rc;
         if (int rc = dev_alloc(h, &sr.Xb_s, (size_t)need_rows * h->dp)) return rc;
-        if (int rc = dev_alloc(h, &sr.Xl_s, (size_t)need_rows * h->dp)) return rc;
+        if (int rc = dev_alloc(h, &sr.Xl_s, h->wide ? 1 : (size_t)need_rows * h->dp)) return rc;   // (the refinement pass: up to 128 features)
         if (int rc = dev_alloc(h, &sr.Xf_s, (size_t)need_rows * h->D)) return rc;
         if (int rc = dev_alloc(h, &sr.xsq_s, (size_t)need_rows)) return rc;
         if (int rc = dev_alloc(h, &sr.xerr_s, (size_t)need_rows)) return rc;
@@ -1190,6 +1216,10 @@ int exact_skip_reserve(som_handle* h, som_handle::ExactScratch::SortedRows& sr, 
     if (int rc = dev_alloc(h, &ex.sk_keys2, (size_t)stride)) return rc;
     if (int rc = dev_alloc(h, &ex.sk_vals, (size_t)stride)) return rc;
     if (int rc = dev_alloc(h, &ex.scout_g, (size_t)stride)) return rc;
+    if (h->wide) {
+        (void)hipFree(ex.tq); ex.tq = nullptr;
+        if (int rc = dev_alloc(h, &ex.tq, (size_t)stride)) return rc;
+    }
     if (int rc = dev_alloc(h, &ex.need, (size_t)tiles * ex.cen[0].n_cstages)) return rc;
     if (int rc = dev_alloc(h, &ex.need2, (size_t)tiles * ex.cen[1].n_cstages)) return rc;
     if (int rc = dev_alloc(h, &ex.glist, (size_t)tiles * n_groups)) return rc;
@@ -1364,6 +1394,83 @@ int exact_skip_plan(som_handle* h, som_handle::ExactScratch::SortedRows& sr, lon
     return 0;
 }
 
+// ---- block skipping beyond 128 features (exact_skip_wide.hpp) ---------------------------------------------------------------
+// centroids, radii, |c|^2 of the groups under the current codebook; their 32-to-a-stage image with its tails and its measured
+// rounding error
+template <class E>
+int exact_wide_centroids(som_handle* h, const float* xmax2) {
+    auto& ex = h->ex;
+    auto& c0 = ex.cen[0];
+    const float* Wsrc = h->ex_patch ? h->Wp : h->W;
+    const int n_groups = (int)cdiv(h->K, EX_GROUP);
+    wide_centroids_kernel<<<dim3((unsigned)n_groups), dim3(256), 0, h->stream>>>(Wsrc, h->K, h->D, n_groups, c0.Cc, c0.rg, c0.csq, c0.cmax2, h->wmax2);
+    const long total = (long)c0.n_img_stages * WD_T * h->n_kchunks * 64;
+    prep_w_bf16_wide_kernel<E><<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(c0.Cc, n_groups, h->D, h->n_kchunks, c0.Cst, c0.n_img_stages,
+                                                                                             nullptr, h->wmax2);
+    exact_werr_kernel<E><<<dim3((unsigned)cdiv(n_groups, 4 * EX_WERR_UNITS)), dim3(256), 0, h->stream>>>(c0.Cc, n_groups, h->D, h->wmax2, c0.cmax2 + 1, nullptr);
+    wide_centroid_tail_kernel<<<dim3((unsigned)cdiv((long)c0.n_img_stages * WD_STAGE_UNITS, 256)), dim3(256), 0, h->stream>>>(
+        c0.rg, c0.csq, n_groups, c0.Cst, c0.n_img_stages, h->stage_bytes, xmax2, h->wmax2);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// the sorted pass: float32 rows, norms, last BMUs gathered in the order, the tile image built from the sorted rows
+template <class E>
+int exact_wide_gather(som_handle* h, som_handle::ExactScratch::SortedRows& sr, long s0, const float* X, long n, const float* xsq, const float* xerr,
+                      const int* prev, const float* xmax2) {
+    const long np = round_up(n, SK_TILE);
+    wide_gather_sorted_kernel<<<dim3((unsigned)cdiv(np, 4)), dim3(256), 0, h->stream>>>(sr.order + s0, n, np, h->D, X, xsq, xerr, prev,
+                                                                                      sr.Xf_s + s0 * h->D, sr.xsq_s + s0, sr.xerr_s + s0, sr.lastpos_s + s0);
+    const long n_blocks = np / h->tl_bm;
+    const long total = n_blocks * h->n_kchunks * (h->tl_bm / 16) * TL_KS * 64;
+    prep_tiles_bf16_kernel<E><<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
+        sr.Xf_s + s0 * h->D, n, h->D, h->n_kchunks, n_blocks, h->tl_bm, h->tl_xtile, 1.0f, nullptr, (char*)(sr.Xb_s + s0 * h->dp), xmax2);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// one pass's plan on the sorted rows: the float32 score of every row's last BMU, the rows' thresholds, the wide kernel in its
+// PLAN mode over the centroid image, the tiles' lists
+template <int KS32, class E>
+int exact_wide_plan_ks(som_handle* h, som_handle::ExactScratch::SortedRows& sr, long s0, long n, const float* xmax2, const ExactBound& eb) {
+    auto& ex = h->ex;
+    const auto& c0 = ex.cen[0];
+    const int n_groups = (int)cdiv(h->K, EX_GROUP);
+    const long np = round_up(n, SK_TILE);
+    const long tiles = np / SK_TILE;
+    // (sr.lastpos_s holds the sorted rows' last BMUs as UNIT ids here; the seed itself is not used beyond 128 features)
+    exact_seed_kernel<<<dim3((unsigned)cdiv(n * 16, 256)), dim3(256), 0, h->stream>>>(
+        sr.Xf_s + s0 * h->D, n, h->D, h->W, h->wsq, h->K, sr.lastpos_s + s0, sr.xsq_s + s0, sr.xerr_s + s0, h->wmax2, xmax2, h->wmax2 + 1, eb, ex.seed, ex.tq);
+    wide_plan_rows_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(n, sr.xsq_s + s0, sr.xerr_s + s0, ex.tq, xmax2, c0.cmax2, h->wmax2,
+                                                                                  h->wmax2 + 1, eb, ex.skip_mode == 3 ? 1 : 0, sr.seed_s + s0, sr.sU_s + s0);
+    HIPCHK(h, hipMemsetAsync(ex.need, 0, (size_t)tiles * c0.n_cstages * sizeof(unsigned long long), h->stream));
+    auto kern = bmu_bf16_wide_kernel<KS32, E, false, false, true>;
+    const size_t lds = (size_t)WD_SLOTS * wd_stage_bytes(KS32) + (size_t)c0.n_cstages * sizeof(unsigned long long);
+    int per_cu = 1;
+    if (int rc = kernel_per_cu(h, (const void*)kern, 64 * WD_NW, lds, &per_cu)) return rc;
+    const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
+    int parts = (int)std::max<long>(1, std::min<long>({cdiv(2 * slots, tiles), 8L, (long)c0.n_img_stages}));
+    bmu_bf16_wide_kernel<KS32, E, false, false, true><<<dim3((unsigned)tiles, (unsigned)parts), dim3(64 * WD_NW), lds, h->stream>>>(
+        (const char*)(sr.Xb_s + s0 * h->dp), n, c0.Cst, c0.n_img_stages, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ExactBound(),
+        nullptr, nullptr, 0, sr.seed_s + s0, sr.sU_s + s0, ex.need, c0.n_cstages);
+    exact_lists_kernel<<<dim3((unsigned)tiles), dim3(64), 0, h->stream>>>(ex.need, c0.n_cstages, nullptr, n_groups, ex.glist, ex.gcnt, ex.tile_counts, ex.tlist, ex.tcnt);
+    exact_list_totals_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(ex.tile_counts, tiles, ex.ctr + 2 * n_groups + 3, ex.ctr + 2 * n_groups + 4);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+template <class E>
+int exact_wide_plan(som_handle* h, som_handle::ExactScratch::SortedRows& sr, long s0, long n, const float* xmax2, const ExactBound& eb) {
+    switch (h->n_kchunks) {
+#define SOM_WIDE_CASE(k) case k: return exact_wide_plan_ks<k, E>(h, sr, s0, n, xmax2, eb);
+    SOM_WIDE_CASE(5) SOM_WIDE_CASE(6) SOM_WIDE_CASE(7) SOM_WIDE_CASE(8) SOM_WIDE_CASE(9) SOM_WIDE_CASE(10)
+    SOM_WIDE_CASE(11) SOM_WIDE_CASE(12) SOM_WIDE_CASE(13) SOM_WIDE_CASE(14) SOM_WIDE_CASE(15) SOM_WIDE_CASE(16)
+    SOM_WIDE_CASE(17) SOM_WIDE_CASE(18) SOM_WIDE_CASE(19) SOM_WIDE_CASE(20) SOM_WIDE_CASE(21) SOM_WIDE_CASE(22)
+    SOM_WIDE_CASE(23) SOM_WIDE_CASE(24) SOM_WIDE_CASE(25)
+#undef SOM_WIDE_CASE
+    }
+    return fail(h, "exact: no wide plan instance for this input_len");
+}
+
 template <int KG>
 int exact_rescore_kg(som_handle* h, const float* X, int n_groups) {
     auto& ex = h->ex;
@@ -1495,7 +1602,10 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     const bool can_skip = ex.skip_mode > 0 && ex.seed_on && !h->wide && !two_round && (ex.skip_mode > 1 ? n_groups >= 2 : h->K >= 4096);
     const bool scout_ok = can_skip && ex.scout_on && n_groups <= 262144 &&
                           (ex.skip_mode > 1 || (double)N * (double)h->K * (double)h->D >= 3.0e11);
-    ex.skip_live = can_skip && (have_last || scout_ok);
+    // beyond 128 features (exact_skip_wide.hpp): euclidean, resident rows with last epoch's BMUs, whole 64-unit groups
+    const bool wide_skip = ex.skip_mode > 0 && ex.seed_on && h->wide && h->cfg.distance == SOM_DIST_EUCLIDEAN && have_last &&
+                           h->K % EX_GROUP == 0 && (h->n_stages & 1) == 0 && (ex.skip_mode > 1 ? n_groups >= 2 : h->K >= 4096);
+    ex.skip_live = (can_skip && (have_last || scout_ok)) || wide_skip;
     // default mode: two launches in a row whose plans kept (nearly) every block -- rows without structure -- are followed
     // by two launches without a plan (the plan costs 4-8 % of a full scan), and so on while the plans stay idle
     if (ex.skip_live && ex.skip_mode == 1) {
@@ -1553,10 +1663,11 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         // (a new row set starts like a new engine: level 2 is taken to pay until it has been measured on these rows)
         if (fresh && resident) { ex.l2_pays = true; ex.l1_share_probe = -1.0; }
         if (ex.l1_share_last > 0.9 && ex.l1_share_probe >= 0.0 && !ex.l2_pays) probe = false;   // (nothing for four times the centroids to find)
-        ex.l2_live = ex.sub_blocks && (ex.l2_pays || probe || ex.skip_mode >= 2 || !resident) &&
+        ex.l2_live = !h->wide && ex.sub_blocks && (ex.l2_pays || probe || ex.skip_mode >= 2 || !resident) &&
                      2 * (size_t)h->stage_bytes + (size_t)cdiv(n_groups, K16_STAGE_UNITS) * (64 * sizeof(int) + 4 * 8) <= 150 * 1024;   // (its list of kept groups lives in LDS)
         ex.scout_live = scout;
-        if (int rc = SOM_HALF(h, exact_skip_centroids, h, xmax2)) return rc;
+        if (h->wide) { if (int rc = SOM_HALF(h, exact_wide_centroids, h, xmax2)) return rc; }
+        else if (int rc = SOM_HALF(h, exact_skip_centroids, h, xmax2)) return rc;
     }
     ex.scout_live = scout;
     // (the forecast from sample tiles: where the scout plans and there is no good recent plan of the same kind to go by)
@@ -1681,7 +1792,18 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
                 X + r0 * h->D, n, h->D, h->W, h->wsq, h->K, out + r0, xsq + r0, xerr + r0, h->wmax2, xmax2, h->wmax2 + 1, eb, ex.seed);
             p_seed = ex.seed;
         }
-        if (ex.skip_live) {
+        if (ex.skip_live && h->wide) {
+            // beyond 128 features: the sorted float32 rows + the tile image built from them, the plan as a mode of the wide kernel
+            if (resort) {
+                if (int rc = SOM_HALF(h, exact_wide_gather, h, sr, s0, X + r0 * h->D, n, xsq + r0, xerr + r0, out + r0, xmax2)) return rc;
+                if (time_phases) { HIPCHK(h, hipEventRecord(cost.ev[6], h->stream)); sort_timed = true; }
+            } else {
+                wide_prev_sorted_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(sr.order + s0, n, out + r0, sr.lastpos_s + s0);
+            }
+            if (int rc = SOM_HALF(h, exact_wide_plan, h, sr, s0, n, xmax2, eb)) return rc;
+            p_xsq = sr.xsq_s + s0; p_xerr = sr.xerr_s + s0; p_seed = nullptr; p_Xb = sr.Xb_s + s0 * h->dp; p_order = sr.order + s0;
+            p_X = sr.Xf_s + s0 * h->D;
+        } else if (ex.skip_live) {
             unsigned long long* best = h->best64 + r0;
             if (resort) {
                 if (int rc = SOM_HALF(h, exact_skip_gather, h, sr, s0, sr.order + s0, X + r0 * h->D, Xb + r0 * h->dp, n, xsq + r0, xerr + r0, xmax2)) return rc;
@@ -1706,8 +1828,10 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         {
             Timed ts(h, SOM_K_SCREEN);
             if (time_phases) { HIPCHK(h, hipEventRecord(cost.ev[1], h->stream)); }
+            // (the lists the screen walks: dense 16-unit tiles up to 128 features, whole groups beyond)
             if (int rc = SOM_HALF(h, exact_screen_ks, h, p_Xb, n, h->best64 + r0, p_xsq, p_xerr, xmax2, eb, p_seed,
-                                  ex.skip_live ? ex.tlist : nullptr, ex.skip_live ? ex.tcnt : nullptr)) return rc;
+                                  ex.skip_live ? (h->wide ? ex.glist : ex.tlist) : nullptr,
+                                  ex.skip_live ? (h->wide ? ex.gcnt : ex.tcnt) : nullptr)) return rc;
             if (time_phases) { HIPCHK(h, hipEventRecord(cost.ev[2], h->stream)); screen_timed = true; }
         }
         const dim3 sel_grid((unsigned)cdiv(n, 64)), sel_block(64 * EX_SCAN_SPLIT);
@@ -1719,13 +1843,14 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
             // round 1: every row against the group that holds its screen minimum; round 2: the groups within the ONE-unit
             // bound of that float32 score (exact_select_kernel<true>: 20-32 % fewer pairs than the one-round scheme on
             // smooth maps, up to one pair per row more on random ones)
+            // (under a plan -- exact_skip_wide.hpp -- rows are sorted positions: p_X, p_xsq, p_xerr; the select kernel walks the lists)
             exact_first_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(
-                best, n, n_groups, ex.stride, xsq + r0, h->wmax2, xmax2, eb, xerr + r0, h->wmax2 + 1, ex.plist, ex.ctr, ex.rowarg);
-            if (int rc = exact_rescore_round(h, X + r0 * h->D, xsq + r0, best, nullptr, ex.ctr + n_groups)) return rc;
+                best, n, n_groups, ex.stride, p_xsq, h->wmax2, xmax2, eb, p_xerr, h->wmax2 + 1, ex.plist, ex.ctr, ex.rowarg);
+            if (int rc = exact_rescore_round(h, p_X, p_xsq, best, nullptr, ex.ctr + n_groups)) return rc;
             exact_select_kernel<true><<<sel_grid, sel_block, 0, h->stream>>>(
-                ex.gmin, ex.gflags, ex.stride, n_groups, n, best, xsq + r0, h->wmax2, xmax2, eb, xerr + r0, h->wmax2 + 1, ex.plist,
-                ex.ctr, ex.rowcnt, ex.rowarg);
-            if (int rc = exact_rescore_round(h, X + r0 * h->D, xsq + r0, best, ex.ctr + n_groups, nullptr)) return rc;
+                ex.gmin, ex.gflags, ex.stride, n_groups, n, best, p_xsq, h->wmax2, xmax2, eb, p_xerr, h->wmax2 + 1, ex.plist,
+                ex.ctr, ex.rowcnt, ex.rowarg, nullptr, ex.skip_live ? ex.glist : nullptr, ex.skip_live ? ex.gcnt : nullptr, SK_TILE);
+            if (int rc = exact_rescore_round(h, p_X, p_xsq, best, ex.ctr + n_groups, nullptr)) return rc;
         } else {
             exact_select_kernel<false><<<sel_grid, sel_block, 0, h->stream>>>(
                 ex.gmin, ex.gflags, ex.stride, n_groups, n, best, p_xsq, h->wmax2, xmax2, eb, p_xerr, h->wmax2 + 1, ex.plist,
@@ -2515,7 +2640,7 @@ void som_destroy(som_handle* h) {
     }
     {
         void* eb[] = {h->ex.gmin, h->ex.gflags, h->ex.rowcnt, h->ex.rowarg, h->ex.seed, h->ex.fb_list, h->ex.ctr, h->ex.fb_ids, h->ex.fbX, h->ex.plist, h->ex.tile_tab,
-                      h->ex.sk_keys, h->ex.sk_keys2, h->ex.sk_vals, h->ex.sk_tmp, h->ex.scout_g,
+                      h->ex.sk_keys, h->ex.sk_keys2, h->ex.sk_vals, h->ex.sk_tmp, h->ex.scout_g, h->ex.tq,
                       h->ex.need, h->ex.need2, h->ex.glist, h->ex.gcnt, h->ex.tile_counts, h->ex.tlist, h->ex.tcnt};
         for (void* b : eb) if (b) (void)hipFree(b);
         for (auto& sr : h->ex.srt) {
