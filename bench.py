@@ -224,6 +224,8 @@ def main():
                     help="weak scaling: the first k ranks draw rows WITHOUT structure (N(0, I)): shards that skip nothing beside shards that skip most")
     ap.add_argument("--no-schedule", action="store_true", help="skip the epoch-by-epoch / whole-schedule / unstructured-rows block")
     ap.add_argument("--no-f32-check", action="store_true", help="skip the float32 run the headline codebook is compared with")
+    ap.add_argument("--shard", default="contiguous", choices=["contiguous", "strided"],
+                    help="strong scaling: which rows of the one data set a rank takes (strided: rank, rank + N, ...: no rank skew from the file's order)")
     ap.add_argument("--no-variants", action="store_true", help="skip the data_variants / survey_schedule / queries blocks")
     args = ap.parse_args()
 
@@ -279,8 +281,9 @@ def main():
     w = w.astype(np.float32)
     # strong scaling: ONE data set, every rank holds its contiguous slice of it (an N = 1 and an N = 8 run train on
     # the same rows, so their codebooks can be compared); weak scaling: each rank draws its own rows
-    rows_host = (workload_rows(args.workload, args.total_rows, 1234)[lo:hi] if args.scaling == "strong"
-                 else workload_rows(args.workload, my_rows, 1234 + rank))
+    rows_host = (np.ascontiguousarray(D.shard_rows(workload_rows(args.workload, args.total_rows, 1234), rank, world, args.shard))
+                 if args.scaling == "strong" else workload_rows(args.workload, my_rows, 1234 + rank))
+    my_rows = len(rows_host)
     if args.scaling == "weak" and rank < args.unstructured_ranks:
         rows_host = np.random.default_rng(4321 + rank).standard_normal((my_rows, FEATURES)).astype(np.float32)
         if args.workload == "c5":
@@ -311,6 +314,8 @@ def main():
             if t == 0 and precision == args.precision:
                 first_epoch["w"] = eng.get_weights()      # the codebook one epoch from the seed (strong scaling: probe)
         fence(eng)
+        D.TIME_ALLREDUCE = dist is not None                # (events around every collective: what the epoch waits for)
+        D.allreduce_ms()
         # The timed region carries HIP events around the dominant (BMU) kernels only -- two event records per epoch
         # (precision 'exact': two more per screen pass).  Event pairs around every kernel family put a ~10 us bubble
         # on the stream at each of the four phase boundaries of an epoch (kernel trace): that breakdown
@@ -324,6 +329,8 @@ def main():
         fence(eng)
         dt = time.perf_counter() - t0
         eng.profile_enable(False)
+        eng.allreduce_ms = D.allreduce_ms()
+        D.TIME_ALLREDUCE = False
         sk1 = eng.exact_skip_stats() if precision == "exact" else (0, 0)
         # block skipping (csrc/exact_skip.hpp): the share of the distance GEMM's (256-row tile, 64-unit group) blocks the
         # screens of the timed epochs actually ran
@@ -340,15 +347,25 @@ def main():
     # every rank's own search time per epoch (hipEvents around its BMU kernels: no waiting in it) and executed share
     rank_spread = None
     if dist is not None:
-        mine = torch.tensor([eng.profile_get("bmu")[0] / max(1, args.steps), head_share], dtype=torch.float64, device="cuda")
+        ar_ms, ar_n = getattr(eng, "allreduce_ms", (0.0, 0))
+        mine = torch.tensor([eng.profile_get("bmu")[0] / max(1, args.steps), head_share, ar_ms / max(1, args.steps)], dtype=torch.float64, device="cuda")
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
         ms_r = [float(v[0].item()) for v in allv]
         sh_r = [float(v[1].item()) for v in allv]
+        ar_r = [float(v[2].item()) for v in allv]
         rank_spread = {"rank_epoch_ms": {"min": min(ms_r), "mean": sum(ms_r) / world, "max": max(ms_r), "by_rank": ms_r,
                                          "what": "each rank's own BMU search per epoch (hipEvents on its stream; the all-reduce is not in it)"},
                        "rank_executed_share": {"min": min(sh_r), "mean": sum(sh_r) / world, "max": max(sh_r), "by_rank": sh_r},
-                       "unstructured_ranks": args.unstructured_ranks}
+                       "unstructured_ranks": args.unstructured_ranks,
+                       # what an epoch WAITS for at its one exchange step: events on the collective's stream around the
+                       # all-reduce (host clocks on host-staged backends) -- the collective itself plus, ahead of it, the
+                       # slowest rank; the fastest rank's figure is the most skew, the slowest rank's the collective alone
+                       "allreduce_exposed_ms": {"min": min(ar_r), "mean": sum(ar_r) / world, "max": max(ar_r), "by_rank": ar_r,
+                                                "collectives_per_epoch": ar_n / max(1, args.steps), "bytes": 4 * MAP_X * MAP_Y * (FEATURES + 1 + (-(FEATURES + 1)) % 4),
+                                                "what": "per epoch, per rank: from the all-reduce's issue on its stream to its end (waiting for the slowest rank included)"},
+                       "epoch_ms_max_minus_mean_over_ranks": max(ms_r) - sum(ms_r) / world,
+                       "shard": args.shard if args.scaling == "strong" else "own rows per rank (weak scaling)"}
     w_after_timed = eng.get_weights() if args.precision == "exact" else None
     bmu_ms, bmu_n = eng.profile_get("bmu")
     scr_ms, scr_n = eng.profile_get("screen")

@@ -53,6 +53,7 @@ for case in range(n_cases):
         data[rs.randint(0, n)] = np.nan
     sig = float(rs.choice([max(min(X, Y) / 2, 1.0), 1.0, 2.5]))
     w2 = (w[::-1, ::-1] * F32(rs.choice([1.0, 0.5, 3.0]))).copy()   # (another codebook of the same kind: the units change places)
+    rs_cut = float(rs.rand())
     if os.environ.get("FUZZ_ONLY") and case != int(os.environ["FUZZ_ONLY"]):   # (replay one case of a seed)
         continue
     if os.environ.get("FUZZ_DUMP"):
@@ -73,16 +74,22 @@ for case in range(n_cases):
             e.set_weights(w2)
             e.epoch_accumulate(sig, 0.5, True)
             bmu3 = e.epoch_fetch()[2]
-            out[p] = (bmu, q, num, den, bmu2, bmu3)
+            # ... and a streamed epoch (chunks have no last BMU: under SOM_EXACT_SKIP=2 every chunk goes through the scout)
+            cut = int(rs_cut * n)
+            e.stream_epoch_accumulate([data[:cut], data[cut:]] if 0 < cut < n else [data], sig, 0.5, True)
+            snum, sden = e.epoch_fetch(want_bmu=False)[:2]
+            out[p] = (bmu, q, num, den, bmu2, bmu3, snum, sden)
             if p == "exact":
                 r, fb, _ = e.exact_stats()
                 rows_total += r; fb_total += fb
             e.close()
         a, b = out["f32"], out["exact"]
         ok = np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True) \
-            and np.array_equal(a[3], b[3], equal_nan=True) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
-        detail = "%d epoch rows, %d query rows, %d / %d rows of the seeded epochs differ" % (
-            (a[0] != b[0]).sum(), (a[1] != b[1]).sum(), (a[4] != b[4]).sum(), (a[5] != b[5]).sum())
+            and np.array_equal(a[3], b[3], equal_nan=True) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5]) \
+            and np.array_equal(a[6], b[6], equal_nan=True) and np.array_equal(a[7], b[7], equal_nan=True)
+        detail = "%d epoch rows, %d query rows, %d / %d rows of the seeded epochs differ; streamed sums equal %s" % (
+            (a[0] != b[0]).sum(), (a[1] != b[1]).sum(), (a[4] != b[4]).sum(), (a[5] != b[5]).sum(),
+            np.array_equal(a[6], b[6], equal_nan=True) and np.array_equal(a[7], b[7], equal_nan=True))
     except Exception as ex:                      # noqa: BLE001
         ok, detail = False, "EXC " + repr(ex)[:200]
     if not ok:

@@ -18,7 +18,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, sharded_input, out_dir, overlap="0"):
+def _worker(rank, world, port, sharded_input, out_dir, overlap="0", shard="contiguous"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), SOM_OVERLAP=overlap)
     import torch.distributed as dist
@@ -33,11 +33,10 @@ def _worker(rank, world, port, sharded_input, out_dir, overlap="0"):
     try:
         assert D.dist_info() == (rank, world)
         data = O.gaussian_blobs(601, 5, seed=11)
-        som = XPySom(7, 6, 5, random_seed=3, decay_function="linear", sharded_input=sharded_input)
+        som = XPySom(7, 6, 5, random_seed=3, decay_function="linear", sharded_input=sharded_input, shard=shard)
         mine = data
         if sharded_input:
-            lo, hi = D.shard_bounds(len(data), rank, world)
-            mine = data[lo:hi]
+            mine = D.shard_rows(data, rank, world, shard)
         som.train(mine, 6)
         np.save(os.path.join(out_dir, "w%d.npy" % rank), som._weights)
         if not sharded_input:                              # one row, two ranks: rank 1's shard is empty
@@ -79,6 +78,33 @@ def test_eight_rank_training_equals_single_process(tmp_path, overlap):
     data = O.gaussian_blobs(601, 5, seed=11)
     ref = O.train(data, O.default_codebook(7, 6, 5, 3), 6, sigma0=3.0, decay="linear", n_parallel=4000)
     np.testing.assert_allclose(ws[0], ref, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("world,sharded_input", [(2, False), (2, True), (8, False)])
+def test_strided_shards_train_the_same_map(tmp_path, world, sharded_input):
+    """shard='strided' (rows rank, rank + world, ...): every rank ends on the same codebook bit for bit, and on the
+    single-process one to float32 summation order -- as the contiguous split does."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(world, _free_port(), sharded_input, str(tmp_path), "0", "strided"), nprocs=world, join=True)
+    ws = [np.load(tmp_path / ("w%d.npy" % r)) for r in range(world)]
+    for w in ws[1:]:
+        assert np.array_equal(ws[0], w)
+    data = O.gaussian_blobs(601, 5, seed=11)
+    ref = O.train(data, O.default_codebook(7, 6, 5, 3), 6, sigma0=3.0, decay="linear", n_parallel=4000)
+    np.testing.assert_allclose(ws[0], ref, rtol=2e-5, atol=2e-6)
+
+
+def test_shard_rows_cover_every_row_once():
+    from xpysom_dask_amd.distributed import shard_rows
+    data = np.arange(23)
+    for shard in ("contiguous", "strided"):
+        for world in (1, 2, 3, 8):
+            got = np.sort(np.concatenate([shard_rows(data, r, world, shard) for r in range(world)]))
+            assert np.array_equal(got, data), (shard, world)
+            sizes = [len(shard_rows(data, r, world, shard)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_rows(data, 0, 2, "random")
 
 
 def test_blockwise_allreduce_host_logic(tmp_path):

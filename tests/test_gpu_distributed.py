@@ -194,4 +194,8 @@ def test_bench_reports_the_rank_spread_when_shards_differ_in_structure():
     # (the four ranks share ONE card here, so whose kernels wait for whose is the scheduler's business: the times are
     #  reported, not compared)
     assert all(v > 0 for v in ms["by_rank"])
+    # what the epoch waits for at its exchange step, and the ranks' spread
+    ar = out["allreduce_exposed_ms"]
+    assert len(ar["by_rank"]) == 4 and ar["collectives_per_epoch"] >= 1 and all(v > 0 for v in ar["by_rank"])
+    assert out["epoch_ms_max_minus_mean_over_ranks"] >= 0.0
 

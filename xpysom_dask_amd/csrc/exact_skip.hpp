@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void exact_gather_sorted_kernel(const int* __r
             }
         }
         *(bf16x8*)((char*)Xb_s + (p * dp + c * 8) * 2) = v;
-        *(bf16x8*)((char*)Xl_s + (p * dp + c * 8) * 2) = vl;
+        if (Xl_s != nullptr) *(bf16x8*)((char*)Xl_s + (p * dp + c * 8) * 2) = vl;   // (allocated when the refinement first engages)
     }
     if (lane == 0) {
         const float nanv = __builtin_nanf("");

@@ -123,7 +123,8 @@ struct som_handle {
             long cap = 0;                 // positions the buffers hold (each pass padded to the tile)
             int* order = nullptr;
             __bf16* Xb_s = nullptr;
-            __bf16* Xl_s = nullptr;       // ... the rows' second half image (the refinement pass)
+            __bf16* Xl_s = nullptr;       // ... the rows' second half image (the refinement pass): allocated when it first engages
+            bool xl_filled = false;       //     ... and written by a gather since
             float *Xf_s = nullptr, *xsq_s = nullptr, *xerr_s = nullptr, *seed_s = nullptr, *sU_s = nullptr;
             int* lastpos_s = nullptr;     // position (patch order) of every sorted row's (pseudo) last BMU
         } srt[2];
@@ -1195,7 +1196,7 @@ int exact_skip_reserve(som_handle* h, som_handle::ExactScratch::SortedRows& sr, 
         if (&sr == &ex.srt[0]) ex.res_valid = false;
         if (int rc = dev_alloc(h, &sr.order, (size_t)need_rows)) return rc;
         if (int rc = dev_alloc(h, &sr.Xb_s, (size_t)need_rows * h->dp)) return rc;
-        if (int rc = dev_alloc(h, &sr.Xl_s, h->wide ? 1 : (size_t)need_rows * h->dp)) return rc;   // (the refinement pass: up to 128 features)
+        // (sr.Xl_s, the rows' second half image: allocated by the first launch whose refinement pass engages -- launch_bmu_exact)
         if (int rc = dev_alloc(h, &sr.Xf_s, (size_t)need_rows * h->D)) return rc;
         if (int rc = dev_alloc(h, &sr.xsq_s, (size_t)need_rows)) return rc;
         if (int rc = dev_alloc(h, &sr.xerr_s, (size_t)need_rows)) return rc;
@@ -1279,7 +1280,7 @@ int exact_skip_gather(som_handle* h, som_handle::ExactScratch::SortedRows& sr, l
                       const float* xsq, const float* xerr, const float* xmax2) {
     const long np = round_up(n, SK_TILE);
     exact_gather_sorted_kernel<E><<<dim3((unsigned)cdiv(np, 4)), dim3(256), 0, h->stream>>>(
-        order, n, np, h->dp, h->D, Xb, X, xsq, xerr, xmax2, sr.Xb_s + s0 * h->dp, sr.Xl_s + s0 * h->dp, sr.Xf_s + s0 * h->D,
+        order, n, np, h->dp, h->D, Xb, X, xsq, xerr, xmax2, sr.Xb_s + s0 * h->dp, sr.Xl_s != nullptr ? sr.Xl_s + s0 * h->dp : nullptr, sr.Xf_s + s0 * h->D,
         sr.xsq_s + s0, sr.xerr_s + s0);
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -1698,6 +1699,12 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     // given (it is bound by the same gather of rows) and leaves one to one and a half pairs a row, at two small launches more:
     // worth it from three candidate pairs a row on (the last planned epoch's count) -- the smooth maps of a schedule's middle
     ex.refine_live = ex.skip_live && ex.refine_on && h->Wst_lo != nullptr && (ex.pairs_per_row_last >= 3.0 || ex.skip_mode >= 2);
+    if (ex.refine_live && !sr.xl_filled) {
+        // the rows' second half image (a quarter of the sorted copies' bytes) exists from the first launch that refines: the
+        // order is rebuilt in that launch, so that the gather fills it
+        if (sr.Xl_s == nullptr && dev_alloc(h, &sr.Xl_s, (size_t)sr.cap * h->dp) != 0) { (void)hipGetLastError(); h->err.clear(); sr.Xl_s = nullptr; ex.refine_live = false; }
+        else resort = true;
+    }
     int64_t groups_run = 0, pairs_in = 0, pairs_out = 0, scout_wins = 0;
     // which phases this launch times (the launch as a whole: always)
     const bool planned_at_start = ex.skip_live;
@@ -1808,6 +1815,7 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
             if (resort) {
                 if (int rc = SOM_HALF(h, exact_skip_gather, h, sr, s0, sr.order + s0, X + r0 * h->D, Xb + r0 * h->dp, n, xsq + r0, xerr + r0, xmax2)) return rc;
                 if (time_phases) { HIPCHK(h, hipEventRecord(cost.ev[6], h->stream)); sort_timed = true; }
+                if (sr.Xl_s != nullptr && r0 + n >= N) sr.xl_filled = true;
             }
             const int* lastpos2 = nullptr;
             if (scout) {

@@ -30,6 +30,50 @@ def shard_bounds(n_rows, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+SHARDS = ("contiguous", "strided")
+
+
+def shard_rows(data, rank, world, shard="contiguous"):
+    """This rank's rows of `data` (a host array or a torch tensor; anything sliceable along axis 0).
+      contiguous  rows [lo, hi) of shard_bounds: what the reference's Dask blocks are (xpysom.py:490,546)
+      strided     rows rank, rank + world, rank + 2 world, ...: every rank sees a sample of the WHOLE file, so an order in
+                  the input (rows sorted by class, by time, by source) cannot become rank skew -- under block skipping a
+                  rank's epoch depends on ITS rows and the all-reduce waits for the slowest.  The sums are over the same rows
+                  either way: the trained map is the same to float32 summation order."""
+    if shard not in SHARDS:
+        raise ValueError("shard must be one of %s" % ", ".join(SHARDS))
+    if world == 1:
+        return data
+    if shard == "strided":
+        mine = data[rank::world]
+        if hasattr(mine, "contiguous"):                  # torch: the engine borrows a dense block
+            mine = mine.contiguous()
+        return mine
+    lo, hi = shard_bounds(len(data), rank, world)
+    return data[lo:hi]
+
+
+# bench.py sets this: every all-reduce is bracketed by events on the stream it runs on (host clocks on host-staged
+# backends); allreduce_ms() returns and clears what they measured.  What is measured is what the epoch WAITS for: the
+# collective itself and, ahead of it, the slowest rank.
+TIME_ALLREDUCE = False
+_ar_events, _ar_host_ms = [], []
+
+
+def allreduce_ms():
+    """(total ms, collectives) since the last call (TIME_ALLREDUCE)."""
+    total, n = float(sum(_ar_host_ms)), len(_ar_host_ms)
+    _ar_host_ms.clear()
+    if _ar_events:
+        import torch
+        torch.cuda.synchronize()
+        for a, b in _ar_events:
+            total += a.elapsed_time(b)
+            n += 1
+        _ar_events.clear()
+    return total, n
+
+
 def allreduce_accumulator(engine):
     """Sum the engine's fused accumulator across ranks, in place."""
     rank, world = dist_info()
@@ -48,13 +92,24 @@ def allreduce_accumulator(engine):
             ext = None
         if ext is not None:
             with torch.cuda.stream(ext):
+                if TIME_ALLREDUCE:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(ext)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                if TIME_ALLREDUCE:
+                    b.record(ext)
+                    _ar_events.append((a, b))
             return
     engine.sync()                      # host-staged backends (gloo): the engine runs on its own stream
+    if TIME_ALLREDUCE:
+        import time
+        t0 = time.perf_counter()
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     if t.is_cuda:
         import torch
         torch.cuda.current_stream(t.device).synchronize()
+    if TIME_ALLREDUCE:
+        _ar_host_ms.append(1e3 * (time.perf_counter() - t0))
 
 
 _comm_streams = {}

@@ -79,7 +79,7 @@ class XPySom:
                  random_seed=None, n_parallel=0, compact_support=False,
                  xp=None,
                  use_dask=False, dask_chunks='auto',
-                 *, precision='exact', device=None, sharded_input=False):
+                 *, precision='exact', device=None, sharded_input=False, shard='contiguous'):
         """Same positional/keyword surface as the reference constructor (xpysom.py:73-82).
 
         ``xp``, ``use_dask`` and ``dask_chunks`` are accepted for source compatibility and
@@ -95,6 +95,10 @@ class XPySom:
           device         HIP device ordinal (default: LOCAL_RANK or 0)
           sharded_input  under an initialised process group: ``train(data)`` receives only this
                          rank's rows (default: every rank passes the full array and takes its slice)
+          shard          which slice that is: 'contiguous' (rows [lo, hi): the reference's Dask blocks, xpysom.py:490,546)
+                         or 'strided' (rows rank, rank + world, ...: every rank a sample of the whole file, so that an
+                         order in the input cannot become rank skew under block skipping); the same map either way, to
+                         float32 summation order
         """
         if sigma >= x or sigma >= y:
             warn('Warning: sigma is too high for the dimension of the map.')
@@ -179,6 +183,9 @@ class XPySom:
         self._precision = precision
         self._device = device
         self._sharded_input = sharded_input
+        if shard not in _dist.SHARDS:
+            raise ValueError("shard must be one of %s" % ", ".join(_dist.SHARDS))
+        self._shard = shard
         self._engine_obj = None
 
     # ------------------------------------------------------------------ engine plumbing
@@ -290,8 +297,7 @@ class XPySom:
         rank, world = _dist.dist_info()
         if _device_rows(data) is not None:               # rows already in HBM: no host round trip
             if world > 1 and not self._sharded_input:
-                lo, hi = _dist.shard_bounds(len(data), rank, world)
-                data = data[lo:hi]
+                data = _dist.shard_rows(data, rank, world, getattr(self, '_shard', 'contiguous'))
             ptr, n, d, dev_index, owner, stream = _device_rows(data)
             eng = self._upload_weights()
             if dev_index is not None and dev_index != eng.device:
@@ -306,8 +312,7 @@ class XPySom:
             if data.ndim != 2:
                 raise ValueError('data must be 2-dimensional (n_samples, input_len)')
             if world > 1 and not self._sharded_input:
-                lo, hi = _dist.shard_bounds(len(data), rank, world)
-                data = data[lo:hi]
+                data = _dist.shard_rows(data, rank, world, getattr(self, '_shard', 'contiguous'))
             eng = self._upload_weights()
             eng.set_data(data)
 
