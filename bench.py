@@ -53,6 +53,10 @@ WORKLOADS = {
                neighborhood="gaussian", cpu_rows=100000, label="BASELINE configs[1]"),
     "c5": dict(map=(512, 512), features=784, rows=250000, precision="exact", distance="cosine",
                neighborhood="mexican_hat", cpu_rows=256, label="BASELINE configs[4], one GPU's shard of 2M rows"),
+    # configs[4]'s map and shard size with the ORDINARY wide pairing, euclidean + gaussian on unnormalised blobs (the G17
+    # family; MNIST-shaped rows): where block skipping beyond 128 features engages (csrc/exact_skip_wide.hpp)
+    "c5e": dict(map=(512, 512), features=784, rows=250000, precision="exact", distance="euclidean",
+                neighborhood="gaussian", cpu_rows=256, label="configs[4]'s map and shard size, euclidean + gaussian (not a BASELINE config)"),
 }
 
 
@@ -415,7 +419,7 @@ def main():
     full_scan = None
     # (the condition is the same on every rank -- the run below holds collectives: never a rank's own measured share)
     if args.precision == "exact" and exact_has_screen(FEATURES, MAP_X * MAP_Y, wl["distance"]) and not args.no_throughput_mode \
-            and FEATURES <= 128 and MAP_X * MAP_Y >= 4096 and os.environ.get("SOM_EXACT_SKIP", "1") != "0":
+            and (FEATURES <= 128 or wl["distance"] == "euclidean") and MAP_X * MAP_Y >= 4096 and os.environ.get("SOM_EXACT_SKIP", "1") != "0":
         old_env = os.environ.get("SOM_EXACT_SKIP")
         os.environ["SOM_EXACT_SKIP"] = "0"
         e_f, dt_f = timed_run("exact")
@@ -464,7 +468,7 @@ def main():
             "epochs_under_a_plan": res[0], "of_which_sorted_the_rows": res[1],
             "codebook_equal_to_headline_run": bool(np.array_equal(w_sched, w_after_timed)),
         }
-        if not args.no_f32_check and FEATURES <= 128:
+        if not args.no_f32_check and (FEATURES <= 128 or wl["distance"] == "euclidean"):
             e_f, ms_f, _ = one_by_one(rows_host, "f32")
             equal_f32 = bool(np.array_equal(e_f.get_weights(), w_sched))
             schedule_block["f32_run_ms_per_epoch"] = sum(ms_f) / total

@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) void merge_prep_wide_kernel(float* __restrict_
 // GM (precision 'exact' beyond 128 features, bmu_exact.hpp): as in bmu_bf16_k16_kernel<.., GM = true> -- values only,
 // the minimum of every GROUP of 64 units (two stages) per row stored where it is within the row's bound of the
 // minimum so far, and the mask of the rows stored (32 per wave) per group; the parts split on group boundaries.
-// TL (GM under a plan, exact_skip_wide.hpp): the workgroup walks its tile's list of GROUPS (glist: group << 4 | 15 items,
-// gcnt of them) -- both stages of each -- instead of every stage.
+// TL (exact_skip_wide.hpp): the workgroup walks its tile's list of GROUPS (glist: group << 4 | 15 items, gcnt of them) -- both
+// stages of each -- instead of every stage.  With GM: the screen under a plan; without: the scout's pick of a pseudo last BMU.
 // PLAN (exact_skip_wide.hpp): the same scan over a stage image of group CENTROIDS (32 to a stage; the stage's tail holds,
 // behind the 32 initial accumulators S'(B' + |c|^2 / 2) - hS r^2, the 32 radii sw r) with the plan's test as its epilogue:
 // need(row, c) = not (acc - (sx sqrt(U))(sw r) > P(row)), rows' P and sx sqrt(U) in planP / planXs; OR over the tile's 256
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
                                                                    const float* __restrict__ planP = nullptr,
                                                                    const float* __restrict__ planXs = nullptr,
                                                                    unsigned long long* __restrict__ need = nullptr, int n_words = 0) {
-    static_assert(!TL || GM, "tile lists belong to the exact mode's screen");
+    // (TL without GM: the scout of exact_skip_wide.hpp -- the plain kernel, unit indices kept, over a tile's few listed groups)
     static_assert(!PLAN || (!GM && !TL), "the plan is a mode of its own");
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;

@@ -761,11 +761,11 @@ __global__ __launch_bounds__(256) void exact_scatter_ids_kernel(const int* __res
     if (i < n) out[list[i]] = ids[i];
 }
 
-// max_n v[n] (positive floats; NaN left out) into *out, which the caller zeroed
+// max_n v[n] (positive floats; NaN left out) into *out, which the caller zeroed.  Grid-stride: a few hundred workgroups hand in
+// one maximum per wave (a workgroup per 256 values put 16 384 atomics of a million-row set on one address: 0.1 ms for 4 MB)
 __global__ __launch_bounds__(256) void exact_max_kernel(const float* __restrict__ v, long n, float* __restrict__ out) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
     float m = 0.0f;
-    if (i < n) { const float s = v[i]; if (s == s) m = s; }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { const float s = v[i]; if (s == s) m = fmaxf(m, s); }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) atomic_max_pos_f32(out, m);

@@ -710,8 +710,10 @@ __global__ __launch_bounds__(256) void exact_groupkey_kernel(const int* __restri
 // per 256-row tile of the sorted pass: the distinct groups of its rows' keys (gkey[p]: ascending over the pass) and, where
 // lastpos is given, of their last BMUs (lastpos[p] >> 6) -- a bitmap of the groups in LDS -- as the tile's dense list of
 // 16-unit tiles (all four of every group, ascending: what bmu_bf16_k16_kernel<.., TL> walks).  One wave per tile.
+// group_items: the list as (group << 4 | 15) items, one per group (what the wide kernel walks), tcnt = groups listed.
 __global__ __launch_bounds__(64) void exact_scout_lists_kernel(const int* __restrict__ gkey, const int* __restrict__ lastpos, long n,
-                                                               int n_groups, int* __restrict__ tlist, int* __restrict__ tcnt) {
+                                                               int n_groups, int* __restrict__ tlist, int* __restrict__ tcnt,
+                                                               int group_items = 0) {
     extern __shared__ unsigned long long sbm[];
     const long tile = blockIdx.x;
     const int lane = threadIdx.x;
@@ -733,7 +735,7 @@ __global__ __launch_bounds__(64) void exact_scout_lists_kernel(const int* __rest
     }
     __syncthreads();
     int base = 0;
-    int* out = tlist + tile * 4 * (long)n_groups;
+    int* out = tlist + tile * (group_items ? 1 : 4) * (long)n_groups;
     for (int w0 = 0; w0 < nw; w0 += 64) {
         unsigned long long word = w0 + lane < nw ? sbm[w0 + lane] : 0ull;
         const int c = __popcll(word);
@@ -743,13 +745,16 @@ __global__ __launch_bounds__(64) void exact_scout_lists_kernel(const int* __rest
         int at = base + incl - c;
         for (; word != 0ull; word &= word - 1ull) {
             const int g = (w0 + lane) * 64 + (int)__builtin_ctzll(word);
+            if (group_items) out[at] = (g << 4) | 15;
+            else {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) out[4 * at + b] = (g << 2) | b;
+                for (int b = 0; b < 4; ++b) out[4 * at + b] = (g << 2) | b;
+            }
             ++at;
         }
         base += __shfl(incl, 63, 64);
     }
-    if (lane == 0) tcnt[tile] = 4 * base;
+    if (lane == 0) tcnt[tile] = group_items ? base : 4 * base;
 }
 
 // Is a plan from the scout worth its launches at all?  First the cheap question: how much of the map does a ROW need?  A sample of
@@ -819,12 +824,14 @@ __global__ __launch_bounds__(256) void exact_sample_tiles_kernel(const int* __re
 
 // the scout's pick per sorted position -> lastpos (a position below K: what the plan's prologue evaluates), and the merge
 // keys back to all ones for the screen proper
+// (perm: positions -> UNIT ids, where the consumer wants units -- the wide plan's float32 seed)
 __global__ __launch_bounds__(256) void exact_scout_pos_kernel(unsigned long long* __restrict__ best64, long n, int K,
-                                                              int* __restrict__ lastpos) {
+                                                              int* __restrict__ lastpos, const int* __restrict__ perm = nullptr) {
     const long p = (long)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     const uint32_t u = (uint32_t)best64[p];
-    lastpos[p] = u < (uint32_t)K ? (int)u : 0;               // (a NaN row: any unit gives a valid bound)
+    const int pos = u < (uint32_t)K ? (int)u : 0;            // (a NaN row: any unit gives a valid bound)
+    lastpos[p] = perm != nullptr ? perm[pos] : pos;
     best64[p] = ~0ull;
 }
 

@@ -70,22 +70,27 @@ __global__ __launch_bounds__(256) void wide_centroids_kernel(const float* __rest
 // the tails of the centroid stage image (32 centroids to a stage; the fragments are prep_w_bf16_wide_kernel's, the measured
 // rounding error exact_werr_kernel's): [0, 32) initial accumulators S'(B' + |c|^2 / 2) - hS r^2, [32, 64) sw r (rounded up);
 // a slot without units: +inf and 0 (never needed); a NaN radius: NaN (always needed)
+// Cst_plain (or null): a copy of the image whose tails are the plain S'(B' + |c|^2 / 2) -- the scout's nearest-centroid scan
+// (its fragments: a device copy of Cst's, made by the host before this kernel).
 __global__ __launch_bounds__(256) void wide_centroid_tail_kernel(const float* __restrict__ rg, const float* __restrict__ csq, int n_groups,
                                                                  char* __restrict__ Cst, int n_img_stages, int stage_bytes,
-                                                                 const float* __restrict__ xmax2, const float* __restrict__ wmax2) {
+                                                                 const float* __restrict__ xmax2, const float* __restrict__ wmax2,
+                                                                 char* __restrict__ Cst_plain = nullptr) {
     const long slot = (long)blockIdx.x * 256 + threadIdx.x;
     if (slot >= (long)n_img_stages * WD_STAGE_UNITS) return;
     const long stage = slot / WD_STAGE_UNITS;
     const int within = (int)(slot - stage * WD_STAGE_UNITS);
     float* tail = (float*)(Cst + (stage + 1) * (long)stage_bytes - 1024);
+    float* ptail = Cst_plain != nullptr ? (float*)(Cst_plain + (stage + 1) * (long)stage_bytes - 1024) : nullptr;
     const float rad = slot < n_groups ? rg[slot] : -1.0f;
-    if (rad < 0.0f) { tail[within] = __builtin_inff(); tail[WD_STAGE_UNITS + within] = 0.0f; return; }
+    if (rad < 0.0f) { tail[within] = __builtin_inff(); tail[WD_STAGE_UNITS + within] = 0.0f; if (ptail) ptail[within] = __builtin_inff(); return; }
     const float sw = ex_scale(*wmax2), sx = ex_scale(*xmax2);
     const float big = __builtin_sqrtf(*wmax2) * __builtin_sqrtf(*xmax2) * (1.0f + 1.0f / 1024.0f);   // (ex_scales: B')
     const float S = sx * sw, hS = 0.5f * S * (1.0f + 1.0f / 1024.0f);
     const float s0 = __builtin_fmaf(0.5f * S, csq[slot], S * big);
     tail[within] = s0 - hS * rad * rad * (1.0f + 0x1p-20f);
     tail[WD_STAGE_UNITS + within] = sw * rad * (1.0f + 0x1p-20f);
+    if (ptail) ptail[within] = (s0 == s0 && s0 < 3.0e38f) ? s0 : __builtin_inff();
 }
 
 // The resident pass in sorted order: the float32 rows, |x|^2, rounding error, last epoch's BMU -- positions behind the pass's

@@ -831,7 +831,7 @@ int prep_rows_half(som_handle* h, const float* X, long N, long Np, __bf16* Xb, f
         if ((!xsq_scratch || !xerr) && N > 0) return fail(h, "exact: no row-norm buffer");
         const float* usq = unit ? xsq_scratch : nullptr;
         if (unit) HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)xmax2, 0x3F800000, 1, h->stream));   // unit-length rows: max |x| = 1
-        else if (N > 0) exact_max_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(xsq_scratch, N, xmax2);
+        else if (N > 0) exact_max_kernel<<<dim3((unsigned)std::min<long>(cdiv(N, 256), 512)), dim3(256), 0, h->stream>>>(xsq_scratch, N, xmax2);
         const long n_blocks = Np / h->tl_bm;
         const long total = n_blocks * h->n_kchunks * (h->tl_bm / 16) * TL_KS * 64;
         prep_tiles_bf16_kernel<E><<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(
@@ -861,7 +861,7 @@ int prep_rows_half(som_handle* h, const float* X, long N, long Np, __bf16* Xb, f
         if (!xsq_scratch && N > 0) return fail(h, "exact: no row norms");
         float* xerr = exact_err_of(h, xsq_scratch);
         if (!xerr && N > 0) return fail(h, "exact: unknown row-norm buffer");
-        if (N > 0) exact_max_kernel<<<dim3((unsigned)cdiv(N, 256)), dim3(256), 0, h->stream>>>(xsq_scratch, N, xmax2);
+        if (N > 0) exact_max_kernel<<<dim3((unsigned)std::min<long>(cdiv(N, 256), 512)), dim3(256), 0, h->stream>>>(xsq_scratch, N, xmax2);
         prep_x_bf16_kernel<E><<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, Dp, Np, Xb, nullptr, 0, xmax2, xerr);
     } else
         prep_x_bf16_kernel<E><<<dim3((unsigned)cdiv(Np, 4)), dim3(256), 0, h->stream>>>(X, N, h->D, Dp, Np, Xb, xmax2, unit ? 1 : 0);
@@ -1179,9 +1179,9 @@ int exact_skip_reserve(som_handle* h, som_handle::ExactScratch::SortedRows& sr, 
             if (int rc = dev_alloc(h, &c.cmax2, 2)) return rc;
             if (int rc = dev_alloc(h, &c.Cst, (size_t)c.n_img_stages * h->stage_bytes)) return rc;
             HIPCHK(h, hipMemsetAsync(c.Cst, 0, (size_t)c.n_img_stages * h->stage_bytes, h->stream));
-            if (lv == 0 && !h->wide) {
-                if (int rc = dev_alloc(h, &c.Cst_plain, (size_t)c.n_cstages * h->stage_bytes)) return rc;
-                HIPCHK(h, hipMemsetAsync(c.Cst_plain, 0, (size_t)c.n_cstages * h->stage_bytes, h->stream));
+            if (lv == 0) {
+                if (int rc = dev_alloc(h, &c.Cst_plain, (size_t)c.n_img_stages * h->stage_bytes)) return rc;
+                HIPCHK(h, hipMemsetAsync(c.Cst_plain, 0, (size_t)c.n_img_stages * h->stage_bytes, h->stream));
             }
         }
         ex.cen_ready = true;
@@ -1409,8 +1409,10 @@ int exact_wide_centroids(som_handle* h, const float* xmax2) {
     prep_w_bf16_wide_kernel<E><<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream>>>(c0.Cc, n_groups, h->D, h->n_kchunks, c0.Cst, c0.n_img_stages,
                                                                                              nullptr, h->wmax2);
     exact_werr_kernel<E><<<dim3((unsigned)cdiv(n_groups, 4 * EX_WERR_UNITS)), dim3(256), 0, h->stream>>>(c0.Cc, n_groups, h->D, h->wmax2, c0.cmax2 + 1, nullptr);
+    char* plain = ex.scout_live ? c0.Cst_plain : nullptr;
+    if (plain) HIPCHK(h, hipMemcpyAsync(plain, c0.Cst, (size_t)c0.n_img_stages * h->stage_bytes, hipMemcpyDeviceToDevice, h->stream));
     wide_centroid_tail_kernel<<<dim3((unsigned)cdiv((long)c0.n_img_stages * WD_STAGE_UNITS, 256)), dim3(256), 0, h->stream>>>(
-        c0.rg, c0.csq, n_groups, c0.Cst, c0.n_img_stages, h->stage_bytes, xmax2, h->wmax2);
+        c0.rg, c0.csq, n_groups, c0.Cst, c0.n_img_stages, h->stage_bytes, xmax2, h->wmax2, plain);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -1428,6 +1430,62 @@ int exact_wide_gather(som_handle* h, som_handle::ExactScratch::SortedRows& sr, l
         sr.Xf_s + s0 * h->D, n, h->D, h->n_kchunks, n_blocks, h->tl_bm, h->tl_xtile, 1.0f, nullptr, (char*)(sr.Xb_s + s0 * h->dp), xmax2);
     HIPCHK(h, hipGetLastError());
     return 0;
+}
+
+// the scout beyond 128 features, step 1: every row's nearest group centroid (the plain wide kernel on the plain centroid image)
+template <int KS32, class E>
+int exact_wide_scout_nearest_ks(som_handle* h, const __bf16* Ximg, long n, unsigned long long* best64, int* g_out) {
+    auto& ex = h->ex;
+    const auto& c0 = ex.cen[0];
+    const size_t lds = (size_t)WD_SLOTS * wd_stage_bytes(KS32);
+    int per_cu = 1;
+    if (int rc = kernel_per_cu(h, (const void*)bmu_bf16_wide_kernel<KS32, E>, 64 * WD_NW, lds, &per_cu)) return rc;
+    const long blocks = cdiv(n, WD_WG_SAMPLES);
+    const long slots = (long)per_cu * (h->n_cus > 0 ? h->n_cus : 256);
+    const int parts = (int)std::max<long>(1, std::min<long>({cdiv(2 * slots, blocks), 8L, (long)c0.n_img_stages}));
+    bmu_bf16_wide_kernel<KS32, E><<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * WD_NW), lds, h->stream>>>(
+        (const char*)Ximg, n, c0.Cst_plain, c0.n_img_stages, best64);
+    bmu_finalize_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(best64, n, c0.n_slots, g_out);
+    HIPCHK(h, hipMemsetAsync(best64, 0xFF, (size_t)n * sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+// ... step 3: per tile of the sorted pass the groups of its rows' keys, the plain wide kernel over those groups' units with
+// indices kept: the best of them, as a UNIT id, -> lastpos_s (what the wide plan's float32 seed evaluates)
+template <int KS32, class E>
+int exact_wide_scout_pick_ks(som_handle* h, som_handle::ExactScratch::SortedRows& sr, long s0, long n, const int* keys, unsigned long long* best64) {
+    auto& ex = h->ex;
+    const int n_groups = (int)cdiv(h->K, EX_GROUP);
+    const long tiles = round_up(n, SK_TILE) / SK_TILE;
+    const size_t lds_l = (size_t)cdiv(n_groups, 64) * sizeof(unsigned long long);
+    exact_scout_lists_kernel<<<dim3((unsigned)tiles), dim3(64), lds_l, h->stream>>>(keys, nullptr, n, n_groups, ex.glist, ex.gcnt, 1);
+    const size_t lds = (size_t)WD_SLOTS * wd_stage_bytes(KS32);
+    int per_cu = 1;
+    if (int rc = kernel_per_cu(h, (const void*)bmu_bf16_wide_kernel<KS32, E, false, true>, 64 * WD_NW, lds, &per_cu)) return rc;
+    bmu_bf16_wide_kernel<KS32, E, false, true><<<dim3((unsigned)tiles, 1), dim3(64 * WD_NW), lds, h->stream>>>(
+        (const char*)(sr.Xb_s + s0 * h->dp), n, h->Wst, h->n_stages, best64, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ExactBound(),
+        ex.glist, ex.gcnt, n_groups);
+    exact_scout_pos_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(best64, n, h->K, sr.lastpos_s + s0, h->ex_perm);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+#define SOM_WIDE_DISPATCH(fn, ...) \
+    switch (h->n_kchunks) { \
+    case 5: return fn<5, E>(__VA_ARGS__); case 6: return fn<6, E>(__VA_ARGS__); case 7: return fn<7, E>(__VA_ARGS__); case 8: return fn<8, E>(__VA_ARGS__); \
+    case 9: return fn<9, E>(__VA_ARGS__); case 10: return fn<10, E>(__VA_ARGS__); case 11: return fn<11, E>(__VA_ARGS__); case 12: return fn<12, E>(__VA_ARGS__); \
+    case 13: return fn<13, E>(__VA_ARGS__); case 14: return fn<14, E>(__VA_ARGS__); case 15: return fn<15, E>(__VA_ARGS__); case 16: return fn<16, E>(__VA_ARGS__); \
+    case 17: return fn<17, E>(__VA_ARGS__); case 18: return fn<18, E>(__VA_ARGS__); case 19: return fn<19, E>(__VA_ARGS__); case 20: return fn<20, E>(__VA_ARGS__); \
+    case 21: return fn<21, E>(__VA_ARGS__); case 22: return fn<22, E>(__VA_ARGS__); case 23: return fn<23, E>(__VA_ARGS__); case 24: return fn<24, E>(__VA_ARGS__); \
+    case 25: return fn<25, E>(__VA_ARGS__); }
+template <class E>
+int exact_wide_scout_nearest(som_handle* h, const __bf16* Ximg, long n, unsigned long long* best64, int* g_out) {
+    SOM_WIDE_DISPATCH(exact_wide_scout_nearest_ks, h, Ximg, n, best64, g_out)
+    return fail(h, "exact: no wide scout instance for this input_len");
+}
+template <class E>
+int exact_wide_scout_pick(som_handle* h, som_handle::ExactScratch::SortedRows& sr, long s0, long n, const int* keys, unsigned long long* best64) {
+    SOM_WIDE_DISPATCH(exact_wide_scout_pick_ks, h, sr, s0, n, keys, best64)
+    return fail(h, "exact: no wide scout instance for this input_len");
 }
 
 // one pass's plan on the sorted rows: the float32 score of every row's last BMU, the rows' thresholds, the wide kernel in its
@@ -1604,8 +1662,11 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     const bool scout_ok = can_skip && ex.scout_on && n_groups <= 262144 &&
                           (ex.skip_mode > 1 || (double)N * (double)h->K * (double)h->D >= 3.0e11);
     // beyond 128 features (exact_skip_wide.hpp): euclidean, resident rows with last epoch's BMUs, whole 64-unit groups
-    const bool wide_skip = ex.skip_mode > 0 && ex.seed_on && h->wide && h->cfg.distance == SOM_DIST_EUCLIDEAN && have_last &&
-                           h->K % EX_GROUP == 0 && (h->n_stages & 1) == 0 && (ex.skip_mode > 1 ? n_groups >= 2 : h->K >= 4096);
+    const bool wide_can = ex.skip_mode > 0 && ex.seed_on && h->wide && h->cfg.distance == SOM_DIST_EUCLIDEAN &&
+                          h->K % EX_GROUP == 0 && (h->n_stages & 1) == 0 && (ex.skip_mode > 1 ? n_groups >= 2 : h->K >= 4096);
+    // (the scout there: rows without last BMUs -- queries, streamed chunks, a first epoch -- from the same break-even on)
+    const bool wide_scout_ok = wide_can && ex.scout_on && n_groups <= 262144 && (ex.skip_mode > 1 || (double)N * (double)h->K * (double)h->D >= 3.0e11);
+    const bool wide_skip = wide_can && (have_last || wide_scout_ok);
     ex.skip_live = (can_skip && (have_last || scout_ok)) || wide_skip;
     // default mode: two launches in a row whose plans kept (nearly) every block -- rows without structure -- are followed
     // by two launches without a plan (the plan costs 4-8 % of a full scan), and so on while the plans stay idle
@@ -1654,6 +1715,7 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         }
         if (scout_on_wins) resort = true;
         scout = scout_ok && (!have_last || (resort && (fresh || ex.res_share_last >= 0.25 || scout_on_wins)));
+        if (h->wide) scout = wide_scout_ok && !have_last;    // (beyond 128 features: only where there is no last BMU)
         // level 2 of the plan (the groups' 16-unit sub-blocks) where it pays.  Whether it does is MEASURED each time it runs
         // (both levels' shares come back with the pass's counters): it costs about a tenth of level 1's share of a full scan
         // (four centroids per kept group), it saves the blocks it drops -- on the smooth maps of a schedule's first epochs
@@ -1672,7 +1734,7 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     }
     ex.scout_live = scout;
     // (the forecast from sample tiles: where the scout plans and there is no good recent plan of the same kind to go by)
-    bool estimate = ex.skip_live && scout && ex.skip_mode == 1 && (resident || ex.tr_share_last >= 0.5);
+    bool estimate = ex.skip_live && scout && !h->wide && ex.skip_mode == 1 && (resident || ex.tr_share_last >= 0.5);
     if (estimate) {
         // the cheap question first (exact_scout_rowneed_kernel): 128 sampled rows against the group centroids.  A tile needs at
         // least what its rows need: where a row alone needs more than 0.9 of the groups -- a random codebook, rows without
@@ -1726,7 +1788,8 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         const int* p_order = nullptr;
         if (ex.skip_live) {
             unsigned long long* best = h->best64 + r0;
-            if (scout)
+            if (scout && h->wide) { if (int rc = SOM_HALF(h, exact_wide_scout_nearest, h, Xb + r0 * h->dp, n, best, ex.scout_g)) return rc; }
+            else if (scout)
                 if (int rc = SOM_HALF(h, exact_scout_nearest, h, Xb + r0 * h->dp, n, best, ex.scout_g)) return rc;
             if (resort) {
                 if (time_phases) { HIPCHK(h, hipEventRecord(cost.ev[5], h->stream)); }
@@ -1802,8 +1865,11 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
         if (ex.skip_live && h->wide) {
             // beyond 128 features: the sorted float32 rows + the tile image built from them, the plan as a mode of the wide kernel
             if (resort) {
-                if (int rc = SOM_HALF(h, exact_wide_gather, h, sr, s0, X + r0 * h->D, n, xsq + r0, xerr + r0, out + r0, xmax2)) return rc;
+                // (no last BMUs: `out` holds nothing yet -- the gather's copy of it is overwritten by the scout's picks below)
+                if (int rc = SOM_HALF(h, exact_wide_gather, h, sr, s0, X + r0 * h->D, n, xsq + r0, xerr + r0, have_last ? out + r0 : ex.scout_g, xmax2)) return rc;
                 if (time_phases) { HIPCHK(h, hipEventRecord(cost.ev[6], h->stream)); sort_timed = true; }
+                if (scout)
+                    if (int rc = SOM_HALF(h, exact_wide_scout_pick, h, sr, s0, n, ex.sk_keys2, h->best64 + r0)) return rc;
             } else {
                 wide_prev_sorted_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(sr.order + s0, n, out + r0, sr.lastpos_s + s0);
             }
@@ -3240,7 +3306,7 @@ int run_query_bmu(som_handle* h, const float* X, long n_rows, int mode) {
 int run_quantization_error(som_handle* h, const float* X, long n_rows, double* qe_out) {
     if (int rc = run_quantization_bmu(h, X, n_rows, true)) return rc;
     HIPCHK(h, hipMemsetAsync(h->dsum, 0, sizeof(double), h->stream));
-    qe_kernel<<<dim3((unsigned)cdiv(n_rows, 4)), dim3(256), 0, h->stream>>>(X, h->qbmu, h->W, n_rows, h->D, h->dsum);
+    qe_kernel<<<dim3((unsigned)std::min<long>(cdiv(n_rows, 4), 4096)), dim3(256), 0, h->stream>>>(X, h->qbmu, h->W, n_rows, h->D, h->dsum);
     HIPCHK(h, hipGetLastError());
     double s = 0.0;
     if (int rc = d2h_blocking(h, &s, h->dsum, sizeof(double))) return rc;
