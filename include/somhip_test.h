@@ -25,6 +25,18 @@ int som_debug_mfma16(som_handle* h, const uint16_t* a_host, const uint16_t* b_ho
  * out_host != NULL reads n_pairs pairs back.  The product build refuses both. */
 int som_debug_stamps(som_handle* h, int64_t n_pairs, uint64_t* out_host);
 
+/* The exact mode's POLICY (csrc/exact_policy.hpp: commit a scouted plan, level 2, did a sort pay, is a plan idle, does the
+ * scout go on, is a row set worth a scout) on caller-supplied numbers -- pure host arithmetic, NO device needed: the seam the
+ * CPU suite tests the decisions through (tests/test_policy_cpu.py).
+ *   costs[9] = {full_total, full_screen, plan_total, plan_over, plan_over_scout, blk_ms, l2_ms_group, l2_ratio, sort_ms}
+ *              (ms per row; blk_ms per 16-unit block; l2_ms_group per kept (tile, group) pair; 0 = not measured yet)
+ *   which: 0 commit_scouted_plan(share, blocks_per_row)   1 level2_from_sample(share, share1, blocks_per_row)
+ *          2 level2_pays(share, share1)                   3 sort_paid(share_stale, share_fresh, blocks_per_row, epochs_served)
+ *          4 plan_idle(share)                             5 scout_continues(win_share, share_last, blocks_per_row)
+ *          6 rows_worth_a_scout(rows, units, features)
+ *   *out = 0 / 1; returns non-zero for an unknown `which` or a NULL argument. */
+int som_policy_eval(int32_t which, const double* costs, const double* args, int32_t* out);
+
 #ifdef __cplusplus
 }
 #endif

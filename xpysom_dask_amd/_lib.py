@@ -74,6 +74,7 @@ SIGNATURES = {
     "som_debug_corrupt_operands": (C.c_int, [_H, C.c_int32]),
     "som_debug_mfma16": (C.c_int, [_H, C.c_void_p, C.c_void_p, _F, _F, C.c_int32]),
     "som_debug_stamps": (C.c_int, [_H, C.c_int64, C.c_void_p]),
+    "som_policy_eval": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "som_patch_order": (C.c_int, [C.c_int32, C.c_int32, _I]),
     "som_exact_stats": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "som_exact_skip_stats": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
