@@ -60,11 +60,15 @@ enum { SOM_TOPO_RECTANGULAR = 0, SOM_TOPO_HEXAGONAL = 1 };
  *           screen's rigorous (partly measured) error bound cannot rule out; rows it cannot vouch for (NaN / infinite
  *           values, a pass with more candidate pairs than re-scoring is worth) go to the F32 kernel.  Euclidean distance
  *           with input_len <= 128; euclidean and cosine with 128 < input_len <= 800 on maps of >= 4096 units; other
- *           configurations run the F32 kernels under this id (which are the exact mode by definition).  Resident rows,
- *           from their second epoch on (input_len <= 128, maps of >= 4096 units): the screen skips the (256-row tile,
- *           group) blocks a centroid-and-radius bound around last epoch's BMU proves empty (csrc/exact_skip.hpp;
- *           SOM_EXACT_SKIP=0 runs every block) -- the ids do not change, the time does, by the data.  Everything but
- *           the BMU search (update, merge, quantization) is as in F32. */
+ *           configurations run the F32 kernels under this id (which are the exact mode by definition).  On maps of >= 4096
+ *           units the screen SKIPS the (256-row tile, block of units) pairs a centroid-and-radius bound proves empty
+ *           (csrc/exact_skip.hpp, exact_skip_wide.hpp; SOM_EXACT_SKIP=0 runs every block): around last epoch's BMU for
+ *           resident rows from their second epoch on (input_len <= 128; euclidean beyond), around a pseudo last BMU found
+ *           from the current codebook's own group centroids for every other large row set -- query rows (som_bmu,
+ *           som_bmu_device, som_quantization_error*), streamed chunks, a row set's first epoch.  A forecast on sample tiles
+ *           declines plans with nothing to skip; the plan's own decisions come from timed costs of the handle's launches.
+ *           The ids do not change, the time does, by the data.  Everything but the BMU search (update, merge,
+ *           quantization) is as in F32. */
 enum { SOM_PREC_F32 = 0, SOM_PREC_BF16 = 1,
        SOM_PREC_RETIRED_2 = 2,  /* was BF16X3 (hi/lo-split operands, three MFMAs per product): som_create refuses it --
                                    EXACT returns float32's own BMUs at three to ten times its speed; the id stays reserved */
@@ -262,7 +266,9 @@ int som_exact_scout_stats(som_handle* h, int64_t* scouted_launches, int64_t* tra
  * half-precision halves, a window some twenty times narrower than the screen's): candidate (row, group) pairs it was
  * given, and how many of them it left for the re-score */
 int som_exact_refine_stats(som_handle* h, int64_t* pairs_in, int64_t* pairs_out);
-/* candidate groups per row of the LAST screen pass (its first n rows): how many 64-unit groups the re-score visited */
+/* candidate groups per row of the LAST screen pass (its first n rows): how many 64-unit groups the select kernel found for the
+ * row.  Under a plan (a sorted pass) entry i belongs to SORTED POSITION i of the pass, not to row i, and the counts are taken
+ * BEFORE the refinement pass compacts the lists (som_exact_refine_stats has the totals on both sides of it). */
 int som_exact_last_counts(som_handle* h, int32_t* counts_out, int64_t n);
 
 /* stream / timing plumbing */

@@ -1,4 +1,5 @@
-// precision 'exact', resident rows from their second epoch on, euclidean, input_len <= 128: BLOCK SKIPPING in the screen.
+// precision 'exact', euclidean, input_len <= 128, maps of >= 4096 units: BLOCK SKIPPING in the screen -- resident rows from their
+// second epoch on (bound: last epoch's BMU) and, through the SCOUT at the end of this file, every other large row set.
 //
 // The screen (bmu_bf16_k16_kernel<.., GM>) is the exact epoch; what is left is not to run it where no BMU can be.  Two facts:
 //   * last epoch's BMU u of a row x gives an upper bound on the distance to this epoch's BMU k*: the float32 kernel picks
@@ -13,9 +14,10 @@
 // one epoch to the next, and a 256-row tile of neighbours shares its blocks either way), so the 256 rows of a workgroup
 // tile lie in one region of the map.
 // BLOCKS come at two levels: the 64-unit GROUPS of the screen (one stage of its image = an 8 x 8 patch of the map) and
-// their four 16-unit SUB-BLOCKS (the stage's four MFMA tiles = 2 x 8 strips of the patch).  Late in a schedule the units
-// of a patch spread out (its radius grows to the scale of the data) and the group bound alone keeps a quarter of all
-// blocks; the sub-blocks' own centroids and radii cut that to a third.  The PLAN kernel below is the screen's MFMA loop
+// their four 16-unit SUB-BLOCKS (the stage's four MFMA tiles = 4 x 4 squares of the patch where both map sides are multiples
+// of 8 -- som_patch_order --, 2 x 8 strips elsewhere).  Late in a schedule the units of a patch spread out (its radius grows
+// to the scale of the data) and the group bound alone keeps a quarter of all blocks; the sub-blocks' own centroids and radii
+// cut that to a third.  The PLAN kernel below is the screen's MFMA loop
 // on centroids with the test as its epilogue and an OR over the tile's rows: level 1 over the group centroids (1/64 of
 // the units), level 2 over the sub-block centroids of the groups level 1 kept.  The screen then walks, per tile, the list
 // of (group, 4-bit sub-block mask) items some row of it needs.
