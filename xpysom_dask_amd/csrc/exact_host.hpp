@@ -627,7 +627,7 @@ int exact_rescore_kg(som_handle* h, const float* X, int n_groups) {
     int per_cu = 1;
     if (int rc = kernel_per_cu(h, (const void*)kern, 256, lds, &per_cu)) return rc;
     // (twice the resident slots: the runs of tiles are uneven -- partial tiles, idle waves -- and finer runs balance them)
-    const long grid = std::min<long>(ex.max_tiles, 2L * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
+    const long grid = std::min<long>(ex.max_tiles, (long)h->ex.grid_mult * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
     kern<<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, h->D, h->Wfst, h->K, ex.tile_tab, ex.ctr + 2 * n_groups + 1, ex.plist,
                                                              h->best64, h->ex_perm, nullptr, h->ex_sub44 ? 1 : 0);
     return 0;
@@ -647,7 +647,7 @@ int exact_refine_ks(som_handle* h, som_handle::ExactScratch::SortedRows& sr, lon
     const size_t lds = (size_t)k16_stage_bytes(KS32) + (size_t)K16_T * KS32 * 1024;
     int per_cu = 1;
     if (int rc = kernel_per_cu(h, (const void*)exact_refine_kernel<KS32, E>, 256, lds, &per_cu)) return rc;
-    const long grid = std::min<long>(ex.max_tiles, 2L * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
+    const long grid = std::min<long>(ex.max_tiles, (long)h->ex.grid_mult * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
     exact_refine_kernel<KS32, E><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(
         sr.Xb_s + r0 * h->dp, sr.Xl_s + r0 * h->dp, h->Wst, h->Wst_lo, ex.tile_tab, n_tiles, ex.plist, ex.gmin, rowmin2);
     exact_select2_kernel<<<dim3((unsigned)n_groups), dim3(256), 0, h->stream>>>(
@@ -688,7 +688,7 @@ int exact_rescore_round(som_handle* h, const float* X, const float* xsq, unsigne
                                   : (const void*)exact_rescore_tiled_kernel<SCORE_EUCLID_PART>;
         int per_cu = 1;
         if (int rc2 = kernel_per_cu(h, kern, 256, 0, &per_cu)) { h->best64 = saved; return rc2; }
-        const long grid = std::min<long>(ex.max_tiles, 2L * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
+        const long grid = std::min<long>(ex.max_tiles, (long)h->ex.grid_mult * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
         if (cosine)
             exact_rescore_tiled_kernel<SCORE_COSINE><<<dim3((unsigned)grid), dim3(256), 0, h->stream>>>(
                 X, h->D, xsq, h->Wfimg, h->ft_kchunks, h->K, ex.tile_tab, n_tiles, ex.plist, best64, h->ex_perm, nullptr, h->ex_sub44 ? 1 : 0);

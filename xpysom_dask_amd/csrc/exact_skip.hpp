@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void exact_centroid_image_kernel(CentroidLevel
 //     the sub-blocks of four consecutive groups); only the tiles whose groups level 1 kept (need1) are loaded and run.
 // eb / scales: the centroid image's (cmax2 = {max |c|^2, max rounding error^2}); wmax2 / werr2: the codebook's.
 template <int KS32, class EL, bool LEVEL2>
-__global__ __launch_bounds__(64 * K16_NW, 2) void exact_plan_kernel(const __bf16* __restrict__ Xb, long N,
+__global__ __launch_bounds__(64 * K16_NW, LEVEL2 ? 3 : 2) void exact_plan_kernel(const __bf16* __restrict__ Xb, long N,
                                                                     const char* __restrict__ Cst, int n_cstages,
                                                                     const float* __restrict__ rg, int n_slots,
                                                                     const float* __restrict__ xsq, const float* __restrict__ xerr,

@@ -147,6 +147,7 @@ struct som_handle {
         double pairs_per_row_last = 0.0;  // candidate (row, group) pairs per row of the last planned epoch
         int64_t pairs_refined_in = 0, pairs_refined_out = 0;   // som_exact_refine_stats
         // the SCOUT (exact_skip.hpp): pseudo last BMUs for rows that have none, or whose last BMUs say little
+        int grid_mult = 2;                // persistent re-score / refinement kernels: workgroups per resident slot (SOM_EXACT_GRID_MULT: A/B)
         bool scout_on = true;             // SOM_EXACT_SCOUT=0: plans only from last epoch's BMUs (A/B)
         bool scout_live = false;          // this launch runs the scout
         int* scout_g = nullptr;           // [stride] nearest group centroid of every row of the pass
@@ -1464,6 +1465,7 @@ int som_create(const som_config* cfg, som_handle** out) {
         if (const char* e = dev_env("SOM_EXACT_SUBBLOCKS")) h->ex.sub_blocks = std::atoi(e) != 0;
         if (const char* e = dev_env("SOM_EXACT_REFINE")) h->ex.refine_on = std::atoi(e) != 0;
         if (const char* e = dev_env("SOM_EXACT_SCOUT")) h->ex.scout_on = std::atoi(e) != 0;
+        if (const char* e = dev_env("SOM_EXACT_GRID_MULT")) h->ex.grid_mult = std::max(1, std::atoi(e));
         if (const char* e = dev_env("SOM_EXACT_RESORT")) h->ex.res_every = std::max(0, std::atoi(e));
         if (const char* e = dev_env("SOM_ASYNC_COPIES")) h->async_copies = std::atoi(e) != 0;
         if (const char* e = dev_env("SOM_FUSE_MERGE")) h->fuse_merge_prep = std::atoi(e) != 0;
