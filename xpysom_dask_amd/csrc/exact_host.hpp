@@ -819,7 +819,7 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
     }
     ex.scout_live = scout;
     // (the forecast from sample tiles: where the scout plans and there is no good recent plan of the same kind to go by)
-    bool estimate = ex.skip_live && scout && !h->wide && ex.skip_mode == 1 && (resident || ex.tr_share_last >= 0.5);
+    bool estimate = ex.skip_live && scout && ex.skip_mode == 1 && (resident || ex.tr_share_last >= 0.5);
     if (estimate) {
         // the cheap question first (exact_scout_rowneed_kernel): 128 sampled rows against the group centroids.  A tile needs at
         // least what its rows need: where a row alone needs more than 0.9 of the groups -- a random codebook, rows without
@@ -840,6 +840,7 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
             ex.skip_live = false; scout = false; resort = false; ex.scout_live = false; estimate = false; ex.scout_declined += 1;
         }
     }
+    if (h->wide) estimate = false;                       // (beyond 128 features: the row sample only, no sample tiles)
     if (estimate && exact_skip_reserve(h, ex.srt[1], 128 * SK_TILE, ex.stride) != 0) { (void)hipGetLastError(); h->err.clear(); estimate = false; }
     ex.share_forecast = resident ? ex.res_share_last : ex.tr_share_last;
     // the refinement pass (bmu_exact.hpp) where it pays: it costs about a third of the float32 re-score of the pairs it is
