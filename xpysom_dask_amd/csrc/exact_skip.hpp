@@ -200,6 +200,16 @@ __device__ __forceinline__ float up_to_half(float v) {
     return f;
 }
 
+// OR of a value over the sixteen lanes of its DPP row (a quad of the MFMA layout: lanes 16 q .. 16 q + 15), in every lane of the
+// row: four rotations inside the row, no LDS, no scalar unit
+__device__ __forceinline__ uint32_t row16_or(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xF, 0xF, false);   // row_ror:1
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xF, 0xF, false);   // row_ror:2
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false);   // row_ror:4
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);   // row_ror:8
+    return v;
+}
+
 // The test of the plan, arranged so that the MFMA evaluates all of it but one comparison per (row, centroid):
 //   skip  <=>  d'_c > A(row) + hS (sU(row) + r_c)^2  =  [A + hS sU^2] + hS r_c^2 + 2 hS sU r_c
 //         <=>  (d'_c - hS r_c^2) - (sx sU (1 + 2^-10)) (sw r_c)  >  P(row) := A + hS sU^2,        2 hS = S (1 + 2^-10), S = sx sw.
@@ -468,6 +478,7 @@ __global__ __launch_bounds__(64 * K16_NW, LEVEL2 ? 3 : 2) void exact_plan_kernel
                 wv = *(const f32x4*)(wq + j * 16 + 4 * quad);
                 rneg = wq[64 + j * 16 + col];
             };
+            uint32_t lane_bits = 0u;                           // bit 4 j + r: tile j of the chunk, accumulator register r
             auto run_tile = [&](int j, const bf16x8 (&a)[KS32], const f32x4& wv, float rneg) {
                 bf16x8 ae;
 #pragma unroll
@@ -482,24 +493,15 @@ __global__ __launch_bounds__(64 * K16_NW, LEVEL2 ? 3 : 2) void exact_plan_kernel
                     for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = mfma16(a[ks], xf[sb][ks], acc[sb]);
 #pragma unroll
                 for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = mfma16(ae, xe[sb], acc[sb]);
-                uint32_t nib[4] = {0u, 0u, 0u, 0u};            // nib[qd]: the sub-blocks of the tile's qd-th group some row needs
+                // (lane (quad, col): bit r <-> its row needs sub-block r of the tile's quad-th group; gathered over the rows
+                //  once per chunk, below -- a ballot and four scalar tests per accumulator register kept the scalar unit busier
+                //  than the matrix pipe)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     bool nd = false;
 #pragma unroll
                     for (int sb = 0; sb < K16_SB; ++sb) nd = nd || !(acc[sb][r] > P[sb]);
-                    const unsigned long long b = __ballot(nd);
-#pragma unroll
-                    for (int qd = 0; qd < 4; ++qd)
-                        if ((b >> (16 * qd)) & 0xFFFFull) nib[qd] |= 1u << r;
-                }
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const int gi = c0 + 4 * j + qd;
-                    if (nib[qd] != 0u && gi < e0) {           // (wave-uniform)
-                        const int g = __builtin_amdgcn_readfirstlane(act[gi]);
-                        if (lane == 0) atomicOr(nl + (g >> 4), (unsigned long long)nib[qd] << (4 * (g & 15)));
-                    }
+                    lane_bits |= nd ? (1u << (4 * j + r)) : 0u;
                 }
             };
             bf16x8 aA[KS32], aB[KS32];
@@ -516,6 +518,20 @@ __global__ __launch_bounds__(64 * K16_NW, LEVEL2 ? 3 : 2) void exact_plan_kernel
                     if (h3) load_tile(3, aB, wvB, rnB);
                     run_tile(2, aA, wvA, rnA);
                     if (h3) run_tile(3, aB, wvB, rnB);
+                }
+            }
+            // the chunk's sixteen groups: OR over the sixteen rows of every quad (lanes of one DPP row), then the quad's first lane
+            // files tile j's nibble under the tile's quad-th group
+            const uint32_t any_row = row16_or(lane_bits);
+            if (col == 0 && any_row != 0u) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t nib = (any_row >> (4 * j)) & 15u;
+                    const int gi = c0 + 4 * j + quad;
+                    if (nib != 0u && gi < e0) {
+                        const int g = act[gi];
+                        atomicOr(nl + (g >> 4), (unsigned long long)nib << (4 * (g & 15)));
+                    }
                 }
             }
             if (c0 + 16 < e0) store_tail(sn, tail_n);
@@ -555,7 +571,7 @@ __global__ __launch_bounds__(64 * K16_NW, LEVEL2 ? 3 : 2) void exact_plan_kernel
         }
         const char* st = smem + ((i - s_begin) & 1) * STAGE;
         const float* wq = (const float*)(st + K16_T * KS32 * 1024);
-        unsigned long long mine = 0ull;                       // bit (16 t16 + 4 quad + r) <-> centroid slot of that place in the stage
+        uint32_t lane_bits = 0u;                              // (the word's bit 16 t16 + 4 quad + r <-> centroid slot of that place in the stage)
         // a tile's operands: its KS32 fragments, its initial accumulators, the centroids' side of the extra step (slot 0 =
         // -up_to_half(sw r)); the NEXT tile's are read under this tile's MFMAs and epilogue
         auto load_tile = [&](int t, bf16x8 (&a)[KS32], f32x4& wv, float& rneg) {
@@ -579,16 +595,13 @@ __global__ __launch_bounds__(64 * K16_NW, LEVEL2 ? 3 : 2) void exact_plan_kernel
                 for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = mfma16(a[ks], xf[sb][ks], acc[sb]);
 #pragma unroll
             for (int sb = 0; sb < K16_SB; ++sb) acc[sb] = mfma16(ae, xe[sb], acc[sb]);
+            // lane (quad, col): bit 4 t16 + r <-> its row needs centroid 4 quad + r of tile t16 (gathered over the rows once per stage)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 bool nd = false;
 #pragma unroll
                 for (int sb = 0; sb < K16_SB; ++sb) nd = nd || !(acc[sb][r] > P[sb]);
-                const unsigned long long b = __ballot(nd);
-                // lanes of quad qd vote for centroid 4 qd + r of the tile
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd)
-                    if ((b >> (16 * qd)) & 0xFFFFull) mine |= 1ull << (t16 * 16 + 4 * qd + r);
+                lane_bits |= nd ? (1u << (4 * t16 + r)) : 0u;
             }
         };
         // up to four tiles, their operands alternating between two register sets (no copies): the next tile's are read
@@ -610,7 +623,13 @@ __global__ __launch_bounds__(64 * K16_NW, LEVEL2 ? 3 : 2) void exact_plan_kernel
                 if (t3 >= 0) run_tile(t3, aB, wvB, rnB);
             }
         }
-        if (lane == 0 && mine != 0ull) atomicOr(nl + (i - s_begin), mine);
+        // OR over the sixteen rows of every quad; the quad's first lane spreads its four nibbles (one per tile) to their places
+        const uint32_t any_row = row16_or(lane_bits);
+        if (col == 0 && any_row != 0u) {
+            const uint32_t lo = ((any_row & 15u) | (((any_row >> 4) & 15u) << 16)) << (4 * quad);
+            const uint32_t hi = (((any_row >> 8) & 15u) | (((any_row >> 12) & 15u) << 16)) << (4 * quad);
+            atomicOr(nl + (i - s_begin), ((unsigned long long)hi << 32) | lo);
+        }
         st_cur = st_next; tm_cur = tm_next;
     }
     __syncthreads();
