@@ -218,21 +218,19 @@ __global__ __launch_bounds__(64 * KS32) void merge_prep_k16_kernel(float* __rest
 // TL (block skipping, exact_skip.hpp): the workgroup walks its tile's dense LIST of 16-unit tiles (group << 2 | sub-block)
 // instead of all stages; only the listed tiles' fragments are staged and multiplied.  With GM: the exact mode's screen
 // under a plan.  Without: the scout's pick of a pseudo last BMU among a tile's few listed groups (unit indices kept).
-template <int KS32, class EL = Bf16, bool GM = false, bool TL = false>
-__global__ __launch_bounds__(64 * K16_NW, (TL && GM) ? 3 : 2) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
-                                                              const char* __restrict__ Wst, int n_stages, int K,
-                                                              unsigned long long* __restrict__ out64,
-                                                              uint32_t* __restrict__ gmin = nullptr, long gm_stride = 0,
-                                                              unsigned long long* __restrict__ gflags = nullptr,
-                                                              const float* __restrict__ xsq = nullptr,
-                                                              const float* __restrict__ xerr = nullptr,
-                                                              const float* __restrict__ xmax2 = nullptr,
-                                                              const float* __restrict__ wmax2 = nullptr,
-                                                              const float* __restrict__ werr2 = nullptr,
-                                                              ExactBound eb = ExactBound(),
-                                                              const float* __restrict__ seed = nullptr,
-                                                              const int* __restrict__ glist = nullptr,
-                                                              const int* __restrict__ gcnt = nullptr) {
+// (the kernel's body for one workgroup's worth of rows: tile bx of K16_WG_SAMPLES rows, part by of ny of the codebook stages -- or,
+//  TL, of the tile's list.  The kernel below calls it once, or -- the exact mode's screen under a plan -- once per work item.)
+template <int KS32, class EL, bool GM, bool TL>
+__device__ __forceinline__ void bmu_bf16_k16_body(const __bf16* __restrict__ Xb, long N,
+                                                  const char* __restrict__ Wst, int n_stages, int K,
+                                                  unsigned long long* __restrict__ out64,
+                                                  uint32_t* __restrict__ gmin, long gm_stride,
+                                                  unsigned long long* __restrict__ gflags,
+                                                  const float* __restrict__ xsq, const float* __restrict__ xerr,
+                                                  const float* __restrict__ xmax2, const float* __restrict__ wmax2,
+                                                  const float* __restrict__ werr2, const ExactBound& eb,
+                                                  const float* __restrict__ seed, const int* __restrict__ glist,
+                                                  const int* __restrict__ gcnt, const long bx, const int by, const int ny) {
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
     constexpr int DP = 32 * KS32;
@@ -244,7 +242,7 @@ __global__ __launch_bounds__(64 * K16_NW, (TL && GM) ? 3 : 2) void bmu_bf16_k16_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int quad = lane >> 4, col = lane & 15;
-    const long wave_s0 = (long)blockIdx.x * K16_WG_SAMPLES + wave * (16 * K16_SB);
+    const long wave_s0 = bx * K16_WG_SAMPLES + wave * (16 * K16_SB);
 
     bf16x8 xf[K16_SB][KS32];
 #pragma unroll
@@ -282,8 +280,8 @@ __global__ __launch_bounds__(64 * K16_NW, (TL && GM) ? 3 : 2) void bmu_bf16_k16_
     // this workgroup's share of the codebook stages: the loop index s walks [s_begin, s_end)  (TL: see the tile-list loop below)
     // (TL without GM: the scout of exact_skip.hpp -- the plain kernel, unit indices kept, over a tile's few listed groups)
     const int n_walk = n_stages;
-    const int s_begin = TL ? 0 : (int)((long)n_walk * blockIdx.y / gridDim.y);
-    const int s_end = TL ? 0 : (int)((long)n_walk * (blockIdx.y + 1) / gridDim.y);
+    const int s_begin = TL ? 0 : (int)((long)n_walk * by / ny);
+    const int s_end = TL ? 0 : (int)((long)n_walk * (by + 1) / ny);
     auto item_of = [&](int s) -> int { return s < s_end ? ((s << 4) | 15) : 15; };
     auto dma_item = [&](int it, char* dst) {
         const char* src = Wst + (long)(it >> 4) * STAGE;
@@ -349,14 +347,14 @@ __global__ __launch_bounds__(64 * K16_NW, (TL && GM) ? 3 : 2) void bmu_bf16_k16_
         // chunk ahead, written into the slot's tail before the next barrier).  A group's minimum is folded when its last
         // tile is in (its tiles are consecutive in the list, across chunks too).  The parts of a tile's list are cut at
         // group boundaries: one part stores a group's minima.
-        const int* tl = glist + (long)blockIdx.x * (4 * n_stages);
-        const int n_t = gcnt[blockIdx.x];
+        const int* tl = glist + bx * (4 * n_stages);
+        const int n_t = gcnt[bx];
         auto bound = [&](int y) -> int {
-            int b = (int)((long)n_t * y / gridDim.y);
+            int b = (int)((long)n_t * y / ny);
             while (b > 0 && b < n_t && (tl[b] >> 2) == (tl[b - 1] >> 2)) ++b;
             return __builtin_amdgcn_readfirstlane(b);
         };
-        const int b0 = bound(blockIdx.y), e0 = bound(blockIdx.y + 1);
+        const int b0 = bound(by), e0 = bound(by + 1);
         auto ent = [&](int i) -> int { return i < e0 ? __builtin_amdgcn_readfirstlane(tl[i]) : -1; };
         constexpr int TQ = K16_T * KS32 * 1024;              // the slot's tail: [tile j][16] initial accumulators
         auto dma_chunk = [&](const int (&en)[4], char* dst) {
@@ -502,6 +500,47 @@ __global__ __launch_bounds__(64 * K16_NW, (TL && GM) ? 3 : 2) void bmu_bf16_k16_
         const long row = wave_s0 + sb * 16 + col;
         if (quad == 0 && row < N) atomicMin(out64 + row, comp);
     }
+}
+
+// items (TL; nullptr: the grid is (tiles, parts)): the screen under a plan as a WORK QUEUE.  The tiles' lists are uneven -- mid-schedule
+// the median tile lists ~100 blocks, a few list 700 -- and a grid of one workgroup per tile ended in a tail of a few long walks
+// that held a fifth to two fifths of the launch (tools/wg_timeline.py).  exact_items_kernel cuts every list into parts of about
+// equal length (item = (tile, part | parts << 16)); a workgroup per slot of the chip takes items off one counter until none is left
+// (every workgroup reaches `it >= *n_items`: the grid drains).  A part re-reads its tile's rows: only the long lists are cut.
+template <int KS32, class EL = Bf16, bool GM = false, bool TL = false>
+__global__ __launch_bounds__(64 * K16_NW, (TL && GM) ? 3 : 2) void bmu_bf16_k16_kernel(const __bf16* __restrict__ Xb, long N,
+                                                              const char* __restrict__ Wst, int n_stages, int K,
+                                                              unsigned long long* __restrict__ out64,
+                                                              uint32_t* __restrict__ gmin = nullptr, long gm_stride = 0,
+                                                              unsigned long long* __restrict__ gflags = nullptr,
+                                                              const float* __restrict__ xsq = nullptr,
+                                                              const float* __restrict__ xerr = nullptr,
+                                                              const float* __restrict__ xmax2 = nullptr,
+                                                              const float* __restrict__ wmax2 = nullptr,
+                                                              const float* __restrict__ werr2 = nullptr,
+                                                              ExactBound eb = ExactBound(),
+                                                              const float* __restrict__ seed = nullptr,
+                                                              const int* __restrict__ glist = nullptr,
+                                                              const int* __restrict__ gcnt = nullptr,
+                                                              const int2* __restrict__ items = nullptr,
+                                                              const int* __restrict__ n_items = nullptr,
+                                                              int* __restrict__ item_ctr = nullptr) {
+    if (TL && items != nullptr) {
+        __shared__ int s_item;
+        const int n = *n_items;
+        for (;;) {
+            if (threadIdx.x == 0) s_item = atomicAdd(item_ctr, 1);
+            __syncthreads();                                 // (everyone is done with the previous item's LDS ring too)
+            const int it = s_item;
+            __syncthreads();
+            if (it >= n) return;
+            const int2 iv = items[it];
+            bmu_bf16_k16_body<KS32, EL, GM, TL>(Xb, N, Wst, n_stages, K, out64, gmin, gm_stride, gflags, xsq, xerr, xmax2, wmax2, werr2, eb,
+                                                seed, glist, gcnt, (long)iv.x, iv.y & 0xFFFF, iv.y >> 16);
+        }
+    }
+    bmu_bf16_k16_body<KS32, EL, GM, TL>(Xb, N, Wst, n_stages, K, out64, gmin, gm_stride, gflags, xsq, xerr, xmax2, wmax2, werr2, eb, seed,
+                                        glist, gcnt, (long)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
 }
 
 // out64 -> raveled ids (a padding unit can only win on a NaN row: numpy's argmin gives 0 there)

@@ -691,20 +691,54 @@ __global__ __launch_bounds__(64) void exact_lists_kernel(const unsigned long lon
 }
 
 // sum of the tiles' (16-unit blocks listed, groups level 1 kept) into the pass's counters.  One workgroup.
+// items != nullptr: ... and the listed screen's WORK ITEMS (bmu_bf16_k16_kernel<.., GM, TL>): every tile's list cut into parts of
+// about L blocks -- L = 1.25 x the mean list, or what gives every slot of the chip two items where the tiles are few; never below
+// 32 blocks (a part re-reads its tile's 64 KB of rows) --, item = (tile, part | parts << 16) in tile order; the queue's counter reset.
+// At most 2 tiles + 3 slots items (the three cases of L).
 __global__ __launch_bounds__(1024) void exact_list_totals_kernel(const int2* __restrict__ tile_counts, long tiles, int* __restrict__ blocks_run,
-                                                                 int* __restrict__ groups_run) {
+                                                                 int* __restrict__ groups_run, int slots = 0, int2* __restrict__ items = nullptr,
+                                                                 int* __restrict__ n_items = nullptr, int* __restrict__ item_ctr = nullptr,
+                                                                 int len_pct = 125) {
     __shared__ int sb[16], sk[16];
+    __shared__ int tot_b;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int b = 0, k = 0;
-    for (long t = threadIdx.x; t < tiles; t += 1024) { const int2 c = tile_counts[t]; b += c.x; k += c.y; }
+    for (long t = tid; t < tiles; t += 1024) { const int2 c = tile_counts[t]; b += c.x; k += c.y; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { b += __shfl_xor(b, o, 64); k += __shfl_xor(k, o, 64); }
-    if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = b; sk[threadIdx.x >> 6] = k; }
+    if (lane == 0) { sb[wave] = b; sk[wave] = k; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         b = 0; k = 0;
         for (int w = 0; w < 16; ++w) { b += sb[w]; k += sk[w]; }
         *blocks_run = b; *groups_run = k;
+        tot_b = b;
     }
+    if (items == nullptr) return;
+    __syncthreads();
+    const long total = tot_b;
+    const long by_mean = (len_pct * total) / (100 * (tiles > 0 ? tiles : 1)) + 1, by_slots = total / (2 * (long)(slots > 0 ? slots : 1));
+    const int L = (int)max(32L, min(by_mean, by_slots));
+    auto parts_of = [&](int cnt) -> int { return cnt <= L ? 1 : (cnt + L - 1) / L; };
+    // a contiguous run of tiles per thread; exclusive scan of the runs' item counts over the 1 024 threads
+    const long per = (tiles + 1023) / 1024, t_b = min((long)tid * per, tiles), t_e = min(t_b + per, tiles);
+    int mine = 0;
+    for (long t = t_b; t < t_e; ++t) mine += parts_of(tile_counts[t].x);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    __syncthreads();                                         // (sb is read above by thread 0)
+    if (lane == 63) sb[wave] = incl;
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { if (w < wave) before += sb[w]; all += sb[w]; }
+    int o = before + incl - mine;
+    for (long t = t_b; t < t_e; ++t) {
+        const int np = parts_of(tile_counts[t].x);
+        for (int q = 0; q < np; ++q) items[o++] = make_int2((int)t, q | (np << 16));
+    }
+    if (tid == 0) { *n_items = all; *item_ctr = 0; }
 }
 
 // ---- the SCOUT: a bound for rows WITHOUT a last BMU (query rows, streamed chunks, a row set's first epoch) and for the

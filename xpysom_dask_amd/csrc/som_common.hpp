@@ -23,8 +23,13 @@ struct SomStamp {
     __device__ __forceinline__ void done() const {
         if (g_som_stamps != nullptr && threadIdx.x == 0) {
             const unsigned long long wg = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
+#if SOM_STAMPS == 2                                         // (tools/wg_timeline.py: when every workgroup's scan began and ended, 100 MHz)
+            g_som_stamps[2 * wg] = r0;
+            g_som_stamps[2 * wg + 1] = __builtin_amdgcn_s_memrealtime();
+#else
             g_som_stamps[2 * wg] = __builtin_amdgcn_s_memtime() - t0;
             g_som_stamps[2 * wg + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+#endif
         }
     }
 };

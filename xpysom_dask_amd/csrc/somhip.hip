@@ -183,6 +183,10 @@ struct som_handle {
         int *glist = nullptr, *gcnt = nullptr;   // per tile: (group << 4 | sub-block mask) items: what the select kernel walks
         int *tlist = nullptr, *tcnt = nullptr;   // per tile: the same blocks as a dense list of 16-unit tiles: what the screen walks
         int2* tile_counts = nullptr;
+        int2* items = nullptr;            // the listed screen's work queue: [0] = (items, counter), from [8] on (tile, part | parts << 16)
+        int item_slots = 0;               // ... sized for this many resident workgroups
+        bool item_queue = true;           // SOM_EXACT_QUEUE=0: one workgroup per tile (and part) instead (A/B)
+        int item_len_pct = 125;           // ... =<pct >= 25>: an item's length in per cent of the mean list
     } ex;
     int n_kchunks = 0;       // tiled: 64-feature chunks
     int n_ublocks = 0;       // tiled: unit blocks of tl_bn
@@ -1464,6 +1468,7 @@ int som_create(const som_config* cfg, som_handle** out) {
         if (const char* e = std::getenv("SOM_EXACT_SKIP")) h->ex.skip_mode = std::atoi(e);
         if (const char* e = dev_env("SOM_EXACT_SUBBLOCKS")) h->ex.sub_blocks = std::atoi(e) != 0;
         if (const char* e = dev_env("SOM_EXACT_REFINE")) h->ex.refine_on = std::atoi(e) != 0;
+        if (const char* e = dev_env("SOM_EXACT_QUEUE")) { h->ex.item_queue = std::atoi(e) != 0; if (std::atoi(e) >= 25) h->ex.item_len_pct = std::atoi(e); }
         if (const char* e = dev_env("SOM_EXACT_SCOUT")) h->ex.scout_on = std::atoi(e) != 0;
         if (const char* e = dev_env("SOM_EXACT_GRID_MULT")) h->ex.grid_mult = std::max(1, std::atoi(e));
         if (const char* e = dev_env("SOM_EXACT_RESORT")) h->ex.res_every = std::max(0, std::atoi(e));
