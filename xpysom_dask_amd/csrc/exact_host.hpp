@@ -376,7 +376,7 @@ template <class E>
 int exact_skip_gather(som_handle* h, som_handle::ExactScratch::SortedRows& sr, long s0, const int* order, const float* X, const __bf16* Xb, long n,
                       const float* xsq, const float* xerr, const float* xmax2) {
     const long np = round_up(n, SK_TILE);
-    exact_gather_sorted_kernel<E><<<dim3((unsigned)cdiv(np, 4)), dim3(256), 0, h->stream>>>(
+    exact_gather_sorted_kernel<E><<<dim3((unsigned)cdiv(np, 16)), dim3(256), 0, h->stream>>>(
         order, n, np, h->dp, h->D, Xb, X, xsq, xerr, xmax2, sr.Xb_s + s0 * h->dp, sr.Xl_s != nullptr ? sr.Xl_s + s0 * h->dp : nullptr, sr.Xf_s + s0 * h->D,
         sr.xsq_s + s0, sr.xerr_s + s0);
     HIPCHK(h, hipGetLastError());

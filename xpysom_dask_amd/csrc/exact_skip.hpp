@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void exact_lastpos_kernel(const int* __restric
 // The pass in sorted order: image rows (DP halves), the float32 rows themselves (what the re-score reads: a candidate
 // group's rows are then neighbours in memory), |x|^2, rounding error -- and the rows' SECOND half image for the refinement
 // pass (bmu_exact.hpp): lo = half(2^11 (x^ - hi)), x^ = sx x.  Positions behind the pass's rows (up to the tile multiple) get
-// zero rows and NaN norms (they keep nothing, need nothing).  One wave per row.
+// zero rows and NaN norms (they keep nothing, need nothing).  Sixteen lanes per row.
 template <class EL>
 __global__ __launch_bounds__(256) void exact_gather_sorted_kernel(const int* __restrict__ order, long n, long np, int dp, int D,
                                                                   const __bf16* __restrict__ Xb, const float* __restrict__ X,
@@ -146,13 +146,15 @@ __global__ __launch_bounds__(256) void exact_gather_sorted_kernel(const int* __r
                                                                   float* __restrict__ xsq_s, float* __restrict__ xerr_s) {
     using E = typename EL::T;
     using bf16x8 = typename V8<E>::t;
-    const int lane = threadIdx.x & 63;
-    const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // (sixteen lanes per row -- dp <= 128 halves = at most sixteen 16-byte pieces --, four rows per wave: a wave per row left
+    //  three quarters of its lanes idle and the kernel at a third of the fabric's rate)
+    const int lane = threadIdx.x & 15;
+    const long p = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
     if (p >= np) return;
     const long r = p < n ? (long)order[p] : -1;
     const float sx = ex_scale(*xmax2);
     const bool vec = (D & 7) == 0;
-    for (int c = lane; c < dp / 8; c += 64) {                 // 16-byte pieces of the half images = 8 features
+    for (int c = lane; c < dp / 8; c += 16) {                 // 16-byte pieces of the half images = 8 features
         bf16x8 v, vl;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { v[j] = (E)0.0f; vl[j] = (E)0.0f; }
