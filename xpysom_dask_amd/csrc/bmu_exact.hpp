@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_mfma_kernel(const float*
                                                                     const int* __restrict__ n_tiles_dev,
                                                                     const int* __restrict__ plist,
                                                                     unsigned long long* __restrict__ best64,
-        const int* __restrict__ perm, const int* __restrict__ order = nullptr, int sub44 = 0) {
+        const int* __restrict__ perm, const int* __restrict__ order = nullptr, int sub44 = 0, int deint = 0) {
     constexpr int STAGE = fr_stage_bytes(KG);
     constexpr int PIECES = FR_UT * KG + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE stage: occupancy (three workgroups per CU), not a
@@ -551,7 +551,17 @@ __global__ __launch_bounds__(256, 3) void exact_rescore_mfma_kernel(const float*
         //  sits at order[entry]; the merge key stays at the entry)
         const int xrow = (order != nullptr && row >= 0) ? order[row] : row;
         float xf[4 * KG];
-        if ((D & 3) == 0) {
+        if (deint) {
+            // (the sorted copy of exact_gather_sorted_kernel: a row's even features, then its odd ones: this lane's parity in
+            //  whole 16-byte pieces -- half the loads of the interleaved row, nothing read to be dropped)
+#pragma unroll
+            for (int c = 0; c < KG; ++c) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row >= 0 && 8 * c < D) v = *(const f32x4*)(X + (long)xrow * D + half * (D >> 1) + 4 * c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xf[4 * c + j] = v[j];
+            }
+        } else if ((D & 3) == 0) {
 #pragma unroll
             for (int c = 0; c < 2 * KG; ++c) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};

@@ -632,7 +632,7 @@ int exact_wide_plan(som_handle* h, som_handle::ExactScratch::SortedRows& sr, lon
 }
 
 template <int KG>
-int exact_rescore_kg(som_handle* h, const float* X, int n_groups) {
+int exact_rescore_kg(som_handle* h, const float* X, int n_groups, int deint) {
     auto& ex = h->ex;
     auto kern = exact_rescore_mfma_kernel<KG>;
     const size_t lds = (size_t)fr_stage_bytes(KG);
@@ -641,7 +641,7 @@ int exact_rescore_kg(som_handle* h, const float* X, int n_groups) {
     // (twice the resident slots: the runs of tiles are uneven -- partial tiles, idle waves -- and finer runs balance them)
     const long grid = std::min<long>(ex.max_tiles, (long)h->ex.grid_mult * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
     kern<<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(X, h->D, h->Wfst, h->K, ex.tile_tab, ex.ctr + 2 * n_groups + 1, ex.plist,
-                                                             h->best64, h->ex_perm, nullptr, h->ex_sub44 ? 1 : 0);
+                                                             h->best64, h->ex_perm, nullptr, h->ex_sub44 ? 1 : 0, deint);
     return 0;
 }
 
@@ -679,9 +679,12 @@ int exact_refine(som_handle* h, som_handle::ExactScratch::SortedRows& sr, long r
 }
 
 // the lists' entries from gstart on -> tiles -> float32 scores merged into best64 (the pass's slice of the merge keys)
+// (sorted_copy: X is a sorted pass's float32 copy -- up to 128 features and a multiple of 8 of them: de-interleaved rows,
+//  exact_gather_sorted_kernel)
 int exact_rescore_round(som_handle* h, const float* X, const float* xsq, unsigned long long* best64, const int* gstart,
-                        int* gstart_out) {
+                        int* gstart_out, bool sorted_copy = false) {
     auto& ex = h->ex;
+    const int deint = (sorted_copy && !h->wide && (h->D & 7) == 0) ? 1 : 0;
     const int n_groups = (int)cdiv(h->K, EX_GROUP);
     int* gcount = ex.ctr; int* fb_count = ex.ctr + 2 * n_groups;
     int* n_tiles = fb_count + 1; int* overflow = fb_count + 2;
@@ -711,11 +714,11 @@ int exact_rescore_round(som_handle* h, const float* X, const float* xsq, unsigne
         return 0;
     }
     switch (h->fr_kg) {
-    case 1: rc = exact_rescore_kg<1>(h, X, n_groups); break;
-    case 2: rc = exact_rescore_kg<2>(h, X, n_groups); break;
-    case 4: rc = exact_rescore_kg<4>(h, X, n_groups); break;
-    case 8: rc = exact_rescore_kg<8>(h, X, n_groups); break;
-    case 16: rc = exact_rescore_kg<16>(h, X, n_groups); break;
+    case 1: rc = exact_rescore_kg<1>(h, X, n_groups, deint); break;
+    case 2: rc = exact_rescore_kg<2>(h, X, n_groups, deint); break;
+    case 4: rc = exact_rescore_kg<4>(h, X, n_groups, deint); break;
+    case 8: rc = exact_rescore_kg<8>(h, X, n_groups, deint); break;
+    case 16: rc = exact_rescore_kg<16>(h, X, n_groups, deint); break;
     default: rc = fail(h, "exact: bad k-group count");
     }
     h->best64 = saved;
@@ -1010,18 +1013,18 @@ int launch_bmu_exact(som_handle* h, const float* X, long N, const float* xsq, co
             // (under a plan -- exact_skip_wide.hpp -- rows are sorted positions: p_X, p_xsq, p_xerr; the select kernel walks the lists)
             exact_first_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(
                 best, n, n_groups, ex.stride, p_xsq, h->wmax2, xmax2, eb, p_xerr, h->wmax2 + 1, ex.plist, ex.ctr, ex.rowarg);
-            if (int rc = exact_rescore_round(h, p_X, p_xsq, best, nullptr, ex.ctr + n_groups)) return rc;
+            if (int rc = exact_rescore_round(h, p_X, p_xsq, best, nullptr, ex.ctr + n_groups, ex.skip_live)) return rc;
             exact_select_kernel<true><<<sel_grid, sel_block, 0, h->stream>>>(
                 ex.gmin, ex.gflags, ex.stride, n_groups, n, best, p_xsq, h->wmax2, xmax2, eb, p_xerr, h->wmax2 + 1, ex.plist,
                 ex.ctr, ex.rowcnt, ex.rowarg, nullptr, ex.skip_live ? ex.glist : nullptr, ex.skip_live ? ex.gcnt : nullptr, SK_TILE);
-            if (int rc = exact_rescore_round(h, p_X, p_xsq, best, ex.ctr + n_groups, nullptr)) return rc;
+            if (int rc = exact_rescore_round(h, p_X, p_xsq, best, ex.ctr + n_groups, nullptr, ex.skip_live)) return rc;
         } else {
             exact_select_kernel<false><<<sel_grid, sel_block, 0, h->stream>>>(
                 ex.gmin, ex.gflags, ex.stride, n_groups, n, best, p_xsq, h->wmax2, xmax2, eb, p_xerr, h->wmax2 + 1, ex.plist,
                 ex.ctr, ex.rowcnt, nullptr, p_seed, ex.skip_live ? ex.glist : nullptr, ex.skip_live ? ex.gcnt : nullptr, SK_TILE);
             if (ex.refine_live)
                 if (int rc = SOM_HALF(h, exact_refine, h, sr, s0, n, xmax2, eb)) return rc;
-            if (int rc = exact_rescore_round(h, p_X, xsq + r0, best, nullptr, nullptr)) return rc;
+            if (int rc = exact_rescore_round(h, p_X, xsq + r0, best, nullptr, nullptr, ex.skip_live)) return rc;
         }
         exact_finalize_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(
             best, n, h->K, ex.ctr + 2 * n_groups + 2, out + r0, ex.fb_list, ex.ctr + 2 * n_groups, p_order);

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void exact_lastpos_kernel(const int* __restric
 }
 
 // The pass in sorted order: image rows (DP halves), the float32 rows themselves (what the re-score reads: a candidate
-// group's rows are then neighbours in memory), |x|^2, rounding error -- and the rows' SECOND half image for the refinement
+// group's rows are then neighbours in memory; input_len a multiple of 8: even features first, then the odd ones), |x|^2, rounding error -- and the rows' SECOND half image for the refinement
 // pass (bmu_exact.hpp): lo = half(2^11 (x^ - hi)), x^ = sx x.  Positions behind the pass's rows (up to the tile multiple) get
 // zero rows and NaN norms (they keep nothing, need nothing).  Sixteen lanes per row.
 template <class EL>
@@ -162,9 +162,12 @@ __global__ __launch_bounds__(256) void exact_gather_sorted_kernel(const int* __r
             v = *(const bf16x8*)((const char*)Xb + (r * dp + c * 8) * 2);
             float f[8];
             if (vec && c * 8 < D) {                           // (one read of the float32 row: its copy and its second half)
+                // (the float32 copy DE-INTERLEAVED: the row's even features, then its odd ones -- a lane of the re-score's 32x32x2 MFMA
+                //  feeds one parity of the features, and reads its half of the row in whole 16-byte pieces: exact_rescore_mfma_kernel)
                 const f32x4 a = *(const f32x4*)(X + r * D + c * 8), b = *(const f32x4*)(X + r * D + c * 8 + 4);
-                *(f32x4*)(Xf_s + p * D + c * 8) = a;
-                *(f32x4*)(Xf_s + p * D + c * 8 + 4) = b;
+                const f32x4 ev = {a[0], a[2], b[0], b[2]}, od = {a[1], a[3], b[1], b[3]};
+                *(f32x4*)(Xf_s + p * D + c * 4) = ev;
+                *(f32x4*)(Xf_s + p * D + D / 2 + c * 4) = od;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[4 + j] = b[j]; }
             } else {
