@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """When does every workgroup of the exact mode's LISTED screen run its scan?  A diagnostic build (-DSOM_STAMPS=2: the first wave
-of every workgroup leaves s_memrealtime at the start and at the end of the kernel's list walk) over the benchmark's schedule;
+of every workgroup leaves s_memrealtime at the start and at the end of the kernel's list walk) over the benchmark's schedule, one workgroup per tile (SOM_EXACT_QUEUE=0: the grid the work queue replaced);
 after the chosen epochs: the walks' durations (how uneven are the tiles' lists) and the launch's occupancy over time (how much of
 the launch is a tail of few long walks).
     python tools/wg_timeline.py          # on the GPU box; WT_EPOCHS=6,12,20"""
@@ -55,5 +55,6 @@ if __name__ == "__main__":
         lib = os.path.join(REPO, "xpysom_dask_amd", "libsomhip_timeline.so")
         if B.built_hash(lib) != B.source_hash():           # (an in-tree build of these sources travels with the snapshot)
             B.build(force=True, verbose=False, extra=["-DSOM_STAMPS=2"], out=lib)
-        env = dict(os.environ, SOM_LIB_PATH=lib)
+        # (one workgroup per tile: under the work queue a workgroup walks many items and only its last one would be stamped)
+        env = dict(os.environ, SOM_LIB_PATH=lib, SOM_TEST_HOOKS="1", SOM_EXACT_QUEUE="0")
         sys.exit(subprocess.call([sys.executable, os.path.abspath(__file__), "--child"], env=env))
