@@ -765,6 +765,30 @@ def test_exact_sub_block_plan_drops_blocks_and_keeps_the_ids(monkeypatch):
     assert np.array_equal(a[1], c[1]) and a[2][1] == c[2][1]
 
 
+def test_exact_listed_screen_work_queue_equals_one_workgroup_per_tile(monkeypatch):
+    """The listed screen as a work queue (the tiles' lists cut into items of about equal length, parts ending at group boundaries,
+    a workgroup per slot taking items off one counter) against the grid of one workgroup per tile (SOM_EXACT_QUEUE=0), and with
+    items a quarter of the mean list (=25: every tile in several parts): the same ids in every epoch, the same codebook, the same
+    blocks run."""
+    X, Y, D, n, T = 96, 64, 64, 40000, 8
+    data = O.gaussian_blobs(n, D, seed=9)
+    w = O.default_codebook(X, Y, D, 3).astype(F32)
+    monkeypatch.delenv("SOM_EXACT_QUEUE", raising=False)
+    runs = {}
+    for tag, q in (("queue", None), ("grid", "0"), ("short", "25"), ("long", "400")):
+        env = {"SOM_EXACT_SKIP": "2"}
+        if q is not None:
+            env["SOM_EXACT_QUEUE"] = q
+        runs[tag] = _train_states(monkeypatch, env, X, Y, D, n, T, data, w)
+        monkeypatch.delenv("SOM_EXACT_QUEUE", raising=False)
+    for tag in ("grid", "short", "long"):
+        for t in range(T):
+            assert np.array_equal(runs["queue"][0][t], runs[tag][0][t]), (tag, t)
+        assert np.array_equal(runs["queue"][1], runs[tag][1]), tag
+        assert runs["queue"][2] == runs[tag][2], (tag, runs["queue"][2], runs[tag][2])
+    assert runs["queue"][2][0] < 0.5 * runs["queue"][2][1]          # (blocks were skipped: the lists are lists)
+
+
 def test_exact_new_rows_of_the_same_size_drop_the_resident_order():
     """som_set_data with another row set of the same shape (the allocator may hand back the same address): the sorted copies
     of the old rows must not survive."""

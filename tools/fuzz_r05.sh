@@ -19,6 +19,8 @@ SOM_EXACT_SKIP=2 SOM_EXACT_PASS_ROWS=1024 run "fuzz_exact SOM_EXACT_SKIP=2 SOM_E
 SOM_EXACT_SKIP=2 FUZZ_MAXSIDE=260 run "fuzz_exact SOM_EXACT_SKIP=2 FUZZ_MAXSIDE=260 seed 249 ($N cases)" python tests/fuzz/fuzz_exact.py 249 $N
 SOM_EXACT_SKIP=2 SOM_VERIFY=64 run "fuzz_exact SOM_EXACT_SKIP=2 SOM_VERIFY=64 seed 250 ($N cases, canary on)" python tests/fuzz/fuzz_exact.py 250 $N
 run "fuzz_exact default switches seed 251 ($N cases)" python tests/fuzz/fuzz_exact.py 251 $N
+SOM_EXACT_SKIP=2 SOM_EXACT_QUEUE=0 run "fuzz_exact SOM_EXACT_SKIP=2 SOM_EXACT_QUEUE=0 seed 255 ($N cases: the listed screen as one workgroup per tile)" python tests/fuzz/fuzz_exact.py 255 $N
+SOM_EXACT_SKIP=2 SOM_EXACT_QUEUE=25 FUZZ_MAXSIDE=260 run "fuzz_exact SOM_EXACT_SKIP=2 SOM_EXACT_QUEUE=25 FUZZ_MAXSIDE=260 seed 256 ($N cases: work items a quarter of the mean list)" python tests/fuzz/fuzz_exact.py 256 $N
 SOM_EXACT_SKIP=2 FUZZ_WIDE=1 run "fuzz_exact SOM_EXACT_SKIP=2 FUZZ_WIDE=1 seed 252 (120 cases, wide screen under a plan)" python tests/fuzz/fuzz_exact.py 252 120
 SOM_EXACT_SKIP=2 FUZZ_WIDE=1 SOM_EXACT_PASS_ROWS=1024 SOM_EXACT_RESORT=1000 run "fuzz_exact SOM_EXACT_SKIP=2 FUZZ_WIDE=1 SOM_EXACT_PASS_ROWS=1024 SOM_EXACT_RESORT=1000 seed 253 (120 cases)" python tests/fuzz/fuzz_exact.py 253 120
 FUZZ_WIDE=1 SOM_VERIFY=64 run "fuzz_exact FUZZ_WIDE=1 SOM_VERIFY=64 seed 254 (120 cases, default switches, canary on)" python tests/fuzz/fuzz_exact.py 254 120
