@@ -126,12 +126,14 @@ int exact_screen(som_handle* h, const __bf16* Xb, long n, unsigned long long* be
         std::fprintf(stderr, "[somhip] exact screen: blocks=%ld per_cu=%d slots=%ld parts=%d groups=%d lists=%d\n", blocks, per_cu,
                      slots, parts, n_groups, tl ? 1 : 0);
     const dim3 grid((unsigned)blocks, (unsigned)parts), block(64 * K16_NW);
-    if (tl && h->ex.item_queue && glist == h->ex.tlist)
-        // (the plan's lists as a work queue: a workgroup per slot of the chip, items of about equal length -- bmu_bf16_k16.hpp)
-        bmu_bf16_k16_kernel<KS32, E, true, true><<<dim3((unsigned)std::min<long>(slots, h->ex.item_slots)), block, lds, h->stream>>>(
+    if (tl && h->ex.item_queue && glist == h->ex.tlist) {
+        // (the plan's lists as a work queue: a workgroup per slot of the chip, items of about equal length -- bmu_bf16_k16.hpp;
+        //  the next plan cuts its lists for this many workgroups)
+        h->ex.screen_slots = (int)std::min<long>(slots, h->ex.item_slots);
+        bmu_bf16_k16_kernel<KS32, E, true, true><<<dim3((unsigned)h->ex.screen_slots), block, lds, h->stream>>>(
             Xb, n, h->Wst, h->n_stages, h->K, best64, h->ex.gmin, h->ex.stride, h->ex.gflags, xsq, xerr, xmax2, h->wmax2, h->wmax2 + 1, eb,
             seed, glist, gcnt, h->ex.items + 8, (const int*)h->ex.items, (int*)h->ex.items + 1);
-    else if (tl)
+    } else if (tl)
         bmu_bf16_k16_kernel<KS32, E, true, true><<<grid, block, lds, h->stream>>>(
             Xb, n, h->Wst, h->n_stages, h->K, best64, h->ex.gmin, h->ex.stride, h->ex.gflags, xsq, xerr, xmax2, h->wmax2, h->wmax2 + 1, eb,
             seed, glist, gcnt);
@@ -323,7 +325,7 @@ int exact_skip_reserve(som_handle* h, som_handle::ExactScratch::SortedRows& sr, 
     if (int rc = dev_alloc(h, &ex.tlist, (size_t)tiles * n_groups * K16_T)) return rc;
     if (int rc = dev_alloc(h, &ex.tcnt, (size_t)tiles)) return rc;
     // (the listed screen's work items: exact_list_totals_kernel -- at most 2 tiles + 3 slots of them; + the queue's two words)
-    ex.item_slots = 3 * (h->n_cus > 0 ? h->n_cus : 256);
+    ex.item_slots = 8 * (h->n_cus > 0 ? h->n_cus : 256);    // (more workgroups than this never fit a chip: few features, small stages)
     if (int rc = dev_alloc(h, &ex.items, (size_t)(5 * tiles + 4 * ex.item_slots + 16))) return rc;
     int* tmp = nullptr;
     if (int rc = dev_alloc(h, &tmp, radix_scratch_ints(stride))) return rc;
@@ -490,7 +492,8 @@ int exact_skip_plan(som_handle* h, som_handle::ExactScratch::SortedRows& sr, lon
     // (... and the screen's work queue: the lists cut into items of about equal length)
     int2* queue = ex.items + 8;                              // (items[0] = (n_items, counter): the queue's two words)
     exact_list_totals_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(ex.tile_counts, tiles, ex.ctr + 2 * n_groups + 3, ex.ctr + 2 * n_groups + 4,
-                                                                  ex.item_queue ? ex.item_slots : 0, ex.item_queue ? queue : nullptr,
+                                                                  ex.item_queue ? (ex.screen_slots > 0 ? ex.screen_slots : ex.item_slots) : 0,
+                                                                  ex.item_queue ? queue : nullptr,
                                                                   (int*)ex.items, (int*)ex.items + 1, ex.item_len_pct);
     HIPCHK(h, hipGetLastError());
     return 0;

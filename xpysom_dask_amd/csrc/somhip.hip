@@ -185,6 +185,7 @@ struct som_handle {
         int2* tile_counts = nullptr;
         int2* items = nullptr;            // the listed screen's work queue: [0] = (items, counter), from [8] on (tile, part | parts << 16)
         int item_slots = 0;               // ... sized for this many resident workgroups
+        int screen_slots = 0;             // ... the listed screen's last grid (what the next plan cuts its lists for)
         bool item_queue = true;           // SOM_EXACT_QUEUE=0: one workgroup per tile (and part) instead (A/B)
         int item_len_pct = 125;           // ... =<pct >= 25>: an item's length in per cent of the mean list
     } ex;
