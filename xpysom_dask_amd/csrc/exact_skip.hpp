@@ -697,9 +697,9 @@ __global__ __launch_bounds__(64) void exact_lists_kernel(const unsigned long lon
 
 // sum of the tiles' (16-unit blocks listed, groups level 1 kept) into the pass's counters.  One workgroup.
 // items != nullptr: ... and the listed screen's WORK ITEMS (bmu_bf16_k16_kernel<.., GM, TL>): every tile's list cut into parts of
-// about L blocks -- L = 1.25 x the mean list, or what gives every slot of the chip two items where the tiles are few; never below
+// about L blocks -- L = len_pct % of the mean list (1.25 x), or what gives every slot of the chip two items where the tiles are few; never below
 // 32 blocks (a part re-reads its tile's 64 KB of rows) --, item = (tile, part | parts << 16) in tile order; the queue's counter reset.
-// At most 2 tiles + 3 slots items (the three cases of L).
+// At most tiles + max(100 / len_pct tiles, 2.1 slots) items (the three cases of L): with len_pct >= 25, within 5 tiles + 4 slots.
 __global__ __launch_bounds__(1024) void exact_list_totals_kernel(const int2* __restrict__ tile_counts, long tiles, int* __restrict__ blocks_run,
                                                                  int* __restrict__ groups_run, int slots = 0, int2* __restrict__ items = nullptr,
                                                                  int* __restrict__ n_items = nullptr, int* __restrict__ item_ctr = nullptr,
