@@ -333,13 +333,26 @@ __global__ __launch_bounds__(1024) void exact_tiles_kernel(const int* __restrict
         if (tid == 0) { *overflow = 1; *n_tiles_out = 0; }
         return;
     }
+    // (a group's tiles are written by its whole wave, sixty-four at a time: a popular group has a hundred and more, and one
+    //  thread writing them one by one set this launch's time)
     int toff = tbefore + ti - ts;
-    for (int g = b; g < e; ++g) {
-        const int first = gstart ? gstart[g] : 0;
-        const int c = gcount[g] - first;
-        const int off = (int)((long)g * gm_stride) + first;
-        for (int i = 0; i * EX_TR < c; ++i) tile_tab[toff++] = make_int4(g, off + i * EX_TR, min(EX_TR, c - i * EX_TR), 0);
-        if (gstart_out) gstart_out[g] = first + c;
+    for (int k = 0; k < per; ++k) {
+        const int g = b + k;
+        const bool on = g < e;
+        const int first = (on && gstart) ? gstart[g] : 0;
+        const int c = on ? gcount[g] - first : 0;
+        const int off = on ? (int)((long)g * gm_stride) + first : 0;
+        const int mine = toff;
+        toff += (c + EX_TR - 1) / EX_TR;
+        if (on && gstart_out) gstart_out[g] = first + c;
+        for (int src = 0; src < 64; ++src) {
+            const int c_s = __builtin_amdgcn_readlane(c, src);
+            if (c_s <= 0) continue;                           // (wave-uniform)
+            const int g_s = __builtin_amdgcn_readlane(g, src), off_s = __builtin_amdgcn_readlane(off, src);
+            const int t_s = __builtin_amdgcn_readlane(mine, src);
+            for (int i = lane; i * EX_TR < c_s; i += 64)
+                tile_tab[t_s + i] = make_int4(g_s, off_s + i * EX_TR, min(EX_TR, c_s - i * EX_TR), 0);
+        }
     }
     if (tid == 1023) *n_tiles_out = ttotal;
 }
@@ -465,19 +478,29 @@ __global__ __launch_bounds__(256, 3) void exact_refine_kernel(const __bf16* __re
     }
 }
 
+// rowmin2[row] (the row's refined minimum) -> the bits of its threshold rowmin2 + E2, in place; all ones where the threshold is not
+// a finite positive number (no bound, a NaN minimum: every pair is kept).  One pass over the rows, so that exact_select2_kernel
+// gathers one word per list entry instead of three (the minimum and the two norms the bound is made of).
+__global__ __launch_bounds__(256) void exact_thr2_kernel(uint32_t* __restrict__ rowmin2, long n, const float* __restrict__ xsq,
+                                                         const float* __restrict__ xerr, const float* __restrict__ wmax2,
+                                                         const float* __restrict__ xmax2, const float* __restrict__ werr2, ExactBound eb) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const ExactScales sc = ex_scales(xmax2, wmax2, werr2);
+    const float thr = __uint_as_float(rowmin2[i]) + ex_refine_bound(eb, sc, xsq[i], xerr[i]);
+    rowmin2[i] = (thr > 0.0f && thr < 3.0e38f) ? __float_as_uint(thr) : 0xFFFFFFFFu;
+}
+
 // One workgroup per group: its list compacted IN PLACE to the pairs whose refined minimum is within E2 of the row's
 // (chunks of 256 entries in order: a chunk is read whole before the survivors are written, never beyond where it was read).
 __global__ __launch_bounds__(256) void exact_select2_kernel(int* __restrict__ plist, const uint32_t* __restrict__ rmin, long gm_stride,
-                                                            int* __restrict__ gcount, const uint32_t* __restrict__ rowmin2,
-                                                            const float* __restrict__ xsq, const float* __restrict__ xerr,
-                                                            const float* __restrict__ wmax2, const float* __restrict__ xmax2,
-                                                            const float* __restrict__ werr2, ExactBound eb, int* __restrict__ kept_total) {
+                                                            int* __restrict__ gcount, const uint32_t* __restrict__ thr2,
+                                                            int* __restrict__ kept_total) {
     __shared__ int wsum[4];
     __shared__ int out_s;
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cnt = gcount[g];
     if (cnt <= 0) return;
-    const ExactScales sc = ex_scales(xmax2, wmax2, werr2);
     int* list = plist + (long)g * gm_stride;
     const uint32_t* rm = rmin + (long)g * gm_stride;
     if (tid == 0) out_s = 0;
@@ -488,9 +511,7 @@ __global__ __launch_bounds__(256) void exact_select2_kernel(int* __restrict__ pl
         bool keep = false;
         if (i < cnt) {
             row = list[i];
-            const float thr = __uint_as_float(rowmin2[row]) + ex_refine_bound(eb, sc, xsq[row], xerr[row]);
-            // (a threshold that is not a finite positive number -- no bound, a NaN minimum -- keeps the pair)
-            keep = !(thr > 0.0f && thr < 3.0e38f) || rm[i] <= __float_as_uint(thr);
+            keep = rm[i] <= thr2[row];                       // (exact_thr2_kernel: all ones where nothing bounds the row)
         }
         const unsigned long long mk = __ballot(keep);
         if (lane == 0) wsum[wave] = __popcll(mk);

@@ -665,8 +665,9 @@ int exact_refine_ks(som_handle* h, som_handle::ExactScratch::SortedRows& sr, lon
     const long grid = std::min<long>(ex.max_tiles, (long)h->ex.grid_mult * per_cu * (h->n_cus > 0 ? h->n_cus : 256));
     exact_refine_kernel<KS32, E><<<dim3((unsigned)grid), dim3(256), lds, h->stream>>>(
         sr.Xb_s + r0 * h->dp, sr.Xl_s + r0 * h->dp, h->Wst, h->Wst_lo, ex.tile_tab, n_tiles, ex.plist, ex.gmin, rowmin2);
-    exact_select2_kernel<<<dim3((unsigned)n_groups), dim3(256), 0, h->stream>>>(
-        ex.plist, ex.gmin, ex.stride, gcount, rowmin2, sr.xsq_s + r0, sr.xerr_s + r0, h->wmax2, xmax2, h->wmax2 + 1, eb, fb_count + 6);
+    exact_thr2_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream>>>(rowmin2, n, sr.xsq_s + r0, sr.xerr_s + r0, h->wmax2, xmax2,
+                                                                               h->wmax2 + 1, eb);
+    exact_select2_kernel<<<dim3((unsigned)n_groups), dim3(256), 0, h->stream>>>(ex.plist, ex.gmin, ex.stride, gcount, rowmin2, fb_count + 6);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
