@@ -15,14 +15,16 @@ def child():
     from xpysom_dask_amd import _lib
     from xpysom_dask_amd.decays import exponential_decay
     from xpysom_dask_amd.synthetic import gaussian_blobs
-    X = Y = 256; D = 128; N = 1 << 20; T = 25
+    # (WT_SIDE / WT_D / WT_ROWS / WT_T: another shape -- e.g. 512 / 784 / 250000 / 12: the wide screen's lists, 250 rows to a tile)
+    X = Y = int(os.environ.get("WT_SIDE", "256")); D = int(os.environ.get("WT_D", "128"))
+    N = int(os.environ.get("WT_ROWS", str(1 << 20))); T = int(os.environ.get("WT_T", "25"))
     epochs = [int(v) for v in os.environ.get("WT_EPOCHS", "6,12,20,24").split(",")]
     data = gaussian_blobs(N, D, seed=1234, centre_seed=1234)
     rs = np.random.RandomState(1234)
     w = rs.rand(X, Y, D) * 2 - 1; w /= np.linalg.norm(w, axis=-1, keepdims=True)
     e = HipEngine(X, Y, D, precision="exact"); e.set_weights(w.astype(np.float32)); e.set_data(data); e.sync()
     lib = _lib.load()
-    wgs = N // 256
+    wgs = (N + 255) // 256
     for t in range(T):
         sig, eta = exponential_decay(min(X, Y) / 2, 1, t, T), exponential_decay(0.5, 0.01, t, T)
         if t in epochs:
@@ -42,7 +44,7 @@ def child():
             print(json.dumps({"epoch": t, "workgroups": int(ok.sum()), "launch_span_us": round(float(span), 1),
                               "walk_us": {"p10": round(float(np.percentile(dur, 10)), 2), "median": round(float(np.median(dur)), 2),
                                           "p90": round(float(np.percentile(dur, 90)), 2), "max": round(float(dur.max()), 2),
-                                          "sum_over_768_slots": round(float(dur.sum() / 768), 1)},
+                                          "sum_over_768_slots": round(float(dur.sum() / 768), 1), "sum": round(float(dur.sum()), 1)},
                               "workgroups_in_their_walk_at_40_instants": occ}), flush=True)
     e.close()
 

@@ -176,23 +176,17 @@ __global__ __launch_bounds__(256) void merge_prep_wide_kernel(float* __restrict_
 // behind the 32 initial accumulators S'(B' + |c|^2 / 2) - hS r^2, the 32 radii sw r) with the plan's test as its epilogue:
 // need(row, c) = not (acc - (sx sqrt(U))(sw r) > P(row)), rows' P and sx sqrt(U) in planP / planXs; OR over the tile's 256
 // rows into need[tile][word] (bit g & 63 of word g >> 6 <-> group g): what exact_lists_kernel turns into the tile's list.
-template <int KS32, class EL = Bf16, bool GM = false, bool TL = false, bool PLAN = false>
-__global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* __restrict__ Ximg, long N,
-                                                                   const char* __restrict__ Wst, int n_stages,
-                                                                   unsigned long long* __restrict__ out64,
-                                                                   uint32_t* __restrict__ gmin = nullptr, long gm_stride = 0,
-                                                                   uint32_t* __restrict__ gflags32 = nullptr,
-                                                                   const float* __restrict__ xsq = nullptr,
-                                                                   const float* __restrict__ xerr = nullptr,
-                                                                   const float* __restrict__ xmax2 = nullptr,
-                                                                   const float* __restrict__ wmax2 = nullptr,
-                                                                   const float* __restrict__ werr2 = nullptr,
-                                                                   ExactBound eb = ExactBound(),
-                                                                   const int* __restrict__ glist = nullptr,
-                                                                   const int* __restrict__ gcnt = nullptr, int n_groups_all = 0,
-                                                                   const float* __restrict__ planP = nullptr,
-                                                                   const float* __restrict__ planXs = nullptr,
-                                                                   unsigned long long* __restrict__ need = nullptr, int n_words = 0) {
+// (the kernel's body for one tile of WD_WG_SAMPLES rows: tile bx, part by of ny of the stages -- TL: of the tile's listed groups)
+template <int KS32, class EL, bool GM, bool TL, bool PLAN>
+__device__ __forceinline__ void bmu_bf16_wide_body(const char* __restrict__ Ximg, long N, const char* __restrict__ Wst, int n_stages,
+                                                   unsigned long long* __restrict__ out64, uint32_t* __restrict__ gmin, long gm_stride,
+                                                   uint32_t* __restrict__ gflags32, const float* __restrict__ xsq,
+                                                   const float* __restrict__ xerr, const float* __restrict__ xmax2,
+                                                   const float* __restrict__ wmax2, const float* __restrict__ werr2, const ExactBound& eb,
+                                                   const int* __restrict__ glist, const int* __restrict__ gcnt, int n_groups_all,
+                                                   const float* __restrict__ planP, const float* __restrict__ planXs,
+                                                   unsigned long long* __restrict__ need, int n_words, const long bx, const int by,
+                                                   const int ny) {
     // (TL without GM: the scout of exact_skip_wide.hpp -- the plain kernel, unit indices kept, over a tile's few listed groups)
     static_assert(!PLAN || (!GM && !TL), "the plan is a mode of its own");
     using E = typename EL::T;
@@ -208,24 +202,24 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
     const int quad = lane >> 4, col = lane & 15;
 
     // this workgroup's share of the codebook stages: POSITIONS [s_begin, s_end) of its walk; sid(position) = the stage there
-    int s_begin = (int)((long)n_stages * blockIdx.y / gridDim.y);
-    int s_end = (int)((long)n_stages * (blockIdx.y + 1) / gridDim.y);
+    int s_begin = (int)((long)n_stages * by / ny);
+    int s_end = (int)((long)n_stages * (by + 1) / ny);
     if (GM) {                                                // parts of whole groups (pairs of stages)
         const int n_groups = (n_stages + 1) / 2;
-        s_begin = 2 * (int)((long)n_groups * blockIdx.y / gridDim.y);
-        s_end = min(2 * (int)((long)n_groups * (blockIdx.y + 1) / gridDim.y), n_stages);
+        s_begin = 2 * (int)((long)n_groups * by / ny);
+        s_end = min(2 * (int)((long)n_groups * (by + 1) / ny), n_stages);
     }
     const int* my_list = nullptr;
     if (TL) {                                                // the tile's listed groups, two stages each (the host: K % 64 == 0)
-        my_list = glist + (long)blockIdx.x * n_groups_all;
-        const int n_g = gcnt[blockIdx.x];
-        s_begin = 2 * (int)((long)n_g * blockIdx.y / gridDim.y);
-        s_end = 2 * (int)((long)n_g * (blockIdx.y + 1) / gridDim.y);
+        my_list = glist + bx * n_groups_all;
+        const int n_g = gcnt[bx];
+        s_begin = 2 * (int)((long)n_g * by / ny);
+        s_end = 2 * (int)((long)n_g * (by + 1) / ny);
     }
     auto sid = [&](int i) -> int { return TL ? 2 * (__builtin_amdgcn_readfirstlane(my_list[i >> 1]) >> 4) + (i & 1) : i; };
     if (s_begin >= s_end) return;                            // (whole workgroup: no barrier is left behind)
     // GM: lane l < 32 <-> row (block, wave, l): its minimum so far, its bound E; pmin: this lane's minimum over the group
-    const long wave_row0 = (long)blockIdx.x * WD_WG_SAMPLES + wave * (WD_SB * 16);
+    const long wave_row0 = bx * WD_WG_SAMPLES + wave * (WD_SB * 16);
     float run_min = __builtin_inff(), row_e = __builtin_inff();
     int run_arg = 0;
     uint32_t pmin[WD_SB];
@@ -251,7 +245,7 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
     // the wave's samples: B fragments of 2 x 16 rows, every feature chunk
     bf16x8 xf[WD_SB][KS32];
     {
-        const char* xb = Ximg + (long)blockIdx.x * KS32 * WD_XTILE + ((wave * WD_SB) * 64 + lane) * 16;
+        const char* xb = Ximg + bx * KS32 * WD_XTILE + ((wave * WD_SB) * 64 + lane) * 16;
 #pragma unroll
         for (int ks = 0; ks < KS32; ++ks)
 #pragma unroll
@@ -449,7 +443,7 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
         __syncthreads();
         // (the parts of a tile's walk share words: OR into the words the host cleared)
         for (int i = tid; i < n_words; i += 64 * WD_NW)
-            if (nl[i] != 0ull) atomicOr(need + (long)blockIdx.x * n_words + i, nl[i]);
+            if (nl[i] != 0ull) atomicOr(need + bx * n_words + i, nl[i]);
         return;
     }
 
@@ -469,9 +463,51 @@ __global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* _
         if (o < comp) comp = o;
         o = __shfl_xor(comp, 32, 64);
         if (o < comp) comp = o;
-        const long row = (long)blockIdx.x * WD_WG_SAMPLES + (wave * WD_SB + sb) * 16 + col;
+        const long row = bx * WD_WG_SAMPLES + (wave * WD_SB + sb) * 16 + col;
         if (quad == 0 && row < N) atomicMin(out64 + row, comp);
     }
+}
+
+// items (GM + TL; nullptr: the grid is (tiles, parts)): the listed screen as a work queue, as bmu_bf16_k16_kernel's -- the tiles'
+// lists are as uneven here (tools/wg_timeline.py with WT_SIDE=512 WT_D=784: a third of a launch was a tail of a few long walks).
+template <int KS32, class EL = Bf16, bool GM = false, bool TL = false, bool PLAN = false>
+__global__ __launch_bounds__(64 * WD_NW) void bmu_bf16_wide_kernel(const char* __restrict__ Ximg, long N,
+                                                                   const char* __restrict__ Wst, int n_stages,
+                                                                   unsigned long long* __restrict__ out64,
+                                                                   uint32_t* __restrict__ gmin = nullptr, long gm_stride = 0,
+                                                                   uint32_t* __restrict__ gflags32 = nullptr,
+                                                                   const float* __restrict__ xsq = nullptr,
+                                                                   const float* __restrict__ xerr = nullptr,
+                                                                   const float* __restrict__ xmax2 = nullptr,
+                                                                   const float* __restrict__ wmax2 = nullptr,
+                                                                   const float* __restrict__ werr2 = nullptr,
+                                                                   ExactBound eb = ExactBound(),
+                                                                   const int* __restrict__ glist = nullptr,
+                                                                   const int* __restrict__ gcnt = nullptr, int n_groups_all = 0,
+                                                                   const float* __restrict__ planP = nullptr,
+                                                                   const float* __restrict__ planXs = nullptr,
+                                                                   unsigned long long* __restrict__ need = nullptr, int n_words = 0,
+                                                                   const int2* __restrict__ items = nullptr,
+                                                                   const int* __restrict__ n_items = nullptr,
+                                                                   int* __restrict__ item_ctr = nullptr) {
+    if (GM && TL && items != nullptr) {
+        __shared__ int s_item;
+        const int n = *n_items;
+        for (;;) {
+            if (threadIdx.x == 0) s_item = atomicAdd(item_ctr, 1);
+            __syncthreads();                                 // (everyone is done with the previous item's LDS ring too)
+            const int it = s_item;
+            __syncthreads();
+            if (it >= n) return;
+            const int2 iv = items[it];
+            bmu_bf16_wide_body<KS32, EL, GM, TL, PLAN>(Ximg, N, Wst, n_stages, out64, gmin, gm_stride, gflags32, xsq, xerr, xmax2, wmax2, werr2, eb,
+                                                       glist, gcnt, n_groups_all, planP, planXs, need, n_words, (long)iv.x, iv.y & 0xFFFF,
+                                                       iv.y >> 16);
+        }
+    }
+    bmu_bf16_wide_body<KS32, EL, GM, TL, PLAN>(Ximg, N, Wst, n_stages, out64, gmin, gm_stride, gflags32, xsq, xerr, xmax2, wmax2, werr2, eb, glist,
+                                               gcnt, n_groups_all, planP, planXs, need, n_words, (long)blockIdx.x, (int)blockIdx.y,
+                                               (int)gridDim.y);
 }
 
 }  // namespace somhip

@@ -164,6 +164,15 @@ int exact_screen_wide(som_handle* h, const __bf16* Ximg, long n, unsigned long l
         parts = std::max(1, std::min(parts, n_groups));
         if (h->debug)
             std::fprintf(stderr, "[somhip] exact screen (wide, lists): blocks=%ld per_cu=%d slots=%ld parts=%d groups=%d\n", blocks, per_cu, slots, parts, n_groups);
+        if (h->ex.item_queue && glist == h->ex.glist) {
+            // (the plan's lists as a work queue: a workgroup per slot of the chip -- bmu_bf16_wide.hpp; the next plan cuts for this many)
+            h->ex.screen_slots = (int)std::min<long>(slots, h->ex.item_slots);
+            bmu_bf16_wide_kernel<KS32, E, true, true><<<dim3((unsigned)h->ex.screen_slots), dim3(64 * WD_NW), lds, h->stream>>>(
+                (const char*)Ximg, n, h->Wst, h->n_stages, best64, h->ex.gmin, h->ex.stride, (uint32_t*)h->ex.gflags, xsq, xerr, xmax2,
+                h->wmax2, h->wmax2 + 1, eb, glist, gcnt, n_groups, nullptr, nullptr, nullptr, 0, h->ex.items + 8, (const int*)h->ex.items,
+                (int*)h->ex.items + 1);
+            return 0;
+        }
         bmu_bf16_wide_kernel<KS32, E, true, true><<<dim3((unsigned)blocks, (unsigned)parts), dim3(64 * WD_NW), lds, h->stream>>>(
             (const char*)Ximg, n, h->Wst, h->n_stages, best64, h->ex.gmin, h->ex.stride, (uint32_t*)h->ex.gflags, xsq, xerr, xmax2,
             h->wmax2, h->wmax2 + 1, eb, glist, gcnt, n_groups);
@@ -617,7 +626,11 @@ int exact_wide_plan_ks(som_handle* h, som_handle::ExactScratch::SortedRows& sr, 
         (const char*)(sr.Xb_s + s0 * h->dp), n, c0.Cst, c0.n_img_stages, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ExactBound(),
         nullptr, nullptr, 0, sr.seed_s + s0, sr.sU_s + s0, ex.need, c0.n_cstages);
     exact_lists_kernel<<<dim3((unsigned)tiles), dim3(64), 0, h->stream>>>(ex.need, c0.n_cstages, nullptr, n_groups, ex.glist, ex.gcnt, ex.tile_counts, ex.tlist, ex.tcnt);
-    exact_list_totals_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(ex.tile_counts, tiles, ex.ctr + 2 * n_groups + 3, ex.ctr + 2 * n_groups + 4);
+    // (... and the listed screen's work queue: the lists -- counted in 16-unit blocks, four to a group -- cut into items)
+    exact_list_totals_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(ex.tile_counts, tiles, ex.ctr + 2 * n_groups + 3, ex.ctr + 2 * n_groups + 4,
+                                                                  ex.item_queue ? (ex.screen_slots > 0 ? ex.screen_slots : ex.item_slots) : 0,
+                                                                  ex.item_queue ? ex.items + 8 : nullptr, (int*)ex.items, (int*)ex.items + 1,
+                                                                  ex.item_len_pct);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
