@@ -24,6 +24,7 @@ SOM_EXACT_SKIP=2 SOM_EXACT_QUEUE=25 FUZZ_MAXSIDE=260 run "fuzz_exact SOM_EXACT_S
 SOM_EXACT_SKIP=2 FUZZ_WIDE=1 run "fuzz_exact SOM_EXACT_SKIP=2 FUZZ_WIDE=1 seed 252 (120 cases, wide screen under a plan)" python tests/fuzz/fuzz_exact.py 252 120
 SOM_EXACT_SKIP=2 FUZZ_WIDE=1 SOM_EXACT_PASS_ROWS=1024 SOM_EXACT_RESORT=1000 run "fuzz_exact SOM_EXACT_SKIP=2 FUZZ_WIDE=1 SOM_EXACT_PASS_ROWS=1024 SOM_EXACT_RESORT=1000 seed 253 (120 cases)" python tests/fuzz/fuzz_exact.py 253 120
 FUZZ_WIDE=1 SOM_VERIFY=64 run "fuzz_exact FUZZ_WIDE=1 SOM_VERIFY=64 seed 254 (120 cases, default switches, canary on)" python tests/fuzz/fuzz_exact.py 254 120
+SOM_EXACT_SKIP=2 FUZZ_WIDE=1 SOM_EXACT_QUEUE=0 run "fuzz_exact SOM_EXACT_SKIP=2 FUZZ_WIDE=1 SOM_EXACT_QUEUE=0 seed 257 (120 cases: the wide listed screen as one workgroup per tile and part)" python tests/fuzz/fuzz_exact.py 257 120
 run "fuzz_shapes seed 205 ($N cases)" python tests/fuzz/fuzz_shapes.py 205 $N
 run "fuzz_paths seed 305 (150 cases)" python tests/fuzz/fuzz_paths.py 305 150
 run "fuzz_train seed 405 (150 cases)" python tests/fuzz/fuzz_train.py 405 150
